@@ -1,0 +1,193 @@
+/* fgumi_amd.h — C ABI of the MI355X-native consensus engine (drop-in for fgumi's
+ * per-UMI-family consensus hot path).
+ *
+ * The reference has no FFI surface (100% Rust, `#![deny(unsafe_code)]`), so every entry
+ * point below replaces a *Rust* interface; the citation names it (paths relative to the
+ * reference checkout).  INTEGRATION.md shows the `extern "C"` binding a maintainer would add
+ * on the Rust side.
+ *
+ * Seam: the BATCH level, i.e. the `process_fn: Fn(MiGroupBatch) -> io::Result<ProcessedBatch>`
+ * closure of `fgumi simplex|duplex|codec`
+ *   (src/lib/commands/simplex.rs:637-718, duplex.rs:742ff, codec.rs:722ff),
+ * which wraps `ConsensusCaller::consensus_reads` (crates/fgumi-consensus/src/caller.rs:220-252)
+ * and `apply_overlapping_consensus` (crates/fgumi-consensus/src/overlapping.rs:627-684).
+ * A per-family call would mean one kernel launch per molecule; a GPU wants >= 1e5 families per
+ * call, so a caller should aggregate many reference-sized batches (50/100/1000 groups).
+ *
+ * Plain pointers and sizes only; no torch / HIP types.  Device pointers are `void*`.
+ */
+#ifndef FGUMI_AMD_H
+#define FGUMI_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* RejectionReason, in declaration order (crates/fgumi-consensus/src/caller.rs:401-446). */
+enum {
+  FGX_REJ_FRAGMENT_READ = 0, FGX_REJ_INSUFFICIENT_READS, FGX_REJ_QUALITY_TOO_LOW, FGX_REJ_UNMAPPED,
+  FGX_REJ_MAPPED, FGX_REJ_TOO_MANY_NS, FGX_REJ_MINORITY_ALIGNMENT, FGX_REJ_SECONDARY_OR_SUPPLEMENTARY,
+  FGX_REJ_FAILED_QC, FGX_REJ_MISSING_UMI, FGX_REJ_QUALITY_TRIMMED, FGX_REJ_ZERO_LENGTH_AFTER_TRIMMING,
+  FGX_REJ_INSUFFICIENT_OVERLAP, FGX_REJ_ORPHAN_CONSENSUS, FGX_REJ_INDEL_ERROR_BETWEEN_STRANDS,
+  FGX_REJ_CLIP_OVERLAP_FAILED, FGX_REJ_HIGH_DUPLEX_DISAGREEMENT, FGX_REJ_POTENTIAL_COLLISION,
+  FGX_REJ_NOT_PRIMARY_FR_PAIR, FGX_REJ_DOWNSAMPLED, FGX_REJ_OTHER, FGX_N_REJECTION
+};
+
+/* stats[] layout returned with every batch:
+ *   [0] total_reads  [1] consensus_reads  [2] filtered_reads      (ConsensusCallingStats, caller.rs:256-321)
+ *   [3 .. 3+21)      per-RejectionReason counters, enum order above
+ *   [24..28)         CorrectionStats of the overlapping pre-step: overlapping_bases, bases_agreeing,
+ *                    bases_disagreeing, bases_corrected            (overlapping.rs:51-60)               */
+#define FGX_STATS_LEN 28
+
+enum { FGX_CALLER_SIMPLEX = 0, FGX_CALLER_DUPLEX = 1, FGX_CALLER_CODEC = 2 };
+enum { FGX_TIE_FGBIO_COMPAT = 0, FGX_TIE_ULP_RELATIVE = 1 };  /* base_builder.rs:418-438 */
+
+/* Options = VanillaUmiConsensusOptions (vanilla_caller.rs:292-334) + the command-level knobs the
+ * process_fn closure captures (read_name_prefix, read_group_id, overlapping on/off, rejects
+ * tracking; simplex.rs:590-611) + duplex (duplex_caller.rs:344-513) and CODEC
+ * (codec_caller.rs:145-223) option blocks.  Zero-initialise, then call fgx_options_default(). */
+typedef struct fgx_options {
+  uint32_t struct_size;                 /* = sizeof(fgx_options); ABI guard */
+  uint32_t caller_kind;                 /* FGX_CALLER_* */
+  char     tag[2];                      /* "MI" */
+  char     cell_tag[2];                 /* "CB" as the commands pass it; {0,0} = None */
+  uint8_t  error_rate_pre_umi;          /* 45 */
+  uint8_t  error_rate_post_umi;         /* 40 */
+  uint8_t  min_input_base_quality;      /* 10 */
+  uint8_t  min_consensus_base_quality;  /* CLI default 2 (common.rs:749-806) */
+  uint8_t  produce_per_base_tags;       /* 1 */
+  uint8_t  trim;                        /* 0 */
+  uint8_t  tie_rule;                    /* FGX_TIE_FGBIO_COMPAT */
+  uint8_t  overlapping_consensus;       /* 1: simplex/duplex default on */
+  uint8_t  track_rejects;               /* 0 */
+  uint8_t  _pad0[3];
+  uint32_t min_reads;                   /* simplex --min-reads (required by the CLI) */
+  int64_t  max_reads;                   /* -1 = None */
+  const char* read_name_prefix;         /* "" when the header has no @RG (caller.rs:612-645) */
+  const char* read_group_id;            /* "A" */
+  /* duplex (duplex_caller.rs:465-489) */
+  uint32_t duplex_min_reads[3];         /* [total, XY, YX] */
+  int64_t  duplex_max_reads_per_strand; /* -1 = None */
+  /* codec (codec_caller.rs:145-200) */
+  uint32_t codec_min_reads_per_strand;  /* 1 */
+  int64_t  codec_max_reads_per_strand;  /* -1 = None */
+  uint32_t codec_min_duplex_length;     /* 1 */
+  uint8_t  codec_single_strand_qual;    /* 0 = None */
+  uint8_t  codec_outer_bases_qual;      /* 0 = None */
+  uint8_t  codec_has_single_strand_qual;
+  uint8_t  codec_has_outer_bases_qual;
+  uint32_t codec_outer_bases_length;    /* 5 */
+  uint32_t codec_max_duplex_disagreements;   /* usize::MAX in the reference => 0xFFFFFFFF */
+  double   codec_max_duplex_disagreement_rate; /* 1.0 */
+  int32_t  device;                      /* HIP device ordinal; -1 = current */
+  uint32_t _pad1;
+} fgx_options;
+
+/* What one batch returns: `ConsensusOutput { data, count }` (caller.rs:172-177) + the stats the
+ * closure merges per batch (simplex.rs:711-717) + `take_rejected_reads` (vanilla_caller.rs:529).
+ * All pointers stay owned by the caller object and are valid until its next call / destroy. */
+typedef struct fgx_output {
+  const uint8_t* data;       /* concatenated BAM records, each prefixed by LE u32 block_size, input group order */
+  uint64_t data_len;
+  uint64_t count;            /* number of consensus records in `data` */
+  uint64_t stats[FGX_STATS_LEN];
+  const uint8_t* rejects;    /* when track_rejects: rejected input records, each with block_size prefix */
+  uint64_t rejects_len;
+  uint64_t n_rejects;
+  /* timing of the last call, milliseconds (0 when not measured) */
+  double ms_host_prep, ms_h2d, ms_kernels, ms_d2h, ms_emit;
+} fgx_output;
+
+typedef struct fgx_caller fgx_caller;
+
+/* Fill `o` with the reference defaults (src/lib/commands/common.rs:749-806, 894-904). */
+void fgx_options_default(fgx_options* o);
+
+/* Replaces `VanillaUmiConsensusCaller::new_with_rejects_tracking` (vanilla_caller.rs:432-463),
+ * `DuplexConsensusCaller::new` and `CodecConsensusCaller::new`.  Builds the Phred tables
+ * (base_builder.rs:349-370, 615-656, 743-754; vanilla_caller.rs:469-501), uploads them, and
+ * creates the HIP stream.  Returns NULL on error (see fgx_global_error()).  Fails loudly when
+ * no HIP device is usable — there is no CPU fallback. */
+fgx_caller* fgx_create(const fgx_options* opts);
+void fgx_destroy(fgx_caller* c);
+const char* fgx_last_error(const fgx_caller* c);
+const char* fgx_global_error(void);
+
+/* Replaces the Process-step closure `process_fn(MiGroupBatch)`
+ * (src/lib/commands/simplex.rs:637-718): for each MI group — min-reads short-circuit,
+ * overlapping-bases pre-correction, `consensus_reads` — concatenating output in group order.
+ *
+ *   records   : blob holding the raw BAM records of the batch (host memory)
+ *   rec_off   : n_rec byte offsets of each record body (the bytes AFTER its block_size prefix)
+ *   rec_len   : n_rec record body lengths (= block_size)
+ *   grp_first : n_grp+1 record indices; group g = records [grp_first[g], grp_first[g+1])
+ *               (one group = one MiGroup, src/lib/mi_group.rs:22-57: consecutive records with the
+ *               same MI — duplex: same MI with /A,/B stripped)
+ * Records are not modified (the overlap pre-step works on device/host copies).
+ * Returns 0 on success; non-zero is fatal for the run, like the reference's `anyhow::Error`
+ * (simplex.rs:699-701).  Message via fgx_last_error(). */
+int fgx_process_batch(fgx_caller* c, const uint8_t* records, uint64_t records_len, const uint64_t* rec_off,
+                      const uint32_t* rec_len, uint32_t n_rec, const uint32_t* grp_first, uint32_t n_grp,
+                      fgx_output* out);
+
+/* Same contract with every input array already resident in HBM (device pointers) and the
+ * consensus records left in HBM: the measured configuration of bench.py and the multi-GPU path.
+ * `out->data` is a DEVICE pointer; `out->stats` is copied back (112 bytes).  Families the device
+ * fast path cannot decide (indel-bearing CIGARs in the alignment filter, name-unpaired mates, …)
+ * are reported in *n_deferred / d_deferred_groups and must be re-submitted through
+ * fgx_process_batch; 0 for `simulate`-shaped input. */
+int fgx_process_batch_device(fgx_caller* c, const void* d_records, uint64_t records_len, const void* d_rec_off,
+                             const void* d_rec_len, uint32_t n_rec, const void* d_grp_first, uint32_t n_grp,
+                             fgx_output* out, uint32_t* n_deferred, const void** d_deferred_groups);
+
+/* ---- column-level entry (ConsensusBaseBuilder, base_builder.rs:775-1081) -----------------
+ * Calls `n_cols` independent columns on the device: column j has observations
+ * (bases[j*depth + i], quals[j*depth + i]) for i < depth, added in that order; bases are ASCII
+ * ('N'/other = ignored, as `add` does).  Outputs the raw call() result (before thresholds),
+ * contributions() and depth - observations_for_base(base).  Used by the parity tests that
+ * mirror base_builder.rs's own unit tests. */
+int fgx_call_columns(fgx_caller* c, const uint8_t* bases, const uint8_t* quals, uint32_t n_cols, uint32_t depth,
+                     uint8_t* out_base, uint8_t* out_qual, uint32_t* out_depth, uint32_t* out_errors);
+
+/* Device self-test of the glibc-compatible libm: op 0 exp, 1 log, 2 log1p, 3 expm1. */
+int fgx_device_libm(fgx_caller* c, int op, const double* x, double* y, uint64_t n);
+
+/* Host copies of the tables the kernels use (94 entries each), for parity tests:
+ * which: 0 correct[q], 1 error_per_alt[q], 2 gap thresholds, 3 cerr_min; *cap = pre-UMI cap. */
+int fgx_get_table(const fgx_caller* c, int which, double* out94, uint32_t* cap);
+
+/* ---- synthetic grouped reads (`fgumi simulate grouped-reads` model) ------------------------
+ * Restates the record SHAPE of src/lib/commands/simulate/grouped_reads.rs:666-1011 and the
+ * quality model of src/lib/simulate/quality.rs:60-135 with a counter-based integer RNG so the
+ * same molecule is generated bit-identically on host and device (the reference's ChaCha12
+ * stream cannot be reproduced; seeds are this build's own). */
+typedef struct fgx_sim_params {
+  uint64_t seed;            /* 42 */
+  uint32_t n_families;
+  uint32_t read_length;     /* 150 */
+  uint32_t family_size;     /* pairs per molecule when family_size_max == 0 */
+  uint32_t family_size_max; /* >0: long-tail sizes in [family_size, family_size_max], count ~ size^-1.5 */
+  uint32_t duplex;          /* 1: /A,/B strand split like --duplex */
+  uint32_t insert_mean;     /* 300 */
+  uint32_t insert_sd;       /* 50  */
+  uint32_t error_rate_ppm;  /* per-base substitution probability * 1e6 (1000 = 0.001) */
+  uint32_t first_family;    /* molecule id of family 0 (sharding) */
+  uint32_t codec;           /* 1: CODEC-shaped pairs (both strands in one pair, overlapping mates) */
+} fgx_sim_params;
+
+/* Sizes for a parameter set: total blob bytes (records WITH block_size prefixes) and record count. */
+int fgx_sim_sizes(const fgx_sim_params* p, uint64_t* blob_len, uint64_t* n_rec);
+/* Host generation into caller-provided arrays (blob_len bytes; n_rec offsets/lengths; n_families+1 firsts). */
+int fgx_sim_generate_host(const fgx_sim_params* p, uint8_t* blob, uint64_t* rec_off, uint32_t* rec_len,
+                          uint32_t* grp_first);
+/* Device generation straight into HBM (same layout, device pointers). */
+int fgx_sim_generate_device(fgx_caller* c, const fgx_sim_params* p, void* d_blob, void* d_rec_off, void* d_rec_len,
+                            void* d_grp_first);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FGUMI_AMD_H */

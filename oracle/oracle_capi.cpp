@@ -1,0 +1,314 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+// C entry points (ctypes) over the C++ restatement of the reference CPU caller.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <thread>
+#include "../include/fgumi_amd.h"
+#include "oracle_vanilla.hpp"
+#ifdef ORC_WITH_DUPLEX
+#include "oracle_duplex.hpp"
+#endif
+#ifdef ORC_WITH_CODEC
+#include "oracle_codec.hpp"
+#endif
+
+using namespace orc;
+
+static thread_local std::string g_err;
+
+struct OrcResult {
+  Bytes data;
+  uint64_t count = 0;
+  uint64_t stats[FGX_STATS_LEN] = {0};
+  Bytes rejects;
+  uint64_t n_rejects = 0;
+};
+
+static VanillaOptions vanilla_options_from(const fgx_options* o) {
+  VanillaOptions v;
+  v.tag = std::string(o->tag, 2);
+  v.error_rate_pre_umi = o->error_rate_pre_umi;
+  v.error_rate_post_umi = o->error_rate_post_umi;
+  v.min_input_base_quality = o->min_input_base_quality;
+  v.min_reads = o->min_reads;
+  v.has_max_reads = o->max_reads >= 0;
+  v.max_reads = o->max_reads >= 0 ? (size_t)o->max_reads : 0;
+  v.produce_per_base_tags = o->produce_per_base_tags;
+  v.trim = o->trim;
+  v.min_consensus_base_quality = o->min_consensus_base_quality;
+  v.has_cell_tag = o->cell_tag[0] != 0;
+  v.cell_tag[0] = o->cell_tag[0];
+  v.cell_tag[1] = o->cell_tag[1];
+  v.tie_rule = o->tie_rule == FGX_TIE_ULP_RELATIVE ? TieRule::UlpRelative : TieRule::FgbioCompat;
+  return v;
+}
+
+static void stats_to_array(const Stats& s, const CorrectionStats& cs, uint64_t* out) {
+  out[0] += s.total_reads; out[1] += s.consensus_reads; out[2] += s.filtered_reads;
+  for (int i = 0; i < N_REJECTION; i++) out[3 + i] += s.rejection[i];
+  out[24] += cs.overlapping_bases; out[25] += cs.bases_agreeing; out[26] += cs.bases_disagreeing; out[27] += cs.bases_corrected;
+}
+
+static void append_reject(OrcResult& r, const uint8_t* p, size_t n) {
+  uint32_t bs = (uint32_t)n;
+  for (int i = 0; i < 4; i++) r.rejects.push_back((bs >> (8 * i)) & 0xFF);
+  r.rejects.insert(r.rejects.end(), p, p + n);
+  r.n_rejects++;
+}
+
+// One Process-step batch over groups [g0, g1): restates process_fn (simplex.rs:637-718).
+static void simplex_groups(const fgx_options* o, const uint8_t* blob, const uint64_t* rec_off, const uint32_t* rec_len,
+                           const uint32_t* grp_first, uint32_t g0, uint32_t g1, OrcResult& res) {
+  VanillaOptions vo = vanilla_options_from(o);
+  VanillaCaller caller(o->read_name_prefix ? o->read_name_prefix : "", o->read_group_id ? o->read_group_id : "A", vo,
+                       o->track_rejects != 0);
+  Stats batch_stats;
+  CorrectionStats batch_overlap;
+  for (uint32_t g = g0; g < g1; g++) {
+    caller.clear();
+    uint32_t r0 = grp_first[g], r1 = grp_first[g + 1];
+    size_t n = r1 - r0;
+    if (n < vo.min_reads) {  // simplex.rs:673-683
+      batch_stats.record_input(n);
+      batch_stats.record_rejection(InsufficientReads, n);
+      if (o->track_rejects) for (uint32_t r = r0; r < r1; r++) append_reject(res, blob + rec_off[r], rec_len[r]);
+      continue;
+    }
+    std::vector<Bytes> recs;
+    recs.reserve(n);
+    for (uint32_t r = r0; r < r1; r++) recs.emplace_back(blob + rec_off[r], blob + rec_off[r] + rec_len[r]);
+    if (o->overlapping_consensus) { CorrectionStats cs; apply_overlapping_consensus(recs, cs);
+      batch_overlap.overlapping_bases += cs.overlapping_bases; batch_overlap.bases_agreeing += cs.bases_agreeing;
+      batch_overlap.bases_disagreeing += cs.bases_disagreeing; batch_overlap.bases_corrected += cs.bases_corrected; }
+    std::vector<std::pair<const uint8_t*, size_t>> ptrs;
+    for (auto& b : recs) ptrs.push_back({b.data(), b.size()});
+    ConsensusOutput out = caller.consensus_reads(ptrs);
+    res.data.insert(res.data.end(), out.data.begin(), out.data.end());
+    res.count += out.count;
+    batch_stats.merge(caller.stats);
+    if (o->track_rejects) for (auto& rj : caller.rejected_reads) append_reject(res, rj.data(), rj.size());
+  }
+  stats_to_array(batch_stats, batch_overlap, res.stats);
+}
+
+typedef void (*groups_fn)(const fgx_options*, const uint8_t*, const uint64_t*, const uint32_t*, const uint32_t*, uint32_t,
+                          uint32_t, OrcResult&);
+
+static groups_fn pick(const fgx_options* o) {
+  switch (o->caller_kind) {
+    case FGX_CALLER_SIMPLEX: return simplex_groups;
+#ifdef ORC_WITH_DUPLEX
+    case FGX_CALLER_DUPLEX: return duplex_groups;
+#endif
+#ifdef ORC_WITH_CODEC
+    case FGX_CALLER_CODEC: return codec_groups;
+#endif
+    default: return nullptr;
+  }
+}
+
+extern "C" {
+
+const char* orc_last_error() { return g_err.c_str(); }
+
+// Whole input, mirroring `--threads T`: batches of `batch_groups` MI groups (50 simplex / 100
+// duplex / 1000 codec in the reference), one caller object per batch, batches pulled by T worker
+// threads, output concatenated in input order.  threads <= 1 runs inline.
+void* orc_process(const fgx_options* o, const uint8_t* blob, const uint64_t* rec_off, const uint32_t* rec_len,
+                  uint32_t n_rec, const uint32_t* grp_first, uint32_t n_grp, uint32_t batch_groups, uint32_t threads) {
+  (void)n_rec;
+  groups_fn fn = pick(o);
+  if (!fn) { g_err = "unsupported caller kind in this oracle build"; return nullptr; }
+  if (batch_groups == 0) batch_groups = 50;
+  uint32_t n_batches = (n_grp + batch_groups - 1) / batch_groups;
+  std::vector<OrcResult> parts(n_batches);
+  std::atomic<uint32_t> next(0);
+  std::atomic<bool> failed(false);
+  std::string err;
+  auto worker = [&]() {
+    for (;;) {
+      uint32_t b = next.fetch_add(1);
+      if (b >= n_batches || failed.load()) return;
+      uint32_t g0 = b * batch_groups, g1 = std::min(n_grp, g0 + batch_groups);
+      try { fn(o, blob, rec_off, rec_len, grp_first, g0, g1, parts[b]); }
+      catch (const OracleError& e) { if (!failed.exchange(true)) err = e.what; return; }
+    }
+  };
+  if (threads <= 1) worker();
+  else {
+    std::vector<std::thread> ts;
+    for (uint32_t t = 0; t < threads; t++) ts.emplace_back(worker);
+    for (auto& t : ts) t.join();
+  }
+  if (failed.load()) { g_err = err; return nullptr; }
+  OrcResult* res = new OrcResult();
+  size_t total = 0, rtotal = 0;
+  for (auto& p : parts) { total += p.data.size(); rtotal += p.rejects.size(); }
+  res->data.reserve(total);
+  res->rejects.reserve(rtotal);
+  for (auto& p : parts) {
+    res->data.insert(res->data.end(), p.data.begin(), p.data.end());
+    res->rejects.insert(res->rejects.end(), p.rejects.begin(), p.rejects.end());
+    res->count += p.count;
+    res->n_rejects += p.n_rejects;
+    for (int i = 0; i < FGX_STATS_LEN; i++) res->stats[i] += p.stats[i];
+  }
+  return res;
+}
+const uint8_t* orc_result_data(void* r) { return ((OrcResult*)r)->data.data(); }
+uint64_t orc_result_len(void* r) { return ((OrcResult*)r)->data.size(); }
+uint64_t orc_result_count(void* r) { return ((OrcResult*)r)->count; }
+void orc_result_stats(void* r, uint64_t* out) { memcpy(out, ((OrcResult*)r)->stats, sizeof(uint64_t) * FGX_STATS_LEN); }
+const uint8_t* orc_result_rejects(void* r) { return ((OrcResult*)r)->rejects.data(); }
+uint64_t orc_result_rejects_len(void* r) { return ((OrcResult*)r)->rejects.size(); }
+uint64_t orc_result_n_rejects(void* r) { return ((OrcResult*)r)->n_rejects; }
+void orc_result_free(void* r) { delete (OrcResult*)r; }
+
+// ---- scalar / column level, for the known-answer tests ---------------------------------------
+double orc_phred_to_ln_error_prob(uint8_t q) { return phred_to_ln_error_prob(q); }
+double orc_phred_to_ln_correct_prob(uint8_t q) { return phred_to_ln_correct_prob(q); }
+uint8_t orc_ln_prob_to_phred(double x) { return ln_prob_to_phred(x); }
+double orc_log1pexp(double x) { return log1pexp(x); }
+double orc_ln_sum_exp(double a, double b) { return ln_sum_exp(a, b); }
+double orc_ln_sum_exp_array(const double* v, uint32_t n) { return ln_sum_exp_array(v, n); }
+double orc_ln_not(double x) { return ln_not(x); }
+double orc_ln_error_prob_two_trials(double a, double b) { try { return ln_error_prob_two_trials(a, b); } catch (const OracleError&) { return NAN; } }
+// returns 1 when the reference would panic (a < b by >= EPSILON)
+int orc_ln_a_minus_b(double a, double b, double* out) { try { *out = ln_a_minus_b(a, b); return 0; } catch (const OracleError&) { return 1; } }
+int orc_fgbio_unique_max_index(const double* ll) { return fgbio_unique_max_index(ll); }
+int orc_unique_max_index(const double* ll) { return unique_max_index(ll); }
+double orc_consensus_error(double gap) { return consensus_error(gap); }
+uint8_t orc_unanimous_quality_from_gap(double gap, uint8_t pre) { return unanimous_quality_from_gap(gap, phred_to_ln_error_prob(pre)); }
+double orc_unanimous_margin(double w, double l, double c) { return unanimous_margin(w, l, c); }
+
+void* orc_builder_new(uint8_t pre, uint8_t post, int tie_rule) {
+  auto* b = new ConsensusBaseBuilder(pre, post);
+  b->tie_rule = tie_rule == FGX_TIE_ULP_RELATIVE ? TieRule::UlpRelative : TieRule::FgbioCompat;
+  return b;
+}
+void orc_builder_free(void* b) { delete (ConsensusBaseBuilder*)b; }
+void orc_builder_reset(void* b) { ((ConsensusBaseBuilder*)b)->reset(); }
+void orc_builder_add(void* b, uint8_t base, uint8_t qual) { ((ConsensusBaseBuilder*)b)->add(base, qual); }
+void orc_builder_add_n(void* b, uint8_t base, uint8_t qual, uint32_t n) { for (uint32_t i = 0; i < n; i++) ((ConsensusBaseBuilder*)b)->add(base, qual); }
+void orc_builder_call(void* b, uint8_t* base, uint8_t* qual) { ((ConsensusBaseBuilder*)b)->call(*base, *qual); }
+void orc_builder_call_full(void* b, uint8_t* base, uint8_t* qual) { ((ConsensusBaseBuilder*)b)->call_full(*base, *qual); }
+int orc_builder_fast_path(void* b, uint8_t* base, uint8_t* qual) { return ((ConsensusBaseBuilder*)b)->try_unanimous_fast_path(*base, *qual) ? 1 : 0; }
+uint32_t orc_builder_contributions(void* b) { return ((ConsensusBaseBuilder*)b)->contributions(); }
+uint32_t orc_builder_observations_for_base(void* b, uint8_t base) { return ((ConsensusBaseBuilder*)b)->observations_for_base(base); }
+void orc_builder_likelihoods(void* b, double* out4) { memcpy(out4, ((ConsensusBaseBuilder*)b)->likelihoods, 32); }
+void orc_builder_set_likelihoods(void* b, const double* ll, const uint32_t* obs) {
+  auto* B = (ConsensusBaseBuilder*)b;
+  for (int i = 0; i < 4; i++) { B->likelihoods[i] = ll[i]; B->compensations[i] = 0.0; B->observations[i] = obs[i]; }
+}
+// which: 0 correct, 1 error_per_alt, 2 thresholds, 3 cerr_min
+void orc_builder_table(void* b, int which, double* out94, uint32_t* cap) {
+  auto* B = (ConsensusBaseBuilder*)b;
+  const double* src = which == 0 ? B->adj.correct : which == 1 ? B->adj.error_per_alt : which == 2 ? B->gap.thresholds : B->gap.cerr_min;
+  memcpy(out94, src, 94 * sizeof(double));
+  if (cap) *cap = (uint32_t)B->gap.cap;
+}
+// Column batch with the same contract as fgx_call_columns.
+void orc_call_columns(uint8_t pre, uint8_t post, int tie_rule, const uint8_t* bases, const uint8_t* quals, uint32_t n_cols,
+                      uint32_t depth, uint8_t* out_base, uint8_t* out_qual, uint32_t* out_depth, uint32_t* out_errors) {
+  ConsensusBaseBuilder b(pre, post);
+  b.tie_rule = tie_rule == FGX_TIE_ULP_RELATIVE ? TieRule::UlpRelative : TieRule::FgbioCompat;
+  for (uint32_t j = 0; j < n_cols; j++) {
+    b.reset();
+    for (uint32_t i = 0; i < depth; i++) { uint8_t base = bases[(size_t)j * depth + i]; if (base != NO_CALL_BASE) b.add(base, quals[(size_t)j * depth + i]); }
+    uint8_t cb, cq;
+    b.call(cb, cq);
+    out_base[j] = cb; out_qual[j] = cq;
+    out_depth[j] = b.contributions();
+    out_errors[j] = b.contributions() - b.observations_for_base(cb);
+  }
+}
+void orc_single_input_quals(const fgx_options* o, uint8_t* out94) {
+  VanillaCaller c("", "A", vanilla_options_from(o));
+  memcpy(out94, c.single_input_quals, 94);
+}
+int32_t orc_read_name_rank(const uint8_t* name, uint32_t n) { return fgbio_read_name_rank(name, n); }
+uint64_t orc_mate_clip(const uint8_t* rec, uint32_t n) { return num_bases_extending_past_mate_raw(RecView(rec, n)); }
+uint64_t orc_mate_clip_ops(int is_reverse, int32_t this_pos1, const uint32_t* this_ops, uint32_t n_this, int32_t mate_pos1,
+                           const uint32_t* mate_ops, uint32_t n_mate) {
+  return bases_extending_past_mate_ops(is_reverse != 0, this_pos1, std::vector<uint32_t>(this_ops, this_ops + n_this), mate_pos1,
+                                       std::vector<uint32_t>(mate_ops, mate_ops + n_mate));
+}
+// returns 1 and (lead soft, ref len, trail soft) when the MC CIGAR parses, else 0
+int orc_parse_mc(const char* s, int32_t* out3) {
+  std::vector<uint32_t> ops;
+  if (!parse_mc_cigar_ops((const uint8_t*)s, strlen(s), ops)) return 0;
+  size_t ls = leading_soft_clip(ops), ts = trailing_soft_clip(ops);
+  out3[0] = ls > (size_t)INT32_MAX ? INT32_MAX : (int32_t)ls;
+  out3[1] = saturating_reference_length(ops);
+  out3[2] = ts > (size_t)INT32_MAX ? INT32_MAX : (int32_t)ts;
+  return 1;
+}
+uint32_t orc_quality_trim_point(const uint8_t* q, uint32_t n, uint8_t trim_qual) { return (uint32_t)VanillaCaller::find_quality_trim_point(Bytes(q, q + n), trim_qual); }
+// consensus_umis over '\n'-separated UMIs; returns length written (or -1 on panic)
+int orc_consensus_umis(const char* joined, char* out, uint32_t cap) {
+  std::vector<std::string> umis;
+  std::string cur;
+  for (const char* p = joined;; p++) { if (*p == '\n' || *p == 0) { umis.push_back(cur); cur.clear(); if (*p == 0) break; } else cur.push_back(*p); }
+  try { std::string r = consensus_umis(umis); if (r.size() + 1 > cap) return -1; memcpy(out, r.c_str(), r.size() + 1); return (int)r.size(); }
+  catch (const OracleError&) { return -1; }
+}
+// Overlap pre-step on one pair (records modified in place). Returns 1 if call() returned true.
+int orc_overlap_pair(uint8_t* r1, uint32_t n1, uint8_t* r2, uint32_t n2, uint64_t* stats4) {
+  CorrectionStats cs;
+  bool ok = overlapping_call(r1, n1, r2, n2, cs);
+  stats4[0] = cs.overlapping_bases; stats4[1] = cs.bases_agreeing; stats4[2] = cs.bases_disagreeing; stats4[3] = cs.bases_corrected;
+  return ok ? 1 : 0;
+}
+
+// Replays the reference's fast-path ≡ call_full sweeps (base_builder.rs:1986-2012, 2042-2083,
+// 2092-2123).  which: 0 broad (30 720 cases), 1 dense contiguous-depth, 2 deep cap region.
+// Returns the number of mismatches; *n_cases = cases evaluated.
+uint64_t orc_sweep_fast_vs_full(int which, uint64_t* n_cases) {
+  uint64_t bad = 0, n = 0;
+  const uint8_t bases[4] = {'A', 'C', 'G', 'T'};
+  auto same = [&](ConsensusBaseBuilder& b) {
+    uint8_t b1, q1, b2, q2;
+    b.call(b1, q1); b.call_full(b2, q2);
+    n++;
+    if (b1 != b2 || q1 != q2) bad++;
+  };
+  if (which == 0) {
+    const uint8_t pres[] = {0, 2, 20, 45, 69, 70, 90, 93}, posts[] = {0, 1, 2, 5, 10, 20, 40, 93};
+    const uint32_t depths[] = {1, 2, 3, 5, 8, 12, 20, 35, 50, 100, 400, 1000};
+    const uint8_t quals[] = {0, 1, 2, 5, 10, 20, 30, 40, 60, 93};
+    for (uint8_t pre : pres) for (uint8_t post : posts) for (uint8_t base : bases) {
+      ConsensusBaseBuilder b(pre, post);
+      for (uint32_t d : depths) for (uint8_t q : quals) { b.reset(); for (uint32_t i = 0; i < d; i++) b.add(base, q); same(b); }
+    }
+  } else if (which == 1) {
+    const uint8_t pres[] = {45, 70, 90};
+    for (uint8_t pre : pres) for (uint8_t base : bases) for (int post = 0; post <= 12; post++) {
+      ConsensusBaseBuilder b(pre, (uint8_t)post);
+      double cap_thr = b.gap.thresholds[b.gap.cap];
+      int idx = base_to_index(base);
+      for (int obs = 0; obs <= 12; obs++) {
+        b.reset();
+        for (uint32_t d = 1; d <= 4000; d++) {
+          b.add(base, (uint8_t)obs);
+          same(b);
+          double g = b.likelihoods[idx] - b.likelihoods[(idx + 1) % 4];
+          if (std::isfinite(g) && g > cap_thr + 50.0) break;
+        }
+      }
+    }
+  } else {
+    const int cfg[3][5] = {{90, 93, 93, 1450, 1560}, {93, 93, 40, 1550, 1660}, {90, 90, 40, 3150, 3260}};
+    for (auto& c : cfg) {
+      ConsensusBaseBuilder b((uint8_t)c[0], (uint8_t)c[1]);
+      for (int i = 0; i < c[3] - 1; i++) b.add('A', (uint8_t)c[2]);
+      for (int d = c[3]; d <= c[4]; d++) { b.add('A', (uint8_t)c[2]); same(b); }
+    }
+  }
+  if (n_cases) *n_cases = n;
+  return bad;
+}
+
+}  // extern "C"

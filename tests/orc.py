@@ -1,0 +1,123 @@
+"""ctypes binding of the ORACLE (test infrastructure only; never imported by the product)."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_SO = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
+
+
+def _load():
+    if not os.path.exists(_SO):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    lib = C.CDLL(_SO)
+    D, U8, U32, I32, U64, VP, CP = C.c_double, C.c_uint8, C.c_uint32, C.c_int32, C.c_uint64, C.c_void_p, C.c_char_p
+    P = C.POINTER
+    sig = {
+        "orc_last_error": (CP, []),
+        "orc_process": (VP, [VP, VP, VP, VP, U32, VP, U32, U32, U32]),
+        "orc_result_data": (VP, [VP]), "orc_result_len": (U64, [VP]), "orc_result_count": (U64, [VP]),
+        "orc_result_stats": (None, [VP, VP]), "orc_result_rejects": (VP, [VP]), "orc_result_rejects_len": (U64, [VP]),
+        "orc_result_n_rejects": (U64, [VP]), "orc_result_free": (None, [VP]),
+        "orc_phred_to_ln_error_prob": (D, [U8]), "orc_phred_to_ln_correct_prob": (D, [U8]), "orc_ln_prob_to_phred": (U8, [D]),
+        "orc_log1pexp": (D, [D]), "orc_ln_sum_exp": (D, [D, D]), "orc_ln_sum_exp_array": (D, [VP, U32]), "orc_ln_not": (D, [D]),
+        "orc_ln_error_prob_two_trials": (D, [D, D]), "orc_ln_a_minus_b": (C.c_int, [D, D, P(D)]),
+        "orc_fgbio_unique_max_index": (C.c_int, [VP]), "orc_unique_max_index": (C.c_int, [VP]),
+        "orc_consensus_error": (D, [D]), "orc_unanimous_quality_from_gap": (U8, [D, U8]), "orc_unanimous_margin": (D, [D, D, D]),
+        "orc_builder_new": (VP, [U8, U8, C.c_int]), "orc_builder_free": (None, [VP]), "orc_builder_reset": (None, [VP]),
+        "orc_builder_add": (None, [VP, U8, U8]), "orc_builder_add_n": (None, [VP, U8, U8, U32]),
+        "orc_builder_call": (None, [VP, P(U8), P(U8)]), "orc_builder_call_full": (None, [VP, P(U8), P(U8)]),
+        "orc_builder_fast_path": (C.c_int, [VP, P(U8), P(U8)]), "orc_builder_contributions": (U32, [VP]),
+        "orc_builder_observations_for_base": (U32, [VP, U8]), "orc_builder_likelihoods": (None, [VP, VP]),
+        "orc_builder_set_likelihoods": (None, [VP, VP, VP]), "orc_builder_table": (None, [VP, C.c_int, VP, P(U32)]),
+        "orc_call_columns": (None, [U8, U8, C.c_int, VP, VP, U32, U32, VP, VP, VP, VP]),
+        "orc_single_input_quals": (None, [VP, VP]), "orc_read_name_rank": (I32, [CP, U32]), "orc_mate_clip": (U64, [VP, U32]),
+        "orc_mate_clip_ops": (U64, [C.c_int, I32, VP, U32, I32, VP, U32]), "orc_parse_mc": (C.c_int, [CP, VP]),
+        "orc_quality_trim_point": (U32, [VP, U32, U8]), "orc_consensus_umis": (C.c_int, [CP, VP, U32]),
+        "orc_overlap_pair": (C.c_int, [VP, U32, VP, U32, VP]),
+        "orc_sweep_fast_vs_full": (U64, [C.c_int, P(U64)]),
+    }
+    for name, (res, args) in sig.items():
+        if hasattr(lib, name):
+            f = getattr(lib, name)
+            f.restype = res
+            f.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Builder:
+    def __init__(self, pre, post, tie=0):
+        self.h = lib.orc_builder_new(pre, post, tie)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.orc_builder_free(self.h)
+            self.h = None
+
+    def reset(self):
+        lib.orc_builder_reset(self.h)
+
+    def add(self, base, qual, n=1):
+        b = ord(base) if isinstance(base, str) else base
+        lib.orc_builder_add_n(self.h, b, qual, n)
+
+    def _bq(self, fn):
+        b, q = C.c_uint8(), C.c_uint8()
+        r = fn(self.h, C.byref(b), C.byref(q))
+        return r, chr(b.value), q.value
+
+    def call(self):
+        _, b, q = self._bq(lib.orc_builder_call)
+        return b, q
+
+    def call_full(self):
+        _, b, q = self._bq(lib.orc_builder_call_full)
+        return b, q
+
+    def fast_path(self):
+        r, b, q = self._bq(lib.orc_builder_fast_path)
+        return (b, q) if r else None
+
+    def contributions(self):
+        return lib.orc_builder_contributions(self.h)
+
+    def observations_for_base(self, base):
+        return lib.orc_builder_observations_for_base(self.h, ord(base))
+
+    def likelihoods(self):
+        a = np.zeros(4)
+        lib.orc_builder_likelihoods(self.h, ptr(a))
+        return a
+
+    def table(self, which):
+        a = np.zeros(94)
+        cap = C.c_uint32()
+        lib.orc_builder_table(self.h, which, ptr(a), C.byref(cap))
+        return a, cap.value
+
+
+def process(opts, blob, rec_off, rec_len, grp_first, batch_groups=50, threads=1):
+    """Run the oracle over a whole input. Returns dict(data=bytes, count, stats=np.uint64[28], rejects, n_rejects)."""
+    n_rec = len(rec_off)
+    n_grp = len(grp_first) - 1
+    h = lib.orc_process(C.addressof(opts), ptr(blob), ptr(rec_off), ptr(rec_len), n_rec, ptr(grp_first), n_grp, batch_groups, threads)
+    if not h:
+        raise RuntimeError("oracle error: " + lib.orc_last_error().decode())
+    try:
+        n = lib.orc_result_len(h)
+        data = C.string_at(lib.orc_result_data(h), n) if n else b""
+        stats = np.zeros(28, dtype=np.uint64)
+        lib.orc_result_stats(h, ptr(stats))
+        rn = lib.orc_result_rejects_len(h)
+        rej = C.string_at(lib.orc_result_rejects(h), rn) if rn else b""
+        return dict(data=data, count=lib.orc_result_count(h), stats=stats, rejects=rej, n_rejects=lib.orc_result_n_rejects(h))
+    finally:
+        lib.orc_result_free(h)
