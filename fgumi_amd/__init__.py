@@ -1,0 +1,9 @@
+"""fgumi_amd — MI355X-native consensus engine (drop-in for fgumi's per-UMI-family consensus hot path).
+
+The product is the HIP shared library `libfgumi_amd.so` behind the C ABI in `include/fgumi_amd.h`;
+this package is the thin Python host mirror of the reference's caller interface
+(crates/fgumi-consensus/src/caller.rs:220-252) used by tests, bench.py and integrators.
+"""
+from ._lib import lib, load, Options, Output, SimParams, default_options, LibraryMissing  # noqa: F401
+from .caller import (ConsensusCaller, VanillaUmiConsensusCaller, VanillaUmiConsensusOptions, ConsensusOutput,  # noqa: F401
+                     ConsensusCallingStats, RejectionReason, GroupedReads, simulate_grouped_reads, split_records)

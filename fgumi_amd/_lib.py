@@ -1,0 +1,112 @@
+"""ctypes binding of libfgumi_amd.so (include/fgumi_amd.h).  There is no fallback: if the HIP
+library is missing the import of any product entry point fails loudly."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "libfgumi_amd.so")
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+class Options(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("caller_kind", C.c_uint32), ("tag", C.c_char * 2), ("cell_tag", C.c_char * 2),
+        ("error_rate_pre_umi", C.c_uint8), ("error_rate_post_umi", C.c_uint8), ("min_input_base_quality", C.c_uint8),
+        ("min_consensus_base_quality", C.c_uint8), ("produce_per_base_tags", C.c_uint8), ("trim", C.c_uint8),
+        ("tie_rule", C.c_uint8), ("overlapping_consensus", C.c_uint8), ("track_rejects", C.c_uint8), ("_pad0", C.c_uint8 * 3),
+        ("min_reads", C.c_uint32), ("max_reads", C.c_int64), ("read_name_prefix", C.c_char_p), ("read_group_id", C.c_char_p),
+        ("duplex_min_reads", C.c_uint32 * 3), ("duplex_max_reads_per_strand", C.c_int64),
+        ("codec_min_reads_per_strand", C.c_uint32), ("codec_max_reads_per_strand", C.c_int64), ("codec_min_duplex_length", C.c_uint32),
+        ("codec_single_strand_qual", C.c_uint8), ("codec_outer_bases_qual", C.c_uint8), ("codec_has_single_strand_qual", C.c_uint8),
+        ("codec_has_outer_bases_qual", C.c_uint8), ("codec_outer_bases_length", C.c_uint32),
+        ("codec_max_duplex_disagreements", C.c_uint32), ("codec_max_duplex_disagreement_rate", C.c_double),
+        ("device", C.c_int32), ("_pad1", C.c_uint32),
+    ]
+
+
+class Output(C.Structure):
+    _fields_ = [
+        ("data", C.c_void_p), ("data_len", C.c_uint64), ("count", C.c_uint64), ("stats", C.c_uint64 * 28),
+        ("rejects", C.c_void_p), ("rejects_len", C.c_uint64), ("n_rejects", C.c_uint64),
+        ("ms_host_prep", C.c_double), ("ms_h2d", C.c_double), ("ms_kernels", C.c_double), ("ms_d2h", C.c_double), ("ms_emit", C.c_double),
+    ]
+
+
+class SimParams(C.Structure):
+    _fields_ = [
+        ("seed", C.c_uint64), ("n_families", C.c_uint32), ("read_length", C.c_uint32), ("family_size", C.c_uint32),
+        ("family_size_max", C.c_uint32), ("duplex", C.c_uint32), ("insert_mean", C.c_uint32), ("insert_sd", C.c_uint32),
+        ("error_rate_ppm", C.c_uint32), ("first_family", C.c_uint32), ("codec", C.c_uint32),
+    ]
+
+
+# every symbol include/fgumi_amd.h declares
+EXPORTS = ["fgx_options_default", "fgx_create", "fgx_destroy", "fgx_last_error", "fgx_global_error", "fgx_process_batch",
+           "fgx_process_batch_device", "fgx_call_columns", "fgx_device_libm", "fgx_get_table", "fgx_sim_sizes",
+           "fgx_sim_generate_host", "fgx_sim_generate_device"]
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO):
+        raise LibraryMissing(f"{SO} is missing: build it with `python -m fgumi_amd.build` (hipcc, gfx950). "
+                             "There is no CPU fallback for the consensus path.")
+    L = C.CDLL(SO)
+    VP, U8, U32, U64, I = C.c_void_p, C.c_uint8, C.c_uint32, C.c_uint64, C.c_int
+    P = C.POINTER
+    L.fgx_options_default.argtypes = [P(Options)]
+    L.fgx_options_default.restype = None
+    L.fgx_create.argtypes = [P(Options)]
+    L.fgx_create.restype = VP
+    L.fgx_destroy.argtypes = [VP]
+    L.fgx_destroy.restype = None
+    L.fgx_last_error.argtypes = [VP]
+    L.fgx_last_error.restype = C.c_char_p
+    L.fgx_global_error.argtypes = []
+    L.fgx_global_error.restype = C.c_char_p
+    L.fgx_process_batch.argtypes = [VP, VP, U64, VP, VP, U32, VP, U32, P(Output)]
+    L.fgx_process_batch.restype = I
+    L.fgx_process_batch_device.argtypes = [VP, VP, U64, VP, VP, U32, VP, U32, P(Output), P(U32), P(VP)]
+    L.fgx_process_batch_device.restype = I
+    L.fgx_call_columns.argtypes = [VP, VP, VP, U32, U32, VP, VP, VP, VP]
+    L.fgx_call_columns.restype = I
+    L.fgx_device_libm.argtypes = [VP, I, VP, VP, U64]
+    L.fgx_device_libm.restype = I
+    L.fgx_get_table.argtypes = [VP, I, VP, P(U32)]
+    L.fgx_get_table.restype = I
+    L.fgx_sim_sizes.argtypes = [P(SimParams), P(U64), P(U64)]
+    L.fgx_sim_sizes.restype = I
+    L.fgx_sim_generate_host.argtypes = [P(SimParams), VP, VP, VP, VP]
+    L.fgx_sim_generate_host.restype = I
+    L.fgx_sim_generate_device.argtypes = [VP, P(SimParams), VP, VP, VP, VP]
+    L.fgx_sim_generate_device.restype = I
+    # host-only helpers (not part of the public header; used by CPU-side tests)
+    L.fgx_build_tables_host.argtypes = [U8, U8, I, VP, P(U32), VP]
+    L.fgx_build_tables_host.restype = I
+    L.fgx_host_libm_array.argtypes = [I, VP, VP, U64]
+    L.fgx_host_libm_array.restype = None
+    _lib = L
+    return L
+
+
+class _Lazy:
+    def __getattr__(self, name):
+        return getattr(load(), name)
+
+
+lib = _Lazy()
+
+
+def default_options(**kw):
+    o = Options()
+    load().fgx_options_default(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o

@@ -1,0 +1,291 @@
+"""Python host mirror of the reference's consensus-caller interface, over the C ABI.
+
+Mirrors (names, argument meaning, error behaviour):
+  * `ConsensusCaller` trait            crates/fgumi-consensus/src/caller.rs:220-252
+  * `ConsensusOutput`                  caller.rs:172-177
+  * `ConsensusCallingStats`            caller.rs:256-321, `RejectionReason` caller.rs:401-446
+  * `VanillaUmiConsensusOptions`       vanilla_caller.rs:292-353 (library defaults, NOT the CLI's)
+  * `VanillaUmiConsensusCaller::new_with_rejects_tracking`   vanilla_caller.rs:432-463
+  * the Process-step closure           src/lib/commands/simplex.rs:637-718  (`process_batch`)
+
+All arithmetic runs in the HIP library; nothing here computes consensus on the CPU.
+"""
+import ctypes as C
+import enum
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from ._lib import Options, Output, SimParams, lib, load
+
+
+class RejectionReason(enum.IntEnum):
+    FragmentRead = 0
+    InsufficientReads = 1
+    QualityTooLow = 2
+    Unmapped = 3
+    Mapped = 4
+    TooManyNs = 5
+    MinorityAlignment = 6
+    SecondaryOrSupplementary = 7
+    FailedQC = 8
+    MissingUmi = 9
+    QualityTrimmed = 10
+    ZeroLengthAfterTrimming = 11
+    InsufficientOverlap = 12
+    OrphanConsensus = 13
+    IndelErrorBetweenStrands = 14
+    ClipOverlapFailed = 15
+    HighDuplexDisagreement = 16
+    PotentialCollision = 17
+    NotPrimaryFrPair = 18
+    Downsampled = 19
+    Other = 20
+
+
+@dataclass
+class ConsensusOutput:
+    """Concatenated BAM records, each prefixed by its LE u32 block_size (caller.rs:172-177)."""
+    data: bytes = b""
+    count: int = 0
+
+    def extend(self, other: "ConsensusOutput"):
+        self.data += other.data
+        self.count += other.count
+
+
+@dataclass
+class ConsensusCallingStats:
+    total_reads: int = 0
+    consensus_reads: int = 0
+    filtered_reads: int = 0
+    rejection_reasons: Dict[RejectionReason, int] = field(default_factory=dict)
+    overlapping: Dict[str, int] = field(default_factory=dict)
+
+    @classmethod
+    def from_array(cls, a):
+        s = cls(int(a[0]), int(a[1]), int(a[2]))
+        for r in RejectionReason:
+            if a[3 + r]:
+                s.rejection_reasons[r] = int(a[3 + r])
+        s.overlapping = dict(overlapping_bases=int(a[24]), bases_agreeing=int(a[25]), bases_disagreeing=int(a[26]),
+                             bases_corrected=int(a[27]))
+        return s
+
+    def merge(self, o: "ConsensusCallingStats"):
+        self.total_reads += o.total_reads
+        self.consensus_reads += o.consensus_reads
+        self.filtered_reads += o.filtered_reads
+        for k, v in o.rejection_reasons.items():
+            self.rejection_reasons[k] = self.rejection_reasons.get(k, 0) + v
+        for k, v in o.overlapping.items():
+            self.overlapping[k] = self.overlapping.get(k, 0) + v
+
+
+@dataclass
+class VanillaUmiConsensusOptions:
+    """vanilla_caller.rs:292-353 (same defaults as `impl Default`)."""
+    tag: str = "MI"
+    error_rate_pre_umi: int = 45
+    error_rate_post_umi: int = 40
+    min_input_base_quality: int = 10
+    min_reads: int = 2
+    max_reads: Optional[int] = None
+    produce_per_base_tags: bool = True
+    trim: bool = False
+    min_consensus_base_quality: int = 40
+    cell_tag: Optional[str] = None
+    tie_rule: int = 0  # 0 FgbioCompat (default), 1 UlpRelative
+
+
+@dataclass
+class GroupedReads:
+    """A batch of MI groups = `MiGroupBatch` (src/lib/mi_group.rs:22-57) as flat arrays."""
+    blob: np.ndarray       # uint8: BAM record stream
+    rec_off: np.ndarray    # uint64[n_rec]: offset of each record body
+    rec_len: np.ndarray    # uint32[n_rec]
+    grp_first: np.ndarray  # uint32[n_grp+1]
+
+    @property
+    def n_rec(self):
+        return len(self.rec_off)
+
+    @property
+    def n_grp(self):
+        return len(self.grp_first) - 1
+
+    @classmethod
+    def from_groups(cls, groups: Sequence[Sequence[bytes]]) -> "GroupedReads":
+        chunks, off, lens, first = [], [], [], [0]
+        pos = 0
+        for g in groups:
+            for r in g:
+                chunks.append(len(r).to_bytes(4, "little"))
+                chunks.append(bytes(r))
+                off.append(pos + 4)
+                lens.append(len(r))
+                pos += 4 + len(r)
+            first.append(len(off))
+        blob = np.frombuffer(b"".join(chunks) or b"\0", dtype=np.uint8).copy()
+        return cls(blob, np.array(off, dtype=np.uint64), np.array(lens, dtype=np.uint32), np.array(first, dtype=np.uint32))
+
+    def records(self, g: int) -> List[bytes]:
+        a, b = int(self.grp_first[g]), int(self.grp_first[g + 1])
+        return [bytes(self.blob[int(self.rec_off[r]): int(self.rec_off[r]) + int(self.rec_len[r])]) for r in range(a, b)]
+
+    def subset(self, g0: int, g1: int) -> "GroupedReads":
+        return GroupedReads.from_groups([self.records(g) for g in range(g0, g1)])
+
+
+def split_records(data: bytes) -> List[bytes]:
+    """Split `ConsensusOutput.data` into record bodies (without the block_size prefixes)."""
+    out, p = [], 0
+    while p < len(data):
+        n = int.from_bytes(data[p:p + 4], "little")
+        out.append(data[p + 4:p + 4 + n])
+        p += 4 + n
+    return out
+
+
+def simulate_grouped_reads(n_families, family_size=3, read_length=150, seed=42, **kw) -> GroupedReads:
+    """Host generation of `fgumi simulate grouped-reads`-shaped input (see csrc/simgen.h)."""
+    p = SimParams()
+    p.seed, p.n_families, p.read_length, p.family_size = seed, n_families, read_length, family_size
+    p.insert_mean, p.insert_sd, p.error_rate_ppm = 300, 50, 1000
+    for k, v in kw.items():
+        setattr(p, k, v)
+    bl, nr = C.c_uint64(), C.c_uint64()
+    if lib.fgx_sim_sizes(C.byref(p), C.byref(bl), C.byref(nr)) != 0:
+        raise ValueError("simulated input too large for 32-bit record indices")
+    blob = np.zeros(max(1, bl.value), dtype=np.uint8)
+    rec_off = np.zeros(nr.value, dtype=np.uint64)
+    rec_len = np.zeros(nr.value, dtype=np.uint32)
+    grp_first = np.zeros(n_families + 1, dtype=np.uint32)
+    lib.fgx_sim_generate_host(C.byref(p), blob.ctypes.data, rec_off.ctypes.data, rec_len.ctypes.data, grp_first.ctypes.data)
+    return GroupedReads(blob, rec_off, rec_len, grp_first)
+
+
+class ConsensusCaller:
+    """The `ConsensusCaller` trait (caller.rs:220-252)."""
+
+    def consensus_reads(self, records: Sequence[bytes]) -> ConsensusOutput:
+        raise NotImplementedError
+
+    def total_reads(self) -> int:
+        return self._stats.total_reads
+
+    def total_filtered(self) -> int:
+        return self._stats.filtered_reads
+
+    def consensus_reads_constructed(self) -> int:
+        return self._stats.consensus_reads
+
+    def statistics(self) -> ConsensusCallingStats:
+        return self._stats
+
+    def log_statistics(self):
+        import logging
+        log = logging.getLogger("fgumi_amd")
+        log.info("Consensus Calling Statistics:")
+        log.info("  Total input reads: %d", self._stats.total_reads)
+        log.info("  Consensus reads generated: %d", self._stats.consensus_reads)
+        log.info("  Reads filtered: %d", self._stats.filtered_reads)
+        for reason, count in self._stats.rejection_reasons.items():
+            log.info("    %s: %d", reason.name, count)
+
+
+class _HandleCaller(ConsensusCaller):
+    kind = 0
+
+    def __init__(self, opts: Options, read_name_prefix: str, read_group_id: str):
+        load()
+        self._prefix = read_name_prefix.encode()
+        self._rg = read_group_id.encode()
+        opts.read_name_prefix = self._prefix
+        opts.read_group_id = self._rg
+        self._opts = opts
+        self._h = lib.fgx_create(C.byref(opts))
+        if not self._h:
+            raise RuntimeError(lib.fgx_global_error().decode())
+        self._stats = ConsensusCallingStats()
+        self._rejected: List[bytes] = []
+        self.last_timing = {}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.fgx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- batch level: the process_fn closure -------------------------------------------------
+    def process_batch(self, grouped: GroupedReads) -> ConsensusOutput:
+        out = Output()
+        rc = lib.fgx_process_batch(self._h, grouped.blob.ctypes.data, grouped.blob.size, grouped.rec_off.ctypes.data,
+                                   grouped.rec_len.ctypes.data, grouped.n_rec, grouped.grp_first.ctypes.data, grouped.n_grp, C.byref(out))
+        if rc != 0:
+            raise RuntimeError(lib.fgx_last_error(self._h).decode())  # every error is fatal to the run (simplex.rs:699-701)
+        self._last_stats = ConsensusCallingStats.from_array(out.stats)
+        self._stats.merge(self._last_stats)
+        if out.n_rejects:
+            self._rejected.extend(split_records(C.string_at(out.rejects, out.rejects_len)))
+        self.last_timing = dict(host_prep=out.ms_host_prep, h2d=out.ms_h2d, kernels=out.ms_kernels, d2h=out.ms_d2h, emit=out.ms_emit)
+        data = C.string_at(out.data, out.data_len) if out.data_len else b""
+        return ConsensusOutput(data, int(out.count))
+
+    def last_batch_statistics(self) -> ConsensusCallingStats:
+        return self._last_stats
+
+    # ---- the trait -----------------------------------------------------------------------------
+    def consensus_reads(self, records: Sequence[bytes]) -> ConsensusOutput:
+        if not records:
+            return ConsensusOutput()
+        return self.process_batch(GroupedReads.from_groups([list(records)]))
+
+    def rejected_reads(self) -> List[bytes]:
+        return self._rejected
+
+    def take_rejected_reads(self) -> List[bytes]:
+        r, self._rejected = self._rejected, []
+        return r
+
+    def clear(self):
+        self._stats = ConsensusCallingStats()
+        self._rejected = []
+
+
+def _fill_vanilla(o: Options, v: VanillaUmiConsensusOptions):
+    if len(v.tag) != 2:
+        raise ValueError(f"Tag '{v.tag}' must be exactly 2 characters")  # vanilla_caller.rs:1892-1894
+    o.tag = v.tag.encode()
+    o.cell_tag = (v.cell_tag.encode() if v.cell_tag else b"\0\0")
+    o.error_rate_pre_umi, o.error_rate_post_umi = v.error_rate_pre_umi, v.error_rate_post_umi
+    o.min_input_base_quality, o.min_consensus_base_quality = v.min_input_base_quality, v.min_consensus_base_quality
+    o.min_reads = v.min_reads
+    o.max_reads = -1 if v.max_reads is None else v.max_reads
+    o.produce_per_base_tags, o.trim, o.tie_rule = int(v.produce_per_base_tags), int(v.trim), v.tie_rule
+
+
+class VanillaUmiConsensusCaller(_HandleCaller):
+    """`VanillaUmiConsensusCaller::new_with_rejects_tracking(read_name_prefix, read_group_id, options, track_rejects)`.
+
+    `overlapping_consensus` switches on the R1/R2 pre-correction the commands apply before the caller
+    (simplex.rs:688-694); it is off for the bare trait object, as in the reference."""
+
+    def __init__(self, read_name_prefix: str, read_group_id: str, options: Optional[VanillaUmiConsensusOptions] = None,
+                 track_rejects: bool = False, overlapping_consensus: bool = False, device: int = -1):
+        from ._lib import default_options
+        options = options or VanillaUmiConsensusOptions()
+        o = default_options()
+        o.caller_kind = 0
+        _fill_vanilla(o, options)
+        o.track_rejects = int(track_rejects)
+        o.overlapping_consensus = int(overlapping_consensus)
+        o.device = device
+        self.options = options
+        super().__init__(o, read_name_prefix, read_group_id)

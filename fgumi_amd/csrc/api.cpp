@@ -1,0 +1,300 @@
+// api.cpp — the C ABI declared in include/fgumi_amd.h.
+#include <chrono>
+#include <cstdio>
+#include <stdexcept>
+#include <cstring>
+#include <string>
+#include "engine.h"
+#include "host_common.h"
+#include "simgen.h"
+
+using namespace fgx;
+
+static thread_local std::string g_global_err;
+
+namespace fgx {
+
+void hip_check(hipError_t e, const char* what) {
+  if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+void DevBuf::reserve(size_t n) {
+  if (n <= cap) return;
+  size_t want = n + n / 4 + 256;
+  if (p) hip_check(hipFree(p), "hipFree");
+  p = nullptr;
+  cap = 0;
+  hip_check(hipMalloc(&p, want), "hipMalloc");
+  cap = want;
+}
+void DevBuf::free_() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
+void PinnedBuf::reserve(size_t n) {
+  if (n <= cap) return;
+  size_t want = n + n / 4 + 256;
+  if (p) hip_check(hipHostFree(p), "hipHostFree");
+  p = nullptr;
+  cap = 0;
+  hip_check(hipHostMalloc(&p, want, hipHostMallocDefault), "hipHostMalloc");
+  cap = want;
+}
+void PinnedBuf::free_() { if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; } }
+
+}  // namespace fgx
+
+double fgx_caller::run_columns(ColumnBatch& b, ColParams prm) {
+  b.ob.assign(b.n_cols, 0); b.oq.assign(b.n_cols, 0); b.od.assign(b.n_cols, 0); b.oe.assign(b.n_cols, 0);
+  if (b.jobs.empty() || b.n_cols == 0) return 0.0;
+  std::vector<Tile> tiles;
+  for (uint32_t j = 0; j < b.jobs.size(); j++)
+    for (uint32_t p0 = 0; p0 < b.jobs[j].cons_len; p0 += 64) tiles.push_back(Tile{j, p0});
+  hip_check(hipSetDevice(device), "hipSetDevice");
+  d_stage.reserve(b.stage.size());
+  d_reads.reserve(b.reads.size() * sizeof(ReadDesc));
+  d_jobs.reserve(b.jobs.size() * sizeof(ColJob));
+  d_tiles.reserve(tiles.size() * sizeof(Tile));
+  d_ob.reserve(b.n_cols); d_oq.reserve(b.n_cols); d_od.reserve(2ull * b.n_cols); d_oe.reserve(2ull * b.n_cols);
+  hip_check(hipMemcpyAsync(d_stage.p, b.stage.data(), b.stage.size(), hipMemcpyHostToDevice, stream), "H2D stage");
+  hip_check(hipMemcpyAsync(d_reads.p, b.reads.data(), b.reads.size() * sizeof(ReadDesc), hipMemcpyHostToDevice, stream), "H2D reads");
+  hip_check(hipMemcpyAsync(d_jobs.p, b.jobs.data(), b.jobs.size() * sizeof(ColJob), hipMemcpyHostToDevice, stream), "H2D jobs");
+  hip_check(hipMemcpyAsync(d_tiles.p, tiles.data(), tiles.size() * sizeof(Tile), hipMemcpyHostToDevice, stream), "H2D tiles");
+  hip_check(hipEventRecord(ev0, stream), "event");
+  launch_column_jobs(stream, d_stage.as<uint8_t>(), d_reads.as<ReadDesc>(), d_jobs.as<ColJob>(), d_tiles.as<Tile>(), (uint32_t)tiles.size(),
+                     d_tables.as<DeviceTables>(), prm, d_ob.as<uint8_t>(), d_oq.as<uint8_t>(), d_od.as<uint16_t>(), d_oe.as<uint16_t>());
+  hip_check(hipGetLastError(), "k_column_jobs launch");
+  hip_check(hipEventRecord(ev1, stream), "event");
+  hip_check(hipMemcpyAsync(b.ob.data(), d_ob.p, b.n_cols, hipMemcpyDeviceToHost, stream), "D2H");
+  hip_check(hipMemcpyAsync(b.oq.data(), d_oq.p, b.n_cols, hipMemcpyDeviceToHost, stream), "D2H");
+  hip_check(hipMemcpyAsync(b.od.data(), d_od.p, 2ull * b.n_cols, hipMemcpyDeviceToHost, stream), "D2H");
+  hip_check(hipMemcpyAsync(b.oe.data(), d_oe.p, 2ull * b.n_cols, hipMemcpyDeviceToHost, stream), "D2H");
+  hip_check(hipStreamSynchronize(stream), "sync");
+  float ms = 0;
+  hip_check(hipEventElapsedTime(&ms, ev0, ev1), "elapsed");
+  return ms;
+}
+
+extern "C" {
+
+void fgx_options_default(fgx_options* o) {
+  memset(o, 0, sizeof(*o));
+  o->struct_size = sizeof(fgx_options);
+  o->caller_kind = FGX_CALLER_SIMPLEX;
+  o->tag[0] = 'M'; o->tag[1] = 'I';
+  o->cell_tag[0] = 'C'; o->cell_tag[1] = 'B';
+  o->error_rate_pre_umi = 45; o->error_rate_post_umi = 40;
+  o->min_input_base_quality = 10; o->min_consensus_base_quality = 2;
+  o->produce_per_base_tags = 1; o->trim = 0; o->tie_rule = FGX_TIE_FGBIO_COMPAT;
+  o->overlapping_consensus = 1; o->track_rejects = 0;
+  o->min_reads = 1; o->max_reads = -1;
+  o->read_name_prefix = ""; o->read_group_id = "A";
+  o->duplex_min_reads[0] = 1; o->duplex_min_reads[1] = 1; o->duplex_min_reads[2] = 0;
+  o->duplex_max_reads_per_strand = -1;
+  o->codec_min_reads_per_strand = 1; o->codec_max_reads_per_strand = -1; o->codec_min_duplex_length = 1;
+  o->codec_outer_bases_length = 5; o->codec_max_duplex_disagreements = 0xFFFFFFFFu; o->codec_max_duplex_disagreement_rate = 1.0;
+  o->device = -1;
+}
+
+const char* fgx_global_error(void) { return g_global_err.c_str(); }
+const char* fgx_last_error(const fgx_caller* c) { return c ? c->err.c_str() : g_global_err.c_str(); }
+
+fgx_caller* fgx_create(const fgx_options* opts) {
+  if (!opts || opts->struct_size != sizeof(fgx_options)) { g_global_err = "fgx_create: bad options struct_size (ABI mismatch)"; return nullptr; }
+  fgx_caller* c = nullptr;
+  try {
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) {
+      g_global_err = std::string("fgx_create: no usable HIP device (") + (e != hipSuccess ? hipGetErrorString(e) : "device count 0") +
+                     "); this engine has no CPU fallback";
+      return nullptr;
+    }
+    c = new fgx_caller();
+    c->opt = *opts;
+    c->prefix = opts->read_name_prefix ? opts->read_name_prefix : "";
+    c->rg = opts->read_group_id ? opts->read_group_id : "A";
+    c->opt.read_name_prefix = nullptr;
+    c->opt.read_group_id = nullptr;
+    if (opts->device >= 0) c->device = opts->device; else hip_check(hipGetDevice(&c->device), "hipGetDevice");
+    hip_check(hipSetDevice(c->device), "hipSetDevice");
+    hip_check(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate");
+    hip_check(hipEventCreate(&c->ev0), "hipEventCreate");
+    hip_check(hipEventCreate(&c->ev1), "hipEventCreate");
+    memset(&c->h_tables, 0, sizeof(c->h_tables));
+    memset(&c->h_umi_tables, 0, sizeof(c->h_umi_tables));
+    build_tables(c->h_tables.t, opts->error_rate_pre_umi, opts->error_rate_post_umi, opts->tie_rule);
+    build_single_input_quals(c->h_tables.single_input_quals, opts->error_rate_pre_umi, opts->error_rate_post_umi);
+    build_tables(c->h_umi_tables.t, 90, 90, FGX_TIE_FGBIO_COMPAT);
+    build_single_input_quals(c->h_umi_tables.single_input_quals, 90, 90);
+    c->d_tables.reserve(sizeof(DeviceTables));
+    c->d_umi_tables.reserve(sizeof(DeviceTables));
+    hip_check(hipMemcpy(c->d_tables.p, &c->h_tables, sizeof(DeviceTables), hipMemcpyHostToDevice), "tables H2D");
+    hip_check(hipMemcpy(c->d_umi_tables.p, &c->h_umi_tables, sizeof(DeviceTables), hipMemcpyHostToDevice), "tables H2D");
+    return c;
+  } catch (const std::exception& ex) {
+    g_global_err = std::string("fgx_create: ") + ex.what();
+    delete c;
+    return nullptr;
+  }
+}
+
+void fgx_destroy(fgx_caller* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  for (DevBuf* b : {&c->d_tables, &c->d_umi_tables, &c->d_stage, &c->d_reads, &c->d_jobs, &c->d_tiles, &c->d_ob, &c->d_oq, &c->d_od,
+                    &c->d_oe, &c->d_scratch_a, &c->d_scratch_b})
+    b->free_();
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int fgx_process_batch(fgx_caller* c, const uint8_t* records, uint64_t records_len, const uint64_t* rec_off, const uint32_t* rec_len,
+                      uint32_t n_rec, const uint32_t* grp_first, uint32_t n_grp, fgx_output* out) {
+  if (!c || !out) return 1;
+  c->err.clear();
+  try {
+    for (uint32_t r = 0; r < n_rec; r++) {
+      if (rec_len[r] < 32 || rec_off[r] + rec_len[r] > records_len) { c->err = "fgx_process_batch: record outside the blob or shorter than the fixed BAM header"; return 1; }
+    }
+    if (n_grp && grp_first[n_grp] > n_rec) { c->err = "fgx_process_batch: group boundaries exceed n_rec"; return 1; }
+    switch (c->opt.caller_kind) {
+      case FGX_CALLER_SIMPLEX: return simplex_process_general(c, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
+      default: c->err = "fgx_process_batch: caller kind not implemented"; return 1;
+    }
+  } catch (const std::exception& ex) {
+    c->err = ex.what();
+    return 3;
+  }
+}
+
+int fgx_process_batch_device(fgx_caller* c, const void*, uint64_t, const void*, const void*, uint32_t, const void*, uint32_t, fgx_output*,
+                             uint32_t*, const void**) {
+  if (c) c->err = "fgx_process_batch_device: not implemented yet";
+  return 1;
+}
+
+int fgx_call_columns(fgx_caller* c, const uint8_t* bases, const uint8_t* quals, uint32_t n_cols, uint32_t depth, uint8_t* out_base,
+                     uint8_t* out_qual, uint32_t* out_depth, uint32_t* out_errors) {
+  if (!c) return 1;
+  c->err.clear();
+  try {
+    // Each column becomes a job of `depth` one-base source reads … laid out transposed so that one job
+    // holds up to 64 columns: read i of the job = observation i of each column.
+    ColumnBatch& B = c->batch;
+    B.clear();
+    std::vector<uint8_t> rb, rq;
+    for (uint32_t j0 = 0; j0 < n_cols; j0 += 4096) {
+      uint32_t w = std::min<uint32_t>(4096, n_cols - j0);
+      uint32_t rd0 = (uint32_t)B.reads.size();
+      for (uint32_t i = 0; i < depth; i++) {
+        rb.resize(w); rq.resize(w);
+        for (uint32_t k = 0; k < w; k++) { rb[k] = bases[(size_t)(j0 + k) * depth + i]; rq[k] = quals[(size_t)(j0 + k) * depth + i]; }
+        B.add_read(rb.data(), rq.data(), w);
+      }
+      if (depth == 0) { B.add_job(rd0, 0, w); continue; }
+      // n_reads == 1 would take the single-read LUT path; pad with an ignored all-'N' read to stay in the builder path
+      if (depth == 1) { rb.assign(w, 'N'); rq.assign(w, 0); B.add_read(rb.data(), rq.data(), w); B.add_job(rd0, 2, w); }
+      else B.add_job(rd0, depth, w);
+    }
+    ColParams prm{0, 0};   // no thresholds: raw call() result
+    c->run_columns(B, prm);
+    // raw call(): thresholds disabled, but a no-call comes back as ('N', 2) and errors = depth
+    for (uint32_t j = 0; j < n_cols; j++) { out_base[j] = B.ob[j]; out_qual[j] = B.oq[j]; out_depth[j] = B.od[j]; out_errors[j] = B.oe[j]; }
+    return 0;
+  } catch (const std::exception& ex) { c->err = ex.what(); return 3; }
+}
+
+int fgx_device_libm(fgx_caller* c, int op, const double* x, double* y, uint64_t n) {
+  if (!c) return 1;
+  try {
+    hip_check(hipSetDevice(c->device), "hipSetDevice");
+    c->d_scratch_a.reserve(n * 8); c->d_scratch_b.reserve(n * 8);
+    hip_check(hipMemcpyAsync(c->d_scratch_a.p, x, n * 8, hipMemcpyHostToDevice, c->stream), "H2D");
+    launch_libm_test(c->stream, op, c->d_scratch_a.as<double>(), c->d_scratch_b.as<double>(), n);
+    hip_check(hipGetLastError(), "k_libm launch");
+    hip_check(hipMemcpyAsync(y, c->d_scratch_b.p, n * 8, hipMemcpyDeviceToHost, c->stream), "D2H");
+    hip_check(hipStreamSynchronize(c->stream), "sync");
+    return 0;
+  } catch (const std::exception& ex) { c->err = ex.what(); return 3; }
+}
+
+int fgx_get_table(const fgx_caller* c, int which, double* out94, uint32_t* cap) {
+  if (!c) return 1;
+  const ConsensusTables& t = c->h_tables.t;
+  const double* src = which == 0 ? t.correct : which == 1 ? t.error_per_alt : which == 2 ? t.thresholds : t.cerr_min;
+  memcpy(out94, src, 94 * sizeof(double));
+  if (cap) *cap = t.cap;
+  return 0;
+}
+
+// Tables without a device (host-only; used by the CPU-side tests of the table builders).
+int fgx_build_tables_host(uint8_t pre, uint8_t post, int which, double* out94, uint32_t* cap, uint8_t* single94) {
+  ConsensusTables t;
+  build_tables(t, pre, post, 0);
+  const double* src = which == 0 ? t.correct : which == 1 ? t.error_per_alt : which == 2 ? t.thresholds : t.cerr_min;
+  memcpy(out94, src, 94 * sizeof(double));
+  if (cap) *cap = t.cap;
+  if (single94) build_single_input_quals(single94, pre, post);
+  return 0;
+}
+// Host evaluation of the shared device/host math, for CPU-side parity tests of glibc_libm.h + consensus_math.h.
+double fgx_host_libm(int op, double x) { return op == 0 ? g_exp(x) : op == 1 ? g_log(x) : op == 2 ? g_log1p(x) : g_expm1(x); }
+void fgx_host_libm_array(int op, const double* x, double* y, uint64_t n) { for (uint64_t i = 0; i < n; i++) y[i] = fgx_host_libm(op, x[i]); }
+
+// ---- synthetic reads ----------------------------------------------------------------------------
+static void sim_layout(const fgx_sim_params* p, std::vector<uint64_t>& byte_off, std::vector<uint32_t>& rec_first, uint64_t* blob_len,
+                       uint64_t* n_rec) {
+  byte_off.resize(p->n_families);
+  rec_first.resize(p->n_families);
+  uint64_t off = 0, r = 0;
+  for (uint32_t f = 0; f < p->n_families; f++) {
+    sim::Molecule m = sim::make_molecule(*p, f);
+    byte_off[f] = off;
+    rec_first[f] = (uint32_t)r;
+    off += 2ull * m.pairs * (sim::record_size(*p, m.mol_id) + 4);
+    r += 2ull * m.pairs;
+  }
+  *blob_len = off;
+  *n_rec = r;
+}
+
+int fgx_sim_sizes(const fgx_sim_params* p, uint64_t* blob_len, uint64_t* n_rec) {
+  std::vector<uint64_t> bo;
+  std::vector<uint32_t> rf;
+  sim_layout(p, bo, rf, blob_len, n_rec);
+  return *n_rec > 0xFFFFFFFFull ? 1 : 0;
+}
+
+int fgx_sim_generate_host(const fgx_sim_params* p, uint8_t* blob, uint64_t* rec_off, uint32_t* rec_len, uint32_t* grp_first) {
+  std::vector<uint64_t> bo;
+  std::vector<uint32_t> rf;
+  uint64_t bl, nr;
+  sim_layout(p, bo, rf, &bl, &nr);
+  for (uint32_t f = 0; f < p->n_families; f++) sim::write_family(*p, f, bo[f], rf[f], blob, rec_off, rec_len, grp_first);
+  grp_first[p->n_families] = (uint32_t)nr;
+  return 0;
+}
+
+int fgx_sim_generate_device(fgx_caller* c, const fgx_sim_params* p, void* d_blob, void* d_rec_off, void* d_rec_len, void* d_grp_first) {
+  if (!c) return 1;
+  try {
+    std::vector<uint64_t> bo;
+    std::vector<uint32_t> rf;
+    uint64_t bl, nr;
+    sim_layout(p, bo, rf, &bl, &nr);
+    hip_check(hipSetDevice(c->device), "hipSetDevice");
+    DevBuf dbo, drf;
+    dbo.reserve(bo.size() * 8 + 8); drf.reserve(rf.size() * 4 + 4);
+    hip_check(hipMemcpy(dbo.p, bo.data(), bo.size() * 8, hipMemcpyHostToDevice), "H2D");
+    hip_check(hipMemcpy(drf.p, rf.data(), rf.size() * 4, hipMemcpyHostToDevice), "H2D");
+    launch_sim_generate(c->stream, *p, dbo.as<uint64_t>(), drf.as<uint32_t>(), (uint8_t*)d_blob, (uint64_t*)d_rec_off, (uint32_t*)d_rec_len,
+                        (uint32_t*)d_grp_first);
+    hip_check(hipGetLastError(), "k_sim_generate launch");
+    uint32_t total = (uint32_t)nr;
+    hip_check(hipMemcpyAsync((uint32_t*)d_grp_first + p->n_families, &total, 4, hipMemcpyHostToDevice, c->stream), "H2D");
+    hip_check(hipStreamSynchronize(c->stream), "sync");
+    dbo.free_(); drf.free_();
+    return 0;
+  } catch (const std::exception& ex) { c->err = ex.what(); return 3; }
+}
+
+}  // extern "C"

@@ -1,0 +1,114 @@
+// engine.h — internal declarations shared by the host side and the HIP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/fgumi_amd.h"
+#include "consensus_math.h"
+
+namespace fgx {
+
+// ---- device-visible job descriptions (general path: SourceReads staged by the host) ------------
+struct ReadDesc {      // one SourceRead: bases at stage[off, off+len), quals at stage[off+len, off+2*len)
+  uint64_t off;
+  uint32_t len;
+  uint32_t _pad;
+};
+struct ColJob {        // one single-strand consensus call (vanilla_caller.rs:1652-1755)
+  uint32_t rd0;        // first ReadDesc
+  uint32_t n_reads;
+  uint32_t cons_len;   // consensus length = min_reads-th longest source read
+  uint32_t out_off;    // first output column of this job in the SoA result arrays
+};
+struct Tile {          // 64 consecutive columns of one job = one wavefront
+  uint32_t job;
+  uint32_t p0;
+};
+struct ColParams {
+  uint32_t min_reads;              // depth < min_reads → ('N', 0)
+  uint32_t min_consensus_base_quality;  // qual < this → ('N', 2)
+};
+struct DeviceTables {
+  ConsensusTables t;
+  uint8_t single_input_quals[96];  // vanilla_caller.rs:469-501 (94 used)
+};
+
+struct DevBuf {  // grow-only device allocation
+  void* p = nullptr;
+  size_t cap = 0;
+  void reserve(size_t n);
+  void free_();
+  template <class T> T* as() { return (T*)p; }
+};
+struct PinnedBuf {  // grow-only pinned host allocation
+  void* p = nullptr;
+  size_t cap = 0;
+  void reserve(size_t n);
+  void free_();
+  template <class T> T* as() { return (T*)p; }
+};
+
+void hip_check(hipError_t e, const char* what);
+
+// kernels.hip
+void launch_column_jobs(hipStream_t s, const uint8_t* d_stage, const ReadDesc* d_reads, const ColJob* d_jobs, const Tile* d_tiles,
+                        uint32_t n_tiles, const DeviceTables* d_tables, ColParams prm, uint8_t* d_ob, uint8_t* d_oq, uint16_t* d_od,
+                        uint16_t* d_oe);
+void launch_libm_test(hipStream_t s, int op, const double* d_x, double* d_y, uint64_t n);
+void launch_sim_generate(hipStream_t s, fgx_sim_params p, const uint64_t* d_fam_byte_off, const uint32_t* d_fam_rec_first,
+                         uint8_t* d_blob, uint64_t* d_rec_off, uint32_t* d_rec_len, uint32_t* d_grp_first);
+
+// One batch of single-strand consensus jobs, staged on the host and run on the device.
+struct ColumnBatch {
+  std::vector<uint8_t> stage;
+  std::vector<ReadDesc> reads;
+  std::vector<ColJob> jobs;
+  uint32_t n_cols = 0;
+  // results (host copies)
+  std::vector<uint8_t> ob, oq;
+  std::vector<uint16_t> od, oe;
+  void clear() { stage.clear(); reads.clear(); jobs.clear(); n_cols = 0; }
+  // Appends a source read; returns its ReadDesc index.
+  uint32_t add_read(const uint8_t* bases, const uint8_t* quals, uint32_t len) {
+    ReadDesc d; d.off = stage.size(); d.len = len; d._pad = 0;
+    stage.insert(stage.end(), bases, bases + len);
+    stage.insert(stage.end(), quals, quals + len);
+    reads.push_back(d);
+    return (uint32_t)reads.size() - 1;
+  }
+  uint32_t add_job(uint32_t rd0, uint32_t n_reads, uint32_t cons_len) {
+    ColJob j; j.rd0 = rd0; j.n_reads = n_reads; j.cons_len = cons_len; j.out_off = n_cols;
+    n_cols += cons_len;
+    jobs.push_back(j);
+    return (uint32_t)jobs.size() - 1;
+  }
+};
+
+}  // namespace fgx
+
+// The caller object behind the C ABI.
+struct fgx_caller {
+  fgx_options opt;
+  std::string prefix, rg;
+  std::string err;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  fgx::DeviceTables h_tables;       // main tables (pre, post from options)
+  fgx::DeviceTables h_umi_tables;   // consensus_umis tables (90, 90), simple_umi.rs:12-18
+  fgx::DevBuf d_tables, d_umi_tables;
+  fgx::DevBuf d_stage, d_reads, d_jobs, d_tiles, d_ob, d_oq, d_od, d_oe, d_scratch_a, d_scratch_b;
+  fgx::ColumnBatch batch;
+  // outputs of the last call
+  std::vector<uint8_t> out_data, out_rejects;
+
+  // Runs the staged column jobs of `b` on the device and fills b.ob/oq/od/oe. Returns kernel ms.
+  double run_columns(fgx::ColumnBatch& b, fgx::ColParams prm);
+};
+
+namespace fgx {
+// simplex_host.cpp — general path (any CIGAR, any family shape): host orchestration, device columns.
+int simplex_process_general(fgx_caller* c, const uint8_t* blob, const uint64_t* rec_off, const uint32_t* rec_len, uint32_t n_rec,
+                            const uint32_t* grp_first, uint32_t n_grp, fgx_output* out);
+}

@@ -1,0 +1,223 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the oracle on the
+same inputs.  Bit-exact for every byte (integer/byte work; f64 column math must match glibc)."""
+import ctypes as C
+import math
+import random
+
+import numpy as np
+import pytest
+
+import bamutil
+import cases
+import fgx_opts
+import orc
+from fgumi_amd import (GroupedReads, VanillaUmiConsensusCaller, VanillaUmiConsensusOptions, simulate_grouped_reads, split_records)
+from fgumi_amd._lib import default_options, lib
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def handle():
+    o = default_options()
+    h = lib.fgx_create(C.byref(o))
+    assert h, lib.fgx_global_error().decode()
+    yield h
+    lib.fgx_destroy(h)
+
+
+# ---- device libm ≡ glibc ----------------------------------------------------------------------
+@pytest.mark.parametrize("op,fn,ranges", [
+    (0, math.exp, [(-40.0, 20.0), (-745.5, -700.0), (700.0, 710.0), (-1e-3, 1e-3)]),
+    (1, math.log, [(1e-300, 1e-290), (1e-9, 10.0), (0.93, 1.07), (1.0, 1e9)]),
+    (2, math.log1p, [(-0.99999, 2.0), (-1e-6, 1e-6), (1.0, 1e12)]),
+    (3, math.expm1, [(-0.7, 0.7), (-40.0, 5.0), (-1e-9, 1e-9)]),
+])
+def test_device_libm_bit_exact(handle, op, fn, ranges):
+    rng = np.random.default_rng(op + 11)
+    x = np.concatenate([rng.uniform(lo, hi, 250000) for lo, hi in ranges] + [np.array([0.0, -0.0, 1.0, -1.0 if op in (0, 3) else 0.5])])
+    y = np.zeros_like(x)
+    assert lib.fgx_device_libm(handle, op, x.ctypes.data, y.ctypes.data, x.size) == 0
+    ref = np.array([fn(v) for v in x])
+    bad = np.nonzero(y.view(np.uint64) != ref.view(np.uint64))[0]
+    assert bad.size == 0, f"{bad.size} mismatches, first x={x[bad[0]]!r} got={y[bad[0]]!r} want={ref[bad[0]]!r}"
+
+
+def test_device_tables_equal_oracle(handle):
+    b = orc.Builder(45, 40)
+    for which in range(4):
+        want, cap = b.table(which)
+        got = np.zeros(94)
+        gcap = C.c_uint32()
+        lib.fgx_get_table(handle, which, got.ctypes.data, C.byref(gcap))
+        assert np.array_equal(got.view(np.uint64), want.view(np.uint64)) and gcap.value == cap
+
+
+# ---- column level: ConsensusBaseBuilder -----------------------------------------------------
+def _columns(handle, bases, quals, pre=45, post=40, tie=0):
+    n_cols, depth = bases.shape
+    o = default_options(error_rate_pre_umi=pre, error_rate_post_umi=post, tie_rule=tie)
+    h = lib.fgx_create(C.byref(o))
+    assert h
+    try:
+        ob, oq = np.zeros(n_cols, np.uint8), np.zeros(n_cols, np.uint8)
+        od, oe = np.zeros(n_cols, np.uint32), np.zeros(n_cols, np.uint32)
+        b, q = np.ascontiguousarray(bases), np.ascontiguousarray(quals)
+        assert lib.fgx_call_columns(h, b.ctypes.data, q.ctypes.data, n_cols, depth, ob.ctypes.data, oq.ctypes.data, od.ctypes.data, oe.ctypes.data) == 0
+    finally:
+        lib.fgx_destroy(h)
+    wb, wq = np.zeros(n_cols, np.uint8), np.zeros(n_cols, np.uint8)
+    wd, we = np.zeros(n_cols, np.uint32), np.zeros(n_cols, np.uint32)
+    orc.lib.orc_call_columns(pre, post, tie, orc.ptr(b), orc.ptr(q), n_cols, depth, orc.ptr(wb), orc.ptr(wq), orc.ptr(wd), orc.ptr(we))
+    return (ob, oq, od, oe), (wb, wq, wd, we)
+
+
+@pytest.mark.parametrize("pre,post,tie", [(45, 40, 0), (45, 40, 1), (90, 90, 0), (93, 93, 0), (20, 10, 0), (70, 5, 0), (2, 2, 0), (50, 50, 0)])
+def test_random_columns_match_oracle(handle, pre, post, tie):
+    rng = np.random.default_rng(pre * 100 + post + tie)
+    for depth in [1, 2, 3, 4, 8, 16, 50]:
+        n = 20000
+        truth = rng.integers(0, 4, n)
+        err = rng.random((n, depth)) < 0.08
+        alt = rng.integers(0, 4, (n, depth))
+        idx = np.where(err, alt, truth[:, None])
+        bases = np.frombuffer(b"ACGT", dtype=np.uint8)[idx]
+        bases = np.where(rng.random((n, depth)) < 0.03, ord("N"), bases).astype(np.uint8)
+        quals = rng.integers(0, 60, (n, depth)).astype(np.uint8)
+        quals[rng.random((n, depth)) < 0.3] = 37            # equal qualities provoke near-ties
+        got, want = _columns(handle, bases, quals, pre, post, tie)
+        for g, w, what in zip(got, want, ("base", "qual", "depth", "errors")):
+            bad = np.nonzero(g != w)[0]
+            assert bad.size == 0, f"{what}: {bad.size} mismatches at depth {depth}; first col {bad[0]}: bases={bases[bad[0]].tobytes()} quals={quals[bad[0]].tolist()} got={g[bad[0]]} want={w[bad[0]]}"
+
+
+def test_reference_column_pins_on_device(handle):
+    # base_builder.rs:2500-2526, 1510-1603, 2682-2708 replayed through the kernel
+    def one(obs, pre, post, tie=0):
+        bases = np.array([[ord(b) for b, _ in obs]], dtype=np.uint8)
+        quals = np.array([[q for _, q in obs]], dtype=np.uint8)
+        got, want = _columns(handle, bases, quals, pre, post, tie)
+        assert all(int(g[0]) == int(w[0]) for g, w in zip(got, want))
+        return chr(got[0][0]), int(got[1][0])
+
+    for pre, post, obs, depth, exp in [(45, 2, 2, 50, 16), (70, 5, 5, 15, 65), (70, 5, 5, 40, 70), (93, 40, 20, 3, 69), (20, 10, 10, 4, 19),
+                                       (45, 40, 40, 50, 45), (93, 93, 93, 100, 93), (2, 2, 2, 5, 2)]:
+        assert one([("A", obs)] * depth, pre, post) == ("A", exp)
+    assert one([("C", 37), ("C", 37), ("T", 37), ("T", 37)], 45, 40, 0) == ("T", 3)
+    assert one([("C", 37), ("C", 37), ("T", 37), ("T", 37)], 45, 40, 1) == ("N", 2)
+    assert one([("A", 20), ("C", 20)], 93, 93) == ("N", 2)
+    assert one([("A", 30), ("A", 30)], 45, 40) == ("A", 44)
+    assert one([("A", 30), ("A", 30), ("C", 0)], 45, 40) == ("A", 44)
+    assert one([("C", 20)] * 1000 + [("T", 20)] * 10, 50, 50) == ("C", 50)
+    assert one([("A", 20)], 50, 50) == ("A", 20)
+
+
+def test_deep_unanimous_columns_match_oracle(handle):
+    # contiguous depths straddle the gap-table bracket edges (base_builder.rs:2042-2083)
+    for pre, post, q in [(45, 3, 3), (70, 5, 7), (90, 93, 93), (93, 93, 40)]:
+        depths = list(range(1, 400))
+        D = max(depths)
+        bases = np.full((len(depths), D), ord("N"), dtype=np.uint8)
+        for i, d in enumerate(depths):
+            bases[i, :d] = ord("G")
+        quals = np.full((len(depths), D), q, dtype=np.uint8)
+        got, want = _columns(handle, bases, quals, pre, post)
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w)
+
+
+# ---- whole batches: process_fn ------------------------------------------------------------------
+def _oracle(grouped, **optkw):
+    o = fgx_opts.defaults(**optkw)
+    return orc.process(o, grouped.blob, grouped.rec_off, grouped.rec_len, grouped.grp_first)
+
+
+def _device(grouped, min_reads=1, overlapping=True, track_rejects=False, prefix="", **optkw):
+    vo = VanillaUmiConsensusOptions(min_reads=min_reads, min_consensus_base_quality=optkw.pop("min_consensus_base_quality", 2),
+                                    cell_tag="CB", **optkw)
+    c = VanillaUmiConsensusCaller(prefix, "A", vo, track_rejects=track_rejects, overlapping_consensus=overlapping)
+    out = c.process_batch(grouped)
+    stats = c.last_batch_statistics()
+    rej = c.take_rejected_reads()
+    c.close()
+    return out, stats, rej
+
+
+def _assert_same(grouped, min_reads=1, overlapping=True, track_rejects=False, **kw):
+    okw = dict(min_reads=min_reads, overlapping_consensus=int(overlapping), track_rejects=int(track_rejects))
+    for k, v in kw.items():
+        if k == "max_reads":
+            okw["max_reads"] = -1 if v is None else v
+        elif k == "trim":
+            okw["trim"] = int(v)
+        elif k == "prefix":
+            okw["read_name_prefix"] = v.encode()
+        elif k == "produce_per_base_tags":
+            okw[k] = int(v)
+        else:
+            okw[k] = v
+    want = _oracle(grouped, **okw)
+    out, stats, rej = _device(grouped, min_reads=min_reads, overlapping=overlapping, track_rejects=track_rejects, **kw)
+    assert out.count == want["count"]
+    if out.data != want["data"]:
+        a, b = split_records(out.data), split_records(want["data"])
+        for i, (x, y) in enumerate(zip(a, b)):
+            if x != y:
+                raise AssertionError(f"record {i} differs:\n got {bamutil.parse(x)}\nwant {bamutil.parse(y)}")
+        raise AssertionError("record count/length differs")
+    arr = np.zeros(28, dtype=np.uint64)
+    arr[0], arr[1], arr[2] = stats.total_reads, stats.consensus_reads, stats.filtered_reads
+    for r, v in stats.rejection_reasons.items():
+        arr[3 + int(r)] = v
+    arr[24:28] = [stats.overlapping[k] for k in ("overlapping_bases", "bases_agreeing", "bases_disagreeing", "bases_corrected")]
+    assert np.array_equal(arr, want["stats"]), (arr.tolist(), want["stats"].tolist())
+    if track_rejects:
+        assert rej == split_records(want["rejects"])
+    return out, want
+
+
+def test_config1_simplex_10k_families_depth3(handle):
+    """BASELINE.json configs[0]: 10k families, depth 3, 150 bp — byte-identical ConsensusOutput."""
+    g = simulate_grouped_reads(10000, family_size=3)
+    out, want = _assert_same(g, min_reads=1)
+    assert out.count == 20000
+
+
+@pytest.mark.parametrize("kw", [dict(min_reads=2), dict(min_reads=3), dict(overlapping=False), dict(min_reads=1, track_rejects=True),
+                                dict(min_reads=2, track_rejects=True, min_consensus_base_quality=40), dict(trim=True),
+                                dict(max_reads=2, track_rejects=True), dict(min_reads=2, max_reads=2), dict(produce_per_base_tags=False),
+                                dict(error_rate_pre_umi=30, error_rate_post_umi=20), dict(tie_rule=1), dict(min_input_base_quality=30)])
+def test_simplex_option_matrix(handle, kw):
+    g = simulate_grouped_reads(600, family_size=4, error_rate_ppm=20000)
+    _assert_same(g, **kw)
+
+
+def test_simplex_depth8_and_long_tail(handle):
+    _assert_same(simulate_grouped_reads(2000, family_size=8))
+    _assert_same(simulate_grouped_reads(1500, family_size=2, family_size_max=50), min_reads=2)
+    _assert_same(simulate_grouped_reads(300, family_size=1), min_reads=1)                 # single-read LUT path
+    _assert_same(simulate_grouped_reads(300, family_size=3, read_length=300, insert_mean=350, insert_sd=60))
+    _assert_same(simulate_grouped_reads(300, family_size=3, read_length=151, insert_mean=120, insert_sd=30))   # read-through clips
+
+
+def test_crafted_edge_cases(handle):
+    groups = cases.crafted_groups()
+    g = GroupedReads.from_groups(groups)
+    for mr in (1, 2):
+        for ov in (True, False):
+            _assert_same(g, min_reads=mr, overlapping=ov, track_rejects=True, prefix="lib1")
+    _assert_same(g, min_reads=1, trim=True, track_rejects=True)
+    _assert_same(g, min_reads=1, max_reads=1, track_rejects=True)
+
+
+def test_fatal_errors_match_reference(handle):
+    # missing MI tag (vanilla_caller.rs:1901-1904), absent qualities (:1119-1124), over-long read name (:1795-1797)
+    c = VanillaUmiConsensusCaller("", "A", VanillaUmiConsensusOptions(min_reads=1))
+    with pytest.raises(RuntimeError, match="Missing UMI tag"):
+        c.consensus_reads([bamutil.make_record("x", "ACGT", [30] * 4)])
+    with pytest.raises(RuntimeError, match="missing base qualities"):
+        c.consensus_reads([bamutil.make_record("x", "ACGT", None, tags=[("MI", "Z", "1")])])
+    with pytest.raises(RuntimeError, match="read name"):
+        c.consensus_reads([bamutil.frag("x", "ACGT", 30, "U" * 300)])
+    assert c.consensus_reads([]).count == 0
+    c.close()
