@@ -6,4 +6,5 @@ this package is the thin Python host mirror of the reference's caller interface
 """
 from ._lib import lib, load, Options, Output, SimParams, default_options, LibraryMissing  # noqa: F401
 from .caller import (ConsensusCaller, VanillaUmiConsensusCaller, VanillaUmiConsensusOptions, ConsensusOutput,  # noqa: F401
-                     ConsensusCallingStats, RejectionReason, GroupedReads, simulate_grouped_reads, split_records)
+                     ConsensusCallingStats, RejectionReason, GroupedReads, DeviceGroupedReads, DeviceOutput,
+                     simulate_grouped_reads, split_records)

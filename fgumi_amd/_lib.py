@@ -58,6 +58,14 @@ def load():
     if not os.path.exists(SO):
         raise LibraryMissing(f"{SO} is missing: build it with `python -m fgumi_amd.build` (hipcc, gfx950). "
                              "There is no CPU fallback for the consensus path.")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64; when torch is present,
+    # let it load (and initialise) first so this library binds to the same runtime instance.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     L = C.CDLL(SO)
     VP, U8, U32, U64, I = C.c_void_p, C.c_uint8, C.c_uint32, C.c_uint64, C.c_int
     P = C.POINTER
@@ -92,6 +100,10 @@ def load():
     L.fgx_build_tables_host.restype = I
     L.fgx_host_libm_array.argtypes = [I, VP, VP, U64]
     L.fgx_host_libm_array.restype = None
+    L.fgx_set_general_only.argtypes = [VP, I]
+    L.fgx_set_general_only.restype = None
+    L.fgx_set_fast_lds_bytes.argtypes = [VP, U32]
+    L.fgx_set_fast_lds_bytes.restype = None
     _lib = L
     return L
 
@@ -110,3 +122,17 @@ def default_options(**kw):
     for k, v in kw.items():
         setattr(o, k, v)
     return o
+
+
+def hip_memcpy_d2h(dev_ptr: int, n: int) -> bytes:
+    """Copy `n` bytes from a device pointer to host (libamdhip64 hipMemcpy)."""
+    if n == 0:
+        return b""
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemcpy.restype = C.c_int
+    buf = C.create_string_buffer(n)
+    rc = hip.hipMemcpy(buf, C.c_void_p(dev_ptr), n, 2)  # hipMemcpyDeviceToHost
+    if rc != 0:
+        raise RuntimeError(f"hipMemcpy D2H failed: {rc}")
+    return buf.raw

@@ -138,6 +138,33 @@ class GroupedReads:
         return GroupedReads.from_groups([self.records(g) for g in range(g0, g1)])
 
 
+@dataclass
+class DeviceGroupedReads:
+    """A batch of MI groups resident in HBM (torch tensors own the memory; plumbing only)."""
+    blob: object
+    blob_len: int
+    rec_off: object
+    rec_len: object
+    grp_first: object
+    n_rec: int
+    n_grp: int
+
+
+@dataclass
+class DeviceOutput:
+    """`ConsensusOutput` left in HBM: `data_ptr` is a device pointer owned by the caller object."""
+    data_ptr: int
+    data_len: int
+    count: int
+    n_deferred: int
+    deferred_ptr: Optional[int]
+
+    def to_host(self) -> bytes:
+        import torch  # noqa: F401  (ensures the HIP runtime is initialised in this process)
+        from ._lib import hip_memcpy_d2h
+        return hip_memcpy_d2h(self.data_ptr, self.data_len)
+
+
 def split_records(data: bytes) -> List[bytes]:
     """Split `ConsensusOutput.data` into record bodies (without the block_size prefixes)."""
     out, p = [], 0
@@ -240,6 +267,45 @@ class _HandleCaller(ConsensusCaller):
 
     def last_batch_statistics(self) -> ConsensusCallingStats:
         return self._last_stats
+
+    def set_general_only(self, on: bool = True):
+        """Route every family through the general host-orchestrated path (default: device-resident fast
+        path, general path only for the families it defers)."""
+        lib.fgx_set_general_only(self._h, int(on))
+
+    # ---- device-resident batch (inputs and outputs stay in HBM) ---------------------------------
+    def process_batch_device(self, dg: "DeviceGroupedReads"):
+        out = Output()
+        n_def = C.c_uint32()
+        d_def = C.c_void_p()
+        rc = lib.fgx_process_batch_device(self._h, dg.blob.data_ptr(), dg.blob_len, dg.rec_off.data_ptr(), dg.rec_len.data_ptr(), dg.n_rec,
+                                          dg.grp_first.data_ptr(), dg.n_grp, C.byref(out), C.byref(n_def), C.byref(d_def))
+        if rc != 0:
+            raise RuntimeError(lib.fgx_last_error(self._h).decode())
+        self._last_stats = ConsensusCallingStats.from_array(out.stats)
+        self.last_timing = dict(kernels=out.ms_kernels)
+        return DeviceOutput(out.data, int(out.data_len), int(out.count), int(n_def.value), d_def.value)
+
+    def simulate_on_device(self, n_families, family_size=3, read_length=150, seed=42, **kw) -> "DeviceGroupedReads":
+        import torch
+        p = SimParams()
+        p.seed, p.n_families, p.read_length, p.family_size = seed, n_families, read_length, family_size
+        p.insert_mean, p.insert_sd, p.error_rate_ppm = 300, 50, 1000
+        for k, v in kw.items():
+            setattr(p, k, v)
+        bl, nr = C.c_uint64(), C.c_uint64()
+        if lib.fgx_sim_sizes(C.byref(p), C.byref(bl), C.byref(nr)) != 0:
+            raise ValueError("simulated input too large for 32-bit record indices")
+        dev = torch.device("cuda", self._opts.device if self._opts.device >= 0 else torch.cuda.current_device())
+        blob = torch.empty(max(16, bl.value), dtype=torch.uint8, device=dev)
+        rec_off = torch.empty(max(1, nr.value), dtype=torch.int64, device=dev)
+        rec_len = torch.empty(max(1, nr.value), dtype=torch.int32, device=dev)
+        grp_first = torch.empty(n_families + 1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize(dev)
+        rc = lib.fgx_sim_generate_device(self._h, C.byref(p), blob.data_ptr(), rec_off.data_ptr(), rec_len.data_ptr(), grp_first.data_ptr())
+        if rc != 0:
+            raise RuntimeError(lib.fgx_last_error(self._h).decode())
+        return DeviceGroupedReads(blob, bl.value, rec_off, rec_len, grp_first, nr.value, n_families)
 
     # ---- the trait -----------------------------------------------------------------------------
     def consensus_reads(self, records: Sequence[bytes]) -> ConsensusOutput:

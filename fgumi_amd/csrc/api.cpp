@@ -5,12 +5,15 @@
 #include <cstring>
 #include <string>
 #include "engine.h"
+#include "fastpath.h"
 #include "host_common.h"
 #include "simgen.h"
 
 using namespace fgx;
 
 static thread_local std::string g_global_err;
+
+struct FastState { fgx::FastPath fp; std::vector<uint8_t> spliced; };
 
 namespace fgx {
 
@@ -139,12 +142,84 @@ void fgx_destroy(fgx_caller* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   for (DevBuf* b : {&c->d_tables, &c->d_umi_tables, &c->d_stage, &c->d_reads, &c->d_jobs, &c->d_tiles, &c->d_ob, &c->d_oq, &c->d_od,
-                    &c->d_oe, &c->d_scratch_a, &c->d_scratch_b})
+                    &c->d_oe, &c->d_scratch_a, &c->d_scratch_b, &c->d_in_blob, &c->d_in_off, &c->d_in_len, &c->d_in_grp})
     b->free_();
+  if (c->fast) { c->fast->fp.release(); delete c->fast; }
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
+}
+
+// Host-input entry: upload once, run the device-resident pipeline, bring the records back, and send
+// only the families the fast path deferred through the general path, splicing both in group order.
+static int simplex_process_hybrid(fgx_caller* c, const uint8_t* records, uint64_t records_len, const uint64_t* rec_off,
+                                  const uint32_t* rec_len, uint32_t n_rec, const uint32_t* grp_first, uint32_t n_grp, fgx_output* out) {
+  using clk = std::chrono::steady_clock;
+  auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  if (c->opt.track_rejects || n_grp == 0) return simplex_process_general(c, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
+  if (!c->fast) c->fast = new FastState();
+  auto t0 = clk::now();
+  hip_check(hipSetDevice(c->device), "hipSetDevice");
+  c->d_in_blob.reserve(records_len + 16);
+  c->d_in_off.reserve((size_t)n_rec * 8 + 8);
+  c->d_in_len.reserve((size_t)n_rec * 4 + 4);
+  c->d_in_grp.reserve((size_t)(n_grp + 1) * 4);
+  hip_check(hipMemcpyAsync(c->d_in_blob.p, records, records_len, hipMemcpyHostToDevice, c->stream), "H2D blob");
+  hip_check(hipMemcpyAsync(c->d_in_off.p, rec_off, (size_t)n_rec * 8, hipMemcpyHostToDevice, c->stream), "H2D rec_off");
+  hip_check(hipMemcpyAsync(c->d_in_len.p, rec_len, (size_t)n_rec * 4, hipMemcpyHostToDevice, c->stream), "H2D rec_len");
+  hip_check(hipMemcpyAsync(c->d_in_grp.p, grp_first, (size_t)(n_grp + 1) * 4, hipMemcpyHostToDevice, c->stream), "H2D grp_first");
+  hip_check(hipStreamSynchronize(c->stream), "sync");
+  auto t1 = clk::now();
+  FastResult fr;
+  c->fast->fp.run(c, c->d_in_blob.as<uint8_t>(), records_len, c->d_in_off.as<uint64_t>(), c->d_in_len.as<uint32_t>(), n_rec,
+                  c->d_in_grp.as<uint32_t>(), n_grp, &fr);
+  auto t2 = clk::now();
+  std::vector<uint8_t>& fast_out = c->fast->spliced;
+  fast_out.resize(fr.out_len);
+  if (fr.out_len) hip_check(hipMemcpy(fast_out.data(), fr.d_out, fr.out_len, hipMemcpyDeviceToHost), "D2H out");
+  auto t3 = clk::now();
+  memset(out, 0, sizeof(*out));
+  if (fr.n_deferred == 0) {
+    c->out_data.swap(fast_out);
+    out->data = c->out_data.data(); out->data_len = c->out_data.size(); out->count = fr.count;
+    for (int i = 0; i < FGX_STATS_LEN; i++) out->stats[i] = fr.stats[i];
+    out->ms_h2d = ms(t0, t1); out->ms_kernels = fr.ms_kernels; out->ms_d2h = ms(t2, t3);
+    return 0;
+  }
+  // deferred families → general path, then splice in group order
+  std::vector<uint32_t> def(fr.n_deferred);
+  hip_check(hipMemcpy(def.data(), fr.d_deferred, (size_t)fr.n_deferred * 4, hipMemcpyDeviceToHost), "D2H deferred");
+  std::sort(def.begin(), def.end());
+  std::vector<uint64_t> slot_off((size_t)3 * n_grp);
+  hip_check(hipMemcpy(slot_off.data(), fr.d_out_off, slot_off.size() * 8, hipMemcpyDeviceToHost), "D2H offsets");
+  std::vector<uint64_t> d_off;
+  std::vector<uint32_t> d_len, d_grp(1, 0);
+  for (uint32_t g : def) {
+    for (uint32_t r = grp_first[g]; r < grp_first[g + 1]; r++) { d_off.push_back(rec_off[r]); d_len.push_back(rec_len[r]); }
+    d_grp.push_back((uint32_t)d_off.size());
+  }
+  fgx_output gen;
+  int rc = simplex_process_general(c, records, d_off.data(), d_len.data(), (uint32_t)d_off.size(), d_grp.data(), (uint32_t)def.size(), &gen);
+  if (rc != 0) return rc;
+  std::vector<uint8_t> merged;
+  merged.reserve(fast_out.size() + c->out_data.size());
+  uint64_t fpos = 0;   // fast output is contiguous in group order; deferred groups contributed nothing to it
+  uint64_t gprev = 0;
+  for (size_t k = 0; k < def.size(); k++) {
+    uint64_t upto = slot_off[(size_t)3 * def[k]];          // fast bytes of all groups before def[k]
+    merged.insert(merged.end(), fast_out.begin() + fpos, fast_out.begin() + upto);
+    fpos = upto;
+    merged.insert(merged.end(), c->out_data.begin() + gprev, c->out_data.begin() + c->grp_out_end[k]);
+    gprev = c->grp_out_end[k];
+  }
+  merged.insert(merged.end(), fast_out.begin() + fpos, fast_out.end());
+  c->out_data.swap(merged);
+  out->data = c->out_data.data(); out->data_len = c->out_data.size(); out->count = fr.count + gen.count;
+  for (int i = 0; i < FGX_STATS_LEN; i++) out->stats[i] = fr.stats[i] + gen.stats[i];
+  out->ms_h2d = ms(t0, t1); out->ms_kernels = fr.ms_kernels + gen.ms_kernels; out->ms_d2h = ms(t2, t3);
+  out->ms_host_prep = gen.ms_host_prep; out->ms_emit = gen.ms_emit;
+  return 0;
 }
 
 int fgx_process_batch(fgx_caller* c, const uint8_t* records, uint64_t records_len, const uint64_t* rec_off, const uint32_t* rec_len,
@@ -157,7 +232,9 @@ int fgx_process_batch(fgx_caller* c, const uint8_t* records, uint64_t records_le
     }
     if (n_grp && grp_first[n_grp] > n_rec) { c->err = "fgx_process_batch: group boundaries exceed n_rec"; return 1; }
     switch (c->opt.caller_kind) {
-      case FGX_CALLER_SIMPLEX: return simplex_process_general(c, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
+      case FGX_CALLER_SIMPLEX:
+        if (c->general_only) return simplex_process_general(c, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
+        return simplex_process_hybrid(c, records, records_len, rec_off, rec_len, n_rec, grp_first, n_grp, out);
       default: c->err = "fgx_process_batch: caller kind not implemented"; return 1;
     }
   } catch (const std::exception& ex) {
@@ -166,11 +243,33 @@ int fgx_process_batch(fgx_caller* c, const uint8_t* records, uint64_t records_le
   }
 }
 
-int fgx_process_batch_device(fgx_caller* c, const void*, uint64_t, const void*, const void*, uint32_t, const void*, uint32_t, fgx_output*,
-                             uint32_t*, const void**) {
-  if (c) c->err = "fgx_process_batch_device: not implemented yet";
-  return 1;
+int fgx_process_batch_device(fgx_caller* c, const void* d_records, uint64_t records_len, const void* d_rec_off, const void* d_rec_len,
+                             uint32_t n_rec, const void* d_grp_first, uint32_t n_grp, fgx_output* out, uint32_t* n_deferred,
+                             const void** d_deferred_groups) {
+  if (!c || !out) return 1;
+  c->err.clear();
+  try {
+    if (c->opt.caller_kind != FGX_CALLER_SIMPLEX) { c->err = "fgx_process_batch_device: caller kind not implemented"; return 1; }
+    if (c->opt.track_rejects) { c->err = "fgx_process_batch_device: --rejects needs the host path (fgx_process_batch)"; return 1; }
+    if (!c->fast) c->fast = new FastState();
+    hip_check(hipSetDevice(c->device), "hipSetDevice");
+    FastResult fr;
+    c->fast->fp.run(c, (const uint8_t*)d_records, records_len, (const uint64_t*)d_rec_off, (const uint32_t*)d_rec_len, n_rec,
+                    (const uint32_t*)d_grp_first, n_grp, &fr);
+    memset(out, 0, sizeof(*out));
+    out->data = fr.d_out; out->data_len = fr.out_len; out->count = fr.count;
+    for (int i = 0; i < FGX_STATS_LEN; i++) out->stats[i] = fr.stats[i];
+    out->ms_kernels = fr.ms_kernels;
+    if (n_deferred) *n_deferred = fr.n_deferred;
+    if (d_deferred_groups) *d_deferred_groups = fr.d_deferred;
+    return 0;
+  } catch (const std::exception& ex) { c->err = ex.what(); return 3; }
 }
+
+// 1: route everything through the general host path (parity tests of that path); 0: hybrid (default)
+void fgx_set_general_only(fgx_caller* c, int on) { if (c) c->general_only = on != 0; }
+// dynamic LDS bytes the family kernel gets for its base/qual tiles (default 16 KiB)
+void fgx_set_fast_lds_bytes(fgx_caller* c, uint32_t bytes) { if (c) { if (!c->fast) c->fast = new FastState(); c->fast->fp.lds_tile_bytes = bytes; } }
 
 int fgx_call_columns(fgx_caller* c, const uint8_t* bases, const uint8_t* quals, uint32_t n_cols, uint32_t depth, uint8_t* out_base,
                      uint8_t* out_qual, uint32_t* out_depth, uint32_t* out_errors) {

@@ -243,5 +243,50 @@ BAM_HD int parse_mc(const uint8_t* s, uint32_t n, uint32_t* ops, uint32_t cap) {
   return (int)cnt;
 }
 
+// is_fr_pair_raw (overlap.rs:21-69); `ops` = this record's CIGAR ops
+BAM_HD bool is_fr_pair(const Rec& v, const uint32_t* ops, uint32_t n_ops) {
+  uint16_t f = v.flags();
+  if (!(f & F_PAIRED) || (f & F_UNMAPPED) || (f & F_MATE_UNMAPPED)) return false;
+  if (v.ref_id() != v.mate_ref_id()) return false;
+  bool rev = (f & F_REVERSE) != 0, mrev = (f & F_MATE_REVERSE) != 0;
+  if (rev == mrev) return false;
+  uint32_t astart = (uint32_t)v.pos() + 1u, mstart = (uint32_t)v.mate_pos() + 1u;
+  int32_t p5, n5;
+  if (rev) {
+    int32_t rl = ref_len_checked0(ops, n_ops);
+    int32_t ext = rl - 1 > 0 ? rl - 1 : 0;
+    p5 = (int32_t)mstart;
+    n5 = (int32_t)(astart + (uint32_t)ext);
+  } else {
+    p5 = (int32_t)astart;
+    n5 = (int32_t)(astart + (uint32_t)v.tlen());
+  }
+  return p5 < n5;
+}
+
+// num_bases_extending_past_mate_raw (overlap.rs:181-207) given the MC value (mc, mc_len; mc == nullptr
+// when the tag is absent).  `scratch` holds the parsed mate ops; *overflow is set when it is too small.
+BAM_HD uint64_t mate_clip(const Rec& v, const uint32_t* ops, uint32_t n_ops, const uint8_t* mc, uint32_t mc_len, uint32_t* scratch,
+                          uint32_t cap, bool* overflow) {
+  if (!mc) return 0;
+  int n = parse_mc(mc, mc_len, scratch, cap);
+  if (n < 0) { *overflow = true; return 0; }
+  if (n == 0) return 0;
+  int32_t mate_ref_len = sat_ref_len(scratch, (uint32_t)n);
+  uint16_t f = v.flags();
+  if (!(f & F_PAIRED) || (f & F_UNMAPPED) || (f & F_MATE_UNMAPPED)) return 0;
+  if (v.ref_id() != v.mate_ref_id()) return 0;
+  bool rev = (f & F_REVERSE) != 0, mrev = (f & F_MATE_REVERSE) != 0;
+  if (rev == mrev) return 0;
+  int32_t this_pos1 = (int32_t)((uint32_t)v.pos() + 1u), mate_pos1 = (int32_t)((uint32_t)v.mate_pos() + 1u);
+  if (rev) { if (!is_fr_pair(v, ops, n_ops)) return 0; }
+  else {
+    int32_t ext = mate_ref_len - 1 > 0 ? mate_ref_len - 1 : 0;
+    int32_t mate_end = sat_add(mate_pos1, ext);
+    if (!(this_pos1 < mate_end)) return 0;
+  }
+  return past_mate_ops(rev, this_pos1, ops, n_ops, mate_pos1, scratch, (uint32_t)n);
+}
+
 }  // namespace bam
 }  // namespace fgx

@@ -88,6 +88,7 @@ struct ColumnBatch {
 }  // namespace fgx
 
 // The caller object behind the C ABI.
+struct FastState;
 struct fgx_caller {
   fgx_options opt;
   std::string prefix, rg;
@@ -102,6 +103,10 @@ struct fgx_caller {
   fgx::ColumnBatch batch;
   // outputs of the last call
   std::vector<uint8_t> out_data, out_rejects;
+  std::vector<uint64_t> grp_out_end;      // general path: cumulative out_data size after each group
+  bool general_only = false;
+  struct FastState* fast = nullptr;        // device-resident pipeline state (fastpath.hip)
+  fgx::DevBuf d_in_blob, d_in_off, d_in_len, d_in_grp;   // host-input staging for fgx_process_batch
 
   // Runs the staged column jobs of `b` on the device and fills b.ob/oq/od/oe. Returns kernel ms.
   double run_columns(fgx::ColumnBatch& b, fgx::ColParams prm);

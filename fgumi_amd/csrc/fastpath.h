@@ -1,0 +1,63 @@
+// fastpath.h — declarations for the device-resident simplex pipeline (fastpath.hip).
+#pragma once
+#include "engine.h"
+
+namespace fgx {
+
+constexpr int FAST_RX_CAP = 48;   // longest RX value handled on the device (longer → general path)
+
+struct EndDesc {            // one consensus read (a family end), written by k_family, consumed by k_emit
+  uint64_t col_off;         // first column in the per-position arrays
+  uint32_t cons_len;
+  uint32_t first_rec;       // first record of the MI group (MI value → read name + MI tag)
+  uint32_t first_kept_rec;  // first retained source read (cell-barcode tag)
+  uint32_t rec_size;        // BAM block_size of the record to emit
+  float ce;
+  uint16_t maxd, mind;
+  uint16_t mi_off, cb_off;
+  uint8_t mi_len, cb_len, rx_len, type;   // type: 0 fragment, 1 R1, 2 R2
+  uint8_t has_cb, has_rx, valid, _pad;
+  char rx[FAST_RX_CAP];
+};
+
+struct FastParams {
+  const uint8_t* blob; const uint64_t* rec_off; const uint32_t* rec_len; const uint32_t* grp_first;
+  uint32_t g0;
+  const DeviceTables* T; const DeviceTables* TU;
+  uint32_t min_reads; int64_t max_reads;
+  uint8_t min_input_bq, min_cons_bq, trim, overlap, per_base_tags, track_rejects;
+  char tag0, tag1, cell0, cell1;
+  uint32_t prefix_len, rg_len;
+  EndDesc* ends; uint64_t* rec_sizes;
+  uint8_t* col_code; uint8_t* col_qual; uint16_t* col_depth; uint16_t* col_err;
+  unsigned long long* col_cursor; uint64_t col_capacity;
+  unsigned long long* stats;
+  uint32_t* deferred; uint32_t* n_deferred;
+  uint32_t lds_tile_bytes;
+};
+
+struct EmitParams {
+  const uint8_t* blob; const uint64_t* rec_off; const EndDesc* ends; const uint64_t* out_off; uint8_t* out;
+  uint64_t out_base; uint32_t slot0, slot_end;
+  const uint8_t* col_code; const uint8_t* col_qual; const uint16_t* col_depth; const uint16_t* col_err;
+  const char* prefix; uint32_t prefix_len; const char* rg; uint32_t rg_len;
+  uint8_t per_base_tags; char tag0, tag1, cell0, cell1;
+};
+
+struct FastResult {
+  const uint8_t* d_out; uint64_t out_len; uint64_t count;
+  uint64_t stats[FGX_STATS_LEN];
+  uint32_t n_deferred; const uint32_t* d_deferred;
+  const uint64_t* d_out_off;     // byte offset of each of the 3*n_grp slots in d_out
+  double ms_kernels; uint64_t cols_used;
+};
+
+struct FastPath {
+  DevBuf d_ends, d_sizes, d_offsets, d_code, d_qual, d_depth, d_err, d_misc, d_deferred, d_out, d_scan_tmp, d_strings;
+  uint32_t lds_tile_bytes = 16384;
+  int run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const uint64_t* d_rec_off, const uint32_t* d_rec_len, uint32_t n_rec,
+          const uint32_t* d_grp_first, uint32_t n_grp, FastResult* res);
+  void release();
+};
+
+}  // namespace fgx

@@ -1,0 +1,779 @@
+// fastpath.hip — the device-resident simplex pipeline: raw BAM records in HBM → consensus BAM
+// records in HBM, no host work per family.
+//
+//   k_family  (pass A)  one workgroup per MI group (family).  Lanes parse the record headers and
+//                       aux tags, stage every read's 4-bit bases + quals into LDS (unpacked to one
+//                       byte per base), apply the R1/R2 overlapping-bases pre-correction in LDS,
+//                       compute each read's oriented / masked / mate-clipped length, run the
+//                       family gates (min-reads at every shrink point, R1/R2 orphan rule), then call
+//                       every consensus column (one lane per column, reads walked serially in file
+//                       order — summation order is observable) and the per-character UMI consensus.
+//                       Writes the four per-position arrays + one descriptor per consensus read.
+//   hipcub scan         exclusive sum of record sizes → byte offsets (output order = input order).
+//   k_emit    (pass B)  one wavefront per consensus read: assembles the unmapped BAM record
+//                       (header, name `<prefix>:<MI>`, 4-bit sequence, quals, tags RG cD cM cE [cd ce]
+//                       MI [CB] RX) at its offset.
+//
+// Reference semantics restated (bit-exact contract), all paths under crates/fgumi-consensus/src/:
+//   src/lib/commands/simplex.rs:669-701 (group skip, overlap pre-step, consensus_reads)
+//   overlapping.rs:236-336, 627-684 ; vanilla_caller.rs:862-877, 1080-1190, 1304-1422, 1454-1646,
+//   1652-1755, 1767-1881 ; simple_umi.rs:46-117 ; raw-bam/src/overlap.rs:181-357 ; builder.rs:122-301
+//
+// Families the fast path does not decide are DEFERRED untouched to the general host path
+// (simplex_host.cpp): any read with a CIGAR other than one M/=/X op spanning the read, unmapped
+// reads, --max-reads that bites, malformed records (so that the general path raises the
+// reference's fatal error), more than FAST_MAX_READS reads or more LDS than the launch provides.
+#include <hipcub/hipcub.hpp>
+#include "bamrec.h"
+#include "engine.h"
+#include "fastpath.h"
+
+namespace fgx {
+
+using bam::rd16;
+using bam::rd32;
+
+namespace {
+
+constexpr int NT = 256;                 // threads per family workgroup
+constexpr int FAST_MAX_READS = 128;     // per-read LDS tables
+constexpr int MAX_MC_OPS = 8;
+
+struct ReadInfo {          // LDS, one per record of the family
+  uint64_t goff;           // record body offset in the blob
+  int32_t pos, ref_id;
+  uint32_t name_hash;
+  uint32_t row;            // row offset (bytes) of this read's bases / quals in the LDS tiles
+  uint16_t l_seq, flags, seq_off, name_len;
+  uint16_t final_len, trim_to, clip, mi_off;
+  uint16_t rx_off, cb_off;
+  int16_t mate;            // index of the R2 paired with this R1 (only set on the R1), else -1
+  uint8_t mi_len, rx_len, cb_len, end;   // end: 0 fragment, 1 R1, 2 R2, 255 = not a candidate
+  uint8_t has_mi, has_rx, has_cb, all_ff;
+  uint8_t excluded, zero_len, _p0, _p1;
+};
+
+struct Shared {
+  ReadInfo ri[FAST_MAX_READS];
+  uint16_t members[FAST_MAX_READS];     // kept reads, grouped by end, file order inside an end
+  uint32_t stats[FGX_STATS_LEN];
+  uint32_t defer;
+  uint32_t n_ends;
+  uint32_t end_type[3], end_first[3], end_cnt[3], end_len[3], end_coloff[3];
+  uint32_t end_maxd[3], end_mind[3], end_sumd[3], end_sume[3];
+  uint32_t end_rx_cnt[3], end_rx_len[3], end_rx_first[3];
+  char end_rx[3][FAST_RX_CAP];
+  uint32_t rx_bad;
+  uint64_t col_base;
+  uint32_t tile_bytes;
+};
+
+__device__ __forceinline__ void defer(Shared& S) { S.defer = 1; }
+
+__device__ __forceinline__ uint32_t int_tag_width(uint32_t v) { return v <= 255 ? 1 : 2; }   // depth <= 32767: c / C / S
+
+// Oriented, mask-aware view of read `r` at consensus position p.  Returns the 4-bit code (15 = N, also
+// for masked bases) and the quality the reference's SourceRead would hold there.
+__device__ __forceinline__ void oriented(const Shared& S, const uint8_t* lb, const uint8_t* lq, const ReadInfo& R, uint32_t p,
+                                         uint32_t min_bq, uint8_t* code, uint8_t* qual) {
+  bool rev = (R.flags & bam::F_REVERSE) != 0;
+  uint32_t idx = rev ? (uint32_t)R.l_seq - 1 - p : p;
+  uint8_t c = lb[R.row + idx];
+  uint8_t q = lq[R.row + idx];
+  if (rev) c = bam::code_complement(c);
+  if (p < R.trim_to && q < min_bq) { c = 15; q = FGX_MIN_PHRED; }
+  *code = c;
+  *qual = q;
+}
+
+__global__ __launch_bounds__(NT) void k_family(FastParams P) {
+  extern __shared__ __align__(16) uint8_t dyn[];
+  __shared__ Shared S;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t g = P.g0 + blockIdx.x;
+  const uint32_t r0 = P.grp_first[g], r1 = P.grp_first[g + 1];
+  const uint32_t n = r1 - r0;
+  const uint32_t slot0 = 3 * g;
+
+  if (tid < FGX_STATS_LEN) S.stats[tid] = 0;
+  if (tid == 0) { S.defer = 0; S.n_ends = 0; S.rx_bad = 0; }
+  if (tid < 3) { P.ends[slot0 + tid].valid = 0; P.rec_sizes[slot0 + tid] = 0; }
+  __syncthreads();
+
+  // ---- group-level short circuit (simplex.rs:673-683) ---------------------------------------------
+  if (n < P.min_reads) {
+    if (tid == 0) {
+      atomicAdd(&P.stats[0], (unsigned long long)n);
+      atomicAdd(&P.stats[2], (unsigned long long)n);
+      atomicAdd(&P.stats[3 + FGX_REJ_INSUFFICIENT_READS], (unsigned long long)n);
+    }
+    return;
+  }
+  if (n > FAST_MAX_READS) {
+    if (tid == 0) { uint32_t k = atomicAdd(P.n_deferred, 1u); P.deferred[k] = g; }
+    return;
+  }
+
+  // ---- 1. parse one record per lane -----------------------------------------------------------------
+  if (tid < n) {
+    ReadInfo R;
+    memset(&R, 0, sizeof(R));
+    R.mate = -1;
+    R.end = 255;
+    uint64_t off = P.rec_off[r0 + tid];
+    uint32_t len = P.rec_len[r0 + tid];
+    const uint8_t* p = P.blob + off;
+    R.goff = off;
+    bool bad = len < 32;
+    if (!bad) {
+      uint32_t l_name = p[8], n_cig = rd16(p + 12), l_seq = rd32(p + 16);
+      uint16_t flag = rd16(p + 14);
+      uint64_t seq_off = 32ull + l_name + 4ull * n_cig;
+      uint64_t qual_off = seq_off + ((uint64_t)l_seq + 1) / 2;
+      uint64_t aux_off = qual_off + l_seq;
+      if (aux_off > len || l_seq > 65535 || l_name == 0) bad = true;
+      else {
+        R.flags = flag; R.l_seq = (uint16_t)l_seq; R.seq_off = (uint16_t)seq_off; R.name_len = (uint16_t)(l_name - 1);
+        R.pos = (int32_t)rd32(p + 4); R.ref_id = (int32_t)rd32(p);
+        R.excluded = (flag & (bam::F_SECONDARY | bam::F_SUPPLEMENTARY)) ? 1 : 0;
+        uint32_t op = 0;
+        if (!R.excluded) {
+          if ((flag & bam::F_UNMAPPED) || n_cig != 1 || l_seq == 0 || R.pos < 0) bad = true;
+          else {
+            op = rd32(p + 32 + l_name);
+            uint32_t ty = op & 15;
+            if (!(ty == 0 || ty == 7 || ty == 8) || (op >> 4) != l_seq) bad = true;
+          }
+        }
+        // aux walk: first occurrence of MC / <tag> / RX / <cell tag>; malformed aux stops the walk (tags.rs:13-34)
+        const uint8_t* aux = p + aux_off;
+        uint32_t an = (uint32_t)(len - aux_off);
+        uint32_t q = 0;
+        int mc_off = -1; uint32_t mc_len = 0;
+        bool seen_mc = false, seen_mi = false, seen_rx = false, seen_cb = false;
+        while (q + 3 <= an) {
+          uint8_t t0 = aux[q], t1 = aux[q + 1], vt = aux[q + 2];
+          uint32_t size = 0;
+          int fixed = bam::tag_fixed_size(vt);
+          int64_t zend = -1;
+          if (fixed > 0) size = (uint32_t)fixed;
+          else if (vt == 'Z' || vt == 'H') {
+            zend = bam::find_nul(aux + q + 3, an - (q + 3));
+            if (zend < 0) {   // unterminated: a matching key reads as None, everything after is unreachable
+              break;
+            }
+            size = (uint32_t)zend + 1;
+          } else if (vt == 'B') {
+            if (an - (q + 3) < 5) break;
+            int es = bam::tag_fixed_size(aux[q + 3]);
+            if (es == 0) {
+              // value size unknown: a key match at this position is still found first (type != Z → None)
+              if (t0 == 'M' && t1 == 'C') seen_mc = true;
+              if (t0 == (uint8_t)P.tag0 && t1 == (uint8_t)P.tag1) seen_mi = true;
+              if (t0 == 'R' && t1 == 'X') seen_rx = true;
+              if (t0 == (uint8_t)P.cell0 && t1 == (uint8_t)P.cell1) seen_cb = true;
+              break;
+            }
+            uint64_t s = 5ull + (uint64_t)rd32(aux + q + 4) * (uint64_t)es;
+            if (s > 0xFFFFFFFFull) break;
+            size = (uint32_t)s;
+          } else {
+            if (t0 == 'M' && t1 == 'C') seen_mc = true;
+            if (t0 == (uint8_t)P.tag0 && t1 == (uint8_t)P.tag1) seen_mi = true;
+            if (t0 == 'R' && t1 == 'X') seen_rx = true;
+            if (t0 == (uint8_t)P.cell0 && t1 == (uint8_t)P.cell1) seen_cb = true;
+            break;
+          }
+          bool isz = (vt == 'Z');
+          uint32_t voff = (uint32_t)aux_off + q + 3;
+          if (!seen_mc && t0 == 'M' && t1 == 'C') { seen_mc = true; if (isz) { mc_off = (int)voff; mc_len = (uint32_t)zend; } }
+          if (!seen_mi && t0 == (uint8_t)P.tag0 && t1 == (uint8_t)P.tag1) {
+            seen_mi = true;
+            if (isz) { if (zend > 255 || voff > 65535) bad = true; else { R.has_mi = 1; R.mi_off = (uint16_t)voff; R.mi_len = (uint8_t)zend; } }
+          }
+          if (!seen_rx && t0 == 'R' && t1 == 'X') {
+            seen_rx = true;
+            if (isz) { if (zend > 255 || voff > 65535) bad = true; else { R.has_rx = 1; R.rx_off = (uint16_t)voff; R.rx_len = (uint8_t)zend; } }
+          }
+          if (!seen_cb && P.cell0 && t0 == (uint8_t)P.cell0 && t1 == (uint8_t)P.cell1) {
+            seen_cb = true;
+            if (isz) { if (zend > 255 || voff > 65535) bad = true; else { R.has_cb = 1; R.cb_off = (uint16_t)voff; R.cb_len = (uint8_t)zend; } }
+          }
+          uint64_t nq = (uint64_t)q + 3 + size;
+          if (nq > an) break;
+          q = (uint32_t)nq;
+        }
+        if (!bad && !R.excluded) {
+          // mate-overlap clip (raw-bam/overlap.rs:181-207)
+          uint32_t mops[MAX_MC_OPS];
+          bool overflow = false;
+          bam::Rec v{p, len};
+          uint64_t clip = bam::mate_clip(v, &op, 1, mc_off >= 0 ? p + mc_off : nullptr, mc_len, mops, MAX_MC_OPS, &overflow);
+          if (overflow) bad = true;
+          R.clip = (uint16_t)(clip > 65535 ? 65535 : clip);
+          // FNV-1a over the read name, for mate pairing
+          uint32_t h = 2166136261u;
+          for (uint32_t i = 0; i < R.name_len; i++) { h ^= p[32 + i]; h *= 16777619u; }
+          R.name_hash = h;
+        }
+      }
+    }
+    if (bad) defer(S);
+    S.ri[tid] = R;
+  }
+  __syncthreads();
+  // UMI = MI tag of the first record (vanilla_caller.rs:1897-1908); missing → fatal in the reference
+  if (tid == 0 && !S.defer) {
+    if (!S.ri[0].has_mi) defer(S);
+    else if ((uint32_t)P.prefix_len + 1 + S.ri[0].mi_len >= 255) defer(S);   // read name too long → fatal
+    // LDS tile rows
+    uint32_t row = 0;
+    for (uint32_t i = 0; i < n; i++) { S.ri[i].row = row; if (!S.ri[i].excluded) row += ((uint32_t)S.ri[i].l_seq + 3) & ~3u; }
+    S.tile_bytes = row;
+    if (2ull * row > P.lds_tile_bytes) defer(S);
+  }
+  __syncthreads();
+  if (S.defer) {
+    if (tid == 0) { uint32_t k = atomicAdd(P.n_deferred, 1u); P.deferred[k] = g; }
+    return;
+  }
+  uint8_t* lb = dyn;
+  uint8_t* lq = dyn + S.tile_bytes;
+
+  // ---- 2. stage bases (unpacked 4-bit codes) and quals into LDS -------------------------------------
+  for (uint32_t r = 0; r < n; r++) {
+    const ReadInfo& R = S.ri[r];
+    if (R.excluded) continue;
+    const uint8_t* p = P.blob + R.goff;
+    const uint8_t* sq = p + R.seq_off;
+    const uint8_t* ql = sq + ((uint32_t)R.l_seq + 1) / 2;
+    for (uint32_t i = tid; i < R.l_seq; i += NT) {
+      uint8_t b = sq[i >> 1];
+      lb[R.row + i] = (i & 1) ? (b & 0xF) : (b >> 4);
+      lq[R.row + i] = ql[i];
+    }
+  }
+  // absent qualities (every byte 0xFF) are a fatal input error in the reference (:1119-1124) → general path
+  __syncthreads();
+  if (tid < n && !S.ri[tid].excluded) {
+    // serial re-check only when the first qual is 0xFF (cheap early-out; the all-0xFF case is a fatal error)
+    const ReadInfo& R = S.ri[tid];
+    if (lq[R.row] == 0xFF) {
+      bool all = true;
+      for (uint32_t i = 0; i < R.l_seq; i++) if (lq[R.row + i] != 0xFF) { all = false; break; }
+      if (all) defer(S);
+    }
+  }
+  __syncthreads();
+  if (S.defer) {
+    if (tid == 0) { uint32_t k = atomicAdd(P.n_deferred, 1u); P.deferred[k] = g; }
+    return;
+  }
+
+  // ---- 3. overlapping-bases pre-correction (overlapping.rs:236-336, 627-684) ------------------------
+  if (P.overlap) {
+    // pair map semantics: for each name the LAST primary record with FIRST set and the LAST with (not FIRST and) LAST set
+    if (tid < n) {
+      ReadInfo& R = S.ri[tid];
+      bool is_r1 = !R.excluded && (R.flags & bam::F_FIRST);
+      if (is_r1) {
+        const uint8_t* nm = P.blob + R.goff + 32;
+        auto same_name = [&](const ReadInfo& O) {
+          if (O.name_hash != R.name_hash || O.name_len != R.name_len) return false;
+          const uint8_t* on = P.blob + O.goff + 32;
+          for (uint32_t i = 0; i < R.name_len; i++) if (on[i] != nm[i]) return false;
+          return true;
+        };
+        bool last_r1 = true;
+        for (uint32_t u = tid + 1; u < n && last_r1; u++) {
+          const ReadInfo& O = S.ri[u];
+          if (!O.excluded && (O.flags & bam::F_FIRST) && same_name(O)) last_r1 = false;
+        }
+        if (last_r1) {
+          int m = -1;
+          for (uint32_t u = 0; u < n; u++) {
+            const ReadInfo& O = S.ri[u];
+            if (!O.excluded && !(O.flags & bam::F_FIRST) && (O.flags & bam::F_LAST) && same_name(O)) m = (int)u;
+          }
+          R.mate = (int16_t)m;
+        }
+      }
+    }
+    __syncthreads();
+    uint32_t ov_bases = 0, ov_agree = 0, ov_dis = 0, ov_corr = 0;
+    const uint32_t wave = tid >> 6, lane = tid & 63;
+    for (uint32_t a = wave; a < n; a += NT / 64) {
+      const ReadInfo& A = S.ri[a];
+      if (A.mate < 0) continue;
+      const ReadInfo& B = S.ri[A.mate];
+      if (A.ref_id != B.ref_id) continue;
+      // single M/=/X op spanning the read: alignment = [pos+1, pos+l_seq], query offset = ref - (pos+1)
+      int64_t s1 = (int64_t)A.pos + 1, e1 = (int64_t)A.pos + A.l_seq, s2 = (int64_t)B.pos + 1, e2 = (int64_t)B.pos + B.l_seq;
+      int64_t lo = s1 > s2 ? s1 : s2, hi = e1 < e2 ? e1 : e2;
+      for (int64_t x = lo + lane; x <= hi; x += 64) {
+        uint32_t i1 = (uint32_t)(x - s1), i2 = (uint32_t)(x - s2);
+        uint8_t c1 = lb[A.row + i1], c2 = lb[B.row + i2];
+        if (c1 == 15 || c2 == 15) continue;
+        ov_bases++;
+        uint8_t qa = lq[A.row + i1], qb = lq[B.row + i2];
+        if (c1 == c2) {
+          ov_agree++;
+          uint32_t s = (uint32_t)qa + qb;
+          uint8_t nq = (uint8_t)(s < 93 ? s : 93);
+          lq[A.row + i1] = nq; lq[B.row + i2] = nq;
+          if (nq != qa || nq != qb) ov_corr++;
+        } else {
+          ov_dis++;
+          uint8_t cb, cq;
+          if (qa == qb) { cb = 15; cq = FGX_MIN_PHRED; }
+          else if (qa > qb) { cb = c1; cq = (uint8_t)(qa - qb); if (cq < FGX_MIN_PHRED) cq = FGX_MIN_PHRED; }
+          else { cb = c2; cq = (uint8_t)(qb - qa); if (cq < FGX_MIN_PHRED) cq = FGX_MIN_PHRED; }
+          lb[A.row + i1] = cb; lb[B.row + i2] = cb; lq[A.row + i1] = cq; lq[B.row + i2] = cq;
+          ov_corr += 2;
+        }
+      }
+    }
+    if (ov_bases) atomicAdd(&S.stats[24], ov_bases);
+    if (ov_agree) atomicAdd(&S.stats[25], ov_agree);
+    if (ov_dis) atomicAdd(&S.stats[26], ov_dis);
+    if (ov_corr) atomicAdd(&S.stats[27], ov_corr);
+    __syncthreads();
+  }
+
+  // ---- 4. per-read source-read geometry (vanilla_caller.rs:1129-1160) ---------------------------------
+  if (tid < n && !S.ri[tid].excluded) {
+    ReadInfo& R = S.ri[tid];
+    bool rev = (R.flags & bam::F_REVERSE) != 0;
+    uint32_t L = R.l_seq;
+    uint32_t trim_to = L;
+    if (P.trim) {   // find_quality_trim_point on the oriented qualities (:992-1016)
+      uint32_t tq = P.min_input_bq;
+      if (tq < 1 || L == 0) trim_to = 0;
+      else {
+        int32_t score = 0, max_score = 0;
+        uint32_t point = L;
+        for (uint32_t i = L; i-- > 0;) {
+          uint32_t idx = rev ? L - 1 - i : i;
+          score += (int32_t)tq - (int32_t)lq[R.row + idx];
+          if (score < 0) break;
+          if (score > max_score) { max_score = score; point = i; }
+        }
+        trim_to = point;
+      }
+    }
+    R.trim_to = (uint16_t)trim_to;
+    uint32_t clip_pos = L > R.clip ? L - R.clip : 0;
+    uint32_t fl = clip_pos < trim_to ? clip_pos : trim_to;
+    while (fl > 0) {
+      uint8_t c, q;
+      oriented(S, lb, lq, R, fl - 1, P.min_input_bq, &c, &q);
+      if (c != 15) break;
+      fl--;
+    }
+    R.final_len = (uint16_t)fl;
+    R.zero_len = fl == 0;
+  }
+  __syncthreads();
+
+  // ---- 5. family gates (process_group :1329-1422, process_subgroup :1454-1646) -------------------------
+  if (tid == 0) {
+    uint32_t* st = S.stats;
+    st[0] += n;
+    uint32_t n_sec = 0, n_reads = 0;
+    for (uint32_t i = 0; i < n; i++) { if (S.ri[i].excluded) n_sec++; else n_reads++; }
+    if (n_sec) { st[2] += n_sec; st[3 + FGX_REJ_SECONDARY_OR_SUPPLEMENTARY] += n_sec; }
+    bool go = n_reads > 0;
+    if (go && n_reads < P.min_reads) { st[2] += n_reads; st[3 + FGX_REJ_INSUFFICIENT_READS] += n_reads; go = false; }
+    uint32_t n_members = 0;
+    bool ok[3] = {false, false, false};
+    uint32_t surv[3] = {0, 0, 0}, first[3] = {0, 0, 0}, clen[3] = {0, 0, 0};
+    if (go) {
+      for (uint32_t i = 0; i < n; i++) {
+        ReadInfo& R = S.ri[i];
+        if (R.excluded) continue;
+        if (!(R.flags & bam::F_PAIRED)) R.end = 0;
+        else if (R.flags & bam::F_FIRST) R.end = 1;
+        else if (R.flags & bam::F_LAST) R.end = 2;
+      }
+      for (uint32_t e = 0; e < 3 && !S.defer; e++) {
+        uint32_t cnt = 0, zero = 0;
+        for (uint32_t i = 0; i < n; i++) if (S.ri[i].end == e) { cnt++; if (S.ri[i].zero_len) zero++; }
+        if (cnt == 0) continue;
+        if (cnt < P.min_reads) { st[2] += cnt; st[3 + FGX_REJ_INSUFFICIENT_READS] += cnt; continue; }
+        if (zero) { st[2] += zero; st[3 + FGX_REJ_ZERO_LENGTH_AFTER_TRIMMING] += zero; }
+        uint32_t rem = cnt - zero;
+        if (rem < P.min_reads) { if (rem) { st[2] += rem; st[3 + FGX_REJ_INSUFFICIENT_READS] += rem; } continue; }
+        // alignment filter: every read is mapped with one M-like op → a single prefix-compatible group, all kept
+        if (P.max_reads >= 0 && (int64_t)rem > P.max_reads) { defer(S); break; }
+        first[e] = n_members;
+        for (uint32_t i = 0; i < n; i++) if (S.ri[i].end == e && !S.ri[i].zero_len) S.members[n_members++] = (uint16_t)i;
+        surv[e] = rem;
+        // consensus length = min_reads-th longest kept read (:1661-1669)
+        uint32_t k = P.min_reads, best = 0;
+        for (uint32_t a = first[e]; a < n_members; a++) {
+          uint32_t la = S.ri[S.members[a]].final_len, ge = 0;
+          for (uint32_t b = first[e]; b < n_members; b++) if (S.ri[S.members[b]].final_len >= la) ge++;
+          if (ge >= k && la > best) best = la;
+        }
+        clen[e] = best;
+        ok[e] = true;
+      }
+    }
+    if (!S.defer) {
+      uint32_t ne = 0;
+      auto push_end = [&](uint32_t e) {
+        S.end_type[ne] = e; S.end_first[ne] = first[e]; S.end_cnt[ne] = surv[e]; S.end_len[ne] = clen[e];
+        S.end_maxd[ne] = 0; S.end_mind[ne] = 0xFFFFFFFFu; S.end_sumd[ne] = 0; S.end_sume[ne] = 0;
+        ne++;
+      };
+      if (ok[0]) { st[1] += 1; push_end(0); }
+      if (ok[1] && ok[2]) { st[1] += 2; push_end(1); push_end(2); }
+      else if (ok[1]) { st[2] += surv[1]; st[3 + FGX_REJ_ORPHAN_CONSENSUS] += surv[1]; }
+      else if (ok[2]) { st[2] += surv[2]; st[3 + FGX_REJ_ORPHAN_CONSENSUS] += surv[2]; }
+      uint32_t total = 0;
+      for (uint32_t k = 0; k < ne; k++) { S.end_coloff[k] = total; total += S.end_len[k]; }
+      S.n_ends = ne;
+      if (total) {
+        unsigned long long base = atomicAdd(P.col_cursor, (unsigned long long)total);
+        if (base + total > P.col_capacity) defer(S);
+        S.col_base = base;
+      }
+      // UMIs carried by the kept reads of each end (vanilla_caller.rs:1842-1856)
+      for (uint32_t k = 0; k < ne && !S.defer; k++) {
+        uint32_t cnt = 0, len0 = 0, firstr = 0;
+        bool same = true;
+        for (uint32_t a = 0; a < S.end_cnt[k]; a++) {
+          const ReadInfo& R = S.ri[S.members[S.end_first[k] + a]];
+          if (!R.has_rx) continue;
+          if (cnt == 0) { len0 = R.rx_len; firstr = S.members[S.end_first[k] + a]; }
+          else if (R.rx_len != len0) same = false;
+          cnt++;
+        }
+        S.end_rx_cnt[k] = cnt; S.end_rx_len[k] = len0; S.end_rx_first[k] = firstr;
+        if (cnt > 1 && !same) defer(S);          // consensus_umis panics on unequal lengths → general path reports it
+        if (cnt >= 1 && len0 > FAST_RX_CAP) defer(S);
+      }
+    }
+  }
+  __syncthreads();
+  if (S.defer) {
+    if (tid == 0) { uint32_t k = atomicAdd(P.n_deferred, 1u); P.deferred[k] = g; }
+    return;
+  }
+
+  // ---- 6. consensus columns (create_consensus_from_source_reads :1652-1755) -------------------------
+  const DeviceTables* T = P.T;
+  const uint32_t ne = S.n_ends;
+  uint32_t total_cols = ne ? S.end_coloff[ne - 1] + S.end_len[ne - 1] : 0;
+  for (uint32_t c = tid; c < total_cols; c += NT) {
+    uint32_t k = 0;
+    while (k + 1 < ne && c >= S.end_coloff[k + 1]) k++;
+    uint32_t p = c - S.end_coloff[k];
+    uint32_t m0 = S.end_first[k], mc = S.end_cnt[k];
+    uint8_t ob, oq;
+    uint32_t depth, err;
+    if (mc == 1) {   // single-read consensus: LUT keyed by the unclamped quality (:1677-1708)
+      uint8_t code, q;
+      oriented(S, lb, lq, S.ri[S.members[m0]], p, P.min_input_bq, &code, &q);
+      uint8_t adj = q < 94 ? T->single_input_quals[q] : 0;
+      if (adj < P.min_cons_bq) { ob = 15; oq = FGX_MIN_PHRED; } else { ob = code; oq = adj; }
+      depth = code != 15 ? 1 : 0;
+      err = 0;
+    } else {
+      ColumnAcc acc;
+      acc.reset();
+      for (uint32_t a = 0; a < mc; a++) {
+        const ReadInfo& R = S.ri[S.members[m0 + a]];
+        if (p < R.final_len) {
+          uint8_t code, q;
+          oriented(S, lb, lq, R, p, P.min_input_bq, &code, &q);
+          int lane = bam::code_to_lane(code);   // N (incl. masked) and IUPAC codes contribute nothing
+          if (lane != 255) {
+            uint32_t qq = q < FGX_MAX_PHRED ? q : FGX_MAX_PHRED;
+            acc.add(lane, T->t.correct[qq], T->t.error_per_alt[qq]);
+          }
+        }
+      }
+      int bi;
+      uint8_t q;
+      column_call(T->t, acc.s, acc.obs, &bi, &q);
+      depth = acc.contributions();
+      err = depth - (bi >= 0 ? acc.obs[bi] : 0);
+      const uint8_t LANE_CODE[4] = {1, 2, 4, 8};
+      uint8_t code = bi >= 0 ? LANE_CODE[bi] : 15;
+      if (depth < P.min_reads) { ob = 15; oq = 0; }
+      else if (q < P.min_cons_bq) { ob = 15; oq = FGX_MIN_PHRED; }
+      else { ob = code; oq = q; }
+    }
+    uint32_t d16 = depth < 32767u ? depth : 32767u, e16 = err < 32767u ? err : 32767u;
+    uint64_t o = S.col_base + c;
+    P.col_code[o] = ob; P.col_qual[o] = oq; P.col_depth[o] = (uint16_t)d16; P.col_err[o] = (uint16_t)e16;
+    atomicMax(&S.end_maxd[k], d16); atomicMin(&S.end_mind[k], d16); atomicAdd(&S.end_sumd[k], d16); atomicAdd(&S.end_sume[k], e16);
+  }
+
+  // ---- 7. consensus UMI per end (simple_umi.rs:46-117): Q20 observations at (Q90, Q90) -----------------
+  {
+    const DeviceTables* TU = P.TU;
+    for (uint32_t w = tid; w < ne * FAST_RX_CAP; w += NT) {
+      uint32_t k = w / FAST_RX_CAP, i = w % FAST_RX_CAP;
+      uint32_t cnt = S.end_rx_cnt[k];
+      if (cnt == 0 || i >= S.end_rx_len[k]) continue;
+      if (cnt == 1) { const ReadInfo& R = S.ri[S.end_rx_first[k]]; S.end_rx[k][i] = (char)P.blob[R.goff + R.rx_off + i]; continue; }
+      ColumnAcc acc;
+      acc.reset();
+      uint32_t non_dna = 0, seen = 0;
+      uint8_t fc = 0;
+      bool mixed = false;
+      for (uint32_t a = 0; a < S.end_cnt[k]; a++) {
+        const ReadInfo& R = S.ri[S.members[S.end_first[k] + a]];
+        if (!R.has_rx) continue;
+        uint8_t ch = P.blob[R.goff + R.rx_off + i];
+        if (seen == 0) fc = ch;
+        seen++;
+        uint8_t up = (ch >= 'a' && ch <= 'z') ? (uint8_t)(ch - 32) : ch;
+        bool dna = up == 'A' || up == 'C' || up == 'G' || up == 'T' || up == 'N';
+        if (dna) { int lane = bam::ascii_to_lane(ch); if (lane != 255) acc.add(lane, TU->t.correct[20], TU->t.error_per_alt[20]); }
+        else { non_dna++; if (ch != fc) mixed = true; }
+      }
+      char out;
+      if (non_dna == 0) { int bi; uint8_t q; column_call(TU->t, acc.s, acc.obs, &bi, &q); out = bi >= 0 ? "ACGT"[bi] : 'N'; }
+      else if (non_dna == seen && !mixed) out = (char)fc;
+      else { out = '?'; S.rx_bad = 1; }      // the reference panics here
+      S.end_rx[k][i] = out;
+    }
+  }
+  __syncthreads();
+  if (S.rx_bad) {   // undo: the general path raises the reference's error
+    if (tid == 0) { uint32_t k = atomicAdd(P.n_deferred, 1u); P.deferred[k] = g; }
+    return;
+  }
+
+  // ---- 8. descriptors + stats ---------------------------------------------------------------------------
+  if (tid < ne) {
+    uint32_t k = tid;
+    EndDesc D;
+    memset(&D, 0, sizeof(D));
+    uint32_t Lc = S.end_len[k];
+    D.col_off = S.col_base + S.end_coloff[k];
+    D.cons_len = Lc;
+    D.first_rec = r0;
+    D.first_kept_rec = r0 + S.members[S.end_first[k]];
+    D.type = (uint8_t)S.end_type[k];
+    uint32_t maxd = Lc ? S.end_maxd[k] : 0, mind = Lc ? S.end_mind[k] : 0;
+    D.maxd = (uint16_t)maxd; D.mind = (uint16_t)mind;
+    uint32_t te = S.end_sume[k], td = S.end_sumd[k];
+    D.ce = td > 0 ? (float)te / (float)td : 0.0f;
+    D.mi_off = S.ri[0].mi_off; D.mi_len = S.ri[0].mi_len;
+    const ReadInfo& F = S.ri[S.members[S.end_first[k]]];
+    D.has_cb = (P.cell0 && F.has_cb) ? 1 : 0; D.cb_off = F.cb_off; D.cb_len = F.cb_len;
+    D.has_rx = S.end_rx_cnt[k] > 0; D.rx_len = (uint8_t)S.end_rx_len[k];
+    for (uint32_t i = 0; i < D.rx_len; i++) D.rx[i] = S.end_rx[k][i];
+    D.valid = 1;
+    uint32_t name_len = P.prefix_len + 1 + D.mi_len;
+    uint32_t size = 32 + name_len + 1 + (Lc + 1) / 2 + Lc + (3 + P.rg_len + 1) + (3 + int_tag_width(maxd)) + (3 + int_tag_width(mind)) + 7 +
+                    (P.per_base_tags ? 2 * (8 + 2 * Lc) : 0) + (3 + D.mi_len + 1) + (D.has_cb ? 3 + D.cb_len + 1 : 0) +
+                    (D.has_rx ? 3 + D.rx_len + 1 : 0);
+    D.rec_size = size;
+    // emission order inside a family: fragment, R1, R2 → slot = end type
+    P.ends[slot0 + D.type] = D;
+    P.rec_sizes[slot0 + D.type] = (uint64_t)size + 4;
+  }
+  if (tid < FGX_STATS_LEN && S.stats[tid]) atomicAdd(&P.stats[tid], (unsigned long long)S.stats[tid]);
+}
+
+// -----------------------------------------------------------------------------------------------------
+// pass B: one wavefront per consensus read
+// -----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void put_int_tag(uint8_t* q, char a, char b, uint32_t v, uint32_t* n) {
+  q[0] = a; q[1] = b;
+  if (v <= 127) { q[2] = 'c'; q[3] = (uint8_t)v; *n = 4; }
+  else if (v <= 255) { q[2] = 'C'; q[3] = (uint8_t)v; *n = 4; }
+  else { q[2] = 'S'; q[3] = (uint8_t)v; q[4] = (uint8_t)(v >> 8); *n = 5; }
+}
+
+__global__ __launch_bounds__(256) void k_emit(EmitParams P) {
+  uint32_t slot = P.slot0 + ((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  uint32_t lane = threadIdx.x & 63;
+  if (slot >= P.slot_end) return;
+  const EndDesc& D = P.ends[slot];
+  if (!D.valid) return;
+  uint8_t* out = P.out + (P.out_off[slot] - P.out_base);
+  uint32_t Lc = D.cons_len;
+  const uint8_t* first = P.blob + P.rec_off[D.first_rec];
+  uint32_t name_len = P.prefix_len + 1 + D.mi_len;
+  uint16_t flag = bam::F_UNMAPPED;
+  if (D.type == 1) flag |= bam::F_PAIRED | bam::F_FIRST | bam::F_MATE_UNMAPPED;
+  else if (D.type == 2) flag |= bam::F_PAIRED | bam::F_LAST | bam::F_MATE_UNMAPPED;
+  uint8_t* q = out;
+  if (lane == 0) {
+    uint32_t bs = D.rec_size;
+    q[0] = (uint8_t)bs; q[1] = (uint8_t)(bs >> 8); q[2] = (uint8_t)(bs >> 16); q[3] = (uint8_t)(bs >> 24);
+    uint8_t* h = q + 4;
+    for (int i = 0; i < 8; i++) h[i] = 0xFF;                       // ref_id = -1, pos = -1
+    h[8] = (uint8_t)(name_len + 1); h[9] = 0;                      // l_read_name, mapq
+    h[10] = (uint8_t)(4680 & 0xFF); h[11] = (uint8_t)(4680 >> 8);  // bin
+    h[12] = 0; h[13] = 0;                                          // n_cigar_op
+    h[14] = (uint8_t)flag; h[15] = (uint8_t)(flag >> 8);
+    h[16] = (uint8_t)Lc; h[17] = (uint8_t)(Lc >> 8); h[18] = (uint8_t)(Lc >> 16); h[19] = (uint8_t)(Lc >> 24);
+    for (int i = 20; i < 28; i++) h[i] = 0xFF;                     // next_ref_id, next_pos
+    for (int i = 28; i < 32; i++) h[i] = 0;                        // tlen
+  }
+  q += 36;
+  for (uint32_t i = lane; i < name_len + 1; i += 64) {
+    uint8_t ch;
+    if (i < P.prefix_len) ch = (uint8_t)P.prefix[i];
+    else if (i == P.prefix_len) ch = ':';
+    else if (i < name_len) ch = first[D.mi_off + (i - P.prefix_len - 1)];
+    else ch = 0;
+    q[i] = ch;
+  }
+  q += name_len + 1;
+  const uint8_t* code = P.col_code + D.col_off;
+  for (uint32_t i = lane; i < (Lc + 1) / 2; i += 64) {
+    uint8_t hi = code[2 * i], lo = (2 * i + 1 < Lc) ? code[2 * i + 1] : 0;
+    q[i] = (uint8_t)((hi << 4) | lo);
+  }
+  q += (Lc + 1) / 2;
+  const uint8_t* cq = P.col_qual + D.col_off;
+  for (uint32_t i = lane; i < Lc; i += 64) q[i] = cq[i];
+  q += Lc;
+  // tags: RG cD cM cE [cd ce] MI [CB] RX
+  uint32_t n_cd, n_cm;
+  if (lane == 0) { q[0] = 'R'; q[1] = 'G'; q[2] = 'Z'; }
+  for (uint32_t i = lane; i < P.rg_len + 1; i += 64) q[3 + i] = i < P.rg_len ? (uint8_t)P.rg[i] : 0;
+  q += 3 + P.rg_len + 1;
+  n_cd = 3 + int_tag_width(D.maxd);
+  n_cm = 3 + int_tag_width(D.mind);
+  if (lane == 0) {
+    uint32_t w;
+    put_int_tag(q, 'c', 'D', D.maxd, &w);
+    put_int_tag(q + n_cd, 'c', 'M', D.mind, &w);
+    uint8_t* f = q + n_cd + n_cm;
+    uint32_t u = __float_as_uint(D.ce);
+    f[0] = 'c'; f[1] = 'E'; f[2] = 'f'; f[3] = (uint8_t)u; f[4] = (uint8_t)(u >> 8); f[5] = (uint8_t)(u >> 16); f[6] = (uint8_t)(u >> 24);
+  }
+  q += n_cd + n_cm + 7;
+  if (P.per_base_tags) {
+    const uint16_t* cd = P.col_depth + D.col_off;
+    const uint16_t* ce = P.col_err + D.col_off;
+    for (int pass = 0; pass < 2; pass++) {
+      if (lane == 0) {
+        q[0] = 'c'; q[1] = pass == 0 ? 'd' : 'e'; q[2] = 'B'; q[3] = 's';
+        q[4] = (uint8_t)Lc; q[5] = (uint8_t)(Lc >> 8); q[6] = (uint8_t)(Lc >> 16); q[7] = (uint8_t)(Lc >> 24);
+      }
+      const uint16_t* src = pass == 0 ? cd : ce;
+      for (uint32_t i = lane; i < Lc; i += 64) { uint16_t v = src[i]; q[8 + 2 * i] = (uint8_t)v; q[9 + 2 * i] = (uint8_t)(v >> 8); }
+      q += 8 + 2 * Lc;
+    }
+  }
+  if (lane == 0) { q[0] = (uint8_t)P.tag0; q[1] = (uint8_t)P.tag1; q[2] = 'Z'; }
+  for (uint32_t i = lane; i < (uint32_t)D.mi_len + 1; i += 64) q[3 + i] = i < D.mi_len ? first[D.mi_off + i] : 0;
+  q += 3 + D.mi_len + 1;
+  if (D.has_cb) {
+    const uint8_t* fk = P.blob + P.rec_off[D.first_kept_rec];
+    if (lane == 0) { q[0] = (uint8_t)P.cell0; q[1] = (uint8_t)P.cell1; q[2] = 'Z'; }
+    for (uint32_t i = lane; i < (uint32_t)D.cb_len + 1; i += 64) q[3 + i] = i < D.cb_len ? fk[D.cb_off + i] : 0;
+    q += 3 + D.cb_len + 1;
+  }
+  if (D.has_rx) {
+    if (lane == 0) { q[0] = 'R'; q[1] = 'X'; q[2] = 'Z'; }
+    for (uint32_t i = lane; i < (uint32_t)D.rx_len + 1; i += 64) q[3 + i] = i < D.rx_len ? (uint8_t)D.rx[i] : 0;
+    q += 3 + D.rx_len + 1;
+  }
+}
+
+}  // namespace
+
+// -----------------------------------------------------------------------------------------------------
+// host driver
+// -----------------------------------------------------------------------------------------------------
+void FastPath::release() {
+  for (DevBuf* b : {&d_ends, &d_sizes, &d_offsets, &d_code, &d_qual, &d_depth, &d_err, &d_misc, &d_deferred, &d_out, &d_scan_tmp, &d_strings})
+    b->free_();
+}
+
+int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const uint64_t* d_rec_off, const uint32_t* d_rec_len,
+                  uint32_t n_rec, const uint32_t* d_grp_first, uint32_t n_grp, FastResult* res) {
+  const fgx_options& o = c->opt;
+  hipStream_t s = c->stream;
+  memset(res, 0, sizeof(*res));
+  if (n_grp == 0) return 0;
+  const uint32_t n_slots = 3 * n_grp;
+  d_ends.reserve((size_t)n_slots * sizeof(EndDesc));
+  d_sizes.reserve((size_t)n_slots * 8);
+  d_offsets.reserve((size_t)n_slots * 8);
+  d_deferred.reserve((size_t)n_grp * 4);
+  // misc: [0..28) stats, [28] col_cursor, [29] n_deferred (u32 in low half), [30] valid count
+  d_misc.reserve(32 * 8);
+  hip_check(hipMemsetAsync(d_misc.p, 0, 32 * 8, s), "memset");
+  // strings: prefix | rg
+  std::string strs = c->prefix + c->rg;
+  d_strings.reserve(strs.size() + 16);
+  if (!strs.empty()) hip_check(hipMemcpyAsync(d_strings.p, strs.data(), strs.size(), hipMemcpyHostToDevice, s), "H2D strings");
+  // column scratch: Σ consensus_len ≤ Σ l_seq ≤ (blob bytes − 32·n_rec) / 1.5
+  uint64_t col_cap = blob_len > 32ull * n_rec ? (blob_len - 32ull * n_rec) * 2 / 3 + 1024 : 1024;
+  d_code.reserve(col_cap); d_qual.reserve(col_cap); d_depth.reserve(col_cap * 2); d_err.reserve(col_cap * 2);
+
+  FastParams P;
+  memset(&P, 0, sizeof(P));
+  P.blob = d_blob; P.rec_off = d_rec_off; P.rec_len = d_rec_len; P.grp_first = d_grp_first;
+  P.g0 = 0;
+  P.T = c->d_tables.as<DeviceTables>(); P.TU = c->d_umi_tables.as<DeviceTables>();
+  P.min_reads = o.min_reads; P.max_reads = o.max_reads;
+  P.min_input_bq = o.min_input_base_quality; P.min_cons_bq = o.min_consensus_base_quality;
+  P.trim = o.trim; P.overlap = o.overlapping_consensus; P.per_base_tags = o.produce_per_base_tags; P.track_rejects = o.track_rejects;
+  P.tag0 = o.tag[0]; P.tag1 = o.tag[1]; P.cell0 = o.cell_tag[0]; P.cell1 = o.cell_tag[1];
+  P.prefix_len = (uint32_t)c->prefix.size(); P.rg_len = (uint32_t)c->rg.size();
+  P.ends = d_ends.as<EndDesc>(); P.rec_sizes = d_sizes.as<uint64_t>();
+  P.col_code = d_code.as<uint8_t>(); P.col_qual = d_qual.as<uint8_t>(); P.col_depth = d_depth.as<uint16_t>(); P.col_err = d_err.as<uint16_t>();
+  unsigned long long* misc = d_misc.as<unsigned long long>();
+  P.stats = misc; P.col_cursor = misc + 28; P.n_deferred = (uint32_t*)(misc + 29); P.col_capacity = col_cap;
+  P.deferred = d_deferred.as<uint32_t>();
+  P.lds_tile_bytes = lds_tile_bytes;
+
+  hip_check(hipEventRecord(c->ev0, s), "event");
+  hipLaunchKernelGGL(k_family, dim3(n_grp), dim3(NT), lds_tile_bytes, s, P);
+  hip_check(hipGetLastError(), "k_family launch");
+
+  size_t tmp_bytes = 0;
+  hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_sizes.as<uint64_t>(), d_offsets.as<uint64_t>(), (int)n_slots, s);
+  d_scan_tmp.reserve(tmp_bytes);
+  hip_check(hipcub::DeviceScan::ExclusiveSum(d_scan_tmp.p, tmp_bytes, d_sizes.as<uint64_t>(), d_offsets.as<uint64_t>(), (int)n_slots, s), "scan");
+
+  // total output size = last offset + last size
+  uint64_t last[2];
+  hip_check(hipMemcpyAsync(&last[0], d_offsets.as<uint64_t>() + (n_slots - 1), 8, hipMemcpyDeviceToHost, s), "D2H");
+  hip_check(hipMemcpyAsync(&last[1], d_sizes.as<uint64_t>() + (n_slots - 1), 8, hipMemcpyDeviceToHost, s), "D2H");
+  unsigned long long h_misc[32];
+  hip_check(hipMemcpyAsync(h_misc, misc, sizeof(h_misc), hipMemcpyDeviceToHost, s), "D2H");
+  hip_check(hipStreamSynchronize(s), "sync");
+  uint64_t out_len = last[0] + last[1];
+  d_out.reserve(out_len + 16);
+
+  EmitParams E;
+  memset(&E, 0, sizeof(E));
+  E.blob = d_blob; E.rec_off = d_rec_off; E.ends = d_ends.as<EndDesc>(); E.out_off = d_offsets.as<uint64_t>(); E.out = d_out.as<uint8_t>();
+  E.out_base = 0; E.slot0 = 0; E.slot_end = n_slots;
+  E.col_code = P.col_code; E.col_qual = P.col_qual; E.col_depth = P.col_depth; E.col_err = P.col_err;
+  E.prefix = d_strings.as<char>(); E.prefix_len = P.prefix_len; E.rg = d_strings.as<char>() + P.prefix_len; E.rg_len = P.rg_len;
+  E.per_base_tags = P.per_base_tags; E.tag0 = P.tag0; E.tag1 = P.tag1; E.cell0 = P.cell0; E.cell1 = P.cell1;
+  hipLaunchKernelGGL(k_emit, dim3((n_slots + 3) / 4), dim3(256), 0, s, E);
+  hip_check(hipGetLastError(), "k_emit launch");
+  hip_check(hipEventRecord(c->ev1, s), "event");
+  hip_check(hipStreamSynchronize(s), "sync");
+  float ms = 0;
+  hip_check(hipEventElapsedTime(&ms, c->ev0, c->ev1), "elapsed");
+
+  res->d_out = d_out.as<uint8_t>();
+  res->out_len = out_len;
+  res->count = h_misc[1];   // every consensus read of a fast-path family is one record
+  for (int i = 0; i < FGX_STATS_LEN; i++) res->stats[i] = h_misc[i];
+  res->n_deferred = (uint32_t)(h_misc[29] & 0xFFFFFFFFull);
+  res->d_deferred = d_deferred.as<uint32_t>();
+  res->d_out_off = d_offsets.as<uint64_t>();
+  res->ms_kernels = ms;
+  res->cols_used = h_misc[28];
+  return 0;
+}
+
+}  // namespace fgx

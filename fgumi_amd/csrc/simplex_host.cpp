@@ -282,6 +282,8 @@ int simplex_process_general(fgx_caller* c, const uint8_t* blob, const uint64_t* 
   c->batch.clear();
   c->out_data.clear();
   c->out_rejects.clear();
+  c->grp_out_end.assign(n_grp, 0);
+  std::vector<uint32_t> grp_pending_end(n_grp, 0);
   const fgx_options& o = c->opt;
   std::vector<std::vector<uint8_t>> scratch;   // per-group mutable copies for the overlap pre-step
   std::vector<Positioned> records;
@@ -292,6 +294,7 @@ int simplex_process_general(fgx_caller* c, const uint8_t* blob, const uint64_t* 
       x.stats.total_reads += n;
       x.stats.reject(FGX_REJ_INSUFFICIENT_READS, n);
       if (o.track_rejects) for (uint32_t r = r0; r < r1; r++) x.reject_now(blob + rec_off[r], rec_len[r]);
+      grp_pending_end[g] = (uint32_t)x.pending.size();
       continue;
     }
     records.clear();
@@ -318,6 +321,7 @@ int simplex_process_general(fgx_caller* c, const uint8_t* blob, const uint64_t* 
     }
     std::string umi((const char*)first.b + first.aux_off() + off, vl);
     if (process_group(x, umi, records) < 0) { c->err = x.err; return 2; }
+    grp_pending_end[g] = (uint32_t)x.pending.size();
   }
   auto t1 = clk::now();
 
@@ -328,7 +332,10 @@ int simplex_process_general(fgx_caller* c, const uint8_t* blob, const uint64_t* 
   // build_consensus_record_into (vanilla_caller.rs:1767-1881)
   ColumnBatch& B = c->batch;
   std::vector<uint8_t> rec;
+  uint32_t g_cur = 0, pi = 0;
   for (auto& pr : x.pending) {
+    while (g_cur < n_grp && grp_pending_end[g_cur] <= pi) { c->grp_out_end[g_cur] = c->out_data.size(); g_cur++; }
+    pi++;
     const ColJob& j = B.jobs[pr.job];
     const uint8_t* bases = B.ob.data() + j.out_off;
     const uint8_t* quals = B.oq.data() + j.out_off;
@@ -359,6 +366,7 @@ int simplex_process_general(fgx_caller* c, const uint8_t* blob, const uint64_t* 
     }
     append_with_block_size(c->out_data, rec.data(), (uint32_t)rec.size());
   }
+  for (; g_cur < n_grp; g_cur++) c->grp_out_end[g_cur] = c->out_data.size();
   auto t3 = clk::now();
 
   memset(out, 0, sizeof(*out));

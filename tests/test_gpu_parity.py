@@ -135,10 +135,22 @@ def _oracle(grouped, **optkw):
     return orc.process(o, grouped.blob, grouped.rec_off, grouped.rec_len, grouped.grp_first)
 
 
+MODE = {"general_only": False}
+
+
+@pytest.fixture(params=["fast+general", "general-only"], autouse=True)
+def _path_mode(request):
+    """Every batch test runs twice: through the device-resident fast path (general path only for the
+    families it defers) and with every family forced through the general host-orchestrated path."""
+    MODE["general_only"] = request.param == "general-only"
+    yield
+
+
 def _device(grouped, min_reads=1, overlapping=True, track_rejects=False, prefix="", **optkw):
     vo = VanillaUmiConsensusOptions(min_reads=min_reads, min_consensus_base_quality=optkw.pop("min_consensus_base_quality", 2),
                                     cell_tag="CB", **optkw)
     c = VanillaUmiConsensusCaller(prefix, "A", vo, track_rejects=track_rejects, overlapping_consensus=overlapping)
+    c.set_general_only(MODE["general_only"])
     out = c.process_batch(grouped)
     stats = c.last_batch_statistics()
     rej = c.take_rejected_reads()
@@ -211,6 +223,29 @@ def test_crafted_edge_cases(handle):
             _assert_same(g, min_reads=mr, overlapping=ov, track_rejects=True, prefix="lib1")
     _assert_same(g, min_reads=1, trim=True, track_rejects=True)
     _assert_same(g, min_reads=1, max_reads=1, track_rejects=True)
+
+
+def test_device_resident_pipeline_matches_oracle(handle):
+    """Input generated in HBM by the device generator, consensus records left in HBM: the measured
+    configuration of bench.py.  The same molecules regenerated on the host feed the oracle."""
+    for kw in [dict(n_families=3000, family_size=8), dict(n_families=2000, family_size=2, family_size_max=40),
+               dict(n_families=500, family_size=3, read_length=300, insert_mean=350, insert_sd=60)]:
+        c = VanillaUmiConsensusCaller("", "A", VanillaUmiConsensusOptions(min_reads=1, min_consensus_base_quality=2, cell_tag="CB"),
+                                      overlapping_consensus=True)
+        dg = c.simulate_on_device(**kw)
+        out = c.process_batch_device(dg)
+        assert out.n_deferred == 0
+        data = out.to_host()
+        g = simulate_grouped_reads(**kw)
+        want = _oracle(g, min_reads=1)
+        assert out.count == want["count"] and data == want["data"]
+        st = c.last_batch_statistics()
+        assert st.total_reads == int(want["stats"][0]) and st.consensus_reads == int(want["stats"][1])
+        assert st.overlapping["bases_corrected"] == int(want["stats"][27])
+        # repeated passes over the same resident input are identical (input is never modified)
+        out2 = c.process_batch_device(dg)
+        assert out2.to_host() == data
+        c.close()
 
 
 def test_fatal_errors_match_reference(handle):
