@@ -2,11 +2,16 @@
 """bench.py — simplex consensus throughput on MI355X (BASELINE.json metric).
 
 `python bench.py --gpus N --steps K --warmup W`; for N>1 the driver launches one rank per GPU via
-torch.distributed.run (RCCL).  One "step" = one pass of the consensus hot path over one batch of
-synthetic `simulate`-shaped families resident in HBM.  Rank 0 prints ONE JSON line.
+torch.distributed.run (backend nccl = RCCL).  One "step" = one pass of the consensus hot path
+(raw BAM records resident in HBM → consensus BAM records in HBM) over one batch of synthetic
+`simulate grouped-reads`-shaped families.  Rank 0 prints ONE JSON line.
+
+Workload at N=1: BASELINE.json configs[1] — simplex, 5 M families, depth 8 (pairs), 150 bp paired.
+Weak scaling: every rank processes its own contiguous shard of the family stream (families are
+independent → no data-path collective); the only collective is the gather of the per-rank
+consensus payload sizes + stats (what a writer needs to concatenate shards in input order).
 """
 import argparse
-import ctypes as C
 import json
 import os
 import sys
@@ -20,33 +25,35 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 def cpu_baseline(n_families, family_size, read_length, threads):
     """Bounded sample of the same workload through the ORACLE (C++ restatement of the reference CPU
-    caller, `--threads`-style batches of 50 groups) on the host cores.  Reported, not optimised."""
+    caller; `--threads`-style batches of 50 MI groups, one caller object per batch) on this box's
+    host cores.  A reported baseline, not the optimisation target."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import fgx_opts
     import orc
     from fgumi_amd import simulate_grouped_reads
     g = simulate_grouped_reads(n_families, family_size=family_size, read_length=read_length)
     o = fgx_opts.defaults(min_reads=1)
-    orc.process(o, g.blob, g.rec_off, g.rec_len, g.grp_first, batch_groups=50, threads=threads)  # warm-up
-    best = None
-    for _ in range(2):
+    best, res = None, None
+    for _ in range(3):
         t0 = time.perf_counter()
         res = orc.process(o, g.blob, g.rec_off, g.rec_len, g.grp_first, batch_groups=50, threads=threads)
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
     return dict(value=g.n_rec / best, unit="raw reads/s", cores=threads, kind="port",
-                sample=f"{n_families} families x {family_size} pairs x {read_length}bp (compute-only, records in RAM, "
-                       f"batches of 50 groups, best of 2)", consensus_reads_per_s=res["count"] / best)
+                sample=f"{n_families} families x {family_size} pairs x {read_length}bp, compute-only (records in RAM → ConsensusOutput "
+                       f"bytes), batches of 50 MI groups over {threads} threads, best of 3",
+                consensus_reads_per_s=res["count"] / best)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--families", type=int, default=int(os.environ.get("FGX_BENCH_FAMILIES", "200000")))
+    ap.add_argument("--families", type=int, default=int(os.environ.get("FGX_BENCH_FAMILIES", "5000000")))
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--read-length", type=int, default=150)
+    ap.add_argument("--cpu-sample-families", type=int, default=300000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -60,53 +67,68 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl")
 
-    from fgumi_amd import VanillaUmiConsensusCaller, VanillaUmiConsensusOptions, simulate_grouped_reads
+    from fgumi_amd import VanillaUmiConsensusCaller, VanillaUmiConsensusOptions
 
-    # weak scaling: every rank gets its own contiguous shard of the family stream (no data-path collective)
-    fam_per_rank = args.families
-    g = simulate_grouped_reads(fam_per_rank, family_size=args.depth, read_length=args.read_length, first_family=rank * fam_per_rank)
+    fam = args.families
     caller = VanillaUmiConsensusCaller("", "A", VanillaUmiConsensusOptions(min_reads=1, min_consensus_base_quality=2, cell_tag="CB"),
                                        overlapping_consensus=True, device=local_rank)
+    # synthetic families generated straight into HBM; rank r owns molecules [r*fam, (r+1)*fam)
+    dg = caller.simulate_on_device(fam, family_size=args.depth, read_length=args.read_length, first_family=rank * fam)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    out = None
     for _ in range(args.warmup):
-        out = caller.process_batch(g)
+        out = caller.process_batch_device(dg)
     barrier()
     t0 = time.perf_counter()
-    kern_ms = 0.0
+    k_family_ms = k_emit_ms = k_total_ms = 0.0
     for _ in range(args.steps):
-        out = caller.process_batch(g)
-        kern_ms += caller.last_timing["kernels"]
+        out = caller.process_batch_device(dg)
+        k_family_ms += caller.last_timing["k_family"]
+        k_emit_ms += caller.last_timing["k_emit"]
+        k_total_ms += caller.last_timing["kernels"]
     barrier()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    sizes = torch.tensor([out.data_len, out.count, dg.n_rec, out.n_deferred], dtype=torch.int64, device="cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        gathered = [torch.zeros_like(sizes) for _ in range(world)]
+        dist.all_gather(gathered, sizes)      # shard payload sizes, rank (= input) order
+        sizes = torch.stack(gathered).sum(0)
     dt = float(t.item())
+    total_bytes, total_cons, total_raw, total_def = [int(v) for v in sizes.tolist()]
 
     if rank == 0:
-        raw_reads = g.n_rec * world * args.steps
-        cons_reads = out.count * world * args.steps
         L = args.read_length
-        alg_bytes_per_launch = g.n_rec * ((L + 1) // 2 + L) + out.count * 6 * L
-        k_avg_s = kern_ms / args.steps / 1e3
-        achieved = alg_bytes_per_launch / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
+        steps = args.steps
+        # algorithmic bytes of ONE k_family launch on ONE GPU: per raw read ceil(L/2)+L read,
+        # per consensus read 6*Lc written (bases, quals, depth i16, errors i16)
+        alg_read = dg.n_rec * ((L + 1) // 2 + L)
+        alg_write = out.count * 6 * L
+        k_avg_s = k_family_ms / steps / 1e3
+        achieved = (alg_read + alg_write) / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
         line = {
-            "metric": "simplex consensus, input raw reads/s (depth-8 x 150bp)", "value": raw_reads / dt, "unit": "raw reads/s",
-            "consensus_reads_per_s": cons_reads / dt, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"simplex consensus, {fam_per_rank} families/GPU, depth={args.depth}, {L}bp paired, "
-                                   f"general host-orchestrated path", "min_reads": 1, "overlapping_consensus": True},
+            "metric": "simplex consensus throughput, input raw reads/s (depth-8 x 150bp)",
+            "value": total_raw * steps / dt, "unit": "raw reads/s",
+            "consensus_reads_per_s": total_cons * steps / dt,
+            "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": dt / steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"simplex consensus, {fam} families per GPU, depth={args.depth} pairs, {L}bp paired "
+                                   f"(BASELINE configs[1] shape), device-resident: raw BAM records in HBM -> consensus BAM records in HBM",
+                       "min_reads": 1, "overlapping_consensus": True, "families_per_gpu": fam, "raw_reads_per_gpu": dg.n_rec,
+                       "deferred_families": total_def, "output_bytes": total_bytes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "k_column_jobs", "kernel_ms": kern_ms / args.steps},
+                         "traffic": None, "kernel": "k_family", "kernel_ms": k_family_ms / steps, "k_emit_ms": k_emit_ms / steps,
+                         "device_ms_per_step": k_total_ms / steps, "algorithmic_bytes_per_launch": alg_read + alg_write,
+                         "read_only_GBs": alg_read / k_avg_s / 1e9 if k_avg_s > 0 else 0.0},
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(min(fam_per_rank, 20000), args.depth, L, os.cpu_count() or 1)
+            line["cpu_baseline"] = cpu_baseline(min(fam, args.cpu_sample_families), args.depth, L, os.cpu_count() or 1)
         print(json.dumps(line))
     caller.close()
     if world > 1:

@@ -32,6 +32,7 @@ class Output(C.Structure):
         ("data", C.c_void_p), ("data_len", C.c_uint64), ("count", C.c_uint64), ("stats", C.c_uint64 * 28),
         ("rejects", C.c_void_p), ("rejects_len", C.c_uint64), ("n_rejects", C.c_uint64),
         ("ms_host_prep", C.c_double), ("ms_h2d", C.c_double), ("ms_kernels", C.c_double), ("ms_d2h", C.c_double), ("ms_emit", C.c_double),
+        ("ms_k_family", C.c_double), ("ms_k_emit", C.c_double),
     ]
 
 

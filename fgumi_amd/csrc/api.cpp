@@ -259,7 +259,7 @@ int fgx_process_batch_device(fgx_caller* c, const void* d_records, uint64_t reco
     memset(out, 0, sizeof(*out));
     out->data = fr.d_out; out->data_len = fr.out_len; out->count = fr.count;
     for (int i = 0; i < FGX_STATS_LEN; i++) out->stats[i] = fr.stats[i];
-    out->ms_kernels = fr.ms_kernels;
+    out->ms_kernels = fr.ms_kernels; out->ms_k_family = fr.ms_k_family; out->ms_k_emit = fr.ms_k_emit;
     if (n_deferred) *n_deferred = fr.n_deferred;
     if (d_deferred_groups) *d_deferred_groups = fr.d_deferred;
     return 0;
@@ -268,8 +268,8 @@ int fgx_process_batch_device(fgx_caller* c, const void* d_records, uint64_t reco
 
 // 1: route everything through the general host path (parity tests of that path); 0: hybrid (default)
 void fgx_set_general_only(fgx_caller* c, int on) { if (c) c->general_only = on != 0; }
-// dynamic LDS bytes the family kernel gets for its base/qual tiles (default 16 KiB)
-void fgx_set_fast_lds_bytes(fgx_caller* c, uint32_t bytes) { if (c) { if (!c->fast) c->fast = new FastState(); c->fast->fp.lds_tile_bytes = bytes; } }
+// dynamic LDS bytes of the large-family launch of the family kernel (default 48 KiB)
+void fgx_set_fast_lds_bytes(fgx_caller* c, uint32_t bytes) { if (c) { if (!c->fast) c->fast = new FastState(); c->fast->fp.lds_tile_bytes_large = bytes; } }
 
 int fgx_call_columns(fgx_caller* c, const uint8_t* bases, const uint8_t* quals, uint32_t n_cols, uint32_t depth, uint8_t* out_base,
                      uint8_t* out_qual, uint32_t* out_depth, uint32_t* out_errors) {

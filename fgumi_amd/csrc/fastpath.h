@@ -33,6 +33,8 @@ struct FastParams {
   unsigned long long* col_cursor; uint64_t col_capacity;
   unsigned long long* stats;
   uint32_t* deferred; uint32_t* n_deferred;
+  const uint32_t* group_list;      // nullptr: group = g0 + blockIdx.x
+  uint32_t* retry; uint32_t* n_retry;   // families needing more LDS than this launch provides (nullptr: defer them)
   uint32_t lds_tile_bytes;
 };
 
@@ -49,12 +51,15 @@ struct FastResult {
   uint64_t stats[FGX_STATS_LEN];
   uint32_t n_deferred; const uint32_t* d_deferred;
   const uint64_t* d_out_off;     // byte offset of each of the 3*n_grp slots in d_out
-  double ms_kernels; uint64_t cols_used;
+  double ms_kernels, ms_k_family, ms_k_emit; uint64_t cols_used;
 };
 
 struct FastPath {
   DevBuf d_ends, d_sizes, d_offsets, d_code, d_qual, d_depth, d_err, d_misc, d_deferred, d_out, d_scan_tmp, d_strings;
-  uint32_t lds_tile_bytes = 16384;
+  uint32_t lds_tile_bytes = 12288;        // first launch: tiles of the common small families
+  uint32_t lds_tile_bytes_large = 49152;  // second launch over the families that did not fit
+  DevBuf d_retry;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   int run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const uint64_t* d_rec_off, const uint32_t* d_rec_len, uint32_t n_rec,
           const uint32_t* d_grp_first, uint32_t n_grp, FastResult* res);
   void release();

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
   extern __shared__ __align__(16) uint8_t dyn[];
   __shared__ Shared S;
   const uint32_t tid = threadIdx.x;
-  const uint32_t g = P.g0 + blockIdx.x;
+  const uint32_t g = P.group_list ? P.group_list[blockIdx.x] : P.g0 + blockIdx.x;
   const uint32_t r0 = P.grp_first[g], r1 = P.grp_first[g + 1];
   const uint32_t n = r1 - r0;
   const uint32_t slot0 = 3 * g;
@@ -230,11 +230,14 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
     uint32_t row = 0;
     for (uint32_t i = 0; i < n; i++) { S.ri[i].row = row; if (!S.ri[i].excluded) row += ((uint32_t)S.ri[i].l_seq + 3) & ~3u; }
     S.tile_bytes = row;
-    if (2ull * row > P.lds_tile_bytes) defer(S);
+    if (2ull * row > P.lds_tile_bytes && !S.defer) S.defer = P.retry ? 2 : 1;
   }
   __syncthreads();
   if (S.defer) {
-    if (tid == 0) { uint32_t k = atomicAdd(P.n_deferred, 1u); P.deferred[k] = g; }
+    if (tid == 0) {
+      if (S.defer == 2) { uint32_t k = atomicAdd(P.n_retry, 1u); P.retry[k] = g; }
+      else { uint32_t k = atomicAdd(P.n_deferred, 1u); P.deferred[k] = g; }
+    }
     return;
   }
   uint8_t* lb = dyn;
@@ -682,14 +685,33 @@ __global__ __launch_bounds__(256) void k_emit(EmitParams P) {
   }
 }
 
+// Upper bound on the consensus columns a batch can produce: a family yields at most three ends, each no
+// longer than its longest read, and l_seq <= (block_size - 33) * 2 / 3.
+__global__ void k_col_bound(const uint32_t* __restrict__ grp_first, const uint32_t* __restrict__ rec_len, uint32_t n_grp,
+                            unsigned long long* out) {
+  uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long v = 0;
+  if (g < n_grp) {
+    uint32_t a = grp_first[g], b = grp_first[g + 1], mx = 0;
+    for (uint32_t r = a; r < b; r++) { uint32_t l = rec_len[r]; mx = l > mx ? l : mx; }
+    uint32_t lb = mx > 33 ? (mx - 33) * 2 / 3 + 1 : 1;
+    uint32_t ends = (b - a) < 3 ? (b - a) : 3;
+    v = (unsigned long long)ends * lb;
+  }
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
+}
+
 }  // namespace
 
 // -----------------------------------------------------------------------------------------------------
 // host driver
 // -----------------------------------------------------------------------------------------------------
 void FastPath::release() {
-  for (DevBuf* b : {&d_ends, &d_sizes, &d_offsets, &d_code, &d_qual, &d_depth, &d_err, &d_misc, &d_deferred, &d_out, &d_scan_tmp, &d_strings})
+  for (DevBuf* b : {&d_ends, &d_sizes, &d_offsets, &d_code, &d_qual, &d_depth, &d_err, &d_misc, &d_deferred, &d_out, &d_scan_tmp, &d_strings,
+                    &d_retry})
     b->free_();
+  for (int i = 0; i < 4; i++) if (ev[i]) { (void)hipEventDestroy(ev[i]); ev[i] = nullptr; }
 }
 
 int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const uint64_t* d_rec_off, const uint32_t* d_rec_len,
@@ -710,8 +732,16 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
   std::string strs = c->prefix + c->rg;
   d_strings.reserve(strs.size() + 16);
   if (!strs.empty()) hip_check(hipMemcpyAsync(d_strings.p, strs.data(), strs.size(), hipMemcpyHostToDevice, s), "H2D strings");
-  // column scratch: Σ consensus_len ≤ Σ l_seq ≤ (blob bytes − 32·n_rec) / 1.5
-  uint64_t col_cap = blob_len > 32ull * n_rec ? (blob_len - 32ull * n_rec) * 2 / 3 + 1024 : 1024;
+  // column scratch: sized from a per-family upper bound (k_col_bound)
+  (void)blob_len; (void)n_rec;
+  for (int i = 0; i < 4; i++) if (!ev[i]) hip_check(hipEventCreate(&ev[i]), "hipEventCreate");
+  unsigned long long* misc0 = d_misc.as<unsigned long long>();
+  hipLaunchKernelGGL(k_col_bound, dim3((n_grp + 255) / 256), dim3(256), 0, s, d_grp_first, d_rec_len, n_grp, misc0 + 28);
+  uint64_t col_cap = 0;
+  hip_check(hipMemcpyAsync(&col_cap, misc0 + 28, 8, hipMemcpyDeviceToHost, s), "D2H");
+  hip_check(hipStreamSynchronize(s), "sync");
+  hip_check(hipMemsetAsync(misc0 + 28, 0, 8, s), "memset");
+  col_cap += 1024;
   d_code.reserve(col_cap); d_qual.reserve(col_cap); d_depth.reserve(col_cap * 2); d_err.reserve(col_cap * 2);
 
   FastParams P;
@@ -730,13 +760,29 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
   P.stats = misc; P.col_cursor = misc + 28; P.n_deferred = (uint32_t*)(misc + 29); P.col_capacity = col_cap;
   P.deferred = d_deferred.as<uint32_t>();
   P.lds_tile_bytes = lds_tile_bytes;
+  d_retry.reserve((size_t)n_grp * 4);
+  P.retry = d_retry.as<uint32_t>(); P.n_retry = (uint32_t*)(misc + 31);
+  P.group_list = nullptr;
 
   hip_check(hipEventRecord(c->ev0, s), "event");
+  hip_check(hipEventRecord(ev[0], s), "event");
   hipLaunchKernelGGL(k_family, dim3(n_grp), dim3(NT), lds_tile_bytes, s, P);
   hip_check(hipGetLastError(), "k_family launch");
+  {   // families whose tiles did not fit: second launch with large LDS tiles
+    uint32_t n_retry = 0;
+    hip_check(hipMemcpyAsync(&n_retry, P.n_retry, 4, hipMemcpyDeviceToHost, s), "D2H");
+    hip_check(hipStreamSynchronize(s), "sync");
+    if (n_retry) {
+      FastParams P2 = P;
+      P2.group_list = d_retry.as<uint32_t>(); P2.retry = nullptr; P2.n_retry = nullptr; P2.lds_tile_bytes = lds_tile_bytes_large;
+      hipLaunchKernelGGL(k_family, dim3(n_retry), dim3(NT), lds_tile_bytes_large, s, P2);
+      hip_check(hipGetLastError(), "k_family (large) launch");
+    }
+  }
+  hip_check(hipEventRecord(ev[1], s), "event");
 
   size_t tmp_bytes = 0;
-  hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_sizes.as<uint64_t>(), d_offsets.as<uint64_t>(), (int)n_slots, s);
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_sizes.as<uint64_t>(), d_offsets.as<uint64_t>(), (int)n_slots, s);
   d_scan_tmp.reserve(tmp_bytes);
   hip_check(hipcub::DeviceScan::ExclusiveSum(d_scan_tmp.p, tmp_bytes, d_sizes.as<uint64_t>(), d_offsets.as<uint64_t>(), (int)n_slots, s), "scan");
 
@@ -757,8 +803,10 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
   E.col_code = P.col_code; E.col_qual = P.col_qual; E.col_depth = P.col_depth; E.col_err = P.col_err;
   E.prefix = d_strings.as<char>(); E.prefix_len = P.prefix_len; E.rg = d_strings.as<char>() + P.prefix_len; E.rg_len = P.rg_len;
   E.per_base_tags = P.per_base_tags; E.tag0 = P.tag0; E.tag1 = P.tag1; E.cell0 = P.cell0; E.cell1 = P.cell1;
+  hip_check(hipEventRecord(ev[2], s), "event");
   hipLaunchKernelGGL(k_emit, dim3((n_slots + 3) / 4), dim3(256), 0, s, E);
   hip_check(hipGetLastError(), "k_emit launch");
+  hip_check(hipEventRecord(ev[3], s), "event");
   hip_check(hipEventRecord(c->ev1, s), "event");
   hip_check(hipStreamSynchronize(s), "sync");
   float ms = 0;
@@ -772,6 +820,10 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
   res->d_deferred = d_deferred.as<uint32_t>();
   res->d_out_off = d_offsets.as<uint64_t>();
   res->ms_kernels = ms;
+  float msf = 0, mse = 0;
+  hip_check(hipEventElapsedTime(&msf, ev[0], ev[1]), "elapsed");
+  hip_check(hipEventElapsedTime(&mse, ev[2], ev[3]), "elapsed");
+  res->ms_k_family = msf; res->ms_k_emit = mse;
   res->cols_used = h_misc[28];
   return 0;
 }

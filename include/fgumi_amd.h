@@ -99,6 +99,8 @@ typedef struct fgx_output {
   uint64_t n_rejects;
   /* timing of the last call, milliseconds (0 when not measured) */
   double ms_host_prep, ms_h2d, ms_kernels, ms_d2h, ms_emit;
+  /* device-resident pipeline: HIP-event time of its two kernels on the caller's stream */
+  double ms_k_family, ms_k_emit;
 } fgx_output;
 
 typedef struct fgx_caller fgx_caller;
