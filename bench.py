@@ -121,7 +121,8 @@ def main():
             "config": {"workload": f"simplex consensus, {fam} families per GPU, depth={args.depth} pairs, {L}bp paired "
                                    f"(BASELINE configs[1] shape), device-resident: raw BAM records in HBM -> consensus BAM records in HBM",
                        "min_reads": 1, "overlapping_consensus": True, "families_per_gpu": fam, "raw_reads_per_gpu": dg.n_rec,
-                       "deferred_families": total_def, "output_bytes": total_bytes},
+                       "deferred_families": total_def, "output_bytes": total_bytes,
+                       "columns_needing_call_full_per_step": caller.last_timing.get("full_columns")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "k_family", "kernel_ms": k_family_ms / steps, "k_emit_ms": k_emit_ms / steps,
                          "device_ms_per_step": k_total_ms / steps, "algorithmic_bytes_per_launch": alg_read + alg_write,

@@ -283,7 +283,7 @@ class _HandleCaller(ConsensusCaller):
         if rc != 0:
             raise RuntimeError(lib.fgx_last_error(self._h).decode())
         self._last_stats = ConsensusCallingStats.from_array(out.stats)
-        self.last_timing = dict(kernels=out.ms_kernels, k_family=out.ms_k_family, k_emit=out.ms_k_emit)
+        self.last_timing = dict(kernels=out.ms_kernels, k_family=out.ms_k_family, k_emit=out.ms_k_emit, full_columns=int(out.ms_emit))
         return DeviceOutput(out.data, int(out.data_len), int(out.count), int(n_def.value), d_def.value)
 
     def simulate_on_device(self, n_families, family_size=3, read_length=150, seed=42, **kw) -> "DeviceGroupedReads":

@@ -260,6 +260,7 @@ int fgx_process_batch_device(fgx_caller* c, const void* d_records, uint64_t reco
     out->data = fr.d_out; out->data_len = fr.out_len; out->count = fr.count;
     for (int i = 0; i < FGX_STATS_LEN; i++) out->stats[i] = fr.stats[i];
     out->ms_kernels = fr.ms_kernels; out->ms_k_family = fr.ms_k_family; out->ms_k_emit = fr.ms_k_emit;
+    out->ms_emit = (double)fr.full_items;   /* device path: number of columns that needed call_full (diagnostic) */
     if (n_deferred) *n_deferred = fr.n_deferred;
     if (d_deferred_groups) *d_deferred_groups = fr.d_deferred;
     return 0;

@@ -216,9 +216,10 @@ struct ColumnAcc {
       double t = s[lane] + y;
       c[lane] = (t - s[lane]) - y;
       s[lane] = t;
+      obs[lane] += (lane == idx) ? 1u : 0u;     // no dynamic register indexing (would spill to scratch)
     }
-    obs[idx] += 1;
   }
+  FGX_HD uint32_t obs_of(int idx) const { return idx == 0 ? obs[0] : idx == 1 ? obs[1] : idx == 2 ? obs[2] : idx == 3 ? obs[3] : 0u; }
   FGX_HD uint32_t contributions() const { return obs[0] + obs[1] + obs[2] + obs[3]; }
 };
 
@@ -258,6 +259,13 @@ FGX_HD void call_full(const ConsensusTables& T, const double* ll, int* base_idx,
   double ln_final = ln_error_prob_two_trials(T.ln_error_pre_umi, ln_cons_err, nullptr);
   *base_idx = max_idx;
   *qual = ln_prob_to_phred(ln_final);
+}
+
+// call() without the call_full leg: true when the answer is established (no observations, or the
+// unanimous fast path's sufficient condition holds); false → the column needs call_full.
+FGX_HD bool column_call_fast(const ConsensusTables& T, const double* ll, const uint32_t* obs, int* base_idx, uint8_t* qual) {
+  if (obs[0] + obs[1] + obs[2] + obs[3] == 0) { *base_idx = -1; *qual = FGX_MIN_PHRED; return true; }
+  return unanimous_fast_path(T, ll, obs, base_idx, qual);
 }
 
 // ConsensusBaseBuilder::call

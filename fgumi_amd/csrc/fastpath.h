@@ -20,6 +20,14 @@ struct EndDesc {            // one consensus read (a family end), written by k_f
   char rx[FAST_RX_CAP];
 };
 
+struct FullItem {           // a column (or UMI character) whose call needs the full log-sum-exp chain
+  uint64_t dest;            // bit 63 clear: scratch column index; set: (slot << 8 | char index) of an RX character
+  double ll[4];
+  uint32_t obs;             // per-base observation counts, one byte each (A,C,G,T)
+  uint32_t _pad;
+};
+constexpr int N_LISTS = 1024;
+
 struct FastParams {
   const uint8_t* blob; const uint64_t* rec_off; const uint32_t* rec_len; const uint32_t* grp_first;
   uint32_t g0;
@@ -30,12 +38,14 @@ struct FastParams {
   uint32_t prefix_len, rg_len;
   EndDesc* ends; uint64_t* rec_sizes;
   uint8_t* col_code; uint8_t* col_qual; uint16_t* col_depth; uint16_t* col_err;
-  unsigned long long* col_cursor; uint64_t col_capacity;
+  const uint64_t* col_base;        // per-group first scratch column (exclusive scan of the column bound)
   unsigned long long* stats;
   uint32_t* deferred; uint32_t* n_deferred;
   const uint32_t* group_list;      // nullptr: group = g0 + blockIdx.x
   uint32_t* retry; uint32_t* n_retry;   // families needing more LDS than this launch provides (nullptr: defer them)
   uint32_t lds_tile_bytes;
+  uint32_t lds_wave_bytes;
+  FullItem* full_items; uint32_t* full_count; uint32_t full_cap;   // N_LISTS append lists of `full_cap` items each
 };
 
 struct EmitParams {
@@ -51,14 +61,15 @@ struct FastResult {
   uint64_t stats[FGX_STATS_LEN];
   uint32_t n_deferred; const uint32_t* d_deferred;
   const uint64_t* d_out_off;     // byte offset of each of the 3*n_grp slots in d_out
-  double ms_kernels, ms_k_family, ms_k_emit; uint64_t cols_used;
+  double ms_kernels, ms_k_family, ms_k_emit; uint64_t cols_used; uint64_t full_items;
 };
 
 struct FastPath {
   DevBuf d_ends, d_sizes, d_offsets, d_code, d_qual, d_depth, d_err, d_misc, d_deferred, d_out, d_scan_tmp, d_strings;
   uint32_t lds_tile_bytes = 12288;        // first launch: tiles of the common small families
   uint32_t lds_tile_bytes_large = 49152;  // second launch over the families that did not fit
-  DevBuf d_retry;
+  DevBuf d_retry, d_bound, d_colbase, d_statslots, d_full_items, d_full_count;
+  uint32_t lds_wave_bytes = 6144;         // wave-per-family kernel: LDS copy of one family's raw records
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   int run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const uint64_t* d_rec_off, const uint32_t* d_rec_len, uint32_t n_rec,
           const uint32_t* d_grp_first, uint32_t n_grp, FastResult* res);

@@ -38,6 +38,7 @@ namespace {
 constexpr int NT = 256;                 // threads per family workgroup
 constexpr int FAST_MAX_READS = 128;     // per-read LDS tables
 constexpr int MAX_MC_OPS = 8;
+constexpr int STAT_SLOTS = 1024;        // spread the per-batch counters over many addresses (atomic contention)
 
 struct ReadInfo {          // LDS, one per record of the family
   uint64_t goff;           // record body offset in the blob
@@ -103,9 +104,10 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
   // ---- group-level short circuit (simplex.rs:673-683) ---------------------------------------------
   if (n < P.min_reads) {
     if (tid == 0) {
-      atomicAdd(&P.stats[0], (unsigned long long)n);
-      atomicAdd(&P.stats[2], (unsigned long long)n);
-      atomicAdd(&P.stats[3 + FGX_REJ_INSUFFICIENT_READS], (unsigned long long)n);
+      unsigned long long* st = P.stats + (size_t)(blockIdx.x & (STAT_SLOTS - 1)) * 32;
+      atomicAdd(&st[0], (unsigned long long)n);
+      atomicAdd(&st[2], (unsigned long long)n);
+      atomicAdd(&st[3 + FGX_REJ_INSUFFICIENT_READS], (unsigned long long)n);
     }
     return;
   }
@@ -436,11 +438,7 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
       uint32_t total = 0;
       for (uint32_t k = 0; k < ne; k++) { S.end_coloff[k] = total; total += S.end_len[k]; }
       S.n_ends = ne;
-      if (total) {
-        unsigned long long base = atomicAdd(P.col_cursor, (unsigned long long)total);
-        if (base + total > P.col_capacity) defer(S);
-        S.col_base = base;
-      }
+      S.col_base = P.col_base[g];   // deterministic scratch slot: exclusive scan of the per-family column bound
       // UMIs carried by the kept reads of each end (vanilla_caller.rs:1842-1856)
       for (uint32_t k = 0; k < ne && !S.defer; k++) {
         uint32_t cnt = 0, len0 = 0, firstr = 0;
@@ -501,7 +499,7 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
       uint8_t q;
       column_call(T->t, acc.s, acc.obs, &bi, &q);
       depth = acc.contributions();
-      err = depth - (bi >= 0 ? acc.obs[bi] : 0);
+      err = depth - acc.obs_of(bi);
       const uint8_t LANE_CODE[4] = {1, 2, 4, 8};
       uint8_t code = bi >= 0 ? LANE_CODE[bi] : 15;
       if (depth < P.min_reads) { ob = 15; oq = 0; }
@@ -581,7 +579,536 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
     P.ends[slot0 + D.type] = D;
     P.rec_sizes[slot0 + D.type] = (uint64_t)size + 4;
   }
-  if (tid < FGX_STATS_LEN && S.stats[tid]) atomicAdd(&P.stats[tid], (unsigned long long)S.stats[tid]);
+  if (tid < FGX_STATS_LEN && S.stats[tid]) atomicAdd(&P.stats[(size_t)(blockIdx.x & (STAT_SLOTS - 1)) * 32 + tid], (unsigned long long)S.stats[tid]);
+}
+
+// -----------------------------------------------------------------------------------------------------
+// k_family_wave — the common case: ONE WAVEFRONT PER FAMILY (≤ 64 records whose raw bytes fit the wave's
+// LDS slice).  The family's records are contiguous in the BAM stream, so the wave copies that byte span
+// into LDS with coalesced 16-byte loads (one pass over HBM at full line efficiency) and then does ALL
+// parsing, aux-tag walking, overlap correction and column reads out of LDS.  Lane r owns record r; per-read
+// state lives in lane r's registers and is broadcast with v_readlane, the family gates are ballots and
+// popcounts — no serial lane-0 section and no block barrier.  Semantics identical to k_family below.
+// -----------------------------------------------------------------------------------------------------
+constexpr int WAVES_PER_BLOCK = 4;
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ uint32_t rlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) { for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_xor(v, o); v = t > v ? t : v; } return v; }
+__device__ __forceinline__ uint32_t wave_min(uint32_t v) { for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_xor(v, o); v = t < v ? t : v; } return v; }
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
+__device__ __forceinline__ unsigned long long wave_max64(unsigned long long v) { for (int o = 32; o > 0; o >>= 1) { unsigned long long t = __shfl_xor(v, o); v = t > v ? t : v; } return v; }
+__device__ __forceinline__ unsigned long long wave_min64(unsigned long long v) { for (int o = 32; o > 0; o >>= 1) { unsigned long long t = __shfl_xor(v, o); v = t < v ? t : v; } return v; }
+__device__ __forceinline__ uint8_t comp_code(uint8_t c) { return (uint8_t)((0xF7B3D591E6A2C480ULL >> (4 * (c & 15))) & 15); }
+
+__global__ __launch_bounds__(256) void k_family_wave(FastParams P, uint32_t n_grp_total) {
+  extern __shared__ __align__(16) uint8_t dyn[];
+  __shared__ ConsensusTables sT;     // Phred tables: 3 KB, shared by the block's four families
+  {
+    const uint64_t* src = (const uint64_t*)&P.T->t;
+    uint64_t* dst = (uint64_t*)&sT;
+    for (uint32_t i = threadIdx.x; i < sizeof(ConsensusTables) / 8; i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t g = P.g0 + blockIdx.x * WAVES_PER_BLOCK + wv;
+  if (g >= n_grp_total) return;
+  uint8_t* W = dyn + (size_t)wv * P.lds_wave_bytes;
+  const uint32_t my_list = blockIdx.x & (N_LISTS - 1);
+  bool list_overflow = false;
+  // wave-aggregated append of the columns whose call needs call_full (processed densely by k_call_full)
+  auto push_full = [&](bool need, uint64_t dest, const double* ll, const uint32_t* obs) {
+    bool pending = need;
+    uint32_t l = my_list;
+    for (uint32_t tries = 0;; tries++) {           // a full list chains to the next one; only a globally full pool overflows
+      unsigned long long m = __ballot(pending);
+      if (!m) break;
+      if (tries >= N_LISTS) { list_overflow |= pending; break; }
+      uint32_t cnt = (uint32_t)__popcll(m), leader = (uint32_t)__builtin_ctzll(m);
+      uint32_t base = 0;
+      if (lane == leader) base = atomicAdd(&P.full_count[l], cnt);
+      base = __shfl(base, leader);
+      if (pending) {
+        uint32_t idx = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+        if (idx < P.full_cap) {
+          FullItem* it = &P.full_items[(size_t)l * P.full_cap + idx];
+          it->dest = dest; it->ll[0] = ll[0]; it->ll[1] = ll[1]; it->ll[2] = ll[2]; it->ll[3] = ll[3];
+          it->obs = obs[0] | (obs[1] << 8) | (obs[2] << 16) | (obs[3] << 24);
+          pending = false;
+        }
+      }
+      l = (l + 1) & (N_LISTS - 1);
+    }
+  };
+  unsigned long long* st = P.stats + (size_t)(blockIdx.x & (STAT_SLOTS - 1)) * 32;
+  const uint32_t r0 = P.grp_first[g], n = P.grp_first[g + 1] - r0;
+  const uint32_t slot0 = 3 * g;
+  if (lane < 3) { P.ends[slot0 + lane].valid = 0; P.rec_sizes[slot0 + lane] = 0; }
+
+  if (n < P.min_reads) {   // simplex.rs:673-683
+    if (lane == 0) { atomicAdd(&st[0], (unsigned long long)n); atomicAdd(&st[2], (unsigned long long)n); atomicAdd(&st[3 + FGX_REJ_INSUFFICIENT_READS], (unsigned long long)n); }
+    return;
+  }
+  auto to_retry = [&]() { if (lane == 0) { uint32_t k = atomicAdd(P.n_retry, 1u); P.retry[k] = g; } };
+  auto to_defer = [&]() { if (lane == 0) { uint32_t k = atomicAdd(P.n_deferred, 1u); P.deferred[k] = g; } };
+  if (n > 64) { to_retry(); return; }
+
+  // ---- 1. stage the family's raw records into LDS ------------------------------------------------------
+  const bool act = lane < n;
+  unsigned long long off = act ? P.rec_off[r0 + lane] : ~0ull;
+  uint32_t len = act ? P.rec_len[r0 + lane] : 0;
+  unsigned long long lo_off = wave_min64(off);
+  unsigned long long hi_end = wave_max64(act ? off + len : 0ull);
+  if (__any(act && len < 32)) { to_defer(); return; }
+  unsigned long long base16 = lo_off & ~15ull;
+  unsigned long long span = hi_end - base16;
+  if (span > (unsigned long long)P.lds_wave_bytes) { to_retry(); return; }
+  const uint32_t span16 = ((uint32_t)span + 15) & ~15u;
+  {
+    const uint8_t* src = P.blob + base16;
+    for (uint32_t i = lane * 16; i < span16; i += 64 * 16) *(uint4*)(W + i) = *(const uint4*)(src + i);
+  }
+  wave_sync();
+
+  // ---- 2. parse: lane r owns record r ---------------------------------------------------------------------
+  const uint32_t lo = act ? (uint32_t)(off - base16) : 0;       // LDS offset of this lane's record
+  auto b8 = [&](uint32_t o) -> uint32_t { return W[o]; };
+  auto b16 = [&](uint32_t o) -> uint32_t { return (uint32_t)W[o] | ((uint32_t)W[o + 1] << 8); };
+  auto b32 = [&](uint32_t o) -> uint32_t { return (uint32_t)W[o] | ((uint32_t)W[o + 1] << 8) | ((uint32_t)W[o + 2] << 16) | ((uint32_t)W[o + 3] << 24); };
+  uint32_t flags = 0, l_seq = 0, seq_lo = 0, qual_lo = 0, name_len = 0, clip = 0, hash = 0;
+  int32_t pos = 0, ref_id = 0;
+  uint32_t mi_lo = 0, mi_len = 0, rx_lo = 0, rx_len = 0, cb_lo = 0, cb_len = 0;   // LDS offsets of tag values
+  bool has_mi = false, has_rx = false, has_cb = false, excluded = false, bad = false;
+  if (act) {
+    uint32_t l_name = b8(lo + 8), n_cig = b16(lo + 12);
+    l_seq = b32(lo + 16);
+    flags = b16(lo + 14);
+    unsigned long long seq_off = 32ull + l_name + 4ull * n_cig;
+    unsigned long long qual_off = seq_off + ((unsigned long long)l_seq + 1) / 2;
+    unsigned long long aux_off = qual_off + l_seq;
+    if (aux_off > len || l_seq > 65535 || l_name == 0) bad = true;
+    else {
+      name_len = l_name - 1;
+      pos = (int32_t)b32(lo + 4); ref_id = (int32_t)b32(lo);
+      seq_lo = lo + (uint32_t)seq_off; qual_lo = lo + (uint32_t)qual_off;
+      excluded = (flags & (bam::F_SECONDARY | bam::F_SUPPLEMENTARY)) != 0;
+      uint32_t op = 0;
+      if (!excluded) {
+        if ((flags & bam::F_UNMAPPED) || n_cig != 1 || l_seq == 0 || pos < 0) bad = true;
+        else {
+          op = b32(lo + 32 + l_name);
+          uint32_t ty = op & 15;
+          if (!(ty == 0 || ty == 7 || ty == 8) || (op >> 4) != l_seq) bad = true;
+        }
+      }
+      // aux walk in LDS (tags.rs:13-34): first occurrence of MC / <tag> / RX / <cell tag>
+      const uint32_t a0 = lo + (uint32_t)aux_off, an = len - (uint32_t)aux_off;
+      uint32_t q = 0, mc_lo = 0, mc_len = 0;
+      bool has_mc = false, seen_mc = false, seen_mi = false, seen_rx = false, seen_cb = false;
+      while (q + 3 <= an) {
+        uint32_t t0 = W[a0 + q], t1 = W[a0 + q + 1], vt = W[a0 + q + 2];
+        uint32_t size = 0;
+        int fixed = bam::tag_fixed_size((uint8_t)vt);
+        int64_t zend = -1;
+        bool stop = false;
+        if (fixed > 0) size = (uint32_t)fixed;
+        else if (vt == 'Z' || vt == 'H') { zend = bam::find_nul(W + a0 + q + 3, an - (q + 3)); if (zend < 0) break; size = (uint32_t)zend + 1; }
+        else if (vt == 'B') {
+          if (an - (q + 3) < 5) break;
+          int es = bam::tag_fixed_size(W[a0 + q + 3]);
+          if (es == 0) stop = true;
+          else { unsigned long long sz = 5ull + (unsigned long long)b32(a0 + q + 4) * (unsigned long long)es; if (sz > 0xFFFFFFFFull) break; size = (uint32_t)sz; }
+        } else stop = true;
+        bool isz = (vt == 'Z') && !stop;
+        uint32_t vlo = a0 + q + 3;
+        if (!seen_mc && t0 == 'M' && t1 == 'C') { seen_mc = true; if (isz) { has_mc = true; mc_lo = vlo; mc_len = (uint32_t)zend; } }
+        if (!seen_mi && t0 == (uint8_t)P.tag0 && t1 == (uint8_t)P.tag1) { seen_mi = true; if (isz) { if (zend > 255) bad = true; else { has_mi = true; mi_lo = vlo; mi_len = (uint32_t)zend; } } }
+        if (!seen_rx && t0 == 'R' && t1 == 'X') { seen_rx = true; if (isz) { if (zend > 255) bad = true; else { has_rx = true; rx_lo = vlo; rx_len = (uint32_t)zend; } } }
+        if (!seen_cb && P.cell0 && t0 == (uint8_t)P.cell0 && t1 == (uint8_t)P.cell1) { seen_cb = true; if (isz) { if (zend > 255) bad = true; else { has_cb = true; cb_lo = vlo; cb_len = (uint32_t)zend; } } }
+        if (stop) break;
+        unsigned long long nq = (unsigned long long)q + 3 + size;
+        if (nq > an) break;
+        q = (uint32_t)nq;
+      }
+      if (!bad && !excluded) {
+        uint32_t mops[MAX_MC_OPS];
+        bool overflow = false;
+        bam::Rec v{W + lo, len};
+        unsigned long long cl = bam::mate_clip(v, &op, 1, has_mc ? W + mc_lo : nullptr, mc_len, mops, MAX_MC_OPS, &overflow);
+        if (overflow) bad = true;
+        clip = (uint32_t)(cl > 65535 ? 65535 : cl);
+        uint32_t h = 2166136261u;
+        for (uint32_t i = 0; i < name_len; i++) { h ^= W[lo + 32 + i]; h *= 16777619u; }
+        hash = h;
+      }
+    }
+  }
+  // first record must carry the MI tag and give a legal read name (vanilla_caller.rs:1897-1908, 1795-1797)
+  const uint32_t mi0_lo = rlane(mi_lo, 0), mi0_len = rlane(mi_len, 0);
+  if (lane == 0 && (!has_mi || P.prefix_len + 1 + mi_len >= 255)) bad = true;
+  // absent qualities (all 0xFF) are a fatal input error (:1119-1124)
+  if (act && !bad && !excluded && W[qual_lo] == 0xFF) {
+    bool all = true;
+    for (uint32_t i = 0; i < l_seq; i++) if (W[qual_lo + i] != 0xFF) { all = false; break; }
+    if (all) bad = true;
+  }
+  if (__any(bad)) { to_defer(); return; }
+  const bool cand = act && !excluded;
+  const bool rev = (flags & bam::F_REVERSE) != 0;
+  const unsigned long long rxmask = __ballot(cand && has_rx), cbmask = __ballot(cand && has_cb);
+
+  // ---- 3. overlapping-bases pre-correction in LDS (overlapping.rs:236-336, 627-684) ----------------------
+  uint32_t ov_bases = 0, ov_agree = 0, ov_dis = 0, ov_corr = 0;
+  if (P.overlap) {
+    const bool is_r1 = cand && (flags & bam::F_FIRST);
+    const bool is_r2 = cand && !(flags & bam::F_FIRST) && (flags & bam::F_LAST);
+    // pair map: per name, the LAST R1-type and the LAST R2-type primary record
+    int mate = -1;
+    bool later_r1 = false;
+    const unsigned long long r1mask = __ballot(is_r1), r2mask = __ballot(is_r2);
+    for (uint32_t u = 0; u < n; u++) {
+      uint32_t hu = rlane(hash, u), nlu = rlane(name_len, u), lou = rlane(lo, u);
+      bool u_r1 = (r1mask >> u) & 1, u_r2 = (r2mask >> u) & 1;
+      if (!is_r1 || (!u_r1 && !u_r2) || hu != hash || nlu != name_len) continue;
+      bool same = true;
+      for (uint32_t i = 0; i < name_len; i++) if (W[lou + 32 + i] != W[lo + 32 + i]) { same = false; break; }
+      if (!same) continue;
+      if (u_r1 && u > lane) later_r1 = true;
+      if (u_r2) mate = (int)u;
+    }
+    if (later_r1) mate = -1;
+    unsigned long long pm = __ballot(mate >= 0);
+    for (; pm; pm &= pm - 1) {
+      uint32_t a = (uint32_t)__builtin_ctzll(pm);
+      uint32_t b = rlane((uint32_t)mate, a);
+      int32_t pa = (int32_t)rlane((uint32_t)pos, a), pb = (int32_t)rlane((uint32_t)pos, b);
+      if ((int32_t)rlane((uint32_t)ref_id, a) != (int32_t)rlane((uint32_t)ref_id, b)) continue;
+      uint32_t la = rlane(l_seq, a), lb2 = rlane(l_seq, b);
+      uint32_t sa = rlane(seq_lo, a), sb = rlane(seq_lo, b), qa0 = rlane(qual_lo, a), qb0 = rlane(qual_lo, b);
+      long long s1 = (long long)pa + 1, e1 = (long long)pa + la, s2 = (long long)pb + 1, e2 = (long long)pb + lb2;
+      long long lox = s1 > s2 ? s1 : s2, hix = e1 < e2 ? e1 : e2;
+      for (long long x = lox + lane; x <= hix; x += 64) {
+        uint32_t i1 = (uint32_t)(x - s1), i2 = (uint32_t)(x - s2);
+        uint32_t o1 = sa + (i1 >> 1), o2 = sb + (i2 >> 1);
+        uint8_t c1 = (i1 & 1) ? (W[o1] & 15) : (W[o1] >> 4), c2 = (i2 & 1) ? (W[o2] & 15) : (W[o2] >> 4);
+        if (c1 == 15 || c2 == 15) continue;
+        ov_bases++;
+        uint8_t qa = W[qa0 + i1], qb = W[qb0 + i2];
+        if (c1 == c2) {
+          ov_agree++;
+          uint32_t sm = (uint32_t)qa + qb;
+          uint8_t nq = (uint8_t)(sm < 93 ? sm : 93);
+          W[qa0 + i1] = nq; W[qb0 + i2] = nq;
+          if (nq != qa || nq != qb) ov_corr++;
+        } else {
+          ov_dis++;
+          uint8_t cb, cq;
+          if (qa == qb) { cb = 15; cq = FGX_MIN_PHRED; }
+          else if (qa > qb) { cb = c1; cq = (uint8_t)(qa - qb); if (cq < FGX_MIN_PHRED) cq = FGX_MIN_PHRED; }
+          else { cb = c2; cq = (uint8_t)(qb - qa); if (cq < FGX_MIN_PHRED) cq = FGX_MIN_PHRED; }
+          // nibble updates: neighbouring lanes own the other nibble of the same byte → 32-bit LDS atomics
+          auto setn = [&](uint32_t o, uint32_t idx, uint8_t code) {
+            uint32_t* w = (uint32_t*)(W + (o & ~3u));
+            uint32_t sh = 8 * (o & 3) + ((idx & 1) ? 0 : 4);
+            atomicAnd(w, ~(0xFu << sh));
+            atomicOr(w, (uint32_t)code << sh);
+          };
+          setn(o1, i1, cb); setn(o2, i2, cb);
+          W[qa0 + i1] = cq; W[qb0 + i2] = cq;
+          ov_corr += 2;
+        }
+      }
+      wave_sync();
+    }
+  }
+  wave_sync();
+
+  // oriented, mask-aware view of one read (given its uniform descriptors) at consensus position p
+  auto view = [&](uint32_t s_lo, uint32_t q_lo, uint32_t L, bool rv, uint32_t trim_to, uint32_t p, uint8_t* code, uint8_t* qual) {
+    uint32_t idx = rv ? L - 1 - p : p;
+    uint8_t bb = W[s_lo + (idx >> 1)];
+    uint8_t c = (idx & 1) ? (bb & 15) : (bb >> 4);
+    uint8_t q = W[q_lo + idx];
+    if (rv) c = comp_code(c);
+    if (p < trim_to && q < P.min_input_bq) { c = 15; q = FGX_MIN_PHRED; }
+    *code = c; *qual = q;
+  };
+
+  // ---- 4. source-read geometry per lane (vanilla_caller.rs:1129-1160) -----------------------------------------
+  uint32_t trim_to = l_seq, final_len = 0;
+  if (cand) {
+    if (P.trim) {
+      uint32_t tq = P.min_input_bq;
+      if (tq < 1 || l_seq == 0) trim_to = 0;
+      else {
+        int32_t score = 0, max_score = 0;
+        uint32_t point = l_seq;
+        for (uint32_t i = l_seq; i-- > 0;) {
+          uint32_t idx = rev ? l_seq - 1 - i : i;
+          score += (int32_t)tq - (int32_t)W[qual_lo + idx];
+          if (score < 0) break;
+          if (score > max_score) { max_score = score; point = i; }
+        }
+        trim_to = point;
+      }
+    }
+    uint32_t clip_pos = l_seq > clip ? l_seq - clip : 0;
+    uint32_t fl = clip_pos < trim_to ? clip_pos : trim_to;
+    while (fl > 0) {
+      uint8_t c, q;
+      view(seq_lo, qual_lo, l_seq, rev, trim_to, fl - 1, &c, &q);
+      if (c != 15) break;
+      fl--;
+    }
+    final_len = fl;
+  }
+
+  // ---- 5. family gates with ballots (process_group :1329-1422, process_subgroup :1454-1646) -----------------
+  uint32_t s_total = n, s_cons = 0, s_filtered = 0, s_sec = 0, s_insuf = 0, s_zero = 0, s_orphan = 0;
+  const uint32_t n_sec = (uint32_t)__popcll(__ballot(act && excluded));
+  const uint32_t n_reads = n - n_sec;
+  if (n_sec) { s_filtered += n_sec; s_sec = n_sec; }
+  bool go = n_reads > 0;
+  if (go && n_reads < P.min_reads) { s_filtered += n_reads; s_insuf += n_reads; go = false; }
+  uint32_t my_end = 255;
+  if (cand) { if (!(flags & bam::F_PAIRED)) my_end = 0; else if (flags & bam::F_FIRST) my_end = 1; else if (flags & bam::F_LAST) my_end = 2; }
+  bool ok[3] = {false, false, false};
+  unsigned long long mem[3] = {0, 0, 0};
+  uint32_t surv[3] = {0, 0, 0}, clen[3] = {0, 0, 0};
+  bool need_defer = false;
+  if (go) {
+#pragma unroll
+    for (uint32_t e = 0; e < 3; e++) {
+      unsigned long long in_e = __ballot(my_end == e);
+      uint32_t cnt = (uint32_t)__popcll(in_e);
+      if (cnt == 0) continue;
+      if (cnt < P.min_reads) { s_filtered += cnt; s_insuf += cnt; continue; }
+      unsigned long long kept = __ballot(my_end == e && final_len > 0);
+      uint32_t rem = (uint32_t)__popcll(kept), zero = cnt - rem;
+      if (zero) { s_filtered += zero; s_zero += zero; }
+      if (rem < P.min_reads) { if (rem) { s_filtered += rem; s_insuf += rem; } continue; }
+      if (P.max_reads >= 0 && (long long)rem > P.max_reads) { need_defer = true; break; }
+      // consensus length = min_reads-th longest kept read
+      uint32_t ge = 0;
+      for (unsigned long long m = kept; m; m &= m - 1) { uint32_t fj = rlane(final_len, (uint32_t)__builtin_ctzll(m)); ge += (fj >= final_len) ? 1 : 0; }
+      bool mine = (kept >> lane) & 1;
+      clen[e] = wave_max((mine && ge >= P.min_reads) ? final_len : 0);
+      mem[e] = kept; surv[e] = rem; ok[e] = true;
+    }
+  }
+  if (need_defer) { to_defer(); return; }
+  uint32_t ne = 0, e_type[3], e_len[3], e_coloff[3];
+  unsigned long long e_mem[3];
+  if (ok[0]) { s_cons += 1; e_type[ne] = 0; e_len[ne] = clen[0]; e_mem[ne] = mem[0]; ne++; }
+  if (ok[1] && ok[2]) { s_cons += 2; e_type[ne] = 1; e_len[ne] = clen[1]; e_mem[ne] = mem[1]; ne++; e_type[ne] = 2; e_len[ne] = clen[2]; e_mem[ne] = mem[2]; ne++; }
+  else if (ok[1]) { s_filtered += surv[1]; s_orphan += surv[1]; }
+  else if (ok[2]) { s_filtered += surv[2]; s_orphan += surv[2]; }
+  uint32_t total_cols = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < 3; k++) if (k < ne) { e_coloff[k] = total_cols; total_cols += e_len[k]; }
+
+  // UMIs carried by the kept reads of each end; unequal lengths → consensus_umis panics → general path
+  uint32_t e_rx_cnt[3] = {0, 0, 0}, e_rx_len[3] = {0, 0, 0}, e_rx_first[3] = {0, 0, 0};
+#pragma unroll
+  for (uint32_t k = 0; k < 3; k++) {
+    if (k >= ne) break;
+    unsigned long long with = e_mem[k] & rxmask;
+    uint32_t cnt = (uint32_t)__popcll(with);
+    e_rx_cnt[k] = cnt;
+    if (cnt) {
+      uint32_t f = (uint32_t)__builtin_ctzll(with);
+      e_rx_first[k] = f; e_rx_len[k] = rlane(rx_len, f);
+      if (__any(((with >> lane) & 1) && rx_len != e_rx_len[k])) need_defer = true;
+      if (e_rx_len[k] > FAST_RX_CAP) need_defer = true;
+    }
+  }
+  if (need_defer) { to_defer(); return; }
+
+  // ---- 6. consensus columns: one lane per column, member reads walked in file order -------------------------
+  const DeviceTables* T = P.T;
+  const uint64_t col_base = P.col_base[g];
+#pragma unroll
+  for (uint32_t k = 0; k < 3; k++) {
+    if (k >= ne) break;
+    const unsigned long long members = e_mem[k];
+    const uint32_t mc = (uint32_t)__popcll(members);
+    for (uint32_t p = lane; p < e_len[k]; p += 64) {
+      uint8_t ob, oq;
+      uint32_t depth, err;
+      if (mc == 1) {   // single-read consensus: LUT keyed by the unclamped quality (:1677-1708)
+        uint32_t r = (uint32_t)__builtin_ctzll(members);
+        uint8_t code, q;
+        view(rlane(seq_lo, r), rlane(qual_lo, r), rlane(l_seq, r), (rlane(flags, r) & bam::F_REVERSE) != 0, rlane(trim_to, r), p, &code, &q);
+        uint8_t adj = q < 94 ? T->single_input_quals[q] : 0;
+        if (adj < P.min_cons_bq) { ob = 15; oq = FGX_MIN_PHRED; } else { ob = code; oq = adj; }
+        depth = code != 15 ? 1 : 0;
+        err = 0;
+      } else {
+        ColumnAcc acc;
+        acc.reset();
+        for (unsigned long long m = members; m; m &= m - 1) {
+          uint32_t r = (uint32_t)__builtin_ctzll(m);
+          uint32_t fl = rlane(final_len, r);
+          if (p < fl) {
+            uint8_t code, q;
+            view(rlane(seq_lo, r), rlane(qual_lo, r), rlane(l_seq, r), (rlane(flags, r) & bam::F_REVERSE) != 0, rlane(trim_to, r), p, &code, &q);
+            int bl = bam::code_to_lane(code);
+            if (bl != 255) {
+              uint32_t qq = q < FGX_MAX_PHRED ? q : FGX_MAX_PHRED;
+              acc.add(bl, sT.correct[qq], sT.error_per_alt[qq]);
+            }
+          }
+        }
+        int bi;
+        uint8_t q;
+        bool resolved = column_call_fast(sT, acc.s, acc.obs, &bi, &q);
+        depth = acc.contributions();
+        uint64_t o = col_base + e_coloff[k] + p;
+        uint32_t d16 = depth < 32767u ? depth : 32767u;
+        P.col_depth[o] = (uint16_t)d16;
+        push_full(!resolved, o, acc.s, acc.obs);
+        if (!resolved) continue;           // code / qual / errors arrive from k_call_full
+        err = depth - acc.obs_of(bi);
+        uint8_t code = bi >= 0 ? (uint8_t)(1u << bi) : 15;
+        if (depth < P.min_reads) { ob = 15; oq = 0; }
+        else if (q < P.min_cons_bq) { ob = 15; oq = FGX_MIN_PHRED; }
+        else { ob = code; oq = q; }
+        uint32_t e16 = err < 32767u ? err : 32767u;
+        P.col_code[o] = ob; P.col_qual[o] = oq; P.col_err[o] = (uint16_t)e16;
+        continue;
+      }
+      uint32_t d16 = depth < 32767u ? depth : 32767u, e16 = err < 32767u ? err : 32767u;
+      uint64_t o = col_base + e_coloff[k] + p;
+      P.col_code[o] = ob; P.col_qual[o] = oq; P.col_depth[o] = (uint16_t)d16; P.col_err[o] = (uint16_t)e16;
+    }
+  }
+
+  // ---- 7. consensus UMI per end (simple_umi.rs:46-117) ---------------------------------------------------------
+  const DeviceTables* TU = P.TU;
+  char my_rx[3] = {0, 0, 0};      // lane i holds character i of each end's consensus UMI
+  bool rx_bad = false;
+#pragma unroll
+  for (uint32_t k = 0; k < 3; k++) {
+    if (k >= ne) break;
+    if (e_rx_cnt[k] == 0) continue;                     // uniform
+    const bool mychar = lane < e_rx_len[k];
+    if (e_rx_cnt[k] == 1) { if (mychar) my_rx[k] = (char)W[rlane(rx_lo, e_rx_first[k]) + lane]; continue; }
+    ColumnAcc acc;
+    acc.reset();
+    uint32_t non_dna = 0, seen = 0;
+    uint8_t fc = 0;
+    bool mixed = false;
+    for (unsigned long long m = e_mem[k] & rxmask; m; m &= m - 1) {
+      uint32_t r = (uint32_t)__builtin_ctzll(m);
+      uint8_t ch = mychar ? W[rlane(rx_lo, r) + lane] : (uint8_t)'A';
+      if (seen == 0) fc = ch;
+      seen++;
+      uint8_t up = (ch >= 'a' && ch <= 'z') ? (uint8_t)(ch - 32) : ch;
+      bool dna = up == 'A' || up == 'C' || up == 'G' || up == 'T' || up == 'N';
+      if (dna) { int bl = bam::ascii_to_lane(ch); if (bl != 255) acc.add(bl, TU->t.correct[20], TU->t.error_per_alt[20]); }
+      else { non_dna++; if (ch != fc) mixed = true; }
+    }
+    bool need_full = false;
+    if (!mychar) { /* lanes past the UMI length only take part in the ballots below */ }
+    else if (non_dna == 0) {
+      int bi; uint8_t q;
+      bool resolved = column_call_fast(TU->t, acc.s, acc.obs, &bi, &q);
+      my_rx[k] = bi >= 0 ? "ACGT"[bi] : 'N';
+      need_full = !resolved;
+    }
+    else if (non_dna == seen && !mixed) my_rx[k] = (char)fc;
+    else rx_bad = true;
+    if (!mychar) { need_full = false; rx_bad = false; }
+    push_full(need_full, (1ull << 63) | ((uint64_t)(slot0 + e_type[k]) << 8) | lane, acc.s, acc.obs);
+  }
+  if (__any(rx_bad) || __any(list_overflow)) { to_defer(); return; }
+
+  // ---- 8. descriptors + stats ---------------------------------------------------------------------------------------
+#pragma unroll
+  for (uint32_t k = 0; k < 3; k++) {
+    if (k >= ne) break;
+    uint32_t Lc = e_len[k];
+    uint32_t slot = slot0 + e_type[k];
+    EndDesc* D = &P.ends[slot];
+    if (lane < e_rx_len[k] && e_rx_cnt[k]) D->rx[lane] = my_rx[k];
+    uint32_t fk = (uint32_t)__builtin_ctzll(e_mem[k]);     // first retained read (cell barcode source)
+    uint32_t fk_has_cb = (uint32_t)((cbmask >> fk) & 1), fk_cb_lo = rlane(cb_lo, fk), fk_cb_len = rlane(cb_len, fk), fk_lo = rlane(lo, fk);
+    if (lane == 0) {
+      D->col_off = col_base + e_coloff[k];
+      D->cons_len = Lc;
+      D->first_rec = r0; D->first_kept_rec = r0 + fk;
+      D->type = (uint8_t)e_type[k];
+      D->mi_off = (uint16_t)(mi0_lo - lo); D->mi_len = (uint8_t)mi0_len;          // lane 0: lo = record 0
+      bool hcb = P.cell0 && fk_has_cb;
+      D->has_cb = hcb ? 1 : 0; D->cb_off = (uint16_t)(fk_cb_lo - fk_lo); D->cb_len = (uint8_t)fk_cb_len;
+      D->has_rx = e_rx_cnt[k] > 0; D->rx_len = (uint8_t)e_rx_len[k];
+      uint32_t nm = P.prefix_len + 1 + mi0_len;
+      // cD / cM <= member count <= 64 → one-byte int tags (k_emit derives the values from the arrays)
+      uint32_t size = 32 + nm + 1 + (Lc + 1) / 2 + Lc + (3 + P.rg_len + 1) + 4 + 4 + 7 +
+                      (P.per_base_tags ? 2 * (8 + 2 * Lc) : 0) + (3 + mi0_len + 1) + (hcb ? 3 + fk_cb_len + 1 : 0) +
+                      (e_rx_cnt[k] ? 3 + e_rx_len[k] + 1 : 0);
+      D->rec_size = size;
+      D->valid = 1;
+      P.rec_sizes[slot] = (uint64_t)size + 4;
+    }
+  }
+  ov_bases = wave_sum(ov_bases); ov_agree = wave_sum(ov_agree); ov_dis = wave_sum(ov_dis); ov_corr = wave_sum(ov_corr);
+  if (lane == 0) {
+    atomicAdd(&st[0], (unsigned long long)s_total);
+    if (s_cons) atomicAdd(&st[1], (unsigned long long)s_cons);
+    if (s_filtered) atomicAdd(&st[2], (unsigned long long)s_filtered);
+    if (s_sec) atomicAdd(&st[3 + FGX_REJ_SECONDARY_OR_SUPPLEMENTARY], (unsigned long long)s_sec);
+    if (s_insuf) atomicAdd(&st[3 + FGX_REJ_INSUFFICIENT_READS], (unsigned long long)s_insuf);
+    if (s_zero) atomicAdd(&st[3 + FGX_REJ_ZERO_LENGTH_AFTER_TRIMMING], (unsigned long long)s_zero);
+    if (s_orphan) atomicAdd(&st[3 + FGX_REJ_ORPHAN_CONSENSUS], (unsigned long long)s_orphan);
+    if (ov_bases) atomicAdd(&st[24], (unsigned long long)ov_bases);
+    if (ov_agree) atomicAdd(&st[25], (unsigned long long)ov_agree);
+    if (ov_dis) atomicAdd(&st[26], (unsigned long long)ov_dis);
+    if (ov_corr) atomicAdd(&st[27], (unsigned long long)ov_corr);
+  }
+}
+
+// -----------------------------------------------------------------------------------------------------
+// k_call_full — the columns (and UMI characters) the fast path could not establish, compacted by the
+// family kernels into N_LISTS append lists: one lane per item, every lane busy with the full
+// log-sum-exp chain (call_full, base_builder.rs:1023-1054) on the glibc-compatible device libm.
+// -----------------------------------------------------------------------------------------------------
+struct FullParams {
+  const FullItem* items; const uint32_t* count; uint32_t cap;
+  const DeviceTables* T; const DeviceTables* TU;
+  uint32_t min_reads; uint8_t min_cons_bq;
+  uint8_t* col_code; uint8_t* col_qual; uint16_t* col_err;
+  EndDesc* ends;
+};
+
+__global__ __launch_bounds__(256) void k_call_full(FullParams P) {
+  const uint32_t list = blockIdx.y;
+  uint32_t cnt = P.count[list];
+  if (cnt > P.cap) cnt = P.cap;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cnt) return;
+  const FullItem it = P.items[(size_t)list * P.cap + i];
+  const bool is_rx = (it.dest >> 63) != 0;
+  const ConsensusTables& T = is_rx ? P.TU->t : P.T->t;
+  int bi;
+  uint8_t q;
+  call_full(T, it.ll, &bi, &q);
+  if (is_rx) {
+    uint64_t d = it.dest & ~(1ull << 63);
+    P.ends[d >> 8].rx[d & 0xFF] = bi >= 0 ? "ACGT"[bi] : 'N';
+    return;
+  }
+  uint32_t obs[4] = {it.obs & 0xFF, (it.obs >> 8) & 0xFF, (it.obs >> 16) & 0xFF, it.obs >> 24};
+  uint32_t depth = obs[0] + obs[1] + obs[2] + obs[3];
+  uint32_t err = depth - (bi >= 0 ? obs[bi] : 0);
+  uint8_t code = bi >= 0 ? (uint8_t)(1u << bi) : 15, ob, oq;
+  if (depth < P.min_reads) { ob = 15; oq = 0; }
+  else if (q < P.min_cons_bq) { ob = 15; oq = FGX_MIN_PHRED; }
+  else { ob = code; oq = q; }
+  P.col_code[it.dest] = ob; P.col_qual[it.dest] = oq; P.col_err[it.dest] = (uint16_t)(err < 32767u ? err : 32767u);
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -645,14 +1172,28 @@ __global__ __launch_bounds__(256) void k_emit(EmitParams P) {
   if (lane == 0) { q[0] = 'R'; q[1] = 'G'; q[2] = 'Z'; }
   for (uint32_t i = lane; i < P.rg_len + 1; i += 64) q[3 + i] = i < P.rg_len ? (uint8_t)P.rg[i] : 0;
   q += 3 + P.rg_len + 1;
-  n_cd = 3 + int_tag_width(D.maxd);
-  n_cm = 3 + int_tag_width(D.mind);
+  // cD / cM / cE from the per-position arrays (vanilla_caller.rs:1800-1810): max / min depth, Σerrors / Σdepth as f32
+  uint32_t maxd = 0, mind = 0xFFFFFFFFu, sumd = 0, sume = 0;
+  {
+    const uint16_t* cd = P.col_depth + D.col_off;
+    const uint16_t* ce = P.col_err + D.col_off;
+    for (uint32_t i = lane; i < Lc; i += 64) { uint32_t d = cd[i], e = ce[i]; maxd = d > maxd ? d : maxd; mind = d < mind ? d : mind; sumd += d; sume += e; }
+    for (int o = 32; o > 0; o >>= 1) {
+      uint32_t a = __shfl_xor(maxd, o), b = __shfl_xor(mind, o);
+      maxd = a > maxd ? a : maxd; mind = b < mind ? b : mind;
+      sumd += __shfl_xor(sumd, o); sume += __shfl_xor(sume, o);
+    }
+    if (Lc == 0) { maxd = 0; mind = 0; }
+  }
+  const float ce_rate = sumd > 0 ? (float)sume / (float)sumd : 0.0f;
+  n_cd = 3 + int_tag_width(maxd);
+  n_cm = 3 + int_tag_width(mind);
   if (lane == 0) {
     uint32_t w;
-    put_int_tag(q, 'c', 'D', D.maxd, &w);
-    put_int_tag(q + n_cd, 'c', 'M', D.mind, &w);
+    put_int_tag(q, 'c', 'D', maxd, &w);
+    put_int_tag(q + n_cd, 'c', 'M', mind, &w);
     uint8_t* f = q + n_cd + n_cm;
-    uint32_t u = __float_as_uint(D.ce);
+    uint32_t u = __float_as_uint(ce_rate);
     f[0] = 'c'; f[1] = 'E'; f[2] = 'f'; f[3] = (uint8_t)u; f[4] = (uint8_t)(u >> 8); f[5] = (uint8_t)(u >> 16); f[6] = (uint8_t)(u >> 24);
   }
   q += n_cd + n_cm + 7;
@@ -688,18 +1229,22 @@ __global__ __launch_bounds__(256) void k_emit(EmitParams P) {
 // Upper bound on the consensus columns a batch can produce: a family yields at most three ends, each no
 // longer than its longest read, and l_seq <= (block_size - 33) * 2 / 3.
 __global__ void k_col_bound(const uint32_t* __restrict__ grp_first, const uint32_t* __restrict__ rec_len, uint32_t n_grp,
-                            unsigned long long* out) {
+                            uint64_t* __restrict__ bound) {
   uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_grp) return;
+  uint32_t a = grp_first[g], b = grp_first[g + 1], mx = 0;
+  for (uint32_t r = a; r < b; r++) { uint32_t l = rec_len[r]; mx = l > mx ? l : mx; }
+  uint32_t lb = mx > 33 ? (mx - 33) * 2 / 3 + 1 : 1;
+  uint32_t ends = (b - a) < 3 ? (b - a) : 3;
+  bound[g] = (uint64_t)ends * lb;
+}
+
+__global__ void k_reduce_stats(const unsigned long long* __restrict__ slots, unsigned long long* __restrict__ out) {
+  uint32_t k = threadIdx.x;   // one thread per counter
+  if (k >= FGX_STATS_LEN) return;
   unsigned long long v = 0;
-  if (g < n_grp) {
-    uint32_t a = grp_first[g], b = grp_first[g + 1], mx = 0;
-    for (uint32_t r = a; r < b; r++) { uint32_t l = rec_len[r]; mx = l > mx ? l : mx; }
-    uint32_t lb = mx > 33 ? (mx - 33) * 2 / 3 + 1 : 1;
-    uint32_t ends = (b - a) < 3 ? (b - a) : 3;
-    v = (unsigned long long)ends * lb;
-  }
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-  if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
+  for (int i = 0; i < STAT_SLOTS; i++) v += slots[(size_t)i * 32 + k];
+  out[k] = v;
 }
 
 }  // namespace
@@ -709,7 +1254,7 @@ __global__ void k_col_bound(const uint32_t* __restrict__ grp_first, const uint32
 // -----------------------------------------------------------------------------------------------------
 void FastPath::release() {
   for (DevBuf* b : {&d_ends, &d_sizes, &d_offsets, &d_code, &d_qual, &d_depth, &d_err, &d_misc, &d_deferred, &d_out, &d_scan_tmp, &d_strings,
-                    &d_retry})
+                    &d_retry, &d_bound, &d_colbase, &d_statslots, &d_full_items, &d_full_count})
     b->free_();
   for (int i = 0; i < 4; i++) if (ev[i]) { (void)hipEventDestroy(ev[i]); ev[i] = nullptr; }
 }
@@ -732,16 +1277,25 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
   std::string strs = c->prefix + c->rg;
   d_strings.reserve(strs.size() + 16);
   if (!strs.empty()) hip_check(hipMemcpyAsync(d_strings.p, strs.data(), strs.size(), hipMemcpyHostToDevice, s), "H2D strings");
-  // column scratch: sized from a per-family upper bound (k_col_bound)
+  // column scratch: deterministic per-family slots from an exclusive scan of the column bound
   (void)blob_len; (void)n_rec;
   for (int i = 0; i < 4; i++) if (!ev[i]) hip_check(hipEventCreate(&ev[i]), "hipEventCreate");
-  unsigned long long* misc0 = d_misc.as<unsigned long long>();
-  hipLaunchKernelGGL(k_col_bound, dim3((n_grp + 255) / 256), dim3(256), 0, s, d_grp_first, d_rec_len, n_grp, misc0 + 28);
-  uint64_t col_cap = 0;
-  hip_check(hipMemcpyAsync(&col_cap, misc0 + 28, 8, hipMemcpyDeviceToHost, s), "D2H");
+  unsigned long long* misc = d_misc.as<unsigned long long>();
+  d_bound.reserve((size_t)n_grp * 8); d_colbase.reserve((size_t)n_grp * 8);
+  d_statslots.reserve((size_t)STAT_SLOTS * 32 * 8);
+  hip_check(hipMemsetAsync(d_statslots.p, 0, (size_t)STAT_SLOTS * 32 * 8, s), "memset");
+  hipLaunchKernelGGL(k_col_bound, dim3((n_grp + 255) / 256), dim3(256), 0, s, d_grp_first, d_rec_len, n_grp, d_bound.as<uint64_t>());
+  {
+    size_t tb = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_bound.as<uint64_t>(), d_colbase.as<uint64_t>(), (int)n_grp, s);
+    d_scan_tmp.reserve(tb);
+    hip_check(hipcub::DeviceScan::ExclusiveSum(d_scan_tmp.p, tb, d_bound.as<uint64_t>(), d_colbase.as<uint64_t>(), (int)n_grp, s), "scan bound");
+  }
+  uint64_t lastb[2];
+  hip_check(hipMemcpyAsync(&lastb[0], d_colbase.as<uint64_t>() + (n_grp - 1), 8, hipMemcpyDeviceToHost, s), "D2H");
+  hip_check(hipMemcpyAsync(&lastb[1], d_bound.as<uint64_t>() + (n_grp - 1), 8, hipMemcpyDeviceToHost, s), "D2H");
   hip_check(hipStreamSynchronize(s), "sync");
-  hip_check(hipMemsetAsync(misc0 + 28, 0, 8, s), "memset");
-  col_cap += 1024;
+  uint64_t col_cap = lastb[0] + lastb[1] + 64;
   d_code.reserve(col_cap); d_qual.reserve(col_cap); d_depth.reserve(col_cap * 2); d_err.reserve(col_cap * 2);
 
   FastParams P;
@@ -756,30 +1310,56 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
   P.prefix_len = (uint32_t)c->prefix.size(); P.rg_len = (uint32_t)c->rg.size();
   P.ends = d_ends.as<EndDesc>(); P.rec_sizes = d_sizes.as<uint64_t>();
   P.col_code = d_code.as<uint8_t>(); P.col_qual = d_qual.as<uint8_t>(); P.col_depth = d_depth.as<uint16_t>(); P.col_err = d_err.as<uint16_t>();
-  unsigned long long* misc = d_misc.as<unsigned long long>();
-  P.stats = misc; P.col_cursor = misc + 28; P.n_deferred = (uint32_t*)(misc + 29); P.col_capacity = col_cap;
+  P.col_base = d_colbase.as<uint64_t>();
+  P.stats = d_statslots.as<unsigned long long>(); P.n_deferred = (uint32_t*)(misc + 29);
   P.deferred = d_deferred.as<uint32_t>();
-  P.lds_tile_bytes = lds_tile_bytes;
   d_retry.reserve((size_t)n_grp * 4);
   P.retry = d_retry.as<uint32_t>(); P.n_retry = (uint32_t*)(misc + 31);
   P.group_list = nullptr;
+  // append lists for the columns that need call_full: room for 1/8 of the column bound (overflow → general path)
+  uint64_t full_total = col_cap / 8 + (uint64_t)N_LISTS * 256;
+  uint32_t full_cap = (uint32_t)std::min<uint64_t>(full_total / N_LISTS, 0x7FFFFFFFull);
+  d_full_items.reserve((size_t)full_cap * N_LISTS * sizeof(FullItem));
+  d_full_count.reserve((size_t)N_LISTS * 4);
+  hip_check(hipMemsetAsync(d_full_count.p, 0, (size_t)N_LISTS * 4, s), "memset");
+  P.full_items = d_full_items.as<FullItem>(); P.full_count = d_full_count.as<uint32_t>(); P.full_cap = full_cap;
+  P.lds_wave_bytes = lds_wave_bytes;
+  P.lds_tile_bytes = lds_tile_bytes_large;
 
   hip_check(hipEventRecord(c->ev0, s), "event");
   hip_check(hipEventRecord(ev[0], s), "event");
-  hipLaunchKernelGGL(k_family, dim3(n_grp), dim3(NT), lds_tile_bytes, s, P);
-  hip_check(hipGetLastError(), "k_family launch");
-  {   // families whose tiles did not fit: second launch with large LDS tiles
+  hipLaunchKernelGGL(k_family_wave, dim3((n_grp + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(256), WAVES_PER_BLOCK * lds_wave_bytes, s, P, n_grp);
+  hip_check(hipGetLastError(), "k_family_wave launch");
+  {   // families that do not fit a wave (more than 64 records / more bytes than the LDS slice): one workgroup each
     uint32_t n_retry = 0;
     hip_check(hipMemcpyAsync(&n_retry, P.n_retry, 4, hipMemcpyDeviceToHost, s), "D2H");
     hip_check(hipStreamSynchronize(s), "sync");
     if (n_retry) {
       FastParams P2 = P;
-      P2.group_list = d_retry.as<uint32_t>(); P2.retry = nullptr; P2.n_retry = nullptr; P2.lds_tile_bytes = lds_tile_bytes_large;
+      P2.group_list = d_retry.as<uint32_t>(); P2.retry = nullptr; P2.n_retry = nullptr;
       hipLaunchKernelGGL(k_family, dim3(n_retry), dim3(NT), lds_tile_bytes_large, s, P2);
       hip_check(hipGetLastError(), "k_family (large) launch");
     }
   }
+  uint64_t n_full = 0;
+  {   // dense call_full pass over the compacted lists
+    std::vector<uint32_t> counts(N_LISTS);
+    hip_check(hipMemcpyAsync(counts.data(), d_full_count.p, (size_t)N_LISTS * 4, hipMemcpyDeviceToHost, s), "D2H");
+    hip_check(hipStreamSynchronize(s), "sync");
+    uint32_t mx = 0;
+    for (uint32_t v : counts) { uint32_t vv = v < full_cap ? v : full_cap; mx = vv > mx ? vv : mx; n_full += vv; }
+    if (mx) {
+      FullParams F;
+      memset(&F, 0, sizeof(F));
+      F.items = d_full_items.as<FullItem>(); F.count = d_full_count.as<uint32_t>(); F.cap = full_cap;
+      F.T = P.T; F.TU = P.TU; F.min_reads = P.min_reads; F.min_cons_bq = P.min_cons_bq;
+      F.col_code = P.col_code; F.col_qual = P.col_qual; F.col_err = P.col_err; F.ends = P.ends;
+      hipLaunchKernelGGL(k_call_full, dim3((mx + 255) / 256, N_LISTS), dim3(256), 0, s, F);
+      hip_check(hipGetLastError(), "k_call_full launch");
+    }
+  }
   hip_check(hipEventRecord(ev[1], s), "event");
+  hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(64), 0, s, d_statslots.as<unsigned long long>(), misc);
 
   size_t tmp_bytes = 0;
   (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_sizes.as<uint64_t>(), d_offsets.as<uint64_t>(), (int)n_slots, s);
@@ -825,6 +1405,7 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
   hip_check(hipEventElapsedTime(&mse, ev[2], ev[3]), "elapsed");
   res->ms_k_family = msf; res->ms_k_emit = mse;
   res->cols_used = h_misc[28];
+  res->full_items = n_full;
   return 0;
 }
 

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void k_column_jobs(const uint8_t* __restrict__
   uint8_t q;
   column_call(T->t, acc.s, acc.obs, &bi, &q);
   uint32_t depth = acc.contributions();
-  uint32_t match = bi >= 0 ? acc.obs[bi] : 0;
+  uint32_t match = acc.obs_of(bi);
   uint32_t err = depth - match;
   od[o] = (uint16_t)(depth < 32767u ? depth : 32767u);
   oe[o] = (uint16_t)(err < 32767u ? err : 32767u);
