@@ -604,13 +604,36 @@ __device__ __forceinline__ unsigned long long wave_max64(unsigned long long v) {
 __device__ __forceinline__ unsigned long long wave_min64(unsigned long long v) { for (int o = 32; o > 0; o >>= 1) { unsigned long long t = __shfl_xor(v, o); v = t < v ? t : v; } return v; }
 __device__ __forceinline__ uint8_t comp_code(uint8_t c) { return (uint8_t)((0xF7B3D591E6A2C480ULL >> (4 * (c & 15))) & 15); }
 
+// unaligned LDS reads built from aligned dwords (v_alignbyte_b32)
+__device__ __forceinline__ uint32_t ldsw(const uint8_t* W, uint32_t o) { return *(const uint32_t*)(W + o); }
+__device__ __forceinline__ uint32_t ld32u(const uint8_t* W, uint32_t o) {
+  uint32_t a = o & ~3u;
+  return __builtin_amdgcn_alignbyte(ldsw(W, a + 4), ldsw(W, a), o & 3);
+}
+__device__ __forceinline__ unsigned long long ld64u(const uint8_t* W, uint32_t o) {
+  uint32_t a = o & ~3u, sh = o & 3;
+  uint32_t w0 = ldsw(W, a), w1 = ldsw(W, a + 4), w2 = ldsw(W, a + 8);
+  return (unsigned long long)__builtin_amdgcn_alignbyte(w1, w0, sh) | ((unsigned long long)__builtin_amdgcn_alignbyte(w2, w1, sh) << 32);
+}
+// offset of the first NUL in W[o, o+n), 8 bytes per step; -1 if none
+__device__ __forceinline__ int find_nul64(const uint8_t* W, uint32_t o, uint32_t n) {
+  for (uint32_t i = 0; i < n; i += 8) {
+    unsigned long long v = ld64u(W, o + i);
+    unsigned long long t = (v - 0x0101010101010101ULL) & ~v & 0x8080808080808080ULL;
+    if (t) { uint32_t k = i + ((uint32_t)__builtin_ctzll(t) >> 3); return k < n ? (int)k : -1; }
+  }
+  return -1;
+}
+
 __global__ __launch_bounds__(256) void k_family_wave(FastParams P, uint32_t n_grp_total) {
   extern __shared__ __align__(16) uint8_t dyn[];
-  __shared__ ConsensusTables sT;     // Phred tables: 3 KB, shared by the block's four families
+  __shared__ ConsensusTables sT;          // thresholds / cerr_min / scalars (and the plain tables for reference)
+  __shared__ __align__(16) double sPair[94][2];   // {correct[q], error_per_alt[q]} interleaved: one ds_read_b128 per observation
   {
     const uint64_t* src = (const uint64_t*)&P.T->t;
     uint64_t* dst = (uint64_t*)&sT;
     for (uint32_t i = threadIdx.x; i < sizeof(ConsensusTables) / 8; i += blockDim.x) dst[i] = src[i];
+    for (uint32_t i = threadIdx.x; i < 94; i += blockDim.x) { sPair[i][0] = P.T->t.correct[i]; sPair[i][1] = P.T->t.error_per_alt[i]; }
   }
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -665,7 +688,7 @@ __global__ __launch_bounds__(256) void k_family_wave(FastParams P, uint32_t n_gr
   if (__any(act && len < 32)) { to_defer(); return; }
   unsigned long long base16 = lo_off & ~15ull;
   unsigned long long span = hi_end - base16;
-  if (span > (unsigned long long)P.lds_wave_bytes) { to_retry(); return; }
+  if (span + 16 > (unsigned long long)P.lds_wave_bytes) { to_retry(); return; }   // +16: slack for the dword-composed reads
   const uint32_t span16 = ((uint32_t)span + 15) & ~15u;
   {
     const uint8_t* src = P.blob + base16;
@@ -675,31 +698,29 @@ __global__ __launch_bounds__(256) void k_family_wave(FastParams P, uint32_t n_gr
 
   // ---- 2. parse: lane r owns record r ---------------------------------------------------------------------
   const uint32_t lo = act ? (uint32_t)(off - base16) : 0;       // LDS offset of this lane's record
-  auto b8 = [&](uint32_t o) -> uint32_t { return W[o]; };
-  auto b16 = [&](uint32_t o) -> uint32_t { return (uint32_t)W[o] | ((uint32_t)W[o + 1] << 8); };
-  auto b32 = [&](uint32_t o) -> uint32_t { return (uint32_t)W[o] | ((uint32_t)W[o + 1] << 8) | ((uint32_t)W[o + 2] << 16) | ((uint32_t)W[o + 3] << 24); };
   uint32_t flags = 0, l_seq = 0, seq_lo = 0, qual_lo = 0, name_len = 0, clip = 0, hash = 0;
   int32_t pos = 0, ref_id = 0;
   uint32_t mi_lo = 0, mi_len = 0, rx_lo = 0, rx_len = 0, cb_lo = 0, cb_len = 0;   // LDS offsets of tag values
   bool has_mi = false, has_rx = false, has_cb = false, excluded = false, bad = false;
   if (act) {
-    uint32_t l_name = b8(lo + 8), n_cig = b16(lo + 12);
-    l_seq = b32(lo + 16);
-    flags = b16(lo + 14);
+    const uint32_t h2 = ld32u(W, lo + 8), h3 = ld32u(W, lo + 12);
+    const uint32_t l_name = h2 & 0xFF, n_cig = h3 & 0xFFFF;
+    l_seq = ld32u(W, lo + 16);
+    flags = h3 >> 16;
     unsigned long long seq_off = 32ull + l_name + 4ull * n_cig;
     unsigned long long qual_off = seq_off + ((unsigned long long)l_seq + 1) / 2;
     unsigned long long aux_off = qual_off + l_seq;
     if (aux_off > len || l_seq > 65535 || l_name == 0) bad = true;
     else {
       name_len = l_name - 1;
-      pos = (int32_t)b32(lo + 4); ref_id = (int32_t)b32(lo);
+      ref_id = (int32_t)ld32u(W, lo); pos = (int32_t)ld32u(W, lo + 4);
       seq_lo = lo + (uint32_t)seq_off; qual_lo = lo + (uint32_t)qual_off;
       excluded = (flags & (bam::F_SECONDARY | bam::F_SUPPLEMENTARY)) != 0;
       uint32_t op = 0;
       if (!excluded) {
         if ((flags & bam::F_UNMAPPED) || n_cig != 1 || l_seq == 0 || pos < 0) bad = true;
         else {
-          op = b32(lo + 32 + l_name);
+          op = ld32u(W, lo + 32 + l_name);
           uint32_t ty = op & 15;
           if (!(ty == 0 || ty == 7 || ty == 8) || (op >> 4) != l_seq) bad = true;
         }
@@ -708,41 +729,89 @@ __global__ __launch_bounds__(256) void k_family_wave(FastParams P, uint32_t n_gr
       const uint32_t a0 = lo + (uint32_t)aux_off, an = len - (uint32_t)aux_off;
       uint32_t q = 0, mc_lo = 0, mc_len = 0;
       bool has_mc = false, seen_mc = false, seen_mi = false, seen_rx = false, seen_cb = false;
+      const uint32_t key_mi = (uint32_t)(uint8_t)P.tag0 | ((uint32_t)(uint8_t)P.tag1 << 8);
+      const uint32_t key_cb = (uint32_t)(uint8_t)P.cell0 | ((uint32_t)(uint8_t)P.cell1 << 8);
       while (q + 3 <= an) {
-        uint32_t t0 = W[a0 + q], t1 = W[a0 + q + 1], vt = W[a0 + q + 2];
+        const uint32_t hd = ld32u(W, a0 + q);
+        const uint32_t key = hd & 0xFFFF, vt = (hd >> 16) & 0xFF;
         uint32_t size = 0;
         int fixed = bam::tag_fixed_size((uint8_t)vt);
-        int64_t zend = -1;
+        int zend = -1;
         bool stop = false;
         if (fixed > 0) size = (uint32_t)fixed;
-        else if (vt == 'Z' || vt == 'H') { zend = bam::find_nul(W + a0 + q + 3, an - (q + 3)); if (zend < 0) break; size = (uint32_t)zend + 1; }
+        else if (vt == 'Z' || vt == 'H') { zend = find_nul64(W, a0 + q + 3, an - (q + 3)); if (zend < 0) break; size = (uint32_t)zend + 1; }
         else if (vt == 'B') {
           if (an - (q + 3) < 5) break;
-          int es = bam::tag_fixed_size(W[a0 + q + 3]);
+          int es = bam::tag_fixed_size((uint8_t)(hd >> 24));
           if (es == 0) stop = true;
-          else { unsigned long long sz = 5ull + (unsigned long long)b32(a0 + q + 4) * (unsigned long long)es; if (sz > 0xFFFFFFFFull) break; size = (uint32_t)sz; }
+          else { unsigned long long sz = 5ull + (unsigned long long)ld32u(W, a0 + q + 4) * (unsigned long long)es; if (sz > 0xFFFFFFFFull) break; size = (uint32_t)sz; }
         } else stop = true;
-        bool isz = (vt == 'Z') && !stop;
-        uint32_t vlo = a0 + q + 3;
-        if (!seen_mc && t0 == 'M' && t1 == 'C') { seen_mc = true; if (isz) { has_mc = true; mc_lo = vlo; mc_len = (uint32_t)zend; } }
-        if (!seen_mi && t0 == (uint8_t)P.tag0 && t1 == (uint8_t)P.tag1) { seen_mi = true; if (isz) { if (zend > 255) bad = true; else { has_mi = true; mi_lo = vlo; mi_len = (uint32_t)zend; } } }
-        if (!seen_rx && t0 == 'R' && t1 == 'X') { seen_rx = true; if (isz) { if (zend > 255) bad = true; else { has_rx = true; rx_lo = vlo; rx_len = (uint32_t)zend; } } }
-        if (!seen_cb && P.cell0 && t0 == (uint8_t)P.cell0 && t1 == (uint8_t)P.cell1) { seen_cb = true; if (isz) { if (zend > 255) bad = true; else { has_cb = true; cb_lo = vlo; cb_len = (uint32_t)zend; } } }
+        const bool isz = (vt == 'Z') && !stop;
+        const uint32_t vlo = a0 + q + 3;
+        if (!seen_mc && key == ('M' | ('C' << 8))) { seen_mc = true; if (isz) { has_mc = true; mc_lo = vlo; mc_len = (uint32_t)zend; } }
+        if (!seen_mi && key == key_mi) { seen_mi = true; if (isz) { if (zend > 255) bad = true; else { has_mi = true; mi_lo = vlo; mi_len = (uint32_t)zend; } } }
+        if (!seen_rx && key == ('R' | ('X' << 8))) { seen_rx = true; if (isz) { if (zend > 255) bad = true; else { has_rx = true; rx_lo = vlo; rx_len = (uint32_t)zend; } } }
+        if (!seen_cb && P.cell0 && key == key_cb) { seen_cb = true; if (isz) { if (zend > 255) bad = true; else { has_cb = true; cb_lo = vlo; cb_len = (uint32_t)zend; } } }
         if (stop) break;
         unsigned long long nq = (unsigned long long)q + 3 + size;
         if (nq > an) break;
         q = (uint32_t)nq;
       }
       if (!bad && !excluded) {
-        uint32_t mops[MAX_MC_OPS];
-        bool overflow = false;
-        bam::Rec v{W + lo, len};
-        unsigned long long cl = bam::mate_clip(v, &op, 1, has_mc ? W + mc_lo : nullptr, mc_len, mops, MAX_MC_OPS, &overflow);
-        if (overflow) bad = true;
-        clip = (uint32_t)(cl > 65535 ? 65535 : cl);
-        uint32_t h = 2166136261u;
-        for (uint32_t i = 0; i < name_len; i++) { h ^= W[lo + 32 + i]; h *= 16777619u; }
-        hash = h;
+        // mate-overlap clip (raw-bam/overlap.rs:181-357).  Closed form when the MC tag is one M op and all
+        // coordinates are in the ordinary range (no saturating arithmetic can trigger); general code otherwise.
+        bool fastclip = false;
+        uint32_t ML = 0;
+        if (has_mc && mc_len >= 2 && mc_len <= 8) {
+          unsigned long long v = ld64u(W, mc_lo);
+          uint32_t k = 0, val = 0;
+          while (k < mc_len - 1) { uint32_t ch = (uint32_t)(v >> (8 * k)) & 0xFF; if (ch < '0' || ch > '9') break; val = val * 10 + (ch - '0'); k++; }
+          if (k == mc_len - 1 && ((v >> (8 * k)) & 0xFF) == 'M' && val > 0) { fastclip = true; ML = val; }
+        }
+        const int32_t mpos = (int32_t)ld32u(W, lo + 24);
+        if (fastclip && pos < (1 << 30) && mpos >= 0 && mpos < (1 << 30)) {
+          uint64_t cl = 0;
+          const int32_t mref = (int32_t)ld32u(W, lo + 20);
+          const bool rv = (flags & bam::F_REVERSE) != 0, mrv = (flags & bam::F_MATE_REVERSE) != 0;
+          const long long L = l_seq, tp = (long long)pos + 1, mp = (long long)mpos + 1;
+          bool fr = (flags & bam::F_PAIRED) && !(flags & bam::F_MATE_UNMAPPED) && ref_id == mref && rv != mrv;
+          if (fr) fr = rv ? (mp < tp + (L - 1)) : (tp < mp + ((long long)ML - 1));
+          if (fr) {
+            const long long read_end = tp - 1 + L, mate_end = mp - 1 + (long long)ML;
+            if (rv) {
+              if (!(tp > mate_end) && !(read_end < mp)) {
+                long long fs = tp > mp ? tp : mp;
+                long long rb = fs - tp; if (rb > L) rb = L;
+                long long mb = fs - mp; if (mb > (long long)ML) mb = ML;
+                cl = rb > mb ? (uint64_t)(rb - mb) : 0;
+              }
+            } else {
+              if (!(read_end < mp) && !(mate_end < tp)) {
+                long long ls = read_end < mate_end ? read_end : mate_end;
+                long long ra = ls - tp + 1; if (ra > L) ra = L;
+                long long ma = ls - mp + 1; if (ma > (long long)ML) ma = ML;
+                long long rp = L - ra, mq = (long long)ML - ma;
+                cl = rp > mq ? (uint64_t)(rp - mq) : 0;
+              }
+            }
+          }
+          clip = (uint32_t)(cl > 65535 ? 65535 : cl);
+        } else {
+          uint32_t mops[MAX_MC_OPS];
+          bool overflow = false;
+          bam::Rec v{W + lo, len};
+          unsigned long long cl = bam::mate_clip(v, &op, 1, has_mc ? W + mc_lo : nullptr, mc_len, mops, MAX_MC_OPS, &overflow);
+          if (overflow) bad = true;
+          clip = (uint32_t)(cl > 65535 ? 65535 : cl);
+        }
+        // name hash (8 bytes per step) for mate pairing
+        unsigned long long h = 0x9E3779B97F4A7C15ULL ^ name_len;
+        for (uint32_t i = 0; i < name_len; i += 8) {
+          unsigned long long w = ld64u(W, lo + 32 + i);
+          if (i + 8 > name_len) w &= (1ULL << (8 * (name_len - i))) - 1;
+          h = (h ^ w) * 0xBF58476D1CE4E5B9ULL;
+        }
+        hash = (uint32_t)(h >> 32);
       }
     }
   }
@@ -769,15 +838,20 @@ __global__ __launch_bounds__(256) void k_family_wave(FastParams P, uint32_t n_gr
     int mate = -1;
     bool later_r1 = false;
     const unsigned long long r1mask = __ballot(is_r1), r2mask = __ballot(is_r2);
-    for (uint32_t u = 0; u < n; u++) {
-      uint32_t hu = rlane(hash, u), nlu = rlane(name_len, u), lou = rlane(lo, u);
-      bool u_r1 = (r1mask >> u) & 1, u_r2 = (r2mask >> u) & 1;
-      if (!is_r1 || (!u_r1 && !u_r2) || hu != hash || nlu != name_len) continue;
+    for (unsigned long long um = r1mask | r2mask; um; um &= um - 1) {
+      const uint32_t u = (uint32_t)__builtin_ctzll(um);
+      const uint32_t hu = rlane(hash, u), nlu = rlane(name_len, u), lou = rlane(lo, u);
+      const bool u_r1 = (r1mask >> u) & 1;
+      if (!is_r1 || hu != hash || nlu != name_len) continue;
       bool same = true;
-      for (uint32_t i = 0; i < name_len; i++) if (W[lou + 32 + i] != W[lo + 32 + i]) { same = false; break; }
+      for (uint32_t i = 0; i < name_len; i += 8) {
+        unsigned long long wa = ld64u(W, lou + 32 + i), wb = ld64u(W, lo + 32 + i);
+        if (i + 8 > name_len) { unsigned long long mk = (1ULL << (8 * (name_len - i))) - 1; wa &= mk; wb &= mk; }
+        if (wa != wb) { same = false; break; }
+      }
       if (!same) continue;
-      if (u_r1 && u > lane) later_r1 = true;
-      if (u_r2) mate = (int)u;
+      if (u_r1) { if (u > lane) later_r1 = true; }
+      else mate = (int)u;
     }
     if (later_r1) mate = -1;
     unsigned long long pm = __ballot(mate >= 0);
@@ -826,44 +900,56 @@ __global__ __launch_bounds__(256) void k_family_wave(FastParams P, uint32_t n_gr
   }
   wave_sync();
 
-  // oriented, mask-aware view of one read (given its uniform descriptors) at consensus position p
-  auto view = [&](uint32_t s_lo, uint32_t q_lo, uint32_t L, bool rv, uint32_t trim_to, uint32_t p, uint8_t* code, uint8_t* qual) {
+  // Oriented, mask-aware view of one read at consensus position p.  d0 = seq_lo | qual_lo << 16, `rv` uniform.
+  // Returns the 4-bit code in read orientation (15 = N / masked) and the SourceRead quality.
+  auto view = [&](uint32_t s_lo, uint32_t q_lo, uint32_t L, bool rv, uint32_t trim_to, uint32_t p, uint32_t* code, uint32_t* qual) {
     uint32_t idx = rv ? L - 1 - p : p;
-    uint8_t bb = W[s_lo + (idx >> 1)];
-    uint8_t c = (idx & 1) ? (bb & 15) : (bb >> 4);
-    uint8_t q = W[q_lo + idx];
-    if (rv) c = comp_code(c);
+    uint32_t bb = W[s_lo + (idx >> 1)];
+    uint32_t c = (bb >> ((~idx & 1) << 2)) & 15;
+    uint32_t q = W[q_lo + idx];
+    if (rv) c = comp_code((uint8_t)c);
     if (p < trim_to && q < P.min_input_bq) { c = 15; q = FGX_MIN_PHRED; }
     *code = c; *qual = q;
   };
 
   // ---- 4. source-read geometry per lane (vanilla_caller.rs:1129-1160) -----------------------------------------
   uint32_t trim_to = l_seq, final_len = 0;
-  if (cand) {
-    if (P.trim) {
-      uint32_t tq = P.min_input_bq;
-      if (tq < 1 || l_seq == 0) trim_to = 0;
-      else {
-        int32_t score = 0, max_score = 0;
-        uint32_t point = l_seq;
-        for (uint32_t i = l_seq; i-- > 0;) {
-          uint32_t idx = rev ? l_seq - 1 - i : i;
-          score += (int32_t)tq - (int32_t)W[qual_lo + idx];
-          if (score < 0) break;
-          if (score > max_score) { max_score = score; point = i; }
-        }
-        trim_to = point;
+  if (cand && P.trim) {
+    uint32_t tq = P.min_input_bq;
+    if (tq < 1 || l_seq == 0) trim_to = 0;
+    else {
+      int32_t score = 0, max_score = 0;
+      uint32_t point = l_seq;
+      for (uint32_t i = l_seq; i-- > 0;) {
+        uint32_t idx = rev ? l_seq - 1 - i : i;
+        score += (int32_t)tq - (int32_t)W[qual_lo + idx];
+        if (score < 0) break;
+        if (score > max_score) { max_score = score; point = i; }
       }
+      trim_to = point;
     }
+  }
+  {
     uint32_t clip_pos = l_seq > clip ? l_seq - clip : 0;
     uint32_t fl = clip_pos < trim_to ? clip_pos : trim_to;
-    while (fl > 0) {
-      uint8_t c, q;
-      view(seq_lo, qual_lo, l_seq, rev, trim_to, fl - 1, &c, &q);
-      if (c != 15) break;
-      fl--;
+    bool tail_n = false;
+    if (cand && fl > 0) { uint32_t c, q; view(seq_lo, qual_lo, l_seq, rev, trim_to, fl - 1, &c, &q); tail_n = (c == 15); }
+    final_len = cand ? fl : 0;
+    // reads ending in N / masked bases: strip the run 64 positions at a time (lanes scan backwards together)
+    for (unsigned long long tm = __ballot(tail_n); tm; tm &= tm - 1) {
+      const uint32_t r = (uint32_t)__builtin_ctzll(tm);
+      uint32_t flr = rlane(final_len, r);
+      const uint32_t s_r = rlane(seq_lo, r), q_r = rlane(qual_lo, r), L_r = rlane(l_seq, r), t_r = rlane(trim_to, r);
+      const bool rv_r = (rlane(flags, r) & bam::F_REVERSE) != 0;
+      while (flr > 0) {
+        bool real = false;
+        if (lane < flr) { uint32_t c, q; view(s_r, q_r, L_r, rv_r, t_r, flr - 1 - lane, &c, &q); real = (c != 15); }
+        unsigned long long bm = __ballot(real);
+        if (bm) { flr -= (uint32_t)__builtin_ctzll(bm); break; }
+        flr -= flr < 64 ? flr : 64;
+      }
+      if (lane == r) final_len = flr;
     }
-    final_len = fl;
   }
 
   // ---- 5. family gates with ballots (process_group :1329-1422, process_subgroup :1454-1646) -----------------
@@ -892,10 +978,13 @@ __global__ __launch_bounds__(256) void k_family_wave(FastParams P, uint32_t n_gr
       if (rem < P.min_reads) { if (rem) { s_filtered += rem; s_insuf += rem; } continue; }
       if (P.max_reads >= 0 && (long long)rem > P.max_reads) { need_defer = true; break; }
       // consensus length = min_reads-th longest kept read
-      uint32_t ge = 0;
-      for (unsigned long long m = kept; m; m &= m - 1) { uint32_t fj = rlane(final_len, (uint32_t)__builtin_ctzll(m)); ge += (fj >= final_len) ? 1 : 0; }
       bool mine = (kept >> lane) & 1;
-      clen[e] = wave_max((mine && ge >= P.min_reads) ? final_len : 0);
+      if (P.min_reads == 1) clen[e] = wave_max(mine ? final_len : 0);
+      else {
+        uint32_t ge = 0;
+        for (unsigned long long m = kept; m; m &= m - 1) { uint32_t fj = rlane(final_len, (uint32_t)__builtin_ctzll(m)); ge += (fj >= final_len) ? 1 : 0; }
+        clen[e] = wave_max((mine && ge >= P.min_reads) ? final_len : 0);
+      }
       mem[e] = kept; surv[e] = rem; ok[e] = true;
     }
   }
@@ -928,8 +1017,11 @@ __global__ __launch_bounds__(256) void k_family_wave(FastParams P, uint32_t n_gr
   if (need_defer) { to_defer(); return; }
 
   // ---- 6. consensus columns: one lane per column, member reads walked in file order -------------------------
+  // per-read descriptors packed for broadcast: d0 = seq_lo | qual_lo << 16 ; d1 = l_seq | final_len << 16 ; d2 = trim_to | rev << 16
+  const uint32_t d0 = seq_lo | (qual_lo << 16), d1 = l_seq | (final_len << 16), d2 = trim_to | ((rev ? 1u : 0u) << 16);
   const DeviceTables* T = P.T;
   const uint64_t col_base = P.col_base[g];
+  const uint32_t min_bq = P.min_input_bq;
 #pragma unroll
   for (uint32_t k = 0; k < 3; k++) {
     if (k >= ne) break;
@@ -940,25 +1032,32 @@ __global__ __launch_bounds__(256) void k_family_wave(FastParams P, uint32_t n_gr
       uint32_t depth, err;
       if (mc == 1) {   // single-read consensus: LUT keyed by the unclamped quality (:1677-1708)
         uint32_t r = (uint32_t)__builtin_ctzll(members);
-        uint8_t code, q;
+        uint32_t code, q;
         view(rlane(seq_lo, r), rlane(qual_lo, r), rlane(l_seq, r), (rlane(flags, r) & bam::F_REVERSE) != 0, rlane(trim_to, r), p, &code, &q);
         uint8_t adj = q < 94 ? T->single_input_quals[q] : 0;
-        if (adj < P.min_cons_bq) { ob = 15; oq = FGX_MIN_PHRED; } else { ob = code; oq = adj; }
+        if (adj < P.min_cons_bq) { ob = 15; oq = FGX_MIN_PHRED; } else { ob = (uint8_t)code; oq = adj; }
         depth = code != 15 ? 1 : 0;
         err = 0;
       } else {
         ColumnAcc acc;
         acc.reset();
         for (unsigned long long m = members; m; m &= m - 1) {
-          uint32_t r = (uint32_t)__builtin_ctzll(m);
-          uint32_t fl = rlane(final_len, r);
-          if (p < fl) {
-            uint8_t code, q;
-            view(rlane(seq_lo, r), rlane(qual_lo, r), rlane(l_seq, r), (rlane(flags, r) & bam::F_REVERSE) != 0, rlane(trim_to, r), p, &code, &q);
-            int bl = bam::code_to_lane(code);
-            if (bl != 255) {
-              uint32_t qq = q < FGX_MAX_PHRED ? q : FGX_MAX_PHRED;
-              acc.add(bl, sT.correct[qq], sT.error_per_alt[qq]);
+          const uint32_t r = (uint32_t)__builtin_ctzll(m);
+          const uint32_t x0 = rlane(d0, r), x1 = rlane(d1, r), x2 = rlane(d2, r);
+          if (p < (x1 >> 16)) {
+            const bool rv = (x2 >> 16) != 0;
+            const uint32_t idx = rv ? (x1 & 0xFFFF) - 1 - p : p;
+            const uint32_t bb = W[(x0 & 0xFFFF) + (idx >> 1)];
+            const uint32_t c = (bb >> ((~idx & 1) << 2)) & 15;
+            const uint32_t q = W[(x0 >> 16) + idx];
+            // code → accumulator lane (A,C,G,T = 0..3, anything else 15), complemented for reverse reads
+            const unsigned long long LUT = rv ? 0xFFFFFFF0FFF1F23FULL : 0xFFFFFFF3FFF2F10FULL;
+            const uint32_t bl = (uint32_t)(LUT >> (4 * c)) & 15;
+            const bool masked = p < (x2 & 0xFFFF) && q < min_bq;
+            if (bl < 4 && !masked) {
+              const uint32_t qq = q < FGX_MAX_PHRED ? q : FGX_MAX_PHRED;
+              const double2 pr = *(const double2*)&sPair[qq][0];
+              acc.add((int)bl, pr.x, pr.y);
             }
           }
         }
@@ -996,11 +1095,14 @@ __global__ __launch_bounds__(256) void k_family_wave(FastParams P, uint32_t n_gr
     if (e_rx_cnt[k] == 0) continue;                     // uniform
     const bool mychar = lane < e_rx_len[k];
     if (e_rx_cnt[k] == 1) { if (mychar) my_rx[k] = (char)W[rlane(rx_lo, e_rx_first[k]) + lane]; continue; }
+    // all-identical UMIs (the usual case): the consensus of n identical strings… still has to be CALLED (a single
+    // Q20 observation is not enough to keep the base), so run the per-character columns
     ColumnAcc acc;
     acc.reset();
     uint32_t non_dna = 0, seen = 0;
     uint8_t fc = 0;
     bool mixed = false;
+    const double uc = TU->t.correct[20], ue = TU->t.error_per_alt[20];
     for (unsigned long long m = e_mem[k] & rxmask; m; m &= m - 1) {
       uint32_t r = (uint32_t)__builtin_ctzll(m);
       uint8_t ch = mychar ? W[rlane(rx_lo, r) + lane] : (uint8_t)'A';
@@ -1008,7 +1110,7 @@ __global__ __launch_bounds__(256) void k_family_wave(FastParams P, uint32_t n_gr
       seen++;
       uint8_t up = (ch >= 'a' && ch <= 'z') ? (uint8_t)(ch - 32) : ch;
       bool dna = up == 'A' || up == 'C' || up == 'G' || up == 'T' || up == 'N';
-      if (dna) { int bl = bam::ascii_to_lane(ch); if (bl != 255) acc.add(bl, TU->t.correct[20], TU->t.error_per_alt[20]); }
+      if (dna) { int bl = bam::ascii_to_lane(ch); if (bl != 255) acc.add(bl, uc, ue); }
       else { non_dna++; if (ch != fc) mixed = true; }
     }
     bool need_full = false;
