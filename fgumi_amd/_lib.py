@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(HERE, "libfgumi_amd.so")
+SO = os.environ.get("FGX_LIB") or os.path.join(HERE, "libfgumi_amd.so")
 
 
 class LibraryMissing(RuntimeError):
