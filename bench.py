@@ -93,15 +93,10 @@ def main():
         k_total_ms += caller.last_timing["kernels"]
     barrier()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    sizes = torch.tensor([out.data_len, out.count, dg.n_rec, out.n_deferred], dtype=torch.int64, device="cuda")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        gathered = [torch.zeros_like(sizes) for _ in range(world)]
-        dist.all_gather(gathered, sizes)      # shard payload sizes, rank (= input) order
-        sizes = torch.stack(gathered).sum(0)
-    dt = float(t.item())
-    total_bytes, total_cons, total_raw, total_def = [int(v) for v in sizes.tolist()]
+    from fgumi_amd.distributed import gather_sizes, max_over_ranks
+    dt = max_over_ranks(dt, "cuda")                                                   # MAX over ranks
+    per_rank = gather_sizes([out.data_len, out.count, dg.n_rec, out.n_deferred], "cuda")   # shard payload sizes, rank (= input) order
+    total_bytes, total_cons, total_raw, total_def = [int(v) for v in per_rank.sum(0).tolist()]
 
     if rank == 0:
         L = args.read_length
