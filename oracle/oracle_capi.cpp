@@ -94,6 +94,45 @@ static void simplex_groups(const fgx_options* o, const uint8_t* blob, const uint
   stats_to_array(batch_stats, batch_overlap, res.stats);
 }
 
+#ifdef ORC_WITH_DUPLEX
+// process_fn of `fgumi duplex` (src/lib/commands/duplex.rs:742-830)
+static void duplex_groups(const fgx_options* o, const uint8_t* blob, const uint64_t* rec_off, const uint32_t* rec_len,
+                          const uint32_t* grp_first, uint32_t g0, uint32_t g1, OrcResult& res) {
+  DuplexOptions d;
+  d.min_total = o->duplex_min_reads[0]; d.min_xy = o->duplex_min_reads[1]; d.min_yx = o->duplex_min_reads[2];
+  d.min_input_base_quality = o->min_input_base_quality; d.per_base_tags = o->produce_per_base_tags; d.trim = o->trim;
+  d.has_max_reads = o->duplex_max_reads_per_strand >= 0; d.max_reads = d.has_max_reads ? (size_t)o->duplex_max_reads_per_strand : 0;
+  d.has_cell_tag = o->cell_tag[0] != 0; d.cell_tag[0] = o->cell_tag[0]; d.cell_tag[1] = o->cell_tag[1];
+  d.pre = o->error_rate_pre_umi; d.post = o->error_rate_post_umi;
+  d.tie_rule = o->tie_rule == FGX_TIE_ULP_RELATIVE ? TieRule::UlpRelative : TieRule::FgbioCompat;
+  if (d.min_xy > d.min_total || d.min_yx > d.min_xy) throw OracleError{"min-reads values must be specified high to low"};
+  DuplexCaller caller(o->read_name_prefix ? o->read_name_prefix : "", o->read_group_id ? o->read_group_id : "A", d, o->track_rejects != 0);
+  const bool single_strand_allowed = d.min_yx == 0;
+  Stats batch_stats;
+  CorrectionStats batch_overlap;
+  for (uint32_t g = g0; g < g1; g++) {
+    caller.clear();
+    uint32_t r0 = grp_first[g], r1 = grp_first[g + 1];
+    std::vector<Bytes> recs;
+    for (uint32_t r = r0; r < r1; r++) recs.emplace_back(blob + rec_off[r], blob + rec_off[r] + rec_len[r]);
+    if (o->overlapping_consensus && (single_strand_allowed || has_both_strands_raw(recs))) {
+      CorrectionStats cs;
+      apply_overlapping_consensus(recs, cs);
+      batch_overlap.overlapping_bases += cs.overlapping_bases; batch_overlap.bases_agreeing += cs.bases_agreeing;
+      batch_overlap.bases_disagreeing += cs.bases_disagreeing; batch_overlap.bases_corrected += cs.bases_corrected;
+    }
+    std::vector<DuplexCaller::Rec> ptrs;
+    for (auto& b : recs) ptrs.push_back({b.data(), b.size()});
+    ConsensusOutput out = caller.consensus_reads(ptrs);
+    res.data.insert(res.data.end(), out.data.begin(), out.data.end());
+    res.count += out.count;
+    batch_stats.merge(caller.stats);
+    if (o->track_rejects) for (auto& rj : caller.rejected) append_reject(res, rj.data(), rj.size());
+  }
+  stats_to_array(batch_stats, batch_overlap, res.stats);
+}
+#endif
+
 typedef void (*groups_fn)(const fgx_options*, const uint8_t*, const uint64_t*, const uint32_t*, const uint32_t*, uint32_t,
                           uint32_t, OrcResult&);
 

@@ -111,3 +111,28 @@ def parse(rec: bytes):
         order.append(tag)
     return dict(name=name, flag=flag, ref_id=ref_id, pos=pos, seq=seq, quals=quals, tags=tags, tag_order=order, bin=bin_, mapq=mapq,
                 n_cigar=n_cig, mate_ref=mref, mate_pos=mpos, tlen=tlen)
+
+
+def pair2(name, seq1, q1, seq2, q2, mi, start1, start2, rev1=False, rev2=True, ref_id=0, rx=None, extra=(), cigar1=None, cigar2=None):
+    """`SamBuilder::add_pair()` (fgumi-sam/src/builder.rs:1642-1762): 1-based starts, sequences stored as given,
+    MC tags, TLEN from the outer coordinates; tags in the order attr(s), MC."""
+    L1, L2 = len(seq1), len(seq2)
+    c1, c2 = cigar1 or f"{L1}M", cigar2 or f"{L2}M"
+    q1 = [q1] * L1 if isinstance(q1, int) else q1
+    q2 = [q2] * L2 if isinstance(q2, int) else q2
+
+    def reflen(c):
+        return sum(o >> 4 for o in cigar_ops(c) if (o & 15) in (0, 2, 3, 7, 8))
+
+    p1, p2 = start1, start2
+    e1, e2 = p1 + reflen(c1) - 1, p2 + reflen(c2) - 1
+    left, right = (p1, e2) if p1 <= p2 else (p2, e1)
+    tlen = right - left + 1
+    t1 = tlen if p1 <= p2 else -tlen
+    t2 = tlen if p2 <= p1 else -tlen
+    tags = [("MI", "Z", mi)] + ([("RX", "Z", rx)] if rx else []) + list(extra)
+    f1 = 0x1 | 0x40 | (0x10 if rev1 else 0) | (0x20 if rev2 else 0)
+    f2 = 0x1 | 0x80 | (0x10 if rev2 else 0) | (0x20 if rev1 else 0)
+    r1 = make_record(name, seq1, q1, flag=f1, ref_id=ref_id, pos=p1 - 1, cigar=c1, mate_ref=ref_id, mate_pos=p2 - 1, tlen=t1, tags=tags + [("MC", "Z", c2)])
+    r2 = make_record(name, seq2, q2, flag=f2, ref_id=ref_id, pos=p2 - 1, cigar=c2, mate_ref=ref_id, mate_pos=p1 - 1, tlen=t2, tags=tags + [("MC", "Z", c1)])
+    return r1, r2
