@@ -33,6 +33,8 @@ def build(force=False, verbose=True):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc] + FLAGS
+    if os.path.exists(os.path.join(CSRC, "codec_host.cpp")):
+        cmd.append("-DFGX_HAVE_CODEC")
     for s in sources():
         cmd += ["-x", "hip", s]
     cmd += ["-o", OUT]

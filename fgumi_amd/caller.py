@@ -355,3 +355,36 @@ class VanillaUmiConsensusCaller(_HandleCaller):
         o.device = device
         self.options = options
         super().__init__(o, read_name_prefix, read_group_id)
+
+
+class DuplexConsensusCaller(_HandleCaller):
+    """`DuplexConsensusCaller::new(read_name_prefix, read_group_id, min_reads, min_input_base_quality,
+    produce_per_base_tags, trim, max_reads_per_strand, cell_tag, track_rejects, error_rate_pre_umi,
+    error_rate_post_umi)` (crates/fgumi-consensus/src/duplex_caller.rs:403-513).  `min_reads` = 1-3 values
+    [total, XY, YX], missing slots repeat the last one (fgbio `padTo(3, last)`), must be high to low."""
+
+    def __init__(self, read_name_prefix: str, read_group_id: str, min_reads: Sequence[int], min_input_base_quality: int = 10,
+                 produce_per_base_tags: bool = True, trim: bool = False, max_reads_per_strand: Optional[int] = None,
+                 cell_tag: Optional[str] = None, track_rejects: bool = False, error_rate_pre_umi: int = 45, error_rate_post_umi: int = 40,
+                 tie_rule: int = 0, overlapping_consensus: bool = False, device: int = -1):
+        from ._lib import default_options
+        mr = list(min_reads)
+        if not mr:
+            raise ValueError("min_reads parameter must have at least 1 value")           # duplex_caller.rs:369-371
+        if len(mr) > 3:
+            raise ValueError(f"min_reads parameter must have 1-3 values (total, [XY, [YX]]), got {len(mr)} values")
+        total, xy, yx = mr[0], (mr[1] if len(mr) > 1 else mr[-1]), (mr[2] if len(mr) > 2 else mr[-1])
+        if xy > total:
+            raise ValueError("min-reads values must be specified high to low (total >= XY)")
+        if yx > xy:
+            raise ValueError("min-reads values must be specified high to low (XY >= YX)")
+        o = default_options()
+        o.caller_kind = 1
+        o.duplex_min_reads[0], o.duplex_min_reads[1], o.duplex_min_reads[2] = total, xy, yx
+        o.min_input_base_quality = min_input_base_quality
+        o.produce_per_base_tags, o.trim, o.tie_rule = int(produce_per_base_tags), int(trim), tie_rule
+        o.duplex_max_reads_per_strand = -1 if max_reads_per_strand is None else max_reads_per_strand
+        o.cell_tag = cell_tag.encode() if cell_tag else b"\0\0"
+        o.error_rate_pre_umi, o.error_rate_post_umi = error_rate_pre_umi, error_rate_post_umi
+        o.track_rejects, o.overlapping_consensus, o.device = int(track_rejects), int(overlapping_consensus), device
+        super().__init__(o, read_name_prefix, read_group_id)

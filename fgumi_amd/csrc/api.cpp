@@ -235,6 +235,10 @@ int fgx_process_batch(fgx_caller* c, const uint8_t* records, uint64_t records_le
       case FGX_CALLER_SIMPLEX:
         if (c->general_only) return simplex_process_general(c, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
         return simplex_process_hybrid(c, records, records_len, rec_off, rec_len, n_rec, grp_first, n_grp, out);
+      case FGX_CALLER_DUPLEX: return duplex_process_general(c, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
+#ifdef FGX_HAVE_CODEC
+      case FGX_CALLER_CODEC: return codec_process_general(c, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
+#endif
       default: c->err = "fgx_process_batch: caller kind not implemented"; return 1;
     }
   } catch (const std::exception& ex) {

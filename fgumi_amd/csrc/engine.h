@@ -116,4 +116,9 @@ namespace fgx {
 // simplex_host.cpp — general path (any CIGAR, any family shape): host orchestration, device columns.
 int simplex_process_general(fgx_caller* c, const uint8_t* blob, const uint64_t* rec_off, const uint32_t* rec_len, uint32_t n_rec,
                             const uint32_t* grp_first, uint32_t n_grp, fgx_output* out);
+// duplex_host.cpp / codec_host.cpp — general paths of the duplex and CODEC callers
+int duplex_process_general(fgx_caller* c, const uint8_t* blob, const uint64_t* rec_off, const uint32_t* rec_len, uint32_t n_rec,
+                           const uint32_t* grp_first, uint32_t n_grp, fgx_output* out);
+int codec_process_general(fgx_caller* c, const uint8_t* blob, const uint64_t* rec_off, const uint32_t* rec_len, uint32_t n_rec,
+                          const uint32_t* grp_first, uint32_t n_grp, fgx_output* out);
 }
