@@ -133,6 +133,46 @@ static void duplex_groups(const fgx_options* o, const uint8_t* blob, const uint6
 }
 #endif
 
+#ifdef ORC_WITH_CODEC
+// process_fn of `fgumi codec` (src/lib/commands/codec.rs:722-790).  stats[24..28) carry the CODEC-only
+// counters: consensus_bases_emitted, consensus_duplex_bases_emitted, duplex_disagreement_base_count,
+// consensus_reads_rejected_hdd (codec_caller.rs:264-310).
+static void codec_groups(const fgx_options* o, const uint8_t* blob, const uint64_t* rec_off, const uint32_t* rec_len,
+                         const uint32_t* grp_first, uint32_t g0, uint32_t g1, OrcResult& res) {
+  CodecOptions c;
+  c.min_input_base_quality = o->min_input_base_quality; c.pre = o->error_rate_pre_umi; c.post = o->error_rate_post_umi;
+  c.min_reads_per_strand = o->codec_min_reads_per_strand;
+  c.has_max_reads = o->codec_max_reads_per_strand >= 0; c.max_reads_per_strand = c.has_max_reads ? (size_t)o->codec_max_reads_per_strand : 0;
+  c.min_duplex_length = o->codec_min_duplex_length;
+  c.has_ss_qual = o->codec_has_single_strand_qual; c.ss_qual = o->codec_single_strand_qual;
+  c.has_outer_qual = o->codec_has_outer_bases_qual; c.outer_qual = o->codec_outer_bases_qual;
+  c.outer_bases_length = o->codec_outer_bases_length;
+  c.max_duplex_disagreements = o->codec_max_duplex_disagreements == 0xFFFFFFFFu ? UINT64_MAX : o->codec_max_duplex_disagreements;
+  c.max_duplex_disagreement_rate = o->codec_max_duplex_disagreement_rate;
+  c.has_cell_tag = o->cell_tag[0] != 0; c.cell_tag[0] = o->cell_tag[0]; c.cell_tag[1] = o->cell_tag[1];
+  c.per_base_tags = o->produce_per_base_tags;
+  c.tie_rule = o->tie_rule == FGX_TIE_ULP_RELATIVE ? TieRule::UlpRelative : TieRule::FgbioCompat;
+  CodecCaller caller(o->read_name_prefix ? o->read_name_prefix : "", o->read_group_id ? o->read_group_id : "A", c, o->track_rejects != 0);
+  CodecStats batch;
+  for (uint32_t g = g0; g < g1; g++) {
+    caller.clear();
+    uint32_t r0 = grp_first[g], r1 = grp_first[g + 1];
+    std::vector<CodecCaller::Rec> ptrs;
+    for (uint32_t r = r0; r < r1; r++) ptrs.push_back({blob + rec_off[r], rec_len[r]});
+    ConsensusOutput out;
+    caller.consensus_reads(ptrs, out);   // a duplex-disagreement error is recoverable: stats and rejects are kept
+    res.data.insert(res.data.end(), out.data.begin(), out.data.end());
+    res.count += out.count;
+    batch.merge(caller.stats);
+    if (o->track_rejects) for (auto& rj : caller.rejected) append_reject(res, rj.data(), rj.size());
+  }
+  CorrectionStats none;
+  stats_to_array(batch, none, res.stats);
+  res.stats[24] += batch.consensus_bases_emitted; res.stats[25] += batch.duplex_bases_emitted;
+  res.stats[26] += batch.disagreement_bases; res.stats[27] += batch.rejected_hdd;
+}
+#endif
+
 typedef void (*groups_fn)(const fgx_options*, const uint8_t*, const uint64_t*, const uint32_t*, const uint32_t*, uint32_t,
                           uint32_t, OrcResult&);
 
