@@ -5,6 +5,7 @@ this package is the thin Python host mirror of the reference's caller interface
 (crates/fgumi-consensus/src/caller.rs:220-252) used by tests, bench.py and integrators.
 """
 from ._lib import lib, load, Options, Output, SimParams, default_options, LibraryMissing  # noqa: F401
-from .caller import (ConsensusCaller, VanillaUmiConsensusCaller, DuplexConsensusCaller, VanillaUmiConsensusOptions, ConsensusOutput,  # noqa: F401
+from .caller import (ConsensusCaller, VanillaUmiConsensusCaller, DuplexConsensusCaller, CodecConsensusCaller, CodecConsensusOptions,  # noqa: F401
+                     CodecConsensusStats, VanillaUmiConsensusOptions, ConsensusOutput,
                      ConsensusCallingStats, RejectionReason, GroupedReads, DeviceGroupedReads, DeviceOutput,
                      simulate_grouped_reads, split_records)

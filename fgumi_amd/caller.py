@@ -388,3 +388,75 @@ class DuplexConsensusCaller(_HandleCaller):
         o.error_rate_pre_umi, o.error_rate_post_umi = error_rate_pre_umi, error_rate_post_umi
         o.track_rejects, o.overlapping_consensus, o.device = int(track_rejects), int(overlapping_consensus), device
         super().__init__(o, read_name_prefix, read_group_id)
+
+
+@dataclass
+class CodecConsensusOptions:
+    """codec_caller.rs:176-262 (same defaults as `impl Default`)."""
+    min_input_base_quality: int = 10
+    error_rate_pre_umi: int = 45
+    error_rate_post_umi: int = 40
+    min_reads_per_strand: int = 1
+    max_reads_per_strand: Optional[int] = None
+    min_duplex_length: int = 1
+    single_strand_qual: Optional[int] = None
+    outer_bases_qual: Optional[int] = None
+    outer_bases_length: int = 5
+    max_duplex_disagreements: Optional[int] = None       # None = usize::MAX
+    max_duplex_disagreement_rate: float = 1.0
+    cell_tag: Optional[str] = None
+    produce_per_base_tags: bool = False
+    tie_rule: int = 0
+
+
+@dataclass
+class CodecConsensusStats:
+    """codec_caller.rs:264-310."""
+    total_input_reads: int = 0
+    consensus_reads_generated: int = 0
+    reads_filtered: int = 0
+    consensus_bases_emitted: int = 0
+    consensus_duplex_bases_emitted: int = 0
+    duplex_disagreement_base_count: int = 0
+    consensus_reads_rejected_hdd: int = 0
+    rejection_reasons: Dict[RejectionReason, int] = field(default_factory=dict)
+
+    def duplex_disagreement_rate(self) -> float:
+        d = self.consensus_duplex_bases_emitted
+        return self.duplex_disagreement_base_count / d if d else 0.0
+
+
+class CodecConsensusCaller(_HandleCaller):
+    """`CodecConsensusCaller::new_with_rejects_tracking(read_name_prefix, read_group_id, options, track_rejects)`
+    (crates/fgumi-consensus/src/codec_caller.rs:361-445).  A molecule over the duplex-disagreement thresholds is a
+    counted, recoverable reject exactly as in `fgumi codec`'s process_fn (commands/codec.rs:745-775): it emits
+    nothing, is counted under HighDuplexDisagreement and the batch carries on."""
+
+    def __init__(self, read_name_prefix: str, read_group_id: str, options: Optional[CodecConsensusOptions] = None,
+                 track_rejects: bool = False, device: int = -1):
+        from ._lib import default_options
+        v = options or CodecConsensusOptions()
+        o = default_options()
+        o.caller_kind = 2
+        o.min_input_base_quality = v.min_input_base_quality
+        o.error_rate_pre_umi, o.error_rate_post_umi = v.error_rate_pre_umi, v.error_rate_post_umi
+        o.codec_min_reads_per_strand = v.min_reads_per_strand
+        o.codec_max_reads_per_strand = -1 if v.max_reads_per_strand is None else v.max_reads_per_strand
+        o.codec_min_duplex_length = v.min_duplex_length
+        o.codec_has_single_strand_qual, o.codec_single_strand_qual = int(v.single_strand_qual is not None), v.single_strand_qual or 0
+        o.codec_has_outer_bases_qual, o.codec_outer_bases_qual = int(v.outer_bases_qual is not None), v.outer_bases_qual or 0
+        o.codec_outer_bases_length = v.outer_bases_length
+        o.codec_max_duplex_disagreements = 0xFFFFFFFF if v.max_duplex_disagreements is None else min(v.max_duplex_disagreements, 0xFFFFFFFE)
+        o.codec_max_duplex_disagreement_rate = v.max_duplex_disagreement_rate
+        o.cell_tag = v.cell_tag.encode() if v.cell_tag else b"\0\0"
+        o.produce_per_base_tags, o.tie_rule = int(v.produce_per_base_tags), v.tie_rule
+        o.track_rejects, o.overlapping_consensus, o.device = int(track_rejects), 0, device
+        self.options = v
+        super().__init__(o, read_name_prefix, read_group_id)
+
+    def codec_statistics(self) -> CodecConsensusStats:
+        """Counters of the last batch in the reference's `CodecConsensusStats` shape."""
+        s = self.last_batch_statistics()
+        ov = s.overlapping
+        return CodecConsensusStats(s.total_reads, s.consensus_reads, s.filtered_reads, ov.get("overlapping_bases", 0), ov.get("bases_agreeing", 0),
+                                   ov.get("bases_disagreeing", 0), ov.get("bases_corrected", 0), dict(s.rejection_reasons))

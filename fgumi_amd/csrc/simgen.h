@@ -167,7 +167,8 @@ SIM_HD uint32_t put_dec(uint8_t* p, uint64_t v, uint32_t width) {  // zero-padde
 }
 
 // Sequence of one mate in STORED orientation. fwd: template[0..L) ; rev: RC(template[rs..rs+re)) ; both padded
-// with random bases to L (grouped_reads.rs:853-887).
+// with random bases to L (grouped_reads.rs:853-887).  p.codec = 1 stores the reverse mate in reference orientation
+// (template[rs..rs+re)), the way an aligner writes SEQ, so the two strands of a CODEC pair agree where they overlap.
 SIM_HD uint8_t mate_base(const fgx_sim_params& p, const Molecule& m, bool fwd_mate, uint32_t read_stream, uint32_t i) {
   const char B[4] = {'A', 'C', 'G', 'T'};
   uint32_t L = p.read_length, ins = m.insert;
@@ -180,7 +181,7 @@ SIM_HD uint8_t mate_base(const fgx_sim_params& p, const Molecule& m, bool fwd_ma
     uint32_t rs = ins > L ? ins - L : 0;
     uint32_t avail = ins - rs;
     uint32_t re = L < avail ? L : avail;
-    if (i < re) b = comp(template_base(m, rs + (re - 1 - i)));
+    if (i < re) b = p.codec ? template_base(m, rs + i) : comp(template_base(m, rs + (re - 1 - i)));
     else b = (uint8_t)B[(rnd(m.key, ST_PAD, ((uint64_t)read_stream << 16) | i) >> 9) & 3];
   }
   if (p.error_rate_ppm) {

@@ -38,8 +38,10 @@ enum {
 /* stats[] layout returned with every batch:
  *   [0] total_reads  [1] consensus_reads  [2] filtered_reads      (ConsensusCallingStats, caller.rs:256-321)
  *   [3 .. 3+21)      per-RejectionReason counters, enum order above
- *   [24..28)         CorrectionStats of the overlapping pre-step: overlapping_bases, bases_agreeing,
- *                    bases_disagreeing, bases_corrected            (overlapping.rs:51-60)               */
+ *   [24..28)         simplex / duplex: CorrectionStats of the overlapping pre-step: overlapping_bases,
+ *                    bases_agreeing, bases_disagreeing, bases_corrected   (overlapping.rs:51-60)
+ *                    CODEC: consensus_bases_emitted, consensus_duplex_bases_emitted,
+ *                    duplex_disagreement_base_count, consensus_reads_rejected_hdd (codec_caller.rs:264-310) */
 #define FGX_STATS_LEN 28
 
 enum { FGX_CALLER_SIMPLEX = 0, FGX_CALLER_DUPLEX = 1, FGX_CALLER_CODEC = 2 };
@@ -177,7 +179,8 @@ typedef struct fgx_sim_params {
   uint32_t insert_sd;       /* 50  */
   uint32_t error_rate_ppm;  /* per-base substitution probability * 1e6 (1000 = 0.001) */
   uint32_t first_family;    /* molecule id of family 0 (sharding) */
-  uint32_t codec;           /* 1: CODEC-shaped pairs (both strands in one pair, overlapping mates) */
+  uint32_t codec;           /* 1: the reverse mate's SEQ is stored in reference orientation (aligner convention) so overlapping
+                               mates agree — the CODEC workload; 0 keeps the reference simulator's RC(template) bytes */
 } fgx_sim_params;
 
 /* Sizes for a parameter set: total blob bytes (records WITH block_size prefixes) and record count. */
