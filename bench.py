@@ -126,6 +126,15 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(min(fam, args.cpu_sample_families), args.depth, L, os.cpu_count() or 1)
         print(json.dumps(line))
+    if rank == 0:   # profiling builds (-DFGX_PHASE_TIMING=1) expose per-phase cycle totals of k_family_wave
+        import ctypes
+        from fgumi_amd import lib
+        if hasattr(lib, "fgx_debug_phase_cycles"):
+            ph = (ctypes.c_uint64 * 16)()
+            lib.fgx_debug_phase_cycles(ph, 1)
+            tot = float(sum(ph)) or 1.0
+            names = ["-", "stage", "parse", "overlap", "geometry", "gates", "columns", "umi", "descriptors"]
+            print("phase share: " + "  ".join(f"{names[i]}={100.0 * ph[i] / tot:.1f}%" for i in range(1, 9)), file=sys.stderr)
     caller.close()
     if world > 1:
         dist.destroy_process_group()

@@ -28,21 +28,27 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
-    if not force and not needs_build():
+def build(force=False, verbose=True, out=OUT, extra_flags=()):
+    """`out` / `extra_flags` build profiling variants (e.g. -DFGX_PHASE_TIMING=1) next to the product library."""
+    if out == OUT and not force and not needs_build():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS
+    cmd = [hipcc] + FLAGS + list(extra_flags)
     if os.path.exists(os.path.join(CSRC, "codec_host.cpp")):
         cmd.append("-DFGX_HAVE_CODEC")
     for s in sources():
         cmd += ["-x", "hip", s]
-    cmd += ["-o", OUT]
+    cmd += ["-o", out]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    # python -m fgumi_amd.build [--force] [--variant NAME -DFOO=1 ...]  → fgumi_amd/variant_NAME.so
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        build(force=True, out=os.path.join(HERE, f"variant_{sys.argv[i + 1]}.so"), extra_flags=sys.argv[i + 2:])
+    else:
+        build(force="--force" in sys.argv)

@@ -697,6 +697,15 @@ __device__ __forceinline__ int find_nul64(const uint8_t* W, uint32_t o, uint32_t
   return -1;
 }
 
+#ifndef FGX_PHASE_TIMING
+#define FGX_PHASE_TIMING 0   /* 1: per-phase s_memtime deltas of k_family_wave into g_phase (profiling builds only) */
+#endif
+#if FGX_PHASE_TIMING
+__device__ unsigned long long g_phase[64 * 16];
+#define PH(i) { unsigned long long _n = __builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(&g_phase[(blockIdx.x & 63) * 16 + (i)], _n - _t); _t = _n; }
+#else
+#define PH(i)
+#endif
 #ifndef FGX_WAVE_OCC
 #define FGX_WAVE_OCC 5   /* measured on MI355X, 1M depth-8 families: occ 4 19.2 ms, 5 17.2 ms, 6 18.1 ms */
 #endif
@@ -757,6 +766,9 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
   auto to_defer = [&]() { if (lane == 0) { uint32_t k = atomicAdd(P.n_deferred, 1u); P.deferred[k] = g; } };
   if (n > 64) { to_retry(); return; }
 
+#if FGX_PHASE_TIMING
+  unsigned long long _t = __builtin_amdgcn_s_memtime();
+#endif
   // ---- 1. stage the family's raw records into LDS ------------------------------------------------------
   const bool act = lane < n;
   unsigned long long off = act ? P.rec_off[r0 + lane] : ~0ull;
@@ -774,6 +786,7 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
   }
   wave_sync();
 
+  PH(1)
   // ---- 2. parse: lane r owns record r ---------------------------------------------------------------------
   const uint32_t lo = act ? (uint32_t)(off - base16) : 0;       // LDS offset of this lane's record
   uint32_t flags = 0, l_seq = 0, seq_lo = 0, qual_lo = 0, name_len = 0, clip = 0, hash = 0;
@@ -907,6 +920,7 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
   const bool rev = (flags & bam::F_REVERSE) != 0;
   const unsigned long long rxmask = __ballot(cand && has_rx), cbmask = __ballot(cand && has_cb);
 
+  PH(2)
   // ---- 3. overlapping-bases pre-correction in LDS (overlapping.rs:236-336, 627-684) ----------------------
   uint32_t ov_bases = 0, ov_agree = 0, ov_dis = 0, ov_corr = 0;
   if (P.overlap) {
@@ -916,64 +930,95 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
     int mate = -1;
     bool later_r1 = false;
     const unsigned long long r1mask = __ballot(is_r1), r2mask = __ballot(is_r2);
+    // candidates of each R1 lane: the other R1/R2 lanes with the same (name hash, name length) — one compare per lane
+    // pair here, the byte-wise name check below runs for all R1 lanes at once (usually a single round: the mate)
+    uint32_t eq_lo = 0, eq_hi = 0;
     for (unsigned long long um = r1mask | r2mask; um; um &= um - 1) {
       const uint32_t u = (uint32_t)__builtin_ctzll(um);
-      const uint32_t hu = rlane(hash, u), nlu = rlane(name_len, u), lou = rlane(lo, u);
-      const bool u_r1 = (r1mask >> u) & 1;
-      if (!is_r1 || hu != hash || nlu != name_len) continue;
-      bool same = true;
-      for (uint32_t i = 0; i < name_len; i += 8) {
-        unsigned long long wa = ld64u(W, lou + 32 + i), wb = ld64u(W, lo + 32 + i);
-        if (i + 8 > name_len) { unsigned long long mk = (1ULL << (8 * (name_len - i))) - 1; wa &= mk; wb &= mk; }
-        if (wa != wb) { same = false; break; }
-      }
-      if (!same) continue;
-      if (u_r1) { if (u > lane) later_r1 = true; }
-      else mate = (int)u;
+      const bool eq = rlane(hash, u) == hash && rlane(name_len, u) == name_len && u != lane;
+      if (u < 32) eq_lo |= (eq ? 1u : 0u) << u; else eq_hi |= (eq ? 1u : 0u) << (u - 32);
     }
-    if (later_r1) mate = -1;
-    unsigned long long pm = __ballot(mate >= 0);
-    for (; pm; pm &= pm - 1) {
-      uint32_t a = (uint32_t)__builtin_ctzll(pm);
-      uint32_t b = rlane((uint32_t)mate, a);
-      int32_t pa = (int32_t)rlane((uint32_t)pos, a), pb = (int32_t)rlane((uint32_t)pos, b);
-      if ((int32_t)rlane((uint32_t)ref_id, a) != (int32_t)rlane((uint32_t)ref_id, b)) continue;
-      uint32_t la = rlane(l_seq, a), lb2 = rlane(l_seq, b);
-      uint32_t sa = rlane(seq_lo, a), sb = rlane(seq_lo, b), qa0 = rlane(qual_lo, a), qb0 = rlane(qual_lo, b);
-      long long s1 = (long long)pa + 1, e1 = (long long)pa + la, s2 = (long long)pb + 1, e2 = (long long)pb + lb2;
-      long long lox = s1 > s2 ? s1 : s2, hix = e1 < e2 ? e1 : e2;
-      for (long long x = lox + lane; x <= hix; x += 64) {
-        uint32_t i1 = (uint32_t)(x - s1), i2 = (uint32_t)(x - s2);
-        uint32_t o1 = sa + (i1 >> 1), o2 = sb + (i2 >> 1);
-        uint8_t c1 = (i1 & 1) ? (W[o1] & 15) : (W[o1] >> 4), c2 = (i2 & 1) ? (W[o2] & 15) : (W[o2] >> 4);
-        if (c1 == 15 || c2 == 15) continue;
-        ov_bases++;
-        uint8_t qa = W[qa0 + i1], qb = W[qb0 + i2];
-        if (c1 == c2) {
-          ov_agree++;
-          uint32_t sm = (uint32_t)qa + qb;
-          uint8_t nq = (uint8_t)(sm < 93 ? sm : 93);
-          W[qa0 + i1] = nq; W[qb0 + i2] = nq;
-          if (nq != qa || nq != qb) ov_corr++;
-        } else {
-          ov_dis++;
-          uint8_t cb, cq;
-          if (qa == qb) { cb = 15; cq = FGX_MIN_PHRED; }
-          else if (qa > qb) { cb = c1; cq = (uint8_t)(qa - qb); if (cq < FGX_MIN_PHRED) cq = FGX_MIN_PHRED; }
-          else { cb = c2; cq = (uint8_t)(qb - qa); if (cq < FGX_MIN_PHRED) cq = FGX_MIN_PHRED; }
-          // nibble updates: neighbouring lanes own the other nibble of the same byte → 32-bit LDS atomics
-          auto setn = [&](uint32_t o, uint32_t idx, uint8_t code) {
-            uint32_t* w = (uint32_t*)(W + (o & ~3u));
-            uint32_t sh = 8 * (o & 3) + ((idx & 1) ? 0 : 4);
-            atomicAnd(w, ~(0xFu << sh));
-            atomicOr(w, (uint32_t)code << sh);
-          };
-          setn(o1, i1, cb); setn(o2, i2, cb);
-          W[qa0 + i1] = cq; W[qb0 + i2] = cq;
-          ov_corr += 2;
+    unsigned long long todo = is_r1 ? ((unsigned long long)eq_lo | ((unsigned long long)eq_hi << 32)) : 0ull;
+    while (__any(todo != 0)) {
+      const bool mine = todo != 0;
+      const uint32_t u = mine ? (uint32_t)__builtin_ctzll(todo) : lane;
+      todo &= todo - 1;
+      const uint32_t lou = (uint32_t)__shfl((int)lo, (int)u);
+      if (mine) {
+        bool same = true;
+        for (uint32_t i = 0; i < name_len; i += 8) {
+          unsigned long long wa = ld64u(W, lou + 32 + i), wb = ld64u(W, lo + 32 + i);
+          if (i + 8 > name_len) { unsigned long long mk = (1ULL << (8 * (name_len - i))) - 1; wa &= mk; wb &= mk; }
+          if (wa != wb) { same = false; break; }
+        }
+        if (same) {
+          if ((r1mask >> u) & 1) { if (u > lane) later_r1 = true; }
+          else mate = (int)u;     // ascending u: the LAST R2-type record of the name wins
         }
       }
-      wave_sync();
+    }
+    if (later_r1) mate = -1;
+    // Every overlapping position of every pair is one work item; items are laid out pair after pair (exclusive scan
+    // of the per-pair overlap lengths) and taken 64 at a time, so short overlaps of several pairs share an iteration.
+    const int msrc = mate >= 0 ? mate : (int)lane;
+    const int32_t pos_b = (int32_t)__shfl((int)pos, msrc), ref_b = (int32_t)__shfl((int)ref_id, msrc);
+    const uint32_t lseq_b = (uint32_t)__shfl((int)l_seq, msrc);
+    const uint32_t dsc_a = seq_lo | (qual_lo << 16), dsc_b = (uint32_t)__shfl((int)dsc_a, msrc);
+    uint32_t cntp = 0, off1 = 0, off2 = 0;
+    if (mate >= 0 && ref_id == ref_b) {
+      const long long s1 = (long long)pos + 1, e1 = (long long)pos + l_seq, s2 = (long long)pos_b + 1, e2 = (long long)pos_b + lseq_b;
+      const long long lox = s1 > s2 ? s1 : s2, hix = e1 < e2 ? e1 : e2;
+      if (hix >= lox) { cntp = (uint32_t)(hix - lox + 1); off1 = (uint32_t)(lox - s1); off2 = (uint32_t)(lox - s2); }
+    }
+    uint32_t incl = cntp;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t t = (uint32_t)__shfl_up((int)incl, o); if ((int)lane >= o) incl += t; }
+    const uint32_t first_item = incl - cntp, n_items = rlane(incl, 63);
+    for (uint32_t base = 0; base < n_items; base += 64) {
+      const uint32_t w = base + lane;
+      bool have = false;
+      uint32_t i1 = 0, i2 = 0, sa = 0, sb = 0, qa0 = 0, qb0 = 0;
+      for (unsigned long long pm = __ballot(cntp != 0 && first_item < base + 64 && first_item + cntp > base); pm; pm &= pm - 1) {
+        const uint32_t a = (uint32_t)__builtin_ctzll(pm);
+        const uint32_t st_a = rlane(first_item, a), cn_a = rlane(cntp, a), da = rlane(dsc_a, a), db = rlane(dsc_b, a);
+        const uint32_t o1a = rlane(off1, a), o2a = rlane(off2, a);
+        if (w >= st_a && w - st_a < cn_a) {
+          have = true;
+          i1 = o1a + (w - st_a); i2 = o2a + (w - st_a);
+          sa = da & 0xFFFF; qa0 = da >> 16; sb = db & 0xFFFF; qb0 = db >> 16;
+        }
+      }
+      if (have) {
+        uint32_t o1 = sa + (i1 >> 1), o2 = sb + (i2 >> 1);
+        uint8_t c1 = (i1 & 1) ? (W[o1] & 15) : (W[o1] >> 4), c2 = (i2 & 1) ? (W[o2] & 15) : (W[o2] >> 4);
+        if (c1 != 15 && c2 != 15) {
+          ov_bases++;
+          uint8_t qa = W[qa0 + i1], qb = W[qb0 + i2];
+          if (c1 == c2) {
+            ov_agree++;
+            uint32_t sm = (uint32_t)qa + qb;
+            uint8_t nq = (uint8_t)(sm < 93 ? sm : 93);
+            W[qa0 + i1] = nq; W[qb0 + i2] = nq;
+            if (nq != qa || nq != qb) ov_corr++;
+          } else {
+            ov_dis++;
+            uint8_t cb, cq;
+            if (qa == qb) { cb = 15; cq = FGX_MIN_PHRED; }
+            else if (qa > qb) { cb = c1; cq = (uint8_t)(qa - qb); if (cq < FGX_MIN_PHRED) cq = FGX_MIN_PHRED; }
+            else { cb = c2; cq = (uint8_t)(qb - qa); if (cq < FGX_MIN_PHRED) cq = FGX_MIN_PHRED; }
+            // nibble updates: neighbouring lanes own the other nibble of the same byte → 32-bit LDS atomics
+            auto setn = [&](uint32_t o, uint32_t idx, uint8_t code) {
+              uint32_t* wd = (uint32_t*)(W + (o & ~3u));
+              uint32_t sh = 8 * (o & 3) + ((idx & 1) ? 0 : 4);
+              atomicAnd(wd, ~(0xFu << sh));
+              atomicOr(wd, (uint32_t)code << sh);
+            };
+            setn(o1, i1, cb); setn(o2, i2, cb);
+            W[qa0 + i1] = cq; W[qb0 + i2] = cq;
+            ov_corr += 2;
+          }
+        }
+      }
     }
   }
   wave_sync();
@@ -990,6 +1035,7 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
     *code = c; *qual = q;
   };
 
+  PH(3)
   // ---- 4. source-read geometry per lane (vanilla_caller.rs:1129-1160) -----------------------------------------
   uint32_t trim_to = l_seq, final_len = 0;
   if (cand && P.trim) {
@@ -1030,6 +1076,7 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
     }
   }
 
+  PH(4)
   // ---- 5. family gates with ballots (process_group :1329-1422, process_subgroup :1454-1646) -----------------
   uint32_t s_total = n, s_cons = 0, s_filtered = 0, s_sec = 0, s_insuf = 0, s_zero = 0, s_orphan = 0;
   const uint32_t n_sec = (uint32_t)__popcll(__ballot(act && excluded));
@@ -1094,6 +1141,7 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
   }
   if (need_defer) { to_defer(); return; }
 
+  PH(5)
   // ---- 6. consensus columns: one lane per column, member reads walked in file order -------------------------
   // per-read descriptors packed for broadcast: d0 = seq_lo | qual_lo << 16 ; d1 = l_seq | final_len << 16 ; d2 = trim_to | rev << 16
   const uint32_t d0 = seq_lo | (qual_lo << 16), d1 = l_seq | (final_len << 16), d2 = trim_to | ((rev ? 1u : 0u) << 16);
@@ -1169,6 +1217,7 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
     }
   }
 
+  PH(6)
   // ---- 7. consensus UMI per end (simple_umi.rs:46-117) ---------------------------------------------------------
   const DeviceTables* TU = P.TU;
   char my_rx[3] = {0, 0, 0};      // lane i holds character i of each end's consensus UMI
@@ -1179,8 +1228,29 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
     if (e_rx_cnt[k] == 0) continue;                     // uniform
     const bool mychar = lane < e_rx_len[k];
     if (e_rx_cnt[k] == 1) { if (mychar) my_rx[k] = (char)W[rlane(rx_lo, e_rx_first[k]) + lane]; continue; }
-    // all-identical UMIs (the usual case): the consensus of n identical strings… still has to be CALLED (a single
-    // Q20 observation is not enough to keep the base), so run the per-character columns
+    // Byte-identical UMIs (the usual case) need no arithmetic: n >= 2 agreeing observations of base b leave b the
+    // strict maximum of the four likelihoods whatever n is, so the call is the upper-cased base; a column of N/n has
+    // no observations and calls 'N'; a non-DNA character shared by every string is kept (simple_umi.rs:69-103).
+    {
+      const uint32_t f_lo = rlane(rx_lo, e_rx_first[k]), ulen = e_rx_len[k];
+      bool differs = false;
+      if ((e_mem[k] & rxmask) >> lane & 1) {
+        for (uint32_t i = 0; i < ulen; i += 8) {
+          unsigned long long a = ld64u(W, rx_lo + i), b = ld64u(W, f_lo + i);
+          if (i + 8 > ulen) { unsigned long long mk = (1ULL << (8 * (ulen - i))) - 1; a &= mk; b &= mk; }
+          differs |= a != b;
+        }
+      }
+      if (!__any(differs)) {
+        if (mychar) {
+          const uint8_t ch = W[f_lo + lane];
+          const int bl = bam::ascii_to_lane(ch);
+          my_rx[k] = bl != 255 ? "ACGT"[bl] : (ch == 'N' || ch == 'n') ? 'N' : (char)ch;
+        }
+        continue;
+      }
+    }
+    // UMIs that differ (sequencing errors inside a family): per-character likelihood columns
     ColumnAcc acc;
     acc.reset();
     uint32_t non_dna = 0, seen = 0;
@@ -1212,6 +1282,7 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
   }
   if (__any(rx_bad) || __any(list_overflow)) { to_defer(); return; }
 
+  PH(7)
   // ---- 8. descriptors + stats ---------------------------------------------------------------------------------------
 #pragma unroll
   for (uint32_t k = 0; k < 3; k++) {
@@ -1255,6 +1326,7 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
     if (ov_dis) atomicAdd(&st[26], (unsigned long long)ov_dis);
     if (ov_corr) atomicAdd(&st[27], (unsigned long long)ov_corr);
   }
+  PH(8)
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -1596,3 +1668,13 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
 }
 
 }  // namespace fgx
+
+#if FGX_PHASE_TIMING
+extern "C" int fgx_debug_phase_cycles(unsigned long long* out16, int reset) {
+  unsigned long long h[64 * 16];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(fgx::g_phase), sizeof(h)) != hipSuccess) return 1;
+  for (int i = 0; i < 16; i++) { out16[i] = 0; for (int b = 0; b < 64; b++) out16[i] += h[b * 16 + i]; }
+  if (reset) { memset(h, 0, sizeof(h)); if (hipMemcpyToSymbol(HIP_SYMBOL(fgx::g_phase), h, sizeof(h)) != hipSuccess) return 1; }
+  return 0;
+}
+#endif
