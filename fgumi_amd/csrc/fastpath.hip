@@ -1372,116 +1372,201 @@ __global__ __launch_bounds__(256) void k_call_full(FullParams P) {
 // -----------------------------------------------------------------------------------------------------
 // pass B: one wavefront per consensus read
 // -----------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void put_int_tag(uint8_t* q, char a, char b, uint32_t v, uint32_t* n) {
-  q[0] = a; q[1] = b;
-  if (v <= 127) { q[2] = 'c'; q[3] = (uint8_t)v; *n = 4; }
-  else if (v <= 255) { q[2] = 'C'; q[3] = (uint8_t)v; *n = 4; }
-  else { q[2] = 'S'; q[3] = (uint8_t)v; q[4] = (uint8_t)(v >> 8); *n = 5; }
+// byte j of an integer tag `ab:<c|C|S>:v` (smallest type, signed first; v <= 32767 here)
+__device__ __forceinline__ uint8_t int_tag_byte(uint32_t j, char a, char b, uint32_t v) {
+  return j == 0 ? (uint8_t)a : j == 1 ? (uint8_t)b : j == 2 ? (uint8_t)(v <= 127 ? 'c' : v <= 255 ? 'C' : 'S') : j == 3 ? (uint8_t)v : (uint8_t)(v >> 8);
 }
 
-__global__ __launch_bounds__(256) void k_emit(EmitParams P) {
-  uint32_t slot = P.slot0 + ((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-  uint32_t lane = threadIdx.x & 63;
-  if (slot >= P.slot_end) return;
-  const EndDesc& D = P.ends[slot];
-  if (!D.valid) return;
-  uint8_t* out = P.out + (P.out_off[slot] - P.out_base);
-  uint32_t Lc = D.cons_len;
-  const uint8_t* first = P.blob + P.rec_off[D.first_rec];
-  uint32_t name_len = P.prefix_len + 1 + D.mi_len;
-  uint16_t flag = bam::F_UNMAPPED;
-  if (D.type == 1) flag |= bam::F_PAIRED | bam::F_FIRST | bam::F_MATE_UNMAPPED;
-  else if (D.type == 2) flag |= bam::F_PAIRED | bam::F_LAST | bam::F_MATE_UNMAPPED;
-  uint8_t* q = out;
-  if (lane == 0) {
-    uint32_t bs = D.rec_size;
-    q[0] = (uint8_t)bs; q[1] = (uint8_t)(bs >> 8); q[2] = (uint8_t)(bs >> 16); q[3] = (uint8_t)(bs >> 24);
-    uint8_t* h = q + 4;
-    for (int i = 0; i < 8; i++) h[i] = 0xFF;                       // ref_id = -1, pos = -1
-    h[8] = (uint8_t)(name_len + 1); h[9] = 0;                      // l_read_name, mapq
-    h[10] = (uint8_t)(4680 & 0xFF); h[11] = (uint8_t)(4680 >> 8);  // bin
-    h[12] = 0; h[13] = 0;                                          // n_cigar_op
-    h[14] = (uint8_t)flag; h[15] = (uint8_t)(flag >> 8);
-    h[16] = (uint8_t)Lc; h[17] = (uint8_t)(Lc >> 8); h[18] = (uint8_t)(Lc >> 16); h[19] = (uint8_t)(Lc >> 24);
-    for (int i = 20; i < 28; i++) h[i] = 0xFF;                     // next_ref_id, next_pos
-    for (int i = 28; i < 32; i++) h[i] = 0;                        // tlen
+// One wavefront serialises one consensus record (block_size prefix, 32-byte core, name, packed bases, quals, tags
+// `RG cD cM cE [cd ce] MI [CB] RX` — vanilla_caller.rs:1767-1881).  The kernel is bound by memory round trips per
+// wavefront, not by bytes: so (hot path, consensus <= 192 columns and short names/tags) EVERY load of the record is
+// issued before the first store — one wait instead of one per field — descriptor fields are scalar loads, and every
+// field group is one full-wave store in which each lane computes the byte it owns (fixed header bytes included).
+struct EmitCtx {
+  uint8_t* q; const uint8_t* first; const uint8_t* code; const uint8_t* cq; const uint16_t* cd; const uint16_t* ce;
+  uint32_t Lc, name_len, mi_len, mi_off, flag, rec_size;
+};
+
+__device__ __forceinline__ void emit_core(uint8_t* q, uint32_t lane, const EmitCtx& X) {
+  // block_size + fixed core: ref_id -1, pos -1, l_read_name, mapq 0, bin 4680, n_cigar_op 0, flag, l_seq, next_ref -1, next_pos -1, tlen 0
+  if (lane < 36) {
+    const uint32_t dw = lane >> 2;
+    const uint32_t v = dw == 0 ? X.rec_size : dw == 3 ? ((X.name_len + 1) | (4680u << 16)) : dw == 4 ? (X.flag << 16) : dw == 5 ? X.Lc : dw == 8 ? 0u : 0xFFFFFFFFu;
+    q[lane] = (uint8_t)(v >> (8 * (lane & 3)));
   }
+}
+__device__ __forceinline__ uint8_t cdcmce_byte(uint32_t lane, uint32_t n_cd, uint32_t n_cm, uint32_t maxd, uint32_t mind, float rate) {
+  if (lane < n_cd) return int_tag_byte(lane, 'c', 'D', maxd);
+  if (lane < n_cd + n_cm) return int_tag_byte(lane - n_cd, 'c', 'M', mind);
+  const uint32_t j = lane - n_cd - n_cm, u = __float_as_uint(rate);
+  return j == 0 ? 'c' : j == 1 ? 'E' : j == 2 ? 'f' : (uint8_t)(u >> (8 * (j - 3)));
+}
+
+// any length: field after field (one load → store round trip per 64 bytes)
+__device__ void emit_generic(const EmitParams& P, const EndDesc& D, const EmitCtx& X, uint32_t lane) {
+  uint8_t* q = X.q;
+  const uint32_t Lc = X.Lc, name_len = X.name_len, mi_len = X.mi_len, mi_off = X.mi_off;
+  uint32_t maxd = 0, mind = 0xFFFFFFFFu, sumd = 0, sume = 0;
+  for (uint32_t i = lane; i < Lc; i += 64) { uint32_t d = X.cd[i], e = X.ce[i]; maxd = d > maxd ? d : maxd; mind = d < mind ? d : mind; sumd += d; sume += e; }
+  emit_core(q, lane, X);
   q += 36;
   for (uint32_t i = lane; i < name_len + 1; i += 64) {
     uint8_t ch;
     if (i < P.prefix_len) ch = (uint8_t)P.prefix[i];
     else if (i == P.prefix_len) ch = ':';
-    else if (i < name_len) ch = first[D.mi_off + (i - P.prefix_len - 1)];
+    else if (i < name_len) ch = X.first[mi_off + (i - P.prefix_len - 1)];
     else ch = 0;
     q[i] = ch;
   }
   q += name_len + 1;
-  const uint8_t* code = P.col_code + D.col_off;
   for (uint32_t i = lane; i < (Lc + 1) / 2; i += 64) {
-    uint8_t hi = code[2 * i], lo = (2 * i + 1 < Lc) ? code[2 * i + 1] : 0;
+    uint8_t hi = X.code[2 * i], lo = (2 * i + 1 < Lc) ? X.code[2 * i + 1] : 0;
     q[i] = (uint8_t)((hi << 4) | lo);
   }
   q += (Lc + 1) / 2;
-  const uint8_t* cq = P.col_qual + D.col_off;
-  for (uint32_t i = lane; i < Lc; i += 64) q[i] = cq[i];
+  for (uint32_t i = lane; i < Lc; i += 64) q[i] = X.cq[i];
   q += Lc;
-  // tags: RG cD cM cE [cd ce] MI [CB] RX
-  uint32_t n_cd, n_cm;
-  if (lane == 0) { q[0] = 'R'; q[1] = 'G'; q[2] = 'Z'; }
-  for (uint32_t i = lane; i < P.rg_len + 1; i += 64) q[3 + i] = i < P.rg_len ? (uint8_t)P.rg[i] : 0;
+  for (uint32_t i = lane; i < 3 + P.rg_len + 1; i += 64) q[i] = i == 0 ? 'R' : i == 1 ? 'G' : i == 2 ? 'Z' : i - 3 < P.rg_len ? (uint8_t)P.rg[i - 3] : 0;
   q += 3 + P.rg_len + 1;
-  // cD / cM / cE from the per-position arrays (vanilla_caller.rs:1800-1810): max / min depth, Σerrors / Σdepth as f32
-  uint32_t maxd = 0, mind = 0xFFFFFFFFu, sumd = 0, sume = 0;
-  {
-    const uint16_t* cd = P.col_depth + D.col_off;
-    const uint16_t* ce = P.col_err + D.col_off;
-    for (uint32_t i = lane; i < Lc; i += 64) { uint32_t d = cd[i], e = ce[i]; maxd = d > maxd ? d : maxd; mind = d < mind ? d : mind; sumd += d; sume += e; }
-    for (int o = 32; o > 0; o >>= 1) {
-      uint32_t a = __shfl_xor(maxd, o), b = __shfl_xor(mind, o);
-      maxd = a > maxd ? a : maxd; mind = b < mind ? b : mind;
-      sumd += __shfl_xor(sumd, o); sume += __shfl_xor(sume, o);
-    }
-    if (Lc == 0) { maxd = 0; mind = 0; }
+  for (int o = 32; o > 0; o >>= 1) {
+    uint32_t a = __shfl_xor(maxd, o), b = __shfl_xor(mind, o);
+    maxd = a > maxd ? a : maxd; mind = b < mind ? b : mind;
+    sumd += __shfl_xor(sumd, o); sume += __shfl_xor(sume, o);
   }
+  if (Lc == 0) { maxd = 0; mind = 0; }
   const float ce_rate = sumd > 0 ? (float)sume / (float)sumd : 0.0f;
-  n_cd = 3 + int_tag_width(maxd);
-  n_cm = 3 + int_tag_width(mind);
-  if (lane == 0) {
-    uint32_t w;
-    put_int_tag(q, 'c', 'D', maxd, &w);
-    put_int_tag(q + n_cd, 'c', 'M', mind, &w);
-    uint8_t* f = q + n_cd + n_cm;
-    uint32_t u = __float_as_uint(ce_rate);
-    f[0] = 'c'; f[1] = 'E'; f[2] = 'f'; f[3] = (uint8_t)u; f[4] = (uint8_t)(u >> 8); f[5] = (uint8_t)(u >> 16); f[6] = (uint8_t)(u >> 24);
-  }
+  const uint32_t n_cd = 3 + int_tag_width(maxd), n_cm = 3 + int_tag_width(mind);
+  if (lane < n_cd + n_cm + 7) q[lane] = cdcmce_byte(lane, n_cd, n_cm, maxd, mind, ce_rate);
   q += n_cd + n_cm + 7;
   if (P.per_base_tags) {
-    const uint16_t* cd = P.col_depth + D.col_off;
-    const uint16_t* ce = P.col_err + D.col_off;
     for (int pass = 0; pass < 2; pass++) {
-      if (lane == 0) {
-        q[0] = 'c'; q[1] = pass == 0 ? 'd' : 'e'; q[2] = 'B'; q[3] = 's';
-        q[4] = (uint8_t)Lc; q[5] = (uint8_t)(Lc >> 8); q[6] = (uint8_t)(Lc >> 16); q[7] = (uint8_t)(Lc >> 24);
+      const uint16_t* src = pass == 0 ? X.cd : X.ce;
+      for (uint32_t i = lane; i < 8 + 2 * Lc; i += 64) {
+        uint8_t v;
+        if (i < 8) v = i == 0 ? 'c' : i == 1 ? (pass == 0 ? 'd' : 'e') : i == 2 ? 'B' : i == 3 ? 's' : (uint8_t)(Lc >> (8 * (i - 4)));
+        else { const uint32_t k = i - 8; const uint16_t w = src[k >> 1]; v = (k & 1) ? (uint8_t)(w >> 8) : (uint8_t)w; }
+        q[i] = v;
       }
-      const uint16_t* src = pass == 0 ? cd : ce;
-      for (uint32_t i = lane; i < Lc; i += 64) { uint16_t v = src[i]; q[8 + 2 * i] = (uint8_t)v; q[9 + 2 * i] = (uint8_t)(v >> 8); }
       q += 8 + 2 * Lc;
     }
   }
-  if (lane == 0) { q[0] = (uint8_t)P.tag0; q[1] = (uint8_t)P.tag1; q[2] = 'Z'; }
-  for (uint32_t i = lane; i < (uint32_t)D.mi_len + 1; i += 64) q[3 + i] = i < D.mi_len ? first[D.mi_off + i] : 0;
-  q += 3 + D.mi_len + 1;
+  for (uint32_t i = lane; i < 3 + mi_len + 1; i += 64) q[i] = i == 0 ? (uint8_t)P.tag0 : i == 1 ? (uint8_t)P.tag1 : i == 2 ? 'Z' : i - 3 < mi_len ? X.first[mi_off + i - 3] : 0;
+  q += 3 + mi_len + 1;
   if (D.has_cb) {
     const uint8_t* fk = P.blob + P.rec_off[D.first_kept_rec];
-    if (lane == 0) { q[0] = (uint8_t)P.cell0; q[1] = (uint8_t)P.cell1; q[2] = 'Z'; }
-    for (uint32_t i = lane; i < (uint32_t)D.cb_len + 1; i += 64) q[3 + i] = i < D.cb_len ? fk[D.cb_off + i] : 0;
-    q += 3 + D.cb_len + 1;
+    const uint32_t cb_len = D.cb_len, cb_off = D.cb_off;
+    for (uint32_t i = lane; i < 3 + cb_len + 1; i += 64) q[i] = i == 0 ? (uint8_t)P.cell0 : i == 1 ? (uint8_t)P.cell1 : i == 2 ? 'Z' : i - 3 < cb_len ? fk[cb_off + i - 3] : 0;
+    q += 3 + cb_len + 1;
   }
   if (D.has_rx) {
-    if (lane == 0) { q[0] = 'R'; q[1] = 'X'; q[2] = 'Z'; }
-    for (uint32_t i = lane; i < (uint32_t)D.rx_len + 1; i += 64) q[3 + i] = i < D.rx_len ? (uint8_t)D.rx[i] : 0;
-    q += 3 + D.rx_len + 1;
+    const uint32_t rx_len = D.rx_len;
+    for (uint32_t i = lane; i < 3 + rx_len + 1; i += 64) q[i] = i == 0 ? 'R' : i == 1 ? 'X' : i == 2 ? 'Z' : i - 3 < rx_len ? (uint8_t)D.rx[i - 3] : 0;
   }
+}
+
+__global__ __launch_bounds__(256) void k_emit(EmitParams P) {
+  const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(P.slot0 + ((blockIdx.x * blockDim.x + threadIdx.x) >> 6)));
+  const uint32_t lane = threadIdx.x & 63;
+  if (slot >= P.slot_end) return;
+  const EndDesc& D = P.ends[slot];
+  if (!D.valid) return;
+  EmitCtx X;
+  X.q = P.out + (P.out_off[slot] - P.out_base);
+  X.Lc = D.cons_len;
+  X.first = P.blob + P.rec_off[D.first_rec];
+  X.mi_len = D.mi_len; X.mi_off = D.mi_off;
+  X.name_len = P.prefix_len + 1 + X.mi_len;
+  X.rec_size = D.rec_size;
+  X.flag = bam::F_UNMAPPED;
+  if (D.type == 1) X.flag |= bam::F_PAIRED | bam::F_FIRST | bam::F_MATE_UNMAPPED;
+  else if (D.type == 2) X.flag |= bam::F_PAIRED | bam::F_LAST | bam::F_MATE_UNMAPPED;
+  X.code = P.col_code + D.col_off; X.cq = P.col_qual + D.col_off; X.cd = P.col_depth + D.col_off; X.ce = P.col_err + D.col_off;
+  const uint32_t Lc = X.Lc, name_len = X.name_len, mi_len = X.mi_len, mi_off = X.mi_off;
+  const bool has_cb = D.has_cb != 0, has_rx = D.has_rx != 0;
+  const uint32_t cb_len = has_cb ? D.cb_len : 0, rx_len = has_rx ? D.rx_len : 0;
+  if (Lc > 192 || name_len + 1 > 64 || P.rg_len + 4 > 64 || cb_len + 4 > 64) { emit_generic(P, D, X, lane); return; }
+
+  // ---- every load of the record, back to back ----------------------------------------------------------------
+  // (unconditional, indices clamped into the record's own arrays: no branch, hence no wait, between the loads)
+  uint32_t dv[3], ev[3], qv[3], sh[2], sl[2], ad[7], ae[7];
+  const uint32_t last_col = Lc ? Lc - 1 : 0;
+#pragma unroll
+  for (int t = 0; t < 3; t++) {
+    const uint32_t i = lane + 64 * t, ic = i < last_col ? i : last_col;
+    dv[t] = X.cd[ic]; ev[t] = X.ce[ic]; qv[t] = X.cq[ic];
+  }
+#pragma unroll
+  for (int t = 0; t < 2; t++) {
+    const uint32_t i = 2 * (lane + 64 * t), i0 = i < last_col ? i : last_col, i1 = i + 1 < last_col ? i + 1 : last_col;
+    sh[t] = X.code[i0]; sl[t] = i + 1 < Lc ? X.code[i1] : 0;
+  }
+  const uint32_t n_arr = P.per_base_tags ? 8 + 2 * Lc : 0;
+#pragma unroll
+  for (int t = 0; t < 7; t++) {
+    const uint32_t i = lane + 64 * t;
+    uint32_t k = i >= 8 ? (i - 8) >> 1 : 0;
+    k = k < last_col ? k : last_col;
+    ad[t] = X.cd[k]; ae[t] = X.ce[k];
+  }
+  const uint32_t j3 = lane >= 3 ? lane - 3 : 0;
+  const uint32_t ni = lane > P.prefix_len ? lane - P.prefix_len - 1 : 0;
+  const uint8_t pfx = (uint8_t)P.prefix[lane < P.prefix_len ? lane : 0];                       // d_strings keeps 16 bytes of slack
+  const uint8_t nmb = X.first[mi_off + (ni < mi_len ? ni : mi_len)];                            // index mi_len is the tag's NUL
+  const uint8_t nb = lane < P.prefix_len ? pfx : lane == P.prefix_len ? (uint8_t)':' : lane < name_len ? nmb : (uint8_t)0;
+  const uint8_t rgb = (uint8_t)P.rg[j3 < P.rg_len ? j3 : 0];
+  const uint8_t mib = X.first[mi_off + (j3 < mi_len ? j3 : mi_len)];
+  const uint8_t* fk = has_cb ? P.blob + P.rec_off[D.first_kept_rec] + D.cb_off : X.first;
+  const uint8_t cbb = fk[j3 < cb_len ? j3 : 0];
+  const uint8_t rxb = (uint8_t)D.rx[j3 < FAST_RX_CAP ? j3 : 0];
+
+  // ---- cD / cM / cE (vanilla_caller.rs:1800-1810): max / min depth, Σerrors / Σdepth as f32 ---------------------
+  uint32_t maxd = 0, mind = 0xFFFFFFFFu, sumd = 0, sume = 0;
+#pragma unroll
+  for (int t = 0; t < 3; t++) if (lane + 64 * t < Lc) { maxd = dv[t] > maxd ? dv[t] : maxd; mind = dv[t] < mind ? dv[t] : mind; sumd += dv[t]; sume += ev[t]; }
+  for (int o = 32; o > 0; o >>= 1) {
+    uint32_t a = __shfl_xor(maxd, o), b = __shfl_xor(mind, o);
+    maxd = a > maxd ? a : maxd; mind = b < mind ? b : mind;
+    sumd += __shfl_xor(sumd, o); sume += __shfl_xor(sume, o);
+  }
+  if (Lc == 0) { maxd = 0; mind = 0; }
+  const float ce_rate = sumd > 0 ? (float)sume / (float)sumd : 0.0f;
+  const uint32_t n_cd = 3 + int_tag_width(maxd), n_cm = 3 + int_tag_width(mind);
+
+  // ---- stores -----------------------------------------------------------------------------------------------------------
+  uint8_t* q = X.q;
+  emit_core(q, lane, X);
+  q += 36;
+  if (lane < name_len + 1) q[lane] = nb;
+  q += name_len + 1;
+#pragma unroll
+  for (int t = 0; t < 2; t++) { const uint32_t i = lane + 64 * t; if (i < (Lc + 1) / 2) q[i] = (uint8_t)((sh[t] << 4) | sl[t]); }
+  q += (Lc + 1) / 2;
+#pragma unroll
+  for (int t = 0; t < 3; t++) { const uint32_t i = lane + 64 * t; if (i < Lc) q[i] = (uint8_t)qv[t]; }
+  q += Lc;
+  if (lane < 3 + P.rg_len + 1) q[lane] = lane == 0 ? 'R' : lane == 1 ? 'G' : lane == 2 ? 'Z' : j3 < P.rg_len ? rgb : (uint8_t)0;
+  q += 3 + P.rg_len + 1;
+  if (lane < n_cd + n_cm + 7) q[lane] = cdcmce_byte(lane, n_cd, n_cm, maxd, mind, ce_rate);
+  q += n_cd + n_cm + 7;
+  if (P.per_base_tags) {
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+#pragma unroll
+      for (int t = 0; t < 7; t++) {
+        const uint32_t i = lane + 64 * t;
+        if (i < n_arr) {
+          const uint32_t w = pass == 0 ? ad[t] : ae[t];
+          q[i] = i < 8 ? (i == 0 ? 'c' : i == 1 ? (pass == 0 ? 'd' : 'e') : i == 2 ? 'B' : i == 3 ? 's' : (uint8_t)(Lc >> (8 * (i - 4))))
+                       : (uint8_t)(((i - 8) & 1) ? (w >> 8) : w);
+        }
+      }
+      q += n_arr;
+    }
+  }
+  if (lane < 3 + mi_len + 1) q[lane] = lane == 0 ? (uint8_t)P.tag0 : lane == 1 ? (uint8_t)P.tag1 : lane == 2 ? 'Z' : j3 < mi_len ? mib : (uint8_t)0;
+  q += 3 + mi_len + 1;
+  if (has_cb) { if (lane < 3 + cb_len + 1) q[lane] = lane == 0 ? (uint8_t)P.cell0 : lane == 1 ? (uint8_t)P.cell1 : lane == 2 ? 'Z' : j3 < cb_len ? cbb : (uint8_t)0; q += 3 + cb_len + 1; }
+  if (has_rx) { if (lane < 3 + rx_len + 1) q[lane] = lane == 0 ? 'R' : lane == 1 ? 'X' : lane == 2 ? 'Z' : j3 < rx_len ? rxb : (uint8_t)0; }
 }
 
 // Upper bound on the consensus columns a batch can produce: a family yields at most three ends, each no
