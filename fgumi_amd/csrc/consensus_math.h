@@ -138,6 +138,11 @@ struct ConsensusTables {
   double ln_error_pre_umi;
   uint32_t cap;
   uint32_t tie_rule;         // 0 FgbioCompat, 1 UlpRelative
+  // Search hint for the gap → quality bracket lookup: qguess[k] = number of thresholds <= k/8, so a gap in
+  // [k/8, (k+1)/8) has its upper bound at or just above qguess[k] (derived data, not a reference table).
+  uint8_t qguess[256];
+  double cap_threshold;      // thresholds[cap]
+  double half_cerr_at_cap;   // 0.5 * cerr_min[cap - 1], the cap-region budget of unanimous_fast_path
 };
 
 FGX_HD uint8_t unanimous_quality_from_gap(double gap, double ln_error_pre_umi) {
@@ -186,6 +191,14 @@ inline void build_tables(ConsensusTables& t, uint8_t pre, uint8_t post, uint32_t
   for (int q = 0; q <= FGX_MAX_PHRED; q++) t.cerr_min[q] = 0.0;
   for (uint32_t q = 0; q < t.cap && q < 94; q++) t.cerr_min[q] = consensus_error(t.thresholds[q + 1]);
   t.tie_rule = tie_rule;
+  for (int k = 0; k < 256; k++) {
+    double edge = (double)k * 0.125;
+    int n = 0;
+    for (int q = 0; q <= FGX_MAX_PHRED; q++) if (t.thresholds[q] <= edge) n++;
+    t.qguess[k] = (uint8_t)n;
+  }
+  t.cap_threshold = t.thresholds[t.cap < 94 ? t.cap : 93];
+  t.half_cerr_at_cap = 0.5 * t.cerr_min[t.cap ? t.cap - 1 : 0];
 }
 
 // single_input_consensus_quals (vanilla_caller.rs:469-501)

@@ -697,6 +697,55 @@ __device__ __forceinline__ int find_nul64(const uint8_t* W, uint32_t o, uint32_t
   return -1;
 }
 
+// column_call_fast for the wave kernel: same decisions as consensus_math.h's unanimous_fast_path, arranged for the
+// GPU — the four likelihoods stay in registers (selects instead of dynamic indexing, which would go through scratch
+// memory) and the bracket q with thresholds[q] <= gap < thresholds[q+1] comes from the qguess hint plus ONE parallel
+// probe of five neighbouring thresholds instead of a 7-step dependent binary search through LDS.
+struct CallConst { double cap_threshold, half_cerr_at_cap; uint32_t cap; };
+__device__ __forceinline__ double uniform_f64(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double sel4(const double* v, uint32_t i) { return i == 0 ? v[0] : i == 1 ? v[1] : i == 2 ? v[2] : v[3]; }
+__device__ __forceinline__ bool column_call_fast_lds(const ConsensusTables& T, const CallConst& K, const double* ll, const uint32_t* obs,
+                                                     int* base_idx, uint8_t* qual) {
+  if (obs[0] + obs[1] + obs[2] + obs[3] == 0) { *base_idx = -1; *qual = FGX_MIN_PHRED; return true; }
+  const uint32_t n_obs = (obs[0] > 0) + (obs[1] > 0) + (obs[2] > 0) + (obs[3] > 0);
+  if (n_obs != 1) return false;
+  const uint32_t observed = obs[3] > 0 ? 3u : obs[2] > 0 ? 2u : obs[1] > 0 ? 1u : 0u;
+  const double w = sel4(ll, observed), l = sel4(ll, (observed + 1) & 3);
+  const double gap = w - l;
+  if (!(m_isfinite(gap) && gap > FGX_DBL_EPSILON)) return false;
+  if (gap >= K.cap_threshold) {
+    const double delta = unanimous_margin(w, l, 1.0);
+    if (gap - K.cap_threshold >= FGX_LN_2 && delta < K.half_cerr_at_cap) { *base_idx = (int)observed; *qual = (uint8_t)K.cap; return true; }
+    return false;
+  }
+  uint32_t lo;
+  double thq, thq1;
+  bool probed = false;
+  if (gap < 32.0) {
+    const uint32_t b = T.qguess[(uint32_t)(gap * 8.0)];            // thresholds[0..b) <= gap for sure; b >= 1 (thresholds[0] = 0)
+    if (b >= 1) {
+      double t[5];
+#pragma unroll
+      for (int j = 0; j < 5; j++) { uint32_t idx = b - 1 + j; t[j] = T.thresholds[idx < 93 ? idx : 93]; }
+      const uint32_t c = (t[1] <= gap) + (t[2] <= gap) + (t[3] <= gap) + (t[4] <= gap);
+      if (c < 4) { lo = b + c; thq = c == 0 ? t[0] : c == 1 ? t[1] : c == 2 ? t[2] : t[3]; thq1 = c == 0 ? t[1] : c == 1 ? t[2] : c == 2 ? t[3] : t[4]; probed = true; }
+    }
+  }
+  if (!probed) {
+    uint32_t a = 0, hi = 94;
+    while (a < hi) { uint32_t mid = a + (hi - a) / 2; if (T.thresholds[mid] <= gap) a = mid + 1; else hi = mid; }
+    lo = a; thq = T.thresholds[lo - 1]; thq1 = T.thresholds[lo];
+  }
+  const uint32_t q = lo - 1;
+  const double margin = unanimous_margin(w, l, T.cerr_min[q]);
+  if (gap - thq > margin && thq1 - gap > margin) { *base_idx = (int)observed; *qual = (uint8_t)q; return true; }
+  return false;
+}
+
 #ifndef FGX_PHASE_TIMING
 #define FGX_PHASE_TIMING 0   /* 1: per-phase s_memtime deltas of k_family_wave into g_phase (profiling builds only) */
 #endif
@@ -1114,10 +1163,17 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
     }
   }
   if (need_defer) { to_defer(); return; }
-  uint32_t ne = 0, e_type[3], e_len[3], e_coloff[3];
+  // emitted ends in output order (Fragment, R1, R2), written with static indices only (a dynamically indexed local
+  // array would live in scratch memory)
+  uint32_t e_type[3], e_len[3], e_coloff[3];
   unsigned long long e_mem[3];
-  if (ok[0]) { s_cons += 1; e_type[ne] = 0; e_len[ne] = clen[0]; e_mem[ne] = mem[0]; ne++; }
-  if (ok[1] && ok[2]) { s_cons += 2; e_type[ne] = 1; e_len[ne] = clen[1]; e_mem[ne] = mem[1]; ne++; e_type[ne] = 2; e_len[ne] = clen[2]; e_mem[ne] = mem[2]; ne++; }
+  const bool has_frag = ok[0], has_pair = ok[1] && ok[2];
+  const uint32_t ne = (has_frag ? 1u : 0u) + (has_pair ? 2u : 0u);
+  e_type[0] = has_frag ? 0u : 1u; e_len[0] = has_frag ? clen[0] : clen[1]; e_mem[0] = has_frag ? mem[0] : mem[1];
+  e_type[1] = has_frag ? 1u : 2u; e_len[1] = has_frag ? clen[1] : clen[2]; e_mem[1] = has_frag ? mem[1] : mem[2];
+  e_type[2] = 2u; e_len[2] = clen[2]; e_mem[2] = mem[2];
+  if (has_frag) s_cons += 1;
+  if (has_pair) s_cons += 2;
   else if (ok[1]) { s_filtered += surv[1]; s_orphan += surv[1]; }
   else if (ok[2]) { s_filtered += surv[2]; s_orphan += surv[2]; }
   uint32_t total_cols = 0;
@@ -1148,6 +1204,9 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
   const DeviceTables* T = P.T;
   const uint64_t col_base = P.col_base[g];
   const uint32_t min_bq = P.min_input_bq;
+  CallConst KC;   // wave-uniform, pinned into SGPRs (readfirstlane): no VGPRs held, nothing to spill
+  KC.cap = (uint32_t)__builtin_amdgcn_readfirstlane((int)sT.cap);
+  KC.cap_threshold = uniform_f64(sT.cap_threshold); KC.half_cerr_at_cap = uniform_f64(sT.half_cerr_at_cap);
 #pragma unroll
   for (uint32_t k = 0; k < 3; k++) {
     if (k >= ne) break;
@@ -1195,7 +1254,7 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
         acc.finish(ll, obs);
         int bi;
         uint8_t q;
-        bool resolved = column_call_fast(sT, ll, obs, &bi, &q);
+        bool resolved = column_call_fast_lds(sT, KC, ll, obs, &bi, &q);
         depth = obs[0] + obs[1] + obs[2] + obs[3];
         uint64_t o = col_base + e_coloff[k] + p;
         uint32_t d16 = depth < 32767u ? depth : 32767u;
@@ -1271,7 +1330,9 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
     if (!mychar) { /* lanes past the UMI length only take part in the ballots below */ }
     else if (non_dna == 0) {
       int bi; uint8_t q;
-      bool resolved = column_call_fast(TU->t, acc.s, acc.obs, &bi, &q);
+      CallConst KU;
+      KU.cap = TU->t.cap; KU.cap_threshold = TU->t.cap_threshold; KU.half_cerr_at_cap = TU->t.half_cerr_at_cap;
+      bool resolved = column_call_fast_lds(TU->t, KU, acc.s, acc.obs, &bi, &q);
       my_rx[k] = bi >= 0 ? "ACGT"[bi] : 'N';
       need_full = !resolved;
     }
