@@ -45,6 +45,26 @@ def cpu_baseline(n_families, family_size, read_length, threads):
                 consensus_reads_per_s=res["count"] / best)
 
 
+def pmc_traffic(families, depth, read_length):
+    """HBM bytes of one k_family_wave launch from the committed rocprofv3 PMC passes of THIS workload (collected by
+    tools/profile_round.sh in separate --pmc runs, summarised by tools/pmc_parse.py): 2 x FETCH_SIZE (the gfx950
+    correction for wide coalesced reads, MI355X_MICROARCH.md "HBM") + WRITE_SIZE, both in KiB.  WRITE_SIZE tallies a
+    full request granule per partial-line store, so it over-states the kernel's many small descriptor stores; k_emit's
+    streaming stores calibrate it at 0.99 of the true byte count.  None when no profile matches the workload."""
+    if (depth, read_length) != (8, 150):
+        return None
+    import glob
+    tag = f"{families // 1000000}M" if families % 1000000 == 0 else str(families)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*pmc_{tag}_families.json")))
+    if not files:
+        return None
+    try:
+        k = json.load(open(files[-1]))["k_family_wave"]
+        return (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
+    except (KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,7 +139,7 @@ def main():
                        "deferred_families": total_def, "output_bytes": total_bytes,
                        "columns_needing_call_full_per_step": caller.last_timing.get("full_columns")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "k_family", "kernel_ms": k_family_ms / steps, "k_emit_ms": k_emit_ms / steps,
+                         "traffic": pmc_traffic(fam, args.depth, L), "kernel": "k_family", "kernel_ms": k_family_ms / steps, "k_emit_ms": k_emit_ms / steps,
                          "device_ms_per_step": k_total_ms / steps, "algorithmic_bytes_per_launch": alg_read + alg_write,
                          "read_only_GBs": alg_read / k_avg_s / 1e9 if k_avg_s > 0 else 0.0},
         }

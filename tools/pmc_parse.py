@@ -1,0 +1,17 @@
+"""Summarise rocprofv3 --pmc counter_collection CSVs (one per pass) into {kernel: {counter: mean per launch}}.
+usage: python tools/pmc_parse.py gpurun_out/<dir> > profiles/<name>.json"""
+import csv, glob, json, os, re, sys
+from collections import defaultdict
+
+d = sys.argv[1]
+acc = defaultdict(lambda: defaultdict(list))
+for f in sorted(glob.glob(os.path.join(d, "*_counter_collection.csv"))):
+    per = defaultdict(lambda: defaultdict(float))   # (dispatch id, kernel) -> counter -> sum over dimensions
+    for row in csv.DictReader(open(f)):
+        m = re.search(r"(k_[a-z_]+)", row["Kernel_Name"]); k = m.group(1) if m else row["Kernel_Name"][:40]
+        per[(row["Dispatch_Id"], k)][row["Counter_Name"]] += float(row["Counter_Value"])
+    for (_, k), cs in per.items():
+        for c, v in cs.items():
+            acc[k][c].append(v)
+out = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items() if k.startswith("k_")}
+json.dump(out, sys.stdout, indent=1, sort_keys=True)
