@@ -153,11 +153,12 @@ void fgx_destroy(fgx_caller* c) {
 
 // Host-input entry: upload once, run the device-resident pipeline, bring the records back, and send
 // only the families the fast path deferred through the general path, splicing both in group order.
-static int simplex_process_hybrid(fgx_caller* c, const uint8_t* records, uint64_t records_len, const uint64_t* rec_off,
-                                  const uint32_t* rec_len, uint32_t n_rec, const uint32_t* grp_first, uint32_t n_grp, fgx_output* out) {
+typedef int (*general_fn)(fgx_caller*, const uint8_t*, const uint64_t*, const uint32_t*, uint32_t, const uint32_t*, uint32_t, fgx_output*);
+static int process_hybrid(fgx_caller* c, general_fn general, const uint8_t* records, uint64_t records_len, const uint64_t* rec_off,
+                          const uint32_t* rec_len, uint32_t n_rec, const uint32_t* grp_first, uint32_t n_grp, fgx_output* out) {
   using clk = std::chrono::steady_clock;
   auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-  if (c->opt.track_rejects || n_grp == 0) return simplex_process_general(c, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
+  if (c->opt.track_rejects || n_grp == 0) return general(c, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
   if (!c->fast) c->fast = new FastState();
   auto t0 = clk::now();
   hip_check(hipSetDevice(c->device), "hipSetDevice");
@@ -200,7 +201,7 @@ static int simplex_process_hybrid(fgx_caller* c, const uint8_t* records, uint64_
     d_grp.push_back((uint32_t)d_off.size());
   }
   fgx_output gen;
-  int rc = simplex_process_general(c, records, d_off.data(), d_len.data(), (uint32_t)d_off.size(), d_grp.data(), (uint32_t)def.size(), &gen);
+  int rc = general(c, records, d_off.data(), d_len.data(), (uint32_t)d_off.size(), d_grp.data(), (uint32_t)def.size(), &gen);
   if (rc != 0) return rc;
   std::vector<uint8_t> merged;
   merged.reserve(fast_out.size() + c->out_data.size());
@@ -234,8 +235,12 @@ int fgx_process_batch(fgx_caller* c, const uint8_t* records, uint64_t records_le
     switch (c->opt.caller_kind) {
       case FGX_CALLER_SIMPLEX:
         if (c->general_only) return simplex_process_general(c, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
-        return simplex_process_hybrid(c, records, records_len, rec_off, rec_len, n_rec, grp_first, n_grp, out);
-      case FGX_CALLER_DUPLEX: return duplex_process_general(c, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
+        return process_hybrid(c, simplex_process_general, records, records_len, rec_off, rec_len, n_rec, grp_first, n_grp, out);
+      case FGX_CALLER_DUPLEX:
+        if (c->general_only) return duplex_process_general(c, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
+        if (c->opt.duplex_min_reads[1] > c->opt.duplex_min_reads[0] || c->opt.duplex_min_reads[2] > c->opt.duplex_min_reads[1])
+          return duplex_process_general(c, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);   // raises the reference's error
+        return process_hybrid(c, duplex_process_general, records, records_len, rec_off, rec_len, n_rec, grp_first, n_grp, out);
 #ifdef FGX_HAVE_CODEC
       case FGX_CALLER_CODEC: return codec_process_general(c, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
 #endif
@@ -253,7 +258,7 @@ int fgx_process_batch_device(fgx_caller* c, const void* d_records, uint64_t reco
   if (!c || !out) return 1;
   c->err.clear();
   try {
-    if (c->opt.caller_kind != FGX_CALLER_SIMPLEX) { c->err = "fgx_process_batch_device: caller kind not implemented"; return 1; }
+    if (c->opt.caller_kind != FGX_CALLER_SIMPLEX && c->opt.caller_kind != FGX_CALLER_DUPLEX) { c->err = "fgx_process_batch_device: caller kind not implemented"; return 1; }
     if (c->opt.track_rejects) { c->err = "fgx_process_batch_device: --rejects needs the host path (fgx_process_batch)"; return 1; }
     if (!c->fast) c->fast = new FastState();
     hip_check(hipSetDevice(c->device), "hipSetDevice");

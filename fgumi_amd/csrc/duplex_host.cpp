@@ -221,6 +221,7 @@ int duplex_process_general(fgx_caller* c, const uint8_t* blob, const uint64_t* r
   B.clear();
   c->out_data.clear();
   c->out_rejects.clear();
+  c->grp_out_end.assign(n_grp, 0);
   const bool track = o.track_rejects;
   const bool single_strand_allowed = x.min_yx == 0;
   const SrcParams sp{o.min_input_base_quality, o.trim != 0, o.duplex_max_reads_per_strand >= 0};
@@ -427,6 +428,7 @@ int duplex_process_general(fgx_caller* c, const uint8_t* blob, const uint64_t* r
       if (kept) for (auto& r : m.ss_rejects) reject_out(r.data(), r.size());
       else { for (auto& r : m.a) reject_out(r.p, r.n); for (auto& r : m.b) reject_out(r.p, r.n); }
     }
+    c->grp_out_end[g] = c->out_data.size();
   }
   auto t3 = clk::now();
 

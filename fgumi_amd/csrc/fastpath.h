@@ -20,6 +20,18 @@ struct EndDesc {            // one consensus read (a family end), written by k_f
   char rx[FAST_RX_CAP];
 };
 
+struct DuplexDesc {         // one duplex consensus record (slot 3g+1 = R1, 3g+2 = R2), written by k_family_wave<1>, consumed by k_emit_duplex
+  uint64_t a_off, b_off;    // first column of the AB-side strand and of the BA-side strand (b = a when a single strand is passed through)
+  uint32_t len;             // record length: the paired span of both strands, or the whole lone strand
+  uint32_t first_rec;       // first paired record of the molecule (MI value → read name + MI tag, minus the /A|/B suffix)
+  uint32_t cb_rec;          // first /A (else /B) record: cell-barcode source
+  uint32_t rec_size;
+  uint16_t mi_off, cb_off;
+  uint8_t mi_len, cb_len, rx_len, type;
+  uint8_t has_cb, has_rx, valid, has_ba;
+  char rx[FAST_RX_CAP];
+};
+
 struct FullItem {           // a column (or UMI character) whose call needs the full log-sum-exp chain
   uint64_t dest;            // bit 63 clear: scratch column index; set: (slot << 8 | char index) of an RX character
   double ll[4];
@@ -46,6 +58,10 @@ struct FastParams {
   uint32_t lds_tile_bytes;
   uint32_t lds_wave_bytes;
   FullItem* full_items; uint32_t* full_count; uint32_t full_cap;   // N_LISTS append lists of `full_cap` items each
+  // duplex (k_family_wave<1>)
+  uint32_t dmin_total, dmin_xy, dmin_yx; int64_t dmax_reads;
+  uint32_t* col_obs;               // per column: observation counts of A,C,G,T, one byte each
+  DuplexDesc* dends;
 };
 
 struct EmitParams {
@@ -54,6 +70,14 @@ struct EmitParams {
   const uint8_t* col_code; const uint8_t* col_qual; const uint16_t* col_depth; const uint16_t* col_err;
   const char* prefix; uint32_t prefix_len; const char* rg; uint32_t rg_len;
   uint8_t per_base_tags; char tag0, tag1, cell0, cell1;
+};
+
+struct DuplexEmitParams {
+  const uint8_t* blob; const uint64_t* rec_off; const DuplexDesc* ends; const uint64_t* out_off; uint8_t* out;
+  uint32_t slot0, slot_end;
+  const uint8_t* col_code; const uint8_t* col_qual; const uint16_t* col_err; const uint32_t* col_obs;
+  const char* prefix; uint32_t prefix_len; const char* rg; uint32_t rg_len;
+  uint8_t per_base_tags; char cell0, cell1;
 };
 
 struct FastResult {
@@ -68,8 +92,9 @@ struct FastPath {
   DevBuf d_ends, d_sizes, d_offsets, d_code, d_qual, d_depth, d_err, d_misc, d_deferred, d_out, d_scan_tmp, d_strings;
   uint32_t lds_tile_bytes = 12288;        // first launch: tiles of the common small families
   uint32_t lds_tile_bytes_large = 49152;  // second launch over the families that did not fit
-  DevBuf d_retry, d_bound, d_colbase, d_statslots, d_full_items, d_full_count;
+  DevBuf d_retry, d_bound, d_colbase, d_statslots, d_full_items, d_full_count, d_obs;
   uint32_t lds_wave_bytes = 6144;         // wave-per-family kernel: LDS copy of one family's raw records
+  uint32_t lds_wave_bytes_duplex = 8704;  // duplex molecules carry both strands (config 3: 24 records x ~330 B)
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   int run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const uint64_t* d_rec_off, const uint32_t* d_rec_len, uint32_t n_rec,
           const uint32_t* d_grp_first, uint32_t n_grp, FastResult* res);

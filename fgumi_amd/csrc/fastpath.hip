@@ -702,6 +702,10 @@ __device__ __forceinline__ int find_nul64(const uint8_t* W, uint32_t o, uint32_t
 // memory) and the bracket q with thresholds[q] <= gap < thresholds[q+1] comes from the qguess hint plus ONE parallel
 // probe of five neighbouring thresholds instead of a 7-step dependent binary search through LDS.
 struct CallConst { double cap_threshold, half_cerr_at_cap; uint32_t cap; };
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long u) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
 __device__ __forceinline__ double uniform_f64(double v) {
   const unsigned long long u = (unsigned long long)__double_as_longlong(v);
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
@@ -761,6 +765,9 @@ __device__ unsigned long long g_phase[64 * 16];
 #ifndef FGX_RANKACC
 #define FGX_RANKACC 0    /* rank-of-appearance accumulators: fewer f64 ops but more VGPRs; measured slower (19.9 vs 17.2 ms) */
 #endif
+// MODE 0: simplex (vanilla caller).  MODE 1: duplex — phases 1-4 are shared, the strand partition, the four single-strand
+// column sets and the descriptors of the two duplex records replace phases 5-8 (see the MODE == 1 branch).
+template <int MODE>
 __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P, uint32_t n_grp_total) {
   extern __shared__ __align__(16) uint8_t dyn[];
   __shared__ ConsensusTables sT;          // thresholds / cerr_min / scalars (and the plain tables for reference)
@@ -805,15 +812,15 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
   unsigned long long* st = P.stats + (size_t)(blockIdx.x & (STAT_SLOTS - 1)) * 32;
   const uint32_t r0 = P.grp_first[g], n = P.grp_first[g + 1] - r0;
   const uint32_t slot0 = 3 * g;
-  if (lane < 3) { P.ends[slot0 + lane].valid = 0; P.rec_sizes[slot0 + lane] = 0; }
+  if (lane < 3) { if (MODE == 0) P.ends[slot0 + lane].valid = 0; else P.dends[slot0 + lane].valid = 0; P.rec_sizes[slot0 + lane] = 0; }
 
-  if (n < P.min_reads) {   // simplex.rs:673-683
+  if (MODE == 0 && n < P.min_reads) {   // simplex.rs:673-683
     if (lane == 0) { atomicAdd(&st[0], (unsigned long long)n); atomicAdd(&st[2], (unsigned long long)n); atomicAdd(&st[3 + FGX_REJ_INSUFFICIENT_READS], (unsigned long long)n); }
     return;
   }
   auto to_retry = [&]() { if (lane == 0) { uint32_t k = atomicAdd(P.n_retry, 1u); P.retry[k] = g; } };
   auto to_defer = [&]() { if (lane == 0) { uint32_t k = atomicAdd(P.n_deferred, 1u); P.deferred[k] = g; } };
-  if (n > 64) { to_retry(); return; }
+  if (n > 64) { if (MODE == 0) to_retry(); else to_defer(); return; }
 
 #if FGX_PHASE_TIMING
   unsigned long long _t = __builtin_amdgcn_s_memtime();
@@ -827,7 +834,7 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
   if (__any(act && len < 32)) { to_defer(); return; }
   unsigned long long base16 = lo_off & ~15ull;
   unsigned long long span = hi_end - base16;
-  if (span + 16 > (unsigned long long)P.lds_wave_bytes) { to_retry(); return; }   // +16: slack for the dword-composed reads
+  if (span + 16 > (unsigned long long)P.lds_wave_bytes) { if (MODE == 0) to_retry(); else to_defer(); return; }   // +16: slack for the dword-composed reads
   const uint32_t span16 = ((uint32_t)span + 15) & ~15u;
   {
     const uint8_t* src = P.blob + base16;
@@ -842,6 +849,7 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
   int32_t pos = 0, ref_id = 0;
   uint32_t mi_lo = 0, mi_len = 0, rx_lo = 0, rx_len = 0, cb_lo = 0, cb_len = 0;   // LDS offsets of tag values
   bool has_mi = false, has_rx = false, has_cb = false, excluded = false, bad = false;
+  uint32_t strand = 0;   // duplex: 1 = MI ends in /A, 2 = /B
   if (act) {
     const uint32_t h2 = ld32u(W, lo + 8), h3 = ld32u(W, lo + 12);
     const uint32_t l_name = h2 & 0xFF, n_cig = h3 & 0xFFFF;
@@ -856,6 +864,7 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
       ref_id = (int32_t)ld32u(W, lo); pos = (int32_t)ld32u(W, lo + 4);
       seq_lo = lo + (uint32_t)seq_off; qual_lo = lo + (uint32_t)qual_off;
       excluded = (flags & (bam::F_SECONDARY | bam::F_SUPPLEMENTARY)) != 0;
+      if (MODE == 1 && excluded) bad = true;   // the duplex caller has no secondary/supplementary filter: general path
       uint32_t op = 0;
       if (!excluded) {
         if ((flags & bam::F_UNMAPPED) || n_cig != 1 || l_seq == 0 || pos < 0) bad = true;
@@ -896,6 +905,10 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
         unsigned long long nq = (unsigned long long)q + 3 + size;
         if (nq > an) break;
         q = (uint32_t)nq;
+      }
+      if (MODE == 1) {   // strand from the MI suffix; every paired read needs `<id>/A` or `<id>/B` (duplex_caller.rs:2557-2566: fatal otherwise)
+        if (has_mi && mi_len >= 2 && W[mi_lo + mi_len - 2] == '/') { const uint8_t sc = W[mi_lo + mi_len - 1]; strand = sc == 'A' ? 1u : sc == 'B' ? 2u : 0u; }
+        if ((flags & bam::F_PAIRED) && (strand == 0 || P.prefix_len + 1 + (mi_len - 2) >= 255)) bad = true;
       }
       if (!bad && !excluded) {
         // mate-overlap clip (raw-bam/overlap.rs:181-357).  Closed form when the MC tag is one M op and all
@@ -957,7 +970,7 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
   }
   // first record must carry the MI tag and give a legal read name (vanilla_caller.rs:1897-1908, 1795-1797)
   const uint32_t mi0_lo = rlane(mi_lo, 0), mi0_len = rlane(mi_len, 0);
-  if (lane == 0 && (!has_mi || P.prefix_len + 1 + mi_len >= 255)) bad = true;
+  if (MODE == 0 && lane == 0 && (!has_mi || P.prefix_len + 1 + mi_len >= 255)) bad = true;
   // absent qualities (all 0xFF) are a fatal input error (:1119-1124)
   if (act && !bad && !excluded && W[qual_lo] == 0xFF) {
     bool all = true;
@@ -972,7 +985,10 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
   PH(2)
   // ---- 3. overlapping-bases pre-correction in LDS (overlapping.rs:236-336, 627-684) ----------------------
   uint32_t ov_bases = 0, ov_agree = 0, ov_dis = 0, ov_corr = 0;
-  if (P.overlap) {
+  bool do_overlap = P.overlap != 0;
+  if (MODE == 1 && do_overlap && P.dmin_yx != 0)   // duplex.rs:786-795: only molecules with both strands when single-strand output is off
+    do_overlap = n >= 2 && __any(act && strand == 1) && __any(act && strand == 2);
+  if (do_overlap) {
     const bool is_r1 = cand && (flags & bam::F_FIRST);
     const bool is_r2 = cand && !(flags & bam::F_FIRST) && (flags & bam::F_LAST);
     // pair map: per name, the LAST R1-type and the LAST R2-type primary record
@@ -1126,6 +1142,7 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
   }
 
   PH(4)
+  if constexpr (MODE == 0) {
   // ---- 5. family gates with ballots (process_group :1329-1422, process_subgroup :1454-1646) -----------------
   uint32_t s_total = n, s_cons = 0, s_filtered = 0, s_sec = 0, s_insuf = 0, s_zero = 0, s_orphan = 0;
   const uint32_t n_sec = (uint32_t)__popcll(__ballot(act && excluded));
@@ -1388,6 +1405,284 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
     if (ov_corr) atomicAdd(&st[27], (unsigned long long)ov_corr);
   }
   PH(8)
+  } else {
+  // =====================================================================================================================
+  // MODE 1 — duplex.  Mirrors DuplexConsensusCaller::consensus_reads / process_group (duplex_caller.rs:2545-2624,
+  // 1944-2540) for the molecules the device can decide exactly; anything else is deferred to duplex_host.cpp.
+  // =====================================================================================================================
+  // ---- 5D. fragments out, strand partition, min-reads and collision gates ------------------------------------------------
+  const bool paired = act && (flags & bam::F_PAIRED);
+  const unsigned long long pmask = __ballot(paired);
+  const uint32_t n_frag = n - (uint32_t)__popcll(pmask);
+  uint32_t s_cons = 0, s_filtered = n_frag, rj_insuf = 0, rj_coll = 0, rj_zero = 0;
+  auto flush_stats = [&]() {
+    ov_bases = wave_sum(ov_bases); ov_agree = wave_sum(ov_agree); ov_dis = wave_sum(ov_dis); ov_corr = wave_sum(ov_corr);
+    if (lane == 0) {
+      atomicAdd(&st[0], (unsigned long long)n);
+      if (s_cons) atomicAdd(&st[1], (unsigned long long)s_cons);
+      if (s_filtered) atomicAdd(&st[2], (unsigned long long)s_filtered);
+      if (n_frag) atomicAdd(&st[3 + FGX_REJ_FRAGMENT_READ], (unsigned long long)n_frag);
+      if (rj_insuf) atomicAdd(&st[3 + FGX_REJ_INSUFFICIENT_READS], (unsigned long long)rj_insuf);
+      if (rj_coll) atomicAdd(&st[3 + FGX_REJ_POTENTIAL_COLLISION], (unsigned long long)rj_coll);
+      if (rj_zero) atomicAdd(&st[3 + FGX_REJ_ZERO_LENGTH_AFTER_TRIMMING], (unsigned long long)rj_zero);
+      if (ov_bases) atomicAdd(&st[24], (unsigned long long)ov_bases);
+      if (ov_agree) atomicAdd(&st[25], (unsigned long long)ov_agree);
+      if (ov_dis) atomicAdd(&st[26], (unsigned long long)ov_dis);
+      if (ov_corr) atomicAdd(&st[27], (unsigned long long)ov_corr);
+    }
+  };
+  if (!pmask) { flush_stats(); return; }                                  // nothing but fragments: no MI to work from
+  const bool is_r1 = paired && (flags & bam::F_FIRST), is_r2 = paired && (flags & bam::F_LAST);
+  if (__any(paired && is_r1 == is_r2)) { to_defer(); return; }            // FIRST and LAST both set or both clear: general path
+  const unsigned long long amask = __ballot(paired && strand == 1), bmask = __ballot(paired && strand == 2);
+  const unsigned long long r1m = __ballot(is_r1), r2m = __ballot(is_r2);
+  const uint32_t n_ab = (uint32_t)__popcll(amask | bmask);
+  auto min_ok = [&](uint32_t x, uint32_t y) {                             // has_minimum_number_of_reads :824-862
+    const uint32_t xy = x > y ? x : y, yx = x > y ? y : x;
+    return P.dmin_total <= xy + yx && P.dmin_xy <= xy && P.dmin_yx <= yx;
+  };
+  if (!min_ok((uint32_t)__popcll(amask & r1m), (uint32_t)__popcll(bmask & r1m))) { rj_insuf = n_ab; s_filtered += n_ab; flush_stats(); return; }
+  if (amask && bmask) {                                                   // /A R1 with /B R2 (and /A R2 with /B R1) must share a strand
+    const unsigned long long revm = __ballot(paired && rev);
+    const unsigned long long g1 = (amask & r1m) | (bmask & r2m), g2 = (amask & r2m) | (bmask & r1m);
+    const bool same1 = (g1 & revm) == 0 || (g1 & revm) == g1, same2 = (g2 & revm) == 0 || (g2 & revm) == g2;
+    if (!same1 || !same2) { rj_coll = n_ab; s_filtered += n_ab; flush_stats(); return; }
+  }
+  const unsigned long long nzm = __ballot(paired && final_len > 0);
+  const uint32_t n_zero = (uint32_t)__popcll((amask | bmask) & ~nzm);     // ZeroLengthAfterTrimming (single-strand caller's stats)
+  // the four single-strand read sets: 0 = AB-R1, 1 = AB-R2, 2 = BA-R1, 3 = BA-R2
+  unsigned long long em[4];
+  em[0] = uniform_u64(amask & r1m & nzm); em[1] = uniform_u64(amask & r2m & nzm); em[2] = uniform_u64(bmask & r1m & nzm); em[3] = uniform_u64(bmask & r2m & nzm);
+  uint32_t elen[4], eoff[4];
+  {
+    bool cap_bites = false;
+    uint32_t tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (P.dmax_reads >= 0 && (long long)__popcll(em[k]) > P.dmax_reads) cap_bites = true;
+      elen[k] = em[k] ? wave_max(((em[k] >> lane) & 1) ? final_len : 0) : 0;
+      eoff[k] = tot; tot += elen[k];
+    }
+    if (cap_bites) { to_defer(); return; }                                 // --max-reads-per-strand that bites: name-rank downsampling on the host
+  }
+  const uint32_t plen1 = (em[0] && em[3]) ? (elen[0] < elen[3] ? elen[0] : elen[3]) : 0;    // R1 duplex: AB-R1 with BA-R2
+  const uint32_t plen2 = (em[1] && em[2]) ? (elen[1] < elen[2] ? elen[1] : elen[2]) : 0;    // R2 duplex: AB-R2 with BA-R1
+
+  PH(5)
+  // ---- 6D. the four single-strand column sets (ss caller: min_reads 1, min consensus base quality 2) ----------------------
+  const uint32_t d0 = seq_lo | (qual_lo << 16), d1 = l_seq | (final_len << 16), d2 = trim_to | ((rev ? 1u : 0u) << 16);
+  const DeviceTables* T = P.T;
+  const uint64_t col_base = P.col_base[g];
+  const uint32_t min_bq = P.min_input_bq;
+  CallConst KC;
+  KC.cap = (uint32_t)__builtin_amdgcn_readfirstlane((int)sT.cap);
+  KC.cap_threshold = uniform_f64(sT.cap_threshold); KC.half_cerr_at_cap = uniform_f64(sT.half_cerr_at_cap);
+  uint32_t dm_tr[4] = {0, 0, 0, 0}, dm_fu[4] = {0, 0, 0, 0};     // max depth over the paired (truncated) span / the whole strand
+  bool odd_base = false;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const unsigned long long members = em[k];
+    if (!members) continue;
+    const uint32_t mc = (uint32_t)__popcll(members);
+    const uint32_t plen = (k == 0 || k == 3) ? plen1 : plen2;
+    for (uint32_t p = lane; p < elen[k]; p += 64) {
+      const uint64_t o = col_base + eoff[k] + p;
+      uint32_t depth, obs[4];
+      if (mc == 1) {   // single-read consensus: LUT keyed by the unclamped quality (vanilla_caller.rs:1677-1708)
+        const uint32_t r = (uint32_t)__builtin_ctzll(members);
+        uint32_t code, q;
+        view(rlane(seq_lo, r), rlane(qual_lo, r), rlane(l_seq, r), (rlane(flags, r) & bam::F_REVERSE) != 0, rlane(trim_to, r), p, &code, &q);
+        const uint8_t adj = q < 94 ? T->single_input_quals[q] : 0;
+        const bool low = adj < FGX_MIN_PHRED;
+        P.col_code[o] = low ? (uint8_t)15 : (uint8_t)code; P.col_qual[o] = low ? (uint8_t)FGX_MIN_PHRED : adj; P.col_err[o] = 0;
+        obs[0] = code == 1; obs[1] = code == 2; obs[2] = code == 4; obs[3] = code == 8;
+        depth = code != 15 ? 1u : 0u;
+        if (depth && !(obs[0] | obs[1] | obs[2] | obs[3])) odd_base = true;     // IUPAC code in a lone read: general path
+      } else {
+        ColumnAcc acc;
+        acc.reset();
+        for (unsigned long long m = members; m; m &= m - 1) {
+          const uint32_t r = (uint32_t)__builtin_ctzll(m);
+          const uint32_t x0 = rlane(d0, r), x1 = rlane(d1, r), x2 = rlane(d2, r);
+          bool valid = p < (x1 >> 16);
+          const bool rv = (x2 >> 16) != 0;
+          const uint32_t idx = valid ? (rv ? (x1 & 0xFFFF) - 1 - p : p) : 0;
+          const uint32_t bb = W[(x0 & 0xFFFF) + (idx >> 1)];
+          const uint32_t c = (bb >> ((~idx & 1) << 2)) & 15;
+          const uint32_t q = W[(x0 >> 16) + idx];
+          const unsigned long long LUT = rv ? 0xFFFFFFF0FFF1F23FULL : 0xFFFFFFF3FFF2F10FULL;
+          const uint32_t bl = (uint32_t)(LUT >> (4 * c)) & 15;
+          const bool masked = p < (x2 & 0xFFFF) && q < min_bq;
+          valid = valid && bl < 4 && !masked;
+          const uint32_t qq = q < FGX_MAX_PHRED ? q : FGX_MAX_PHRED;
+          const double2 pr = *(const double2*)&sPair[qq][0];
+          if (valid) acc.add((int)bl, pr.x, pr.y);
+        }
+        double ll[4] = {acc.s[0], acc.s[1], acc.s[2], acc.s[3]};
+        obs[0] = acc.obs[0]; obs[1] = acc.obs[1]; obs[2] = acc.obs[2]; obs[3] = acc.obs[3];
+        int bi;
+        uint8_t q;
+        const bool resolved = column_call_fast_lds(sT, KC, ll, obs, &bi, &q);
+        depth = obs[0] + obs[1] + obs[2] + obs[3];
+        push_full(!resolved, o, ll, obs);
+        if (resolved) {
+          const uint32_t err = depth - (bi == 0 ? obs[0] : bi == 1 ? obs[1] : bi == 2 ? obs[2] : bi == 3 ? obs[3] : 0u);
+          uint8_t ob, oq;
+          if (depth < 1) { ob = 15; oq = 0; }
+          else if (q < FGX_MIN_PHRED) { ob = 15; oq = FGX_MIN_PHRED; }
+          else { ob = bi >= 0 ? (uint8_t)(1u << bi) : (uint8_t)15; oq = q; }
+          P.col_code[o] = ob; P.col_qual[o] = oq; P.col_err[o] = (uint16_t)err;
+        }
+      }
+      P.col_obs[o] = obs[0] | (obs[1] << 8) | (obs[2] << 16) | (obs[3] << 24);
+      dm_fu[k] = depth > dm_fu[k] ? depth : dm_fu[k];
+      if (p < plen) dm_tr[k] = depth > dm_tr[k] ? depth : dm_tr[k];
+    }
+  }
+  if (__any(odd_base)) { to_defer(); return; }
+#pragma unroll
+  for (int k = 0; k < 4; k++) { dm_fu[k] = wave_max(dm_fu[k]); dm_tr[k] = wave_max(dm_tr[k]); }
+
+  PH(6)
+  // ---- 7D. which records come out (duplex_consensus :931-1108, process_group :2400-2540) ------------------------------------
+  // A duplex record takes strand `sa` (and `sb` when both strands are covered); a strand alone is passed through.
+  struct Out { bool ok; bool has_ba; uint32_t sa, sb, len; };
+  auto duplex_of = [&](int ka, int kb, uint32_t plen) {          // ka: AB-side set or -1, kb: BA-side set or -1
+    Out r; r.ok = false; r.has_ba = false; r.sa = 0; r.sb = 0; r.len = 0;
+    const bool have_a = ka >= 0, have_b = kb >= 0;
+    const uint32_t da = have_a ? (have_b ? dm_tr[ka < 0 ? 0 : ka] : dm_fu[ka < 0 ? 0 : ka]) : 0;
+    const uint32_t db = have_b ? (have_a ? dm_tr[kb < 0 ? 0 : kb] : dm_fu[kb < 0 ? 0 : kb]) : 0;
+    const bool cov_a = have_a && da > 0, cov_b = have_b && db > 0;
+    if (!cov_a && !cov_b) return r;
+    if (cov_a && cov_b) { r.ok = min_ok(da, db); r.has_ba = true; r.sa = (uint32_t)ka; r.sb = (uint32_t)kb; r.len = plen; return r; }
+    const int ks = cov_a ? ka : kb;                                 // one covered strand: copied whole, depth over its full length
+    const uint32_t ds = dm_fu[ks < 0 ? 0 : ks];
+    r.ok = min_ok(ds, 0); r.sa = (uint32_t)ks; r.sb = (uint32_t)ks; r.len = elen[ks < 0 ? 0 : ks];
+    return r;
+  };
+  const bool h1 = em[0] != 0, h2 = em[1] != 0, h3 = em[2] != 0, h4 = em[3] != 0;
+  Out o1, o2;
+  o1.ok = o2.ok = false; o1.has_ba = o2.has_ba = false; o1.sa = o1.sb = o2.sa = o2.sb = 0; o1.len = o2.len = 0;
+  if (h1 && h2 && h3 && h4) { o1 = duplex_of(0, 3, plen1); o2 = duplex_of(1, 2, plen2); }
+  else if (h1 && h2 && !h3 && !h4) { if (P.dmin_yx == 0) { o1 = duplex_of(0, -1, 0); o2 = duplex_of(1, -1, 0); } }
+  else if (!h1 && !h2 && h3 && h4) { if (P.dmin_yx == 0) { o1 = duplex_of(-1, 2, 0); o2 = duplex_of(-1, 3, 0); } }
+  const bool emitted = o1.ok && o2.ok;
+  // statistics (duplex_caller.rs:2587-2610 with the re-attribution of :1894-1926)
+  if (emitted) { s_cons = 2; rj_zero = n_zero; s_filtered += n_zero; }
+  else { rj_insuf = n_ab - n_zero; rj_zero = n_zero; s_filtered += n_ab; }
+
+  // ---- 8D. consensus UMI and descriptor of each record ----------------------------------------------------------------------
+  if (emitted) {
+    const DeviceTables* TU = P.TU;
+    const unsigned long long rxm = rxmask;
+    // '-' structure of this lane's RX (flipping a paired UMI swaps the halves around the single dash)
+    uint32_t n_dash = 0, dash_pos = 0;
+    if (act && has_rx) for (uint32_t i = 0; i < rx_len; i++) if (W[rx_lo + i] == '-') { if (!n_dash) dash_pos = i; n_dash++; }
+    const uint32_t fp = (uint32_t)__builtin_ctzll(pmask);                     // first paired record: MI → name and MI tag
+    const uint32_t fp_mi_lo = rlane(mi_lo, fp), fp_mi_len = rlane(mi_len, fp) - 2, fp_lo = rlane(lo, fp);
+    const uint32_t fc = amask ? (uint32_t)__builtin_ctzll(amask) : (uint32_t)__builtin_ctzll(bmask);   // cell barcode source
+    const bool fc_has_cb = P.cell0 && ((cbmask >> fc) & 1);
+    const uint32_t fc_cb_lo = rlane(cb_lo, fc), fc_cb_len = rlane(cb_len, fc), fc_lo = rlane(lo, fc);
+    bool rx_fail = false;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const Out& O = t == 0 ? o1 : o2;
+      // source reads of this record's UMIs, A-side first (file order inside a side); a read is flipped when its FIRST flag
+      // differs from the record's (duplex_read_into :1336-1368)
+      unsigned long long sa_m = 0, sb_m = 0;
+      if (h1 && h2 && h3 && h4) { sa_m = t == 0 ? em[0] : em[1]; sb_m = t == 0 ? em[3] : em[2]; }
+      else if (h1) { sa_m = t == 0 ? em[0] : em[1]; }
+      else { sb_m = t == 0 ? em[2] : em[3]; }
+      sa_m &= rxm; sb_m &= rxm;
+      const bool rec_first = t == 0;
+      const uint32_t cnt = (uint32_t)__popcll(sa_m | sb_m);
+      uint32_t ulen = 0;
+      char my_ch = 0;
+      if (cnt) {
+        const uint32_t f = sa_m ? (uint32_t)__builtin_ctzll(sa_m) : (uint32_t)__builtin_ctzll(sb_m);
+        ulen = rlane(rx_len, f);
+        const bool in_set = ((sa_m | sb_m) >> lane) & 1;
+        const bool flip_me = in_set && (((flags & bam::F_FIRST) != 0) != rec_first);
+        if (__any(in_set && rx_len != ulen) || ulen > FAST_RX_CAP || __any(flip_me && n_dash > 1)) rx_fail = true;
+        else {
+          // character j of read r's UMI as it enters the consensus
+          auto chr = [&](uint32_t r, uint32_t j) -> uint8_t {
+            const uint32_t rlo = rlane(rx_lo, r), nd = rlane(n_dash, r), dp = rlane(dash_pos, r);
+            const bool fl = (((rlane(flags, r) & bam::F_FIRST) != 0) != rec_first) && nd == 1;
+            uint32_t src = j;
+            if (fl) { const uint32_t ql = ulen - dp - 1; src = j < ql ? dp + 1 + j : j == ql ? dp : j - ql - 1; }
+            return j < ulen ? W[rlo + src] : (uint8_t)'A';
+          };
+          const bool mychar = lane < ulen;
+          const uint8_t c0 = chr(f, lane);
+          bool differs = false;
+          for (unsigned long long m = sa_m | sb_m; m; m &= m - 1) differs |= chr((uint32_t)__builtin_ctzll(m), lane) != c0;
+          if (cnt == 1 || !__any(mychar && differs)) {
+            const int bl = bam::ascii_to_lane(c0);
+            my_ch = cnt == 1 ? (char)c0 : bl != 255 ? "ACGT"[bl] : (c0 == 'N' || c0 == 'n') ? 'N' : (char)c0;
+          } else {
+            ColumnAcc acc;
+            acc.reset();
+            uint32_t non_dna = 0, seen = 0;
+            uint8_t fch = 0;
+            bool mixed = false;
+            const double uc = TU->t.correct[20], ue = TU->t.error_per_alt[20];
+#pragma unroll
+            for (int side = 0; side < 2; side++)
+              for (unsigned long long m = side == 0 ? sa_m : sb_m; m; m &= m - 1) {
+                const uint8_t ch = chr((uint32_t)__builtin_ctzll(m), lane);
+                if (seen == 0) fch = ch;
+                seen++;
+                const uint8_t up = (ch >= 'a' && ch <= 'z') ? (uint8_t)(ch - 32) : ch;
+                const bool dna = up == 'A' || up == 'C' || up == 'G' || up == 'T' || up == 'N';
+                if (dna) { const int bl = bam::ascii_to_lane(ch); if (bl != 255) acc.add(bl, uc, ue); }
+                else { non_dna++; if (ch != fch) mixed = true; }
+              }
+            bool need_full = false, bad_col = false;
+            if (non_dna == 0) {
+              CallConst KU;
+              KU.cap = TU->t.cap; KU.cap_threshold = TU->t.cap_threshold; KU.half_cerr_at_cap = TU->t.half_cerr_at_cap;
+              int bi; uint8_t q;
+              const bool resolved = column_call_fast_lds(TU->t, KU, acc.s, acc.obs, &bi, &q);
+              my_ch = bi >= 0 ? "ACGT"[bi] : 'N';
+              need_full = !resolved;
+            } else if (non_dna == seen && !mixed) my_ch = (char)fch;
+            else bad_col = true;
+            if (!mychar) { need_full = false; bad_col = false; }
+            if (__any(bad_col)) rx_fail = true;
+            push_full(need_full, (1ull << 63) | ((uint64_t)(slot0 + 1 + t) << 8) | lane, acc.s, acc.obs);
+          }
+        }
+      }
+      const uint32_t slot = slot0 + 1 + t;
+      DuplexDesc* D = &P.dends[slot];
+      if (lane < ulen && cnt) D->rx[lane] = my_ch;
+      if (lane == 0) {
+        const uint32_t L = O.len;
+        D->a_off = col_base + eoff[O.sa]; D->b_off = col_base + eoff[O.sb];
+        D->len = L; D->first_rec = r0 + fp; D->cb_rec = r0 + fc;
+        D->mi_off = (uint16_t)(fp_mi_lo - fp_lo); D->mi_len = (uint8_t)fp_mi_len;
+        D->has_cb = fc_has_cb ? 1 : 0; D->cb_off = (uint16_t)(fc_cb_lo - fc_lo); D->cb_len = (uint8_t)fc_cb_len;
+        D->has_rx = cnt > 0; D->rx_len = (uint8_t)ulen; D->type = (uint8_t)(1 + t); D->has_ba = O.has_ba ? 1 : 0;
+        const uint32_t nm = P.prefix_len + 1 + fp_mi_len;
+        const uint32_t per_strand = P.per_base_tags ? 2 * (3 + L + 1) + 2 * (8 + 2 * L) : 0;     // ac/aq strings + ad/ae arrays
+        // every int tag holds a depth <= 128 here (<= 64 records per wavefront): 4 bytes each
+        const uint32_t size = 32 + nm + 1 + (L + 1) / 2 + L + (3 + fp_mi_len + 1) + (fc_has_cb ? 3 + fc_cb_len + 1 : 0) + (3 + P.rg_len + 1) +
+                              3 * (4 + 7 + 4) + per_strand + (O.has_ba ? per_strand : 0) + (cnt ? 3 + ulen + 1 : 0);
+        D->rec_size = size;
+        D->valid = 1;
+        P.rec_sizes[slot] = (uint64_t)size + 4;
+      }
+    }
+    if (rx_fail || __any(list_overflow)) {            // undo: the general path owns this molecule
+      if (lane < 2) { P.dends[slot0 + 1 + lane].valid = 0; P.rec_sizes[slot0 + 1 + lane] = 0; }
+      to_defer();
+      return;
+    }
+  } else if (__any(list_overflow)) { to_defer(); return; }
+  flush_stats();
+  PH(8)
+  }
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -1400,7 +1695,7 @@ struct FullParams {
   const DeviceTables* T; const DeviceTables* TU;
   uint32_t min_reads; uint8_t min_cons_bq;
   uint8_t* col_code; uint8_t* col_qual; uint16_t* col_err;
-  EndDesc* ends;
+  char* rx_base; uint32_t rx_stride;   // consensus-UMI characters: rx_base + slot * rx_stride + index
 };
 
 __global__ __launch_bounds__(256) void k_call_full(FullParams P) {
@@ -1417,7 +1712,7 @@ __global__ __launch_bounds__(256) void k_call_full(FullParams P) {
   call_full(T, it.ll, &bi, &q);
   if (is_rx) {
     uint64_t d = it.dest & ~(1ull << 63);
-    P.ends[d >> 8].rx[d & 0xFF] = bi >= 0 ? "ACGT"[bi] : 'N';
+    P.rx_base[(size_t)(d >> 8) * P.rx_stride + (d & 0xFF)] = bi >= 0 ? "ACGT"[bi] : 'N';
     return;
   }
   uint32_t obs[4] = {it.obs & 0xFF, (it.obs >> 8) & 0xFF, (it.obs >> 16) & 0xFF, it.obs >> 24};
@@ -1630,16 +1925,145 @@ __global__ __launch_bounds__(256) void k_emit(EmitParams P) {
   if (has_rx) { if (lane < 3 + rx_len + 1) q[lane] = lane == 0 ? 'R' : lane == 1 ? 'X' : lane == 2 ? 'Z' : j3 < rx_len ? rxb : (uint8_t)0; }
 }
 
+// -----------------------------------------------------------------------------------------------------
+// k_emit_duplex — one wavefront per duplex consensus record: the A/B strand combine of duplex_consensus
+// (duplex_caller.rs:931-1108) over the two single-strand column segments, then the record of duplex_read_into
+// (:1118-1405): tags MI [CB] RG aD aE aM [ac ad ae aq] bD bE bM [bc bd be bq] cD cE cM RX.
+// -----------------------------------------------------------------------------------------------------
+struct DCol { uint32_t ca, qa, ea, da, cb, qb, eb, db, oc, oq, oe; };
+__device__ __forceinline__ uint32_t obs_sum(uint32_t o) { return (o & 0xFF) + ((o >> 8) & 0xFF) + ((o >> 16) & 0xFF) + (o >> 24); }
+__device__ __forceinline__ uint32_t obs_of_code(uint32_t o, uint32_t code) {   // count of the base with 4-bit code 1/2/4/8
+  return code == 1 ? (o & 0xFF) : code == 2 ? ((o >> 8) & 0xFF) : code == 4 ? ((o >> 16) & 0xFF) : code == 8 ? (o >> 24) : 0u;
+}
+__device__ __forceinline__ uint32_t cap_q(int32_t v) { return v < 2 ? 2u : v > 93 ? 93u : (uint32_t)v; }
+
+__global__ __launch_bounds__(256) void k_emit_duplex(DuplexEmitParams P) {
+  const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(P.slot0 + ((blockIdx.x * blockDim.x + threadIdx.x) >> 6)));
+  const uint32_t lane = threadIdx.x & 63;
+  if (slot >= P.slot_end) return;
+  const DuplexDesc& D = P.ends[slot];
+  if (!D.valid) return;
+  uint8_t* q = P.out + P.out_off[slot];
+  const uint32_t L = D.len;
+  const bool has_ba = D.has_ba != 0;
+  const uint64_t a_off = D.a_off, b_off = D.b_off;
+  const uint8_t* first = P.blob + P.rec_off[D.first_rec];
+  const uint32_t mi_len = D.mi_len, mi_off = D.mi_off, name_len = P.prefix_len + 1 + mi_len;
+  const bool has_cb = D.has_cb != 0, has_rx = D.has_rx != 0;
+  const uint32_t cb_len = has_cb ? D.cb_len : 0, rx_len = has_rx ? D.rx_len : 0;
+  uint32_t flag = bam::F_UNMAPPED | bam::F_PAIRED | bam::F_MATE_UNMAPPED | (D.type == 1 ? bam::F_FIRST : bam::F_LAST);
+  // one position of the record: both strands' single-strand calls and the duplex call
+  auto col = [&](uint32_t i) {
+    DCol c;
+    const uint32_t oa = P.col_obs[a_off + i];
+    c.ca = P.col_code[a_off + i]; c.qa = P.col_qual[a_off + i]; c.ea = P.col_err[a_off + i]; c.da = obs_sum(oa);
+    if (!has_ba) { c.cb = 15; c.qb = 0; c.eb = 0; c.db = 0; c.oc = c.ca; c.oq = c.qa; c.oe = c.ea; return c; }
+    const uint32_t ob = P.col_obs[b_off + i];
+    c.cb = P.col_code[b_off + i]; c.qb = P.col_qual[b_off + i]; c.eb = P.col_err[b_off + i]; c.db = obs_sum(ob);
+    uint32_t rb, rq;
+    if (c.ca == c.cb) { rb = c.ca; rq = cap_q((int32_t)c.qa + (int32_t)c.qb); }
+    else if (c.qa > c.qb) { rb = c.ca; rq = cap_q((int32_t)c.qa - (int32_t)c.qb); }
+    else if (c.qb > c.qa) { rb = c.cb; rq = cap_q((int32_t)c.qb - (int32_t)c.qa); }
+    else { rb = c.ca; rq = FGX_MIN_PHRED; }
+    const bool nocall = c.ca == 15 || c.cb == 15 || rq == FGX_MIN_PHRED;
+    c.oc = nocall ? 15u : rb; c.oq = nocall ? (uint32_t)FGX_MIN_PHRED : rq;
+    // errors: source reads of both strands that disagree with the raw duplex base (N never counts)
+    const uint32_t agree = obs_of_code(oa, rb) + obs_of_code(ob, rb);
+    c.oe = rb == 15 ? 0u : (c.da + c.db) - agree;
+    return c;
+  };
+  // ---- reductions for aD aM aE / bD bM bE / cD cM cE -------------------------------------------------------------------------
+  uint32_t amax = 0, amin = 0xFFFFFFFFu, asd = 0, ase = 0, bmax = 0, bmin = 0xFFFFFFFFu, bsd = 0, bse = 0, cmax = 0, cmin = 0xFFFFFFFFu, csd = 0, cse = 0;
+  for (uint32_t i = lane; i < L; i += 64) {
+    const DCol c = col(i);
+    amax = c.da > amax ? c.da : amax; amin = c.da < amin ? c.da : amin; asd += c.da; ase += c.ea;
+    bmax = c.db > bmax ? c.db : bmax; bmin = c.db < bmin ? c.db : bmin; bsd += c.db; bse += c.eb;
+    const uint32_t t = c.da + c.db;
+    cmax = t > cmax ? t : cmax; cmin = t < cmin ? t : cmin; csd += t; cse += c.oe;
+  }
+  amax = wave_max(amax); amin = wave_min(amin); asd = wave_sum(asd); ase = wave_sum(ase);
+  bmax = wave_max(bmax); bmin = wave_min(bmin); bsd = wave_sum(bsd); bse = wave_sum(bse);
+  cmax = wave_max(cmax); cmin = wave_min(cmin); csd = wave_sum(csd); cse = wave_sum(cse);
+  if (L == 0) { amin = 0; bmin = 0; cmin = 0; }
+  if (!has_ba) { bmax = 0; bmin = 0; bsd = 0; bse = 0; }
+  const float a_rate = asd ? (float)ase / (float)asd : 0.0f, b_rate = bsd ? (float)bse / (float)bsd : 0.0f, c_rate = csd ? (float)cse / (float)csd : 0.0f;
+
+  // ---- block_size + core, name, bases, quals ------------------------------------------------------------------------------------
+  if (lane < 36) {
+    const uint32_t dw = lane >> 2;
+    const uint32_t v = dw == 0 ? D.rec_size : dw == 3 ? ((name_len + 1) | (4680u << 16)) : dw == 4 ? (flag << 16) : dw == 5 ? L : dw == 8 ? 0u : 0xFFFFFFFFu;
+    q[lane] = (uint8_t)(v >> (8 * (lane & 3)));
+  }
+  q += 36;
+  for (uint32_t i = lane; i < name_len + 1; i += 64)
+    q[i] = i < P.prefix_len ? (uint8_t)P.prefix[i] : i == P.prefix_len ? (uint8_t)':' : i < name_len ? first[mi_off + (i - P.prefix_len - 1)] : (uint8_t)0;
+  q += name_len + 1;
+  for (uint32_t i = lane; i < (L + 1) / 2; i += 64) {
+    const uint32_t hi = col(2 * i).oc, lo = 2 * i + 1 < L ? col(2 * i + 1).oc : 0u;
+    q[i] = (uint8_t)((hi << 4) | lo);
+  }
+  q += (L + 1) / 2;
+  for (uint32_t i = lane; i < L; i += 64) q[i] = (uint8_t)col(i).oq;
+  q += L;
+  // ---- tags -----------------------------------------------------------------------------------------------------------------------
+  auto z_tag = [&](char t0, char t1, const uint8_t* src, uint32_t n) {     // Z tag from a byte string in global memory
+    for (uint32_t i = lane; i < 3 + n + 1; i += 64) q[i] = i == 0 ? (uint8_t)t0 : i == 1 ? (uint8_t)t1 : i == 2 ? (uint8_t)'Z' : i - 3 < n ? src[i - 3] : (uint8_t)0;
+    q += 3 + n + 1;
+  };
+  auto scalar_tags = [&](char s, uint32_t dmax, float rate, uint32_t dmin) {   // <s>D int, <s>E float, <s>M int: 4 + 7 + 4 bytes
+    if (lane < 15) {
+      uint8_t v;
+      if (lane < 4) v = int_tag_byte(lane, s, 'D', dmax);
+      else if (lane < 11) { const uint32_t j = lane - 4, u = __float_as_uint(rate); v = j == 0 ? (uint8_t)s : j == 1 ? (uint8_t)'E' : j == 2 ? (uint8_t)'f' : (uint8_t)(u >> (8 * (j - 3))); }
+      else v = int_tag_byte(lane - 11, s, 'M', dmin);
+      q[lane] = v;
+    }
+    q += 15;
+  };
+  auto per_base = [&](char s, bool b_side) {      // <s>c bases, <s>d depths, <s>e errors, <s>q quals of one strand
+    for (uint32_t i = lane; i < 3 + L + 1; i += 64) {
+      uint8_t v = i == 0 ? (uint8_t)s : i == 1 ? (uint8_t)'c' : i == 2 ? (uint8_t)'Z' : (uint8_t)0;
+      if (i >= 3 && i - 3 < L) { const DCol c = col(i - 3); v = bam::code_to_ascii((uint8_t)(b_side ? c.cb : c.ca)); }
+      q[i] = v;
+    }
+    q += 3 + L + 1;
+    for (int pass = 0; pass < 2; pass++) {
+      for (uint32_t i = lane; i < 8 + 2 * L; i += 64) {
+        uint8_t v;
+        if (i < 8) v = i == 0 ? (uint8_t)s : i == 1 ? (uint8_t)(pass == 0 ? 'd' : 'e') : i == 2 ? (uint8_t)'B' : i == 3 ? (uint8_t)'s' : (uint8_t)(L >> (8 * (i - 4)));
+        else { const uint32_t k = i - 8; const DCol c = col(k >> 1); const uint32_t w = pass == 0 ? (b_side ? c.db : c.da) : (b_side ? c.eb : c.ea); v = (k & 1) ? (uint8_t)(w >> 8) : (uint8_t)w; }
+        q[i] = v;
+      }
+      q += 8 + 2 * L;
+    }
+    for (uint32_t i = lane; i < 3 + L + 1; i += 64) {
+      uint8_t v = i == 0 ? (uint8_t)s : i == 1 ? (uint8_t)'q' : i == 2 ? (uint8_t)'Z' : (uint8_t)0;
+      if (i >= 3 && i - 3 < L) { const DCol c = col(i - 3); const uint32_t qq = (b_side ? c.qb : c.qa) + 33; v = (uint8_t)(qq > 255 ? 255 : qq); }
+      q[i] = v;
+    }
+    q += 3 + L + 1;
+  };
+  z_tag('M', 'I', first + mi_off, mi_len);
+  if (has_cb) z_tag(P.cell0, P.cell1, P.blob + P.rec_off[D.cb_rec] + D.cb_off, cb_len);
+  z_tag('R', 'G', (const uint8_t*)P.rg, P.rg_len);
+  scalar_tags('a', amax, a_rate, amin);
+  if (P.per_base_tags) per_base('a', false);
+  scalar_tags('b', bmax, b_rate, bmin);
+  if (P.per_base_tags && has_ba) per_base('b', true);
+  scalar_tags('c', cmax, c_rate, cmin);
+  if (has_rx) z_tag('R', 'X', (const uint8_t*)D.rx, rx_len);
+}
+
 // Upper bound on the consensus columns a batch can produce: a family yields at most three ends, each no
 // longer than its longest read, and l_seq <= (block_size - 33) * 2 / 3.
 __global__ void k_col_bound(const uint32_t* __restrict__ grp_first, const uint32_t* __restrict__ rec_len, uint32_t n_grp,
-                            uint64_t* __restrict__ bound) {
+                            uint64_t* __restrict__ bound, uint32_t max_ends) {
   uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n_grp) return;
   uint32_t a = grp_first[g], b = grp_first[g + 1], mx = 0;
   for (uint32_t r = a; r < b; r++) { uint32_t l = rec_len[r]; mx = l > mx ? l : mx; }
   uint32_t lb = mx > 33 ? (mx - 33) * 2 / 3 + 1 : 1;
-  uint32_t ends = (b - a) < 3 ? (b - a) : 3;
+  uint32_t ends = (b - a) < max_ends ? (b - a) : max_ends;
   bound[g] = (uint64_t)ends * lb;
 }
 
@@ -1657,7 +2081,7 @@ __global__ void k_reduce_stats(const unsigned long long* __restrict__ slots, uns
 // host driver
 // -----------------------------------------------------------------------------------------------------
 void FastPath::release() {
-  for (DevBuf* b : {&d_ends, &d_sizes, &d_offsets, &d_code, &d_qual, &d_depth, &d_err, &d_misc, &d_deferred, &d_out, &d_scan_tmp, &d_strings,
+  for (DevBuf* b : {&d_ends, &d_sizes, &d_offsets, &d_code, &d_qual, &d_depth, &d_err, &d_misc, &d_deferred, &d_out, &d_scan_tmp, &d_strings, &d_obs,
                     &d_retry, &d_bound, &d_colbase, &d_statslots, &d_full_items, &d_full_count})
     b->free_();
   for (int i = 0; i < 4; i++) if (ev[i]) { (void)hipEventDestroy(ev[i]); ev[i] = nullptr; }
@@ -1666,11 +2090,12 @@ void FastPath::release() {
 int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const uint64_t* d_rec_off, const uint32_t* d_rec_len,
                   uint32_t n_rec, const uint32_t* d_grp_first, uint32_t n_grp, FastResult* res) {
   const fgx_options& o = c->opt;
+  const bool duplex = o.caller_kind == FGX_CALLER_DUPLEX;
   hipStream_t s = c->stream;
   memset(res, 0, sizeof(*res));
   if (n_grp == 0) return 0;
-  const uint32_t n_slots = 3 * n_grp;
-  d_ends.reserve((size_t)n_slots * sizeof(EndDesc));
+  const uint32_t n_slots = 3 * n_grp;   // simplex: Fragment, R1, R2 of each family; duplex: slot 0 unused, R1, R2
+  d_ends.reserve((size_t)n_slots * (duplex ? sizeof(DuplexDesc) : sizeof(EndDesc)));
   d_sizes.reserve((size_t)n_slots * 8);
   d_offsets.reserve((size_t)n_slots * 8);
   d_deferred.reserve((size_t)n_grp * 4);
@@ -1688,7 +2113,7 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
   d_bound.reserve((size_t)n_grp * 8); d_colbase.reserve((size_t)n_grp * 8);
   d_statslots.reserve((size_t)STAT_SLOTS * 32 * 8);
   hip_check(hipMemsetAsync(d_statslots.p, 0, (size_t)STAT_SLOTS * 32 * 8, s), "memset");
-  hipLaunchKernelGGL(k_col_bound, dim3((n_grp + 255) / 256), dim3(256), 0, s, d_grp_first, d_rec_len, n_grp, d_bound.as<uint64_t>());
+  hipLaunchKernelGGL(k_col_bound, dim3((n_grp + 255) / 256), dim3(256), 0, s, d_grp_first, d_rec_len, n_grp, d_bound.as<uint64_t>(), duplex ? 4u : 3u);
   {
     size_t tb = 0;
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_bound.as<uint64_t>(), d_colbase.as<uint64_t>(), (int)n_grp, s);
@@ -1700,7 +2125,8 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
   hip_check(hipMemcpyAsync(&lastb[1], d_bound.as<uint64_t>() + (n_grp - 1), 8, hipMemcpyDeviceToHost, s), "D2H");
   hip_check(hipStreamSynchronize(s), "sync");
   uint64_t col_cap = lastb[0] + lastb[1] + 64;
-  d_code.reserve(col_cap); d_qual.reserve(col_cap); d_depth.reserve(col_cap * 2); d_err.reserve(col_cap * 2);
+  d_code.reserve(col_cap); d_qual.reserve(col_cap); d_err.reserve(col_cap * 2);
+  if (duplex) d_obs.reserve(col_cap * 4); else d_depth.reserve(col_cap * 2);
 
   FastParams P;
   memset(&P, 0, sizeof(P));
@@ -1709,8 +2135,14 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
   P.T = c->d_tables.as<DeviceTables>(); P.TU = c->d_umi_tables.as<DeviceTables>();
   P.min_reads = o.min_reads; P.max_reads = o.max_reads;
   P.min_input_bq = o.min_input_base_quality; P.min_cons_bq = o.min_consensus_base_quality;
+  if (duplex) {   // single-strand caller of the duplex caller (duplex_caller.rs:474-489): min_reads 1, min consensus base quality 2
+    P.min_reads = 1; P.max_reads = -1; P.min_cons_bq = FGX_MIN_PHRED;
+    P.dmin_total = o.duplex_min_reads[0]; P.dmin_xy = o.duplex_min_reads[1]; P.dmin_yx = o.duplex_min_reads[2];
+    P.dmax_reads = o.duplex_max_reads_per_strand;
+    P.col_obs = d_obs.as<uint32_t>(); P.dends = d_ends.as<DuplexDesc>();
+  }
   P.trim = o.trim; P.overlap = o.overlapping_consensus; P.per_base_tags = o.produce_per_base_tags; P.track_rejects = o.track_rejects;
-  P.tag0 = o.tag[0]; P.tag1 = o.tag[1]; P.cell0 = o.cell_tag[0]; P.cell1 = o.cell_tag[1];
+  P.tag0 = duplex ? 'M' : o.tag[0]; P.tag1 = duplex ? 'I' : o.tag[1]; P.cell0 = o.cell_tag[0]; P.cell1 = o.cell_tag[1];
   P.prefix_len = (uint32_t)c->prefix.size(); P.rg_len = (uint32_t)c->rg.size();
   P.ends = d_ends.as<EndDesc>(); P.rec_sizes = d_sizes.as<uint64_t>();
   P.col_code = d_code.as<uint8_t>(); P.col_qual = d_qual.as<uint8_t>(); P.col_depth = d_depth.as<uint16_t>(); P.col_err = d_err.as<uint16_t>();
@@ -1727,14 +2159,16 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
   d_full_count.reserve((size_t)N_LISTS * 4);
   hip_check(hipMemsetAsync(d_full_count.p, 0, (size_t)N_LISTS * 4, s), "memset");
   P.full_items = d_full_items.as<FullItem>(); P.full_count = d_full_count.as<uint32_t>(); P.full_cap = full_cap;
-  P.lds_wave_bytes = lds_wave_bytes;
+  const uint32_t wave_bytes = duplex ? lds_wave_bytes_duplex : lds_wave_bytes;
+  P.lds_wave_bytes = wave_bytes;
   P.lds_tile_bytes = lds_tile_bytes_large;
 
   hip_check(hipEventRecord(c->ev0, s), "event");
   hip_check(hipEventRecord(ev[0], s), "event");
-  hipLaunchKernelGGL(k_family_wave, dim3((n_grp + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(256), WAVES_PER_BLOCK * lds_wave_bytes, s, P, n_grp);
+  if (duplex) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_family_wave<1>), dim3((n_grp + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(256), WAVES_PER_BLOCK * wave_bytes, s, P, n_grp);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_family_wave<0>), dim3((n_grp + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(256), WAVES_PER_BLOCK * wave_bytes, s, P, n_grp);
   hip_check(hipGetLastError(), "k_family_wave launch");
-  {   // families that do not fit a wave (more than 64 records / more bytes than the LDS slice): one workgroup each
+  if (!duplex) {   // families that do not fit a wave (more than 64 records / more bytes than the LDS slice): one workgroup each
     uint32_t n_retry = 0;
     hip_check(hipMemcpyAsync(&n_retry, P.n_retry, 4, hipMemcpyDeviceToHost, s), "D2H");
     hip_check(hipStreamSynchronize(s), "sync");
@@ -1757,7 +2191,9 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
       memset(&F, 0, sizeof(F));
       F.items = d_full_items.as<FullItem>(); F.count = d_full_count.as<uint32_t>(); F.cap = full_cap;
       F.T = P.T; F.TU = P.TU; F.min_reads = P.min_reads; F.min_cons_bq = P.min_cons_bq;
-      F.col_code = P.col_code; F.col_qual = P.col_qual; F.col_err = P.col_err; F.ends = P.ends;
+      F.col_code = P.col_code; F.col_qual = P.col_qual; F.col_err = P.col_err;
+      if (duplex) { F.rx_base = (char*)P.dends + offsetof(DuplexDesc, rx); F.rx_stride = sizeof(DuplexDesc); }
+      else { F.rx_base = (char*)P.ends + offsetof(EndDesc, rx); F.rx_stride = sizeof(EndDesc); }
       hipLaunchKernelGGL(k_call_full, dim3((mx + 255) / 256, N_LISTS), dim3(256), 0, s, F);
       hip_check(hipGetLastError(), "k_call_full launch");
     }
@@ -1788,7 +2224,16 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
   E.prefix = d_strings.as<char>(); E.prefix_len = P.prefix_len; E.rg = d_strings.as<char>() + P.prefix_len; E.rg_len = P.rg_len;
   E.per_base_tags = P.per_base_tags; E.tag0 = P.tag0; E.tag1 = P.tag1; E.cell0 = P.cell0; E.cell1 = P.cell1;
   hip_check(hipEventRecord(ev[2], s), "event");
-  hipLaunchKernelGGL(k_emit, dim3((n_slots + 3) / 4), dim3(256), 0, s, E);
+  if (duplex) {
+    DuplexEmitParams DE;
+    memset(&DE, 0, sizeof(DE));
+    DE.blob = d_blob; DE.rec_off = d_rec_off; DE.ends = d_ends.as<DuplexDesc>(); DE.out_off = d_offsets.as<uint64_t>(); DE.out = d_out.as<uint8_t>();
+    DE.slot0 = 0; DE.slot_end = n_slots;
+    DE.col_code = P.col_code; DE.col_qual = P.col_qual; DE.col_err = P.col_err; DE.col_obs = P.col_obs;
+    DE.prefix = E.prefix; DE.prefix_len = E.prefix_len; DE.rg = E.rg; DE.rg_len = E.rg_len;
+    DE.per_base_tags = P.per_base_tags; DE.cell0 = P.cell0; DE.cell1 = P.cell1;
+    hipLaunchKernelGGL(k_emit_duplex, dim3((n_slots + 3) / 4), dim3(256), 0, s, DE);
+  } else hipLaunchKernelGGL(k_emit, dim3((n_slots + 3) / 4), dim3(256), 0, s, E);
   hip_check(hipGetLastError(), "k_emit launch");
   hip_check(hipEventRecord(ev[3], s), "event");
   hip_check(hipEventRecord(c->ev1, s), "event");

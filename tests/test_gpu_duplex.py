@@ -11,6 +11,18 @@ from test_oracle_duplex import duplex_fixture
 
 pytestmark = pytest.mark.gpu
 
+GENERAL_ONLY = False
+
+
+@pytest.fixture(autouse=True, params=["device", "general"])
+def path_mode(request):
+    """Every case runs through the device-resident duplex pipeline (deferred molecules fall back to the general path)
+    and through the general host-orchestrated path alone."""
+    global GENERAL_ONLY
+    GENERAL_ONLY = request.param == "general"
+    yield
+    GENERAL_ONLY = False
+
 
 def _same(g, min_reads=(1,), overlapping=True, track_rejects=False, cell_tag="CB", prefix="", **kw):
     mr = list(min_reads)
@@ -28,6 +40,7 @@ def _same(g, min_reads=(1,), overlapping=True, track_rejects=False, cell_tag="CB
     o.duplex_min_reads[0], o.duplex_min_reads[1], o.duplex_min_reads[2] = total, xy, yx
     want = orc.process(o, g.blob, g.rec_off, g.rec_len, g.grp_first, batch_groups=100)
     c = DuplexConsensusCaller(prefix, "A", mr, cell_tag=cell_tag, track_rejects=track_rejects, overlapping_consensus=overlapping, **kw)
+    c.set_general_only(GENERAL_ONLY)
     out = c.process_batch(g)
     st = c.last_batch_statistics()
     rej = c.take_rejected_reads()
@@ -94,3 +107,22 @@ def test_duplex_fatal_errors():
         DuplexConsensusCaller("", "A", [1, 2])
     with pytest.raises(ValueError):
         DuplexConsensusCaller("", "A", [])
+
+
+def test_duplex_device_resident_matches_oracle():
+    """Inputs generated in HBM, outputs left in HBM: nothing deferred on simulate-shaped molecules, bytes equal the oracle's."""
+    if GENERAL_ONLY:
+        pytest.skip("device-resident entry only")
+    for kw, mr in ((dict(n_families=3000, family_size=12, duplex=1), (1, 1, 1)), (dict(n_families=2000, family_size=5, duplex=1, error_rate_ppm=20000), (2, 1, 0)),
+                   (dict(n_families=1500, family_size=3, duplex=1, read_length=100, insert_mean=150, insert_sd=40), (1, 1, 0))):
+        c = DuplexConsensusCaller("", "A", list(mr), cell_tag="CB", overlapping_consensus=True)
+        dg = c.simulate_on_device(**kw)
+        out = c.process_batch_device(dg)
+        data = out.to_host()
+        g = simulate_grouped_reads(kw["n_families"], **{k: v for k, v in kw.items() if k != "n_families"})
+        o = fgx_opts.defaults(kind=1, overlapping_consensus=1, cell_tag=b"CB")
+        o.duplex_min_reads[0], o.duplex_min_reads[1], o.duplex_min_reads[2] = mr
+        want = orc.process(o, g.blob, g.rec_off, g.rec_len, g.grp_first, batch_groups=100)
+        assert out.n_deferred == 0
+        assert out.count == want["count"] and data == want["data"]
+        c.close()
