@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(n_families, family_size, read_length, threads):
+def cpu_baseline(n_families, family_size, read_length, threads, duplex=False):
     """Bounded sample of the same workload through the ORACLE (C++ restatement of the reference CPU
     caller; `--threads`-style batches of 50 MI groups, one caller object per batch) on this box's
     host cores.  A reported baseline, not the optimisation target."""
@@ -31,17 +31,19 @@ def cpu_baseline(n_families, family_size, read_length, threads):
     import fgx_opts
     import orc
     from fgumi_amd import simulate_grouped_reads
-    g = simulate_grouped_reads(n_families, family_size=family_size, read_length=read_length)
-    o = fgx_opts.defaults(min_reads=1)
+    g = simulate_grouped_reads(n_families, family_size=family_size, read_length=read_length, duplex=int(duplex))
+    o = fgx_opts.defaults(min_reads=1, kind=1 if duplex else 0)
+    if duplex:
+        o.duplex_min_reads[0], o.duplex_min_reads[1], o.duplex_min_reads[2] = 1, 1, 1
     best, res = None, None
     for _ in range(3):
         t0 = time.perf_counter()
-        res = orc.process(o, g.blob, g.rec_off, g.rec_len, g.grp_first, batch_groups=50, threads=threads)
+        res = orc.process(o, g.blob, g.rec_off, g.rec_len, g.grp_first, batch_groups=100 if duplex else 50, threads=threads)
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
     return dict(value=g.n_rec / best, unit="raw reads/s", cores=threads, kind="port",
-                sample=f"{n_families} families x {family_size} pairs x {read_length}bp, compute-only (records in RAM → ConsensusOutput "
-                       f"bytes), batches of 50 MI groups over {threads} threads, best of 3",
+                sample=f"{n_families} families x {family_size} pairs x {read_length}bp{' (--duplex)' if duplex else ''}, compute-only (records in RAM → "
+                       f"ConsensusOutput bytes), batches of {100 if duplex else 50} MI groups over {threads} threads, best of 3",
                 consensus_reads_per_s=res["count"] / best)
 
 
@@ -70,12 +72,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--families", type=int, default=int(os.environ.get("FGX_BENCH_FAMILIES", "5000000")))
-    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--caller", choices=["simplex", "duplex"], default="simplex",
+                    help="simplex = BASELINE configs[1] (the headline metric); duplex = configs[2] shape (2M molecules, 6+6 pairs)")
+    ap.add_argument("--families", type=int, default=None)
+    ap.add_argument("--depth", type=int, default=None)
     ap.add_argument("--read-length", type=int, default=150)
     ap.add_argument("--cpu-sample-families", type=int, default=300000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    duplex = args.caller == "duplex"
+    if args.families is None:
+        args.families = int(os.environ.get("FGX_BENCH_FAMILIES", "2000000" if duplex else "5000000"))
+    if args.depth is None:
+        args.depth = 12 if duplex else 8
 
     import torch
     import torch.distributed as dist
@@ -87,13 +96,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl")
 
-    from fgumi_amd import VanillaUmiConsensusCaller, VanillaUmiConsensusOptions
+    from fgumi_amd import DuplexConsensusCaller, VanillaUmiConsensusCaller, VanillaUmiConsensusOptions
 
     fam = args.families
-    caller = VanillaUmiConsensusCaller("", "A", VanillaUmiConsensusOptions(min_reads=1, min_consensus_base_quality=2, cell_tag="CB"),
-                                       overlapping_consensus=True, device=local_rank)
+    if duplex:
+        caller = DuplexConsensusCaller("", "A", [1], cell_tag="CB", overlapping_consensus=True, device=local_rank)
+    else:
+        caller = VanillaUmiConsensusCaller("", "A", VanillaUmiConsensusOptions(min_reads=1, min_consensus_base_quality=2, cell_tag="CB"),
+                                           overlapping_consensus=True, device=local_rank)
     # synthetic families generated straight into HBM; rank r owns molecules [r*fam, (r+1)*fam)
-    dg = caller.simulate_on_device(fam, family_size=args.depth, read_length=args.read_length, first_family=rank * fam)
+    dg = caller.simulate_on_device(fam, family_size=args.depth, read_length=args.read_length, first_family=rank * fam, duplex=int(duplex))
 
     def barrier():
         if world > 1:
@@ -124,27 +136,29 @@ def main():
         # algorithmic bytes of ONE k_family launch on ONE GPU: per raw read ceil(L/2)+L read,
         # per consensus read 6*Lc written (bases, quals, depth i16, errors i16)
         alg_read = dg.n_rec * ((L + 1) // 2 + L)
-        alg_write = out.count * 6 * L
+        alg_write = out.count * 6 * L * (2 if duplex else 1)     # duplex: each record is built from two single-strand column sets
         k_avg_s = k_family_ms / steps / 1e3
         achieved = (alg_read + alg_write) / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
         line = {
-            "metric": "simplex consensus throughput, input raw reads/s (depth-8 x 150bp)",
+            "metric": ("duplex consensus throughput, input raw reads/s (depth 6+6 x 150bp)" if duplex
+                       else "simplex consensus throughput, input raw reads/s (depth-8 x 150bp)"),
             "value": total_raw * steps / dt, "unit": "raw reads/s",
             "consensus_reads_per_s": total_cons * steps / dt,
             "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"simplex consensus, {fam} families per GPU, depth={args.depth} pairs, {L}bp paired "
-                                   f"(BASELINE configs[1] shape), device-resident: raw BAM records in HBM -> consensus BAM records in HBM",
+            "config": {"workload": (f"duplex consensus, {fam} molecules per GPU, {args.depth} pairs split over /A and /B, {L}bp paired (BASELINE configs[2] shape), "
+                                    if duplex else f"simplex consensus, {fam} families per GPU, depth={args.depth} pairs, {L}bp paired (BASELINE configs[1] shape), ")
+                                   + "device-resident: raw BAM records in HBM -> consensus BAM records in HBM",
                        "min_reads": 1, "overlapping_consensus": True, "families_per_gpu": fam, "raw_reads_per_gpu": dg.n_rec,
                        "deferred_families": total_def, "output_bytes": total_bytes,
                        "columns_needing_call_full_per_step": caller.last_timing.get("full_columns")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(fam, args.depth, L), "kernel": "k_family", "kernel_ms": k_family_ms / steps, "k_emit_ms": k_emit_ms / steps,
+                         "traffic": None if duplex else pmc_traffic(fam, args.depth, L), "kernel": "k_family", "kernel_ms": k_family_ms / steps, "k_emit_ms": k_emit_ms / steps,
                          "device_ms_per_step": k_total_ms / steps, "algorithmic_bytes_per_launch": alg_read + alg_write,
                          "read_only_GBs": alg_read / k_avg_s / 1e9 if k_avg_s > 0 else 0.0},
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(min(fam, args.cpu_sample_families), args.depth, L, os.cpu_count() or 1)
+            line["cpu_baseline"] = cpu_baseline(min(fam, args.cpu_sample_families), args.depth, L, os.cpu_count() or 1, duplex)
         print(json.dumps(line))
     if rank == 0:   # profiling builds (-DFGX_PHASE_TIMING=1) expose per-phase cycle totals of k_family_wave
         import ctypes

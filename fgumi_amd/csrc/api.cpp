@@ -242,7 +242,12 @@ int fgx_process_batch(fgx_caller* c, const uint8_t* records, uint64_t records_le
           return duplex_process_general(c, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);   // raises the reference's error
         return process_hybrid(c, duplex_process_general, records, records_len, rec_off, rec_len, n_rec, grp_first, n_grp, out);
 #ifdef FGX_HAVE_CODEC
-      case FGX_CALLER_CODEC: return codec_process_general(c, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
+      case FGX_CALLER_CODEC:
+        // the device pipeline emits every molecule that passes the geometry gates: only valid while the duplex-disagreement
+        // thresholds cannot reject anything (their defaults); otherwise the general path decides after the strand combine
+        if (c->general_only || c->opt.codec_max_duplex_disagreements != 0xFFFFFFFFu || c->opt.codec_max_duplex_disagreement_rate < 1.0)
+          return codec_process_general(c, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
+        return process_hybrid(c, codec_process_general, records, records_len, rec_off, rec_len, n_rec, grp_first, n_grp, out);
 #endif
       default: c->err = "fgx_process_batch: caller kind not implemented"; return 1;
     }
@@ -258,7 +263,9 @@ int fgx_process_batch_device(fgx_caller* c, const void* d_records, uint64_t reco
   if (!c || !out) return 1;
   c->err.clear();
   try {
-    if (c->opt.caller_kind != FGX_CALLER_SIMPLEX && c->opt.caller_kind != FGX_CALLER_DUPLEX) { c->err = "fgx_process_batch_device: caller kind not implemented"; return 1; }
+    if (c->opt.caller_kind == FGX_CALLER_CODEC && (c->opt.codec_max_duplex_disagreements != 0xFFFFFFFFu || c->opt.codec_max_duplex_disagreement_rate < 1.0)) {
+      c->err = "fgx_process_batch_device: CODEC duplex-disagreement thresholds need the host path (fgx_process_batch)"; return 1;
+    }
     if (c->opt.track_rejects) { c->err = "fgx_process_batch_device: --rejects needs the host path (fgx_process_batch)"; return 1; }
     if (!c->fast) c->fast = new FastState();
     hip_check(hipSetDevice(c->device), "hipSetDevice");

@@ -155,7 +155,8 @@ struct Strand {   // SingleStrandConsensus, the fields with an observable effect
 };
 
 inline uint8_t comp_ascii(uint8_t c) {
-  switch (c) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; default: return c; }   // consensus alphabet: ACGT, N, n
+  if (c == 'n') return 'n';   // padding stays lower case; a lone read can put any IUPAC letter into its strand consensus
+  return bam::code_to_ascii(bam::code_complement(bam::ascii_to_code(c)));
 }
 Strand rc(const Strand& s) {
   Strand o;
@@ -205,6 +206,7 @@ int codec_process_general(fgx_caller* c, const uint8_t* blob, const uint64_t* re
   ColumnBatch& B = c->batch;
   B.clear();
   c->out_data.clear(); c->out_rejects.clear();
+  c->grp_out_end.assign(n_grp, 0);
   c->err.clear();
   std::vector<Group> groups(n_grp);
   std::vector<uint8_t> tb, tq;
@@ -488,6 +490,7 @@ int codec_process_general(fgx_caller* c, const uint8_t* blob, const uint64_t* re
     for (int i = 0; i < FGX_N_REJECTION; i++) batch.rej[i] += G.st.rej[i];
     if (track)
       for (uint32_t i = 0; i < n; i++) if (G.mask[i]) { append_with_block_size(c->out_rejects, blob + rec_off[r0 + i], rec_len[r0 + i]); n_rejects++; }
+    c->grp_out_end[g] = c->out_data.size();
   }
   auto t3 = clk::now();
 

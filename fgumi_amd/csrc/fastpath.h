@@ -32,6 +32,16 @@ struct DuplexDesc {         // one duplex consensus record (slot 3g+1 = R1, 3g+2
   char rx[FAST_RX_CAP];
 };
 
+struct CodecDesc {          // one CODEC consensus record (slot 3g+1), written by k_family_wave<2>, consumed by k_emit_codec
+  uint64_t s1_off, s2_off;  // R1-strand and R2-strand single-strand column segments (read orientation)
+  uint32_t l1, l2, cons_len;
+  uint32_t first_rec, cb_rec, rec_size;
+  uint16_t mi_off, cb_off;
+  uint8_t mi_len, cb_len, rx_len, flags;   // flags: bit 0 = longest R1 on the reverse strand, bit 1 = longest R2 on the reverse strand
+  uint8_t has_cb, has_rx, valid, _pad;
+  char rx[FAST_RX_CAP];
+};
+
 struct FullItem {           // a column (or UMI character) whose call needs the full log-sum-exp chain
   uint64_t dest;            // bit 63 clear: scratch column index; set: (slot << 8 | char index) of an RX character
   double ll[4];
@@ -62,6 +72,8 @@ struct FastParams {
   uint32_t dmin_total, dmin_xy, dmin_yx; int64_t dmax_reads;
   uint32_t* col_obs;               // per column: observation counts of A,C,G,T, one byte each
   DuplexDesc* dends;
+  // CODEC (k_family_wave<2>)
+  CodecDesc* cends; uint32_t cmin_reads, cmin_duplex_len; int64_t cmax_reads;
 };
 
 struct EmitParams {
@@ -78,6 +90,16 @@ struct DuplexEmitParams {
   const uint8_t* col_code; const uint8_t* col_qual; const uint16_t* col_err; const uint32_t* col_obs;
   const char* prefix; uint32_t prefix_len; const char* rg; uint32_t rg_len;
   uint8_t per_base_tags; char cell0, cell1;
+};
+
+struct CodecEmitParams {
+  const uint8_t* blob; const uint64_t* rec_off; const CodecDesc* ends; const uint64_t* out_off; uint8_t* out;
+  uint32_t slot0, slot_end;
+  const uint8_t* col_code; const uint8_t* col_qual; const uint16_t* col_depth; const uint16_t* col_err;
+  const char* prefix; uint32_t prefix_len; const char* rg; uint32_t rg_len;
+  uint8_t per_base_tags; char cell0, cell1;
+  uint8_t has_outer, outer_qual, has_ss, ss_qual; uint32_t outer_len;
+  unsigned long long* stats;       // slot-spread counters: [24] consensus bases, [25] duplex bases, [26] disagreeing duplex bases
 };
 
 struct FastResult {

@@ -812,7 +812,7 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
   unsigned long long* st = P.stats + (size_t)(blockIdx.x & (STAT_SLOTS - 1)) * 32;
   const uint32_t r0 = P.grp_first[g], n = P.grp_first[g + 1] - r0;
   const uint32_t slot0 = 3 * g;
-  if (lane < 3) { if (MODE == 0) P.ends[slot0 + lane].valid = 0; else P.dends[slot0 + lane].valid = 0; P.rec_sizes[slot0 + lane] = 0; }
+  if (lane < 3) { if (MODE == 0) P.ends[slot0 + lane].valid = 0; else if (MODE == 1) P.dends[slot0 + lane].valid = 0; else P.cends[slot0 + lane].valid = 0; P.rec_sizes[slot0 + lane] = 0; }
 
   if (MODE == 0 && n < P.min_reads) {   // simplex.rs:673-683
     if (lane == 0) { atomicAdd(&st[0], (unsigned long long)n); atomicAdd(&st[2], (unsigned long long)n); atomicAdd(&st[3 + FGX_REJ_INSUFFICIENT_READS], (unsigned long long)n); }
@@ -865,6 +865,7 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
       seq_lo = lo + (uint32_t)seq_off; qual_lo = lo + (uint32_t)qual_off;
       excluded = (flags & (bam::F_SECONDARY | bam::F_SUPPLEMENTARY)) != 0;
       if (MODE == 1 && excluded) bad = true;   // the duplex caller has no secondary/supplementary filter: general path
+      if (MODE == 2 && (excluded || !(flags & bam::F_PAIRED))) bad = true;   // CODEC: fragments / non-primary records take the general path
       uint32_t op = 0;
       if (!excluded) {
         if ((flags & bam::F_UNMAPPED) || n_cig != 1 || l_seq == 0 || pos < 0) bad = true;
@@ -910,7 +911,14 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
         if (has_mi && mi_len >= 2 && W[mi_lo + mi_len - 2] == '/') { const uint8_t sc = W[mi_lo + mi_len - 1]; strand = sc == 'A' ? 1u : sc == 'B' ? 2u : 0u; }
         if ((flags & bam::F_PAIRED) && (strand == 0 || P.prefix_len + 1 + (mi_len - 2) >= 255)) bad = true;
       }
-      if (!bad && !excluded) {
+      if (MODE == 2 && !bad) {   // is_fr_pair_raw of THIS record (overlap.rs:21-69); only the reverse record's answer is used
+        const int32_t mpos = (int32_t)ld32u(W, lo + 24), mref = (int32_t)ld32u(W, lo + 20);
+        if (pos >= (1 << 30) || mpos < -1 || mpos >= (1 << 30)) bad = true;
+        const bool rv = (flags & bam::F_REVERSE) != 0, mrv = (flags & bam::F_MATE_REVERSE) != 0;
+        const bool okp = !(flags & bam::F_MATE_UNMAPPED) && ref_id == mref && rv != mrv;
+        strand = (okp && ((long long)mpos + 1 < (long long)pos + 1 + ((long long)l_seq - 1))) ? 1u : 0u;   // `strand` doubles as frself here
+      }
+      if (MODE != 2 && !bad && !excluded) {
         // mate-overlap clip (raw-bam/overlap.rs:181-357).  Closed form when the MC tag is one M op and all
         // coordinates are in the ordinary range (no saturating arithmetic can trigger); general code otherwise.
         bool fastclip = false;
@@ -957,6 +965,8 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
           if (overflow) bad = true;
           clip = (uint32_t)(cl > 65535 ? 65535 : cl);
         }
+      }
+      if (!bad && !excluded) {
         // name hash (8 bytes per step) for mate pairing
         unsigned long long h = 0x9E3779B97F4A7C15ULL ^ name_len;
         for (uint32_t i = 0; i < name_len; i += 8) {
@@ -970,9 +980,9 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
   }
   // first record must carry the MI tag and give a legal read name (vanilla_caller.rs:1897-1908, 1795-1797)
   const uint32_t mi0_lo = rlane(mi_lo, 0), mi0_len = rlane(mi_len, 0);
-  if (MODE == 0 && lane == 0 && (!has_mi || P.prefix_len + 1 + mi_len >= 255)) bad = true;
+  if (MODE != 1 && lane == 0 && (!has_mi || P.prefix_len + 1 + mi_len >= 255)) bad = true;   // (CODEC without an MI names reads by a running counter: general path)
   // absent qualities (all 0xFF) are a fatal input error (:1119-1124)
-  if (act && !bad && !excluded && W[qual_lo] == 0xFF) {
+  if (MODE != 2 && act && !bad && !excluded && W[qual_lo] == 0xFF) {
     bool all = true;
     for (uint32_t i = 0; i < l_seq; i++) if (W[qual_lo + i] != 0xFF) { all = false; break; }
     if (all) bad = true;
@@ -986,6 +996,7 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
   // ---- 3. overlapping-bases pre-correction in LDS (overlapping.rs:236-336, 627-684) ----------------------
   uint32_t ov_bases = 0, ov_agree = 0, ov_dis = 0, ov_corr = 0;
   bool do_overlap = P.overlap != 0;
+  if (MODE == 2) do_overlap = false;
   if (MODE == 1 && do_overlap && P.dmin_yx != 0)   // duplex.rs:786-795: only molecules with both strands when single-strand output is off
     do_overlap = n >= 2 && __any(act && strand == 1) && __any(act && strand == 2);
   if (do_overlap) {
@@ -1103,7 +1114,7 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
   PH(3)
   // ---- 4. source-read geometry per lane (vanilla_caller.rs:1129-1160) -----------------------------------------
   uint32_t trim_to = l_seq, final_len = 0;
-  if (cand && P.trim) {
+  if (MODE != 2 && cand && P.trim) {
     uint32_t tq = P.min_input_bq;
     if (tq < 1 || l_seq == 0) trim_to = 0;
     else {
@@ -1118,7 +1129,7 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
       trim_to = point;
     }
   }
-  {
+  if (MODE != 2) {
     uint32_t clip_pos = l_seq > clip ? l_seq - clip : 0;
     uint32_t fl = clip_pos < trim_to ? clip_pos : trim_to;
     bool tail_n = false;
@@ -1405,7 +1416,7 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
     if (ov_corr) atomicAdd(&st[27], (unsigned long long)ov_corr);
   }
   PH(8)
-  } else {
+  } else if constexpr (MODE == 1) {
   // =====================================================================================================================
   // MODE 1 — duplex.  Mirrors DuplexConsensusCaller::consensus_reads / process_group (duplex_caller.rs:2545-2624,
   // 1944-2540) for the molecules the device can decide exactly; anything else is deferred to duplex_host.cpp.
@@ -1680,6 +1691,285 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
       return;
     }
   } else if (__any(list_overflow)) { to_defer(); return; }
+  flush_stats();
+  PH(8)
+  } else {
+  // =====================================================================================================================
+  // MODE 2 — CODEC.  Mirrors CodecConsensusCaller::consensus_reads_raw (codec_caller.rs:625-1004) for molecules whose
+  // records are all paired primary reads with a single M op, mates adjacent; everything else goes to codec_host.cpp.
+  // The duplex-disagreement thresholds are at their defaults on this path (the host checks), so no molecule is rejected
+  // after the strand combine and every record size is known here.
+  // =====================================================================================================================
+  // ---- 5C. templates: the partner of each record is the one other record with its read name ---------------------------------
+  uint32_t s_filtered = 0, rj_notfr = 0, rj_insuf = 0, rj_overlap = 0, rj_indel = 0, rj_clipfail = 0, s_cons = 0;
+  auto flush_stats = [&]() {
+    if (lane == 0) {
+      atomicAdd(&st[0], (unsigned long long)n);
+      if (s_cons) atomicAdd(&st[1], (unsigned long long)s_cons);
+      if (s_filtered) atomicAdd(&st[2], (unsigned long long)s_filtered);
+      if (rj_notfr) atomicAdd(&st[3 + FGX_REJ_NOT_PRIMARY_FR_PAIR], (unsigned long long)rj_notfr);
+      if (rj_insuf) atomicAdd(&st[3 + FGX_REJ_INSUFFICIENT_READS], (unsigned long long)rj_insuf);
+      if (rj_overlap) atomicAdd(&st[3 + FGX_REJ_INSUFFICIENT_OVERLAP], (unsigned long long)rj_overlap);
+      if (rj_indel) atomicAdd(&st[3 + FGX_REJ_INDEL_ERROR_BETWEEN_STRANDS], (unsigned long long)rj_indel);
+      if (rj_clipfail) atomicAdd(&st[3 + FGX_REJ_CLIP_OVERLAP_FAILED], (unsigned long long)rj_clipfail);
+    }
+  };
+  {
+    uint32_t eq_lo = 0, eq_hi = 0;
+    for (unsigned long long um = __ballot(act); um; um &= um - 1) {
+      const uint32_t u = (uint32_t)__builtin_ctzll(um);
+      const bool eq = rlane(hash, u) == hash && rlane(name_len, u) == name_len && u != lane;
+      if (u < 32) eq_lo |= (eq ? 1u : 0u) << u; else eq_hi |= (eq ? 1u : 0u) << (u - 32);
+    }
+    unsigned long long todo = act ? ((unsigned long long)eq_lo | ((unsigned long long)eq_hi << 32)) : 0ull;
+    uint32_t n_same = 0;
+    bool neighbour = false;
+    while (__any(todo != 0)) {
+      const bool mine = todo != 0;
+      const uint32_t u = mine ? (uint32_t)__builtin_ctzll(todo) : lane;
+      todo &= todo - 1;
+      const uint32_t lou = (uint32_t)__shfl((int)lo, (int)u);
+      if (mine) {
+        bool same = true;
+        for (uint32_t i = 0; i < name_len; i += 8) {
+          unsigned long long wa = ld64u(W, lou + 32 + i), wb = ld64u(W, lo + 32 + i);
+          if (i + 8 > name_len) { unsigned long long mk = (1ULL << (8 * (name_len - i))) - 1; wa &= mk; wb &= mk; }
+          if (wa != wb) { same = false; break; }
+        }
+        if (same) { n_same++; neighbour |= u == (lane ^ 1); }
+      }
+    }
+    // exactly two records per name, mates adjacent (template order by first appearance is then the order of the R1s and of
+    // the R2s — the order the likelihoods are summed in); singletons, triples, interleaved pairs: general path
+    if (__any(act && (n_same != 1 || !neighbour))) { to_defer(); return; }
+  }
+  const bool first = (flags & bam::F_FIRST) != 0;
+  const uint32_t m_flags = (uint32_t)__shfl((int)flags, (int)(lane ^ 1)), m_lseq = (uint32_t)__shfl((int)l_seq, (int)(lane ^ 1));
+  const int32_t m_pos = (int32_t)__shfl((int)pos, (int)(lane ^ 1)), m_ref = (int32_t)__shfl((int)ref_id, (int)(lane ^ 1));
+  const uint32_t m_frself = (uint32_t)__shfl((int)strand, (int)(lane ^ 1));
+  if (__any(act && first == ((m_flags & bam::F_FIRST) != 0))) { to_defer(); return; }          // both mates FIRST or neither
+  // is_primary_fr_pair_raw (overlap.rs:83-108): mapped, mates mapped, one reference, opposite strands, FR by the reverse record
+  const bool m_rev = (m_flags & bam::F_REVERSE) != 0;
+  const bool fr = act && !(flags & bam::F_MATE_UNMAPPED) && !(m_flags & bam::F_MATE_UNMAPPED) && ref_id == m_ref && rev != m_rev &&
+                  (rev ? strand : m_frself) != 0;
+  const uint32_t n_notfr = (uint32_t)__popcll(__ballot(act && !fr));
+  rj_notfr = n_notfr; s_filtered += n_notfr;
+  // overlap clip against the mate in hand (overlap.rs:223-357 for two single-M alignments)
+  if (fr) {
+    const long long L = l_seq, ML = m_lseq, tp = (long long)pos + 1, mp = (long long)m_pos + 1;
+    const long long read_end = tp - 1 + L, mate_end = mp - 1 + ML;
+    long long cl = 0;
+    if (rev) {
+      if (!(tp > mate_end) && !(read_end < mp)) {
+        const long long fs = tp > mp ? tp : mp;
+        long long rb = fs - tp; if (rb > L) rb = L;
+        long long mb = fs - mp; if (mb > ML) mb = ML;
+        cl = rb > mb ? rb - mb : 0;
+      }
+    } else {
+      if (!(read_end < mp) && !(mate_end < tp)) {
+        const long long ls = read_end < mate_end ? read_end : mate_end;
+        long long ra = ls - tp + 1; if (ra > L) ra = L;
+        long long ma = ls - mp + 1; if (ma > ML) ma = ML;
+        const long long rp = L - ra, mq = ML - ma;
+        cl = rp > mq ? rp - mq : 0;
+      }
+    }
+    clip = (uint32_t)cl;
+  }
+  // ClippedRecordInfo (:1006-1040): hard clip at the 3' end; a reverse read loses its start and moves right
+  const uint32_t clen = fr ? (l_seq > clip ? l_seq - clip : 0) : 0;                 // clipped_seq_len = reference span of the clipped M
+  const unsigned long long adj = (unsigned long long)((long long)pos + 1) + (rev ? (clip < l_seq ? clip : l_seq) : 0);
+  const unsigned long long r1set = uniform_u64(__ballot(fr && first)), r2set = uniform_u64(__ballot(fr && !first));
+  const uint32_t n_strand = (uint32_t)__popcll(r1set | r2set);
+  if (!r1set) { flush_stats(); return; }
+  auto reject_all = [&](uint32_t& counter) { counter += n_strand; s_filtered += n_strand; flush_stats(); };
+  if ((uint32_t)__popcll(r1set) < P.cmin_reads) { reject_all(rj_insuf); return; }
+  // most common alignment: with one M op per read the simplified clipped CIGAR is (M, l_seq) — equal read lengths ⇒ one group
+  {
+    const uint32_t l1ref = rlane(l_seq, (uint32_t)__builtin_ctzll(r1set)), l2ref = rlane(l_seq, (uint32_t)__builtin_ctzll(r2set));
+    if (__any(fr && l_seq != (first ? l1ref : l2ref))) { to_defer(); return; }
+  }
+  if (P.cmax_reads >= 0) {
+    if (P.cmax_reads == 0) { reject_all(rj_insuf); return; }
+    if ((long long)__popcll(r1set) > P.cmax_reads) { to_defer(); return; }       // the cap bites: name-rank downsampling on the host
+  }
+  // longest R1 / R2 by clipped reference length (first maximum)
+  const uint32_t mx1 = wave_max((fr && first) ? clen + 1 : 0), mx2 = wave_max((fr && !first) ? clen + 1 : 0);
+  const uint32_t L1 = (uint32_t)__builtin_ctzll(__ballot(fr && first && clen + 1 == mx1)), L2 = (uint32_t)__builtin_ctzll(__ballot(fr && !first && clen + 1 == mx2));
+  const bool r1_neg = (rlane(flags, L1) & bam::F_REVERSE) != 0, r2_neg = (rlane(flags, L2) & bam::F_REVERSE) != 0;
+  const uint32_t adj_lo = (uint32_t)adj, adj_hi = (uint32_t)(adj >> 32);
+  auto adj_of = [&](uint32_t r) { return ((unsigned long long)rlane(adj_hi, r) << 32) | rlane(adj_lo, r); };
+  const uint32_t Lp = r1_neg ? L2 : L1, Ln = r1_neg ? L1 : L2;
+  const unsigned long long adj_p = adj_of(Lp), adj_n = adj_of(Ln), adj_1 = adj_of(L1), adj_2 = adj_of(L2);
+  const uint32_t rl_p = rlane(clen, Lp), rl_n = rlane(clen, Ln), rl_1 = rlane(clen, L1), rl_2 = rlane(clen, L2);
+  const unsigned long long pos_end = adj_p + (rl_p ? rl_p - 1 : 0), neg_end = adj_n + (rl_n ? rl_n - 1 : 0);
+  const unsigned long long ov_s = adj_n > adj_p ? adj_n : adj_p, ov_e = pos_end < neg_end ? pos_end : neg_end;
+  const long long duplex_len = (long long)ov_e - (long long)ov_s + 1;
+  if (duplex_len < (long long)P.cmin_duplex_len) { reject_all(rj_overlap); return; }
+  // read_pos_at_ref_pos_raw (cigar.rs:461-500) on [H?] M [H?]: 1-based query position, 0 = htsjdk's out-of-range sentinel
+  auto read_pos = [](unsigned long long a, uint32_t rl, unsigned long long p) -> long long { return (p >= a && rl && p <= a + rl - 1) ? (long long)(p - a + 1) : 0; };
+  if (read_pos(adj_1, rl_1, ov_s) - read_pos(adj_2, rl_2, ov_s) != read_pos(adj_1, rl_1, ov_e) - read_pos(adj_2, rl_2, ov_e)) { reject_all(rj_indel); return; }
+  const long long prp = read_pos(adj_p, rl_p, ov_e), nrp = read_pos(adj_n, rl_n, ov_e);
+  if (prp == 0 || nrp == 0) { reject_all(rj_indel); return; }
+  if (prp + (long long)rl_n < nrp) { to_defer(); return; }                       // the general path raises the error
+  const uint32_t cons_len = (uint32_t)(prp + (long long)rl_n - nrp);
+  const uint32_t len1 = wave_max((fr && first) ? clen : 0), len2 = wave_max((fr && !first) ? clen : 0);
+  if (cons_len < len1 || cons_len < len2) { reject_all(rj_clipfail); return; }
+
+  PH(5)
+  // ---- 6C. the two single-strand column sets (ss caller: min_reads 1, no quality masking, min consensus base quality 0) ----------
+  final_len = clen;
+  const uint32_t d0 = seq_lo | (qual_lo << 16), d1 = l_seq | (final_len << 16), d2 = (rev ? 1u : 0u) << 16;
+  const DeviceTables* T = P.T;
+  const uint64_t col_base = P.col_base[g];
+  CallConst KC;
+  KC.cap = (uint32_t)__builtin_amdgcn_readfirstlane((int)sT.cap);
+  KC.cap_threshold = uniform_f64(sT.cap_threshold); KC.half_cerr_at_cap = uniform_f64(sT.half_cerr_at_cap);
+  bool odd_base = false;
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const unsigned long long members = k == 0 ? r1set : r2set;
+    const uint32_t mc = (uint32_t)__popcll(members), elen = k == 0 ? len1 : len2, eoff = k == 0 ? 0 : len1;
+    for (uint32_t p = lane; p < elen; p += 64) {
+      const uint64_t o = col_base + eoff + p;
+      if (mc == 1) {   // single-read consensus: LUT keyed by the unclamped quality (vanilla_caller.rs:1677-1708)
+        const uint32_t r = (uint32_t)__builtin_ctzll(members);
+        uint32_t code, q;
+        view(rlane(seq_lo, r), rlane(qual_lo, r), rlane(l_seq, r), (rlane(flags, r) & bam::F_REVERSE) != 0, 0, p, &code, &q);
+        const uint8_t adjq = q < 94 ? T->single_input_quals[q] : 0;
+        P.col_code[o] = (uint8_t)code; P.col_qual[o] = adjq; P.col_depth[o] = code != 15 ? 1 : 0; P.col_err[o] = 0;
+        if (code != 15 && code != 1 && code != 2 && code != 4 && code != 8) odd_base = true;   // IUPAC code in a lone read: general path
+      } else {
+        ColumnAcc acc;
+        acc.reset();
+        for (unsigned long long m = members; m; m &= m - 1) {
+          const uint32_t r = (uint32_t)__builtin_ctzll(m);
+          const uint32_t x0 = rlane(d0, r), x1 = rlane(d1, r), x2 = rlane(d2, r);
+          bool valid = p < (x1 >> 16);
+          const bool rv = (x2 >> 16) != 0;
+          const uint32_t idx = valid ? (rv ? (x1 & 0xFFFF) - 1 - p : p) : 0;
+          const uint32_t bb = W[(x0 & 0xFFFF) + (idx >> 1)];
+          const uint32_t c = (bb >> ((~idx & 1) << 2)) & 15;
+          const uint32_t q = W[(x0 >> 16) + idx];
+          const unsigned long long LUT = rv ? 0xFFFFFFF0FFF1F23FULL : 0xFFFFFFF3FFF2F10FULL;
+          const uint32_t bl = (uint32_t)(LUT >> (4 * c)) & 15;
+          valid = valid && bl < 4;
+          const uint32_t qq = q < FGX_MAX_PHRED ? q : FGX_MAX_PHRED;
+          const double2 pr = *(const double2*)&sPair[qq][0];
+          if (valid) acc.add((int)bl, pr.x, pr.y);
+        }
+        double ll[4] = {acc.s[0], acc.s[1], acc.s[2], acc.s[3]};
+        uint32_t obs[4] = {acc.obs[0], acc.obs[1], acc.obs[2], acc.obs[3]};
+        int bi;
+        uint8_t q;
+        const bool resolved = column_call_fast_lds(sT, KC, ll, obs, &bi, &q);
+        const uint32_t depth = obs[0] + obs[1] + obs[2] + obs[3];
+        P.col_depth[o] = (uint16_t)depth;
+        push_full(!resolved, o, ll, obs);
+        if (resolved) {
+          const uint32_t err = depth - (bi == 0 ? obs[0] : bi == 1 ? obs[1] : bi == 2 ? obs[2] : bi == 3 ? obs[3] : 0u);
+          P.col_code[o] = depth < 1 ? (uint8_t)15 : bi >= 0 ? (uint8_t)(1u << bi) : (uint8_t)15;
+          P.col_qual[o] = depth < 1 ? (uint8_t)0 : q;
+          P.col_err[o] = (uint16_t)err;
+        }
+      }
+    }
+  }
+  if (__any(odd_base)) { to_defer(); return; }
+
+  PH(6)
+  // ---- 7C. consensus UMI over EVERY record of the group that carries RX (codec_caller.rs:1725-1744) -----------------------------
+  const DeviceTables* TU = P.TU;
+  const unsigned long long with = rxmask;
+  const uint32_t rx_cnt = (uint32_t)__popcll(with);
+  uint32_t ulen = 0;
+  char my_ch = 0;
+  bool rx_fail = false;
+  const uint32_t slot = slot0 + 1;
+  if (rx_cnt) {
+    const uint32_t f = (uint32_t)__builtin_ctzll(with);
+    ulen = rlane(rx_len, f);
+    if (__any(((with >> lane) & 1) && rx_len != ulen) || ulen > FAST_RX_CAP) rx_fail = true;
+    else {
+      const bool mychar = lane < ulen;
+      const uint32_t f_lo = rlane(rx_lo, f);
+      const uint8_t c0 = mychar ? W[f_lo + lane] : (uint8_t)'A';
+      bool differs = false;
+      if ((with >> lane) & 1) {
+        for (uint32_t i = 0; i < ulen; i += 8) {
+          unsigned long long a = ld64u(W, rx_lo + i), b = ld64u(W, f_lo + i);
+          if (i + 8 > ulen) { unsigned long long mk = (1ULL << (8 * (ulen - i))) - 1; a &= mk; b &= mk; }
+          differs |= a != b;
+        }
+      }
+      if (rx_cnt == 1 || !__any(differs)) {
+        const int bl = bam::ascii_to_lane(c0);
+        my_ch = rx_cnt == 1 ? (char)c0 : bl != 255 ? "ACGT"[bl] : (c0 == 'N' || c0 == 'n') ? 'N' : (char)c0;
+      } else {
+        ColumnAcc acc;
+        acc.reset();
+        uint32_t non_dna = 0, seen = 0;
+        uint8_t fch = 0;
+        bool mixed = false;
+        const double uc = TU->t.correct[20], ue = TU->t.error_per_alt[20];
+        for (unsigned long long m = with; m; m &= m - 1) {
+          const uint32_t r = (uint32_t)__builtin_ctzll(m);
+          const uint8_t ch = mychar ? W[rlane(rx_lo, r) + lane] : (uint8_t)'A';
+          if (seen == 0) fch = ch;
+          seen++;
+          const uint8_t up = (ch >= 'a' && ch <= 'z') ? (uint8_t)(ch - 32) : ch;
+          const bool dna = up == 'A' || up == 'C' || up == 'G' || up == 'T' || up == 'N';
+          if (dna) { const int bl = bam::ascii_to_lane(ch); if (bl != 255) acc.add(bl, uc, ue); }
+          else { non_dna++; if (ch != fch) mixed = true; }
+        }
+        bool need_full = false, bad_col = false;
+        if (non_dna == 0) {
+          CallConst KU;
+          KU.cap = TU->t.cap; KU.cap_threshold = TU->t.cap_threshold; KU.half_cerr_at_cap = TU->t.half_cerr_at_cap;
+          int bi; uint8_t q;
+          const bool resolved = column_call_fast_lds(TU->t, KU, acc.s, acc.obs, &bi, &q);
+          my_ch = bi >= 0 ? "ACGT"[bi] : 'N';
+          need_full = !resolved;
+        } else if (non_dna == seen && !mixed) my_ch = (char)fch;
+        else bad_col = true;
+        if (!mychar) { need_full = false; bad_col = false; }
+        if (__any(bad_col)) rx_fail = true;
+        push_full(need_full, (1ull << 63) | ((uint64_t)slot << 8) | lane, acc.s, acc.obs);
+      }
+    }
+  }
+  if (rx_fail || __any(list_overflow)) { to_defer(); return; }
+
+  // ---- 8C. descriptor ------------------------------------------------------------------------------------------------------------
+  {
+    CodecDesc* D = &P.cends[slot];
+    bool rx_empty = true;                                    // an all-empty consensus UMI is not written (:1740-1743)
+    if (rx_cnt && ulen) rx_empty = false;
+    if (lane < ulen && rx_cnt) D->rx[lane] = my_ch;
+    // cell barcode: first record, R1s then R2s, that carries a non-empty value (:1708-1722)
+    const unsigned long long cbm = __ballot(act && has_cb && cb_len > 0);
+    const unsigned long long c1 = cbm & r1set, c2 = cbm & r2set;
+    const bool any_cb = P.cell0 && (c1 | c2);
+    const uint32_t fc = c1 ? (uint32_t)__builtin_ctzll(c1) : c2 ? (uint32_t)__builtin_ctzll(c2) : 0;
+    const uint32_t fc_cb_lo = rlane(cb_lo, fc), fc_cb_len = rlane(cb_len, fc), fc_lo = rlane(lo, fc);
+    if (lane == 0) {
+      const uint32_t C = cons_len;
+      D->s1_off = col_base; D->s2_off = col_base + len1; D->l1 = len1; D->l2 = len2; D->cons_len = C;
+      D->first_rec = r0; D->cb_rec = r0 + fc;
+      D->mi_off = (uint16_t)(mi_lo - lo); D->mi_len = (uint8_t)mi_len;                 // lane 0 = record 0
+      D->has_cb = any_cb ? 1 : 0; D->cb_off = (uint16_t)(fc_cb_lo - fc_lo); D->cb_len = (uint8_t)fc_cb_len;
+      D->has_rx = rx_empty ? 0 : 1; D->rx_len = (uint8_t)ulen; D->flags = (uint8_t)((r1_neg ? 1 : 0) | (r2_neg ? 2 : 0));
+      const uint32_t nm = P.prefix_len + 1 + mi_len;
+      // every int tag holds a depth <= 128 (<= 64 records per wavefront): 4 bytes each
+      const uint32_t size = 32 + nm + 1 + (C + 1) / 2 + C + (3 + P.rg_len + 1) + (3 + mi_len + 1) + 3 * (4 + 4 + 7) +
+                            (P.per_base_tags ? 4 * (8 + 2 * C) + 4 * (3 + C + 1) : 0) + (any_cb ? 3 + fc_cb_len + 1 : 0) + (rx_empty ? 0 : 3 + ulen + 1);
+      D->rec_size = size;
+      D->valid = 1;
+      P.rec_sizes[slot] = (uint64_t)size + 4;
+    }
+  }
+  s_cons = 1;
   flush_stats();
   PH(8)
   }
@@ -2054,6 +2344,162 @@ __global__ __launch_bounds__(256) void k_emit_duplex(DuplexEmitParams P) {
   if (has_rx) z_tag('R', 'X', (const uint8_t*)D.rx, rx_len);
 }
 
+// -----------------------------------------------------------------------------------------------------
+// k_emit_codec — one wavefront per CODEC molecule: orient and pad the two single-strand consensi
+// (codec_caller.rs:955-968, 1272-1314), combine them position by position (:1331-1512), apply the quality
+// masks (:1526-1561), turn the result into R1's orientation and write the fragment record (:1590-1757):
+// tags RG MI cD cM cE aD aM aE bD bM bE [ad bd ae be ac bc aq bq] [CB] RX.
+// -----------------------------------------------------------------------------------------------------
+struct CCol { uint32_t b1, q1, d1, e1, b2, q2, d2, e2, ob, oq, oe; bool pad1, pad2, dup, dis; };   // bases as 4-bit codes; padN = lower-case 'n' padding
+
+__global__ __launch_bounds__(256) void k_emit_codec(CodecEmitParams P) {
+  const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(P.slot0 + ((blockIdx.x * blockDim.x + threadIdx.x) >> 6)));
+  const uint32_t lane = threadIdx.x & 63;
+  if (slot >= P.slot_end) return;
+  const CodecDesc& D = P.ends[slot];
+  if (!D.valid) return;
+  uint8_t* q = P.out + P.out_off[slot];
+  const uint32_t C = D.cons_len, l1 = D.l1, l2 = D.l2;
+  const uint64_t s1 = D.s1_off, s2 = D.s2_off;
+  const bool r1_neg = D.flags & 1, r2_neg = (D.flags & 2) != 0;
+  const uint8_t* first = P.blob + P.rec_off[D.first_rec];
+  const uint32_t mi_len = D.mi_len, mi_off = D.mi_off, name_len = P.prefix_len + 1 + mi_len;
+  const bool has_cb = D.has_cb != 0, has_rx = D.has_rx != 0;
+  const uint32_t cb_len = has_cb ? D.cb_len : 0, rx_len = has_rx ? D.rx_len : 0;
+  // Position f of the record (R1's orientation).  Both strands are brought to reference orientation (the reverse strand's
+  // consensus reverse-complemented), the negative-strand one right-aligned by padding on the left, combined, and the whole
+  // thing reverse-complemented again when R1 is the negative strand.
+  auto col = [&](uint32_t f) {
+    CCol c;
+    const uint32_t i = r1_neg ? C - 1 - f : f;
+    auto strand = [&](uint64_t off, uint32_t len, bool rc, bool pad_left, uint32_t& b, uint32_t& qq, uint32_t& d, uint32_t& e, bool& pad) {
+      const uint32_t shift = pad_left ? C - len : 0;
+      pad = i < shift || i - shift >= len;
+      b = 15; qq = 0; d = 0; e = 0;
+      if (!pad) {
+        const uint32_t j = i - shift, k = rc ? len - 1 - j : j;
+        b = P.col_code[off + k]; qq = P.col_qual[off + k]; d = P.col_depth[off + k]; e = P.col_err[off + k];
+        if (rc) b = comp_code((uint8_t)b);
+      }
+    };
+    strand(s1, l1, r1_neg, r1_neg, c.b1, c.q1, c.d1, c.e1, c.pad1);
+    strand(s2, l2, !r1_neg, r2_neg, c.b2, c.q2, c.d2, c.e2, c.pad2);
+    const bool ha = !c.pad1 && c.b1 != 15, hb = !c.pad2 && c.b2 != 15;
+    c.dup = ha && hb; c.dis = false;
+    uint32_t fb, fq, depth, err;
+    if (ha && hb) {
+      uint32_t rb, rq;
+      if (c.b1 == c.b2) { rb = c.b1; const uint32_t sm = c.q1 + c.q2; rq = sm < 93 ? sm : 93; }
+      else if (c.q1 > c.q2) { c.dis = true; rb = c.b1; rq = c.q1 - c.q2; if (rq < FGX_MIN_PHRED) rq = FGX_MIN_PHRED; }
+      else if (c.q2 > c.q1) { c.dis = true; rb = c.b2; rq = c.q2 - c.q1; if (rq < FGX_MIN_PHRED) rq = FGX_MIN_PHRED; }
+      else { c.dis = true; rb = c.b1; rq = FGX_MIN_PHRED; }
+      if (rq == FGX_MIN_PHRED) { fb = 15; fq = FGX_MIN_PHRED; } else { fb = rb; fq = rq; }
+      const uint32_t de = c.b1 == c.b2 ? c.e1 + c.e2 : c.b1 == rb ? c.e1 + (c.d2 > c.e2 ? c.d2 - c.e2 : 0) : c.e2 + (c.d1 > c.e1 ? c.d1 - c.e1 : 0);
+      err = de < 32767 ? de : 32767;
+      depth = c.d1 + c.d2;
+    } else if (ha) { if (c.q1 == FGX_MIN_PHRED) { fb = 15; fq = FGX_MIN_PHRED; } else { fb = c.b1; fq = c.q1; } depth = c.d1; err = c.e1; }
+    else if (hb) { if (c.q2 == FGX_MIN_PHRED) { fb = 15; fq = FGX_MIN_PHRED; } else { fb = c.b2; fq = c.q2; } depth = c.d2; err = c.e2; }
+    else { fb = 15; fq = FGX_MIN_PHRED; depth = 0; const uint32_t de = c.e1 + c.e2; err = de < 32767 ? de : 32767; }
+    if ((!c.pad1 && c.b1 == 15) || (!c.pad2 && c.b2 == 15)) { fb = 15; fq = FGX_MIN_PHRED; }     // an upper-case N on either strand
+    // quality masks, on the reference-orientation index: outer bases first, then single-strand stretches
+    if (P.has_outer && P.outer_len > 0 && (i < P.outer_len || C - 1 - i < P.outer_len)) fq = P.outer_qual;
+    if (P.has_ss && (!ha || !hb)) fq = P.ss_qual;
+    (void)depth;
+    c.ob = r1_neg ? (uint32_t)comp_code((uint8_t)fb) : fb; c.oq = fq; c.oe = err;
+    if (r1_neg) { c.b1 = comp_code((uint8_t)c.b1); c.b2 = comp_code((uint8_t)c.b2); }
+    return c;
+  };
+  // ---- reductions: cD cM cE / aD aM aE / bD bM bE, and the duplex counters -----------------------------------------------------
+  uint32_t amax = 0, amin = 0xFFFFFFFFu, asd = 0, ase = 0, bmax = 0, bmin = 0xFFFFFFFFu, bsd = 0, bse = 0, cmax = 0, cmin = 0xFFFFFFFFu, csd = 0, cse = 0;
+  uint32_t n_dup = 0, n_dis = 0;
+  for (uint32_t f = lane; f < C; f += 64) {
+    const CCol c = col(f);
+    amax = c.d1 > amax ? c.d1 : amax; amin = c.d1 < amin ? c.d1 : amin; asd += c.d1; ase += c.e1;
+    bmax = c.d2 > bmax ? c.d2 : bmax; bmin = c.d2 < bmin ? c.d2 : bmin; bsd += c.d2; bse += c.e2;
+    const uint32_t t = c.d1 + c.d2;
+    cmax = t > cmax ? t : cmax; cmin = t < cmin ? t : cmin; csd += t; cse += c.oe;
+    n_dup += c.dup ? 1 : 0; n_dis += c.dis ? 1 : 0;
+  }
+  amax = wave_max(amax); amin = wave_min(amin); asd = wave_sum(asd); ase = wave_sum(ase);
+  bmax = wave_max(bmax); bmin = wave_min(bmin); bsd = wave_sum(bsd); bse = wave_sum(bse);
+  cmax = wave_max(cmax); cmin = wave_min(cmin); csd = wave_sum(csd); cse = wave_sum(cse);
+  n_dup = wave_sum(n_dup); n_dis = wave_sum(n_dis);
+  if (C == 0) { amin = 0; bmin = 0; cmin = 0; }
+  if (lane == 0) {
+    unsigned long long* st = P.stats + (size_t)(blockIdx.x & (STAT_SLOTS - 1)) * 32;
+    atomicAdd(&st[24], (unsigned long long)C);
+    if (n_dup) atomicAdd(&st[25], (unsigned long long)n_dup);
+    if (n_dis) atomicAdd(&st[26], (unsigned long long)n_dis);
+  }
+  const float a_rate = asd ? (float)ase / (float)asd : 0.0f, b_rate = bsd ? (float)bse / (float)bsd : 0.0f, c_rate = csd ? (float)cse / (float)csd : 0.0f;
+
+  // ---- block_size + core (flag: unmapped fragment), name, bases, quals -------------------------------------------------------------
+  if (lane < 36) {
+    const uint32_t dw = lane >> 2;
+    const uint32_t v = dw == 0 ? D.rec_size : dw == 3 ? ((name_len + 1) | (4680u << 16)) : dw == 4 ? ((uint32_t)bam::F_UNMAPPED << 16) : dw == 5 ? C : dw == 8 ? 0u : 0xFFFFFFFFu;
+    q[lane] = (uint8_t)(v >> (8 * (lane & 3)));
+  }
+  q += 36;
+  for (uint32_t i = lane; i < name_len + 1; i += 64)
+    q[i] = i < P.prefix_len ? (uint8_t)P.prefix[i] : i == P.prefix_len ? (uint8_t)':' : i < name_len ? first[mi_off + (i - P.prefix_len - 1)] : (uint8_t)0;
+  q += name_len + 1;
+  for (uint32_t i = lane; i < (C + 1) / 2; i += 64) {
+    const uint32_t hi = col(2 * i).ob, lo = 2 * i + 1 < C ? col(2 * i + 1).ob : 0u;
+    q[i] = (uint8_t)((hi << 4) | lo);
+  }
+  q += (C + 1) / 2;
+  for (uint32_t i = lane; i < C; i += 64) q[i] = (uint8_t)col(i).oq;
+  q += C;
+  // ---- tags ----------------------------------------------------------------------------------------------------------------------------
+  auto z_tag = [&](char t0, char t1, const uint8_t* src, uint32_t n) {
+    for (uint32_t i = lane; i < 3 + n + 1; i += 64) q[i] = i == 0 ? (uint8_t)t0 : i == 1 ? (uint8_t)t1 : i == 2 ? (uint8_t)'Z' : i - 3 < n ? src[i - 3] : (uint8_t)0;
+    q += 3 + n + 1;
+  };
+  auto scalar_tags = [&](char s, uint32_t dmax, uint32_t dmin, float rate) {   // <s>D int, <s>M int, <s>E float: 4 + 4 + 7 bytes
+    if (lane < 15) {
+      uint8_t v;
+      if (lane < 4) v = int_tag_byte(lane, s, 'D', dmax);
+      else if (lane < 8) v = int_tag_byte(lane - 4, s, 'M', dmin);
+      else { const uint32_t j = lane - 8, u = __float_as_uint(rate); v = j == 0 ? (uint8_t)s : j == 1 ? (uint8_t)'E' : j == 2 ? (uint8_t)'f' : (uint8_t)(u >> (8 * (j - 3))); }
+      q[lane] = v;
+    }
+    q += 15;
+  };
+  z_tag('R', 'G', (const uint8_t*)P.rg, P.rg_len);
+  z_tag('M', 'I', first + mi_off, mi_len);
+  scalar_tags('c', cmax, cmin, c_rate);
+  scalar_tags('a', amax, amin, a_rate);
+  scalar_tags('b', bmax, bmin, b_rate);
+  if (P.per_base_tags) {
+    for (int arr = 0; arr < 4; arr++) {        // ad bd ae be
+      const char t0 = (arr & 1) ? 'b' : 'a', t1 = arr < 2 ? 'd' : 'e';
+      for (uint32_t i = lane; i < 8 + 2 * C; i += 64) {
+        uint8_t v;
+        if (i < 8) v = i == 0 ? (uint8_t)t0 : i == 1 ? (uint8_t)t1 : i == 2 ? (uint8_t)'B' : i == 3 ? (uint8_t)'s' : (uint8_t)(C >> (8 * (i - 4)));
+        else { const uint32_t k = i - 8; const CCol c = col(k >> 1); const uint32_t w = arr == 0 ? c.d1 : arr == 1 ? c.d2 : arr == 2 ? c.e1 : c.e2; v = (k & 1) ? (uint8_t)(w >> 8) : (uint8_t)w; }
+        q[i] = v;
+      }
+      q += 8 + 2 * C;
+    }
+    for (int str = 0; str < 4; str++) {        // ac bc aq bq
+      const char t0 = (str & 1) ? 'b' : 'a', t1 = str < 2 ? 'c' : 'q';
+      for (uint32_t i = lane; i < 3 + C + 1; i += 64) {
+        uint8_t v = i == 0 ? (uint8_t)t0 : i == 1 ? (uint8_t)t1 : i == 2 ? (uint8_t)'Z' : (uint8_t)0;
+        if (i >= 3 && i - 3 < C) {
+          const CCol c = col(i - 3);
+          const bool pd = (str & 1) ? c.pad2 : c.pad1;
+          if (str < 2) v = pd ? (uint8_t)'n' : bam::code_to_ascii((uint8_t)((str & 1) ? c.b2 : c.b1));
+          else { const uint32_t qq = ((str & 1) ? c.q2 : c.q1) + 33; v = (uint8_t)(qq > 255 ? 255 : qq); }
+        }
+        q[i] = v;
+      }
+      q += 3 + C + 1;
+    }
+  }
+  if (has_cb) z_tag(P.cell0, P.cell1, P.blob + P.rec_off[D.cb_rec] + D.cb_off, cb_len);
+  if (has_rx) z_tag('R', 'X', (const uint8_t*)D.rx, rx_len);
+}
+
 // Upper bound on the consensus columns a batch can produce: a family yields at most three ends, each no
 // longer than its longest read, and l_seq <= (block_size - 33) * 2 / 3.
 __global__ void k_col_bound(const uint32_t* __restrict__ grp_first, const uint32_t* __restrict__ rec_len, uint32_t n_grp,
@@ -2090,12 +2536,12 @@ void FastPath::release() {
 int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const uint64_t* d_rec_off, const uint32_t* d_rec_len,
                   uint32_t n_rec, const uint32_t* d_grp_first, uint32_t n_grp, FastResult* res) {
   const fgx_options& o = c->opt;
-  const bool duplex = o.caller_kind == FGX_CALLER_DUPLEX;
+  const bool duplex = o.caller_kind == FGX_CALLER_DUPLEX, codec = o.caller_kind == FGX_CALLER_CODEC;
   hipStream_t s = c->stream;
   memset(res, 0, sizeof(*res));
   if (n_grp == 0) return 0;
   const uint32_t n_slots = 3 * n_grp;   // simplex: Fragment, R1, R2 of each family; duplex: slot 0 unused, R1, R2
-  d_ends.reserve((size_t)n_slots * (duplex ? sizeof(DuplexDesc) : sizeof(EndDesc)));
+  d_ends.reserve((size_t)n_slots * (duplex ? sizeof(DuplexDesc) : codec ? sizeof(CodecDesc) : sizeof(EndDesc)));
   d_sizes.reserve((size_t)n_slots * 8);
   d_offsets.reserve((size_t)n_slots * 8);
   d_deferred.reserve((size_t)n_grp * 4);
@@ -2113,7 +2559,7 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
   d_bound.reserve((size_t)n_grp * 8); d_colbase.reserve((size_t)n_grp * 8);
   d_statslots.reserve((size_t)STAT_SLOTS * 32 * 8);
   hip_check(hipMemsetAsync(d_statslots.p, 0, (size_t)STAT_SLOTS * 32 * 8, s), "memset");
-  hipLaunchKernelGGL(k_col_bound, dim3((n_grp + 255) / 256), dim3(256), 0, s, d_grp_first, d_rec_len, n_grp, d_bound.as<uint64_t>(), duplex ? 4u : 3u);
+  hipLaunchKernelGGL(k_col_bound, dim3((n_grp + 255) / 256), dim3(256), 0, s, d_grp_first, d_rec_len, n_grp, d_bound.as<uint64_t>(), duplex ? 4u : codec ? 2u : 3u);
   {
     size_t tb = 0;
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_bound.as<uint64_t>(), d_colbase.as<uint64_t>(), (int)n_grp, s);
@@ -2141,8 +2587,13 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
     P.dmax_reads = o.duplex_max_reads_per_strand;
     P.col_obs = d_obs.as<uint32_t>(); P.dends = d_ends.as<DuplexDesc>();
   }
+  if (codec) {    // single-strand caller of the CODEC caller (codec_caller.rs:374-397): min_reads 1, no cap, min consensus base quality 0
+    P.min_reads = 1; P.max_reads = -1; P.min_cons_bq = 0; P.trim = 0; P.overlap = 0;
+    P.cends = d_ends.as<CodecDesc>(); P.cmin_reads = o.codec_min_reads_per_strand; P.cmax_reads = o.codec_max_reads_per_strand;
+    P.cmin_duplex_len = o.codec_min_duplex_length;
+  }
   P.trim = o.trim; P.overlap = o.overlapping_consensus; P.per_base_tags = o.produce_per_base_tags; P.track_rejects = o.track_rejects;
-  P.tag0 = duplex ? 'M' : o.tag[0]; P.tag1 = duplex ? 'I' : o.tag[1]; P.cell0 = o.cell_tag[0]; P.cell1 = o.cell_tag[1];
+  P.tag0 = (duplex || codec) ? 'M' : o.tag[0]; P.tag1 = (duplex || codec) ? 'I' : o.tag[1]; P.cell0 = o.cell_tag[0]; P.cell1 = o.cell_tag[1];
   P.prefix_len = (uint32_t)c->prefix.size(); P.rg_len = (uint32_t)c->rg.size();
   P.ends = d_ends.as<EndDesc>(); P.rec_sizes = d_sizes.as<uint64_t>();
   P.col_code = d_code.as<uint8_t>(); P.col_qual = d_qual.as<uint8_t>(); P.col_depth = d_depth.as<uint16_t>(); P.col_err = d_err.as<uint16_t>();
@@ -2165,10 +2616,11 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
 
   hip_check(hipEventRecord(c->ev0, s), "event");
   hip_check(hipEventRecord(ev[0], s), "event");
-  if (duplex) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_family_wave<1>), dim3((n_grp + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(256), WAVES_PER_BLOCK * wave_bytes, s, P, n_grp);
+  if (codec) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_family_wave<2>), dim3((n_grp + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(256), WAVES_PER_BLOCK * wave_bytes, s, P, n_grp);
+  else if (duplex) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_family_wave<1>), dim3((n_grp + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(256), WAVES_PER_BLOCK * wave_bytes, s, P, n_grp);
   else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_family_wave<0>), dim3((n_grp + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(256), WAVES_PER_BLOCK * wave_bytes, s, P, n_grp);
   hip_check(hipGetLastError(), "k_family_wave launch");
-  if (!duplex) {   // families that do not fit a wave (more than 64 records / more bytes than the LDS slice): one workgroup each
+  if (!duplex && !codec) {   // families that do not fit a wave (more than 64 records / more bytes than the LDS slice): one workgroup each
     uint32_t n_retry = 0;
     hip_check(hipMemcpyAsync(&n_retry, P.n_retry, 4, hipMemcpyDeviceToHost, s), "D2H");
     hip_check(hipStreamSynchronize(s), "sync");
@@ -2193,13 +2645,13 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
       F.T = P.T; F.TU = P.TU; F.min_reads = P.min_reads; F.min_cons_bq = P.min_cons_bq;
       F.col_code = P.col_code; F.col_qual = P.col_qual; F.col_err = P.col_err;
       if (duplex) { F.rx_base = (char*)P.dends + offsetof(DuplexDesc, rx); F.rx_stride = sizeof(DuplexDesc); }
+      else if (codec) { F.rx_base = (char*)P.cends + offsetof(CodecDesc, rx); F.rx_stride = sizeof(CodecDesc); }
       else { F.rx_base = (char*)P.ends + offsetof(EndDesc, rx); F.rx_stride = sizeof(EndDesc); }
       hipLaunchKernelGGL(k_call_full, dim3((mx + 255) / 256, N_LISTS), dim3(256), 0, s, F);
       hip_check(hipGetLastError(), "k_call_full launch");
     }
   }
   hip_check(hipEventRecord(ev[1], s), "event");
-  hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(64), 0, s, d_statslots.as<unsigned long long>(), misc);
 
   size_t tmp_bytes = 0;
   (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_sizes.as<uint64_t>(), d_offsets.as<uint64_t>(), (int)n_slots, s);
@@ -2210,8 +2662,6 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
   uint64_t last[2];
   hip_check(hipMemcpyAsync(&last[0], d_offsets.as<uint64_t>() + (n_slots - 1), 8, hipMemcpyDeviceToHost, s), "D2H");
   hip_check(hipMemcpyAsync(&last[1], d_sizes.as<uint64_t>() + (n_slots - 1), 8, hipMemcpyDeviceToHost, s), "D2H");
-  unsigned long long h_misc[32];
-  hip_check(hipMemcpyAsync(h_misc, misc, sizeof(h_misc), hipMemcpyDeviceToHost, s), "D2H");
   hip_check(hipStreamSynchronize(s), "sync");
   uint64_t out_len = last[0] + last[1];
   d_out.reserve(out_len + 16);
@@ -2224,7 +2674,19 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
   E.prefix = d_strings.as<char>(); E.prefix_len = P.prefix_len; E.rg = d_strings.as<char>() + P.prefix_len; E.rg_len = P.rg_len;
   E.per_base_tags = P.per_base_tags; E.tag0 = P.tag0; E.tag1 = P.tag1; E.cell0 = P.cell0; E.cell1 = P.cell1;
   hip_check(hipEventRecord(ev[2], s), "event");
-  if (duplex) {
+  if (codec) {
+    CodecEmitParams CE;
+    memset(&CE, 0, sizeof(CE));
+    CE.blob = d_blob; CE.rec_off = d_rec_off; CE.ends = d_ends.as<CodecDesc>(); CE.out_off = d_offsets.as<uint64_t>(); CE.out = d_out.as<uint8_t>();
+    CE.slot0 = 0; CE.slot_end = n_slots;
+    CE.col_code = P.col_code; CE.col_qual = P.col_qual; CE.col_depth = P.col_depth; CE.col_err = P.col_err;
+    CE.prefix = E.prefix; CE.prefix_len = E.prefix_len; CE.rg = E.rg; CE.rg_len = E.rg_len;
+    CE.per_base_tags = P.per_base_tags; CE.cell0 = P.cell0; CE.cell1 = P.cell1;
+    CE.has_outer = o.codec_has_outer_bases_qual; CE.outer_qual = o.codec_outer_bases_qual; CE.outer_len = o.codec_outer_bases_length;
+    CE.has_ss = o.codec_has_single_strand_qual; CE.ss_qual = o.codec_single_strand_qual;
+    CE.stats = d_statslots.as<unsigned long long>();
+    hipLaunchKernelGGL(k_emit_codec, dim3((n_slots + 3) / 4), dim3(256), 0, s, CE);
+  } else if (duplex) {
     DuplexEmitParams DE;
     memset(&DE, 0, sizeof(DE));
     DE.blob = d_blob; DE.rec_off = d_rec_off; DE.ends = d_ends.as<DuplexDesc>(); DE.out_off = d_offsets.as<uint64_t>(); DE.out = d_out.as<uint8_t>();
@@ -2237,6 +2699,9 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
   hip_check(hipGetLastError(), "k_emit launch");
   hip_check(hipEventRecord(ev[3], s), "event");
   hip_check(hipEventRecord(c->ev1, s), "event");
+  hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(64), 0, s, d_statslots.as<unsigned long long>(), misc);
+  unsigned long long h_misc[32];
+  hip_check(hipMemcpyAsync(h_misc, misc, sizeof(h_misc), hipMemcpyDeviceToHost, s), "D2H");
   hip_check(hipStreamSynchronize(s), "sync");
   float ms = 0;
   hip_check(hipEventElapsedTime(&ms, c->ev0, c->ev1), "elapsed");

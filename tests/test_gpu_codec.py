@@ -11,6 +11,18 @@ import test_oracle_codec as toc
 
 pytestmark = pytest.mark.gpu
 
+GENERAL_ONLY = False
+
+
+@pytest.fixture(autouse=True, params=["device", "general"])
+def path_mode(request):
+    """Every case runs through the device-resident CODEC pipeline (deferred molecules fall back to the general path) and
+    through the general host-orchestrated path alone."""
+    global GENERAL_ONLY
+    GENERAL_ONLY = request.param == "general"
+    yield
+    GENERAL_ONLY = False
+
 
 def _same(g, track_rejects=False, prefix="codec", rg="A", **kw):
     v = CodecConsensusOptions(**kw)
@@ -26,6 +38,7 @@ def _same(g, track_rejects=False, prefix="codec", rg="A", **kw):
     o = fgx_opts.defaults(kind=2, **okw)
     want = orc.process(o, g.blob, g.rec_off, g.rec_len, g.grp_first, batch_groups=max(1, g.n_grp))
     c = CodecConsensusCaller(prefix, rg, v, track_rejects=track_rejects)
+    c.set_general_only(GENERAL_ONLY)
     out = c.process_batch(g)
     st = c.last_batch_statistics()
     cst = c.codec_statistics()
@@ -103,3 +116,34 @@ def test_codec_simulated_config5_shape(codec):
 def test_codec_simulated_150bp_and_counter_names():
     g = simulate_grouped_reads(800, family_size=2, read_length=150, insert_mean=200, insert_sd=30, codec=1)
     _same(g, max_reads_per_strand=1, min_duplex_length=30, track_rejects=True)
+
+
+def test_codec_device_resident_matches_oracle():
+    """Inputs generated in HBM, outputs left in HBM: nothing deferred on simulate-shaped molecules, bytes and the CODEC
+    counters equal the oracle's."""
+    if GENERAL_ONLY:
+        pytest.skip("device-resident entry only")
+    for kw, opt in ((dict(n_families=3000, family_size=4, read_length=300, insert_mean=350, insert_sd=60, codec=1), dict(produce_per_base_tags=True)),
+                    (dict(n_families=2000, family_size=1, read_length=150, insert_mean=200, insert_sd=40, codec=1), dict(cell_tag="CB")),
+                    (dict(n_families=2000, family_size=6, read_length=150, insert_mean=220, insert_sd=60, codec=0, error_rate_ppm=20000),
+                     dict(min_reads_per_strand=2, min_duplex_length=40, single_strand_qual=7, outer_bases_qual=9, outer_bases_length=4))):
+        v = CodecConsensusOptions(**opt)
+        c = CodecConsensusCaller("codec", "A", v)
+        dg = c.simulate_on_device(**kw)
+        out = c.process_batch_device(dg)
+        data = out.to_host()
+        st = c.codec_statistics()
+        g = simulate_grouped_reads(kw["n_families"], **{k: x for k, x in kw.items() if k != "n_families"})
+        o = fgx_opts.defaults(kind=2, read_name_prefix=b"codec", overlapping_consensus=0, cell_tag=(v.cell_tag.encode() if v.cell_tag else b"\0\0"),
+                              produce_per_base_tags=int(v.produce_per_base_tags), codec_min_reads_per_strand=v.min_reads_per_strand,
+                              codec_min_duplex_length=v.min_duplex_length, codec_has_single_strand_qual=int(v.single_strand_qual is not None),
+                              codec_single_strand_qual=v.single_strand_qual or 0, codec_has_outer_bases_qual=int(v.outer_bases_qual is not None),
+                              codec_outer_bases_qual=v.outer_bases_qual or 0, codec_outer_bases_length=v.outer_bases_length)
+        want = orc.process(o, g.blob, g.rec_off, g.rec_len, g.grp_first, batch_groups=g.n_grp)
+        assert out.n_deferred == 0
+        assert out.count == want["count"] and data == want["data"]
+        got = [st.total_input_reads, st.consensus_reads_generated, st.reads_filtered, st.consensus_bases_emitted, st.consensus_duplex_bases_emitted,
+               st.duplex_disagreement_base_count, st.consensus_reads_rejected_hdd]
+        ws = want["stats"]
+        assert got == [int(ws[0]), int(ws[1]), int(ws[2]), int(ws[24]), int(ws[25]), int(ws[26]), int(ws[27])]
+        c.close()
