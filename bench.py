@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(n_families, family_size, read_length, threads, duplex=False):
+def cpu_baseline(n_families, family_size, read_length, threads, duplex=False, codec=False):
     """Bounded sample of the same workload through the ORACLE (C++ restatement of the reference CPU
     caller; `--threads`-style batches of 50 MI groups, one caller object per batch) on this box's
     host cores.  A reported baseline, not the optimisation target."""
@@ -31,19 +31,22 @@ def cpu_baseline(n_families, family_size, read_length, threads, duplex=False):
     import fgx_opts
     import orc
     from fgumi_amd import simulate_grouped_reads
-    g = simulate_grouped_reads(n_families, family_size=family_size, read_length=read_length, duplex=int(duplex))
-    o = fgx_opts.defaults(min_reads=1, kind=1 if duplex else 0)
+    extra = dict(insert_mean=350, insert_sd=60, codec=1) if codec else {}
+    g = simulate_grouped_reads(n_families, family_size=family_size, read_length=read_length, duplex=int(duplex), **extra)
+    o = fgx_opts.defaults(min_reads=1, kind=2 if codec else 1 if duplex else 0)
+    if codec:
+        o.overlapping_consensus = 0
     if duplex:
         o.duplex_min_reads[0], o.duplex_min_reads[1], o.duplex_min_reads[2] = 1, 1, 1
     best, res = None, None
     for _ in range(3):
         t0 = time.perf_counter()
-        res = orc.process(o, g.blob, g.rec_off, g.rec_len, g.grp_first, batch_groups=100 if duplex else 50, threads=threads)
+        res = orc.process(o, g.blob, g.rec_off, g.rec_len, g.grp_first, batch_groups=1000 if codec else 100 if duplex else 50, threads=threads)
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
     return dict(value=g.n_rec / best, unit="raw reads/s", cores=threads, kind="port",
-                sample=f"{n_families} families x {family_size} pairs x {read_length}bp{' (--duplex)' if duplex else ''}, compute-only (records in RAM → "
-                       f"ConsensusOutput bytes), batches of {100 if duplex else 50} MI groups over {threads} threads, best of 3",
+                sample=f"{n_families} families x {family_size} pairs x {read_length}bp{' (--duplex)' if duplex else ' (CODEC pairs, insert N(350,60))' if codec else ''}, compute-only (records in RAM → "
+                       f"ConsensusOutput bytes), batches of {1000 if codec else 100 if duplex else 50} MI groups over {threads} threads, best of 3",
                 consensus_reads_per_s=res["count"] / best)
 
 
@@ -72,19 +75,22 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--caller", choices=["simplex", "duplex"], default="simplex",
-                    help="simplex = BASELINE configs[1] (the headline metric); duplex = configs[2] shape (2M molecules, 6+6 pairs)")
+    ap.add_argument("--caller", choices=["simplex", "duplex", "codec"], default="simplex",
+                    help="simplex = BASELINE configs[1] (the headline metric); duplex = configs[2] shape (2M molecules, 6+6 pairs); "
+                         "codec = configs[4] shape (1M molecules, 4 pairs of 2x300bp)")
     ap.add_argument("--families", type=int, default=None)
     ap.add_argument("--depth", type=int, default=None)
-    ap.add_argument("--read-length", type=int, default=150)
+    ap.add_argument("--read-length", type=int, default=None)
     ap.add_argument("--cpu-sample-families", type=int, default=300000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
-    duplex = args.caller == "duplex"
+    duplex, codec = args.caller == "duplex", args.caller == "codec"
     if args.families is None:
-        args.families = int(os.environ.get("FGX_BENCH_FAMILIES", "2000000" if duplex else "5000000"))
+        args.families = int(os.environ.get("FGX_BENCH_FAMILIES", "1000000" if codec else "2000000" if duplex else "5000000"))
     if args.depth is None:
-        args.depth = 12 if duplex else 8
+        args.depth = 4 if codec else 12 if duplex else 8
+    if args.read_length is None:
+        args.read_length = 300 if codec else 150
 
     import torch
     import torch.distributed as dist
@@ -96,16 +102,21 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl")
 
-    from fgumi_amd import DuplexConsensusCaller, VanillaUmiConsensusCaller, VanillaUmiConsensusOptions
+    from fgumi_amd import (CodecConsensusCaller, CodecConsensusOptions, DuplexConsensusCaller, VanillaUmiConsensusCaller,
+                           VanillaUmiConsensusOptions)
 
     fam = args.families
-    if duplex:
+    sim_extra = {}
+    if codec:
+        caller = CodecConsensusCaller("", "A", CodecConsensusOptions(produce_per_base_tags=True, cell_tag="CB"), device=local_rank)
+        sim_extra = dict(insert_mean=350, insert_sd=60, codec=1)
+    elif duplex:
         caller = DuplexConsensusCaller("", "A", [1], cell_tag="CB", overlapping_consensus=True, device=local_rank)
     else:
         caller = VanillaUmiConsensusCaller("", "A", VanillaUmiConsensusOptions(min_reads=1, min_consensus_base_quality=2, cell_tag="CB"),
                                            overlapping_consensus=True, device=local_rank)
     # synthetic families generated straight into HBM; rank r owns molecules [r*fam, (r+1)*fam)
-    dg = caller.simulate_on_device(fam, family_size=args.depth, read_length=args.read_length, first_family=rank * fam, duplex=int(duplex))
+    dg = caller.simulate_on_device(fam, family_size=args.depth, read_length=args.read_length, first_family=rank * fam, duplex=int(duplex), **sim_extra)
 
     def barrier():
         if world > 1:
@@ -136,29 +147,32 @@ def main():
         # algorithmic bytes of ONE k_family launch on ONE GPU: per raw read ceil(L/2)+L read,
         # per consensus read 6*Lc written (bases, quals, depth i16, errors i16)
         alg_read = dg.n_rec * ((L + 1) // 2 + L)
-        alg_write = out.count * 6 * L * (2 if duplex else 1)     # duplex: each record is built from two single-strand column sets
+        # duplex / CODEC: each record is built from two single-strand column sets (CODEC strands are about one read long)
+        alg_write = out.count * 6 * L * (2 if (duplex or codec) else 1)
         k_avg_s = k_family_ms / steps / 1e3
         achieved = (alg_read + alg_write) / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
         line = {
-            "metric": ("duplex consensus throughput, input raw reads/s (depth 6+6 x 150bp)" if duplex
+            "metric": ("CODEC consensus throughput, input raw reads/s (4 pairs x 2x300bp)" if codec
+                       else "duplex consensus throughput, input raw reads/s (depth 6+6 x 150bp)" if duplex
                        else "simplex consensus throughput, input raw reads/s (depth-8 x 150bp)"),
             "value": total_raw * steps / dt, "unit": "raw reads/s",
             "consensus_reads_per_s": total_cons * steps / dt,
             "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": (f"duplex consensus, {fam} molecules per GPU, {args.depth} pairs split over /A and /B, {L}bp paired (BASELINE configs[2] shape), "
+            "config": {"workload": (f"CODEC consensus, {fam} molecules per GPU, {args.depth} pairs of 2x{L}bp, insert N(350,60) (BASELINE configs[4] shape), " if codec else
+                                    f"duplex consensus, {fam} molecules per GPU, {args.depth} pairs split over /A and /B, {L}bp paired (BASELINE configs[2] shape), "
                                     if duplex else f"simplex consensus, {fam} families per GPU, depth={args.depth} pairs, {L}bp paired (BASELINE configs[1] shape), ")
                                    + "device-resident: raw BAM records in HBM -> consensus BAM records in HBM",
                        "min_reads": 1, "overlapping_consensus": True, "families_per_gpu": fam, "raw_reads_per_gpu": dg.n_rec,
                        "deferred_families": total_def, "output_bytes": total_bytes,
                        "columns_needing_call_full_per_step": caller.last_timing.get("full_columns")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None if duplex else pmc_traffic(fam, args.depth, L), "kernel": "k_family", "kernel_ms": k_family_ms / steps, "k_emit_ms": k_emit_ms / steps,
+                         "traffic": None if (duplex or codec) else pmc_traffic(fam, args.depth, L), "kernel": "k_family", "kernel_ms": k_family_ms / steps, "k_emit_ms": k_emit_ms / steps,
                          "device_ms_per_step": k_total_ms / steps, "algorithmic_bytes_per_launch": alg_read + alg_write,
                          "read_only_GBs": alg_read / k_avg_s / 1e9 if k_avg_s > 0 else 0.0},
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(min(fam, args.cpu_sample_families), args.depth, L, os.cpu_count() or 1, duplex)
+            line["cpu_baseline"] = cpu_baseline(min(fam, args.cpu_sample_families), args.depth, L, os.cpu_count() or 1, duplex, codec)
         print(json.dumps(line))
     if rank == 0:   # profiling builds (-DFGX_PHASE_TIMING=1) expose per-phase cycle totals of k_family_wave
         import ctypes
