@@ -49,10 +49,10 @@ def test_reference_pins_file_is_consistent():
 def test_hip_paths_reproduce_golden(name, general_only):
     import ctypes as C
     from fgumi_amd import lib
-    from fgumi_amd._lib import Output
+    from fgumi_amd._lib import Options, Output
     g, data, count, stats = _load(name)
     o, _ = _options(name)
-    h = lib.fgx_create(C.byref(o))
+    h = lib.fgx_create(C.cast(C.pointer(o), C.POINTER(Options)))     # tests/fgx_opts.Options has the same layout
     assert h, lib.fgx_global_error()
     lib.fgx_set_general_only(h, int(general_only))
     out = Output()
