@@ -2220,6 +2220,19 @@ __global__ __launch_bounds__(256) void k_emit(EmitParams P) {
 // (duplex_caller.rs:931-1108) over the two single-strand column segments, then the record of duplex_read_into
 // (:1118-1405): tags MI [CB] RG aD aE aM [ac ad ae aq] bD bE bM [bc bd be bq] cD cE cM RX.
 // -----------------------------------------------------------------------------------------------------
+// records the fast writers (k_emit_duplex_fast / k_emit_codec_fast, below) take; the per-field kernels skip them
+constexpr uint32_t DUP_SLOTS = 2;     // duplex: up to 256 positions
+
+__device__ __forceinline__ bool small_tags(uint32_t name_len, uint32_t mi_len, uint32_t cb_len, uint32_t rg_len, uint32_t rx_len) {
+  return name_len + 1 <= 64 && mi_len + 4 <= 64 && cb_len + 4 <= 64 && rg_len + 4 <= 64 && rx_len + 4 <= 64;
+}
+__device__ __forceinline__ bool duplex_fast_ok(const DuplexDesc& D, uint32_t prefix_len, uint32_t rg_len) {
+  return D.len <= 128 * DUP_SLOTS && small_tags(prefix_len + 1 + D.mi_len, D.mi_len, D.has_cb ? D.cb_len : 0, rg_len, D.has_rx ? D.rx_len : 0);
+}
+__device__ __forceinline__ bool codec_fast_ok(const CodecDesc& D, uint32_t prefix_len, uint32_t rg_len) {
+  return small_tags(prefix_len + 1 + D.mi_len, D.mi_len, D.has_cb ? D.cb_len : 0, rg_len, D.has_rx ? D.rx_len : 0);     // any length: written in windows of 256 positions
+}
+
 struct DCol { uint32_t ca, qa, ea, da, cb, qb, eb, db, oc, oq, oe; };
 __device__ __forceinline__ uint32_t obs_sum(uint32_t o) { return (o & 0xFF) + ((o >> 8) & 0xFF) + ((o >> 16) & 0xFF) + (o >> 24); }
 __device__ __forceinline__ uint32_t obs_of_code(uint32_t o, uint32_t code) {   // count of the base with 4-bit code 1/2/4/8
@@ -2232,7 +2245,7 @@ __global__ __launch_bounds__(256) void k_emit_duplex(DuplexEmitParams P) {
   const uint32_t lane = threadIdx.x & 63;
   if (slot >= P.slot_end) return;
   const DuplexDesc& D = P.ends[slot];
-  if (!D.valid) return;
+  if (!D.valid || duplex_fast_ok(D, P.prefix_len, P.rg_len)) return;     // k_emit_duplex_fast writes those
   uint8_t* q = P.out + P.out_off[slot];
   const uint32_t L = D.len;
   const bool has_ba = D.has_ba != 0;
@@ -2357,7 +2370,7 @@ __global__ __launch_bounds__(256) void k_emit_codec(CodecEmitParams P) {
   const uint32_t lane = threadIdx.x & 63;
   if (slot >= P.slot_end) return;
   const CodecDesc& D = P.ends[slot];
-  if (!D.valid) return;
+  if (!D.valid || codec_fast_ok(D, P.prefix_len, P.rg_len)) return;      // k_emit_codec_fast writes those
   uint8_t* q = P.out + P.out_off[slot];
   const uint32_t C = D.cons_len, l1 = D.l1, l2 = D.l2;
   const uint64_t s1 = D.s1_off, s2 = D.s2_off;
@@ -2498,6 +2511,315 @@ __global__ __launch_bounds__(256) void k_emit_codec(CodecEmitParams P) {
   }
   if (has_cb) z_tag(P.cell0, P.cell1, P.blob + P.rec_off[D.cb_rec] + D.cb_off, cb_len);
   if (has_rx) z_tag('R', 'X', (const uint8_t*)D.rx, rx_len);
+}
+
+// -----------------------------------------------------------------------------------------------------
+// Fast record writers for duplex and CODEC.  The per-field writers above wait on a memory round trip for every
+// 64 bytes they produce and re-evaluate the strand combine for every field; here each lane owns PAIRS of
+// positions (2·lane, 2·lane+1, then +128 per slot), loads all of them in one sweep, evaluates the combine once
+// per position into three packed registers, and then only stores: a string field is two byte stores per slot, an
+// int16 array four, packed bases one — no cross-lane traffic, no waits.  Records that do not fit the register
+// budget (or have unusually long names / tags) are left to the per-field kernels, which skip what is done here.
+// -----------------------------------------------------------------------------------------------------
+// shared field writers (q advances; every lane calls them)
+struct FieldWriter {
+  uint8_t* q; uint32_t lane;
+  // one store: bytes [0, n) with n <= 64, byte i = f(i)
+  template <class F> __device__ __forceinline__ void small(uint32_t n, F f) { if (lane < n) q[lane] = f(lane); q += n; }
+  __device__ __forceinline__ void z_small(char t0, char t1, const uint8_t* src, uint32_t n) {       // Z tag, n + 4 <= 64
+    const uint32_t k = lane >= 3 ? lane - 3 : 0;
+    const uint8_t b = src[k < n ? k : (n ? n - 1 : 0)];
+    small(3 + n + 1, [&](uint32_t i) { return i == 0 ? (uint8_t)t0 : i == 1 ? (uint8_t)t1 : i == 2 ? (uint8_t)'Z' : k < n ? b : (uint8_t)0; });
+  }
+  __device__ __forceinline__ void scalars(char s, bool m_second, uint32_t dmax, uint32_t dmin, float rate) {   // <s>D <s>E <s>M (duplex) or <s>D <s>M <s>E (CODEC)
+    uint8_t v;
+    const uint32_t u = __float_as_uint(rate);
+    if (m_second) {
+      if (lane < 4) v = int_tag_byte(lane, s, 'D', dmax);
+      else if (lane < 8) v = int_tag_byte(lane - 4, s, 'M', dmin);
+      else { const uint32_t j = lane - 8; v = j == 0 ? (uint8_t)s : j == 1 ? (uint8_t)'E' : j == 2 ? (uint8_t)'f' : (uint8_t)(u >> (8 * ((j - 3) & 3))); }
+    } else {
+      if (lane < 4) v = int_tag_byte(lane, s, 'D', dmax);
+      else if (lane < 11) { const uint32_t j = lane - 4; v = j == 0 ? (uint8_t)s : j == 1 ? (uint8_t)'E' : j == 2 ? (uint8_t)'f' : (uint8_t)(u >> (8 * ((j - 3) & 3))); }
+      else v = int_tag_byte(lane - 11, s, 'M', dmin);
+    }
+    if (lane < 15) q[lane] = v;
+    q += 15;
+  }
+  __device__ __forceinline__ void core(uint32_t rec_size, uint32_t name_len, uint32_t flag, uint32_t L) {
+    if (lane < 36) {
+      const uint32_t dw = lane >> 2;
+      const uint32_t v = dw == 0 ? rec_size : dw == 3 ? ((name_len + 1) | (4680u << 16)) : dw == 4 ? (flag << 16) : dw == 5 ? L : dw == 8 ? 0u : 0xFFFFFFFFu;
+      q[lane] = (uint8_t)(v >> (8 * (lane & 3)));
+    }
+    q += 36;
+  }
+};
+
+template <uint32_t SLOTS, class B>      // string field of L bytes after a 3-byte `xyZ` header and before a NUL
+__device__ __forceinline__ void put_string(FieldWriter& W, char t0, char t1, uint32_t L, B byte_of) {
+  W.small(3, [&](uint32_t i) { return i == 0 ? (uint8_t)t0 : i == 1 ? (uint8_t)t1 : (uint8_t)'Z'; });
+#pragma unroll
+  for (uint32_t t = 0; t < SLOTS; t++)
+#pragma unroll
+    for (uint32_t k = 0; k < 2; k++) { const uint32_t p = 128 * t + 2 * W.lane + k; if (p < L) W.q[p] = byte_of(t, k); }
+  if (W.lane == 0) W.q[L] = 0;
+  W.q += L + 1;
+}
+template <uint32_t SLOTS, class V>      // B:s array of L int16 values
+__device__ __forceinline__ void put_i16(FieldWriter& W, char t0, char t1, uint32_t L, V val_of) {
+  W.small(8, [&](uint32_t i) { return i == 0 ? (uint8_t)t0 : i == 1 ? (uint8_t)t1 : i == 2 ? (uint8_t)'B' : i == 3 ? (uint8_t)'s' : (uint8_t)(L >> (8 * ((i - 4) & 3))); });
+#pragma unroll
+  for (uint32_t t = 0; t < SLOTS; t++)
+#pragma unroll
+    for (uint32_t k = 0; k < 2; k++) {
+      const uint32_t p = 128 * t + 2 * W.lane + k;
+      if (p < L) { const uint32_t v = val_of(t, k); W.q[2 * p] = (uint8_t)v; W.q[2 * p + 1] = (uint8_t)(v >> 8); }
+    }
+  W.q += 2 * L;
+}
+template <uint32_t SLOTS, class C, class Q>   // 4-bit packed bases, then qualities
+__device__ __forceinline__ void put_seq_qual(FieldWriter& W, uint32_t L, C code_of, Q qual_of) {
+#pragma unroll
+  for (uint32_t t = 0; t < SLOTS; t++) {
+    const uint32_t p = 128 * t + 2 * W.lane;
+    if (p < L) W.q[p >> 1] = (uint8_t)((code_of(t, 0) << 4) | (p + 1 < L ? code_of(t, 1) : 0u));
+  }
+  W.q += (L + 1) / 2;
+#pragma unroll
+  for (uint32_t t = 0; t < SLOTS; t++)
+#pragma unroll
+    for (uint32_t k = 0; k < 2; k++) { const uint32_t p = 128 * t + 2 * W.lane + k; if (p < L) W.q[p] = (uint8_t)qual_of(t, k); }
+  W.q += L;
+}
+
+__global__ __launch_bounds__(256) void k_emit_duplex_fast(DuplexEmitParams P) {
+  const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(P.slot0 + ((blockIdx.x * blockDim.x + threadIdx.x) >> 6)));
+  const uint32_t lane = threadIdx.x & 63;
+  if (slot >= P.slot_end) return;
+  const DuplexDesc& D = P.ends[slot];
+  if (!D.valid || !duplex_fast_ok(D, P.prefix_len, P.rg_len)) return;
+  const uint32_t L = D.len, lastp = L ? L - 1 : 0;
+  const bool has_ba = D.has_ba != 0;
+  const uint64_t a_off = D.a_off, b_off = has_ba ? D.b_off : D.a_off;
+  const uint8_t* first = P.blob + P.rec_off[D.first_rec];
+  const uint32_t mi_len = D.mi_len, mi_off = D.mi_off, name_len = P.prefix_len + 1 + mi_len;
+  const bool has_cb = D.has_cb != 0, has_rx = D.has_rx != 0;
+  const uint32_t cb_len = has_cb ? D.cb_len : 0, rx_len = has_rx ? D.rx_len : 0;
+  const uint32_t flag = bam::F_UNMAPPED | bam::F_PAIRED | bam::F_MATE_UNMAPPED | (D.type == 1 ? bam::F_FIRST : bam::F_LAST);
+  // ---- every load of the record (indices clamped into the record's own segments, so unconditional) -----------------------
+  uint32_t ca[DUP_SLOTS][2], qa[DUP_SLOTS][2], ea[DUP_SLOTS][2], oa[DUP_SLOTS][2], cb[DUP_SLOTS][2], qb[DUP_SLOTS][2], eb[DUP_SLOTS][2], ob[DUP_SLOTS][2];
+#pragma unroll
+  for (uint32_t t = 0; t < DUP_SLOTS; t++)
+#pragma unroll
+    for (uint32_t k = 0; k < 2; k++) {
+      const uint32_t p = 128 * t + 2 * lane + k, pc = p < lastp ? p : lastp;
+      ca[t][k] = P.col_code[a_off + pc]; qa[t][k] = P.col_qual[a_off + pc]; ea[t][k] = P.col_err[a_off + pc]; oa[t][k] = P.col_obs[a_off + pc];
+      cb[t][k] = P.col_code[b_off + pc]; qb[t][k] = P.col_qual[b_off + pc]; eb[t][k] = P.col_err[b_off + pc]; ob[t][k] = P.col_obs[b_off + pc];
+    }
+  const uint32_t k3 = lane >= 3 ? lane - 3 : 0, ni = lane > P.prefix_len ? lane - P.prefix_len - 1 : 0;
+  const uint8_t pfx = (uint8_t)P.prefix[lane < P.prefix_len ? lane : 0], nmb = first[mi_off + (ni < mi_len ? ni : mi_len)];
+  // ---- the duplex call of each position, packed: w0 = ca | cb<<4 | oc<<8 | qa<<16 | qb<<24 ; w1 = da | db<<8 | ea<<16 | eb<<24 ; w2 = oq | oe<<8
+  uint32_t w0[DUP_SLOTS][2], w1[DUP_SLOTS][2], w2[DUP_SLOTS][2];
+  uint32_t amax = 0, amin = 0xFFFFFFFFu, asd = 0, ase = 0, bmax = 0, bmin = 0xFFFFFFFFu, bsd = 0, bse = 0, cmax = 0, cmin = 0xFFFFFFFFu, csd = 0, cse = 0;
+#pragma unroll
+  for (uint32_t t = 0; t < DUP_SLOTS; t++)
+#pragma unroll
+    for (uint32_t k = 0; k < 2; k++) {
+      const uint32_t da = obs_sum(oa[t][k]);
+      uint32_t db = 0, xcb = 15, xqb = 0, xeb = 0, oc = ca[t][k], oq = qa[t][k], oe = ea[t][k];
+      if (has_ba) {
+        db = obs_sum(ob[t][k]); xcb = cb[t][k]; xqb = qb[t][k]; xeb = eb[t][k];
+        const uint32_t xa = ca[t][k], xq = qa[t][k];
+        uint32_t rb, rq;
+        if (xa == xcb) { rb = xa; rq = cap_q((int32_t)xq + (int32_t)xqb); }
+        else if (xq > xqb) { rb = xa; rq = cap_q((int32_t)xq - (int32_t)xqb); }
+        else if (xqb > xq) { rb = xcb; rq = cap_q((int32_t)xqb - (int32_t)xq); }
+        else { rb = xa; rq = FGX_MIN_PHRED; }
+        const bool nocall = xa == 15 || xcb == 15 || rq == FGX_MIN_PHRED;
+        oc = nocall ? 15u : rb; oq = nocall ? (uint32_t)FGX_MIN_PHRED : rq;
+        oe = rb == 15 ? 0u : (da + db) - (obs_of_code(oa[t][k], rb) + obs_of_code(ob[t][k], rb));
+      }
+      w0[t][k] = ca[t][k] | (xcb << 4) | (oc << 8) | (qa[t][k] << 16) | (xqb << 24);
+      w1[t][k] = da | (db << 8) | (ea[t][k] << 16) | (xeb << 24);
+      w2[t][k] = oq | (oe << 8);
+      if (128 * t + 2 * lane + k < L) {
+        amax = da > amax ? da : amax; amin = da < amin ? da : amin; asd += da; ase += ea[t][k];
+        bmax = db > bmax ? db : bmax; bmin = db < bmin ? db : bmin; bsd += db; bse += xeb;
+        const uint32_t tt = da + db;
+        cmax = tt > cmax ? tt : cmax; cmin = tt < cmin ? tt : cmin; csd += tt; cse += oe;
+      }
+    }
+  amax = wave_max(amax); amin = wave_min(amin); asd = wave_sum(asd); ase = wave_sum(ase);
+  bmax = wave_max(bmax); bmin = wave_min(bmin); bsd = wave_sum(bsd); bse = wave_sum(bse);
+  cmax = wave_max(cmax); cmin = wave_min(cmin); csd = wave_sum(csd); cse = wave_sum(cse);
+  if (L == 0) { amin = 0; bmin = 0; cmin = 0; }
+  if (!has_ba) { bmax = 0; bmin = 0; bsd = 0; bse = 0; }
+  const float a_rate = asd ? (float)ase / (float)asd : 0.0f, b_rate = bsd ? (float)bse / (float)bsd : 0.0f, c_rate = csd ? (float)cse / (float)csd : 0.0f;
+  // ---- stores ------------------------------------------------------------------------------------------------------------------
+  FieldWriter W{P.out + P.out_off[slot], lane};
+  W.core(D.rec_size, name_len, flag, L);
+  W.small(name_len + 1, [&](uint32_t i) { return i < P.prefix_len ? pfx : i == P.prefix_len ? (uint8_t)':' : i < name_len ? nmb : (uint8_t)0; });
+  put_seq_qual<DUP_SLOTS>(W, L, [&](uint32_t t, uint32_t k) { return (w0[t][k] >> 8) & 15; }, [&](uint32_t t, uint32_t k) { return w2[t][k] & 0xFF; });
+  W.z_small('M', 'I', first + mi_off, mi_len);
+  if (has_cb) W.z_small(P.cell0, P.cell1, P.blob + P.rec_off[D.cb_rec] + D.cb_off, cb_len);
+  W.z_small('R', 'G', (const uint8_t*)P.rg, P.rg_len);
+  W.scalars('a', false, amax, amin, a_rate);
+  if (P.per_base_tags) {
+    put_string<DUP_SLOTS>(W, 'a', 'c', L, [&](uint32_t t, uint32_t k) { return bam::code_to_ascii((uint8_t)(w0[t][k] & 15)); });
+    put_i16<DUP_SLOTS>(W, 'a', 'd', L, [&](uint32_t t, uint32_t k) { return w1[t][k] & 0xFF; });
+    put_i16<DUP_SLOTS>(W, 'a', 'e', L, [&](uint32_t t, uint32_t k) { return (w1[t][k] >> 16) & 0xFF; });
+    put_string<DUP_SLOTS>(W, 'a', 'q', L, [&](uint32_t t, uint32_t k) { return (uint8_t)(((w0[t][k] >> 16) & 0xFF) + 33); });
+  }
+  W.scalars('b', false, bmax, bmin, b_rate);
+  if (P.per_base_tags && has_ba) {
+    put_string<DUP_SLOTS>(W, 'b', 'c', L, [&](uint32_t t, uint32_t k) { return bam::code_to_ascii((uint8_t)((w0[t][k] >> 4) & 15)); });
+    put_i16<DUP_SLOTS>(W, 'b', 'd', L, [&](uint32_t t, uint32_t k) { return (w1[t][k] >> 8) & 0xFF; });
+    put_i16<DUP_SLOTS>(W, 'b', 'e', L, [&](uint32_t t, uint32_t k) { return w1[t][k] >> 24; });
+    put_string<DUP_SLOTS>(W, 'b', 'q', L, [&](uint32_t t, uint32_t k) { return (uint8_t)((w0[t][k] >> 24) + 33); });
+  }
+  W.scalars('c', false, cmax, cmin, c_rate);
+  if (has_rx) W.z_small('R', 'X', (const uint8_t*)D.rx, rx_len);
+}
+
+__global__ __launch_bounds__(256) void k_emit_codec_fast(CodecEmitParams P) {
+  const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(P.slot0 + ((blockIdx.x * blockDim.x + threadIdx.x) >> 6)));
+  const uint32_t lane = threadIdx.x & 63;
+  if (slot >= P.slot_end) return;
+  const CodecDesc& D = P.ends[slot];
+  if (!D.valid || !codec_fast_ok(D, P.prefix_len, P.rg_len)) return;
+  const uint32_t C = D.cons_len, l1 = D.l1, l2 = D.l2;
+  const uint64_t s1 = D.s1_off, s2 = D.s2_off;
+  const bool r1_neg = D.flags & 1, r2_neg = (D.flags & 2) != 0;
+  const uint8_t* first = P.blob + P.rec_off[D.first_rec];
+  const uint32_t mi_len = D.mi_len, mi_off = D.mi_off, name_len = P.prefix_len + 1 + mi_len;
+  const bool has_cb = D.has_cb != 0, has_rx = D.has_rx != 0;
+  const uint32_t cb_len = has_cb ? D.cb_len : 0, rx_len = has_rx ? D.rx_len : 0;
+  const uint32_t ni = lane > P.prefix_len ? lane - P.prefix_len - 1 : 0;
+  const uint8_t pfx = (uint8_t)P.prefix[lane < P.prefix_len ? lane : 0], nmb = first[mi_off + (ni < mi_len ? ni : mi_len)];
+  // strand geometry in reference orientation: strand 1 is reverse-complemented and right-aligned when R1 is the negative read,
+  // strand 2 is reverse-complemented when R1 is NOT negative and right-aligned when R2 is
+  const uint32_t sh1 = r1_neg ? C - l1 : 0, sh2 = r2_neg ? C - l2 : 0;
+  const bool rc1 = r1_neg, rc2 = !r1_neg;
+  // field layout of the record (every offset is known up front, so the position-indexed fields can be written window by window)
+  uint8_t* const rec = P.out + P.out_off[slot];
+  uint8_t* const q_seq = rec + 36 + name_len + 1;
+  uint8_t* const q_qual = q_seq + (C + 1) / 2;
+  uint8_t* const q_rg = q_qual + C;
+  uint8_t* const q_scal = q_rg + (3 + P.rg_len + 1) + (3 + mi_len + 1);
+  uint8_t* const q_arr = q_scal + 45;                       // ad bd ae be: 8 + 2C each
+  uint8_t* const q_str = q_arr + 4 * (8 + 2 * C);           // ac bc aq bq: 3 + C + 1 each
+  uint8_t* const q_tail = P.per_base_tags ? q_str + 4 * (3 + C + 1) : q_arr;
+  uint32_t amax = 0, amin = 0xFFFFFFFFu, asd = 0, ase = 0, bmax = 0, bmin = 0xFFFFFFFFu, bsd = 0, bse = 0, cmax = 0, cmin = 0xFFFFFFFFu, csd = 0, cse = 0;
+  uint32_t n_dup = 0, n_dis = 0;
+  for (uint32_t win = 0; win < C; win += 256) {             // 256 positions per sweep: 4 per lane, all loads of the sweep in flight together
+    uint32_t vb1[4], vq1[4], vd1[4], ve1[4], vb2[4], vq2[4], vd2[4], ve2[4];
+    bool vp1[4], vp2[4];
+    uint32_t vi[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4; u++) {
+      const uint32_t f = win + 128 * (u >> 1) + 2 * lane + (u & 1);
+      const uint32_t i = f < C ? (r1_neg ? C - 1 - f : f) : 0;
+      vi[u] = i;
+      vp1[u] = i < sh1 || i - sh1 >= l1; vp2[u] = i < sh2 || i - sh2 >= l2;
+      const uint32_t j1 = vp1[u] ? 0 : i - sh1, j2 = vp2[u] ? 0 : i - sh2;
+      const uint32_t k1 = l1 ? (rc1 ? l1 - 1 - j1 : j1) : 0, k2 = l2 ? (rc2 ? l2 - 1 - j2 : j2) : 0;
+      vb1[u] = P.col_code[s1 + k1]; vq1[u] = P.col_qual[s1 + k1]; vd1[u] = P.col_depth[s1 + k1]; ve1[u] = P.col_err[s1 + k1];
+      vb2[u] = P.col_code[s2 + k2]; vq2[u] = P.col_qual[s2 + k2]; vd2[u] = P.col_depth[s2 + k2]; ve2[u] = P.col_err[s2 + k2];
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 4; u++) {
+      const uint32_t f = win + 128 * (u >> 1) + 2 * lane + (u & 1), i = vi[u];
+      const bool inrec = f < C, pad1 = vp1[u], pad2 = vp2[u];
+      uint32_t b1 = vb1[u], q1 = vq1[u], d1 = vd1[u], e1 = ve1[u], b2 = vb2[u], q2 = vq2[u], d2 = vd2[u], e2 = ve2[u];
+      if (rc1) b1 = comp_code((uint8_t)b1);
+      if (rc2) b2 = comp_code((uint8_t)b2);
+      if (pad1) { b1 = 15; q1 = 0; d1 = 0; e1 = 0; }
+      if (pad2) { b2 = 15; q2 = 0; d2 = 0; e2 = 0; }
+      const bool ha = !pad1 && b1 != 15, hb = !pad2 && b2 != 15;
+      bool dis = false;
+      uint32_t fb, fq, err;
+      if (ha && hb) {
+        uint32_t rb, rq;
+        if (b1 == b2) { rb = b1; const uint32_t sm = q1 + q2; rq = sm < 93 ? sm : 93; }
+        else if (q1 > q2) { dis = true; rb = b1; rq = q1 - q2; if (rq < FGX_MIN_PHRED) rq = FGX_MIN_PHRED; }
+        else if (q2 > q1) { dis = true; rb = b2; rq = q2 - q1; if (rq < FGX_MIN_PHRED) rq = FGX_MIN_PHRED; }
+        else { dis = true; rb = b1; rq = FGX_MIN_PHRED; }
+        if (rq == FGX_MIN_PHRED) { fb = 15; fq = FGX_MIN_PHRED; } else { fb = rb; fq = rq; }
+        const uint32_t de = b1 == b2 ? e1 + e2 : b1 == rb ? e1 + (d2 > e2 ? d2 - e2 : 0) : e2 + (d1 > e1 ? d1 - e1 : 0);
+        err = de < 32767 ? de : 32767;
+      } else if (ha) { if (q1 == FGX_MIN_PHRED) { fb = 15; fq = FGX_MIN_PHRED; } else { fb = b1; fq = q1; } err = e1; }
+      else if (hb) { if (q2 == FGX_MIN_PHRED) { fb = 15; fq = FGX_MIN_PHRED; } else { fb = b2; fq = q2; } err = e2; }
+      else { fb = 15; fq = FGX_MIN_PHRED; const uint32_t de = e1 + e2; err = de < 32767 ? de : 32767; }
+      if ((!pad1 && b1 == 15) || (!pad2 && b2 == 15)) { fb = 15; fq = FGX_MIN_PHRED; }
+      if (P.has_outer && P.outer_len > 0 && (i < P.outer_len || C - 1 - i < P.outer_len)) fq = P.outer_qual;
+      if (P.has_ss && (!ha || !hb)) fq = P.ss_qual;
+      if (r1_neg) { fb = comp_code((uint8_t)fb); b1 = comp_code((uint8_t)b1); b2 = comp_code((uint8_t)b2); }
+      if (inrec) {
+        amax = d1 > amax ? d1 : amax; amin = d1 < amin ? d1 : amin; asd += d1; ase += e1;
+        bmax = d2 > bmax ? d2 : bmax; bmin = d2 < bmin ? d2 : bmin; bsd += d2; bse += e2;
+        const uint32_t tt = d1 + d2;
+        cmax = tt > cmax ? tt : cmax; cmin = tt < cmin ? tt : cmin; csd += tt; cse += err;
+        n_dup += (ha && hb) ? 1 : 0; n_dis += dis ? 1 : 0;
+        q_qual[f] = (uint8_t)fq;
+        if (P.per_base_tags) {
+          uint8_t* a = q_arr + 8 + 2 * f;
+          a[0] = (uint8_t)d1; a[1] = 0;
+          a += 8 + 2 * C; a[0] = (uint8_t)d2; a[1] = 0;
+          a += 8 + 2 * C; a[0] = (uint8_t)e1; a[1] = 0;
+          a += 8 + 2 * C; a[0] = (uint8_t)e2; a[1] = 0;
+          uint8_t* z = q_str + 3 + f;
+          z[0] = pad1 ? (uint8_t)'n' : bam::code_to_ascii((uint8_t)b1);
+          z += 3 + C + 1; z[0] = pad2 ? (uint8_t)'n' : bam::code_to_ascii((uint8_t)b2);
+          z += 3 + C + 1; z[0] = (uint8_t)(q1 + 33);
+          z += 3 + C + 1; z[0] = (uint8_t)(q2 + 33);
+        }
+      }
+      vb1[u] = fb;       // keep the duplex base for the nibble packing below
+    }
+#pragma unroll
+    for (uint32_t h = 0; h < 2; h++) {   // packed bases: this lane's two positions of each half-window share one byte
+      const uint32_t f = win + 128 * h + 2 * lane;
+      if (f < C) q_seq[f >> 1] = (uint8_t)((vb1[2 * h] << 4) | (f + 1 < C ? vb1[2 * h + 1] : 0u));
+    }
+  }
+  amax = wave_max(amax); amin = wave_min(amin); asd = wave_sum(asd); ase = wave_sum(ase);
+  bmax = wave_max(bmax); bmin = wave_min(bmin); bsd = wave_sum(bsd); bse = wave_sum(bse);
+  cmax = wave_max(cmax); cmin = wave_min(cmin); csd = wave_sum(csd); cse = wave_sum(cse);
+  n_dup = wave_sum(n_dup); n_dis = wave_sum(n_dis);
+  if (C == 0) { amin = 0; bmin = 0; cmin = 0; }
+  if (lane == 0) {
+    unsigned long long* st = P.stats + (size_t)(blockIdx.x & (STAT_SLOTS - 1)) * 32;
+    atomicAdd(&st[24], (unsigned long long)C);
+    if (n_dup) atomicAdd(&st[25], (unsigned long long)n_dup);
+    if (n_dis) atomicAdd(&st[26], (unsigned long long)n_dis);
+  }
+  const float a_rate = asd ? (float)ase / (float)asd : 0.0f, b_rate = bsd ? (float)bse / (float)bsd : 0.0f, c_rate = csd ? (float)cse / (float)csd : 0.0f;
+  // ---- the fields that are not indexed by position ----------------------------------------------------------------------------
+  FieldWriter W{rec, lane};
+  W.core(D.rec_size, name_len, (uint32_t)bam::F_UNMAPPED, C);
+  W.small(name_len + 1, [&](uint32_t i) { return i < P.prefix_len ? pfx : i == P.prefix_len ? (uint8_t)':' : i < name_len ? nmb : (uint8_t)0; });
+  W.q = q_rg;
+  W.z_small('R', 'G', (const uint8_t*)P.rg, P.rg_len);
+  W.z_small('M', 'I', first + mi_off, mi_len);
+  W.scalars('c', true, cmax, cmin, c_rate);
+  W.scalars('a', true, amax, amin, a_rate);
+  W.scalars('b', true, bmax, bmin, b_rate);
+  if (P.per_base_tags) {
+    if (lane < 32) {          // the four array headers and the four string headers + terminators
+      const uint32_t r = lane >> 3, i = lane & 7;
+      const char t0 = (r & 1) ? 'b' : 'a', t1 = r < 2 ? 'd' : 'e';
+      q_arr[(size_t)r * (8 + 2 * C) + i] = i == 0 ? (uint8_t)t0 : i == 1 ? (uint8_t)t1 : i == 2 ? (uint8_t)'B' : i == 3 ? (uint8_t)'s' : (uint8_t)(C >> (8 * ((i - 4) & 3)));
+    } else if (lane < 48) {
+      const uint32_t r = (lane - 32) >> 2, i = (lane - 32) & 3;
+      const char t0 = (r & 1) ? 'b' : 'a', t1 = r < 2 ? 'c' : 'q';
+      uint8_t* z = q_str + (size_t)r * (3 + C + 1);
+      if (i < 3) z[i] = i == 0 ? (uint8_t)t0 : i == 1 ? (uint8_t)t1 : (uint8_t)'Z'; else z[3 + C] = 0;
+    }
+  }
+  W.q = q_tail;
+  if (has_cb) W.z_small(P.cell0, P.cell1, P.blob + P.rec_off[D.cb_rec] + D.cb_off, cb_len);
+  if (has_rx) W.z_small('R', 'X', (const uint8_t*)D.rx, rx_len);
 }
 
 // Upper bound on the consensus columns a batch can produce: a family yields at most three ends, each no
@@ -2685,6 +3007,7 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
     CE.has_outer = o.codec_has_outer_bases_qual; CE.outer_qual = o.codec_outer_bases_qual; CE.outer_len = o.codec_outer_bases_length;
     CE.has_ss = o.codec_has_single_strand_qual; CE.ss_qual = o.codec_single_strand_qual;
     CE.stats = d_statslots.as<unsigned long long>();
+    hipLaunchKernelGGL(k_emit_codec_fast, dim3((n_slots + 3) / 4), dim3(256), 0, s, CE);
     hipLaunchKernelGGL(k_emit_codec, dim3((n_slots + 3) / 4), dim3(256), 0, s, CE);
   } else if (duplex) {
     DuplexEmitParams DE;
@@ -2694,6 +3017,7 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
     DE.col_code = P.col_code; DE.col_qual = P.col_qual; DE.col_err = P.col_err; DE.col_obs = P.col_obs;
     DE.prefix = E.prefix; DE.prefix_len = E.prefix_len; DE.rg = E.rg; DE.rg_len = E.rg_len;
     DE.per_base_tags = P.per_base_tags; DE.cell0 = P.cell0; DE.cell1 = P.cell1;
+    hipLaunchKernelGGL(k_emit_duplex_fast, dim3((n_slots + 3) / 4), dim3(256), 0, s, DE);
     hipLaunchKernelGGL(k_emit_duplex, dim3((n_slots + 3) / 4), dim3(256), 0, s, DE);
   } else hipLaunchKernelGGL(k_emit, dim3((n_slots + 3) / 4), dim3(256), 0, s, E);
   hip_check(hipGetLastError(), "k_emit launch");
