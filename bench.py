@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--families", type=int, default=None)
     ap.add_argument("--depth", type=int, default=None)
     ap.add_argument("--read-length", type=int, default=None)
+    ap.add_argument("--depth-max", type=int, default=0,
+                    help="simplex only: long-tail family sizes in [depth, depth-max] pairs, count ~ size^-1.5 (BASELINE configs[3] shape: --depth 2 --depth-max 50)")
     ap.add_argument("--cpu-sample-families", type=int, default=300000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -106,7 +108,7 @@ def main():
                            VanillaUmiConsensusOptions)
 
     fam = args.families
-    sim_extra = {}
+    sim_extra = dict(family_size_max=args.depth_max) if (args.depth_max and args.caller == "simplex") else {}
     if codec:
         caller = CodecConsensusCaller("", "A", CodecConsensusOptions(produce_per_base_tags=True, cell_tag="CB"), device=local_rank)
         sim_extra = dict(insert_mean=350, insert_sd=60, codec=1)
@@ -161,17 +163,18 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": (f"CODEC consensus, {fam} molecules per GPU, {args.depth} pairs of 2x{L}bp, insert N(350,60) (BASELINE configs[4] shape), " if codec else
                                     f"duplex consensus, {fam} molecules per GPU, {args.depth} pairs split over /A and /B, {L}bp paired (BASELINE configs[2] shape), "
-                                    if duplex else f"simplex consensus, {fam} families per GPU, depth={args.depth} pairs, {L}bp paired (BASELINE configs[1] shape), ")
+                                    if duplex else f"simplex consensus, {fam} families per GPU, depth {args.depth}..{args.depth_max} pairs (long tail), {L}bp paired (BASELINE configs[3] shape), "
+                                    if args.depth_max else f"simplex consensus, {fam} families per GPU, depth={args.depth} pairs, {L}bp paired (BASELINE configs[1] shape), ")
                                    + "device-resident: raw BAM records in HBM -> consensus BAM records in HBM",
                        "min_reads": 1, "overlapping_consensus": True, "families_per_gpu": fam, "raw_reads_per_gpu": dg.n_rec,
                        "deferred_families": total_def, "output_bytes": total_bytes,
                        "columns_needing_call_full_per_step": caller.last_timing.get("full_columns")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None if (duplex or codec) else pmc_traffic(fam, args.depth, L), "kernel": "k_family", "kernel_ms": k_family_ms / steps, "k_emit_ms": k_emit_ms / steps,
+                         "traffic": None if (duplex or codec or args.depth_max) else pmc_traffic(fam, args.depth, L), "kernel": "k_family", "kernel_ms": k_family_ms / steps, "k_emit_ms": k_emit_ms / steps,
                          "device_ms_per_step": k_total_ms / steps, "algorithmic_bytes_per_launch": alg_read + alg_write,
                          "read_only_GBs": alg_read / k_avg_s / 1e9 if k_avg_s > 0 else 0.0},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not args.depth_max:
             line["cpu_baseline"] = cpu_baseline(min(fam, args.cpu_sample_families), args.depth, L, os.cpu_count() or 1, duplex, codec)
         print(json.dumps(line))
     if rank == 0:   # profiling builds (-DFGX_PHASE_TIMING=1) expose per-phase cycle totals of k_family_wave

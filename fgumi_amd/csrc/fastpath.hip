@@ -780,8 +780,9 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
   }
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const uint32_t g = P.g0 + blockIdx.x * WAVES_PER_BLOCK + wv;
-  if (g >= n_grp_total) return;
+  const uint32_t gi = blockIdx.x * WAVES_PER_BLOCK + wv;      // n_grp_total counts the groups of this launch (all of them, or a retry list)
+  if (gi >= n_grp_total) return;
+  const uint32_t g = P.group_list ? P.group_list[gi] : P.g0 + gi;
   uint8_t* W = dyn + (size_t)wv * P.lds_wave_bytes;
   const uint32_t my_list = blockIdx.x & (N_LISTS - 1);
   bool list_overflow = false;
@@ -818,8 +819,10 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
     if (lane == 0) { atomicAdd(&st[0], (unsigned long long)n); atomicAdd(&st[2], (unsigned long long)n); atomicAdd(&st[3 + FGX_REJ_INSUFFICIENT_READS], (unsigned long long)n); }
     return;
   }
-  auto to_retry = [&]() { if (lane == 0) { uint32_t k = atomicAdd(P.n_retry, 1u); P.retry[k] = g; } };
   auto to_defer = [&]() { if (lane == 0) { uint32_t k = atomicAdd(P.n_deferred, 1u); P.deferred[k] = g; } };
+  // does not fit this launch's LDS slice: the next launch (bigger slices, fewer waves per CU) picks it up; after the last one
+  // simplex families go to the workgroup-per-family kernel, duplex / CODEC molecules to the general path
+  auto to_retry = [&]() { if (!P.retry) { to_defer(); return; } if (lane == 0) { uint32_t k = atomicAdd(P.n_retry, 1u); P.retry[k] = g; } };
   if (n > 64) { if (MODE == 0) to_retry(); else to_defer(); return; }
 
 #if FGX_PHASE_TIMING
@@ -834,7 +837,7 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
   if (__any(act && len < 32)) { to_defer(); return; }
   unsigned long long base16 = lo_off & ~15ull;
   unsigned long long span = hi_end - base16;
-  if (span + 16 > (unsigned long long)P.lds_wave_bytes) { if (MODE == 0) to_retry(); else to_defer(); return; }   // +16: slack for the dword-composed reads
+  if (span + 16 > (unsigned long long)P.lds_wave_bytes) { to_retry(); return; }   // +16: slack for the dword-composed reads
   const uint32_t span16 = ((uint32_t)span + 15) & ~15u;
   {
     const uint8_t* src = P.blob + base16;
@@ -2849,7 +2852,7 @@ __global__ void k_reduce_stats(const unsigned long long* __restrict__ slots, uns
 // host driver
 // -----------------------------------------------------------------------------------------------------
 void FastPath::release() {
-  for (DevBuf* b : {&d_ends, &d_sizes, &d_offsets, &d_code, &d_qual, &d_depth, &d_err, &d_misc, &d_deferred, &d_out, &d_scan_tmp, &d_strings, &d_obs,
+  for (DevBuf* b : {&d_ends, &d_sizes, &d_offsets, &d_code, &d_qual, &d_depth, &d_err, &d_misc, &d_deferred, &d_out, &d_scan_tmp, &d_strings, &d_obs, &d_retry2,
                     &d_retry, &d_bound, &d_colbase, &d_statslots, &d_full_items, &d_full_count})
     b->free_();
   for (int i = 0; i < 4; i++) if (ev[i]) { (void)hipEventDestroy(ev[i]); ev[i] = nullptr; }
@@ -2938,18 +2941,46 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
 
   hip_check(hipEventRecord(c->ev0, s), "event");
   hip_check(hipEventRecord(ev[0], s), "event");
-  if (codec) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_family_wave<2>), dim3((n_grp + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(256), WAVES_PER_BLOCK * wave_bytes, s, P, n_grp);
-  else if (duplex) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_family_wave<1>), dim3((n_grp + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(256), WAVES_PER_BLOCK * wave_bytes, s, P, n_grp);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_family_wave<0>), dim3((n_grp + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(256), WAVES_PER_BLOCK * wave_bytes, s, P, n_grp);
-  hip_check(hipGetLastError(), "k_family_wave launch");
-  if (!duplex && !codec) {   // families that do not fit a wave (more than 64 records / more bytes than the LDS slice): one workgroup each
-    uint32_t n_retry = 0;
-    hip_check(hipMemcpyAsync(&n_retry, P.n_retry, 4, hipMemcpyDeviceToHost, s), "D2H");
-    hip_check(hipStreamSynchronize(s), "sync");
-    if (n_retry) {
+  // Wave-per-family launches over growing LDS slices: everything first, then only the groups whose records did not fit
+  // (long-tail families: 6 KB holds ~18 records of 150 bp, 12 KB ~36, 22 KB all 64 a wavefront can take).
+  {
+    const uint32_t stages[3] = {wave_bytes, 12288u, 22016u};
+    static bool lds_attr_set = false;
+    if (!lds_attr_set) {
+      (void)hipFuncSetAttribute((const void*)k_family_wave<0>, hipFuncAttributeMaxDynamicSharedMemorySize, WAVES_PER_BLOCK * 22016);
+      (void)hipFuncSetAttribute((const void*)k_family_wave<1>, hipFuncAttributeMaxDynamicSharedMemorySize, WAVES_PER_BLOCK * 22016);
+      (void)hipFuncSetAttribute((const void*)k_family_wave<2>, hipFuncAttributeMaxDynamicSharedMemorySize, WAVES_PER_BLOCK * 22016);
+      (void)hipGetLastError();
+      lds_attr_set = true;
+    }
+    d_retry2.reserve((size_t)n_grp * 4);
+    uint32_t* lists[2] = {d_retry.as<uint32_t>(), d_retry2.as<uint32_t>()};
+    uint32_t* d_cnt = (uint32_t*)(misc + 31);
+    uint32_t n_cur = n_grp;
+    const uint32_t* cur_list = nullptr;
+    int out_list = 0;
+    for (int st = 0; st < 3 && n_cur; st++) {
+      if (st > 0 && stages[st] <= stages[st - 1]) continue;
+      const bool last = st == 2;
+      hip_check(hipMemsetAsync(d_cnt, 0, 4, s), "memset");
+      FastParams PS = P;
+      PS.group_list = cur_list; PS.lds_wave_bytes = stages[st];
+      PS.retry = (last && (duplex || codec)) ? nullptr : lists[out_list]; PS.n_retry = d_cnt;
+      const dim3 grid((n_cur + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(256);
+      const size_t lds = (size_t)WAVES_PER_BLOCK * stages[st];
+      if (codec) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_family_wave<2>), grid, block, lds, s, PS, n_cur);
+      else if (duplex) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_family_wave<1>), grid, block, lds, s, PS, n_cur);
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_family_wave<0>), grid, block, lds, s, PS, n_cur);
+      hip_check(hipGetLastError(), "k_family_wave launch");
+      uint32_t n_next = 0;
+      hip_check(hipMemcpyAsync(&n_next, d_cnt, 4, hipMemcpyDeviceToHost, s), "D2H");
+      hip_check(hipStreamSynchronize(s), "sync");
+      cur_list = lists[out_list]; n_cur = PS.retry ? n_next : 0; out_list ^= 1;
+    }
+    if (n_cur && !duplex && !codec) {   // more than 64 records, or more bytes than the largest slice: one workgroup per family
       FastParams P2 = P;
-      P2.group_list = d_retry.as<uint32_t>(); P2.retry = nullptr; P2.n_retry = nullptr;
-      hipLaunchKernelGGL(k_family, dim3(n_retry), dim3(NT), lds_tile_bytes_large, s, P2);
+      P2.group_list = cur_list; P2.retry = nullptr; P2.n_retry = nullptr;
+      hipLaunchKernelGGL(k_family, dim3(n_cur), dim3(NT), lds_tile_bytes_large, s, P2);
       hip_check(hipGetLastError(), "k_family (large) launch");
     }
   }
