@@ -13,7 +13,7 @@ using namespace fgx;
 
 static thread_local std::string g_global_err;
 
-struct FastState { fgx::FastPath fp; std::vector<uint8_t> spliced; };
+struct FastState { fgx::FastPath fp; fgx::PinnedBuf pin_out; };   // device pipeline + the pinned landing buffer of its records
 
 namespace fgx {
 
@@ -144,7 +144,7 @@ void fgx_destroy(fgx_caller* c) {
   for (DevBuf* b : {&c->d_tables, &c->d_umi_tables, &c->d_stage, &c->d_reads, &c->d_jobs, &c->d_tiles, &c->d_ob, &c->d_oq, &c->d_od,
                     &c->d_oe, &c->d_scratch_a, &c->d_scratch_b, &c->d_in_blob, &c->d_in_off, &c->d_in_len, &c->d_in_grp})
     b->free_();
-  if (c->fast) { c->fast->fp.release(); delete c->fast; }
+  if (c->fast) { c->fast->fp.release(); c->fast->pin_out.free_(); delete c->fast; }
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -176,14 +176,14 @@ static int process_hybrid(fgx_caller* c, general_fn general, const uint8_t* reco
   c->fast->fp.run(c, c->d_in_blob.as<uint8_t>(), records_len, c->d_in_off.as<uint64_t>(), c->d_in_len.as<uint32_t>(), n_rec,
                   c->d_in_grp.as<uint32_t>(), n_grp, &fr);
   auto t2 = clk::now();
-  std::vector<uint8_t>& fast_out = c->fast->spliced;
-  fast_out.resize(fr.out_len);
-  if (fr.out_len) hip_check(hipMemcpy(fast_out.data(), fr.d_out, fr.out_len, hipMemcpyDeviceToHost), "D2H out");
+  // records land in a pinned host buffer owned by the caller object (pageable destinations cost ~10x: first-touch faults + staging)
+  c->fast->pin_out.reserve(fr.out_len + 16);
+  const uint8_t* fast_out = c->fast->pin_out.as<uint8_t>();
+  if (fr.out_len) hip_check(hipMemcpy(c->fast->pin_out.p, fr.d_out, fr.out_len, hipMemcpyDeviceToHost), "D2H out");
   auto t3 = clk::now();
   memset(out, 0, sizeof(*out));
   if (fr.n_deferred == 0) {
-    c->out_data.swap(fast_out);
-    out->data = c->out_data.data(); out->data_len = c->out_data.size(); out->count = fr.count;
+    out->data = fast_out; out->data_len = fr.out_len; out->count = fr.count;
     for (int i = 0; i < FGX_STATS_LEN; i++) out->stats[i] = fr.stats[i];
     out->ms_h2d = ms(t0, t1); out->ms_kernels = fr.ms_kernels; out->ms_d2h = ms(t2, t3);
     return 0;
@@ -204,17 +204,17 @@ static int process_hybrid(fgx_caller* c, general_fn general, const uint8_t* reco
   int rc = general(c, records, d_off.data(), d_len.data(), (uint32_t)d_off.size(), d_grp.data(), (uint32_t)def.size(), &gen);
   if (rc != 0) return rc;
   std::vector<uint8_t> merged;
-  merged.reserve(fast_out.size() + c->out_data.size());
+  merged.reserve(fr.out_len + c->out_data.size());
   uint64_t fpos = 0;   // fast output is contiguous in group order; deferred groups contributed nothing to it
   uint64_t gprev = 0;
   for (size_t k = 0; k < def.size(); k++) {
     uint64_t upto = slot_off[(size_t)3 * def[k]];          // fast bytes of all groups before def[k]
-    merged.insert(merged.end(), fast_out.begin() + fpos, fast_out.begin() + upto);
+    merged.insert(merged.end(), fast_out + fpos, fast_out + upto);
     fpos = upto;
     merged.insert(merged.end(), c->out_data.begin() + gprev, c->out_data.begin() + c->grp_out_end[k]);
     gprev = c->grp_out_end[k];
   }
-  merged.insert(merged.end(), fast_out.begin() + fpos, fast_out.end());
+  merged.insert(merged.end(), fast_out + fpos, fast_out + fr.out_len);
   c->out_data.swap(merged);
   out->data = c->out_data.data(); out->data_len = c->out_data.size(); out->count = fr.count + gen.count;
   for (int i = 0; i < FGX_STATS_LEN; i++) out->stats[i] = fr.stats[i] + gen.stats[i];
