@@ -113,7 +113,7 @@ struct FastResult {
 struct FastPath {
   DevBuf d_ends, d_sizes, d_offsets, d_code, d_qual, d_depth, d_err, d_misc, d_deferred, d_out, d_scan_tmp, d_strings;
   uint32_t lds_tile_bytes = 12288;        // first launch: tiles of the common small families
-  uint32_t lds_tile_bytes_large = 49152;  // second launch over the families that did not fit
+  uint32_t lds_tile_bytes_large = 65536;  // workgroup-per-family kernel: raw records + unpacked base / quality tiles of one big family (2 workgroups per CU)
   DevBuf d_retry, d_bound, d_colbase, d_statslots, d_full_items, d_full_count, d_obs, d_retry2;
   uint32_t lds_wave_bytes = 6144;         // wave-per-family kernel: LDS copy of one family's raw records
   uint32_t lds_wave_bytes_duplex = 8704;  // duplex molecules carry both strands (config 3: 24 records x ~330 B)

@@ -26,6 +26,7 @@
 #include <hipcub/hipcub.hpp>
 #include "bamrec.h"
 #include "engine.h"
+#include <cstdlib>
 #include "fastpath.h"
 
 namespace fgx {
@@ -67,6 +68,7 @@ struct Shared {
   uint32_t rx_bad;
   uint64_t col_base;
   uint32_t tile_bytes;
+  unsigned long long raw_lo, raw_hi;    // byte span of the family's records in the blob
 };
 
 __device__ __forceinline__ void defer(Shared& S) { S.defer = 1; }
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
   const uint32_t slot0 = 3 * g;
 
   if (tid < FGX_STATS_LEN) S.stats[tid] = 0;
-  if (tid == 0) { S.defer = 0; S.n_ends = 0; S.rx_bad = 0; }
+  if (tid == 0) { S.defer = 0; S.n_ends = 0; S.rx_bad = 0; S.raw_lo = ~0ull; S.raw_hi = 0ull; }
   if (tid < 3) { P.ends[slot0 + tid].valid = 0; P.rec_sizes[slot0 + tid] = 0; }
   __syncthreads();
 
@@ -116,6 +118,24 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
     return;
   }
 
+  // ---- 0. the family's raw records into LDS with coalesced 16-byte loads: everything below (tag walk, name compares,
+  // unpacking of bases and qualities) reads LDS instead of walking HBM byte by byte ------------------------------------
+  {
+    unsigned long long off = tid < n ? P.rec_off[r0 + tid] : ~0ull, end = tid < n ? P.rec_off[r0 + tid] + P.rec_len[r0 + tid] : 0ull;
+    for (int o = 32; o > 0; o >>= 1) { unsigned long long a = __shfl_xor(off, o), b = __shfl_xor(end, o); off = a < off ? a : off; end = b > end ? b : end; }
+    if ((tid & 63) == 0) { atomicMin(&S.raw_lo, off); atomicMax(&S.raw_hi, end); }
+  }
+  __syncthreads();
+  const unsigned long long base16 = S.raw_lo & ~15ull;
+  const uint32_t raw_bytes = (uint32_t)(((S.raw_hi - base16) + 15 + 16) & ~15ull);      // + slack for multi-byte reads past the last record
+  if ((S.raw_hi - base16) + 32 > (unsigned long long)P.lds_tile_bytes) {                  // not even the raw span fits
+    if (tid == 0) { uint32_t k = atomicAdd(P.n_deferred, 1u); P.deferred[k] = g; }
+    return;
+  }
+  for (uint32_t i = tid * 16; i < raw_bytes - 16; i += NT * 16) *(uint4*)(dyn + i) = *(const uint4*)(P.blob + base16 + i);
+  __syncthreads();
+  const uint8_t* const blobL = dyn - base16;          // blobL + <offset in the blob> addresses the LDS copy
+
   // ---- 1. parse one record per lane -----------------------------------------------------------------
   if (tid < n) {
     ReadInfo R;
@@ -124,7 +144,7 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
     R.end = 255;
     uint64_t off = P.rec_off[r0 + tid];
     uint32_t len = P.rec_len[r0 + tid];
-    const uint8_t* p = P.blob + off;
+    const uint8_t* p = blobL + off;
     R.goff = off;
     bool bad = len < 32;
     if (!bad) {
@@ -232,7 +252,7 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
     uint32_t row = 0;
     for (uint32_t i = 0; i < n; i++) { S.ri[i].row = row; if (!S.ri[i].excluded) row += ((uint32_t)S.ri[i].l_seq + 3) & ~3u; }
     S.tile_bytes = row;
-    if (2ull * row > P.lds_tile_bytes && !S.defer) S.defer = P.retry ? 2 : 1;
+    if ((unsigned long long)raw_bytes + 2ull * row > P.lds_tile_bytes && !S.defer) S.defer = P.retry ? 2 : 1;
   }
   __syncthreads();
   if (S.defer) {
@@ -242,14 +262,14 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
     }
     return;
   }
-  uint8_t* lb = dyn;
-  uint8_t* lq = dyn + S.tile_bytes;
+  uint8_t* lb = dyn + raw_bytes;
+  uint8_t* lq = lb + S.tile_bytes;
 
   // ---- 2. stage bases (unpacked 4-bit codes) and quals into LDS -------------------------------------
   for (uint32_t r = 0; r < n; r++) {
     const ReadInfo& R = S.ri[r];
     if (R.excluded) continue;
-    const uint8_t* p = P.blob + R.goff;
+    const uint8_t* p = blobL + R.goff;
     const uint8_t* sq = p + R.seq_off;
     const uint8_t* ql = sq + ((uint32_t)R.l_seq + 1) / 2;
     for (uint32_t i = tid; i < R.l_seq; i += NT) {
@@ -282,10 +302,10 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
       ReadInfo& R = S.ri[tid];
       bool is_r1 = !R.excluded && (R.flags & bam::F_FIRST);
       if (is_r1) {
-        const uint8_t* nm = P.blob + R.goff + 32;
+        const uint8_t* nm = blobL + R.goff + 32;
         auto same_name = [&](const ReadInfo& O) {
           if (O.name_hash != R.name_hash || O.name_len != R.name_len) return false;
-          const uint8_t* on = P.blob + O.goff + 32;
+          const uint8_t* on = blobL + O.goff + 32;
           for (uint32_t i = 0; i < R.name_len; i++) if (on[i] != nm[i]) return false;
           return true;
         };
@@ -519,7 +539,7 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
       uint32_t k = w / FAST_RX_CAP, i = w % FAST_RX_CAP;
       uint32_t cnt = S.end_rx_cnt[k];
       if (cnt == 0 || i >= S.end_rx_len[k]) continue;
-      if (cnt == 1) { const ReadInfo& R = S.ri[S.end_rx_first[k]]; S.end_rx[k][i] = (char)P.blob[R.goff + R.rx_off + i]; continue; }
+      if (cnt == 1) { const ReadInfo& R = S.ri[S.end_rx_first[k]]; S.end_rx[k][i] = (char)blobL[R.goff + R.rx_off + i]; continue; }
       ColumnAcc acc;
       acc.reset();
       uint32_t non_dna = 0, seen = 0;
@@ -528,7 +548,7 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
       for (uint32_t a = 0; a < S.end_cnt[k]; a++) {
         const ReadInfo& R = S.ri[S.members[S.end_first[k] + a]];
         if (!R.has_rx) continue;
-        uint8_t ch = P.blob[R.goff + R.rx_off + i];
+        uint8_t ch = blobL[R.goff + R.rx_off + i];
         if (seen == 0) fc = ch;
         seen++;
         uint8_t up = (ch >= 'a' && ch <= 'z') ? (uint8_t)(ch - 32) : ch;
@@ -2980,6 +3000,9 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
     if (n_cur && !duplex && !codec) {   // more than 64 records, or more bytes than the largest slice: one workgroup per family
       FastParams P2 = P;
       P2.group_list = cur_list; P2.retry = nullptr; P2.n_retry = nullptr;
+      if (const char* e = getenv("FGX_LDS_TILE_LARGE")) { uint32_t v = (uint32_t)atoi(e); if (v >= 16384 && v <= 163840) lds_tile_bytes_large = v & ~15u; P2.lds_tile_bytes = lds_tile_bytes_large; }   // tuning knob
+      (void)hipFuncSetAttribute((const void*)k_family, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile_bytes_large);
+      (void)hipGetLastError();
       hipLaunchKernelGGL(k_family, dim3(n_cur), dim3(NT), lds_tile_bytes_large, s, P2);
       hip_check(hipGetLastError(), "k_family (large) launch");
     }
