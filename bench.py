@@ -186,6 +186,9 @@ def main():
             tot = float(sum(ph)) or 1.0
             names = ["-", "stage", "parse", "overlap", "geometry", "gates", "columns", "umi", "descriptors"]
             print("phase share: " + "  ".join(f"{names[i]}={100.0 * ph[i] / tot:.1f}%" for i in range(1, 9)), file=sys.stderr)
+            bn = ["raw->lds", "parse", "unpack", "overlap", "geometry", "gates", "columns(to umi)"]
+            tb = float(sum(ph[9:16])) or 1.0
+            print("k_family (workgroup) share: " + "  ".join(f"{bn[i - 9]}={100.0 * ph[i] / tb:.1f}%" for i in range(9, 16)), file=sys.stderr)
     caller.close()
     if world > 1:
         dist.destroy_process_group()

@@ -89,10 +89,26 @@ __device__ __forceinline__ void oriented(const Shared& S, const uint8_t* lb, con
   *qual = q;
 }
 
+#ifndef FGX_PHASE_TIMING
+#define FGX_PHASE_TIMING 0   /* 1: per-phase s_memtime deltas of k_family_wave into g_phase (profiling builds only) */
+#endif
+#if FGX_PHASE_TIMING
+__device__ unsigned long long g_phase[64 * 16];
+#define PH(i) { unsigned long long _n = __builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(&g_phase[(blockIdx.x & 63) * 16 + (i)], _n - _t); _t = _n; }
+#else
+#define PH(i)
+#endif
+#if FGX_PHASE_TIMING
+#define PHB(i) { __syncthreads(); unsigned long long _n = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) atomicAdd(&g_phase[(blockIdx.x & 63) * 16 + (i)], _n - _tb); _tb = _n; }
+#else
+#define PHB(i)
+#endif
 __global__ __launch_bounds__(NT) void k_family(FastParams P) {
   extern __shared__ __align__(16) uint8_t dyn[];
   __shared__ Shared S;
+  __shared__ __align__(16) double sPairB[94][2];   // {correct[q], error_per_alt[q]}: one LDS read per observation instead of two global ones
   const uint32_t tid = threadIdx.x;
+  if (tid < 94) { sPairB[tid][0] = P.T->t.correct[tid]; sPairB[tid][1] = P.T->t.error_per_alt[tid]; }
   const uint32_t g = P.group_list ? P.group_list[blockIdx.x] : P.g0 + blockIdx.x;
   const uint32_t r0 = P.grp_first[g], r1 = P.grp_first[g + 1];
   const uint32_t n = r1 - r0;
@@ -118,6 +134,9 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
     return;
   }
 
+#if FGX_PHASE_TIMING
+  unsigned long long _tb = __builtin_amdgcn_s_memtime();
+#endif
   // ---- 0. the family's raw records into LDS with coalesced 16-byte loads: everything below (tag walk, name compares,
   // unpacking of bases and qualities) reads LDS instead of walking HBM byte by byte ------------------------------------
   {
@@ -136,6 +155,7 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
   __syncthreads();
   const uint8_t* const blobL = dyn - base16;          // blobL + <offset in the blob> addresses the LDS copy
 
+  PHB(9)
   // ---- 1. parse one record per lane -----------------------------------------------------------------
   if (tid < n) {
     ReadInfo R;
@@ -265,6 +285,7 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
   uint8_t* lb = dyn + raw_bytes;
   uint8_t* lq = lb + S.tile_bytes;
 
+  PHB(10)
   // ---- 2. stage bases (unpacked 4-bit codes) and quals into LDS -------------------------------------
   for (uint32_t r = 0; r < n; r++) {
     const ReadInfo& R = S.ri[r];
@@ -295,6 +316,7 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
     return;
   }
 
+  PHB(11)
   // ---- 3. overlapping-bases pre-correction (overlapping.rs:236-336, 627-684) ------------------------
   if (P.overlap) {
     // pair map semantics: for each name the LAST primary record with FIRST set and the LAST with (not FIRST and) LAST set
@@ -365,6 +387,7 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
     __syncthreads();
   }
 
+  PHB(12)
   // ---- 4. per-read source-read geometry (vanilla_caller.rs:1129-1160) ---------------------------------
   if (tid < n && !S.ri[tid].excluded) {
     ReadInfo& R = S.ri[tid];
@@ -400,6 +423,7 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
   }
   __syncthreads();
 
+  PHB(13)
   // ---- 5. family gates (process_group :1329-1422, process_subgroup :1454-1646) -------------------------
   if (tid == 0) {
     uint32_t* st = S.stats;
@@ -435,7 +459,8 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
         surv[e] = rem;
         // consensus length = min_reads-th longest kept read (:1661-1669)
         uint32_t k = P.min_reads, best = 0;
-        for (uint32_t a = first[e]; a < n_members; a++) {
+        if (k == 1) { for (uint32_t a = first[e]; a < n_members; a++) { uint32_t la = S.ri[S.members[a]].final_len; if (la > best) best = la; } }   // the longest read
+        else for (uint32_t a = first[e]; a < n_members; a++) {      // O(n^2) order statistic on one thread: only for min_reads > 1
           uint32_t la = S.ri[S.members[a]].final_len, ge = 0;
           for (uint32_t b = first[e]; b < n_members; b++) if (S.ri[S.members[b]].final_len >= la) ge++;
           if (ge >= k && la > best) best = la;
@@ -482,6 +507,7 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
     return;
   }
 
+  PHB(14)
   // ---- 6. consensus columns (create_consensus_from_source_reads :1652-1755) -------------------------
   const DeviceTables* T = P.T;
   const uint32_t ne = S.n_ends;
@@ -511,7 +537,8 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
           int lane = bam::code_to_lane(code);   // N (incl. masked) and IUPAC codes contribute nothing
           if (lane != 255) {
             uint32_t qq = q < FGX_MAX_PHRED ? q : FGX_MAX_PHRED;
-            acc.add(lane, T->t.correct[qq], T->t.error_per_alt[qq]);
+            const double2 pr = *(const double2*)&sPairB[qq][0];
+            acc.add(lane, pr.x, pr.y);
           }
         }
       }
@@ -532,6 +559,7 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
     atomicMax(&S.end_maxd[k], d16); atomicMin(&S.end_mind[k], d16); atomicAdd(&S.end_sumd[k], d16); atomicAdd(&S.end_sume[k], e16);
   }
 
+  PHB(15)
   // ---- 7. consensus UMI per end (simple_umi.rs:46-117): Q20 observations at (Q90, Q90) -----------------
   {
     const DeviceTables* TU = P.TU;
@@ -770,15 +798,6 @@ __device__ __forceinline__ bool column_call_fast_lds(const ConsensusTables& T, c
   return false;
 }
 
-#ifndef FGX_PHASE_TIMING
-#define FGX_PHASE_TIMING 0   /* 1: per-phase s_memtime deltas of k_family_wave into g_phase (profiling builds only) */
-#endif
-#if FGX_PHASE_TIMING
-__device__ unsigned long long g_phase[64 * 16];
-#define PH(i) { unsigned long long _n = __builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(&g_phase[(blockIdx.x & 63) * 16 + (i)], _n - _t); _t = _n; }
-#else
-#define PH(i)
-#endif
 #ifndef FGX_WAVE_OCC
 #define FGX_WAVE_OCC 5   /* measured on MI355X, 1M depth-8 families: occ 4 19.2 ms, 5 17.2 ms, 6 18.1 ms */
 #endif
