@@ -70,6 +70,24 @@ def pmc_traffic(families, depth, read_length):
         return None
 
 
+def pmc_valu_busy(families, depth, read_length, kernel_ms):
+    """Fraction of the launch during which the vector ALUs of a SIMD were issuing (SQ_ACTIVE_INST_VALU counts quad-cycles,
+    summed over the 1024 SIMDs of the chip at 2.4 GHz) — the bound that actually binds this kernel.  From the same committed
+    PMC passes as `traffic`; None when no profile matches the workload."""
+    if (depth, read_length) != (8, 150) or kernel_ms <= 0:
+        return None
+    import glob
+    tag = f"{families // 1000000}M" if families % 1000000 == 0 else str(families)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*pmc_{tag}_families.json")))
+    if not files:
+        return None
+    try:
+        k = json.load(open(files[-1]))["k_family_wave"]
+        return min(1.0, k["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / 2.4e9 / (kernel_ms * 1e-3))
+    except (KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,7 +190,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None if (duplex or codec or args.depth_max) else pmc_traffic(fam, args.depth, L), "kernel": "k_family", "kernel_ms": k_family_ms / steps, "k_emit_ms": k_emit_ms / steps,
                          "device_ms_per_step": k_total_ms / steps, "algorithmic_bytes_per_launch": alg_read + alg_write,
-                         "read_only_GBs": alg_read / k_avg_s / 1e9 if k_avg_s > 0 else 0.0},
+                         "read_only_GBs": alg_read / k_avg_s / 1e9 if k_avg_s > 0 else 0.0,
+                         "valu_busy_frac": None if (duplex or codec or args.depth_max) else pmc_valu_busy(fam, args.depth, L, k_family_ms / steps)},
         }
         if not args.no_cpu_baseline and world == 1 and not args.depth_max:
             line["cpu_baseline"] = cpu_baseline(min(fam, args.cpu_sample_families), args.depth, L, os.cpu_count() or 1, duplex, codec)
