@@ -652,78 +652,6 @@ __device__ __forceinline__ unsigned long long wave_max64(unsigned long long v) {
 __device__ __forceinline__ unsigned long long wave_min64(unsigned long long v) { for (int o = 32; o > 0; o >>= 1) { unsigned long long t = __shfl_xor(v, o); v = t < v ? t : v; } return v; }
 __device__ __forceinline__ uint8_t comp_code(uint8_t c) { return (uint8_t)((0xF7B3D591E6A2C480ULL >> (4 * (c & 15))) & 15); }
 
-// -----------------------------------------------------------------------------------------------------
-// Accumulators kept by ORDER OF APPEARANCE instead of by base.  Lanes of the reference's f64x4 that have
-// received identical value sequences are bit-identical: every base not yet observed in a column has seen
-// only `error_per_alt` terms, so all of them share ONE accumulator (su, cu).  A base gets its own
-// accumulator when it first appears — a copy of (su, cu), which is exactly its history — and from then on
-// receives `correct` when it is the observed base and `error_per_alt` otherwise.  A unanimous column
-// therefore costs two Kahan updates per observation instead of four; second/third/fourth accumulators are
-// only touched once some lane of the wavefront has seen that many distinct bases (wave-uniform branch).
-// The sequence of rounded operations applied to each base's (sum, compensation) is unchanged → bit-exact.
-// -----------------------------------------------------------------------------------------------------
-struct RankAcc {
-  double su, cu;          // shared accumulator of the bases not observed so far
-  double s[4], c[4];      // accumulator of the 1st, 2nd, 3rd, 4th distinct base observed
-  uint32_t bases;         // rank → base lane (A,C,G,T = 0..3), 4 bits each
-  uint32_t napp;          // distinct bases observed
-  uint32_t cnt;           // observations per rank, 8 bits each
-  __device__ __forceinline__ void reset() {
-    su = 0.0; cu = 0.0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) { s[i] = 0.0; c[i] = 0.0; }
-    bases = 0xFFFF; napp = 0; cnt = 0;
-  }
-  static __device__ __forceinline__ void kahan(double& sm, double& cm, double v) {
-    double y = v - cm;
-    double t = sm + y;
-    cm = (t - sm) - y;
-    sm = t;
-  }
-  // `valid` lanes add one observation of base lane bl with table values (corr, err)
-  __device__ __forceinline__ void add(bool valid, uint32_t bl, double corr, double err) {
-    if (valid && napp == 0) { bases = bl | 0xFFF0u; napp = 1; }
-    // lean path (wave-uniform): every contributing lane observes the first base of its column and no contributing
-    // lane holds a second base yet → only the shared and the first accumulator move
-    if (__all(!valid || (((bases & 15) == bl) && napp < 2))) {
-      if (valid) { kahan(su, cu, err); kahan(s[0], c[0], corr); cnt += 1u; }
-      return;
-    }
-    uint32_t r = 4;
-    if (((bases >> 0) & 15) == bl) r = 0;
-    else if (((bases >> 4) & 15) == bl) r = 1;
-    else if (((bases >> 8) & 15) == bl) r = 2;
-    else if (((bases >> 12) & 15) == bl) r = 3;
-    const bool is_new = valid && r == 4;
-    if (is_new) { r = napp; bases = (bases & ~(15u << (4 * r))) | (bl << (4 * r)); napp++; }
-    // a base appearing after others: its history is the shared accumulator's
-    if (is_new && r == 1) { s[1] = su; c[1] = cu; }
-    if (is_new && r == 2) { s[2] = su; c[2] = cu; }
-    if (is_new && r == 3) { s[3] = su; c[3] = cu; }
-    if (valid) {
-      kahan(su, cu, err);
-      kahan(s[0], c[0], r == 0 ? corr : err);
-      cnt += 1u << (8 * r);
-      kahan(s[1], c[1], r == 1 ? corr : err);      // lanes without a 2nd base yet: scratch work, overwritten on appearance
-    }
-    if (__any(valid && napp >= 3)) { if (valid) kahan(s[2], c[2], r == 2 ? corr : err); }
-    if (__any(valid && napp >= 4)) { if (valid) kahan(s[3], c[3], r == 3 ? corr : err); }
-  }
-  // back to per-base lanes: ll[b] / obs[b]
-  __device__ __forceinline__ void finish(double* ll, uint32_t* obs) const {
-#pragma unroll
-    for (uint32_t b = 0; b < 4; b++) {
-      double v = su;
-      uint32_t n = 0;
-      if (napp > 0 && ((bases >> 0) & 15) == b) { v = s[0]; n = cnt & 0xFF; }
-      if (napp > 1 && ((bases >> 4) & 15) == b) { v = s[1]; n = (cnt >> 8) & 0xFF; }
-      if (napp > 2 && ((bases >> 8) & 15) == b) { v = s[2]; n = (cnt >> 16) & 0xFF; }
-      if (napp > 3 && ((bases >> 12) & 15) == b) { v = s[3]; n = cnt >> 24; }
-      ll[b] = v; obs[b] = n;
-    }
-  }
-};
-
 // unaligned LDS reads built from aligned dwords (v_alignbyte_b32)
 __device__ __forceinline__ uint32_t ldsw(const uint8_t* W, uint32_t o) { return *(const uint32_t*)(W + o); }
 __device__ __forceinline__ uint32_t ld32u(const uint8_t* W, uint32_t o) {
@@ -800,9 +728,6 @@ __device__ __forceinline__ bool column_call_fast_lds(const ConsensusTables& T, c
 
 #ifndef FGX_WAVE_OCC
 #define FGX_WAVE_OCC 5   /* measured on MI355X, 1M depth-8 families: occ 4 19.2 ms, 5 17.2 ms, 6 18.1 ms */
-#endif
-#ifndef FGX_RANKACC
-#define FGX_RANKACC 0    /* rank-of-appearance accumulators: fewer f64 ops but more VGPRs; measured slower (19.9 vs 17.2 ms) */
 #endif
 // MODE 0: simplex (vanilla caller).  MODE 1: duplex — phases 1-4 are shared, the strand partition, the four single-strand
 // column sets and the descriptors of the two duplex records replace phases 5-8 (see the MODE == 1 branch).
@@ -1294,12 +1219,8 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
         depth = code != 15 ? 1 : 0;
         err = 0;
       } else {
-#if FGX_RANKACC
-        RankAcc acc;
-#else
         struct { ColumnAcc a; __device__ void reset() { a.reset(); } __device__ void add(bool v, uint32_t bl, double c, double e) { if (v) a.add((int)bl, c, e); }
                  __device__ void finish(double* ll, uint32_t* ob) const { for (int i = 0; i < 4; i++) { ll[i] = a.s[i]; ob[i] = a.obs[i]; } } } acc;
-#endif
         acc.reset();
         for (unsigned long long m = members; m; m &= m - 1) {
           const uint32_t r = (uint32_t)__builtin_ctzll(m);
