@@ -4,6 +4,7 @@
 #include <stdexcept>
 #include <cstring>
 #include <string>
+#include <thread>
 #include "engine.h"
 #include "fastpath.h"
 #include "host_common.h"
@@ -140,6 +141,8 @@ fgx_caller* fgx_create(const fgx_options* opts) {
 
 void fgx_destroy(fgx_caller* c) {
   if (!c) return;
+  for (fgx_caller* w : c->workers) fgx_destroy(w);
+  c->workers.clear();
   (void)hipSetDevice(c->device);
   for (DevBuf* b : {&c->d_tables, &c->d_umi_tables, &c->d_stage, &c->d_reads, &c->d_jobs, &c->d_tiles, &c->d_ob, &c->d_oq, &c->d_od,
                     &c->d_oe, &c->d_scratch_a, &c->d_scratch_b, &c->d_in_blob, &c->d_in_off, &c->d_in_len, &c->d_in_grp})
@@ -154,11 +157,86 @@ void fgx_destroy(fgx_caller* c) {
 // Host-input entry: upload once, run the device-resident pipeline, bring the records back, and send
 // only the families the fast path deferred through the general path, splicing both in group order.
 typedef int (*general_fn)(fgx_caller*, const uint8_t*, const uint64_t*, const uint32_t*, uint32_t, const uint32_t*, uint32_t, fgx_output*);
+
+// The general paths do their per-molecule work (filters, CIGAR majority, record assembly) on the host, one molecule after the
+// other.  Molecules are independent, so a large batch is cut into contiguous shards, one helper caller (own stream, own device
+// buffers) per host thread, and the shard outputs are concatenated in input order — what `--threads N` does in the reference
+// (one caller object per batch, simplex.rs:637-644).  FGX_HOST_THREADS overrides the thread count (1 = inline).
+static unsigned host_threads() {
+  if (const char* e = getenv("FGX_HOST_THREADS")) { int v = atoi(e); if (v >= 1) return (unsigned)(v > 256 ? 256 : v); }
+  unsigned hw = std::thread::hardware_concurrency();
+  return hw == 0 ? 1 : hw > 64 ? 64 : hw;
+}
+
+static int run_general(fgx_caller* c, general_fn fn, const uint8_t* records, const uint64_t* rec_off, const uint32_t* rec_len, uint32_t n_rec,
+                       const uint32_t* grp_first, uint32_t n_grp, fgx_output* out) {
+  constexpr uint32_t MIN_GROUPS = 512;              // below this a shard is not worth a thread
+  unsigned T = host_threads();
+  if (T > n_grp / MIN_GROUPS) T = n_grp / MIN_GROUPS;
+  if (T <= 1) return fn(c, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
+  while (c->workers.size() < T) {
+    fgx_options o = c->opt;
+    o.read_name_prefix = c->prefix.c_str(); o.read_group_id = c->rg.c_str(); o.device = c->device;
+    fgx_caller* w = fgx_create(&o);
+    if (!w) { c->err = std::string("general path worker: ") + fgx_global_error(); return 3; }
+    c->workers.push_back(w);
+  }
+  // contiguous shards balanced by record count
+  std::vector<uint32_t> bound(T + 1, n_grp);
+  bound[0] = 0;
+  {
+    const uint64_t total = grp_first[n_grp] - grp_first[0];
+    uint32_t g = 0;
+    for (unsigned t = 1; t < T; t++) {
+      const uint64_t want = grp_first[0] + total * t / T;
+      while (g < n_grp && grp_first[g] < want) g++;
+      bound[t] = g;
+    }
+  }
+  std::vector<fgx_output> outs(T);
+  std::vector<int> rcs(T, 0);
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < T; t++)
+    th.emplace_back([&, t]() {
+      fgx_caller* w = c->workers[t];
+      w->err.clear();
+      memset(&outs[t], 0, sizeof(fgx_output));
+      if (bound[t + 1] == bound[t]) return;
+      try {
+        hip_check(hipSetDevice(c->device), "hipSetDevice");
+        rcs[t] = fn(w, records, rec_off, rec_len, n_rec, grp_first + bound[t], bound[t + 1] - bound[t], &outs[t]);
+      } catch (const std::exception& ex) { w->err = ex.what(); rcs[t] = 3; }
+    });
+  for (auto& x : th) x.join();
+  for (unsigned t = 0; t < T; t++) if (rcs[t] != 0) { c->err = c->workers[t]->err; return rcs[t]; }
+  if (c->opt.caller_kind == FGX_CALLER_CODEC)        // counter-named reads depend on everything before them: redo in one piece
+    for (unsigned t = 0; t < T; t++) if (c->workers[t]->counter_names_used) return fn(c, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
+  c->out_data.clear(); c->out_rejects.clear();
+  c->grp_out_end.assign(n_grp, 0);
+  size_t total_data = 0, total_rej = 0;
+  for (unsigned t = 0; t < T; t++) { total_data += outs[t].data_len; total_rej += outs[t].rejects_len; }
+  c->out_data.reserve(total_data); c->out_rejects.reserve(total_rej);
+  memset(out, 0, sizeof(*out));
+  for (unsigned t = 0; t < T; t++) {
+    const size_t base = c->out_data.size();
+    const fgx_caller* w = c->workers[t];
+    if (outs[t].data_len) c->out_data.insert(c->out_data.end(), outs[t].data, outs[t].data + outs[t].data_len);
+    if (outs[t].rejects_len) c->out_rejects.insert(c->out_rejects.end(), outs[t].rejects, outs[t].rejects + outs[t].rejects_len);
+    for (uint32_t k = 0; k < bound[t + 1] - bound[t]; k++) c->grp_out_end[bound[t] + k] = base + (k < w->grp_out_end.size() ? w->grp_out_end[k] : outs[t].data_len);
+    out->count += outs[t].count; out->n_rejects += outs[t].n_rejects;
+    for (int i = 0; i < FGX_STATS_LEN; i++) out->stats[i] += outs[t].stats[i];
+    out->ms_host_prep = std::max(out->ms_host_prep, outs[t].ms_host_prep); out->ms_kernels = std::max(out->ms_kernels, outs[t].ms_kernels);
+    out->ms_h2d = std::max(out->ms_h2d, outs[t].ms_h2d); out->ms_emit = std::max(out->ms_emit, outs[t].ms_emit);
+  }
+  out->data = c->out_data.data(); out->data_len = c->out_data.size();
+  out->rejects = c->out_rejects.data(); out->rejects_len = c->out_rejects.size();
+  return 0;
+}
 static int process_hybrid(fgx_caller* c, general_fn general, const uint8_t* records, uint64_t records_len, const uint64_t* rec_off,
                           const uint32_t* rec_len, uint32_t n_rec, const uint32_t* grp_first, uint32_t n_grp, fgx_output* out) {
   using clk = std::chrono::steady_clock;
   auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-  if (c->opt.track_rejects || n_grp == 0) return general(c, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
+  if (c->opt.track_rejects || n_grp == 0) return run_general(c, general, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
   if (!c->fast) c->fast = new FastState();
   auto t0 = clk::now();
   hip_check(hipSetDevice(c->device), "hipSetDevice");
@@ -201,7 +279,7 @@ static int process_hybrid(fgx_caller* c, general_fn general, const uint8_t* reco
     d_grp.push_back((uint32_t)d_off.size());
   }
   fgx_output gen;
-  int rc = general(c, records, d_off.data(), d_len.data(), (uint32_t)d_off.size(), d_grp.data(), (uint32_t)def.size(), &gen);
+  int rc = run_general(c, general, records, d_off.data(), d_len.data(), (uint32_t)d_off.size(), d_grp.data(), (uint32_t)def.size(), &gen);
   if (rc != 0) return rc;
   std::vector<uint8_t> merged;
   merged.reserve(fr.out_len + c->out_data.size());
@@ -234,10 +312,10 @@ int fgx_process_batch(fgx_caller* c, const uint8_t* records, uint64_t records_le
     if (n_grp && grp_first[n_grp] > n_rec) { c->err = "fgx_process_batch: group boundaries exceed n_rec"; return 1; }
     switch (c->opt.caller_kind) {
       case FGX_CALLER_SIMPLEX:
-        if (c->general_only) return simplex_process_general(c, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
+        if (c->general_only) return run_general(c, simplex_process_general, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
         return process_hybrid(c, simplex_process_general, records, records_len, rec_off, rec_len, n_rec, grp_first, n_grp, out);
       case FGX_CALLER_DUPLEX:
-        if (c->general_only) return duplex_process_general(c, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
+        if (c->general_only) return run_general(c, duplex_process_general, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
         if (c->opt.duplex_min_reads[1] > c->opt.duplex_min_reads[0] || c->opt.duplex_min_reads[2] > c->opt.duplex_min_reads[1])
           return duplex_process_general(c, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);   // raises the reference's error
         return process_hybrid(c, duplex_process_general, records, records_len, rec_off, rec_len, n_rec, grp_first, n_grp, out);
@@ -246,7 +324,7 @@ int fgx_process_batch(fgx_caller* c, const uint8_t* records, uint64_t records_le
         // the device pipeline emits every molecule that passes the geometry gates: only valid while the duplex-disagreement
         // thresholds cannot reject anything (their defaults); otherwise the general path decides after the strand combine
         if (c->general_only || c->opt.codec_max_duplex_disagreements != 0xFFFFFFFFu || c->opt.codec_max_duplex_disagreement_rate < 1.0)
-          return codec_process_general(c, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
+          return run_general(c, codec_process_general, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
         return process_hybrid(c, codec_process_general, records, records_len, rec_off, rec_len, n_rec, grp_first, n_grp, out);
 #endif
       default: c->err = "fgx_process_batch: caller kind not implemented"; return 1;

@@ -207,6 +207,7 @@ int codec_process_general(fgx_caller* c, const uint8_t* blob, const uint64_t* re
   B.clear();
   c->out_data.clear(); c->out_rejects.clear();
   c->grp_out_end.assign(n_grp, 0);
+  c->counter_names_used = false;
   c->err.clear();
   std::vector<Group> groups(n_grp);
   std::vector<uint8_t> tb, tq;
@@ -435,6 +436,7 @@ int codec_process_general(fgx_caller* c, const uint8_t* blob, const uint64_t* re
           // build_output_record_into (:1590-1757)
           counter++;
           std::string name = G.has_umi ? c->prefix + ":" + G.umi : c->prefix + ":" + std::to_string(counter);
+          if (!G.has_umi) c->counter_names_used = true;
           std::vector<uint8_t> r;
           if (!build_unmapped_record(r, name, bam::F_UNMAPPED, cs.b.data(), cs.q.data(), (uint32_t)L)) {
             c->err = "could not write the consensus record for read '" + name + "': read name too long";

@@ -105,6 +105,8 @@ struct fgx_caller {
   std::vector<uint8_t> out_data, out_rejects;
   std::vector<uint64_t> grp_out_end;      // general path: cumulative out_data size after each group
   bool general_only = false;
+  bool counter_names_used = false;          // CODEC general path: a read was named by the running counter (no MI): order-dependent
+  std::vector<fgx_caller*> workers;         // helper callers (own stream and buffers) of the multi-threaded general path
   struct FastState* fast = nullptr;        // device-resident pipeline state (fastpath.hip)
   fgx::DevBuf d_in_blob, d_in_off, d_in_len, d_in_grp;   // host-input staging for fgx_process_batch
 
