@@ -134,6 +134,16 @@ class GroupedReads:
         a, b = int(self.grp_first[g]), int(self.grp_first[g + 1])
         return [bytes(self.blob[int(self.rec_off[r]): int(self.rec_off[r]) + int(self.rec_len[r])]) for r in range(a, b)]
 
+    def to_device(self, device=None) -> "DeviceGroupedReads":
+        """Upload to HBM (torch tensors own the memory) for `process_batch_device`."""
+        import torch
+        dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        pad = np.zeros(16, dtype=np.uint8)
+        blob = torch.from_numpy(np.concatenate([self.blob, pad])).to(dev)
+        return DeviceGroupedReads(blob, int(self.blob.size), torch.from_numpy(self.rec_off.astype(np.int64)).to(dev),
+                                  torch.from_numpy(self.rec_len.astype(np.int32)).to(dev), torch.from_numpy(self.grp_first.astype(np.int32)).to(dev),
+                                  self.n_rec, self.n_grp)
+
     def subset(self, g0: int, g1: int) -> "GroupedReads":
         return GroupedReads.from_groups([self.records(g) for g in range(g0, g1)])
 

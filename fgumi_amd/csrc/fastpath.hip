@@ -39,6 +39,7 @@ namespace {
 constexpr int NT = 256;                 // threads per family workgroup
 constexpr int FAST_MAX_READS = 128;     // per-read LDS tables
 constexpr int MAX_MC_OPS = 8;
+constexpr uint32_t MAX_CIG_OPS = 6;     // clips + aligned ops of a read the device pipelines take
 constexpr int STAT_SLOTS = 1024;        // spread the per-batch counters over many addresses (atomic contention)
 
 struct ReadInfo {          // LDS, one per record of the family
@@ -816,6 +817,7 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
   int32_t pos = 0, ref_id = 0;
   uint32_t mi_lo = 0, mi_len = 0, rx_lo = 0, rx_len = 0, cb_lo = 0, cb_len = 0;   // LDS offsets of tag values
   bool has_mi = false, has_rx = false, has_cb = false, excluded = false, bad = false;
+  uint32_t lead_s = 0, m_len = 0;   // query offset of the first aligned base, length of the aligned block
   uint32_t strand = 0;   // duplex: 1 = MI ends in /A, 2 = /B
   if (act) {
     const uint32_t h2 = ld32u(W, lo + 8), h3 = ld32u(W, lo + 12);
@@ -833,14 +835,32 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
       excluded = (flags & (bam::F_SECONDARY | bam::F_SUPPLEMENTARY)) != 0;
       if (MODE == 1 && excluded) bad = true;   // the duplex caller has no secondary/supplementary filter: general path
       if (MODE == 2 && (excluded || !(flags & bam::F_PAIRED))) bad = true;   // CODEC: fragments / non-primary records take the general path
-      uint32_t op = 0;
+      // CIGAR: one aligned block of M/=/X ops, optionally between soft / hard clips (what an aligner gives a read without
+      // indels).  Such reads all simplify to (M, length) for the alignment filter; clips only shift query offsets.
+      uint32_t ops[MAX_CIG_OPS];
+      ops[0] = 0;
       if (!excluded) {
-        if ((flags & bam::F_UNMAPPED) || n_cig != 1 || l_seq == 0 || pos < 0) bad = true;
-        else {
-          op = ld32u(W, lo + 32 + l_name);
-          uint32_t ty = op & 15;
-          if (!(ty == 0 || ty == 7 || ty == 8) || (op >> 4) != l_seq) bad = true;
-        }
+        if ((flags & bam::F_UNMAPPED) || n_cig == 0 || l_seq == 0 || pos < 0) bad = true;
+        else if (n_cig == 1) {
+          ops[0] = ld32u(W, lo + 32 + l_name);
+          const uint32_t ty = ops[0] & 15;
+          if (!(ty == 0 || ty == 7 || ty == 8) || (ops[0] >> 4) != l_seq) bad = true;
+          m_len = l_seq;
+        } else if (MODE != 2 && n_cig <= MAX_CIG_OPS) {
+          uint32_t phase = 0, trail_s = 0;          // 0: leading clips, 1: aligned block, 2: trailing clips
+          bool okc = true;
+#pragma unroll
+          for (uint32_t i = 0; i < MAX_CIG_OPS; i++) {
+            if (i >= n_cig) break;
+            const uint32_t o = ld32u(W, lo + 32 + l_name + 4 * i), t = o & 15, ln = o >> 4;
+            ops[i] = o;
+            if (t == 0 || t == 7 || t == 8) { if (phase == 2) okc = false; phase = 1; m_len += ln; }
+            else if (t == 4) { if (phase == 0) lead_s += ln; else { phase = 2; trail_s += ln; } }
+            else if (t == 5) { if (phase == 1) phase = 2; }
+            else okc = false;                         // I, D, N, P: the general path
+          }
+          if (!okc || m_len == 0 || m_len > 65535 || (unsigned long long)lead_s + m_len + trail_s != l_seq) bad = true;
+        } else bad = true;
       }
       // aux walk in LDS (tags.rs:13-34): first occurrence of MC / <tag> / RX / <cell tag>
       const uint32_t a0 = lo + (uint32_t)aux_off, an = len - (uint32_t)aux_off;
@@ -890,7 +910,7 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
         // coordinates are in the ordinary range (no saturating arithmetic can trigger); general code otherwise.
         bool fastclip = false;
         uint32_t ML = 0;
-        if (has_mc && mc_len >= 2 && mc_len <= 8) {
+        if (n_cig == 1 && has_mc && mc_len >= 2 && mc_len <= 8) {
           unsigned long long v = ld64u(W, mc_lo);
           uint32_t k = 0, val = 0;
           while (k < mc_len - 1) { uint32_t ch = (uint32_t)(v >> (8 * k)) & 0xFF; if (ch < '0' || ch > '9') break; val = val * 10 + (ch - '0'); k++; }
@@ -928,7 +948,7 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
           uint32_t mops[MAX_MC_OPS];
           bool overflow = false;
           bam::Rec v{W + lo, len};
-          unsigned long long cl = bam::mate_clip(v, &op, 1, has_mc ? W + mc_lo : nullptr, mc_len, mops, MAX_MC_OPS, &overflow);
+          unsigned long long cl = bam::mate_clip(v, ops, n_cig, has_mc ? W + mc_lo : nullptr, mc_len, mops, MAX_MC_OPS, &overflow);
           if (overflow) bad = true;
           clip = (uint32_t)(cl > 65535 ? 65535 : cl);
         }
@@ -1005,13 +1025,13 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
     // of the per-pair overlap lengths) and taken 64 at a time, so short overlaps of several pairs share an iteration.
     const int msrc = mate >= 0 ? mate : (int)lane;
     const int32_t pos_b = (int32_t)__shfl((int)pos, msrc), ref_b = (int32_t)__shfl((int)ref_id, msrc);
-    const uint32_t lseq_b = (uint32_t)__shfl((int)l_seq, msrc);
+    const uint32_t aln_a = lead_s | (m_len << 16), aln_b = (uint32_t)__shfl((int)aln_a, msrc);   // query offset of the aligned block | its length
     const uint32_t dsc_a = seq_lo | (qual_lo << 16), dsc_b = (uint32_t)__shfl((int)dsc_a, msrc);
     uint32_t cntp = 0, off1 = 0, off2 = 0;
     if (mate >= 0 && ref_id == ref_b) {
-      const long long s1 = (long long)pos + 1, e1 = (long long)pos + l_seq, s2 = (long long)pos_b + 1, e2 = (long long)pos_b + lseq_b;
+      const long long s1 = (long long)pos + 1, e1 = (long long)pos + (aln_a >> 16), s2 = (long long)pos_b + 1, e2 = (long long)pos_b + (aln_b >> 16);
       const long long lox = s1 > s2 ? s1 : s2, hix = e1 < e2 ? e1 : e2;
-      if (hix >= lox) { cntp = (uint32_t)(hix - lox + 1); off1 = (uint32_t)(lox - s1); off2 = (uint32_t)(lox - s2); }
+      if (hix >= lox) { cntp = (uint32_t)(hix - lox + 1); off1 = (uint32_t)(lox - s1) + (aln_a & 0xFFFF); off2 = (uint32_t)(lox - s2) + (aln_b & 0xFFFF); }
     }
     uint32_t incl = cntp;
 #pragma unroll

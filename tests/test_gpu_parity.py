@@ -259,3 +259,42 @@ def test_fatal_errors_match_reference(handle):
         c.consensus_reads([bamutil.frag("x", "ACGT", 30, "U" * 300)])
     assert c.consensus_reads([]).count == 0
     c.close()
+
+
+def _clipped_groups():
+    """Families whose reads carry soft / hard clips around ONE aligned block (what an aligner gives a read without indels):
+    overlapping mates, clips on either end and strand, =/X ops, MC tags with clips, fragments."""
+    import random
+    rng = random.Random(11)
+    tmpl = "".join(rng.choice("ACGT") for _ in range(600))
+    groups = []
+
+    def pr(name, p1, c1, p2, c2, q1=32, q2=30, mi="m", **kw):
+        def qlen(c):
+            return sum(o >> 4 for o in bamutil.cigar_ops(c) if (o & 15) in (0, 1, 4, 7, 8))
+        return list(bamutil.pair(name, tmpl[p1:p1 + qlen(c1)], q1, tmpl[p2:p2 + qlen(c2)], q2, mi, pos1=1000 + p1, pos2=1000 + p2, cigar1=c1, cigar2=c2, **kw))
+
+    groups.append(pr("a", 0, "5S95M", 60, "90M10S", mi="c1") + pr("b", 0, "5S95M", 60, "90M10S", q1=35, q2=28, mi="c1") + pr("c", 0, "100M", 60, "100M", mi="c1"))
+    groups.append(pr("a", 10, "3H4S50=1X45=2S", 40, "2S98M5H", mi="c2", rx="ACGT-AAAA") + pr("b", 10, "7S96M2S", 40, "2S98M", mi="c2", rx="ACGT-AAAT"))
+    groups.append(pr("a", 0, "20S80M", 30, "70M30S", mi="c3") + pr("b", 0, "100M", 30, "100M", mi="c3") + pr("c", 2, "10S90M", 35, "95M5S", mi="c3"))
+    groups.append([bamutil.frag("f1", tmpl[:80], 33, "c4", cigar="10S70M"), bamutil.frag("f2", tmpl[:80], 30, "c4", cigar="80M"),
+                   bamutil.frag("f3", tmpl[:80], 31, "c4", cigar="5H10S60M10S", flag=0x10)])
+    groups.append(pr("a", 100, "50M50S", 110, "40S60M", mi="c5") + pr("b", 100, "100M", 110, "100M", mi="c5"))      # read-through shaped clips
+    return GroupedReads.from_groups(groups)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(min_reads=2), dict(overlapping=False), dict(trim=True, min_input_base_quality=31)])
+def test_clipped_single_block_cigars(kw):
+    _assert_same(_clipped_groups(), **kw)
+
+
+def test_clipped_single_block_cigars_stay_on_the_device():
+    if MODE["general_only"]:
+        pytest.skip("device-resident entry only")
+    g = _clipped_groups()
+    c = VanillaUmiConsensusCaller("", "A", VanillaUmiConsensusOptions(min_reads=1, min_consensus_base_quality=2, cell_tag="CB"), overlapping_consensus=True)
+    out = c.process_batch_device(g.to_device())
+    want = _oracle(g, min_reads=1)
+    assert out.n_deferred == 0
+    assert out.count == want["count"] and out.to_host() == want["data"]
+    c.close()
