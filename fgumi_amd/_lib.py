@@ -36,6 +36,12 @@ class Output(C.Structure):
     ]
 
 
+class GroupOptions(C.Structure):
+    """`fgx_group_options` (include/fgumi_amd.h)."""
+    _fields_ = [("tag", C.c_char * 2), ("cell_tag", C.c_char * 2), ("strip_strand_suffix", C.c_uint8), ("allow_unmapped", C.c_uint8),
+                ("_pad", C.c_uint8 * 2)]
+
+
 class SimParams(C.Structure):
     _fields_ = [
         ("seed", C.c_uint64), ("n_families", C.c_uint32), ("read_length", C.c_uint32), ("family_size", C.c_uint32),
@@ -47,7 +53,7 @@ class SimParams(C.Structure):
 # every symbol include/fgumi_amd.h declares
 EXPORTS = ["fgx_options_default", "fgx_create", "fgx_destroy", "fgx_last_error", "fgx_global_error", "fgx_process_batch",
            "fgx_process_batch_device", "fgx_call_columns", "fgx_device_libm", "fgx_get_table", "fgx_sim_sizes",
-           "fgx_sim_generate_host", "fgx_sim_generate_device"]
+           "fgx_sim_generate_host", "fgx_sim_generate_device", "fgx_group_records", "fgx_group_records_device"]
 
 _lib = None
 
@@ -96,6 +102,10 @@ def load():
     L.fgx_sim_generate_host.restype = I
     L.fgx_sim_generate_device.argtypes = [VP, P(SimParams), VP, VP, VP, VP]
     L.fgx_sim_generate_device.restype = I
+    L.fgx_group_records.argtypes = [VP, P(GroupOptions), VP, U64, VP, VP, U32, VP, VP, VP, P(U32), P(U32)]
+    L.fgx_group_records.restype = I
+    L.fgx_group_records_device.argtypes = [VP, P(GroupOptions), VP, U64, VP, VP, U32, VP, VP, VP, P(U32), P(U32)]
+    L.fgx_group_records_device.restype = I
     # host-only helpers (not part of the public header; used by CPU-side tests)
     L.fgx_build_tables_host.argtypes = [U8, U8, I, VP, P(U32), VP]
     L.fgx_build_tables_host.restype = I

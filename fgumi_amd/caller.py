@@ -17,7 +17,7 @@ from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 
-from ._lib import Options, Output, SimParams, lib, load
+from ._lib import GroupOptions, Options, Output, SimParams, lib, load
 
 
 class RejectionReason(enum.IntEnum):
@@ -282,6 +282,44 @@ class _HandleCaller(ConsensusCaller):
         """Route every family through the general host-orchestrated path (default: device-resident fast
         path, general path only for the families it defers)."""
         lib.fgx_set_general_only(self._h, int(on))
+
+    # ---- MI grouping (mi_group.rs MiGrouper + the commands' pre-group record filter) ---------------
+    def group_records(self, blob: np.ndarray, rec_off: np.ndarray, rec_len: np.ndarray, tag: str = "MI", cell_tag: Optional[str] = "CB",
+                      strip_strand_suffix: bool = False, allow_unmapped: bool = False) -> GroupedReads:
+        """Which records a consensus command keeps and where the MI groups start, computed on the device from host
+        buffers: drop-in for `MiGrouper::add_records`; the result feeds `process_batch` directly."""
+        o = GroupOptions(tag.encode(), cell_tag.encode() if cell_tag else b"\0\0", int(strip_strand_suffix), int(allow_unmapped))
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        rec_off = np.ascontiguousarray(rec_off, dtype=np.uint64)
+        rec_len = np.ascontiguousarray(rec_len, dtype=np.uint32)
+        n = len(rec_off)
+        out_off = np.zeros(max(1, n), dtype=np.uint64)
+        out_len = np.zeros(max(1, n), dtype=np.uint32)
+        grp = np.zeros(n + 1, dtype=np.uint32)
+        nk, ng = C.c_uint32(), C.c_uint32()
+        rc = lib.fgx_group_records(self._h, C.byref(o), blob.ctypes.data, blob.size, rec_off.ctypes.data, rec_len.ctypes.data, n,
+                                   out_off.ctypes.data, out_len.ctypes.data, grp.ctypes.data, C.byref(nk), C.byref(ng))
+        if rc != 0:
+            raise RuntimeError(lib.fgx_last_error(self._h).decode())
+        return GroupedReads(blob, out_off[:nk.value].copy(), out_len[:nk.value].copy(), grp[:ng.value + 1].copy())
+
+    def group_records_device(self, dg: "DeviceGroupedReads", tag: str = "MI", cell_tag: Optional[str] = "CB", strip_strand_suffix: bool = False,
+                             allow_unmapped: bool = False) -> "DeviceGroupedReads":
+        """Same on a record stream resident in HBM (`dg.grp_first` is ignored); returns a new DeviceGroupedReads over the same blob."""
+        import torch
+        o = GroupOptions(tag.encode(), cell_tag.encode() if cell_tag else b"\0\0", int(strip_strand_suffix), int(allow_unmapped))
+        dev = dg.blob.device
+        n = dg.n_rec
+        out_off = torch.empty(max(1, n), dtype=torch.int64, device=dev)
+        out_len = torch.empty(max(1, n), dtype=torch.int32, device=dev)
+        grp = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize(dev)
+        nk, ng = C.c_uint32(), C.c_uint32()
+        rc = lib.fgx_group_records_device(self._h, C.byref(o), dg.blob.data_ptr(), dg.blob_len, dg.rec_off.data_ptr(), dg.rec_len.data_ptr(), n,
+                                          out_off.data_ptr(), out_len.data_ptr(), grp.data_ptr(), C.byref(nk), C.byref(ng))
+        if rc != 0:
+            raise RuntimeError(lib.fgx_last_error(self._h).decode())
+        return DeviceGroupedReads(dg.blob, dg.blob_len, out_off, out_len, grp, nk.value, ng.value)
 
     # ---- device-resident batch (inputs and outputs stay in HBM) ---------------------------------
     def process_batch_device(self, dg: "DeviceGroupedReads"):

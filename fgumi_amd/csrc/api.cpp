@@ -361,6 +361,50 @@ int fgx_process_batch_device(fgx_caller* c, const void* d_records, uint64_t reco
   } catch (const std::exception& ex) { c->err = ex.what(); return 3; }
 }
 
+int fgx_group_records_device(fgx_caller* c, const fgx_group_options* g, const void* d_records, uint64_t records_len, const void* d_rec_off,
+                             const void* d_rec_len, uint32_t n_rec, void* d_out_rec_off, void* d_out_rec_len, void* d_grp_first,
+                             uint32_t* n_kept, uint32_t* n_grp) {
+  if (!c || !g || !n_kept || !n_grp) return 1;
+  c->err.clear();
+  try {
+    hip_check(hipSetDevice(c->device), "hipSetDevice");
+    return group_records_device(c, g, (const uint8_t*)d_records, records_len, (const uint64_t*)d_rec_off, (const uint32_t*)d_rec_len, n_rec,
+                                (uint64_t*)d_out_rec_off, (uint32_t*)d_out_rec_len, (uint32_t*)d_grp_first, n_kept, n_grp);
+  } catch (const std::exception& ex) { c->err = ex.what(); return 3; }
+}
+
+// host buffers: upload, group on the device, download (the staging buffers of fgx_process_batch are reused, so a following
+// fgx_process_batch on the same records could skip its upload in a later revision)
+int fgx_group_records(fgx_caller* c, const fgx_group_options* g, const uint8_t* records, uint64_t records_len, const uint64_t* rec_off,
+                      const uint32_t* rec_len, uint32_t n_rec, uint64_t* out_rec_off, uint32_t* out_rec_len, uint32_t* grp_first,
+                      uint32_t* n_kept, uint32_t* n_grp) {
+  if (!c || !g || !n_kept || !n_grp) return 1;
+  c->err.clear();
+  try {
+    hip_check(hipSetDevice(c->device), "hipSetDevice");
+    for (uint32_t r = 0; r < n_rec; r++)
+      if (rec_off[r] + rec_len[r] > records_len) { c->err = "fgx_group_records: record outside the blob"; return 1; }
+    c->d_in_blob.reserve(records_len + 16);
+    c->d_in_off.reserve((size_t)n_rec * 8 + 8);
+    c->d_in_len.reserve((size_t)n_rec * 4 + 4);
+    c->d_in_grp.reserve((size_t)(n_rec + 1) * 4);
+    c->d_stage.reserve((size_t)n_rec * 8 + 8);
+    c->d_reads.reserve((size_t)n_rec * 4 + 4);
+    hip_check(hipMemcpyAsync(c->d_in_blob.p, records, records_len, hipMemcpyHostToDevice, c->stream), "H2D blob");
+    hip_check(hipMemcpyAsync(c->d_in_off.p, rec_off, (size_t)n_rec * 8, hipMemcpyHostToDevice, c->stream), "H2D rec_off");
+    hip_check(hipMemcpyAsync(c->d_in_len.p, rec_len, (size_t)n_rec * 4, hipMemcpyHostToDevice, c->stream), "H2D rec_len");
+    int rc = group_records_device(c, g, c->d_in_blob.as<uint8_t>(), records_len, c->d_in_off.as<uint64_t>(), c->d_in_len.as<uint32_t>(), n_rec,
+                                  c->d_stage.as<uint64_t>(), c->d_reads.as<uint32_t>(), c->d_in_grp.as<uint32_t>(), n_kept, n_grp);
+    if (rc != 0) return rc;
+    if (*n_kept) {
+      hip_check(hipMemcpy(out_rec_off, c->d_stage.p, (size_t)*n_kept * 8, hipMemcpyDeviceToHost), "D2H rec_off");
+      hip_check(hipMemcpy(out_rec_len, c->d_reads.p, (size_t)*n_kept * 4, hipMemcpyDeviceToHost), "D2H rec_len");
+    }
+    hip_check(hipMemcpy(grp_first, c->d_in_grp.p, (size_t)(*n_grp + 1) * 4, hipMemcpyDeviceToHost), "D2H grp_first");
+    return 0;
+  } catch (const std::exception& ex) { c->err = ex.what(); return 3; }
+}
+
 // 1: route everything through the general host path (parity tests of that path); 0: hybrid (default)
 void fgx_set_general_only(fgx_caller* c, int on) { if (c) c->general_only = on != 0; }
 // dynamic LDS bytes of the large-family launch of the family kernel (default 48 KiB)

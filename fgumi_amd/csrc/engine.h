@@ -121,6 +121,10 @@ int simplex_process_general(fgx_caller* c, const uint8_t* blob, const uint64_t* 
 // duplex_host.cpp / codec_host.cpp — general paths of the duplex and CODEC callers
 int duplex_process_general(fgx_caller* c, const uint8_t* blob, const uint64_t* rec_off, const uint32_t* rec_len, uint32_t n_rec,
                            const uint32_t* grp_first, uint32_t n_grp, fgx_output* out);
+// grouping.hip — MI grouping on the device
+int group_records_device(fgx_caller* c, const fgx_group_options* o, const uint8_t* d_blob, uint64_t blob_len, const uint64_t* d_rec_off,
+                         const uint32_t* d_rec_len, uint32_t n, uint64_t* d_out_off, uint32_t* d_out_len, uint32_t* d_grp_first, uint32_t* n_kept,
+                         uint32_t* n_grp);
 int codec_process_general(fgx_caller* c, const uint8_t* blob, const uint64_t* rec_off, const uint32_t* rec_len, uint32_t n_rec,
                           const uint32_t* grp_first, uint32_t n_grp, fgx_output* out);
 }

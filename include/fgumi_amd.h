@@ -183,6 +183,27 @@ typedef struct fgx_sim_params {
                                mates agree — the CODEC workload; 0 keeps the reference simulator's RC(template) bytes */
 } fgx_sim_params;
 
+/* MI grouping of a record stream — replaces `MiGrouper::add_records` / `MiGroupIterator` (src/lib/mi_group.rs:227-310, 414-520)
+ * together with the pre-group record filter of the consensus commands (src/lib/commands/common.rs:384-397): records are
+ * kept unless secondary / supplementary (always), unmapped (unless allow_unmapped) or without the group tag; a group is a
+ * run of consecutive kept records with an equal key, key = tag value (cut at its last '/' when strip_strand_suffix is set:
+ * duplex, crates/fgumi-umi/src/lib.rs:370-375) + '\t' + cell-tag value when cell_tag is configured.  Produces exactly the
+ * arrays fgx_process_batch takes: the kept records' offsets / lengths (input order) and grp_first[n_grp + 1].
+ * Output arrays must hold n_rec (+1 for grp_first) entries.  The *_device variant takes and fills device pointers. */
+typedef struct fgx_group_options {
+  char    tag[2];               /* "MI" */
+  char    cell_tag[2];          /* "CB" for all three commands; {0,0} = none */
+  uint8_t strip_strand_suffix;  /* 1 for duplex */
+  uint8_t allow_unmapped;       /* --allow-unmapped */
+  uint8_t _pad[2];
+} fgx_group_options;
+int fgx_group_records_device(fgx_caller* c, const fgx_group_options* g, const void* d_records, uint64_t records_len, const void* d_rec_off,
+                             const void* d_rec_len, uint32_t n_rec, void* d_out_rec_off, void* d_out_rec_len, void* d_grp_first,
+                             uint32_t* n_kept, uint32_t* n_grp);
+int fgx_group_records(fgx_caller* c, const fgx_group_options* g, const uint8_t* records, uint64_t records_len, const uint64_t* rec_off,
+                      const uint32_t* rec_len, uint32_t n_rec, uint64_t* out_rec_off, uint32_t* out_rec_len, uint32_t* grp_first,
+                      uint32_t* n_kept, uint32_t* n_grp);
+
 /* Sizes for a parameter set: total blob bytes (records WITH block_size prefixes) and record count. */
 int fgx_sim_sizes(const fgx_sim_params* p, uint64_t* blob_len, uint64_t* n_rec);
 /* Host generation into caller-provided arrays (blob_len bytes; n_rec offsets/lengths; n_families+1 firsts). */

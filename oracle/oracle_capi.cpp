@@ -193,6 +193,33 @@ extern "C" {
 
 const char* orc_last_error() { return g_err.c_str(); }
 
+// MiGrouper::add_records with the consensus commands' record filter (src/lib/mi_group.rs:227-310;
+// src/lib/commands/common.rs:384-397; crates/fgumi-umi/src/lib.rs:370-375).  Fills the kept records' offsets / lengths and
+// grp_first[n_grp + 1]; returns n_grp, *n_kept = kept records.
+uint32_t orc_group_records(const fgx_group_options* o, const uint8_t* blob, const uint64_t* rec_off, const uint32_t* rec_len, uint32_t n_rec,
+                           uint64_t* out_off, uint32_t* out_len, uint32_t* grp_first, uint32_t* n_kept) {
+  bool have = false;
+  std::string current;
+  uint32_t nk = 0, ng = 0;
+  for (uint32_t r = 0; r < n_rec; r++) {
+    RecView v(blob + rec_off[r], rec_len[r]);
+    if (rec_len[r] < 32) continue;
+    uint16_t f = v.flags();
+    if ((f & flags::SECONDARY) || (f & flags::SUPPLEMENTARY)) continue;          // consensus_pregroup_keep_flags
+    if (!o->allow_unmapped && (f & flags::UNMAPPED)) continue;
+    Slice mi = find_string_tag(v.aux(), o->tag);
+    if (!mi.some) continue;                                                      // records without the tag are skipped
+    std::string key = mi.str();
+    if (o->strip_strand_suffix) { size_t sl = key.rfind('/'); if (sl != std::string::npos && sl > 0) key.resize(sl); }   // extract_mi_base
+    if (o->cell_tag[0]) { key.push_back('\t'); Slice cb = find_string_tag(v.aux(), o->cell_tag); if (cb.some) key += cb.str(); }
+    if (!have || key != current) { grp_first[ng++] = nk; current = key; have = true; }
+    out_off[nk] = rec_off[r]; out_len[nk] = rec_len[r]; nk++;
+  }
+  grp_first[ng] = nk;
+  *n_kept = nk;
+  return ng;
+}
+
 // Whole input, mirroring `--threads T`: batches of `batch_groups` MI groups (50 simplex / 100
 // duplex / 1000 codec in the reference), one caller object per batch, batches pulled by T worker
 // threads, output concatenated in input order.  threads <= 1 runs inline.

@@ -37,6 +37,7 @@ def _load():
         "orc_quality_trim_point": (U32, [VP, U32, U8]), "orc_consensus_umis": (C.c_int, [CP, VP, U32]),
         "orc_overlap_pair": (C.c_int, [VP, U32, VP, U32, VP]),
         "orc_sweep_fast_vs_full": (U64, [C.c_int, P(U64)]),
+        "orc_group_records": (U32, [VP, VP, VP, VP, U32, VP, VP, VP, P(U32)]),
     }
     for name, (res, args) in sig.items():
         if hasattr(lib, name):
@@ -121,3 +122,19 @@ def process(opts, blob, rec_off, rec_len, grp_first, batch_groups=50, threads=1)
         return dict(data=data, count=lib.orc_result_count(h), stats=stats, rejects=rej, n_rejects=lib.orc_result_n_rejects(h))
     finally:
         lib.orc_result_free(h)
+
+
+class GroupOptions(C.Structure):
+    _fields_ = [("tag", C.c_char * 2), ("cell_tag", C.c_char * 2), ("strip_strand_suffix", C.c_uint8), ("allow_unmapped", C.c_uint8), ("_pad", C.c_uint8 * 2)]
+
+
+def group_records(blob, rec_off, rec_len, tag=b"MI", cell_tag=b"CB", strip_strand_suffix=False, allow_unmapped=False):
+    """MiGrouper restatement: returns (kept rec_off, kept rec_len, grp_first)."""
+    o = GroupOptions(tag, cell_tag or b"\0\0", int(strip_strand_suffix), int(allow_unmapped))
+    n = len(rec_off)
+    out_off = np.zeros(max(1, n), dtype=np.uint64)
+    out_len = np.zeros(max(1, n), dtype=np.uint32)
+    grp = np.zeros(n + 1, dtype=np.uint32)
+    nk = C.c_uint32()
+    ng = lib.orc_group_records(C.addressof(o), ptr(blob), ptr(rec_off), ptr(rec_len), n, ptr(out_off), ptr(out_len), ptr(grp), C.byref(nk))
+    return out_off[:nk.value].copy(), out_len[:nk.value].copy(), grp[:ng + 1].copy()
