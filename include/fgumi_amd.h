@@ -204,6 +204,50 @@ int fgx_group_records(fgx_caller* c, const fgx_group_options* g, const uint8_t* 
                       const uint32_t* rec_len, uint32_t n_rec, uint64_t* out_rec_off, uint32_t* out_rec_len, uint32_t* grp_first,
                       uint32_t* n_kept, uint32_t* n_grp);
 
+/* `fgumi filter` on a stream of unmapped consensus records — replaces the Process step of the filter command
+ * (src/lib/commands/filter.rs:581-625 single-read mode, :653-731 template mode) with `Filter::process_record_raw`
+ * (:762-940, no --ref, no methylation filters) and the fgumi-consensus filter functions it calls
+ * (crates/fgumi-consensus/src/filter.rs: filter_read :523-551, filter_duplex_read :558-637, mask_bases :765-811,
+ * mask_duplex_bases :824-923, mean_base_quality_full_length :688-705, compute_read_stats :646-671, template_passes
+ * :371-395, retained_primary_masked_bases :419-442) plus `reverse_per_base_tags_raw` (src/lib/tag_reversal.rs:27-67).
+ * Thresholds arrive already expanded to [duplex (CC), AB, BA] (FilterConfig::new, filter.rs:237-329; the single-strand
+ * thresholds are index 0).  Records are masked IN PLACE in `records` (the reference mutates its RawRecords the same way),
+ * then kept records are concatenated (each with its block_size prefix, template order R1,R2,supplementaries,secondaries as
+ * Template::from_records builds it, src/lib/template.rs:170-352) into `data`, rejected ones into `rejects` when
+ * track_rejects is set.  Errors are fatal like the reference's: a mapped record ("--ref is required ..."), a record
+ * without cD/cE ("... consensus calling tags (cD/cE) ..."), two primary R1s or R2s in a template. */
+typedef struct fgx_filter_options {
+  uint32_t struct_size;                   /* = sizeof(fgx_filter_options) */
+  uint32_t min_reads[3];                  /* --min-reads, expanded [CC, AB, BA] */
+  double   max_read_error_rate[3];        /* --max-read-error-rate (default 0.025) */
+  double   max_base_error_rate[3];        /* --max-base-error-rate (default 0.1) */
+  double   min_mean_base_quality;         /* --min-mean-base-quality when has_min_mean_base_quality */
+  double   max_no_call_fraction;          /* --max-no-call-fraction (default 0.2); >= 1.0 = absolute count */
+  uint8_t  has_min_base_quality, min_base_quality;   /* --min-base-quality (optional) */
+  uint8_t  has_min_mean_base_quality;
+  uint8_t  require_single_strand_agreement;           /* -s */
+  uint8_t  reverse_per_base_tags;                     /* -R */
+  uint8_t  filter_by_template;                        /* --filter-by-template (default true) */
+  uint8_t  track_rejects;                             /* --rejects given */
+  uint8_t  _pad;
+} fgx_filter_options;
+void fgx_filter_options_default(fgx_filter_options* o);   /* min_reads {1,1,1}; everything else the CLI defaults */
+
+typedef struct fgx_filter_output {
+  const uint8_t* data;      uint64_t data_len;      /* kept records (host entry: host memory; device entry: device memory) */
+  const uint8_t* rejects;   uint64_t rejects_len;   /* rejected records when track_rejects */
+  uint64_t records_count, passed_count, bases_masked;   /* FilterProcessedBatchRaw counters (filter.rs:226-238) */
+  uint64_t rejected_count;
+} fgx_filter_output;
+/* Host buffers in and out; `records` is NOT modified (the library masks its device copy).  Buffers in `out` stay valid
+ * until the next call on the handle. */
+int fgx_filter_records(fgx_caller* c, const fgx_filter_options* f, const uint8_t* records, uint64_t records_len, const uint64_t* rec_off,
+                       const uint32_t* rec_len, uint32_t n_rec, fgx_filter_output* out);
+/* Device buffers in (masked in place) and out.  rec_len == 0 entries are skipped (empty consensus slots), so the slot
+ * arrays of a device-resident consensus batch can be passed as they are. */
+int fgx_filter_records_device(fgx_caller* c, const fgx_filter_options* f, void* d_records, uint64_t records_len, const void* d_rec_off,
+                              const void* d_rec_len, uint32_t n_rec, fgx_filter_output* out);
+
 /* Sizes for a parameter set: total blob bytes (records WITH block_size prefixes) and record count. */
 int fgx_sim_sizes(const fgx_sim_params* p, uint64_t* blob_len, uint64_t* n_rec);
 /* Host generation into caller-provided arrays (blob_len bytes; n_rec offsets/lengths; n_families+1 firsts). */

@@ -14,6 +14,7 @@
 #ifdef ORC_WITH_CODEC
 #include "oracle_codec.hpp"
 #endif
+#include "oracle_filter.hpp"
 
 using namespace orc;
 
@@ -218,6 +219,48 @@ uint32_t orc_group_records(const fgx_group_options* o, const uint8_t* blob, cons
   grp_first[ng] = nk;
   *n_kept = nk;
   return ng;
+}
+
+// ---- `fgumi filter` restatement (oracle_filter.hpp) ----------------------------------------------------------------
+// Whole stream; the blob is copied first because masking is in place.  Returns a result handle or nullptr (orc_last_error).
+struct OrcFilterResult { orc_filter::BatchResult r; Bytes blob; };
+void* orc_filter_records(const fgx_filter_options* o, const uint8_t* blob, uint64_t blob_len, const uint64_t* rec_off, const uint32_t* rec_len, uint32_t n_rec) {
+  OrcFilterResult* res = new OrcFilterResult();
+  res->blob.assign(blob, blob + blob_len);
+  try { orc_filter::filter_stream(o, res->blob.data(), rec_off, rec_len, n_rec, res->r); }
+  catch (const OracleError& e) { g_err = e.what; delete res; return nullptr; }
+  return res;
+}
+const uint8_t* orc_filter_data(void* r) { return ((OrcFilterResult*)r)->r.data.data(); }
+uint64_t orc_filter_data_len(void* r) { return ((OrcFilterResult*)r)->r.data.size(); }
+const uint8_t* orc_filter_rejects(void* r) { return ((OrcFilterResult*)r)->r.rejects.data(); }
+uint64_t orc_filter_rejects_len(void* r) { return ((OrcFilterResult*)r)->r.rejects.size(); }
+void orc_filter_counts(void* r, uint64_t* out4) {
+  auto& b = ((OrcFilterResult*)r)->r;
+  out4[0] = b.records_count; out4[1] = b.passed_count; out4[2] = b.bases_masked; out4[3] = b.rejected_count;
+}
+void orc_filter_free(void* r) { delete (OrcFilterResult*)r; }
+// single functions, for replaying the reference's unit tests; thresholds as (min_reads, max_read_error_rate, max_base_error_rate)
+static orc_filter::Thr thr_of(const double* t) { return orc_filter::Thr{(uint64_t)t[0], t[1], t[2]}; }
+int64_t orc_filter_mask_bases(uint8_t* rec, uint32_t len, const double* thr, int has_minq, uint8_t minq) {
+  return (int64_t)orc_filter::mask_bases(rec, len, thr_of(thr), has_minq != 0, minq);
+}
+int64_t orc_filter_mask_duplex_bases(uint8_t* rec, uint32_t len, const double* cc, const double* ab, const double* ba, int has_minq, uint8_t minq, int ss) {
+  return (int64_t)orc_filter::mask_duplex_bases(rec, len, thr_of(cc), thr_of(ab), thr_of(ba), has_minq != 0, minq, ss != 0);
+}
+int orc_filter_read(const uint8_t* rec, uint32_t len, const double* thr) {   // 0 pass, 1 insufficient reads, 2 excessive error rate, -1 error
+  try { return (int)orc_filter::filter_read(RecView(rec, len).aux(), thr_of(thr)); } catch (const OracleError& e) { g_err = e.what; return -1; }
+}
+int orc_filter_duplex_read(const uint8_t* rec, uint32_t len, const double* cc, const double* ab, const double* ba) {
+  try { return (int)orc_filter::filter_duplex_read(RecView(rec, len).aux(), thr_of(cc), thr_of(ab), thr_of(ba)); }
+  catch (const OracleError& e) { g_err = e.what; return -1; }
+}
+int orc_filter_is_duplex(const uint8_t* rec, uint32_t len) { return orc_filter::is_duplex_consensus(RecView(rec, len).aux()); }
+int orc_filter_process_record(const fgx_filter_options* o, uint8_t* rec, uint32_t len, uint64_t* masked, int* pass) {
+  bool p = false;
+  try { orc_filter::process_record_raw(rec, len, o, *masked, p); } catch (const OracleError& e) { g_err = e.what; return -1; }
+  *pass = p;
+  return 0;
 }
 
 // Whole input, mirroring `--threads T`: batches of `batch_groups` MI groups (50 simplex / 100

@@ -38,6 +38,11 @@ def _load():
         "orc_overlap_pair": (C.c_int, [VP, U32, VP, U32, VP]),
         "orc_sweep_fast_vs_full": (U64, [C.c_int, P(U64)]),
         "orc_group_records": (U32, [VP, VP, VP, VP, U32, VP, VP, VP, P(U32)]),
+        "orc_filter_records": (VP, [VP, VP, U64, VP, VP, U32]), "orc_filter_data": (VP, [VP]), "orc_filter_data_len": (U64, [VP]),
+        "orc_filter_rejects": (VP, [VP]), "orc_filter_rejects_len": (U64, [VP]), "orc_filter_counts": (None, [VP, VP]), "orc_filter_free": (None, [VP]),
+        "orc_filter_mask_bases": (C.c_int64, [VP, U32, VP, C.c_int, U8]), "orc_filter_mask_duplex_bases": (C.c_int64, [VP, U32, VP, VP, VP, C.c_int, U8, C.c_int]),
+        "orc_filter_read": (C.c_int, [VP, U32, VP]), "orc_filter_duplex_read": (C.c_int, [VP, U32, VP, VP, VP]), "orc_filter_is_duplex": (C.c_int, [VP, U32]),
+        "orc_filter_process_record": (C.c_int, [VP, VP, U32, P(U64), P(C.c_int)]),
     }
     for name, (res, args) in sig.items():
         if hasattr(lib, name):
@@ -138,3 +143,85 @@ def group_records(blob, rec_off, rec_len, tag=b"MI", cell_tag=b"CB", strip_stran
     nk = C.c_uint32()
     ng = lib.orc_group_records(C.addressof(o), ptr(blob), ptr(rec_off), ptr(rec_len), n, ptr(out_off), ptr(out_len), ptr(grp), C.byref(nk))
     return out_off[:nk.value].copy(), out_len[:nk.value].copy(), grp[:ng + 1].copy()
+
+
+class FilterOptions(C.Structure):
+    """include/fgumi_amd.h fgx_filter_options."""
+    _fields_ = [("struct_size", C.c_uint32), ("min_reads", C.c_uint32 * 3), ("max_read_error_rate", C.c_double * 3), ("max_base_error_rate", C.c_double * 3),
+                ("min_mean_base_quality", C.c_double), ("max_no_call_fraction", C.c_double), ("has_min_base_quality", C.c_uint8), ("min_base_quality", C.c_uint8),
+                ("has_min_mean_base_quality", C.c_uint8), ("require_single_strand_agreement", C.c_uint8), ("reverse_per_base_tags", C.c_uint8),
+                ("filter_by_template", C.c_uint8), ("track_rejects", C.c_uint8), ("_pad", C.c_uint8)]
+
+
+def _three(v):
+    v = list(v) if isinstance(v, (list, tuple)) else [v]
+    return (v + [v[-1]] * 3)[:3]          # expand_three_from_last (filter.rs:20-27)
+
+
+def filter_options(min_reads=1, max_read_error_rate=0.025, max_base_error_rate=0.1, min_base_quality=None, min_mean_base_quality=None,
+                   max_no_call_fraction=0.2, require_single_strand_agreement=False, reverse_per_base_tags=False, filter_by_template=True,
+                   track_rejects=False):
+    o = FilterOptions()
+    o.struct_size = C.sizeof(FilterOptions)
+    o.min_reads[:] = _three(min_reads)
+    o.max_read_error_rate[:] = _three(max_read_error_rate)
+    o.max_base_error_rate[:] = _three(max_base_error_rate)
+    o.has_min_base_quality, o.min_base_quality = int(min_base_quality is not None), int(min_base_quality or 0)
+    o.has_min_mean_base_quality, o.min_mean_base_quality = int(min_mean_base_quality is not None), float(min_mean_base_quality or 0.0)
+    o.max_no_call_fraction = max_no_call_fraction
+    o.require_single_strand_agreement, o.reverse_per_base_tags = int(require_single_strand_agreement), int(reverse_per_base_tags)
+    o.filter_by_template, o.track_rejects = int(filter_by_template), int(track_rejects)
+    return o
+
+
+def _thr(t):
+    return (C.c_double * 3)(float(t[0]), float(t[1]), float(t[2]))
+
+
+def filter_records(o, blob, rec_off, rec_len):
+    """`fgumi filter` restatement over a record stream: dict(data, rejects, records, passed, masked, rejected)."""
+    r = lib.orc_filter_records(C.addressof(o), ptr(blob), len(blob), ptr(rec_off), ptr(rec_len), len(rec_off))
+    if not r:
+        raise RuntimeError(lib.orc_last_error().decode())
+    try:
+        cnt = (C.c_uint64 * 4)()
+        lib.orc_filter_counts(r, cnt)
+        return dict(data=C.string_at(lib.orc_filter_data(r), lib.orc_filter_data_len(r)), rejects=C.string_at(lib.orc_filter_rejects(r), lib.orc_filter_rejects_len(r)),
+                    records=cnt[0], passed=cnt[1], masked=cnt[2], rejected=cnt[3])
+    finally:
+        lib.orc_filter_free(r)
+
+
+def filter_mask_bases(rec, thr, min_base_quality=None):
+    buf = bytearray(rec)
+    a = (C.c_uint8 * len(buf)).from_buffer(buf)
+    n = lib.orc_filter_mask_bases(a, len(buf), _thr(thr), int(min_base_quality is not None), int(min_base_quality or 0))
+    return n, bytes(buf)
+
+
+def filter_mask_duplex_bases(rec, cc, ab, ba, min_base_quality=None, ss_agreement=False):
+    buf = bytearray(rec)
+    a = (C.c_uint8 * len(buf)).from_buffer(buf)
+    n = lib.orc_filter_mask_duplex_bases(a, len(buf), _thr(cc), _thr(ab), _thr(ba), int(min_base_quality is not None), int(min_base_quality or 0), int(ss_agreement))
+    return n, bytes(buf)
+
+
+def filter_read(rec, thr):
+    return lib.orc_filter_read(rec, len(rec), _thr(thr))
+
+
+def filter_duplex_read(rec, cc, ab, ba):
+    return lib.orc_filter_duplex_read(rec, len(rec), _thr(cc), _thr(ab), _thr(ba))
+
+
+def filter_is_duplex(rec):
+    return bool(lib.orc_filter_is_duplex(rec, len(rec)))
+
+
+def filter_process_record(o, rec):
+    buf = bytearray(rec)
+    a = (C.c_uint8 * len(buf)).from_buffer(buf)
+    masked, ok = C.c_uint64(), C.c_int()
+    if lib.orc_filter_process_record(C.addressof(o), a, len(buf), C.byref(masked), C.byref(ok)) != 0:
+        raise RuntimeError(lib.orc_last_error().decode())
+    return masked.value, bool(ok.value), bytes(buf)
