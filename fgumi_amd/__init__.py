@@ -9,3 +9,4 @@ from .caller import (ConsensusCaller, VanillaUmiConsensusCaller, DuplexConsensus
                      CodecConsensusStats, VanillaUmiConsensusOptions, ConsensusOutput,
                      ConsensusCallingStats, RejectionReason, GroupedReads, DeviceGroupedReads, DeviceOutput,
                      simulate_grouped_reads, split_records)
+from .filter import ConsensusFilter, FilterConfig, FilterThresholds, FilterResult, DeviceFilterResult, record_offsets  # noqa: F401,E402

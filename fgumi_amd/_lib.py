@@ -42,6 +42,20 @@ class GroupOptions(C.Structure):
                 ("_pad", C.c_uint8 * 2)]
 
 
+class FilterOptions(C.Structure):
+    """`fgx_filter_options` (include/fgumi_amd.h)."""
+    _fields_ = [("struct_size", C.c_uint32), ("min_reads", C.c_uint32 * 3), ("max_read_error_rate", C.c_double * 3), ("max_base_error_rate", C.c_double * 3),
+                ("min_mean_base_quality", C.c_double), ("max_no_call_fraction", C.c_double), ("has_min_base_quality", C.c_uint8), ("min_base_quality", C.c_uint8),
+                ("has_min_mean_base_quality", C.c_uint8), ("require_single_strand_agreement", C.c_uint8), ("reverse_per_base_tags", C.c_uint8),
+                ("filter_by_template", C.c_uint8), ("track_rejects", C.c_uint8), ("_pad", C.c_uint8)]
+
+
+class FilterOutput(C.Structure):
+    """`fgx_filter_output` (include/fgumi_amd.h)."""
+    _fields_ = [("data", C.c_void_p), ("data_len", C.c_uint64), ("rejects", C.c_void_p), ("rejects_len", C.c_uint64), ("records_count", C.c_uint64),
+                ("passed_count", C.c_uint64), ("bases_masked", C.c_uint64), ("rejected_count", C.c_uint64)]
+
+
 class SimParams(C.Structure):
     _fields_ = [
         ("seed", C.c_uint64), ("n_families", C.c_uint32), ("read_length", C.c_uint32), ("family_size", C.c_uint32),
@@ -53,7 +67,8 @@ class SimParams(C.Structure):
 # every symbol include/fgumi_amd.h declares
 EXPORTS = ["fgx_options_default", "fgx_create", "fgx_destroy", "fgx_last_error", "fgx_global_error", "fgx_process_batch",
            "fgx_process_batch_device", "fgx_call_columns", "fgx_device_libm", "fgx_get_table", "fgx_sim_sizes",
-           "fgx_sim_generate_host", "fgx_sim_generate_device", "fgx_group_records", "fgx_group_records_device"]
+           "fgx_sim_generate_host", "fgx_sim_generate_device", "fgx_group_records", "fgx_group_records_device", "fgx_filter_options_default",
+           "fgx_filter_records", "fgx_filter_records_device", "fgx_filter_last_output_device"]
 
 _lib = None
 
@@ -106,6 +121,14 @@ def load():
     L.fgx_group_records.restype = I
     L.fgx_group_records_device.argtypes = [VP, P(GroupOptions), VP, U64, VP, VP, U32, VP, VP, VP, P(U32), P(U32)]
     L.fgx_group_records_device.restype = I
+    L.fgx_filter_options_default.argtypes = [P(FilterOptions)]
+    L.fgx_filter_options_default.restype = None
+    L.fgx_filter_records.argtypes = [VP, P(FilterOptions), VP, U64, VP, VP, U32, P(FilterOutput)]
+    L.fgx_filter_records.restype = I
+    L.fgx_filter_records_device.argtypes = [VP, P(FilterOptions), VP, U64, VP, VP, U32, P(FilterOutput)]
+    L.fgx_filter_records_device.restype = I
+    L.fgx_filter_last_output_device.argtypes = [VP, P(FilterOptions), P(FilterOutput)]
+    L.fgx_filter_last_output_device.restype = I
     # host-only helpers (not part of the public header; used by CPU-side tests)
     L.fgx_build_tables_host.argtypes = [U8, U8, I, VP, P(U32), VP]
     L.fgx_build_tables_host.restype = I

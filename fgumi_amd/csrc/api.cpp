@@ -14,7 +14,7 @@ using namespace fgx;
 
 static thread_local std::string g_global_err;
 
-struct FastState { fgx::FastPath fp; fgx::PinnedBuf pin_out; };   // device pipeline + the pinned landing buffer of its records
+struct FastState { fgx::FastPath fp; fgx::PinnedBuf pin_out; fgx::FastResult last; bool has_last = false; };   // device pipeline + the pinned landing buffer of its records
 
 namespace fgx {
 
@@ -148,6 +148,7 @@ void fgx_destroy(fgx_caller* c) {
                     &c->d_oe, &c->d_scratch_a, &c->d_scratch_b, &c->d_in_blob, &c->d_in_off, &c->d_in_len, &c->d_in_grp})
     b->free_();
   if (c->fast) { c->fast->fp.release(); c->fast->pin_out.free_(); delete c->fast; }
+  if (c->filt) { c->filt->release(); delete c->filt; }
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -350,6 +351,7 @@ int fgx_process_batch_device(fgx_caller* c, const void* d_records, uint64_t reco
     FastResult fr;
     c->fast->fp.run(c, (const uint8_t*)d_records, records_len, (const uint64_t*)d_rec_off, (const uint32_t*)d_rec_len, n_rec,
                     (const uint32_t*)d_grp_first, n_grp, &fr);
+    c->fast->last = fr; c->fast->has_last = true;
     memset(out, 0, sizeof(*out));
     out->data = fr.d_out; out->data_len = fr.out_len; out->count = fr.count;
     for (int i = 0; i < FGX_STATS_LEN; i++) out->stats[i] = fr.stats[i];
@@ -401,6 +403,92 @@ int fgx_group_records(fgx_caller* c, const fgx_group_options* g, const uint8_t* 
       hip_check(hipMemcpy(out_rec_len, c->d_reads.p, (size_t)*n_kept * 4, hipMemcpyDeviceToHost), "D2H rec_len");
     }
     hip_check(hipMemcpy(grp_first, c->d_in_grp.p, (size_t)(*n_grp + 1) * 4, hipMemcpyDeviceToHost), "D2H grp_first");
+    return 0;
+  } catch (const std::exception& ex) { c->err = ex.what(); return 3; }
+}
+
+// ---- `fgumi filter` (filter.hip) -----------------------------------------------------------------------------------------
+void fgx_filter_options_default(fgx_filter_options* o) {
+  if (!o) return;
+  memset(o, 0, sizeof(*o));
+  o->struct_size = sizeof(fgx_filter_options);
+  for (int i = 0; i < 3; i++) { o->min_reads[i] = 1; o->max_read_error_rate[i] = 0.025; o->max_base_error_rate[i] = 0.1; }
+  o->max_no_call_fraction = 0.2;
+  o->filter_by_template = 1;
+}
+
+// Filter::validate_parameters (src/lib/commands/filter.rs:1021-1107) + FilterConfig::new ordering asserts (filter.rs:284-318)
+static bool filter_options_valid(const fgx_filter_options* f, std::string& err) {
+  if (f->struct_size != sizeof(fgx_filter_options)) { err = "fgx_filter_options.struct_size mismatch"; return false; }
+  for (int i = 0; i < 3; i++) {
+    if (!(f->max_read_error_rate[i] >= 0.0 && f->max_read_error_rate[i] <= 1.0)) { err = "--max-read-error-rate must be between 0.0 and 1.0"; return false; }
+    if (!(f->max_base_error_rate[i] >= 0.0 && f->max_base_error_rate[i] <= 1.0)) { err = "--max-base-error-rate must be between 0.0 and 1.0"; return false; }
+  }
+  if (!(f->max_no_call_fraction >= 0.0)) { err = "--max-no-call-fraction must be >= 0.0"; return false; }
+  if (f->max_no_call_fraction >= 1.0 && f->max_no_call_fraction != (double)(long long)f->max_no_call_fraction && f->max_no_call_fraction < 9e18) {
+    err = "--max-no-call-fraction >= 1.0 must be an integer (count of bases)"; return false;
+  }
+  if (f->min_reads[1] > f->min_reads[0] || f->min_reads[2] > f->min_reads[1]) { err = "min-reads values must be specified high to low (duplex >= AB >= BA)"; return false; }
+  if (f->max_read_error_rate[1] > f->max_read_error_rate[2]) { err = "max-read-error-rate for AB must be <= BA (more stringent)"; return false; }
+  if (f->max_base_error_rate[1] > f->max_base_error_rate[2]) { err = "max-base-error-rate for AB must be <= BA (more stringent)"; return false; }
+  return true;
+}
+
+int fgx_filter_records_device(fgx_caller* c, const fgx_filter_options* f, void* d_records, uint64_t records_len, const void* d_rec_off,
+                              const void* d_rec_len, uint32_t n_rec, fgx_filter_output* out) {
+  if (!c || !f || !out) return 1;
+  c->err.clear();
+  try {
+    if (!filter_options_valid(f, c->err)) return 1;
+    hip_check(hipSetDevice(c->device), "hipSetDevice");
+    if (!c->filt) c->filt = new FilterBuffers();
+    return filter_records_device(c, *c->filt, f, (uint8_t*)d_records, records_len, (const uint64_t*)d_rec_off, (const uint32_t*)d_rec_len, n_rec, out);
+  } catch (const std::exception& ex) { c->err = ex.what(); return 3; }
+}
+
+// The consensus records the handle's last fgx_process_batch_device left in HBM, filtered where they are: the slot table of
+// the device pipeline becomes the record list, no copy and no host round trip in between.
+int fgx_filter_last_output_device(fgx_caller* c, const fgx_filter_options* f, fgx_filter_output* out) {
+  if (!c || !f || !out) return 1;
+  c->err.clear();
+  try {
+    if (!filter_options_valid(f, c->err)) return 1;
+    if (!c->fast || !c->fast->has_last) { c->err = "fgx_filter_last_output_device: no device-resident batch on this handle"; return 1; }
+    hip_check(hipSetDevice(c->device), "hipSetDevice");
+    if (!c->filt) c->filt = new FilterBuffers();
+    const FastResult& L = c->fast->last;
+    return filter_slots_device(c, *c->filt, f, (uint8_t*)L.d_out, L.out_len, L.d_out_off, L.d_slot_size, L.n_slots, out);
+  } catch (const std::exception& ex) { c->err = ex.what(); return 3; }
+}
+
+int fgx_filter_records(fgx_caller* c, const fgx_filter_options* f, const uint8_t* records, uint64_t records_len, const uint64_t* rec_off,
+                       const uint32_t* rec_len, uint32_t n_rec, fgx_filter_output* out) {
+  if (!c || !f || !out) return 1;
+  c->err.clear();
+  try {
+    if (!filter_options_valid(f, c->err)) return 1;
+    hip_check(hipSetDevice(c->device), "hipSetDevice");
+    for (uint32_t r = 0; r < n_rec; r++)
+      if (rec_off[r] + rec_len[r] > records_len) { c->err = "fgx_filter_records: record outside the blob"; return 1; }
+    if (!c->filt) c->filt = new FilterBuffers();
+    FilterBuffers& B = *c->filt;
+    B.in_blob.reserve(records_len + 64);
+    B.in_off.reserve((size_t)n_rec * 8 + 8);
+    B.in_len.reserve((size_t)n_rec * 4 + 4);
+    if (records_len) hip_check(hipMemcpyAsync(B.in_blob.p, records, records_len, hipMemcpyHostToDevice, c->stream), "H2D records");
+    if (n_rec) {
+      hip_check(hipMemcpyAsync(B.in_off.p, rec_off, (size_t)n_rec * 8, hipMemcpyHostToDevice, c->stream), "H2D rec_off");
+      hip_check(hipMemcpyAsync(B.in_len.p, rec_len, (size_t)n_rec * 4, hipMemcpyHostToDevice, c->stream), "H2D rec_len");
+    }
+    int rc = filter_records_device(c, B, f, B.in_blob.as<uint8_t>(), records_len, B.in_off.as<uint64_t>(), B.in_len.as<uint32_t>(), n_rec, out);
+    if (rc != 0) return rc;
+    B.pin_keep.reserve(out->data_len + 64);
+    B.pin_rej.reserve(out->rejects_len + 64);
+    if (out->data_len) hip_check(hipMemcpyAsync(B.pin_keep.p, out->data, out->data_len, hipMemcpyDeviceToHost, c->stream), "D2H kept records");
+    if (out->rejects_len) hip_check(hipMemcpyAsync(B.pin_rej.p, out->rejects, out->rejects_len, hipMemcpyDeviceToHost, c->stream), "D2H rejected records");
+    hip_check(hipStreamSynchronize(c->stream), "sync");
+    out->data = B.pin_keep.as<uint8_t>();
+    out->rejects = B.pin_rej.as<uint8_t>();
     return 0;
   } catch (const std::exception& ex) { c->err = ex.what(); return 3; }
 }

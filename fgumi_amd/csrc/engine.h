@@ -85,6 +85,19 @@ struct ColumnBatch {
   }
 };
 
+// filter.hip — device buffers of the consensus-read filter (grow-only, owned by the caller object)
+struct FilterBuffers {
+  DevBuf pass, masked, newt, incl, first, ord_src, keep_size, rej_size, keep_off, rej_off, misc, scan_tmp, out_keep, out_rej, in_blob, in_off, in_len, slot_flag, slot_pos;
+  PinnedBuf pin_keep, pin_rej;
+  uint32_t lds_slice = 6144;        // LDS bytes per wavefront for the staged record (records beyond it are read from HBM)
+  void release() {
+    for (DevBuf* b : {&pass, &masked, &newt, &incl, &first, &ord_src, &keep_size, &rej_size, &keep_off, &rej_off, &misc, &scan_tmp, &out_keep, &out_rej,
+                      &in_blob, &in_off, &in_len, &slot_flag, &slot_pos})
+      b->free_();
+    pin_keep.free_(); pin_rej.free_();
+  }
+};
+
 }  // namespace fgx
 
 // The caller object behind the C ABI.
@@ -109,6 +122,7 @@ struct fgx_caller {
   std::vector<fgx_caller*> workers;         // helper callers (own stream and buffers) of the multi-threaded general path
   struct FastState* fast = nullptr;        // device-resident pipeline state (fastpath.hip)
   fgx::DevBuf d_in_blob, d_in_off, d_in_len, d_in_grp;   // host-input staging for fgx_process_batch
+  fgx::FilterBuffers* filt = nullptr;      // fgx_filter_records[_device] state (filter.hip)
 
   // Runs the staged column jobs of `b` on the device and fills b.ob/oq/od/oe. Returns kernel ms.
   double run_columns(fgx::ColumnBatch& b, fgx::ColParams prm);
@@ -125,6 +139,11 @@ int duplex_process_general(fgx_caller* c, const uint8_t* blob, const uint64_t* r
 int group_records_device(fgx_caller* c, const fgx_group_options* o, const uint8_t* d_blob, uint64_t blob_len, const uint64_t* d_rec_off,
                          const uint32_t* d_rec_len, uint32_t n, uint64_t* d_out_off, uint32_t* d_out_len, uint32_t* d_grp_first, uint32_t* n_kept,
                          uint32_t* n_grp);
+// filter.hip — `fgumi filter` on the device
+int filter_records_device(fgx_caller* c, FilterBuffers& B, const fgx_filter_options* o, uint8_t* d_blob, uint64_t blob_len, const uint64_t* d_rec_off,
+                          const uint32_t* d_rec_len, uint32_t n, fgx_filter_output* out);
+int filter_slots_device(fgx_caller* c, FilterBuffers& B, const fgx_filter_options* o, uint8_t* d_out, uint64_t out_len, const uint64_t* d_slot_off,
+                        const uint64_t* d_slot_size, uint32_t n_slots, fgx_filter_output* out);
 int codec_process_general(fgx_caller* c, const uint8_t* blob, const uint64_t* rec_off, const uint32_t* rec_len, uint32_t n_rec,
                           const uint32_t* grp_first, uint32_t n_grp, fgx_output* out);
 }

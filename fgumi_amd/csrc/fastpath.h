@@ -107,6 +107,8 @@ struct FastResult {
   uint64_t stats[FGX_STATS_LEN];
   uint32_t n_deferred; const uint32_t* d_deferred;
   const uint64_t* d_out_off;     // byte offset of each of the 3*n_grp slots in d_out
+  const uint64_t* d_slot_size;   // bytes of each slot (block_size prefix included; 0 = no record)
+  uint32_t n_slots;
   double ms_kernels, ms_k_family, ms_k_emit; uint64_t cols_used; uint64_t full_items;
 };
 

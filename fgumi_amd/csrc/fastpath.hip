@@ -3051,6 +3051,8 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
   res->n_deferred = (uint32_t)(h_misc[29] & 0xFFFFFFFFull);
   res->d_deferred = d_deferred.as<uint32_t>();
   res->d_out_off = d_offsets.as<uint64_t>();
+  res->d_slot_size = d_sizes.as<uint64_t>();
+  res->n_slots = n_slots;
   res->ms_kernels = ms;
   float msf = 0, mse = 0;
   hip_check(hipEventElapsedTime(&msf, ev[0], ev[1]), "elapsed");

@@ -1,0 +1,206 @@
+"""Python host mirror of `fgumi filter` for unmapped consensus records, over the C ABI (fgx_filter_*).
+
+Mirrors (names, argument meaning, error behaviour):
+  * `FilterThresholds`, `FilterConfig::{new, for_single_strand, for_duplex, for_duplex_asymmetric}`
+                                         crates/fgumi-consensus/src/filter.rs:29-329 (1-3 values expand from the last; the
+                                         ordering asserts of :284-318 raise ValueError here)
+  * `Filter::validate_parameters`        src/lib/commands/filter.rs:1021-1107
+  * the Process closures                 src/lib/commands/filter.rs:581-625 (single read), :653-731 (template) — `filter_records`
+  * `FilterProcessedBatchRaw`            src/lib/commands/filter.rs:226-238 — `FilterResult`
+
+Masking, thresholds, template decisions and the record copies all run in the HIP library; nothing here filters on the CPU.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+
+from ._lib import FilterOptions, FilterOutput, default_options, lib
+
+
+@dataclass
+class FilterThresholds:
+    min_reads: int
+    max_read_error_rate: float = 0.025
+    max_base_error_rate: float = 0.1
+
+
+def _three(v):
+    v = list(v) if isinstance(v, (list, tuple, np.ndarray)) else [v]
+    if not v:
+        raise ValueError("at least one value required")
+    if len(v) > 3:
+        raise ValueError(f"must have 1-3 values, got {len(v)}")
+    return (v + [v[-1]] * 3)[:3]
+
+
+@dataclass
+class FilterConfig:
+    """[duplex (CC), AB, BA] thresholds + the read-level options (filter.rs:52-75)."""
+    duplex: FilterThresholds
+    ab: FilterThresholds
+    ba: FilterThresholds
+    min_base_quality: Optional[int] = None
+    min_mean_base_quality: Optional[float] = None
+    max_no_call_fraction: float = 0.2
+
+    def __post_init__(self):
+        cc, ab, ba = self.duplex, self.ab, self.ba
+        for t in (cc, ab, ba):
+            if not 0.0 <= t.max_read_error_rate <= 1.0:
+                raise ValueError(f"--max-read-error-rate must be between 0.0 and 1.0, got {t.max_read_error_rate}")
+            if not 0.0 <= t.max_base_error_rate <= 1.0:
+                raise ValueError(f"--max-base-error-rate must be between 0.0 and 1.0, got {t.max_base_error_rate}")
+        if ab.min_reads > cc.min_reads:
+            raise ValueError(f"min-reads values must be specified high to low: AB ({ab.min_reads}) > duplex ({cc.min_reads})")
+        if ba.min_reads > ab.min_reads:
+            raise ValueError(f"min-reads values must be specified high to low: BA ({ba.min_reads}) > AB ({ab.min_reads})")
+        if ab.max_read_error_rate > ba.max_read_error_rate:
+            raise ValueError(f"max-read-error-rate for AB ({ab.max_read_error_rate}) must be <= BA ({ba.max_read_error_rate})")
+        if ab.max_base_error_rate > ba.max_base_error_rate:
+            raise ValueError(f"max-base-error-rate for AB ({ab.max_base_error_rate}) must be <= BA ({ba.max_base_error_rate})")
+        if self.max_no_call_fraction < 0.0:
+            raise ValueError(f"--max-no-call-fraction must be >= 0.0, got {self.max_no_call_fraction}")
+        if self.max_no_call_fraction >= 1.0 and self.max_no_call_fraction != int(self.max_no_call_fraction):
+            raise ValueError(f"--max-no-call-fraction >= 1.0 must be an integer (count of bases), got {self.max_no_call_fraction}")
+
+    @classmethod
+    def new(cls, min_reads: Sequence[int], max_read_error_rate: Sequence[float] = (0.025,), max_base_error_rate: Sequence[float] = (0.1,),
+            min_base_quality: Optional[int] = None, min_mean_base_quality: Optional[float] = None, max_no_call_fraction: float = 0.2) -> "FilterConfig":
+        r, e, b = _three(min_reads), _three(max_read_error_rate), _three(max_base_error_rate)
+        t = [FilterThresholds(int(r[i]), float(e[i]), float(b[i])) for i in range(3)]
+        return cls(t[0], t[1], t[2], min_base_quality, min_mean_base_quality, max_no_call_fraction)
+
+    @classmethod
+    def for_single_strand(cls, thresholds: FilterThresholds, min_base_quality=None, min_mean_base_quality=None, max_no_call_fraction=0.2):
+        return cls(thresholds, thresholds, thresholds, min_base_quality, min_mean_base_quality, max_no_call_fraction)
+
+    @classmethod
+    def for_duplex(cls, duplex: FilterThresholds, strand: FilterThresholds, min_base_quality=None, min_mean_base_quality=None, max_no_call_fraction=0.2):
+        return cls(duplex, strand, strand, min_base_quality, min_mean_base_quality, max_no_call_fraction)
+
+    @classmethod
+    def for_duplex_asymmetric(cls, duplex, ab, ba, min_base_quality=None, min_mean_base_quality=None, max_no_call_fraction=0.2):
+        return cls(duplex, ab, ba, min_base_quality, min_mean_base_quality, max_no_call_fraction)
+
+
+@dataclass
+class FilterResult:
+    """`FilterProcessedBatchRaw`: kept / rejected records as block_size-prefixed streams + the counters."""
+    data: bytes
+    rejects: bytes
+    records_count: int
+    passed_count: int
+    bases_masked: int
+    rejected_count: int
+
+
+@dataclass
+class DeviceFilterResult:
+    data_ptr: int
+    data_len: int
+    rejects_ptr: int
+    rejects_len: int
+    records_count: int
+    passed_count: int
+    bases_masked: int
+    rejected_count: int
+
+    def to_host(self) -> FilterResult:
+        import torch  # noqa: F401
+        from ._lib import hip_memcpy_d2h
+        d = hip_memcpy_d2h(self.data_ptr, self.data_len) if self.data_len else b""
+        r = hip_memcpy_d2h(self.rejects_ptr, self.rejects_len) if self.rejects_len else b""
+        return FilterResult(d, r, self.records_count, self.passed_count, self.bases_masked, self.rejected_count)
+
+
+def record_offsets(data: bytes):
+    """Record boundaries of a block_size-prefixed stream (the sequential length chain; host work, like the reader's FindBoundaries)."""
+    off, ln = [], []
+    p, n = 0, len(data)
+    mv = memoryview(data)
+    while p + 4 <= n:
+        l = int.from_bytes(mv[p:p + 4], "little")
+        off.append(p + 4)
+        ln.append(l)
+        p += 4 + l
+    if p != n:
+        raise ValueError("truncated record stream")
+    return np.array(off, dtype=np.uint64), np.array(ln, dtype=np.uint32)
+
+
+class ConsensusFilter:
+    """`fgumi filter` without --ref: consensus records in, kept (and optionally rejected) records out, masked like the reference."""
+
+    def __init__(self, config: FilterConfig, filter_by_template: bool = True, require_single_strand_agreement: bool = False,
+                 reverse_per_base_tags: bool = False, track_rejects: bool = False, device: int = -1, handle=None):
+        self.config = config
+        o = FilterOptions()
+        lib.fgx_filter_options_default(C.byref(o))
+        for i, t in enumerate((config.duplex, config.ab, config.ba)):
+            o.min_reads[i], o.max_read_error_rate[i], o.max_base_error_rate[i] = t.min_reads, t.max_read_error_rate, t.max_base_error_rate
+        o.has_min_base_quality, o.min_base_quality = int(config.min_base_quality is not None), int(config.min_base_quality or 0)
+        o.has_min_mean_base_quality, o.min_mean_base_quality = int(config.min_mean_base_quality is not None), float(config.min_mean_base_quality or 0.0)
+        o.max_no_call_fraction = config.max_no_call_fraction
+        o.require_single_strand_agreement, o.reverse_per_base_tags = int(require_single_strand_agreement), int(reverse_per_base_tags)
+        o.filter_by_template, o.track_rejects = int(filter_by_template), int(track_rejects)
+        self._o = o
+        self._own = handle is None
+        if handle is None:
+            opts = default_options(device=device)
+            handle = lib.fgx_create(C.byref(opts))
+            if not handle:
+                raise RuntimeError(lib.fgx_global_error().decode())
+        self._h = handle
+
+    def close(self):
+        if self._own and self._h:
+            lib.fgx_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(lib.fgx_last_error(self._h).decode())
+
+    def filter_stream(self, blob: np.ndarray, rec_off: np.ndarray, rec_len: np.ndarray) -> FilterResult:
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        rec_off = np.ascontiguousarray(rec_off, dtype=np.uint64)
+        rec_len = np.ascontiguousarray(rec_len, dtype=np.uint32)
+        out = FilterOutput()
+        self._check(lib.fgx_filter_records(self._h, C.byref(self._o), blob.ctypes.data, blob.size, rec_off.ctypes.data, rec_len.ctypes.data, len(rec_off),
+                                           C.byref(out)))
+        return FilterResult(C.string_at(out.data, out.data_len) if out.data_len else b"", C.string_at(out.rejects, out.rejects_len) if out.rejects_len else b"",
+                            int(out.records_count), int(out.passed_count), int(out.bases_masked), int(out.rejected_count))
+
+    def filter_records(self, data: bytes) -> FilterResult:
+        """`data` = `ConsensusOutput.data` (records with block_size prefixes), e.g. what a consensus caller returned."""
+        off, ln = record_offsets(data)
+        return self.filter_stream(np.frombuffer(data, dtype=np.uint8), off, ln)
+
+    def filter_device(self, blob, blob_len: int, rec_off, rec_len, n_rec: int) -> DeviceFilterResult:
+        """torch tensors resident in HBM; `blob` is masked in place, outputs stay in HBM."""
+        import torch
+        torch.cuda.synchronize(blob.device)
+        out = FilterOutput()
+        self._check(lib.fgx_filter_records_device(self._h, C.byref(self._o), blob.data_ptr(), blob_len, rec_off.data_ptr(), rec_len.data_ptr(), n_rec, C.byref(out)))
+        return DeviceFilterResult(out.data or 0, int(out.data_len), out.rejects or 0, int(out.rejects_len), int(out.records_count), int(out.passed_count),
+                                  int(out.bases_masked), int(out.rejected_count))
+
+    @classmethod
+    def on_caller(cls, caller, config: FilterConfig, **kw) -> "ConsensusFilter":
+        """A filter bound to a consensus caller's handle, for `filter_last_output_device`."""
+        return cls(config, handle=caller._h, **kw)
+
+    def filter_last_output_device(self) -> DeviceFilterResult:
+        """Filters, in HBM, the records the bound caller's last `process_batch_device` produced."""
+        out = FilterOutput()
+        self._check(lib.fgx_filter_last_output_device(self._h, C.byref(self._o), C.byref(out)))
+        return DeviceFilterResult(out.data or 0, int(out.data_len), out.rejects or 0, int(out.rejects_len), int(out.records_count), int(out.passed_count),
+                                  int(out.bases_masked), int(out.rejected_count))

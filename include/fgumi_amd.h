@@ -243,10 +243,13 @@ typedef struct fgx_filter_output {
  * until the next call on the handle. */
 int fgx_filter_records(fgx_caller* c, const fgx_filter_options* f, const uint8_t* records, uint64_t records_len, const uint64_t* rec_off,
                        const uint32_t* rec_len, uint32_t n_rec, fgx_filter_output* out);
-/* Device buffers in (masked in place) and out.  rec_len == 0 entries are skipped (empty consensus slots), so the slot
- * arrays of a device-resident consensus batch can be passed as they are. */
+/* Device buffers in (masked in place) and out (`out->data` / `out->rejects` are device pointers owned by the handle). */
 int fgx_filter_records_device(fgx_caller* c, const fgx_filter_options* f, void* d_records, uint64_t records_len, const void* d_rec_off,
                               const void* d_rec_len, uint32_t n_rec, fgx_filter_output* out);
+
+/* The consensus records the handle's last fgx_process_batch_device call left in HBM, filtered in place (consensus → filter
+ * without leaving the device: the hand-over the reference does through a BAM file or a pipe). */
+int fgx_filter_last_output_device(fgx_caller* c, const fgx_filter_options* f, fgx_filter_output* out);
 
 /* Sizes for a parameter set: total blob bytes (records WITH block_size prefixes) and record count. */
 int fgx_sim_sizes(const fgx_sim_params* p, uint64_t* blob_len, uint64_t* n_rec);

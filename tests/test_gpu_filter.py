@@ -1,0 +1,227 @@
+"""GPU parity: `fgumi filter` on the device (fgx_filter_records / _device / fgx_filter_last_output_device) vs the oracle
+restatement — kept bytes, rejected bytes and the FilterProcessedBatchRaw counters identical, for crafted records (every tag
+type the reference's finders accept), for the consensus callers' own output, and for the device-resident consensus → filter
+hand-over."""
+import random
+import struct
+
+import numpy as np
+import pytest
+
+import bamutil
+import orc
+import test_oracle_filter as tof
+from fgumi_amd import (CodecConsensusCaller, CodecConsensusOptions, ConsensusFilter, DuplexConsensusCaller, FilterConfig, VanillaUmiConsensusCaller,
+                       VanillaUmiConsensusOptions, record_offsets, simulate_grouped_reads)
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(kw):
+    return FilterConfig.new(kw.get("min_reads", [1]), kw.get("max_read_error_rate", [0.025]), kw.get("max_base_error_rate", [0.1]), kw.get("min_base_quality"),
+                            kw.get("min_mean_base_quality"), kw.get("max_no_call_fraction", 0.2))
+
+
+def _flags(kw):
+    return {k: kw[k] for k in ("filter_by_template", "require_single_strand_agreement", "reverse_per_base_tags", "track_rejects") if k in kw}
+
+
+def _same(records, **kw):
+    blob, off, ln = tof.stream(records)
+    want = orc.filter_records(orc.filter_options(**kw), blob, off, ln)
+    f = ConsensusFilter(_cfg(kw), **_flags(kw))
+    got = f.filter_stream(blob, off, ln)
+    f.close()
+    if got.data != want["data"]:
+        a, b = tof.bamutil_split(got.data), tof.bamutil_split(want["data"])
+        for i, (x, y) in enumerate(zip(a, b)):
+            if x != y:
+                raise AssertionError(f"kept record {i} differs:\n got {bamutil.parse(x)}\nwant {bamutil.parse(y)}")
+        raise AssertionError(f"kept count differs: {len(a)} vs {len(b)}")
+    assert got.rejects == want["rejects"]
+    assert (got.records_count, got.passed_count, got.bases_masked, got.rejected_count) == (want["records"], want["passed"], want["masked"], want["rejected"])
+    return got
+
+
+def crafted():
+    rng = random.Random(7)
+    recs = []
+    for t in range(60):
+        L = rng.choice([1, 2, 7, 30, 63, 64, 65, 129, 151])
+        name = "t%03d" % t + "x" * rng.randrange(0, 9)          # varying name lengths: every alignment of the sequence / aux block
+        for flag, base in ((0x4D, "ACGT"), (0x8D, "TGCA")):
+            seq = "".join(rng.choice(base + "N" if rng.random() < 0.03 else base) for _ in range(L))
+            q = [rng.choice([2, 5, 12, 25, 30, 40]) if rng.random() < 0.1 else 35 for _ in range(L)]
+            cd = [rng.choice([0, 1, 2, 3, 9, 200]) if rng.random() < 0.08 else 9 for _ in range(rng.choice([L, L, L, max(0, L - 1), L + 2]))]
+            ce = [rng.choice([1, 2]) if rng.random() < 0.05 else 0 for _ in range(L)]
+            ty = rng.choice(["S", "s", "C", "c"])
+            if ty in "cC":
+                cd = [min(v, 100) for v in cd]
+            if ty in "sc" and cd:
+                cd[0] = -1
+            tags = [("cD", "i", rng.choice([1, 2, 5, 9, 9, 300, 70000])), ("cM", "i", 1), ("cE", "f", rng.choice([0.0, 0.0, 0.01, 0.01, 0.03, 0.2]))]
+            if rng.random() < 0.9:
+                tags.append(tof.arr("cd", cd, ty))
+            if rng.random() < 0.9:
+                tags.append(tof.arr("ce", ce, rng.choice(["S", "C"])))
+            tags.insert(rng.randrange(len(tags) + 1), ("RX", "Z", "ACGT-TTGA"))
+            tags.insert(rng.randrange(len(tags) + 1), ("MI", "Z", str(t)))
+            recs.append(bamutil.make_record(name, seq, q, flag=flag, ref_id=-1, pos=-1, tags=tags))
+    # duplex records with every per-base tag, in shuffled tag order
+    for t in range(60):
+        L = rng.choice([3, 8, 50, 100, 150])
+        name = "d%03d" % t
+        for flag in (0x4D, 0x8D):
+            seq = "".join(rng.choice("ACGTN" if rng.random() < 0.05 else "ACGT") for _ in range(L))
+            q = [rng.choice([2, 10, 30]) if rng.random() < 0.06 else 60 for _ in range(L)]
+            ad = [rng.choice([0, 1, 2, 5]) if rng.random() < 0.06 else 9 for _ in range(L)]
+            bd = [rng.choice([0, 1, 2, 5]) if rng.random() < 0.06 else 7 for _ in range(L)]
+            ae = [1 if rng.random() < 0.04 else 0 for _ in range(L)]
+            be = [rng.choice([1, 3]) if rng.random() < 0.04 else 0 for _ in range(L)]
+            ac = "".join(rng.choice("ACGT") for _ in range(rng.choice([L, L, L - 1])))
+            bc = "".join(a if rng.random() < 0.97 else "T" for a in ac.ljust(L, "A"))
+            tags = [("cD", "i", max(ad) + max(bd)), ("cE", "f", 0.01), ("aD", "i", max(ad)), ("bD", "i", max(bd)), ("aE", "f", rng.choice([0.0, 0.0, 0.02, 0.04])),
+                    ("bE", "f", rng.choice([0.0, 0.0, 0.02, 0.06])), ("aM", "i", min(ad)), ("bM", "i", min(bd)), tof.arr("ad", ad), tof.arr("bd", bd, rng.choice(["S", "C"])),
+                    tof.arr("ae", ae), tof.arr("be", be), ("aq", "Z", "I" * L), ("bq", "Z", "5" * L), ("MI", "Z", str(t)), ("RG", "Z", "A")]
+            if rng.random() < 0.8:
+                tags.append(("ac", "Z", ac))
+            if rng.random() < 0.8:
+                tags.append(("bc", "Z", bc) if rng.random() < 0.7 else tof.arr("bc", [ord(x) for x in bc], "C"))
+            rng.shuffle(tags)
+            if rng.random() < 0.1:
+                tags = [x for x in tags if x[0] != "bD"]           # aD without bD → simplex rules
+            recs.append(bamutil.make_record(name, seq, q, flag=flag, ref_id=-1, pos=-1, tags=tags))
+    return recs
+
+
+OPTION_SETS = [dict(), dict(min_reads=[3], track_rejects=True), dict(min_reads=[5, 3, 2], max_read_error_rate=[0.03, 0.02, 0.05], max_base_error_rate=[0.3, 0.2, 0.4],
+                                                                       min_base_quality=12, track_rejects=True),
+               dict(min_reads=[2], filter_by_template=False, track_rejects=True, min_base_quality=10), dict(min_mean_base_quality=24.0, max_no_call_fraction=0.5),
+               dict(max_no_call_fraction=3.0, min_base_quality=13, track_rejects=True), dict(require_single_strand_agreement=True, min_reads=[2, 1, 1]),
+               dict(min_reads=[1], max_base_error_rate=[1.0], max_read_error_rate=[1.0], max_no_call_fraction=1000.0)]
+
+
+@pytest.mark.parametrize("kw", OPTION_SETS)
+def test_filter_crafted(kw):
+    _same(crafted(), **kw)
+
+
+def test_filter_reference_unit_cases_on_device():
+    # src/lib/commands/filter.rs:1680-1760 mask_bases cases, through the whole process_record_raw
+    got = _same([tof.rec("ACGT", [10, 30, 5, 30], cD=10, cE=0.0, cd=[10] * 4, ce=[0] * 4)], min_base_quality=20, max_no_call_fraction=4.0)
+    assert tof.seq_quals(tof.bamutil_split(got.data)[0]) == ("NCNT", [2, 30, 2, 30]) and got.bases_masked == 2
+    got = _same([tof.rec("ACGT", [30] * 4, cD=10, cE=0.0, cd=[10] * 4, ce=[1, 3, 2, 0])], max_base_error_rate=[0.2], max_no_call_fraction=4.0)
+    assert tof.seq_quals(tof.bamutil_split(got.data)[0])[0] == "ANGT"
+
+
+def test_filter_template_ordering_and_secondaries():
+    def r(flag, tag, ok=True):
+        return tof.rec("ACGTACGTAC", [30] * 10, cD=9 if ok else 1, cE=0.0, flag=flag | 4, name="tpl", extra=[("xx", "Z", tag)])
+    recs = [r(0x881, "r2supA"), r(0x81, "r2"), r(0x841, "r1supA"), r(0x141, "r1secA", ok=False), r(0x41, "r1"), r(0x841, "r1supB"), r(0x181, "r2sec")]
+    got = _same(recs + tof.P("next") + [r(0x841, "only-supp").replace(b"tpl\0", b"zzz\0")], min_reads=[3], track_rejects=True)
+    assert [bamutil.parse(x)["tags"].get("xx", ("Z", "-"))[1] for x in tof.bamutil_split(got.data)] == ["r1", "r2", "r1supB", "r1supA", "r2supA", "r2sec", "-", "-"]
+    _same(recs + tof.P("next"), min_reads=[3], filter_by_template=False, track_rejects=True)
+    _same([r(0x81, "r2first"), r(0x41, "r1second")])
+
+
+def test_filter_reverse_tags_and_large_records():
+    rng = random.Random(3)
+    recs = []
+    for t, L in enumerate([4, 33, 150, 151, 3000, 7000]):        # the last two exceed the LDS slice: read from HBM
+        seq = "".join(rng.choice("ACGT") for _ in range(L))
+        cd = [rng.choice([1, 4, 9]) for _ in range(L)]
+        ce = [rng.choice([0, 0, 1]) for _ in range(L)]
+        ac = "".join(rng.choice("ACGTRYN") for _ in range(L))
+        tags = [tof.arr("cd", cd), tof.arr("ce", ce, "C"), ("aq", "Z", "".join(chr(33 + (i % 60)) for i in range(L))), ("ac", "Z", ac), ("bc", "Z", ac[::-1]),
+                tof.arr("ad", list(range(L)), "i"), tof.arr("ct", [i % 100 for i in range(L)], "s"), ("bq", "Z", "")]
+        for flag in (0x4 | 0x10, 0x4):
+            recs.append(tof.rec(seq, [rng.choice([5, 30]) for _ in range(L)], cD=9, cE=0.0, flag=flag, name=f"rev{t}_{flag}", extra=tags))
+    _same(recs, reverse_per_base_tags=True, min_reads=[3], min_base_quality=10, max_no_call_fraction=0.9, filter_by_template=False, track_rejects=True)
+    _same(recs, reverse_per_base_tags=False, min_reads=[3], max_no_call_fraction=0.9, filter_by_template=False)
+
+
+def test_filter_errors_are_fatal():
+    f = ConsensusFilter(FilterConfig.new([1]))
+    ok1, ok2 = tof.rec("ACGT", [30] * 4, cD=5, cE=0.0, name="a"), tof.rec("ACGT", [30] * 4, cD=5, cE=0.0, name="c")
+    for bad, msg in ((tof.rec("ACGT", [30] * 4, cD=5, cE=0.0, flag=0, pos=10, name="b"), "--ref is required"), (tof.rec("ACGT", [30] * 4, cD=5, name="b"), "cD/cE"),
+                     (tof.rec("ACGT", [30] * 4, cE=0.1, name="b"), "cD/cE")):
+        with pytest.raises(RuntimeError, match=msg):
+            f.filter_stream(*tof.stream([ok1, bad, ok2]))
+        with pytest.raises(RuntimeError):
+            orc.filter_records(orc.filter_options(), *tof.stream([ok1, bad, ok2]))
+    two_r1 = [tof.rec("ACGT", [30] * 4, cD=5, cE=0.0, flag=0x45, name="same"), tof.rec("ACGT", [30] * 4, cD=5, cE=0.0, flag=0x45, name="same")]
+    with pytest.raises(RuntimeError, match="Multiple non-secondary"):
+        f.filter_stream(*tof.stream(two_r1))
+    assert f.filter_stream(*tof.stream([])).records_count == 0
+    f.close()
+    with pytest.raises(ValueError):
+        FilterConfig.new([1, 2])                      # AB > duplex
+    with pytest.raises(ValueError):
+        FilterConfig.new([1], max_no_call_fraction=1.5)
+
+
+def _consensus_records(kind, n):
+    if kind == "simplex":
+        g = simulate_grouped_reads(n, family_size=2, family_size_max=12, error_rate_ppm=20000)
+        c = VanillaUmiConsensusCaller("c", "A", VanillaUmiConsensusOptions(min_reads=1, produce_per_base_tags=True, min_consensus_base_quality=2))
+    elif kind == "duplex":
+        g = simulate_grouped_reads(n, family_size=4, family_size_max=16, duplex=1, error_rate_ppm=20000)
+        c = DuplexConsensusCaller("d", "A", [1], produce_per_base_tags=True)
+    else:
+        g = simulate_grouped_reads(n, family_size=3, read_length=150, insert_mean=200, insert_sd=30, codec=1, error_rate_ppm=20000)
+        c = CodecConsensusCaller("x", "A", CodecConsensusOptions(produce_per_base_tags=True))
+    out = c.process_batch(g)
+    c.close()
+    return out.data
+
+
+@pytest.mark.parametrize("kind", ["simplex", "duplex", "codec"])
+def test_filter_consensus_caller_output(kind):
+    data = _consensus_records(kind, 600)
+    off, ln = record_offsets(data)
+    assert len(off) > 500
+    blob = np.frombuffer(data + b"\0" * 8, dtype=np.uint8)
+    passed = []
+    for kw in (dict(min_reads=[3], track_rejects=True), dict(min_reads=[6, 3, 2], max_base_error_rate=[0.05], min_base_quality=30, track_rejects=True,
+                                                              require_single_strand_agreement=True),
+               dict(min_reads=[2], min_mean_base_quality=35.0, filter_by_template=False, max_no_call_fraction=0.05)):
+        want = orc.filter_records(orc.filter_options(**kw), blob, off, ln)
+        f = ConsensusFilter(_cfg(kw), **_flags(kw))
+        got = f.filter_records(data)
+        f.close()
+        assert got.data == want["data"] and got.rejects == want["rejects"]
+        assert (got.records_count, got.passed_count, got.bases_masked, got.rejected_count) == (want["records"], want["passed"], want["masked"], want["rejected"])
+        passed.append(got.passed_count)
+    assert any(0 < p < len(off) for p in passed)
+
+
+@pytest.mark.parametrize("kind", ["simplex", "duplex", "codec"])
+def test_consensus_then_filter_without_leaving_the_device(kind):
+    """process_batch_device → filter_last_output_device equals (oracle consensus → oracle filter) on the same simulated molecules."""
+    import fgx_opts
+    if kind == "simplex":
+        sim = dict(n_families=1500, family_size=2, family_size_max=12, error_rate_ppm=20000)
+        c = VanillaUmiConsensusCaller("c", "A", VanillaUmiConsensusOptions(min_reads=1, produce_per_base_tags=True, min_consensus_base_quality=2))
+        o = fgx_opts.defaults(kind=0, read_name_prefix=b"c", min_reads=1, produce_per_base_tags=1, overlapping_consensus=0)
+    elif kind == "duplex":
+        sim = dict(n_families=800, family_size=4, family_size_max=16, duplex=1, error_rate_ppm=20000)
+        c = DuplexConsensusCaller("d", "A", [1], produce_per_base_tags=True)
+        o = fgx_opts.defaults(kind=1, read_name_prefix=b"d", produce_per_base_tags=1, overlapping_consensus=0)
+    else:
+        sim = dict(n_families=800, family_size=3, read_length=150, insert_mean=200, insert_sd=30, codec=1, error_rate_ppm=20000)
+        c = CodecConsensusCaller("x", "A", CodecConsensusOptions(produce_per_base_tags=True))
+        o = fgx_opts.defaults(kind=2, read_name_prefix=b"x", overlapping_consensus=0, produce_per_base_tags=1)
+    dg = c.simulate_on_device(**sim)
+    out = c.process_batch_device(dg)
+    assert out.n_deferred == 0
+    kw = dict(min_reads=[3, 2, 1], max_base_error_rate=[0.2], min_base_quality=20, track_rejects=True)
+    f = ConsensusFilter.on_caller(c, _cfg(kw), **_flags(kw))
+    got = f.filter_last_output_device().to_host()
+    g = simulate_grouped_reads(sim["n_families"], **{k: v for k, v in sim.items() if k != "n_families"})
+    cons = orc.process(o, g.blob, g.rec_off, g.rec_len, g.grp_first, batch_groups=g.n_grp)["data"]
+    off, ln = record_offsets(cons)
+    want = orc.filter_records(orc.filter_options(**kw), np.frombuffer(cons + b"\0" * 8, dtype=np.uint8), off, ln)
+    assert got.data == want["data"] and got.rejects == want["rejects"]
+    assert (got.records_count, got.passed_count, got.bases_masked) == (want["records"], want["passed"], want["masked"])
+    assert got.passed_count > 0 and got.rejected_count > 0
+    c.close()
