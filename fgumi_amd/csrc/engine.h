@@ -89,7 +89,7 @@ struct ColumnBatch {
 struct FilterBuffers {
   DevBuf pass, masked, newt, incl, first, ord_src, keep_size, rej_size, keep_off, rej_off, misc, scan_tmp, out_keep, out_rej, in_blob, in_off, in_len, slot_flag, slot_pos;
   PinnedBuf pin_keep, pin_rej;
-  uint32_t lds_slice = 6144;        // LDS bytes per wavefront for the staged record (records beyond it are read from HBM)
+  uint32_t lds_slice = 0;           // LDS bytes per wavefront for the staged record; 0 = sized from the mean record length
   void release() {
     for (DevBuf* b : {&pass, &masked, &newt, &incl, &first, &ord_src, &keep_size, &rej_size, &keep_off, &rej_off, &misc, &scan_tmp, &out_keep, &out_rej,
                       &in_blob, &in_off, &in_len, &slot_flag, &slot_pos})

@@ -77,36 +77,42 @@ __device__ inline uint32_t elem(const uint8_t* A, uint32_t kind, uint32_t off, u
 
 struct Src { uint32_t kind, off, count; };
 
-__global__ __launch_bounds__(256) void k_filter_records(const FilterParams P) {
-  extern __shared__ __align__(16) uint8_t lds_raw[];
-  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint32_t r = blockIdx.x * 4 + wave;
-  if (r >= P.n_rec) return;
-  const uint64_t off = P.rec_off[r];
-  const uint32_t len = P.rec_len[r];
-  if (len < 32 || off + len > P.blob_len) { if (lane == 0) { report(P.error, r, ERR_SHORT); P.pass[r] = 0; P.masked[r] = 0; } return; }
-  uint8_t* g = P.blob + off;
-  const uint32_t l_name = g[8], n_cig = bam::rd16(g + 12), flags = bam::rd16(g + 14), l_seq = bam::rd32(g + 16);
+// TAG_FIXED_SIZES without a branch tree: bit (type - 64) of three masks (A c C → 1, s S → 2, i I f → 4)
+__device__ inline int fixed_size_fast(uint32_t ty) {
+#define BIT(ch) (1ull << ((ch) - 64))
+  constexpr uint64_t M1 = BIT('A') | BIT('C') | BIT('c'), M2 = BIT('S') | BIT('s'), M4 = BIT('I') | BIT('i') | BIT('f');
+#undef BIT
+  const uint32_t i = (ty - 64) & 63;
+  const int v = (int)(((M1 >> i) & 1) | (((M2 >> i) & 1) << 1) | (((M4 >> i) & 1) << 2));
+  return (ty - 64) < 64 ? v : 0;
+}
+
+#ifndef FGX_PHASE_TIMING
+#define FGX_PHASE_TIMING 0   /* 1: per-phase s_memtime deltas of k_filter_records into g_fphase (profiling builds only) */
+#endif
+#if FGX_PHASE_TIMING
+__device__ unsigned long long g_fphase[64 * 8];
+#define FPH(i) { unsigned long long _n = __builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(&g_fphase[(blockIdx.x & 63) * 8 + (i)], _n - _t); _t = _n; }
+#define FPH_ARG , unsigned long long _t
+#define FPH_PASS , _t
+#else
+#define FPH(i)
+#define FPH_ARG
+#define FPH_PASS
+#endif
+
+// Everything after staging; R points at the record in LDS (or in HBM for a record larger than the slice) — called once per
+// address space so that the LDS path compiles to ds_read / ds_write instead of flat accesses.
+__device__ __forceinline__ void filter_body(const FilterParams& P, const uint32_t r, const uint32_t lane, uint8_t* g, uint8_t* R, const bool staged,
+                                            const uint32_t len FPH_ARG) {
+  const uint32_t l_name = R[8], n_cig = bam::rd16(R + 12), flags = bam::rd16(R + 14), l_seq = bam::rd32(R + 16);
   const uint64_t seq_off64 = 32ull + l_name + 4ull * n_cig, aux_off64 = seq_off64 + ((uint64_t)l_seq + 1) / 2 + l_seq;
   if (aux_off64 > len) { if (lane == 0) { report(P.error, r, ERR_SHORT); P.pass[r] = 0; P.masked[r] = 0; } return; }
   if (!(flags & bam::F_UNMAPPED)) { if (lane == 0) { report(P.error, r, ERR_MAPPED); P.pass[r] = 0; P.masked[r] = 0; } return; }
   const uint32_t seq_off = (uint32_t)seq_off64, qual_off = seq_off + (l_seq + 1) / 2, aux_off = (uint32_t)aux_off64, an = len - aux_off;
-
-  // stage the record into this wave's LDS slice, same alignment mod 4 as in HBM so that the copy is whole dwords
-  const uint32_t shift = (uint32_t)((uintptr_t)g & 3);
-  const uint32_t n_dw = (shift + len + 3) / 4;
-  uint8_t* slice = lds_raw + (size_t)wave * P.lds_slice;
-  const bool staged = (uint64_t)n_dw * 4 <= P.lds_slice;
-  if (staged) {
-    const uint32_t* src = (const uint32_t*)(g - shift);
-    uint32_t* dst = (uint32_t*)slice;
-    for (uint32_t i = lane; i < n_dw; i += 64) dst[i] = src[i];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  }
-  uint8_t* R = staged ? slice + shift : g;      // generic pointer: LDS copy, or HBM for records beyond the slice
   const uint8_t* A = R + aux_off;
 
+  FPH(0)
   // ---- one walk over the aux block; lane k (< N_TAGS) remembers the first entry of its tag ----
   const uint16_t my_tag = FILTER_TAGS[lane < N_TAGS ? lane : 0];
   int32_t my_pos = -1;
@@ -115,34 +121,52 @@ __global__ __launch_bounds__(256) void k_filter_records(const FilterParams P) {
   {
     uint32_t p = 0;
     while (p + 3 <= an) {
-      const uint16_t t = (uint16_t)(A[p] | ((uint16_t)A[p + 1] << 8));
-      const uint32_t ty = A[p + 2];
-      const bool m = lane < N_TAGS && t == my_tag && my_pos < 0;
-      if (m) { my_pos = (int32_t)p; my_ty = ty; }
-      int64_t size = -1;
-      const int fx = bam::tag_fixed_size((uint8_t)ty);
-      if (fx > 0) size = fx;
-      else if (ty == 'Z' || ty == 'H') {
-        const uint32_t s = p + 3;
-        for (uint32_t base = s; base < an; base += 64) {
-          const uint32_t i = base + lane;
-          const uint8_t ch = i < an ? A[i] : (uint8_t)1;
-          const uint64_t b = __ballot(ch == 0);
-          if (b) { size = (int64_t)(base - s) + (__ffsll((unsigned long long)b) - 1) + 1; break; }
+      // a 64-byte window of the aux block, one byte per lane; the entries that start inside it are taken apart with scalar
+      // lane reads, so a run of short tags costs one LDS round trip instead of one (or three) per tag
+      const uint32_t wbase = p;
+      const uint32_t wi = wbase + lane;
+      const uint32_t w = wi < an ? (uint32_t)A[wi] : 0x100u;              // 0x100: past the end, never NUL
+      const uint64_t nul = __ballot(w == 0);
+      bool stop = false;
+      for (;;) {
+        const uint32_t o = p - wbase;                                      // p and o are wave-uniform
+        const uint32_t t = (rl(w, o) & 0xFF) | ((rl(w, o + 1) & 0xFF) << 8);
+        const uint32_t ty = rl(w, o + 2) & 0xFF;
+        const bool m = lane < N_TAGS && t == my_tag && my_pos < 0;
+        if (m) { my_pos = (int32_t)p; my_ty = ty; }
+        int64_t size = -1;
+        const int fx = fixed_size_fast(ty);
+        if (fx > 0) size = fx;
+        else if (ty == 'Z' || ty == 'H') {
+          const uint64_t in_window = nul >> (o + 3);
+          if (in_window) size = (int64_t)(__ffsll((unsigned long long)in_window) - 1) + 1;
+          else {
+            const uint32_t s0 = p + 3;
+            for (uint32_t base = wbase + 64; base < an; base += 64) {
+              const uint32_t i = base + lane;
+              const uint8_t ch = i < an ? A[i] : (uint8_t)1;
+              const uint64_t bm = __ballot(ch == 0);
+              if (bm) { size = (int64_t)(base - s0) + (__ffsll((unsigned long long)bm) - 1) + 1; break; }
+            }
+          }
+        } else if (ty == 'B') {
+          if (an - (p + 3) >= 5) {
+            const int es = fixed_size_fast(rl(w, o + 3) & 0xFF);
+            const uint32_t cnt = (rl(w, o + 4) & 0xFF) | ((rl(w, o + 5) & 0xFF) << 8) | ((rl(w, o + 6) & 0xFF) << 16) | ((rl(w, o + 7) & 0xFF) << 24);
+            if (es > 0) size = 5 + (int64_t)cnt * es;
+          }
         }
-      } else if (ty == 'B') {
-        if (an - (p + 3) >= 5) {
-          const int es = bam::tag_fixed_size(A[p + 3]);
-          if (es > 0) size = 5 + (int64_t)bam::rd32(A + p + 4) * es;
-        }
+        if (m) my_size = size;
+        if (size < 0) { stop = true; break; }
+        const uint64_t np = (uint64_t)p + 3 + (uint64_t)size;
+        if (np + 3 > an) { stop = true; break; }
+        p = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)np);
+        if (p - wbase + 8 > 64) break;                                     // next entry header not wholly inside: new window
       }
-      if (m) my_size = size;
-      if (size < 0) break;
-      const uint64_t np = (uint64_t)p + 3 + (uint64_t)size;
-      if (np > an) break;
-      p = (uint32_t)np;
+      if (stop) break;
     }
   }
+  FPH(1)
   // lane-local decode of the remembered entry
   uint32_t has_int = 0, iv_lo = 0, iv_hi = 0, has_f = 0, fbits = 0;
   uint32_t arr_ok = 0, arr_et = 0, arr_es = 0, arr_cnt = 0;
@@ -221,6 +245,7 @@ __global__ __launch_bounds__(256) void k_filter_records(const FilterParams P) {
     __builtin_amdgcn_wave_barrier();
   }
 
+  FPH(2)
   // ---- thresholds and the tags the sweep needs, wave-uniform ----
   const bool duplex = rl(my_present, T_aD) && rl(my_present, T_bD);       // is_duplex_consensus: both tags, any type
   auto src_of = [&](int k) { return Src{rl(src_kind, k), rl(src_off, k), rl(src_cnt, k)}; };
@@ -286,6 +311,7 @@ __global__ __launch_bounds__(256) void k_filter_records(const FilterParams P) {
       if (nb != b) g[seq_off + j] = nb;
     }
   }
+  FPH(3)
   const uint64_t masked_total = wave_sum(n_masked), nocall_total = wave_sum(n_nocall), qsum_total = wave_sum(qsum);
 
   // ---- read-level filters (filter_read / filter_duplex_read, check_no_call_and_quality) ----
@@ -326,6 +352,44 @@ __global__ __launch_bounds__(256) void k_filter_records(const FilterParams P) {
     else ok = (l_seq > 0 ? (double)nocall_total / (double)l_seq : 0.0) <= P.o.max_no_call_fraction;
   }
   if (lane == 0) { P.pass[r] = ok ? 1 : 0; P.masked[r] = (uint32_t)masked_total; }
+  FPH(4)
+}
+
+#ifndef FGX_FILTER_OCC
+#define FGX_FILTER_OCC 8
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FGX_FILTER_OCC, FGX_FILTER_OCC))) void k_filter_records(const FilterParams P) {
+  extern __shared__ __align__(16) uint8_t lds_raw[];
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t r = blockIdx.x * 4 + wave;
+  if (r >= P.n_rec) return;
+#if FGX_PHASE_TIMING
+  unsigned long long _t = __builtin_amdgcn_s_memtime();
+#endif
+  const uint64_t off = P.rec_off[r];
+  const uint32_t len = P.rec_len[r];
+  if (len < 32 || off + len > P.blob_len) { if (lane == 0) { report(P.error, r, ERR_SHORT); P.pass[r] = 0; P.masked[r] = 0; } return; }
+  uint8_t* g = P.blob + off;
+  // stage the record into this wave's LDS slice, same alignment mod 4 as in HBM so that the copy is whole dwords
+  const uint32_t shift = (uint32_t)((uintptr_t)g & 3);
+  const uint32_t n_dw = (shift + len + 3) / 4;
+  if ((uint64_t)n_dw * 4 <= P.lds_slice) {
+    uint8_t* slice = lds_raw + (size_t)wave * P.lds_slice;
+    const uint32_t* src = (const uint32_t*)(g - shift);
+    uint32_t* dst = (uint32_t*)slice;
+    for (uint32_t base = 0; base < n_dw; base += 256) {       // four loads in flight per lane before the first LDS write
+      uint32_t v[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) { const uint32_t i = base + k * 64 + lane; v[k] = src[i < n_dw ? i : n_dw - 1]; }
+#pragma unroll
+      for (int k = 0; k < 4; k++) { const uint32_t i = base + k * 64 + lane; if (i < n_dw) dst[i] = v[k]; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    filter_body(P, r, lane, g, slice + shift, true, len FPH_PASS);
+  } else {
+    filter_body(P, r, lane, g, g, false, len FPH_PASS);      // beyond the slice: read from HBM
+  }
 }
 
 // ---- templates ------------------------------------------------------------------------------------------------------
@@ -491,9 +555,16 @@ int filter_records_device(fgx_caller* c, FilterBuffers& B, const fgx_filter_opti
 
   FilterParams P{};
   P.blob = d_blob; P.blob_len = blob_len; P.rec_off = d_rec_off; P.rec_len = d_rec_len; P.n_rec = n; P.o = *o;
-  P.pass = B.pass.as<uint8_t>(); P.masked = B.masked.as<uint32_t>(); P.error = d_err; P.lds_slice = B.lds_slice;
+  // LDS slice per wavefront: 1.5 x the mean record (records beyond it are read from HBM — correct, slower), small enough to keep
+  // the CU full of waves for short records
+  uint32_t slice = B.lds_slice;
+  if (slice == 0) {
+    const uint64_t mean = blob_len / n;
+    slice = (uint32_t)std::min<uint64_t>(16384, std::max<uint64_t>(1536, ((mean * 3 / 2 + 64 + 255) / 256) * 256));
+  }
+  P.pass = B.pass.as<uint8_t>(); P.masked = B.masked.as<uint32_t>(); P.error = d_err; P.lds_slice = slice;
   const dim3 block(256), grid_w((n + 3) / 4), grid_t((n + 255) / 256);
-  hipLaunchKernelGGL(k_filter_records, grid_w, block, (size_t)B.lds_slice * 4, s, P);
+  hipLaunchKernelGGL(k_filter_records, grid_w, block, (size_t)slice * 4, s, P);
 
   uint32_t n_tmpl = n;
   const uint32_t* d_first = nullptr;
@@ -598,3 +669,13 @@ int filter_slots_device(fgx_caller* c, FilterBuffers& B, const fgx_filter_option
 }
 
 }  // namespace fgx
+
+#if FGX_PHASE_TIMING
+extern "C" int fgx_debug_filter_phase_cycles(unsigned long long* out8, int reset) {
+  unsigned long long h[64 * 8];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(fgx::g_fphase), sizeof(h)) != hipSuccess) return 1;
+  for (int i = 0; i < 8; i++) { out8[i] = 0; for (int b = 0; b < 64; b++) out8[i] += h[b * 8 + i]; }
+  if (reset) { memset(h, 0, sizeof(h)); if (hipMemcpyToSymbol(HIP_SYMBOL(fgx::g_fphase), h, sizeof(h)) != hipSuccess) return 1; }
+  return 0;
+}
+#endif
