@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     L = _lib.load()
     hdr = open(os.path.join(ROOT, "include", "fgumi_amd.h")).read()
     declared = set(re.findall(r"\b(fgx_[a-z_0-9]+)\s*\(", hdr))
-    declared -= {"fgx_options", "fgx_output", "fgx_caller", "fgx_sim_params"}
+    declared -= {"fgx_options", "fgx_output", "fgx_caller", "fgx_sim_params", "fgx_group_options", "fgx_filter_options", "fgx_filter_output"}
     assert declared, "header parse failed"
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in include/fgumi_amd.h but not exported"
@@ -35,6 +35,31 @@ def test_options_struct_layout_matches_header():
     assert o.tag == b"MI" and o.cell_tag == b"CB"
     assert (o.error_rate_pre_umi, o.error_rate_post_umi, o.min_input_base_quality, o.min_consensus_base_quality) == (45, 40, 10, 2)
     assert o.overlapping_consensus == 1 and o.max_reads == -1 and o.read_group_id == b"A"
+
+
+def test_filter_options_layout_defaults_and_host_mirror():
+    """fgx_filter_options: same layout in the product mirror and the oracle's, CLI defaults (src/lib/commands/filter.rs:118-170), and the
+    FilterConfig host logic: 1-3 values expand from the last (filter.rs:20-27), ordering violations are errors (filter.rs:284-318)."""
+    import struct as st
+    from fgumi_amd import FilterConfig, FilterThresholds, record_offsets
+    o = _lib.FilterOptions()
+    lib.fgx_filter_options_default(C.byref(o))
+    assert o.struct_size == C.sizeof(_lib.FilterOptions) == C.sizeof(orc.FilterOptions) == 88
+    assert list(o.min_reads) == [1, 1, 1] and list(o.max_read_error_rate) == [0.025] * 3 and list(o.max_base_error_rate) == [0.1] * 3
+    assert o.max_no_call_fraction == 0.2 and o.filter_by_template == 1 and not o.has_min_base_quality and not o.track_rejects
+    c = FilterConfig.new([5, 3], [0.05], [0.2, 0.1, 0.3], min_base_quality=20)
+    assert (c.duplex.min_reads, c.ab.min_reads, c.ba.min_reads) == (5, 3, 3) and (c.ab.max_base_error_rate, c.ba.max_base_error_rate) == (0.1, 0.3)
+    for bad in (dict(min_reads=[1, 2]), dict(min_reads=[3, 2, 3]), dict(min_reads=[3], max_read_error_rate=[0.1, 0.2, 0.1]),
+                dict(min_reads=[3], max_base_error_rate=[0.1, 0.3, 0.2]), dict(min_reads=[3], max_no_call_fraction=2.5),
+                dict(min_reads=[3], max_read_error_rate=[1.5]), dict(min_reads=[1, 1, 1, 1]), dict(min_reads=[])):
+        with pytest.raises(ValueError):
+            FilterConfig.new(**bad)
+    assert FilterConfig.for_duplex(FilterThresholds(4), FilterThresholds(2)).ba.min_reads == 2
+    data = st.pack("<I", 3) + b"abc" + st.pack("<I", 0) + st.pack("<I", 2) + b"zz"
+    off, ln = record_offsets(data)
+    assert off.tolist() == [4, 11, 15] and ln.tolist() == [3, 0, 2]
+    with pytest.raises(ValueError):
+        record_offsets(data[:-1])
 
 
 def test_create_fails_loudly_without_gpu():
