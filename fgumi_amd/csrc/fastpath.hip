@@ -70,6 +70,8 @@ struct Shared {
   uint64_t col_base;
   uint32_t tile_bytes;
   unsigned long long raw_lo, raw_hi;    // byte span of the family's records in the blob
+  uint32_t g_wcnt[2][3];                // gates: kept reads per wave and end
+  uint32_t g_best[3], g_rxcnt[3], g_rxpos[3], g_rxbad[3];
 };
 
 __device__ __forceinline__ void defer(Shared& S) { S.defer = 1; }
@@ -320,30 +322,39 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
   PHB(11)
   // ---- 3. overlapping-bases pre-correction (overlapping.rs:236-336, 627-684) ------------------------
   if (P.overlap) {
-    // pair map semantics: for each name the LAST primary record with FIRST set and the LAST with (not FIRST and) LAST set
-    if (tid < n) {
-      ReadInfo& R = S.ri[tid];
-      bool is_r1 = !R.excluded && (R.flags & bam::F_FIRST);
-      if (is_r1) {
+    // pair map semantics: for each name the LAST primary record with FIRST set and the LAST with (not FIRST and) LAST set.
+    // One wavefront per R1 candidate, the lanes test 64 records at a time (n <= 128: two steps).
+    {
+      const uint32_t wave_p = tid >> 6, lane_p = tid & 63;
+      for (uint32_t a = wave_p; a < n; a += NT / 64) {
+        const ReadInfo& R = S.ri[a];
+        if (R.excluded || !(R.flags & bam::F_FIRST)) continue;
         const uint8_t* nm = blobL + R.goff + 32;
-        auto same_name = [&](const ReadInfo& O) {
-          if (O.name_hash != R.name_hash || O.name_len != R.name_len) return false;
-          const uint8_t* on = blobL + O.goff + 32;
-          for (uint32_t i = 0; i < R.name_len; i++) if (on[i] != nm[i]) return false;
-          return true;
-        };
-        bool last_r1 = true;
-        for (uint32_t u = tid + 1; u < n && last_r1; u++) {
-          const ReadInfo& O = S.ri[u];
-          if (!O.excluded && (O.flags & bam::F_FIRST) && same_name(O)) last_r1 = false;
-        }
-        if (last_r1) {
-          int m = -1;
-          for (uint32_t u = 0; u < n; u++) {
+        const uint32_t rh = R.name_hash, rl_ = R.name_len;
+        uint64_t later_r1[2], r2s[2];
+        for (int c = 0; c < 2; c++) {
+          const uint32_t u = lane_p + 64u * c;
+          bool is_later_r1 = false, is_r2 = false;
+          if (u < n) {
             const ReadInfo& O = S.ri[u];
-            if (!O.excluded && !(O.flags & bam::F_FIRST) && (O.flags & bam::F_LAST) && same_name(O)) m = (int)u;
+            if (!O.excluded && O.name_hash == rh && O.name_len == rl_) {
+              const bool first = (O.flags & bam::F_FIRST) != 0;
+              const bool cand = first ? (u > a) : ((O.flags & bam::F_LAST) != 0);
+              if (cand) {
+                const uint8_t* on = blobL + O.goff + 32;
+                bool same = true;
+                for (uint32_t i = 0; i < rl_ && same; i++) same = on[i] == nm[i];
+                is_later_r1 = same && first; is_r2 = same && !first;
+              }
+            }
           }
-          R.mate = (int16_t)m;
+          later_r1[c] = __ballot(is_later_r1); r2s[c] = __ballot(is_r2);
+        }
+        if (lane_p == 0 && !(later_r1[0] | later_r1[1])) {
+          int m = -1;
+          if (r2s[1]) m = 64 + (63 - __clzll((long long)r2s[1]));
+          else if (r2s[0]) m = 63 - __clzll((long long)r2s[0]);
+          S.ri[a].mate = (int16_t)m;
         }
       }
     }
@@ -426,79 +437,109 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
 
   PHB(13)
   // ---- 5. family gates (process_group :1329-1422, process_subgroup :1454-1646) -------------------------
-  if (tid == 0) {
-    uint32_t* st = S.stats;
-    st[0] += n;
-    uint32_t n_sec = 0, n_reads = 0;
-    for (uint32_t i = 0; i < n; i++) { if (S.ri[i].excluded) n_sec++; else n_reads++; }
-    if (n_sec) { st[2] += n_sec; st[3 + FGX_REJ_SECONDARY_OR_SUPPLEMENTARY] += n_sec; }
-    bool go = n_reads > 0;
-    if (go && n_reads < P.min_reads) { st[2] += n_reads; st[3 + FGX_REJ_INSUFFICIENT_READS] += n_reads; go = false; }
-    uint32_t n_members = 0;
+  // One thread per record (n <= FAST_MAX_READS = 128: two wavefronts); counts are barrier-counts, the member lists are
+  // built with ballots, and thread 0 only takes the scalar decisions.
+  {
+    if (tid < 3) { S.g_best[tid] = 0; S.g_rxcnt[tid] = 0; S.g_rxpos[tid] = 0xFFFFFFFFu; S.g_rxbad[tid] = 0; S.g_wcnt[0][tid] = 0; S.g_wcnt[1][tid] = 0; }
+    const bool mine = tid < n;
+    const bool exc = mine && S.ri[tid].excluded;
+    const uint32_t n_sec = (uint32_t)__syncthreads_count(exc);
+    const uint32_t n_reads = n - n_sec;
+    bool go = n_reads > 0 && n_reads >= P.min_reads;
+    uint32_t my_end = 255;
+    bool my_zero = false;
+    if (go && mine && !exc) {
+      ReadInfo& R = S.ri[tid];
+      if (!(R.flags & bam::F_PAIRED)) my_end = 0;
+      else if (R.flags & bam::F_FIRST) my_end = 1;
+      else if (R.flags & bam::F_LAST) my_end = 2;
+      R.end = (uint8_t)my_end;
+      my_zero = R.zero_len != 0;
+    }
+    uint32_t cnt[3], zero[3], rem[3], first[3] = {0, 0, 0};
     bool ok[3] = {false, false, false};
-    uint32_t surv[3] = {0, 0, 0}, first[3] = {0, 0, 0}, clen[3] = {0, 0, 0};
-    if (go) {
-      for (uint32_t i = 0; i < n; i++) {
-        ReadInfo& R = S.ri[i];
-        if (R.excluded) continue;
-        if (!(R.flags & bam::F_PAIRED)) R.end = 0;
-        else if (R.flags & bam::F_FIRST) R.end = 1;
-        else if (R.flags & bam::F_LAST) R.end = 2;
+    for (int e = 0; e < 3; e++) {
+      cnt[e] = (uint32_t)__syncthreads_count(my_end == (uint32_t)e);
+      zero[e] = (uint32_t)__syncthreads_count(my_end == (uint32_t)e && my_zero);
+      rem[e] = cnt[e] - zero[e];
+    }
+    bool want_defer = false;
+    uint32_t n_members = 0;
+    for (int e = 0; e < 3; e++) {
+      if (!go || cnt[e] == 0 || cnt[e] < P.min_reads || rem[e] < P.min_reads) continue;
+      if (P.max_reads >= 0 && (int64_t)rem[e] > P.max_reads) { want_defer = true; break; }
+      // alignment filter: every read is mapped with one M-like block → a single prefix-compatible group, all kept
+      ok[e] = true; first[e] = n_members; n_members += rem[e];
+    }
+    // member lists: file order inside an end
+    const bool keep = my_end < 3 && ok[my_end] && !my_zero;
+    const uint32_t wv = tid >> 6, ln = tid & 63;
+    uint32_t my_rank = 0;
+    for (int e = 0; e < 3; e++) {
+      const uint64_t bm = __ballot(keep && my_end == (uint32_t)e);
+      if (wv < 2 && ln == 0) S.g_wcnt[wv][e] = (uint32_t)__popcll(bm);
+      if (keep && my_end == (uint32_t)e) my_rank = (uint32_t)__popcll(bm & ((1ull << ln) - 1));
+    }
+    __syncthreads();
+    uint32_t my_pos = 0;                      // position inside the end's member list
+    if (keep) {
+      my_pos = my_rank + (wv == 1 ? S.g_wcnt[0][my_end] : 0);
+      S.members[first[my_end] + my_pos] = (uint16_t)tid;
+      const ReadInfo& R = S.ri[tid];
+      if (P.min_reads <= 1) atomicMax(&S.g_best[my_end], (uint32_t)R.final_len);      // consensus length = the longest kept read
+      if (R.has_rx) { atomicAdd(&S.g_rxcnt[my_end], 1u); atomicMin(&S.g_rxpos[my_end], my_pos); }
+    }
+    __syncthreads();
+    if (keep) {
+      const ReadInfo& R = S.ri[tid];
+      if (P.min_reads > 1) {                  // min_reads-th longest kept read (:1661-1669): every kept read ranks itself
+        const uint32_t la = R.final_len;
+        uint32_t ge = 0;
+        for (uint32_t bq = 0; bq < rem[my_end]; bq++) if (S.ri[S.members[first[my_end] + bq]].final_len >= la) ge++;
+        if (ge >= P.min_reads) atomicMax(&S.g_best[my_end], la);
       }
-      for (uint32_t e = 0; e < 3 && !S.defer; e++) {
-        uint32_t cnt = 0, zero = 0;
-        for (uint32_t i = 0; i < n; i++) if (S.ri[i].end == e) { cnt++; if (S.ri[i].zero_len) zero++; }
-        if (cnt == 0) continue;
-        if (cnt < P.min_reads) { st[2] += cnt; st[3 + FGX_REJ_INSUFFICIENT_READS] += cnt; continue; }
-        if (zero) { st[2] += zero; st[3 + FGX_REJ_ZERO_LENGTH_AFTER_TRIMMING] += zero; }
-        uint32_t rem = cnt - zero;
-        if (rem < P.min_reads) { if (rem) { st[2] += rem; st[3 + FGX_REJ_INSUFFICIENT_READS] += rem; } continue; }
-        // alignment filter: every read is mapped with one M-like op → a single prefix-compatible group, all kept
-        if (P.max_reads >= 0 && (int64_t)rem > P.max_reads) { defer(S); break; }
-        first[e] = n_members;
-        for (uint32_t i = 0; i < n; i++) if (S.ri[i].end == e && !S.ri[i].zero_len) S.members[n_members++] = (uint16_t)i;
-        surv[e] = rem;
-        // consensus length = min_reads-th longest kept read (:1661-1669)
-        uint32_t k = P.min_reads, best = 0;
-        if (k == 1) { for (uint32_t a = first[e]; a < n_members; a++) { uint32_t la = S.ri[S.members[a]].final_len; if (la > best) best = la; } }   // the longest read
-        else for (uint32_t a = first[e]; a < n_members; a++) {      // O(n^2) order statistic on one thread: only for min_reads > 1
-          uint32_t la = S.ri[S.members[a]].final_len, ge = 0;
-          for (uint32_t b = first[e]; b < n_members; b++) if (S.ri[S.members[b]].final_len >= la) ge++;
-          if (ge >= k && la > best) best = la;
-        }
-        clen[e] = best;
-        ok[e] = true;
+      if (R.has_rx) {                         // UMIs of unequal length (vanilla_caller.rs:1842-1856 → consensus_umis panics)
+        const uint32_t len0 = S.ri[S.members[first[my_end] + S.g_rxpos[my_end]]].rx_len;
+        if (R.rx_len != len0) S.g_rxbad[my_end] = 1;
       }
     }
-    if (!S.defer) {
-      uint32_t ne = 0;
-      auto push_end = [&](uint32_t e) {
-        S.end_type[ne] = e; S.end_first[ne] = first[e]; S.end_cnt[ne] = surv[e]; S.end_len[ne] = clen[e];
-        S.end_maxd[ne] = 0; S.end_mind[ne] = 0xFFFFFFFFu; S.end_sumd[ne] = 0; S.end_sume[ne] = 0;
-        ne++;
-      };
-      if (ok[0]) { st[1] += 1; push_end(0); }
-      if (ok[1] && ok[2]) { st[1] += 2; push_end(1); push_end(2); }
-      else if (ok[1]) { st[2] += surv[1]; st[3 + FGX_REJ_ORPHAN_CONSENSUS] += surv[1]; }
-      else if (ok[2]) { st[2] += surv[2]; st[3 + FGX_REJ_ORPHAN_CONSENSUS] += surv[2]; }
-      uint32_t total = 0;
-      for (uint32_t k = 0; k < ne; k++) { S.end_coloff[k] = total; total += S.end_len[k]; }
-      S.n_ends = ne;
-      S.col_base = P.col_base[g];   // deterministic scratch slot: exclusive scan of the per-family column bound
-      // UMIs carried by the kept reads of each end (vanilla_caller.rs:1842-1856)
-      for (uint32_t k = 0; k < ne && !S.defer; k++) {
-        uint32_t cnt = 0, len0 = 0, firstr = 0;
-        bool same = true;
-        for (uint32_t a = 0; a < S.end_cnt[k]; a++) {
-          const ReadInfo& R = S.ri[S.members[S.end_first[k] + a]];
-          if (!R.has_rx) continue;
-          if (cnt == 0) { len0 = R.rx_len; firstr = S.members[S.end_first[k] + a]; }
-          else if (R.rx_len != len0) same = false;
-          cnt++;
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t* st = S.stats;
+      st[0] += n;
+      if (n_sec) { st[2] += n_sec; st[3 + FGX_REJ_SECONDARY_OR_SUPPLEMENTARY] += n_sec; }
+      if (n_reads > 0 && n_reads < P.min_reads) { st[2] += n_reads; st[3 + FGX_REJ_INSUFFICIENT_READS] += n_reads; }
+      if (want_defer) defer(S);
+      if (go && !want_defer) {
+        for (int e = 0; e < 3; e++) {
+          if (cnt[e] == 0) continue;
+          if (cnt[e] < P.min_reads) { st[2] += cnt[e]; st[3 + FGX_REJ_INSUFFICIENT_READS] += cnt[e]; continue; }
+          if (zero[e]) { st[2] += zero[e]; st[3 + FGX_REJ_ZERO_LENGTH_AFTER_TRIMMING] += zero[e]; }
+          if (rem[e] < P.min_reads) { if (rem[e]) { st[2] += rem[e]; st[3 + FGX_REJ_INSUFFICIENT_READS] += rem[e]; } continue; }
         }
-        S.end_rx_cnt[k] = cnt; S.end_rx_len[k] = len0; S.end_rx_first[k] = firstr;
-        if (cnt > 1 && !same) defer(S);          // consensus_umis panics on unequal lengths → general path reports it
-        if (cnt >= 1 && len0 > FAST_RX_CAP) defer(S);
+      }
+      if (!S.defer) {
+        uint32_t ne = 0;
+        auto push_end = [&](uint32_t e) {
+          S.end_type[ne] = e; S.end_first[ne] = first[e]; S.end_cnt[ne] = rem[e]; S.end_len[ne] = S.g_best[e];
+          S.end_maxd[ne] = 0; S.end_mind[ne] = 0xFFFFFFFFu; S.end_sumd[ne] = 0; S.end_sume[ne] = 0;
+          // UMIs carried by the kept reads of this end
+          const uint32_t rc = S.g_rxcnt[e];
+          const uint32_t fr = rc ? S.members[first[e] + S.g_rxpos[e]] : 0;
+          const uint32_t len0 = rc ? S.ri[fr].rx_len : 0;
+          S.end_rx_cnt[ne] = rc; S.end_rx_len[ne] = len0; S.end_rx_first[ne] = fr;
+          if (rc > 1 && S.g_rxbad[e]) defer(S);          // consensus_umis panics on unequal lengths → general path reports it
+          if (rc >= 1 && len0 > FAST_RX_CAP) defer(S);
+          ne++;
+        };
+        if (ok[0]) { st[1] += 1; push_end(0); }
+        if (ok[1] && ok[2]) { st[1] += 2; push_end(1); push_end(2); }
+        else if (ok[1]) { st[2] += rem[1]; st[3 + FGX_REJ_ORPHAN_CONSENSUS] += rem[1]; }
+        else if (ok[2]) { st[2] += rem[2]; st[3 + FGX_REJ_ORPHAN_CONSENSUS] += rem[2]; }
+        uint32_t total = 0;
+        for (uint32_t k = 0; k < ne; k++) { S.end_coloff[k] = total; total += S.end_len[k]; }
+        S.n_ends = ne;
+        S.col_base = P.col_base[g];   // deterministic scratch slot: exclusive scan of the per-family column bound
       }
     }
   }
@@ -745,7 +786,7 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
   }
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const uint32_t gi = blockIdx.x * WAVES_PER_BLOCK + wv;      // n_grp_total counts the groups of this launch (all of them, or a retry list)
+  const uint32_t gi = blockIdx.x * (blockDim.x >> 6) + wv;    // n_grp_total counts the groups of this launch (all of them, or a retry list)
   if (gi >= n_grp_total) return;
   const uint32_t g = P.group_list ? P.group_list[gi] : P.g0 + gi;
   uint8_t* W = dyn + (size_t)wv * P.lds_wave_bytes;
@@ -2946,8 +2987,11 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
       FastParams PS = P;
       PS.group_list = cur_list; PS.lds_wave_bytes = stages[st];
       PS.retry = (last && (duplex || codec)) ? nullptr : lists[out_list]; PS.n_retry = d_cnt;
-      const dim3 grid((n_cur + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(256);
-      const size_t lds = (size_t)WAVES_PER_BLOCK * stages[st];
+      // fewer wavefronts per workgroup as the slices grow: the LDS a workgroup asks for is what limits the wavefronts a CU holds
+      // (4 x 22 KB = one workgroup = 4 waves per CU; 1 x 22 KB = six workgroups = 6 waves)
+      const uint32_t wpb = st == 0 ? WAVES_PER_BLOCK : st == 1 ? 2u : 1u;
+      const dim3 grid((n_cur + wpb - 1) / wpb), block(64 * wpb);
+      const size_t lds = (size_t)wpb * stages[st];
       if (codec) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_family_wave<2>), grid, block, lds, s, PS, n_cur);
       else if (duplex) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_family_wave<1>), grid, block, lds, s, PS, n_cur);
       else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_family_wave<0>), grid, block, lds, s, PS, n_cur);

@@ -215,6 +215,14 @@ def test_simplex_depth8_and_long_tail(handle):
     _assert_same(simulate_grouped_reads(300, family_size=3, read_length=151, insert_mean=120, insert_sd=30))   # read-through clips
 
 
+@pytest.mark.parametrize("kw", [dict(min_reads=1), dict(min_reads=3), dict(min_reads=40), dict(overlapping=False, min_reads=2), dict(trim=True), dict(max_reads=20),
+                                dict(min_reads=2, min_input_base_quality=30, produce_per_base_tags=False)])
+def test_large_families_workgroup_kernel(handle, kw):
+    """66..128 records per family: beyond one wavefront, the workgroup-per-family kernel (parallel gates, ballot-built member
+    lists, wave-parallel mate pairing) decides them."""
+    _assert_same(simulate_grouped_reads(150, family_size=33, family_size_max=64, error_rate_ppm=5000), **kw)
+
+
 def test_crafted_edge_cases(handle):
     groups = cases.crafted_groups()
     g = GroupedReads.from_groups(groups)
