@@ -36,7 +36,10 @@ using bam::rd32;
 
 namespace {
 
-constexpr int NT = 256;                 // threads per family workgroup
+#ifndef FGX_BLOCK_NT
+#define FGX_BLOCK_NT 512
+#endif
+constexpr int NT = FGX_BLOCK_NT;        // threads per family workgroup
 constexpr int FAST_MAX_READS = 128;     // per-read LDS tables
 constexpr int MAX_MC_OPS = 8;
 constexpr uint32_t MAX_CIG_OPS = 6;     // clips + aligned ops of a read the device pipelines take
@@ -290,13 +293,13 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
 
   PHB(10)
   // ---- 2. stage bases (unpacked 4-bit codes) and quals into LDS -------------------------------------
-  for (uint32_t r = 0; r < n; r++) {
+  for (uint32_t r = tid >> 6; r < n; r += NT / 64) {          // one wavefront per record: NT / 64 records in flight
     const ReadInfo& R = S.ri[r];
     if (R.excluded) continue;
     const uint8_t* p = blobL + R.goff;
     const uint8_t* sq = p + R.seq_off;
     const uint8_t* ql = sq + ((uint32_t)R.l_seq + 1) / 2;
-    for (uint32_t i = tid; i < R.l_seq; i += NT) {
+    for (uint32_t i = tid & 63; i < R.l_seq; i += 64) {
       uint8_t b = sq[i >> 1];
       lb[R.row + i] = (i & 1) ? (b & 0xF) : (b >> 4);
       lq[R.row + i] = ql[i];

@@ -373,7 +373,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FGX_FILTER_
   // stage the record into this wave's LDS slice, same alignment mod 4 as in HBM so that the copy is whole dwords
   const uint32_t shift = (uint32_t)((uintptr_t)g & 3);
   const uint32_t n_dw = (shift + len + 3) / 4;
-  if ((uint64_t)n_dw * 4 <= P.lds_slice) {
+  // whole-dword staging reads up to 3 bytes either side of the record: only when those bytes are still inside the blob
+  if ((uint64_t)n_dw * 4 <= P.lds_slice && off - shift + (uint64_t)n_dw * 4 <= P.blob_len) {
     uint8_t* slice = lds_raw + (size_t)wave * P.lds_slice;
     const uint32_t* src = (const uint32_t*)(g - shift);
     uint32_t* dst = (uint32_t*)slice;
@@ -489,7 +490,7 @@ __global__ void k_template_decide(const DecideParams P) {
 
 // ---- output: one wavefront per record, [block_size][record] at its scanned offset -------------------------------------------
 struct CopyParams {
-  const uint8_t* blob; const uint64_t* rec_off; const uint32_t* rec_len; uint32_t n_rec;
+  const uint8_t* blob; uint64_t blob_len; const uint64_t* rec_off; const uint32_t* rec_len; uint32_t n_rec;
   const uint32_t* ord_src; const uint64_t* keep_size; const uint64_t* rej_size; const uint64_t* keep_off; const uint64_t* rej_off;
   uint8_t* out_keep; uint8_t* out_rej;
 };
@@ -506,6 +507,7 @@ __global__ __launch_bounds__(256) void k_copy_records(const CopyParams P) {
   const uint32_t len = P.rec_len[src];
   const uint8_t* S = P.blob + P.rec_off[src];
   const uint32_t total = len + 4;
+  const uint8_t* blob_end = P.blob + P.blob_len;
   auto out_byte = [&](uint32_t k) -> uint8_t { return k < 4 ? (uint8_t)(len >> (8 * k)) : S[k - 4]; };
   const uint32_t head = (uint32_t)((4 - ((uintptr_t)D & 3)) & 3);                       // bytes before the first aligned destination dword
   const uint32_t n_dw = (total - (head < total ? head : total)) / 4;
@@ -516,10 +518,11 @@ __global__ __launch_bounds__(256) void k_copy_records(const CopyParams P) {
   for (uint32_t w = lane; w < n_dw; w += 64) {
     const uint32_t k = head + 4 * w;                                                   // output byte index of this dword
     uint32_t v;
-    if (k < 4) v = (uint32_t)out_byte(k) | ((uint32_t)out_byte(k + 1) << 8) | ((uint32_t)out_byte(k + 2) << 16) | ((uint32_t)out_byte(k + 3) << 24);
+    const uint8_t* s = S + ((int64_t)k - 4);
+    const uint32_t sh = (uint32_t)((uintptr_t)s & 3);
+    if (k < 4 || (s - sh) + 8 > blob_end)        // the prefix, or an aligned pair of source dwords that would cross the end of the blob
+      v = (uint32_t)out_byte(k) | ((uint32_t)out_byte(k + 1) << 8) | ((uint32_t)out_byte(k + 2) << 16) | ((uint32_t)out_byte(k + 3) << 24);
     else {
-      const uint8_t* s = S + (k - 4);
-      const uint32_t sh = (uint32_t)((uintptr_t)s & 3);
       const uint32_t* sa = (const uint32_t*)(s - sh);
       const uint32_t lo = sa[0];
       v = sh ? (lo >> (8 * sh)) | (sa[1] << (32 - 8 * sh)) : lo;
@@ -620,7 +623,7 @@ int filter_records_device(fgx_caller* c, FilterBuffers& B, const fgx_filter_opti
   B.out_keep.reserve(keep_total + 64);
   B.out_rej.reserve(rej_total + 64);
   CopyParams C{};
-  C.blob = d_blob; C.rec_off = d_rec_off; C.rec_len = d_rec_len; C.n_rec = n; C.ord_src = Q.ord_src; C.keep_size = Q.keep_size; C.rej_size = Q.rej_size;
+  C.blob = d_blob; C.blob_len = blob_len; C.rec_off = d_rec_off; C.rec_len = d_rec_len; C.n_rec = n; C.ord_src = Q.ord_src; C.keep_size = Q.keep_size; C.rej_size = Q.rej_size;
   C.keep_off = B.keep_off.as<uint64_t>(); C.rej_off = B.rej_off.as<uint64_t>(); C.out_keep = B.out_keep.as<uint8_t>(); C.out_rej = B.out_rej.as<uint8_t>();
   hipLaunchKernelGGL(k_copy_records, grid_w, block, 0, s, C);
   hip_check(hipStreamSynchronize(s), "sync");
