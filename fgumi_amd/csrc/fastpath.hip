@@ -75,6 +75,7 @@ struct Shared {
   unsigned long long raw_lo, raw_hi;    // byte span of the family's records in the blob
   uint32_t g_wcnt[2][3];                // gates: kept reads per wave and end
   uint32_t g_best[3], g_rxcnt[3], g_rxpos[3], g_rxbad[3];
+  uint32_t n_pairs, pair_a[FAST_MAX_READS], pair_b[FAST_MAX_READS], pair_n[FAST_MAX_READS];   // overlap correction: start of the shared stretch in both tiles, its length
 };
 
 __device__ __forceinline__ void defer(Shared& S) { S.defer = 1; }
@@ -361,28 +362,40 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
         }
       }
     }
+    if (tid == 0) S.n_pairs = 0;
+    __syncthreads();
+    // one descriptor per pair with a shared stretch (pairs are disjoint, so their order does not matter): single M/=/X op
+    // spanning the read: alignment = [pos+1, pos+l_seq], query offset = ref - (pos+1)
+    if (tid < n) {
+      const ReadInfo& A = S.ri[tid];
+      if (A.mate >= 0) {
+        const ReadInfo& B = S.ri[A.mate];
+        if (A.ref_id == B.ref_id) {
+          const int64_t s1 = (int64_t)A.pos + 1, e1 = (int64_t)A.pos + A.l_seq, s2 = (int64_t)B.pos + 1, e2 = (int64_t)B.pos + B.l_seq;
+          const int64_t lo = s1 > s2 ? s1 : s2, hi = e1 < e2 ? e1 : e2;
+          if (hi >= lo) {
+            const uint32_t k = atomicAdd(&S.n_pairs, 1u);
+            S.pair_a[k] = A.row + (uint32_t)(lo - s1); S.pair_b[k] = B.row + (uint32_t)(lo - s2); S.pair_n[k] = (uint32_t)(hi - lo + 1);
+          }
+        }
+      }
+    }
     __syncthreads();
     uint32_t ov_bases = 0, ov_agree = 0, ov_dis = 0, ov_corr = 0;
     const uint32_t wave = tid >> 6, lane = tid & 63;
-    for (uint32_t a = wave; a < n; a += NT / 64) {
-      const ReadInfo& A = S.ri[a];
-      if (A.mate < 0) continue;
-      const ReadInfo& B = S.ri[A.mate];
-      if (A.ref_id != B.ref_id) continue;
-      // single M/=/X op spanning the read: alignment = [pos+1, pos+l_seq], query offset = ref - (pos+1)
-      int64_t s1 = (int64_t)A.pos + 1, e1 = (int64_t)A.pos + A.l_seq, s2 = (int64_t)B.pos + 1, e2 = (int64_t)B.pos + B.l_seq;
-      int64_t lo = s1 > s2 ? s1 : s2, hi = e1 < e2 ? e1 : e2;
-      for (int64_t x = lo + lane; x <= hi; x += 64) {
-        uint32_t i1 = (uint32_t)(x - s1), i2 = (uint32_t)(x - s2);
-        uint8_t c1 = lb[A.row + i1], c2 = lb[B.row + i2];
+    for (uint32_t k = wave; k < S.n_pairs; k += NT / 64) {
+      const uint32_t pa = S.pair_a[k], pb = S.pair_b[k], pn = S.pair_n[k];
+      for (uint32_t x = lane; x < pn; x += 64) {
+        const uint32_t ia = pa + x, ib = pb + x;
+        uint8_t c1 = lb[ia], c2 = lb[ib];
         if (c1 == 15 || c2 == 15) continue;
         ov_bases++;
-        uint8_t qa = lq[A.row + i1], qb = lq[B.row + i2];
+        uint8_t qa = lq[ia], qb = lq[ib];
         if (c1 == c2) {
           ov_agree++;
           uint32_t s = (uint32_t)qa + qb;
           uint8_t nq = (uint8_t)(s < 93 ? s : 93);
-          lq[A.row + i1] = nq; lq[B.row + i2] = nq;
+          lq[ia] = nq; lq[ib] = nq;
           if (nq != qa || nq != qb) ov_corr++;
         } else {
           ov_dis++;
@@ -390,7 +403,7 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
           if (qa == qb) { cb = 15; cq = FGX_MIN_PHRED; }
           else if (qa > qb) { cb = c1; cq = (uint8_t)(qa - qb); if (cq < FGX_MIN_PHRED) cq = FGX_MIN_PHRED; }
           else { cb = c2; cq = (uint8_t)(qb - qa); if (cq < FGX_MIN_PHRED) cq = FGX_MIN_PHRED; }
-          lb[A.row + i1] = cb; lb[B.row + i2] = cb; lq[A.row + i1] = cq; lq[B.row + i2] = cq;
+          lb[ia] = cb; lb[ib] = cb; lq[ia] = cq; lq[ib] = cq;
           ov_corr += 2;
         }
       }
