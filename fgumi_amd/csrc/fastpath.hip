@@ -56,7 +56,7 @@ struct ReadInfo {          // LDS, one per record of the family
   int16_t mate;            // index of the R2 paired with this R1 (only set on the R1), else -1
   uint8_t mi_len, rx_len, cb_len, end;   // end: 0 fragment, 1 R1, 2 R2, 255 = not a candidate
   uint8_t has_mi, has_rx, has_cb, all_ff;
-  uint8_t excluded, zero_len, _p0, _p1;
+  uint8_t excluded, zero_len, minority, _p1;   // minority: dropped by the alignment filter (select_most_common_alignment_group)
 };
 
 struct Shared {
@@ -75,7 +75,11 @@ struct Shared {
   unsigned long long raw_lo, raw_hi;    // byte span of the family's records in the blob
   uint32_t g_wcnt[2][3];                // gates: kept reads per wave and end
   uint32_t g_best[3], g_rxcnt[3], g_rxpos[3], g_rxbad[3];
-  uint32_t n_pairs, pair_a[FAST_MAX_READS], pair_b[FAST_MAX_READS], pair_n[FAST_MAX_READS];   // overlap correction: start of the shared stretch in both tiles, its length
+  uint32_t scig[FAST_MAX_READS][MAX_CIG_OPS];   // simplified CIGAR of each read (S, H, =, X folded into M, neighbours merged): len << 4 | kind
+  uint8_t n_scig[FAST_MAX_READS];
+  uint8_t b4_order[FAST_MAX_READS];             // alignment filter: members of one end, longest first
+  uint16_t b4_mask[FAST_MAX_READS];             // alignment filter: groups a read belongs to
+  uint32_t any_complex;                         // some read has more than one aligned block or clips
 };
 
 __device__ __forceinline__ void defer(Shared& S) { S.defer = 1; }
@@ -95,6 +99,105 @@ __device__ __forceinline__ void oriented(const Shared& S, const uint8_t* lb, con
   *code = c;
   *qual = q;
 }
+
+// ---- general CIGARs in the workgroup kernel ------------------------------------------------------------------------------------
+// query offset of reference position x (1-based) in a read that starts at ref1, or -1 when x is not inside an aligned block or
+// falls past the stored bases (ReadMateAndRefPosIterator, overlapping.rs:565-620)
+__device__ __forceinline__ int32_t map_ref_to_query(const uint32_t* ops, uint32_t n, int64_t ref1, int64_t x, uint32_t l_seq) {
+  int64_t ref = ref1, q = 0;
+#pragma unroll
+  for (uint32_t i = 0; i < MAX_CIG_OPS; i++) {
+    if (i >= n) break;
+    const uint32_t t = ops[i] & 15;
+    const int64_t len = ops[i] >> 4;
+    if (t == 0 || t == 7 || t == 8) {
+      if (x < ref + len) { if (x < ref) return -1; const int64_t qi = q + (x - ref); return qi < (int64_t)l_seq ? (int32_t)qi : -1; }
+      ref += len; q += len;
+    } else if (t == 1 || t == 4) q += len;
+    else if (t == 2 || t == 3) ref += len;
+  }
+  return -1;
+}
+// SourceRead::simplified_cigar of read r: reversed for a reverse-strand read, truncated to its final length
+// (create_source_read :1172-1176, truncate_simplified_cigar :1028-1062)
+__device__ inline uint32_t oriented_truncated_cigar(const Shared& S, uint32_t r, uint32_t* out) {
+  const ReadInfo& R = S.ri[r];
+  const uint32_t n = S.n_scig[r];
+  const bool rev = (R.flags & bam::F_REVERSE) != 0;
+  uint32_t remaining = R.final_len, m = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    if (remaining == 0) break;
+    const uint32_t v = S.scig[r][rev ? n - 1 - i : i], k = v & 15, len = v >> 4;
+    if (k == 0 || k == 1) { const uint32_t take = len < remaining ? len : remaining; out[m++] = (take << 4) | k; remaining -= take; }
+    else out[m++] = v;
+  }
+  return m;
+}
+__device__ inline bool cigar_is_prefix(const uint32_t* a, uint32_t na, const uint32_t* b, uint32_t nb) {   // clipper.rs:1212-1241
+  if (na > nb) return false;
+  for (uint32_t i = 0; i < na; i++) {
+    if ((a[i] & 15) != (b[i] & 15)) return false;
+    if (i + 1 == na) { if ((a[i] >> 4) > (b[i] >> 4)) return false; }
+    else if ((a[i] >> 4) != (b[i] >> 4)) return false;
+  }
+  return true;
+}
+__device__ inline int cigar_cmp(const uint32_t* a, uint32_t na, const uint32_t* b, uint32_t nb) {   // vanilla_caller.rs:96-113: length, then op kind, then op count
+  const uint32_t n = na < nb ? na : nb;
+  for (uint32_t i = 0; i < n; i++) {
+    if ((a[i] >> 4) != (b[i] >> 4)) return (a[i] >> 4) < (b[i] >> 4) ? -1 : 1;
+    if ((a[i] & 15) != (b[i] & 15)) return (a[i] & 15) < (b[i] & 15) ? -1 : 1;
+  }
+  return na == nb ? 0 : (na < nb ? -1 : 1);
+}
+// filter_source_reads_by_alignment (vanilla_caller.rs:1242-1296) for the kept reads of end e, by one thread: stable sort by
+// length (longest first), greedy multi-membership prefix groups, the largest group wins (ties: the smaller CIGAR, then the
+// later group); everyone outside it is marked `minority`.
+__device__ inline void alignment_filter(Shared& S, uint32_t e, uint32_t n) {
+  uint32_t m = 0;
+  bool single_block = true;
+  for (uint32_t i = 0; i < n; i++)
+    if (S.ri[i].end == e && !S.ri[i].zero_len) { S.b4_order[m++] = (uint8_t)i; if (S.n_scig[i] != 1) single_block = false; }
+  if (m < 2 || single_block) return;        // (M, len) CIGARs are all prefixes of the longest one: a single group, nothing dropped
+  for (uint32_t k = 1; k < m; k++) {        // stable insertion sort, longest first
+    const uint8_t v = S.b4_order[k];
+    const uint32_t lv = S.ri[v].final_len;
+    uint32_t j = k;
+    while (j > 0 && S.ri[S.b4_order[j - 1]].final_len < lv) { S.b4_order[j] = S.b4_order[j - 1]; j--; }
+    S.b4_order[j] = v;
+  }
+  constexpr uint32_t MAX_GROUPS = 16;
+  uint32_t ng = 0;
+  uint8_t founder[MAX_GROUPS];
+  uint32_t count[MAX_GROUPS];
+  uint32_t ca[MAX_CIG_OPS], cb[MAX_CIG_OPS];
+  for (uint32_t k = 0; k < m; k++) {
+    const uint32_t r = S.b4_order[k];
+    const uint32_t na = oriented_truncated_cigar(S, r, ca);
+    uint32_t mask = 0;
+    for (uint32_t g = 0; g < ng; g++) {
+      const uint32_t nb = oriented_truncated_cigar(S, founder[g], cb);
+      if (cigar_is_prefix(ca, na, cb, nb)) { count[g]++; mask |= 1u << g; }      // no break: a read joins every group it is a prefix of
+    }
+    if (!mask) {
+      if (ng == MAX_GROUPS) { defer(S); return; }
+      founder[ng] = (uint8_t)r; count[ng] = 1; mask = 1u << ng; ng++;
+    }
+    S.b4_mask[r] = (uint16_t)mask;
+  }
+  uint32_t best = 0;                         // Iterator::max_by keeps the LAST maximal element
+  for (uint32_t i = 1; i < ng; i++) {
+    int c;
+    if (count[best] != count[i]) c = count[best] < count[i] ? -1 : 1;
+    else {
+      const uint32_t na = oriented_truncated_cigar(S, founder[i], ca), nb = oriented_truncated_cigar(S, founder[best], cb);
+      c = cigar_cmp(ca, na, cb, nb);
+    }
+    if (c <= 0) best = i;
+  }
+  for (uint32_t k = 0; k < m; k++) { const uint32_t r = S.b4_order[k]; if (!((S.b4_mask[r] >> best) & 1)) S.ri[r].minority = 1; }
+}
+
 
 #ifndef FGX_PHASE_TIMING
 #define FGX_PHASE_TIMING 0   /* 1: per-phase s_memtime deltas of k_family_wave into g_phase (profiling builds only) */
@@ -122,7 +225,7 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
   const uint32_t slot0 = 3 * g;
 
   if (tid < FGX_STATS_LEN) S.stats[tid] = 0;
-  if (tid == 0) { S.defer = 0; S.n_ends = 0; S.rx_bad = 0; S.raw_lo = ~0ull; S.raw_hi = 0ull; }
+  if (tid == 0) { S.defer = 0; S.n_ends = 0; S.rx_bad = 0; S.raw_lo = ~0ull; S.raw_hi = 0ull; S.any_complex = 0; }
   if (tid < 3) { P.ends[slot0 + tid].valid = 0; P.rec_sizes[slot0 + tid] = 0; }
   __syncthreads();
 
@@ -185,13 +288,29 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
         R.flags = flag; R.l_seq = (uint16_t)l_seq; R.seq_off = (uint16_t)seq_off; R.name_len = (uint16_t)(l_name - 1);
         R.pos = (int32_t)rd32(p + 4); R.ref_id = (int32_t)rd32(p);
         R.excluded = (flag & (bam::F_SECONDARY | bam::F_SUPPLEMENTARY)) ? 1 : 0;
-        uint32_t op = 0;
+        // CIGAR: up to MAX_CIG_OPS ops of any kind (clips, indels, skips); consensus is called in query space, the CIGAR matters
+        // for the mate clip, the overlap correction and the alignment filter
+        uint32_t ops[MAX_CIG_OPS];
+        uint32_t n_ops = 0;
+        for (uint32_t i = 0; i < MAX_CIG_OPS; i++) ops[i] = 0;
         if (!R.excluded) {
-          if ((flag & bam::F_UNMAPPED) || n_cig != 1 || l_seq == 0 || R.pos < 0) bad = true;
+          if ((flag & bam::F_UNMAPPED) || n_cig == 0 || n_cig > MAX_CIG_OPS || l_seq == 0 || R.pos < 0) bad = true;
           else {
-            op = rd32(p + 32 + l_name);
-            uint32_t ty = op & 15;
-            if (!(ty == 0 || ty == 7 || ty == 8) || (op >> 4) != l_seq) bad = true;
+            uint64_t qsum = 0;
+            uint32_t ns = 0;
+            for (uint32_t i = 0; i < n_cig; i++) {
+              const uint32_t o = rd32(p + 32 + l_name + 4 * i), t = o & 15;
+              ops[i] = o;
+              if (t > 8 || (o >> 4) > 0x3FFFFFu) bad = true;
+              if (t == 0 || t == 1 || t == 4 || t == 7 || t == 8) qsum += o >> 4;
+              const uint32_t k = (t == 4 || t == 5 || t == 7 || t == 8) ? 0u : t;      // simplify_cigar (clipper.rs:1183-1210)
+              if (ns > 0 && (S.scig[tid][ns - 1] & 15) == k) S.scig[tid][ns - 1] += (o >> 4) << 4;
+              else S.scig[tid][ns++] = ((o >> 4) << 4) | k;
+            }
+            n_ops = n_cig;
+            S.n_scig[tid] = (uint8_t)ns;
+            if (qsum != l_seq) bad = true;          // SEQ and CIGAR disagree: the general path decides
+            if (n_cig != 1 || (ops[0] & 15) == 1) S.any_complex = 1;
           }
         }
         // aux walk: first occurrence of MC / <tag> / RX / <cell tag>; malformed aux stops the walk (tags.rs:13-34)
@@ -257,7 +376,7 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
           uint32_t mops[MAX_MC_OPS];
           bool overflow = false;
           bam::Rec v{p, len};
-          uint64_t clip = bam::mate_clip(v, &op, 1, mc_off >= 0 ? p + mc_off : nullptr, mc_len, mops, MAX_MC_OPS, &overflow);
+          uint64_t clip = bam::mate_clip(v, ops, n_ops, mc_off >= 0 ? p + mc_off : nullptr, mc_len, mops, MAX_MC_OPS, &overflow);
           if (overflow) bad = true;
           R.clip = (uint16_t)(clip > 65535 ? 65535 : clip);
           // FNV-1a over the read name, for mate pairing
@@ -362,31 +481,37 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
         }
       }
     }
-    if (tid == 0) S.n_pairs = 0;
-    __syncthreads();
-    // one descriptor per pair with a shared stretch (pairs are disjoint, so their order does not matter): single M/=/X op
-    // spanning the read: alignment = [pos+1, pos+l_seq], query offset = ref - (pos+1)
-    if (tid < n) {
-      const ReadInfo& A = S.ri[tid];
-      if (A.mate >= 0) {
-        const ReadInfo& B = S.ri[A.mate];
-        if (A.ref_id == B.ref_id) {
-          const int64_t s1 = (int64_t)A.pos + 1, e1 = (int64_t)A.pos + A.l_seq, s2 = (int64_t)B.pos + 1, e2 = (int64_t)B.pos + B.l_seq;
-          const int64_t lo = s1 > s2 ? s1 : s2, hi = e1 < e2 ? e1 : e2;
-          if (hi >= lo) {
-            const uint32_t k = atomicAdd(&S.n_pairs, 1u);
-            S.pair_a[k] = A.row + (uint32_t)(lo - s1); S.pair_b[k] = B.row + (uint32_t)(lo - s2); S.pair_n[k] = (uint32_t)(hi - lo + 1);
-          }
-        }
-      }
-    }
     __syncthreads();
     uint32_t ov_bases = 0, ov_agree = 0, ov_dis = 0, ov_corr = 0;
     const uint32_t wave = tid >> 6, lane = tid & 63;
-    for (uint32_t k = wave; k < S.n_pairs; k += NT / 64) {
-      const uint32_t pa = S.pair_a[k], pb = S.pair_b[k], pn = S.pair_n[k];
-      for (uint32_t x = lane; x < pn; x += 64) {
-        const uint32_t ia = pa + x, ib = pb + x;
+    for (uint32_t a = wave; a < n; a += NT / 64) {     // pairs are disjoint, so their order does not matter
+      const ReadInfo& A = S.ri[a];
+      if (A.mate < 0) continue;
+      const ReadInfo& B = S.ri[A.mate];
+      if (A.ref_id != B.ref_id) continue;
+      // both CIGARs out of the LDS copy of the records; positions shared by two aligned blocks are corrected (overlapping.rs:236-336)
+      uint32_t na = 1, nb = 1;
+      uint32_t oa[MAX_CIG_OPS], ob[MAX_CIG_OPS];
+      int32_t rla = A.l_seq, rlb = B.l_seq;
+      oa[0] = (uint32_t)A.l_seq << 4; ob[0] = (uint32_t)B.l_seq << 4;     // family of single-block reads: <l_seq>M, nothing to look up
+      if (S.any_complex) {
+        const uint8_t* pa = blobL + A.goff;
+        const uint8_t* pb = blobL + B.goff;
+        na = rd16(pa + 12); nb = rd16(pb + 12);
+#pragma unroll
+        for (uint32_t i = 0; i < MAX_CIG_OPS; i++) {
+          oa[i] = i < na ? rd32(pa + 32 + A.name_len + 1 + 4 * i) : 0u;
+          ob[i] = i < nb ? rd32(pb + 32 + B.name_len + 1 + 4 * i) : 0u;
+        }
+        rla = bam::ref_len_checked0(oa, na); rlb = bam::ref_len_checked0(ob, nb);
+      }
+      if (rla == 0 || rlb == 0) continue;
+      const int64_t s1 = (int64_t)A.pos + 1, e1 = (int64_t)A.pos + rla, s2 = (int64_t)B.pos + 1, e2 = (int64_t)B.pos + rlb;
+      const int64_t lo = s1 > s2 ? s1 : s2, hi = e1 < e2 ? e1 : e2;
+      for (int64_t x = lo + lane; x <= hi; x += 64) {
+        const int32_t i1 = map_ref_to_query(oa, na, s1, x, A.l_seq), i2 = map_ref_to_query(ob, nb, s2, x, B.l_seq);
+        if (i1 < 0 || i2 < 0) continue;
+        const uint32_t ia = A.row + (uint32_t)i1, ib = B.row + (uint32_t)i2;
         uint8_t c1 = lb[ia], c2 = lb[ib];
         if (c1 == 15 || c2 == 15) continue;
         ov_bases++;
@@ -479,16 +604,30 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
       zero[e] = (uint32_t)__syncthreads_count(my_end == (uint32_t)e && my_zero);
       rem[e] = cnt[e] - zero[e];
     }
+    // alignment filter (filter_source_reads_by_alignment :1242-1296): only when some read of the family has clips or indels —
+    // reads with one aligned block all fall into one prefix-compatible group
+    uint32_t minor[3] = {0, 0, 0};
+    bool my_minor = false;
+    if (go && S.any_complex) {
+      if (tid == 0)
+        for (uint32_t e = 0; e < 3; e++)
+          if (cnt[e] >= P.min_reads && rem[e] >= P.min_reads && rem[e] >= 2) alignment_filter(S, e, n);
+      __syncthreads();
+      my_minor = my_end < 3 && !my_zero && S.ri[tid].minority != 0;
+      for (int e = 0; e < 3; e++) minor[e] = (uint32_t)__syncthreads_count(my_minor && my_end == (uint32_t)e);
+    }
     bool want_defer = false;
     uint32_t n_members = 0;
+    uint32_t kept[3] = {0, 0, 0};               // reads of the end after the zero-length drop and the alignment filter
     for (int e = 0; e < 3; e++) {
       if (!go || cnt[e] == 0 || cnt[e] < P.min_reads || rem[e] < P.min_reads) continue;
-      if (P.max_reads >= 0 && (int64_t)rem[e] > P.max_reads) { want_defer = true; break; }
-      // alignment filter: every read is mapped with one M-like block → a single prefix-compatible group, all kept
-      ok[e] = true; first[e] = n_members; n_members += rem[e];
+      kept[e] = rem[e] - minor[e];
+      if (kept[e] < P.min_reads) continue;
+      if (P.max_reads >= 0 && (int64_t)kept[e] > P.max_reads) { want_defer = true; break; }
+      ok[e] = true; first[e] = n_members; n_members += kept[e];
     }
     // member lists: file order inside an end
-    const bool keep = my_end < 3 && ok[my_end] && !my_zero;
+    const bool keep = my_end < 3 && ok[my_end] && !my_zero && !my_minor;
     const uint32_t wv = tid >> 6, ln = tid & 63;
     uint32_t my_rank = 0;
     for (int e = 0; e < 3; e++) {
@@ -511,7 +650,7 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
       if (P.min_reads > 1) {                  // min_reads-th longest kept read (:1661-1669): every kept read ranks itself
         const uint32_t la = R.final_len;
         uint32_t ge = 0;
-        for (uint32_t bq = 0; bq < rem[my_end]; bq++) if (S.ri[S.members[first[my_end] + bq]].final_len >= la) ge++;
+        for (uint32_t bq = 0; bq < kept[my_end]; bq++) if (S.ri[S.members[first[my_end] + bq]].final_len >= la) ge++;
         if (ge >= P.min_reads) atomicMax(&S.g_best[my_end], la);
       }
       if (R.has_rx) {                         // UMIs of unequal length (vanilla_caller.rs:1842-1856 → consensus_umis panics)
@@ -532,12 +671,14 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
           if (cnt[e] < P.min_reads) { st[2] += cnt[e]; st[3 + FGX_REJ_INSUFFICIENT_READS] += cnt[e]; continue; }
           if (zero[e]) { st[2] += zero[e]; st[3 + FGX_REJ_ZERO_LENGTH_AFTER_TRIMMING] += zero[e]; }
           if (rem[e] < P.min_reads) { if (rem[e]) { st[2] += rem[e]; st[3 + FGX_REJ_INSUFFICIENT_READS] += rem[e]; } continue; }
+          if (minor[e]) { st[2] += minor[e]; st[3 + FGX_REJ_MINORITY_ALIGNMENT] += minor[e]; }
+          if (kept[e] < P.min_reads && kept[e]) { st[2] += kept[e]; st[3 + FGX_REJ_INSUFFICIENT_READS] += kept[e]; }
         }
       }
       if (!S.defer) {
         uint32_t ne = 0;
         auto push_end = [&](uint32_t e) {
-          S.end_type[ne] = e; S.end_first[ne] = first[e]; S.end_cnt[ne] = rem[e]; S.end_len[ne] = S.g_best[e];
+          S.end_type[ne] = e; S.end_first[ne] = first[e]; S.end_cnt[ne] = kept[e]; S.end_len[ne] = S.g_best[e];
           S.end_maxd[ne] = 0; S.end_mind[ne] = 0xFFFFFFFFu; S.end_sumd[ne] = 0; S.end_sume[ne] = 0;
           // UMIs carried by the kept reads of this end
           const uint32_t rc = S.g_rxcnt[e];
@@ -550,8 +691,8 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
         };
         if (ok[0]) { st[1] += 1; push_end(0); }
         if (ok[1] && ok[2]) { st[1] += 2; push_end(1); push_end(2); }
-        else if (ok[1]) { st[2] += rem[1]; st[3 + FGX_REJ_ORPHAN_CONSENSUS] += rem[1]; }
-        else if (ok[2]) { st[2] += rem[2]; st[3 + FGX_REJ_ORPHAN_CONSENSUS] += rem[2]; }
+        else if (ok[1]) { st[2] += kept[1]; st[3 + FGX_REJ_ORPHAN_CONSENSUS] += kept[1]; }
+        else if (ok[2]) { st[2] += kept[2]; st[3 + FGX_REJ_ORPHAN_CONSENSUS] += kept[2]; }
         uint32_t total = 0;
         for (uint32_t k = 0; k < ne; k++) { S.end_coloff[k] = total; total += S.end_len[k]; }
         S.n_ends = ne;
@@ -874,6 +1015,7 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
   int32_t pos = 0, ref_id = 0;
   uint32_t mi_lo = 0, mi_len = 0, rx_lo = 0, rx_len = 0, cb_lo = 0, cb_len = 0;   // LDS offsets of tag values
   bool has_mi = false, has_rx = false, has_cb = false, excluded = false, bad = false;
+  bool cplx = false;                // simplex: a CIGAR with I / D / N / P ops — the family goes to the workgroup-per-family kernel
   uint32_t lead_s = 0, m_len = 0;   // query offset of the first aligned base, length of the aligned block
   uint32_t strand = 0;   // duplex: 1 = MI ends in /A, 2 = /B
   if (act) {
@@ -914,9 +1056,10 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
             if (t == 0 || t == 7 || t == 8) { if (phase == 2) okc = false; phase = 1; m_len += ln; }
             else if (t == 4) { if (phase == 0) lead_s += ln; else { phase = 2; trail_s += ln; } }
             else if (t == 5) { if (phase == 1) phase = 2; }
-            else okc = false;                         // I, D, N, P: the general path
+            else { okc = false; if (t == 1 || t == 2 || t == 3 || t == 6) cplx = true; }   // I, D, N, P: the workgroup kernel
           }
-          if (!okc || m_len == 0 || m_len > 65535 || (unsigned long long)lead_s + m_len + trail_s != l_seq) bad = true;
+          if (cplx && MODE == 0) { /* decided below: the whole family moves to the workgroup-per-family kernel */ }
+          else if (!okc || m_len == 0 || m_len > 65535 || (unsigned long long)lead_s + m_len + trail_s != l_seq) bad = true;
         } else bad = true;
       }
       // aux walk in LDS (tags.rs:13-34): first occurrence of MC / <tag> / RX / <cell tag>
@@ -1032,6 +1175,7 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
     if (all) bad = true;
   }
   if (__any(bad)) { to_defer(); return; }
+  if (MODE == 0 && __any(cplx)) { to_retry(); return; }
   const bool cand = act && !excluded;
   const bool rev = (flags & bam::F_REVERSE) != 0;
   const unsigned long long rxmask = __ballot(cand && has_rx), cbmask = __ballot(cand && has_cb);
