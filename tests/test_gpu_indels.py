@@ -119,3 +119,57 @@ def test_large_family_with_indels_and_clips():
 def test_too_many_cigar_ops_defer_to_the_host():
     rng = random.Random(1)
     _run([fr_pair(rng, "x", "1", 100, 170, "10M1D10M1D10M1D10M1D60M", "100M")], expect_deferred=1)
+
+
+def random_cigar(rng, L):
+    """A CIGAR of at most 6 ops that consumes exactly L query bases (clips, indels, skips and pads in legal and odd places)."""
+    for _ in range(100):
+        ops = []
+        if rng.random() < 0.15:
+            ops.append((rng.randint(1, 5), "H"))
+        if rng.random() < 0.3:
+            ops.append((rng.randint(1, 12), "S"))
+        n_mid = rng.choice([1, 1, 1, 2, 2, 3])
+        for k in range(n_mid):
+            ops.append((0, "M"))
+            if k + 1 < n_mid:
+                ops.append((rng.randint(1, 6), rng.choice("IDDINP")))
+        if rng.random() < 0.3:
+            ops.append((rng.randint(1, 12), "S"))
+        if rng.random() < 0.1:
+            ops.append((rng.randint(1, 5), "H"))
+        if len(ops) > 6:
+            continue
+        fixed = sum(n for n, t in ops if t in "SI")
+        n_m = sum(1 for n, t in ops if t == "M")
+        if L - fixed < n_m:
+            continue
+        rest = L - fixed
+        cuts = sorted(rng.sample(range(1, rest), n_m - 1)) if n_m > 1 else []
+        lens = [b - a for a, b in zip([0] + cuts, cuts + [rest])]
+        it = iter(lens)
+        return "".join(f"{next(it) if t == 'M' else n}{'=' if t == 'M' and rng.random() < 0.1 else t}" for n, t in ops)
+    return f"{L}M"
+
+
+def test_random_cigars_differential():
+    rng = random.Random(77)
+    groups = []
+    for g in range(300):
+        start = rng.randint(10, 3000)
+        insert = rng.choice([90, 130, 170, 240])
+        L = rng.choice([60, 100, 101])
+        shared = [random_cigar(rng, L) for _ in range(2)]
+        recs = []
+        for k in range(rng.randint(1, 10)):
+            c1 = shared[0] if rng.random() < 0.7 else random_cigar(rng, L)
+            c2 = shared[1] if rng.random() < 0.7 else random_cigar(rng, L)
+            pr = fr_pair(rng, f"z{g}r{k}", f"Z{g}", start + rng.choice([0, 0, 0, 1, 3]), insert, c1, c2, q=(2, 41))
+            if rng.random() < 0.1:
+                pr = pr[:1] if rng.random() < 0.5 else pr[1:]          # orphan mates
+            recs += pr
+        if rng.random() < 0.2:
+            recs.append(bamutil.frag(f"frag{g}", TMPL[start:start + L], [33] * L, f"Z{g}", pos=start, cigar=random_cigar(rng, L)))
+        groups.append(recs)
+    for kw in (dict(), dict(min_reads=2), dict(overlapping=False, trim=True)):
+        _run(groups, **kw)
