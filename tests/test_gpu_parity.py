@@ -306,3 +306,44 @@ def test_clipped_single_block_cigars_stay_on_the_device():
     assert out.n_deferred == 0
     assert out.count == want["count"] and out.to_host() == want["data"]
     c.close()
+
+
+def test_full_size_config2_properties():
+    """BASELINE.json configs[1] at full size (5 M families x 8 pairs x 150 bp = 80 M reads, 26 GB of records in HBM): the properties that
+    do not need the oracle at that size.  (1) Sharding invariance, a checksum of checksums: the batch cut into five 1 M-family shards
+    gives outputs whose concatenation IS the output of the whole batch (byte for byte), and whose counters add up; (2) idempotence: a
+    second pass over the same resident input is identical; (3) the accounting identities of the simulated shape.  Small-scale parity
+    against the oracle (same generator, same kernels) is what the rest of this file establishes."""
+    import os
+    if os.environ.get("FGX_SKIP_FULL_SIZE"):
+        pytest.skip("FGX_SKIP_FULL_SIZE set")
+    import torch
+    fam, shard = 5_000_000, 1_000_000
+    if torch.cuda.mem_get_info()[1] < 120 * 2**30:
+        pytest.skip("needs a 288 GB-class GPU")
+    c = VanillaUmiConsensusCaller("", "A", VanillaUmiConsensusOptions(min_reads=1, min_consensus_base_quality=2, cell_tag="CB"), overlapping_consensus=True)
+    dg = c.simulate_on_device(fam, family_size=8)
+    out = c.process_batch_device(dg)
+    assert out.n_deferred == 0 and out.count == 2 * fam
+    st = c.last_batch_statistics()
+    assert st.total_reads == 16 * fam and st.consensus_reads == 2 * fam and st.filtered_reads == 0
+    full = out.to_host()
+    again = c.process_batch_device(dg)
+    assert again.data_len == len(full) and again.to_host() == full                     # idempotent, input untouched
+    del dg, again
+    torch.cuda.empty_cache()
+    off = 0
+    total_reads = 0
+    overlap = 0
+    for k in range(fam // shard):
+        dk = c.simulate_on_device(shard, family_size=8, first_family=k * shard)
+        ok = c.process_batch_device(dk)
+        part = ok.to_host()
+        assert full[off:off + len(part)] == part, f"shard {k} differs from its slice of the whole batch"
+        off += len(part)
+        sk = c.last_batch_statistics()
+        total_reads += sk.total_reads
+        overlap += sk.overlapping["bases_corrected"]
+        del dk
+    assert off == len(full) and total_reads == st.total_reads and overlap == st.overlapping["bases_corrected"]
+    c.close()
