@@ -103,6 +103,9 @@ def main():
                     help="simplex only: long-tail family sizes in [depth, depth-max] pairs, count ~ size^-1.5 (BASELINE configs[3] shape: --depth 2 --depth-max 50)")
     ap.add_argument("--cpu-sample-families", type=int, default=300000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--reassemble", choices=["none", "root"], default="none",
+                    help="root: every step also gathers the shard payloads to rank 0 in rank (= input) order over RCCL, inside the timed region "
+                         "(the north star's reassembly step; off by default: shard outputs are already in input order, see DESIGN.md 6)")
     args = ap.parse_args()
     duplex, codec = args.caller == "duplex", args.caller == "codec"
     if args.families is None:
@@ -149,11 +152,18 @@ def main():
     barrier()
     t0 = time.perf_counter()
     k_family_ms = k_emit_ms = k_total_ms = 0.0
+    gathered_bytes = 0
     for _ in range(args.steps):
         out = caller.process_batch_device(dg)
         k_family_ms += caller.last_timing["k_family"]
         k_emit_ms += caller.last_timing["k_emit"]
         k_total_ms += caller.last_timing["kernels"]
+        if args.reassemble == "root":
+            from fgumi_amd.distributed import gather_payload_to_root
+            whole = gather_payload_to_root(out.as_tensor(local_rank), root=0)
+            if whole is not None:
+                gathered_bytes = int(whole.numel())
+            del whole
     barrier()
     dt = time.perf_counter() - t0
     from fgumi_amd.distributed import gather_sizes, max_over_ranks
@@ -185,7 +195,8 @@ def main():
                                     if args.depth_max else f"simplex consensus, {fam} families per GPU, depth={args.depth} pairs, {L}bp paired (BASELINE configs[1] shape), ")
                                    + "device-resident: raw BAM records in HBM -> consensus BAM records in HBM",
                        "min_reads": 1, "overlapping_consensus": True, "families_per_gpu": fam, "raw_reads_per_gpu": dg.n_rec,
-                       "deferred_families": total_def, "output_bytes": total_bytes,
+                       "deferred_families": total_def, "output_bytes": total_bytes, "reassemble": args.reassemble,
+                       "reassembled_bytes_on_rank0": gathered_bytes,
                        "columns_needing_call_full_per_step": caller.last_timing.get("full_columns")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None if (duplex or codec or args.depth_max) else pmc_traffic(fam, args.depth, L), "kernel": "k_family", "kernel_ms": k_family_ms / steps, "k_emit_ms": k_emit_ms / steps,

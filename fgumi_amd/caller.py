@@ -174,6 +174,19 @@ class DeviceOutput:
         from ._lib import hip_memcpy_d2h
         return hip_memcpy_d2h(self.data_ptr, self.data_len)
 
+    def as_tensor(self, device=None):
+        """Zero-copy uint8 torch view of the records in HBM (valid until the caller's next call): what a collective takes."""
+        import torch
+
+        class _View:
+            pass
+        v = _View()
+        v.__cuda_array_interface__ = {"shape": (int(self.data_len),), "typestr": "|u1", "data": (int(self.data_ptr), False), "version": 2}
+        dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        if self.data_len == 0:
+            return torch.empty(0, dtype=torch.uint8, device=dev)
+        return torch.as_tensor(v, device=dev)
+
 
 def split_records(data: bytes) -> List[bytes]:
     """Split `ConsensusOutput.data` into record bodies (without the block_size prefixes)."""

@@ -247,6 +247,7 @@ def test_device_resident_pipeline_matches_oracle(handle):
         g = simulate_grouped_reads(**kw)
         want = _oracle(g, min_reads=1)
         assert out.count == want["count"] and data == want["data"]
+        assert bytes(out.as_tensor().cpu().numpy()) == data                      # zero-copy tensor view of the records in HBM (what a collective takes)
         st = c.last_batch_statistics()
         assert st.total_reads == int(want["stats"][0]) and st.consensus_reads == int(want["stats"][1])
         assert st.overlapping["bases_corrected"] == int(want["stats"][27])
