@@ -169,19 +169,24 @@ static unsigned host_threads() {
   return hw == 0 ? 1 : hw > 64 ? 64 : hw;
 }
 
+static bool ensure_workers(fgx_caller* c, unsigned T) {
+  while (c->workers.size() < T) {
+    fgx_options o = c->opt;
+    o.read_name_prefix = c->prefix.c_str(); o.read_group_id = c->rg.c_str(); o.device = c->device;
+    fgx_caller* w = fgx_create(&o);
+    if (!w) { c->err = std::string("helper caller: ") + fgx_global_error(); return false; }
+    c->workers.push_back(w);
+  }
+  return true;
+}
+
 static int run_general(fgx_caller* c, general_fn fn, const uint8_t* records, const uint64_t* rec_off, const uint32_t* rec_len, uint32_t n_rec,
                        const uint32_t* grp_first, uint32_t n_grp, fgx_output* out) {
   constexpr uint32_t MIN_GROUPS = 512;              // below this a shard is not worth a thread
   unsigned T = host_threads();
   if (T > n_grp / MIN_GROUPS) T = n_grp / MIN_GROUPS;
   if (T <= 1) return fn(c, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
-  while (c->workers.size() < T) {
-    fgx_options o = c->opt;
-    o.read_name_prefix = c->prefix.c_str(); o.read_group_id = c->rg.c_str(); o.device = c->device;
-    fgx_caller* w = fgx_create(&o);
-    if (!w) { c->err = std::string("general path worker: ") + fgx_global_error(); return 3; }
-    c->workers.push_back(w);
-  }
+  if (!ensure_workers(c, T)) return 3;
   // contiguous shards balanced by record count
   std::vector<uint32_t> bound(T + 1, n_grp);
   bound[0] = 0;
@@ -233,13 +238,12 @@ static int run_general(fgx_caller* c, general_fn fn, const uint8_t* records, con
   out->rejects = c->out_rejects.data(); out->rejects_len = c->out_rejects.size();
   return 0;
 }
-static int process_hybrid(fgx_caller* c, general_fn general, const uint8_t* records, uint64_t records_len, const uint64_t* rec_off,
-                          const uint32_t* rec_len, uint32_t n_rec, const uint32_t* grp_first, uint32_t n_grp, fgx_output* out) {
-  using clk = std::chrono::steady_clock;
-  auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-  if (c->opt.track_rejects || n_grp == 0) return run_general(c, general, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
-  if (!c->fast) c->fast = new FastState();
-  auto t0 = clk::now();
+using clk = std::chrono::steady_clock;
+static double ms_between(clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); }
+
+// host batch → the caller's device staging buffers (blocking)
+static void hybrid_upload(fgx_caller* c, const uint8_t* records, uint64_t records_len, const uint64_t* rec_off, const uint32_t* rec_len, uint32_t n_rec,
+                          const uint32_t* grp_first, uint32_t n_grp) {
   hip_check(hipSetDevice(c->device), "hipSetDevice");
   c->d_in_blob.reserve(records_len + 16);
   c->d_in_off.reserve((size_t)n_rec * 8 + 8);
@@ -250,15 +254,43 @@ static int process_hybrid(fgx_caller* c, general_fn general, const uint8_t* reco
   hip_check(hipMemcpyAsync(c->d_in_len.p, rec_len, (size_t)n_rec * 4, hipMemcpyHostToDevice, c->stream), "H2D rec_len");
   hip_check(hipMemcpyAsync(c->d_in_grp.p, grp_first, (size_t)(n_grp + 1) * 4, hipMemcpyHostToDevice, c->stream), "H2D grp_first");
   hip_check(hipStreamSynchronize(c->stream), "sync");
+}
+
+static int hybrid_after_upload(fgx_caller* c, general_fn general, const uint8_t* records, uint64_t records_len, const uint64_t* rec_off,
+                               const uint32_t* rec_len, uint32_t n_rec, const uint32_t* grp_first, uint32_t n_grp, fgx_output* out,
+                               uint8_t* dst, uint64_t dst_cap);
+
+static int process_hybrid(fgx_caller* c, general_fn general, const uint8_t* records, uint64_t records_len, const uint64_t* rec_off,
+                          const uint32_t* rec_len, uint32_t n_rec, const uint32_t* grp_first, uint32_t n_grp, fgx_output* out) {
+  if (c->opt.track_rejects || n_grp == 0) return run_general(c, general, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
+  if (!c->fast) c->fast = new FastState();
+  auto t0 = clk::now();
+  hybrid_upload(c, records, records_len, rec_off, rec_len, n_rec, grp_first, n_grp);
   auto t1 = clk::now();
+  int rc = hybrid_after_upload(c, general, records, records_len, rec_off, rec_len, n_rec, grp_first, n_grp, out, nullptr, 0);
+  if (rc == 0) out->ms_h2d = ms_between(t0, t1);
+  return rc;
+}
+
+// Kernels, download and the splice with the general path's output for the deferred families.  `dst` (pinned, dst_cap bytes):
+// when the records fit they are downloaded straight there and out->data == dst; otherwise they land in the caller's own buffers.
+static int hybrid_after_upload(fgx_caller* c, general_fn general, const uint8_t* records, uint64_t records_len, const uint64_t* rec_off,
+                               const uint32_t* rec_len, uint32_t n_rec, const uint32_t* grp_first, uint32_t n_grp, fgx_output* out,
+                               uint8_t* dst, uint64_t dst_cap) {
+  auto ms = ms_between;
+  if (!c->fast) c->fast = new FastState();
+  hip_check(hipSetDevice(c->device), "hipSetDevice");
+  auto t0 = clk::now();
+  auto t1 = t0;
   FastResult fr;
   c->fast->fp.run(c, c->d_in_blob.as<uint8_t>(), records_len, c->d_in_off.as<uint64_t>(), c->d_in_len.as<uint32_t>(), n_rec,
                   c->d_in_grp.as<uint32_t>(), n_grp, &fr);
   auto t2 = clk::now();
   // records land in a pinned host buffer owned by the caller object (pageable destinations cost ~10x: first-touch faults + staging)
-  c->fast->pin_out.reserve(fr.out_len + 16);
-  const uint8_t* fast_out = c->fast->pin_out.as<uint8_t>();
-  if (fr.out_len) hip_check(hipMemcpy(c->fast->pin_out.p, fr.d_out, fr.out_len, hipMemcpyDeviceToHost), "D2H out");
+  const bool direct = dst && fr.n_deferred == 0 && fr.out_len <= dst_cap;
+  if (!direct) c->fast->pin_out.reserve(fr.out_len + 16);
+  const uint8_t* fast_out = direct ? dst : c->fast->pin_out.as<uint8_t>();
+  if (fr.out_len) hip_check(hipMemcpy((void*)fast_out, fr.d_out, fr.out_len, hipMemcpyDeviceToHost), "D2H out");
   auto t3 = clk::now();
   memset(out, 0, sizeof(*out));
   if (fr.n_deferred == 0) {

@@ -348,3 +348,4 @@ def test_full_size_config2_properties():
         del dk
     assert off == len(full) and total_reads == st.total_reads and overlap == st.overlapping["bases_corrected"]
     c.close()
+
