@@ -853,14 +853,29 @@ __device__ __forceinline__ uint8_t comp_code(uint8_t c) { return (uint8_t)((0xF7
 
 // unaligned LDS reads built from aligned dwords (v_alignbyte_b32)
 __device__ __forceinline__ uint32_t ldsw(const uint8_t* W, uint32_t o) { return *(const uint32_t*)(W + o); }
+#ifndef FGX_LDS_UNALIGNED
+#define FGX_LDS_UNALIGNED 1   /* gfx950 LDS takes unaligned ds_read_b32 / b64: one instruction instead of two or three aligned reads + alignbyte */
+#endif
 __device__ __forceinline__ uint32_t ld32u(const uint8_t* W, uint32_t o) {
+#if FGX_LDS_UNALIGNED
+  uint32_t v;
+  __builtin_memcpy(&v, W + o, 4);
+  return v;
+#else
   uint32_t a = o & ~3u;
   return __builtin_amdgcn_alignbyte(ldsw(W, a + 4), ldsw(W, a), o & 3);
+#endif
 }
 __device__ __forceinline__ unsigned long long ld64u(const uint8_t* W, uint32_t o) {
+#if FGX_LDS_UNALIGNED
+  unsigned long long v;
+  __builtin_memcpy(&v, W + o, 8);
+  return v;
+#else
   uint32_t a = o & ~3u, sh = o & 3;
   uint32_t w0 = ldsw(W, a), w1 = ldsw(W, a + 4), w2 = ldsw(W, a + 8);
   return (unsigned long long)__builtin_amdgcn_alignbyte(w1, w0, sh) | ((unsigned long long)__builtin_amdgcn_alignbyte(w2, w1, sh) << 32);
+#endif
 }
 // offset of the first NUL in W[o, o+n), 8 bytes per step; -1 if none
 __device__ __forceinline__ int find_nul64(const uint8_t* W, uint32_t o, uint32_t n) {
