@@ -80,6 +80,7 @@ struct Shared {
   uint8_t b4_order[FAST_MAX_READS];             // alignment filter: members of one end, longest first
   uint16_t b4_mask[FAST_MAX_READS];             // alignment filter: groups a read belongs to
   uint32_t any_complex;                         // some read has more than one aligned block or clips
+  int32_t name_rank[FAST_MAX_READS];            // --max-reads: fgbio name rank of each kept read
 };
 
 __device__ __forceinline__ void defer(Shared& S) { S.defer = 1; }
@@ -98,6 +99,18 @@ __device__ __forceinline__ void oriented(const Shared& S, const uint8_t* lb, con
   if (p < R.trim_to && q < min_bq) { c = 15; q = FGX_MIN_PHRED; }
   *code = c;
   *qual = q;
+}
+
+// fgbio_read_name_rank (raw-bam/hash.rs:14-89): Murmur3_32, seed 42, over the UTF-16 code units of the read name, as i32
+__device__ inline int32_t name_rank(const uint8_t* name, uint32_t len) {
+  auto rotl = [](uint32_t v, int r) { return (v << r) | (v >> (32 - r)); };
+  auto mixk = [&](uint32_t k) { k *= 0xcc9e2d51u; k = rotl(k, 15); return k * 0x1b873593u; };
+  uint32_t h = 42;
+  for (uint32_t i = 1; i < len; i += 2) { h ^= mixk((uint32_t)name[i - 1] | ((uint32_t)name[i] << 16)); h = rotl(h, 13) * 5 + 0xe6546b64u; }
+  if (len & 1) h ^= mixk(name[len - 1]);
+  h ^= 2 * len;
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return (int32_t)h;
 }
 
 // ---- general CIGARs in the workgroup kernel ------------------------------------------------------------------------------------
@@ -619,15 +632,40 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
     bool want_defer = false;
     uint32_t n_members = 0;
     uint32_t kept[3] = {0, 0, 0};               // reads of the end after the zero-length drop and the alignment filter
+    uint32_t down[3] = {0, 0, 0};               // ... of which --max-reads drops
+    bool bites = false;
     for (int e = 0; e < 3; e++) {
       if (!go || cnt[e] == 0 || cnt[e] < P.min_reads || rem[e] < P.min_reads) continue;
       kept[e] = rem[e] - minor[e];
-      if (kept[e] < P.min_reads) continue;
-      if (P.max_reads >= 0 && (int64_t)kept[e] > P.max_reads) { want_defer = true; break; }
-      ok[e] = true; first[e] = n_members; n_members += kept[e];
+      if (kept[e] >= P.min_reads && P.max_reads >= 0 && (int64_t)kept[e] > P.max_reads) bites = true;
+    }
+    bool my_down = false;
+    if (bites) {   // downsample_filtered_source_reads (:902-932): the max_reads lowest fgbio name ranks stay, ties in file order
+      const bool cand = my_end < 3 && !my_zero && !my_minor && kept[my_end] >= P.min_reads && (int64_t)kept[my_end] > P.max_reads;
+      if (cand) S.name_rank[tid] = name_rank(blobL + S.ri[tid].goff + 32, S.ri[tid].name_len);
+      __syncthreads();
+      if (cand) {
+        const int32_t rk = S.name_rank[tid];
+        uint32_t before = 0;
+        for (uint32_t j = 0; j < n; j++) {
+          const ReadInfo& O = S.ri[j];
+          if (j == tid || O.end != my_end || O.zero_len || O.minority) continue;
+          const int32_t rj = S.name_rank[j];
+          before += (rj < rk || (rj == rk && j < tid)) ? 1u : 0u;
+        }
+        my_down = (int64_t)before >= P.max_reads;
+      }
+      for (int e = 0; e < 3; e++) down[e] = (uint32_t)__syncthreads_count(my_down && my_end == (uint32_t)e);
+    }
+    uint32_t fin[3] = {0, 0, 0};                // reads of the end that go into the consensus
+    for (int e = 0; e < 3; e++) {
+      if (!go || cnt[e] == 0 || cnt[e] < P.min_reads || rem[e] < P.min_reads || kept[e] < P.min_reads) continue;
+      fin[e] = kept[e] - down[e];
+      if (fin[e] < P.min_reads) continue;
+      ok[e] = true; first[e] = n_members; n_members += fin[e];
     }
     // member lists: file order inside an end
-    const bool keep = my_end < 3 && ok[my_end] && !my_zero && !my_minor;
+    const bool keep = my_end < 3 && ok[my_end] && !my_zero && !my_minor && !my_down;
     const uint32_t wv = tid >> 6, ln = tid & 63;
     uint32_t my_rank = 0;
     for (int e = 0; e < 3; e++) {
@@ -650,7 +688,7 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
       if (P.min_reads > 1) {                  // min_reads-th longest kept read (:1661-1669): every kept read ranks itself
         const uint32_t la = R.final_len;
         uint32_t ge = 0;
-        for (uint32_t bq = 0; bq < kept[my_end]; bq++) if (S.ri[S.members[first[my_end] + bq]].final_len >= la) ge++;
+        for (uint32_t bq = 0; bq < fin[my_end]; bq++) if (S.ri[S.members[first[my_end] + bq]].final_len >= la) ge++;
         if (ge >= P.min_reads) atomicMax(&S.g_best[my_end], la);
       }
       if (R.has_rx) {                         // UMIs of unequal length (vanilla_caller.rs:1842-1856 → consensus_umis panics)
@@ -672,13 +710,15 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
           if (zero[e]) { st[2] += zero[e]; st[3 + FGX_REJ_ZERO_LENGTH_AFTER_TRIMMING] += zero[e]; }
           if (rem[e] < P.min_reads) { if (rem[e]) { st[2] += rem[e]; st[3 + FGX_REJ_INSUFFICIENT_READS] += rem[e]; } continue; }
           if (minor[e]) { st[2] += minor[e]; st[3 + FGX_REJ_MINORITY_ALIGNMENT] += minor[e]; }
-          if (kept[e] < P.min_reads && kept[e]) { st[2] += kept[e]; st[3 + FGX_REJ_INSUFFICIENT_READS] += kept[e]; }
+          if (kept[e] < P.min_reads) { if (kept[e]) { st[2] += kept[e]; st[3 + FGX_REJ_INSUFFICIENT_READS] += kept[e]; } continue; }
+          if (down[e]) { st[2] += down[e]; st[3 + FGX_REJ_DOWNSAMPLED] += down[e]; }
+          if (fin[e] < P.min_reads && fin[e]) { st[2] += fin[e]; st[3 + FGX_REJ_INSUFFICIENT_READS] += fin[e]; }
         }
       }
       if (!S.defer) {
         uint32_t ne = 0;
         auto push_end = [&](uint32_t e) {
-          S.end_type[ne] = e; S.end_first[ne] = first[e]; S.end_cnt[ne] = kept[e]; S.end_len[ne] = S.g_best[e];
+          S.end_type[ne] = e; S.end_first[ne] = first[e]; S.end_cnt[ne] = fin[e]; S.end_len[ne] = S.g_best[e];
           S.end_maxd[ne] = 0; S.end_mind[ne] = 0xFFFFFFFFu; S.end_sumd[ne] = 0; S.end_sume[ne] = 0;
           // UMIs carried by the kept reads of this end
           const uint32_t rc = S.g_rxcnt[e];
@@ -691,8 +731,8 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
         };
         if (ok[0]) { st[1] += 1; push_end(0); }
         if (ok[1] && ok[2]) { st[1] += 2; push_end(1); push_end(2); }
-        else if (ok[1]) { st[2] += kept[1]; st[3 + FGX_REJ_ORPHAN_CONSENSUS] += kept[1]; }
-        else if (ok[2]) { st[2] += kept[2]; st[3 + FGX_REJ_ORPHAN_CONSENSUS] += kept[2]; }
+        else if (ok[1]) { st[2] += fin[1]; st[3 + FGX_REJ_ORPHAN_CONSENSUS] += fin[1]; }
+        else if (ok[2]) { st[2] += fin[2]; st[3 + FGX_REJ_ORPHAN_CONSENSUS] += fin[2]; }
         uint32_t total = 0;
         for (uint32_t k = 0; k < ne; k++) { S.end_coloff[k] = total; total += S.end_len[k]; }
         S.n_ends = ne;
@@ -1358,7 +1398,7 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
   PH(4)
   if constexpr (MODE == 0) {
   // ---- 5. family gates with ballots (process_group :1329-1422, process_subgroup :1454-1646) -----------------
-  uint32_t s_total = n, s_cons = 0, s_filtered = 0, s_sec = 0, s_insuf = 0, s_zero = 0, s_orphan = 0;
+  uint32_t s_total = n, s_cons = 0, s_filtered = 0, s_sec = 0, s_insuf = 0, s_zero = 0, s_orphan = 0, s_down = 0;
   const uint32_t n_sec = (uint32_t)__popcll(__ballot(act && excluded));
   const uint32_t n_reads = n - n_sec;
   if (n_sec) { s_filtered += n_sec; s_sec = n_sec; }
@@ -1381,7 +1421,22 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
       uint32_t rem = (uint32_t)__popcll(kept), zero = cnt - rem;
       if (zero) { s_filtered += zero; s_zero += zero; }
       if (rem < P.min_reads) { if (rem) { s_filtered += rem; s_insuf += rem; } continue; }
-      if (P.max_reads >= 0 && (long long)rem > P.max_reads) { need_defer = true; break; }
+      if (P.max_reads >= 0 && (long long)rem > P.max_reads) {
+        // downsample_filtered_source_reads (:902-932): the max_reads lowest fgbio name ranks stay, ties in file order
+        const int32_t rk = name_rank(W + lo + 32, name_len);
+        const bool cand = (kept >> lane) & 1;
+        uint32_t before = 0;
+        for (unsigned long long m = kept; m; m &= m - 1) {
+          const uint32_t j = (uint32_t)__builtin_ctzll(m);
+          const int32_t rj = (int32_t)rlane((uint32_t)rk, j);
+          before += (rj < rk || (rj == rk && j < lane)) ? 1u : 0u;
+        }
+        const unsigned long long stay = __ballot(cand && (long long)before < P.max_reads);
+        const uint32_t dropped = rem - (uint32_t)__popcll(stay);
+        s_filtered += dropped; s_down += dropped;
+        kept = stay; rem = (uint32_t)__popcll(stay);
+        if (rem < P.min_reads) { if (rem) { s_filtered += rem; s_insuf += rem; } continue; }
+      }
       // consensus length = min_reads-th longest kept read
       bool mine = (kept >> lane) & 1;
       if (P.min_reads == 1) clen[e] = wave_max(mine ? final_len : 0);
@@ -1609,6 +1664,7 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
     if (s_insuf) atomicAdd(&st[3 + FGX_REJ_INSUFFICIENT_READS], (unsigned long long)s_insuf);
     if (s_zero) atomicAdd(&st[3 + FGX_REJ_ZERO_LENGTH_AFTER_TRIMMING], (unsigned long long)s_zero);
     if (s_orphan) atomicAdd(&st[3 + FGX_REJ_ORPHAN_CONSENSUS], (unsigned long long)s_orphan);
+    if (s_down) atomicAdd(&st[3 + FGX_REJ_DOWNSAMPLED], (unsigned long long)s_down);
     if (ov_bases) atomicAdd(&st[24], (unsigned long long)ov_bases);
     if (ov_agree) atomicAdd(&st[25], (unsigned long long)ov_agree);
     if (ov_dis) atomicAdd(&st[26], (unsigned long long)ov_dis);

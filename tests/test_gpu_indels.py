@@ -173,3 +173,30 @@ def test_random_cigars_differential():
         groups.append(recs)
     for kw in (dict(), dict(min_reads=2), dict(overlapping=False, trim=True)):
         _run(groups, **kw)
+
+
+@pytest.mark.parametrize("max_reads,min_reads", [(2, 1), (3, 2), (1, 1), (0, 1), (5, 6)])
+def test_max_reads_downsampling_on_device(max_reads, min_reads):
+    """--max-reads that bites: the fgbio name-rank selection (Murmur3_32 over UTF-16 units, lowest ranks stay, ties in file order) runs in
+    the wave kernel and, for families with indels or more than 64 records, in the workgroup kernel; nothing is deferred."""
+    from fgumi_amd import simulate_grouped_reads
+    g0 = simulate_grouped_reads(400, family_size=1, family_size_max=9, error_rate_ppm=5000)
+    groups = [g0.records(i) for i in range(g0.n_grp)] + indel_groups(seed=8, n_groups=60, max_pairs=10)
+    rng = random.Random(12)
+    big = []
+    for k in range(45):
+        big += fr_pair(rng, f"B{k}", "big", 900, 170, "100M", "100M")
+    groups.append(big)
+    g = GroupedReads.from_groups(groups)
+    opt = VanillaUmiConsensusOptions(min_reads=min_reads, max_reads=max_reads, min_consensus_base_quality=2, cell_tag="CB")
+    c = VanillaUmiConsensusCaller("", "A", opt, overlapping_consensus=True)
+    out = c.process_batch_device(g.to_device())
+    data = out.to_host()
+    st = c.last_batch_statistics()
+    c.close()
+    want = orc.process(fgx_opts.defaults(min_reads=min_reads, max_reads=max_reads), g.blob, g.rec_off, g.rec_len, g.grp_first)
+    assert out.n_deferred == 0
+    assert out.count == want["count"] and data == want["data"]
+    assert st.rejection_reasons.get(19, 0) == int(want["stats"][3 + 19]) and st.filtered_reads == int(want["stats"][2])
+    if max_reads < 9:
+        assert st.rejection_reasons.get(19, 0) > 0
