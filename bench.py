@@ -184,7 +184,8 @@ def main():
         line = {
             "metric": ("CODEC consensus throughput, input raw reads/s (4 pairs x 2x300bp)" if codec
                        else "duplex consensus throughput, input raw reads/s (depth 6+6 x 150bp)" if duplex
-                       else "simplex consensus throughput, input raw reads/s (depth-8 x 150bp)"),
+                       else f"simplex consensus throughput, input raw reads/s (depth {args.depth}..{args.depth_max} long tail x {L}bp)" if args.depth_max
+                       else f"simplex consensus throughput, input raw reads/s (depth-{args.depth} x {L}bp)"),
             "value": total_raw * steps / dt, "unit": "raw reads/s",
             "consensus_reads_per_s": total_cons * steps / dt,
             "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": dt / steps * 1e3,
