@@ -48,9 +48,34 @@ def inputs():
                 fgx_opts.defaults(kind=2, read_name_prefix=b"codec", overlapping_consensus=0, cell_tag=b"CB", produce_per_base_tags=1), 1000))
     out.append(("codec_sim", simulate_grouped_reads(150, family_size=3, read_length=300, insert_mean=350, insert_sd=60, codec=1),
                 fgx_opts.defaults(kind=2, read_name_prefix=b"codec", overlapping_consensus=0, produce_per_base_tags=1), 1000))
+    import test_gpu_indels as tgi          # indel / clip / skip CIGARs, minority alignments (alignment filter), --max-reads downsampling
+    out.append(("simplex_indels", GroupedReads.from_groups(tgi.indel_groups(seed=21, n_groups=60, max_pairs=8)), fgx_opts.defaults(min_reads=1), 50))
+    out.append(("simplex_indels_max_reads", GroupedReads.from_groups(tgi.indel_groups(seed=22, n_groups=40, max_pairs=8)), fgx_opts.defaults(min_reads=2, max_reads=3), 50))
     return out
+
+
+def filter_inputs():
+    """(name, records, oracle filter keyword options) for the `fgumi filter` fixtures; shared with tests/test_golden.py."""
+    import test_gpu_filter as tgf
+    recs = tgf.crafted()
+    return [("filter_crafted_default", recs, dict()),
+            ("filter_crafted_duplex_tiers", recs, dict(min_reads=[5, 3, 2], max_read_error_rate=[0.03, 0.02, 0.05], max_base_error_rate=[0.3, 0.2, 0.4],
+                                                       min_base_quality=12, track_rejects=True, require_single_strand_agreement=True)),
+            ("filter_crafted_single_read", recs, dict(min_reads=[2], filter_by_template=False, track_rejects=True, min_base_quality=10, min_mean_base_quality=30.0))]
+
+
+def freeze_filter(name, recs, kw):
+    import test_oracle_filter as tof
+    blob, off, ln = tof.stream(recs)
+    res = orc.filter_records(orc.filter_options(**kw), blob, off, ln)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), blob=blob, rec_off=off, rec_len=ln, data=np.frombuffer(res["data"], dtype=np.uint8),
+                        rejects=np.frombuffer(res["rejects"], dtype=np.uint8),
+                        counts=np.array([res["records"], res["passed"], res["masked"], res["rejected"]], dtype=np.uint64))
+    print(name, len(recs), "records ->", res["passed"], "kept,", res["masked"], "bases masked")
 
 
 if __name__ == "__main__":
     for name, g, o, batch in inputs():
         freeze(name, g, o, batch)
+    for name, recs, kw in filter_inputs():
+        freeze_filter(name, recs, kw)

@@ -10,7 +10,8 @@ import fgx_opts
 from fgumi_amd import GroupedReads
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-NAMES = ["simplex_crafted", "simplex_sim_depth3", "duplex_sim", "duplex_fgbio_fixture", "codec_crafted", "codec_sim"]
+NAMES = ["simplex_crafted", "simplex_sim_depth3", "duplex_sim", "duplex_fgbio_fixture", "codec_crafted", "codec_sim", "simplex_indels", "simplex_indels_max_reads"]
+FILTER_NAMES = ["filter_crafted_default", "filter_crafted_duplex_tiers", "filter_crafted_single_read"]
 
 
 def _load(name):
@@ -63,3 +64,36 @@ def test_hip_paths_reproduce_golden(name, general_only):
     assert out.count == count and got == data
     assert [int(v) for v in out.stats] == [int(v) for v in stats]
     lib.fgx_destroy(h)
+
+
+def _filter_case(name):
+    import sys
+    sys.path.insert(0, GOLD)
+    import make_golden
+    for n, _, kw in make_golden.filter_inputs():
+        if n == name:
+            z = np.load(os.path.join(GOLD, name + ".npz"))
+            return z, kw
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("name", FILTER_NAMES)
+def test_oracle_filter_reproduces_golden(name):
+    import orc
+    z, kw = _filter_case(name)
+    res = orc.filter_records(orc.filter_options(**kw), z["blob"], z["rec_off"], z["rec_len"])
+    assert res["data"] == bytes(z["data"]) and res["rejects"] == bytes(z["rejects"])
+    assert [res["records"], res["passed"], res["masked"], res["rejected"]] == [int(v) for v in z["counts"]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", FILTER_NAMES)
+def test_hip_filter_reproduces_golden(name):
+    import test_gpu_filter as tgf
+    from fgumi_amd import ConsensusFilter
+    z, kw = _filter_case(name)
+    f = ConsensusFilter(tgf._cfg(kw), **tgf._flags(kw))
+    got = f.filter_stream(z["blob"], z["rec_off"], z["rec_len"])
+    f.close()
+    assert got.data == bytes(z["data"]) and got.rejects == bytes(z["rejects"])
+    assert [got.records_count, got.passed_count, got.bases_masked, got.rejected_count] == [int(v) for v in z["counts"]]
