@@ -16,6 +16,59 @@ namespace fgx {
 
 namespace {
 
+// find_z_tag (bamrec.h) with 4- and 8-byte loads: the tag walk of one record is a chain of dependent HBM loads per thread, so
+// fewer, wider loads is what shortens it.  `safe` = bytes that may be read from `aux` on (the rest of the blob); semantics
+// identical to bam::find_z_tag (first occurrence wins, a malformed entry ends the walk).
+__device__ inline uint32_t ldg32u(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+__device__ inline unsigned long long ldg64u(const uint8_t* p) { unsigned long long v; __builtin_memcpy(&v, p, 8); return v; }
+__device__ inline int64_t find_nul_wide(const uint8_t* p, uint32_t n, uint64_t safe) {
+  uint32_t i = 0;
+  for (; i + 8 <= n && (uint64_t)i + 8 <= safe; i += 8) {
+    const unsigned long long v = ldg64u(p + i);
+    const unsigned long long t = (v - 0x0101010101010101ULL) & ~v & 0x8080808080808080ULL;
+    if (t) return (int64_t)i + (__builtin_ctzll(t) >> 3);
+  }
+  for (; i < n; i++) if (p[i] == 0) return i;
+  return -1;
+}
+__device__ inline int64_t find_z_tag_wide(const uint8_t* aux, uint32_t n, uint64_t safe, uint8_t t0, uint8_t t1, uint32_t* vlen) {
+  const uint32_t want = (uint32_t)t0 | ((uint32_t)t1 << 8);
+  uint32_t p = 0;
+  while (p + 3 <= n) {
+    uint32_t hd;
+    if ((uint64_t)p + 4 <= safe) hd = ldg32u(aux + p);
+    else hd = (uint32_t)aux[p] | ((uint32_t)aux[p + 1] << 8) | ((uint32_t)aux[p + 2] << 16) | (p + 3 < n ? (uint32_t)aux[p + 3] << 24 : 0u);
+    const uint8_t vt = (uint8_t)(hd >> 16);
+    if ((hd & 0xFFFF) == want) {
+      if (vt != 'Z') return -1;
+      const int64_t e = find_nul_wide(aux + p + 3, n - (p + 3), safe - (p + 3));
+      if (e < 0) return -1;
+      *vlen = (uint32_t)e;
+      return (int64_t)p + 3;
+    }
+    const int fixed = bam::tag_fixed_size(vt);
+    uint32_t size;
+    if (fixed > 0) size = (uint32_t)fixed;
+    else if (vt == 'Z' || vt == 'H') {
+      const int64_t e = find_nul_wide(aux + p + 3, n - (p + 3), safe - (p + 3));
+      if (e < 0) return -1;
+      size = (uint32_t)e + 1;
+    } else if (vt == 'B') {
+      if (n - (p + 3) < 5) return -1;
+      const int es = bam::tag_fixed_size((uint8_t)(hd >> 24));
+      if (es == 0) return -1;
+      const uint64_t cnt = (uint64_t)p + 8 <= safe ? ldg32u(aux + p + 4) : bam::rd32(aux + p + 4);
+      const uint64_t sz = 5 + cnt * (uint64_t)es;
+      if (sz > 0xFFFFFFFFull) return -1;
+      size = (uint32_t)sz;
+    } else return -1;
+    const uint64_t np = (uint64_t)p + 3 + size;
+    if (np > n) break;
+    p = (uint32_t)np;
+  }
+  return -1;
+}
+
 struct KeyLoc { uint64_t mi_off; uint32_t mi_len; uint32_t cb_len; uint64_t cb_off; };   // positions of the key's two parts in the blob
 
 // one thread per record: keep decision and key location
@@ -35,7 +88,8 @@ __global__ void k_group_keys(const uint8_t* __restrict__ blob, uint64_t blob_len
     if (flags_ok && aux <= len) {
       const uint32_t an = len - (uint32_t)aux;
       uint32_t vl = 0;
-      const int64_t m = bam::find_z_tag(v.b + aux, an, (uint8_t)o.tag[0], (uint8_t)o.tag[1], &vl);
+      const uint64_t safe = blob_len - (off + aux);        // bytes of the blob from the aux block on
+      const int64_t m = find_z_tag_wide(v.b + aux, an, safe, (uint8_t)o.tag[0], (uint8_t)o.tag[1], &vl);
       if (m >= 0) {
         k = 1;
         if (o.strip_strand_suffix) {          // extract_mi_base: everything before the last '/', unless that '/' leads the value
@@ -45,7 +99,7 @@ __global__ void k_group_keys(const uint8_t* __restrict__ blob, uint64_t blob_len
         L.mi_off = off + aux + (uint64_t)m; L.mi_len = vl;
         if (o.cell_tag[0]) {
           uint32_t cl = 0;
-          const int64_t cpos = bam::find_z_tag(v.b + aux, an, (uint8_t)o.cell_tag[0], (uint8_t)o.cell_tag[1], &cl);
+          const int64_t cpos = find_z_tag_wide(v.b + aux, an, safe, (uint8_t)o.cell_tag[0], (uint8_t)o.cell_tag[1], &cl);
           if (cpos >= 0) { L.cb_off = off + aux + (uint64_t)cpos; L.cb_len = cl; }      // an absent cell tag and an empty one give the same key
         }
       }
@@ -72,10 +126,13 @@ __global__ void k_group_bounds(const uint8_t* __restrict__ blob, const KeyLoc* _
   if (k > 0) {
     const KeyLoc A = kloc[k - 1], B = kloc[k];
     if (A.mi_len == B.mi_len && A.cb_len == B.cb_len) {
-      bool same = true;
-      for (uint32_t i = 0; i < B.mi_len && same; i++) same = blob[A.mi_off + i] == blob[B.mi_off + i];
-      for (uint32_t i = 0; i < B.cb_len && same; i++) same = blob[A.cb_off + i] == blob[B.cb_off + i];
-      if (same) b = 0;
+      auto equal = [&](uint64_t x, uint64_t y, uint32_t n) {      // n bytes at blob + x and blob + y (both runs lie inside records)
+        uint32_t i = 0;
+        for (; i + 8 <= n; i += 8) if (ldg64u(blob + x + i) != ldg64u(blob + y + i)) return false;
+        for (; i < n; i++) if (blob[x + i] != blob[y + i]) return false;
+        return true;
+      };
+      if (equal(A.mi_off, B.mi_off, B.mi_len) && equal(A.cb_off, B.cb_off, B.cb_len)) b = 0;
     }
   }
   bound[k] = b;
