@@ -225,3 +225,40 @@ def test_consensus_then_filter_without_leaving_the_device(kind):
     assert (got.records_count, got.passed_count, got.bases_masked) == (want["records"], want["passed"], want["masked"])
     assert got.passed_count > 0 and got.rejected_count > 0
     c.close()
+
+
+def test_filter_odd_records_and_tag_encodings():
+    """Corners of the raw-tag readers (crates/fgumi-raw-bam/src/tags.rs): every integer width for cD, duplicate tags (first occurrence
+    wins), A / H / B:f / B:i entries to walk over, an unterminated Z string that ends the walk, empty reads, a read without aux data."""
+    import struct
+    recs = []
+    widths = [("c", "<b", 7), ("C", "<B", 200), ("s", "<h", 300), ("S", "<H", 40000), ("i", "<i", 70000), ("I", "<I", 3000000000), ("c", "<b", -3)]
+    for k, (ty, fmt, val) in enumerate(widths):
+        tags = [("cD", "raw", ty.encode() + struct.pack(fmt, val)), ("XA", "raw", b"Aq"), ("XH", "raw", b"H1AF0\0"), tof.arr("XF", [1, 2], "i"), ("cE", "f", 0.01),
+                tof.arr("cd", [9] * 10), tof.arr("ce", [0] * 10, "C"), ("cD", "i", 1), ("cE", "f", 0.9)]       # the later duplicates are ignored
+        recs.append(bamutil.make_record(f"w{k}", "ACGTACGTAC", [30] * 10, flag=4, ref_id=-1, pos=-1, tags=tags))
+    # B:f array named like a per-base tag: find_array_tag accepts it, every element reads as 0
+    recs.append(bamutil.make_record("bf", "ACGT", [30] * 4, flag=4, ref_id=-1, pos=-1,
+                                    tags=[("cD", "i", 9), ("cE", "f", 0.0), ("cd", "raw", b"Bf" + struct.pack("<I4f", 4, 1.0, 2.0, 3.0, 4.0)), tof.arr("ce", [0] * 4)]))
+    # unterminated Z after the consensus tags: the walk ends there, what came before still counts
+    recs.append(bamutil.make_record("unterminated", "ACGT", [30] * 4, flag=4, ref_id=-1, pos=-1,
+                                    tags=[("cD", "i", 9), ("cE", "f", 0.0), ("ZZ", "raw", b"Zno-nul-here")]))
+    # ... and before them: cD / cE are never seen, which is the reference's fatal error — checked separately below
+    recs.append(bamutil.make_record("empty", "", [], flag=4, ref_id=-1, pos=-1, tags=[("cD", "i", 9), ("cE", "f", 0.0)]))
+    recs.append(bamutil.make_record("odd", "ACG", [30, 2, 30], flag=4, ref_id=-1, pos=-1, tags=[("cD", "i", 9), ("cE", "f", 0.0), tof.arr("cd", [9, 9]), tof.arr("ce", [0, 0, 5])]))
+    for kw in (dict(min_reads=[2], filter_by_template=False, track_rejects=True, min_base_quality=10), dict(min_reads=[250], max_no_call_fraction=1000.0, track_rejects=True),
+               dict(min_reads=[1], max_no_call_fraction=0.0, min_mean_base_quality=20.5, track_rejects=True)):
+        _same(recs, **kw)
+    f = ConsensusFilter(FilterConfig.new([1]))
+    bad = bamutil.make_record("hidden", "ACGT", [30] * 4, flag=4, ref_id=-1, pos=-1, tags=[("ZZ", "raw", b"Zno-nul"), ("cD", "i", 9), ("cE", "f", 0.0)])
+    with pytest.raises(RuntimeError, match="cD/cE"):
+        f.filter_stream(*tof.stream([bad]))
+    with pytest.raises(RuntimeError):
+        orc.filter_records(orc.filter_options(), *tof.stream([bad]))
+    no_aux = bamutil.make_record("noaux", "ACGT", [30] * 4, flag=4, ref_id=-1, pos=-1)
+    with pytest.raises(RuntimeError, match="cD/cE"):
+        f.filter_stream(*tof.stream([no_aux]))
+    wrong_type = bamutil.make_record("ce_int", "ACGT", [30] * 4, flag=4, ref_id=-1, pos=-1, tags=[("cD", "i", 9), ("cE", "i", 0)])
+    with pytest.raises(RuntimeError, match="cD/cE"):
+        f.filter_stream(*tof.stream([wrong_type]))
+    f.close()
