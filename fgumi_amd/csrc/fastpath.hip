@@ -1,28 +1,39 @@
-// fastpath.hip — the device-resident simplex pipeline: raw BAM records in HBM → consensus BAM
-// records in HBM, no host work per family.
+// fastpath.hip — the device-resident pipelines of the three callers: raw BAM records in HBM → consensus BAM records in HBM,
+// no host work per family.  Sections, in file order:
 //
-//   k_family  (pass A)  one workgroup per MI group (family).  Lanes parse the record headers and
-//                       aux tags, stage every read's 4-bit bases + quals into LDS (unpacked to one
-//                       byte per base), apply the R1/R2 overlapping-bases pre-correction in LDS,
-//                       compute each read's oriented / masked / mate-clipped length, run the
-//                       family gates (min-reads at every shrink point, R1/R2 orphan rule), then call
-//                       every consensus column (one lane per column, reads walked serially in file
-//                       order — summation order is observable) and the per-character UMI consensus.
-//                       Writes the four per-position arrays + one descriptor per consensus read.
-//   hipcub scan         exclusive sum of record sizes → byte offsets (output order = input order).
-//   k_emit    (pass B)  one wavefront per consensus read: assembles the unmapped BAM record
-//                       (header, name `<prefix>:<MI>`, 4-bit sequence, quals, tags RG cD cM cE [cd ce]
-//                       MI [CB] RX) at its offset.
+//   shared device helpers     ReadInfo / Shared (LDS state of the workgroup kernel), name_rank (fgbio Murmur3 name rank), general-CIGAR
+//                             helpers (map_ref_to_query, simplified CIGARs, alignment_filter = select_most_common_alignment_group)
+//   k_family                  ONE WORKGROUP (512 threads) PER FAMILY: families with more than 64 records, a byte span beyond the largest
+//                             wave slice, or any read with an indel / skip.  Records copied HBM→LDS once; a thread per record parses
+//                             (general CIGARs up to 6 ops), unpacks, pairs mates, corrects overlaps through both CIGARs, computes the
+//                             source-read geometry, runs the gates (alignment filter, --max-reads downsampling, min-reads at every
+//                             shrink point, orphan rule); a thread per column calls the consensus; per-character UMI consensus.
+//   k_family_wave<MODE>       ONE WAVEFRONT PER FAMILY / MOLECULE, the common case.  MODE 0 simplex, 1 duplex (strand partition, four
+//                             single-strand column sets, descriptors of the two duplex records), 2 CODEC (FR pairs, virtual hard clip
+//                             against the mate, overlap geometry, two strand column sets).  Phases: stage raw records into LDS → parse
+//                             (lane = record) → overlap pre-correction → geometry → gates → columns (lane = column, reads walked in file
+//                             order: summation order is observable) → UMI consensus → descriptors + stats.  Columns the unanimous fast
+//                             path cannot decide go to 1024 chained lists for k_call_full.
+//   k_call_full               one lane per deferred column (or UMI character): ln_sum_exp chain on the device libm, tie rule, Phred.
+//   k_emit / k_emit_duplex[_fast] / k_emit_codec[_fast]
+//                             one wavefront per consensus record: header, name `<prefix>:<MI>`, 4-bit sequence, qualities and the
+//                             caller's tag set at the record's scanned offset (the _fast writers take the records of common shape,
+//                             the generic per-field writers the rest); duplex / CODEC combine the strands here.
+//   k_col_bound, k_reduce_stats, FastPath::run
+//                             column-slot bounds, counter reduction, and the host orchestration: staged wave launches over growing
+//                             LDS slices with retry lists (4 / 2 / 1 wavefronts per workgroup), workgroup kernel for what is left,
+//                             scans, emit.
 //
-// Reference semantics restated (bit-exact contract), all paths under crates/fgumi-consensus/src/:
+// Reference semantics restated (bit-exact contract), paths under crates/fgumi-consensus/src/ unless noted:
 //   src/lib/commands/simplex.rs:669-701 (group skip, overlap pre-step, consensus_reads)
-//   overlapping.rs:236-336, 627-684 ; vanilla_caller.rs:862-877, 1080-1190, 1304-1422, 1454-1646,
-//   1652-1755, 1767-1881 ; simple_umi.rs:46-117 ; raw-bam/src/overlap.rs:181-357 ; builder.rs:122-301
+//   overlapping.rs:236-336, 565-684 ; vanilla_caller.rs:48-120, 862-932, 1080-1296, 1304-1422, 1454-1646, 1652-1755, 1767-1881 ;
+//   simple_umi.rs:46-117 ; duplex_caller.rs:560-1405, 1837-2624 ; codec_caller.rs:504-1911 ;
+//   crates/fgumi-raw-bam/src/{overlap.rs:21-357, hash.rs:14-89, builder.rs:122-301, cigar.rs:404-500}
 //
-// Families the fast path does not decide are DEFERRED untouched to the general host path
-// (simplex_host.cpp): any read with a CIGAR other than one M/=/X op spanning the read, unmapped
-// reads, --max-reads that bites, malformed records (so that the general path raises the
-// reference's fatal error), more than FAST_MAX_READS reads or more LDS than the launch provides.
+// Families the device does not decide are DEFERRED untouched to the general host path (simplex_host.cpp, duplex_host.cpp,
+// codec_host.cpp): reads with more than 6 CIGAR ops or SEQ / CIGAR length mismatch, unmapped reads, malformed records (so that
+// the general path raises the reference's fatal error), more than FAST_MAX_READS reads or more LDS than the launch provides,
+// duplex / CODEC molecules with indels or a biting per-strand read cap.  See DESIGN.md 4.
 #include <hipcub/hipcub.hpp>
 #include "bamrec.h"
 #include "engine.h"
