@@ -139,10 +139,11 @@ int fgx_process_batch(fgx_caller* c, const uint8_t* records, uint64_t records_le
 
 /* Same contract with every input array already resident in HBM (device pointers) and the
  * consensus records left in HBM: the measured configuration of bench.py and the multi-GPU path.
- * `out->data` is a DEVICE pointer; `out->stats` is copied back (112 bytes).  Families the device
- * fast path cannot decide (indel-bearing CIGARs in the alignment filter, name-unpaired mates, …)
- * are reported in *n_deferred / d_deferred_groups and must be re-submitted through
- * fgx_process_batch; 0 for `simulate`-shaped input. */
+ * `out->data` is a DEVICE pointer; `out->stats` is copied back (224 bytes).  Families the device
+ * pipelines do not decide (reads with more than 6 CIGAR ops, unmapped reads, malformed records; for
+ * duplex / CODEC also molecules with indels or a biting per-strand read cap) are reported in
+ * *n_deferred / d_deferred_groups and must be re-submitted through fgx_process_batch; 0 for
+ * `simulate`-shaped input. */
 int fgx_process_batch_device(fgx_caller* c, const void* d_records, uint64_t records_len, const void* d_rec_off,
                              const void* d_rec_len, uint32_t n_rec, const void* d_grp_first, uint32_t n_grp,
                              fgx_output* out, uint32_t* n_deferred, const void** d_deferred_groups);
