@@ -119,6 +119,7 @@ struct FastPath {
   DevBuf d_retry, d_bound, d_colbase, d_statslots, d_full_items, d_full_count, d_obs, d_retry2;
   uint32_t lds_wave_bytes = 6144;         // wave-per-family kernel: LDS copy of one family's raw records
   uint32_t lds_wave_bytes_duplex = 8704;  // duplex molecules carry both strands (config 3: 24 records x ~330 B)
+  uint32_t lds_wave_bytes_codec = 5120;   // CODEC (config 5: 8 records x ~570 B): its kernel needs 71 VGPRs, so the smaller slice buys a sixth wave per SIMD (+3 %)
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   int run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const uint64_t* d_rec_off, const uint32_t* d_rec_len, uint32_t n_rec,
           const uint32_t* d_grp_first, uint32_t n_grp, FastResult* res);

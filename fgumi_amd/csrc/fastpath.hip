@@ -3198,7 +3198,7 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
   d_full_count.reserve((size_t)N_LISTS * 4);
   hip_check(hipMemsetAsync(d_full_count.p, 0, (size_t)N_LISTS * 4, s), "memset");
   P.full_items = d_full_items.as<FullItem>(); P.full_count = d_full_count.as<uint32_t>(); P.full_cap = full_cap;
-  uint32_t wave_bytes = duplex ? lds_wave_bytes_duplex : lds_wave_bytes;
+  uint32_t wave_bytes = duplex ? lds_wave_bytes_duplex : codec ? lds_wave_bytes_codec : lds_wave_bytes;
   if (const char* e = getenv("FGX_WAVE_BYTES")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 1024 && v <= 22016) wave_bytes = v & ~15u; }   // tuning knob
   P.lds_wave_bytes = wave_bytes;
   P.lds_tile_bytes = lds_tile_bytes_large;
