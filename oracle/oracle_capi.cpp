@@ -255,6 +255,7 @@ int orc_filter_duplex_read(const uint8_t* rec, uint32_t len, const double* cc, c
   try { return (int)orc_filter::filter_duplex_read(RecView(rec, len).aux(), thr_of(cc), thr_of(ab), thr_of(ba)); }
   catch (const OracleError& e) { g_err = e.what; return -1; }
 }
+void orc_filter_reverse_tags(uint8_t* rec, uint32_t len) { orc_filter::reverse_per_base_tags(rec, len); }   // tag_reversal.rs:27-67 alone
 int orc_filter_is_duplex(const uint8_t* rec, uint32_t len) { return orc_filter::is_duplex_consensus(RecView(rec, len).aux()); }
 int orc_filter_process_record(const fgx_filter_options* o, uint8_t* rec, uint32_t len, uint64_t* masked, int* pass) {
   bool p = false;

@@ -42,7 +42,7 @@ def _load():
         "orc_filter_rejects": (VP, [VP]), "orc_filter_rejects_len": (U64, [VP]), "orc_filter_counts": (None, [VP, VP]), "orc_filter_free": (None, [VP]),
         "orc_filter_mask_bases": (C.c_int64, [VP, U32, VP, C.c_int, U8]), "orc_filter_mask_duplex_bases": (C.c_int64, [VP, U32, VP, VP, VP, C.c_int, U8, C.c_int]),
         "orc_filter_read": (C.c_int, [VP, U32, VP]), "orc_filter_duplex_read": (C.c_int, [VP, U32, VP, VP, VP]), "orc_filter_is_duplex": (C.c_int, [VP, U32]),
-        "orc_filter_process_record": (C.c_int, [VP, VP, U32, P(U64), P(C.c_int)]),
+        "orc_filter_process_record": (C.c_int, [VP, VP, U32, P(U64), P(C.c_int)]), "orc_filter_reverse_tags": (None, [VP, U32]),
     }
     for name, (res, args) in sig.items():
         if hasattr(lib, name):
@@ -225,3 +225,10 @@ def filter_process_record(o, rec):
     if lib.orc_filter_process_record(C.addressof(o), a, len(buf), C.byref(masked), C.byref(ok)) != 0:
         raise RuntimeError(lib.orc_last_error().decode())
     return masked.value, bool(ok.value), bytes(buf)
+
+
+def filter_reverse_tags(rec):
+    buf = bytearray(rec)
+    a = (C.c_uint8 * len(buf)).from_buffer(buf)
+    lib.orc_filter_reverse_tags(a, len(buf))
+    return bytes(buf)

@@ -191,6 +191,24 @@ def test_reverse_per_base_tags():
     assert same(orc.filter_process_record(orc.filter_options(), r)[2], r)
 
 
+# ---- src/lib/tag_reversal.rs tests :130-260 ------------------------------------------------------------------------------
+@pytest.mark.parametrize("ty,fmt", [("c", "b"), ("C", "B"), ("s", "h"), ("S", "H"), ("i", "i"), ("I", "I"), ("f", "f")])
+def test_reverse_every_array_type(ty, fmt):
+    raw = b"B" + ty.encode() + struct.pack("<I", 3) + struct.pack("<3" + fmt, 1, 2, 3)
+    r = bamutil.make_record("q", "ACGT", [30] * 4, flag=UNMAPPED | 0x10, ref_id=-1, pos=-1, tags=[("cd", "raw", raw), ("zz", "raw", raw)])
+    t = bamutil.parse(orc.filter_reverse_tags(r))["tags"]
+    assert list(t["cd"][1]) == [3, 2, 1] and list(t["zz"][1]) == [1, 2, 3]          # only the per-base consensus tags are touched
+
+
+def test_reverse_reference_string_and_array_pins():
+    r = bamutil.make_record("q", "ACGT", [30] * 4, flag=UNMAPPED | 0x10, ref_id=-1, pos=-1,
+                            tags=[("aq", "Z", "IIHG"), ("ac", "Z", "ACGA"), ("bc", "Z", "ACGA"), arr("cd", [1, 2, 3, 4]), ("bq", "Z", ""), ("ad", "i", 7)])
+    t = {k: v[1] for k, v in bamutil.parse(orc.filter_reverse_tags(r))["tags"].items()}
+    assert t["aq"] == "GHII" and t["ac"] == "TCGT" and t["bc"] == "TCGT" and list(t["cd"]) == [4, 3, 2, 1] and t["bq"] == "" and t["ad"] == 7
+    fwd = bamutil.make_record("q", "ACGT", [30] * 4, flag=UNMAPPED, ref_id=-1, pos=-1, tags=[("aq", "Z", "IIHG"), arr("cd", [1, 2, 3, 4])])
+    assert orc.filter_reverse_tags(fwd) == fwd                                      # positive strand: Ok(false), untouched
+
+
 # ---- stream level ------------------------------------------------------------------------------------------------------
 def P(name, ok1=True, ok2=True, n1=0, n2=0):
     """R1/R2 consensus pair; okX False → cD below min-reads 3; nX = bases masked by per-base depth."""
