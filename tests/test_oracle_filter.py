@@ -267,3 +267,20 @@ def test_stream_empty():
     blob, off, ln = stream([])
     res = orc.filter_records(orc.filter_options(), blob, off, ln)
     assert res["data"] == b"" and res["records"] == 0
+
+
+# ---- src/lib/template.rs tests :1851-1945 (Template::from_records ordering) through the template-mode stream ---------------------------
+def _ordered(names_flags):
+    recs = [rec("ACGTACGTAC", [30] * 10, cD=9, cE=0.0, flag=f | UNMAPPED, name="read1", extra=[("xx", "Z", n)]) for n, f in names_flags]
+    blob, off, ln = stream(recs)
+    res = orc.filter_records(orc.filter_options(), blob, off, ln)
+    return [bamutil.parse(x)["tags"]["xx"][1] for x in bamutil_split(res["data"])]
+
+
+def test_template_record_ordering_reference_pins():
+    P1, P2, SUP, SEC = 0x41, 0x81, 0x800, 0x100
+    got = _ordered([("r2_sec1", P2 | SEC), ("r1_supp2", P1 | SUP), ("r1", P1), ("r2_supp", P2 | SUP), ("r1_sec", P1 | SEC), ("r2", P2), ("r2_sec2", P2 | SEC),
+                    ("r1_supp1", P1 | SUP)])
+    assert got == ["r1", "r2", "r1_supp1", "r1_supp2", "r2_supp", "r1_sec", "r2_sec2", "r2_sec1"]
+    got = _ordered([("r1", P1), ("r2", P2), ("s1", P1 | SUP), ("s2", P1 | SUP), ("s3", P1 | SUP), ("t1", P2 | SUP), ("t2", P2 | SUP), ("c1", P1 | SEC), ("c2", P1 | SEC)])
+    assert got == ["r1", "r2", "s3", "s2", "s1", "t2", "t1", "c2", "c1"]       # supplementaries / secondaries come out in reverse input order
