@@ -336,6 +336,9 @@ class _HandleCaller(ConsensusCaller):
 
     # ---- device-resident batch (inputs and outputs stay in HBM) ---------------------------------
     def process_batch_device(self, dg: "DeviceGroupedReads"):
+        import torch
+        # the library runs on its own non-blocking stream: whatever still produces `dg` on torch's stream must have finished
+        torch.cuda.synchronize(dg.blob.device)
         out = Output()
         n_def = C.c_uint32()
         d_def = C.c_void_p()
@@ -344,6 +347,7 @@ class _HandleCaller(ConsensusCaller):
         if rc != 0:
             raise RuntimeError(lib.fgx_last_error(self._h).decode())
         self._last_stats = ConsensusCallingStats.from_array(out.stats)
+        self._stats.merge(self._last_stats)
         self.last_timing = dict(kernels=out.ms_kernels, k_family=out.ms_k_family, k_emit=out.ms_k_emit, full_columns=int(out.ms_emit))
         return DeviceOutput(out.data, int(out.data_len), int(out.count), int(n_def.value), d_def.value)
 

@@ -183,6 +183,7 @@ static bool ensure_workers(fgx_caller* c, unsigned T) {
 static int run_general(fgx_caller* c, general_fn fn, const uint8_t* records, const uint64_t* rec_off, const uint32_t* rec_len, uint32_t n_rec,
                        const uint32_t* grp_first, uint32_t n_grp, fgx_output* out) {
   constexpr uint32_t MIN_GROUPS = 512;              // below this a shard is not worth a thread
+  c->counter_names_used = false;                    // (set by the CODEC general path; stale values must not survive a sharded run)
   unsigned T = host_threads();
   if (T > n_grp / MIN_GROUPS) T = n_grp / MIN_GROUPS;
   if (T <= 1) return fn(c, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
@@ -279,6 +280,7 @@ static int hybrid_after_upload(fgx_caller* c, general_fn general, const uint8_t*
                                uint8_t* dst, uint64_t dst_cap) {
   auto ms = ms_between;
   if (!c->fast) c->fast = new FastState();
+  c->fast->has_last = false;   // this run overwrites (and may reallocate) the device buffers a device-resident batch left behind
   hip_check(hipSetDevice(c->device), "hipSetDevice");
   auto t0 = clk::now();
   auto t1 = t0;
@@ -314,6 +316,10 @@ static int hybrid_after_upload(fgx_caller* c, general_fn general, const uint8_t*
   fgx_output gen;
   int rc = run_general(c, general, records, d_off.data(), d_len.data(), (uint32_t)d_off.size(), d_grp.data(), (uint32_t)def.size(), &gen);
   if (rc != 0) return rc;
+  // CODEC molecules without an MI are named by a counter that advances on EVERY emitted record (codec_caller.rs:1568-1577):
+  // the deferred subset alone would restart it at 0, so the whole batch goes through the general path in one piece
+  if (c->opt.caller_kind == FGX_CALLER_CODEC && c->counter_names_used)
+    return run_general(c, general, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
   std::vector<uint8_t> merged;
   merged.reserve(fr.out_len + c->out_data.size());
   uint64_t fpos = 0;   // fast output is contiguous in group order; deferred groups contributed nothing to it
@@ -339,9 +345,11 @@ int fgx_process_batch(fgx_caller* c, const uint8_t* records, uint64_t records_le
   if (!c || !out) return 1;
   c->err.clear();
   try {
-    for (uint32_t r = 0; r < n_rec; r++) {
-      if (rec_len[r] < 32 || rec_off[r] + rec_len[r] > records_len) { c->err = "fgx_process_batch: record outside the blob or shorter than the fixed BAM header"; return 1; }
+    for (uint32_t r = 0; r < n_rec; r++) {   // overflow-safe: rec_off + rec_len may wrap in u64
+      if (rec_len[r] < 32 || rec_len[r] > records_len || rec_off[r] > records_len - rec_len[r]) { c->err = "fgx_process_batch: record outside the blob or shorter than the fixed BAM header"; return 1; }
     }
+    for (uint32_t g = 0; g < n_grp; g++)
+      if (grp_first[g] > grp_first[g + 1]) { c->err = "fgx_process_batch: group boundaries must be non-decreasing"; return 1; }
     if (n_grp && grp_first[n_grp] > n_rec) { c->err = "fgx_process_batch: group boundaries exceed n_rec"; return 1; }
     switch (c->opt.caller_kind) {
       case FGX_CALLER_SIMPLEX:
@@ -379,6 +387,7 @@ int fgx_process_batch_device(fgx_caller* c, const void* d_records, uint64_t reco
     }
     if (c->opt.track_rejects) { c->err = "fgx_process_batch_device: --rejects needs the host path (fgx_process_batch)"; return 1; }
     if (!c->fast) c->fast = new FastState();
+    c->fast->has_last = false;   // set again only when this batch succeeds
     hip_check(hipSetDevice(c->device), "hipSetDevice");
     FastResult fr;
     c->fast->fp.run(c, (const uint8_t*)d_records, records_len, (const uint64_t*)d_rec_off, (const uint32_t*)d_rec_len, n_rec,
@@ -417,7 +426,7 @@ int fgx_group_records(fgx_caller* c, const fgx_group_options* g, const uint8_t* 
   try {
     hip_check(hipSetDevice(c->device), "hipSetDevice");
     for (uint32_t r = 0; r < n_rec; r++)
-      if (rec_off[r] + rec_len[r] > records_len) { c->err = "fgx_group_records: record outside the blob"; return 1; }
+      if (rec_len[r] > records_len || rec_off[r] > records_len - rec_len[r]) { c->err = "fgx_group_records: record outside the blob"; return 1; }
     c->d_in_blob.reserve(records_len + 16);
     c->d_in_off.reserve((size_t)n_rec * 8 + 8);
     c->d_in_len.reserve((size_t)n_rec * 4 + 4);
@@ -488,7 +497,8 @@ int fgx_filter_last_output_device(fgx_caller* c, const fgx_filter_options* f, fg
     if (!c->fast || !c->fast->has_last) { c->err = "fgx_filter_last_output_device: no device-resident batch on this handle"; return 1; }
     hip_check(hipSetDevice(c->device), "hipSetDevice");
     if (!c->filt) c->filt = new FilterBuffers();
-    const FastResult& L = c->fast->last;
+    const FastResult L = c->fast->last;
+    c->fast->has_last = false;   // single use: the records are masked and reversed IN PLACE, a second pass would re-apply both
     return filter_slots_device(c, *c->filt, f, (uint8_t*)L.d_out, L.out_len, L.d_out_off, L.d_slot_size, L.n_slots, out);
   } catch (const std::exception& ex) { c->err = ex.what(); return 3; }
 }
@@ -501,7 +511,7 @@ int fgx_filter_records(fgx_caller* c, const fgx_filter_options* f, const uint8_t
     if (!filter_options_valid(f, c->err)) return 1;
     hip_check(hipSetDevice(c->device), "hipSetDevice");
     for (uint32_t r = 0; r < n_rec; r++)
-      if (rec_off[r] + rec_len[r] > records_len) { c->err = "fgx_filter_records: record outside the blob"; return 1; }
+      if (rec_len[r] > records_len || rec_off[r] > records_len - rec_len[r]) { c->err = "fgx_filter_records: record outside the blob"; return 1; }
     if (!c->filt) c->filt = new FilterBuffers();
     FilterBuffers& B = *c->filt;
     B.in_blob.reserve(records_len + 64);

@@ -281,7 +281,7 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
   __syncthreads();
   const unsigned long long base16 = S.raw_lo & ~15ull;
   const uint32_t raw_bytes = (uint32_t)(((S.raw_hi - base16) + 15 + 16) & ~15ull);      // + slack for multi-byte reads past the last record
-  if ((S.raw_hi - base16) + 32 > (unsigned long long)P.lds_tile_bytes) {                  // not even the raw span fits
+  if ((S.raw_hi - base16) + 32 > (unsigned long long)P.lds_tile_bytes || S.raw_hi > P.blob_len) {   // not even the raw span fits (or a record ends outside the blob)
     if (tid == 0) { uint32_t k = atomicAdd(P.n_deferred, 1u); P.deferred[k] = g; }
     return;
   }
@@ -1063,7 +1063,7 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
   uint32_t len = act ? P.rec_len[r0 + lane] : 0;
   unsigned long long lo_off = wave_min64(off);
   unsigned long long hi_end = wave_max64(act ? off + len : 0ull);
-  if (__any(act && len < 32)) { to_defer(); return; }
+  if (__any(act && len < 32) || hi_end > P.blob_len) { to_defer(); return; }   // a record outside the blob: the general path raises the error
   unsigned long long base16 = lo_off & ~15ull;
   unsigned long long span = hi_end - base16;
   if (span + 16 > (unsigned long long)P.lds_wave_bytes) { to_retry(); return; }   // +16: slack for the dword-composed reads
@@ -3088,6 +3088,8 @@ __global__ __launch_bounds__(256) void k_emit_codec_fast(CodecEmitParams P) {
   if (has_rx) W.z_small('R', 'X', (const uint8_t*)D.rx, rx_len);
 }
 
+#include "simplex_wave2.inc"
+
 // Upper bound on the consensus columns a batch can produce: a family yields at most three ends, each no
 // longer than its longest read, and l_seq <= (block_size - 33) * 2 / 3.
 __global__ void k_col_bound(const uint32_t* __restrict__ grp_first, const uint32_t* __restrict__ rec_len, uint32_t n_grp,
@@ -3116,7 +3118,7 @@ __global__ void k_reduce_stats(const unsigned long long* __restrict__ slots, uns
 // -----------------------------------------------------------------------------------------------------
 void FastPath::release() {
   for (DevBuf* b : {&d_ends, &d_sizes, &d_offsets, &d_code, &d_qual, &d_depth, &d_err, &d_misc, &d_deferred, &d_out, &d_scan_tmp, &d_strings, &d_obs, &d_retry2,
-                    &d_retry, &d_bound, &d_colbase, &d_statslots, &d_full_items, &d_full_count})
+                    &d_retry, &d_bound, &d_colbase, &d_statslots, &d_full_items, &d_full_count, &d_retry_old})
     b->free_();
   for (int i = 0; i < 4; i++) if (ev[i]) { (void)hipEventDestroy(ev[i]); ev[i] = nullptr; }
 }
@@ -3134,14 +3136,14 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
   d_offsets.reserve((size_t)n_slots * 8);
   d_deferred.reserve((size_t)n_grp * 4);
   // misc: [0..28) stats, [28] col_cursor, [29] n_deferred (u32 in low half), [30] valid count
-  d_misc.reserve(32 * 8);
-  hip_check(hipMemsetAsync(d_misc.p, 0, 32 * 8, s), "memset");
+  d_misc.reserve(40 * 8);   // ... [31] n_retry, [32] n_retry_old (k_simplex_wave2 → k_family_wave<0>)
+  hip_check(hipMemsetAsync(d_misc.p, 0, 40 * 8, s), "memset");
   // strings: prefix | rg
   std::string strs = c->prefix + c->rg;
   d_strings.reserve(strs.size() + 16);
   if (!strs.empty()) hip_check(hipMemcpyAsync(d_strings.p, strs.data(), strs.size(), hipMemcpyHostToDevice, s), "H2D strings");
   // column scratch: deterministic per-family slots from an exclusive scan of the column bound
-  (void)blob_len; (void)n_rec;
+  (void)n_rec;
   for (int i = 0; i < 4; i++) if (!ev[i]) hip_check(hipEventCreate(&ev[i]), "hipEventCreate");
   unsigned long long* misc = d_misc.as<unsigned long long>();
   d_bound.reserve((size_t)n_grp * 8); d_colbase.reserve((size_t)n_grp * 8);
@@ -3165,10 +3167,12 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
   FastParams P;
   memset(&P, 0, sizeof(P));
   P.blob = d_blob; P.rec_off = d_rec_off; P.rec_len = d_rec_len; P.grp_first = d_grp_first;
+  P.blob_len = blob_len;
   P.g0 = 0;
   P.T = c->d_tables.as<DeviceTables>(); P.TU = c->d_umi_tables.as<DeviceTables>();
   P.min_reads = o.min_reads; P.max_reads = o.max_reads;
   P.min_input_bq = o.min_input_base_quality; P.min_cons_bq = o.min_consensus_base_quality;
+  P.trim = o.trim; P.overlap = o.overlapping_consensus;
   if (duplex) {   // single-strand caller of the duplex caller (duplex_caller.rs:474-489): min_reads 1, min consensus base quality 2
     P.min_reads = 1; P.max_reads = -1; P.min_cons_bq = FGX_MIN_PHRED;
     P.dmin_total = o.duplex_min_reads[0]; P.dmin_xy = o.duplex_min_reads[1]; P.dmin_yx = o.duplex_min_reads[2];
@@ -3180,7 +3184,7 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
     P.cends = d_ends.as<CodecDesc>(); P.cmin_reads = o.codec_min_reads_per_strand; P.cmax_reads = o.codec_max_reads_per_strand;
     P.cmin_duplex_len = o.codec_min_duplex_length;
   }
-  P.trim = o.trim; P.overlap = o.overlapping_consensus; P.per_base_tags = o.produce_per_base_tags; P.track_rejects = o.track_rejects;
+  P.per_base_tags = o.produce_per_base_tags; P.track_rejects = o.track_rejects;
   P.tag0 = (duplex || codec) ? 'M' : o.tag[0]; P.tag1 = (duplex || codec) ? 'I' : o.tag[1]; P.cell0 = o.cell_tag[0]; P.cell1 = o.cell_tag[1];
   P.prefix_len = (uint32_t)c->prefix.size(); P.rg_len = (uint32_t)c->rg.size();
   P.ends = d_ends.as<EndDesc>(); P.rec_sizes = d_sizes.as<uint64_t>();
@@ -3223,6 +3227,39 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
     uint32_t n_cur = n_grp;
     const uint32_t* cur_list = nullptr;
     int out_list = 0;
+    // Simplex, no --trim: k_simplex_wave2 (two-accumulator column loop) takes the families of the common record shape over the same
+    // growing LDS slices; what is outside its shape is collected in `retry_old` and goes through the k_family_wave<0> launches below.
+    static const bool use_v2 = [] { const char* e = getenv("FGX_V2"); return !(e && e[0] == '0'); }();
+    if (!duplex && !codec && !o.trim && use_v2) {
+      static bool v2_attr_set = false;
+      if (!v2_attr_set) { (void)hipFuncSetAttribute((const void*)k_simplex_wave2, hipFuncAttributeMaxDynamicSharedMemorySize, WAVES_PER_BLOCK * 22016); (void)hipGetLastError(); v2_attr_set = true; }
+      d_retry_old.reserve((size_t)n_grp * 4);
+      uint32_t* d_cnt_old = (uint32_t*)(misc + 32);
+      uint32_t n_v2 = n_grp;
+      const uint32_t* v2_list = nullptr;
+      int v2_out = 0;
+      for (int st = 0; st < 3 && n_v2; st++) {
+        if (st > 0 && stages[st] <= stages[st - 1]) continue;
+        const bool last = st == 2;
+        hip_check(hipMemsetAsync(d_cnt, 0, 4, s), "memset");
+        FastParams PS = P;
+        PS.group_list = v2_list; PS.lds_wave_bytes = stages[st];
+        PS.retry = last ? nullptr : lists[v2_out]; PS.n_retry = d_cnt;
+        PS.retry_old = d_retry_old.as<uint32_t>(); PS.n_retry_old = d_cnt_old;
+        const uint32_t wpb = st == 0 ? WAVES_PER_BLOCK : st == 1 ? 2u : 1u;
+        hipLaunchKernelGGL(k_simplex_wave2, dim3((n_v2 + wpb - 1) / wpb), dim3(64 * wpb), (size_t)wpb * stages[st], s, PS, n_v2);
+        hip_check(hipGetLastError(), "k_simplex_wave2 launch");
+        uint32_t n_next = 0;
+        hip_check(hipMemcpyAsync(&n_next, d_cnt, 4, hipMemcpyDeviceToHost, s), "D2H");
+        hip_check(hipStreamSynchronize(s), "sync");
+        v2_list = lists[v2_out]; n_v2 = PS.retry ? n_next : 0; v2_out ^= 1;
+      }
+      uint32_t n_old = 0;
+      hip_check(hipMemcpyAsync(&n_old, d_cnt_old, 4, hipMemcpyDeviceToHost, s), "D2H");
+      hip_check(hipStreamSynchronize(s), "sync");
+      n_cur = n_old; cur_list = d_retry_old.as<uint32_t>();
+      out_list = 0;
+    }
     for (int st = 0; st < 3 && n_cur; st++) {
       if (st > 0 && stages[st] <= stages[st - 1]) continue;
       const bool last = st == 2;
