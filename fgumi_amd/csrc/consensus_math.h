@@ -143,6 +143,10 @@ struct ConsensusTables {
   uint8_t qguess[256];
   double cap_threshold;      // thresholds[cap]
   double half_cerr_at_cap;   // 0.5 * cerr_min[cap - 1], the cap-region budget of unanimous_fast_path
+  // margin_scale[q] >= (1 / cerr_min[q]) * (1 + 2^-51): `x * margin_scale[q]` is an upper bound of the reference's
+  // `x / cerr_min[q]` (unanimous_margin), so a gate that holds with it holds with the exact margin; only when it fails
+  // does a kernel pay for the f64 division (derived data, not a reference table)
+  double margin_scale[94];
 };
 
 FGX_HD uint8_t unanimous_quality_from_gap(double gap, double ln_error_pre_umi) {
@@ -196,6 +200,10 @@ inline void build_tables(ConsensusTables& t, uint8_t pre, uint8_t post, uint32_t
     int n = 0;
     for (int q = 0; q <= FGX_MAX_PHRED; q++) if (t.thresholds[q] <= edge) n++;
     t.qguess[k] = (uint8_t)n;
+  }
+  for (int q = 0; q <= FGX_MAX_PHRED; q++) {
+    const double c = t.cerr_min[q];
+    t.margin_scale[q] = c > 0.0 ? (1.0 / c) * (1.0 + 4.0 * FGX_DBL_EPSILON) : m_inf();
   }
   t.cap_threshold = t.thresholds[t.cap < 94 ? t.cap : 93];
   t.half_cerr_at_cap = 0.5 * t.cerr_min[t.cap ? t.cap - 1 : 0];

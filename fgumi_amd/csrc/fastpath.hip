@@ -3089,6 +3089,7 @@ __global__ __launch_bounds__(256) void k_emit_codec_fast(CodecEmitParams P) {
 }
 
 #include "simplex_wave2.inc"
+#include "simplex_seg.inc"
 
 // Upper bound on the consensus columns a batch can produce: a family yields at most three ends, each no
 // longer than its longest read, and l_seq <= (block_size - 33) * 2 / 3.
@@ -3231,24 +3232,48 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
     // growing LDS slices; what is outside its shape is collected in `retry_old` and goes through the k_family_wave<0> launches below.
     static const bool use_v2 = [] { const char* e = getenv("FGX_V2"); return !(e && e[0] == '0'); }();
     if (!duplex && !codec && !o.trim && use_v2) {
+      // Launch chain: k_simplex_seg<4> / <2> (4 / 2 families per wavefront, while the mean family fits a quarter / half of the
+      // wave's LDS) → k_simplex_wave2 over the growing slices.  A family that does not fit a launch moves to the next one.
+      static const bool use_seg = [] { const char* e = getenv("FGX_SEG"); return !(e && e[0] == '0'); }();
+      uint32_t seg_bytes = 11776;   // 4 wavefronts x 11776 B + the static tables = 3 workgroups per CU
+      if (const char* e = getenv("FGX_SEG_BYTES")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 4096 && v <= 32768) seg_bytes = v & ~63u; }
       static bool v2_attr_set = false;
-      if (!v2_attr_set) { (void)hipFuncSetAttribute((const void*)k_simplex_wave2, hipFuncAttributeMaxDynamicSharedMemorySize, WAVES_PER_BLOCK * 22016); (void)hipGetLastError(); v2_attr_set = true; }
+      if (!v2_attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_simplex_wave2, hipFuncAttributeMaxDynamicSharedMemorySize, WAVES_PER_BLOCK * 22016);
+        (void)hipFuncSetAttribute((const void*)k_simplex_seg<2>, hipFuncAttributeMaxDynamicSharedMemorySize, WAVES_PER_BLOCK * 32768);
+        (void)hipFuncSetAttribute((const void*)k_simplex_seg<4>, hipFuncAttributeMaxDynamicSharedMemorySize, WAVES_PER_BLOCK * 32768);
+        (void)hipGetLastError();
+        v2_attr_set = true;
+      }
+      struct Stage { int fam_per_wave; uint32_t bytes; uint32_t wpb; };
+      std::vector<Stage> chain;
+      const double mean_span = (double)blob_len / (double)n_grp + 48.0;   // mean bytes of a family + alignment / read-ahead slack
+      if (use_seg && mean_span + (16 * 8 + 64) <= seg_bytes / 4) chain.push_back({4, seg_bytes, (uint32_t)WAVES_PER_BLOCK});
+      // (two families per wavefront measured slower than one at depth 8 — 14.9 vs 10.7 ms per 1 M families: the column phase costs
+      // the same per family and a CU holds 12 instead of 20 wavefronts; kept behind FGX_SEG2=1 for experiments)
+      static const bool use_seg2 = [] { const char* e = getenv("FGX_SEG2"); return e && e[0] == '1'; }();
+      if (use_seg && use_seg2 && mean_span + (32 * 8 + 64) <= seg_bytes / 2) chain.push_back({2, seg_bytes, (uint32_t)WAVES_PER_BLOCK});
+      for (int st = 0; st < 3; st++) if (st == 0 || stages[st] > stages[st - 1]) chain.push_back({1, stages[st], st == 0 ? (uint32_t)WAVES_PER_BLOCK : st == 1 ? 2u : 1u});
       d_retry_old.reserve((size_t)n_grp * 4);
       uint32_t* d_cnt_old = (uint32_t*)(misc + 32);
       uint32_t n_v2 = n_grp;
       const uint32_t* v2_list = nullptr;
       int v2_out = 0;
-      for (int st = 0; st < 3 && n_v2; st++) {
-        if (st > 0 && stages[st] <= stages[st - 1]) continue;
-        const bool last = st == 2;
+      for (size_t ci = 0; ci < chain.size() && n_v2; ci++) {
+        const Stage& S = chain[ci];
+        const bool last = ci + 1 == chain.size();
         hip_check(hipMemsetAsync(d_cnt, 0, 4, s), "memset");
         FastParams PS = P;
-        PS.group_list = v2_list; PS.lds_wave_bytes = stages[st];
+        PS.group_list = v2_list; PS.lds_wave_bytes = S.bytes;
         PS.retry = last ? nullptr : lists[v2_out]; PS.n_retry = d_cnt;
         PS.retry_old = d_retry_old.as<uint32_t>(); PS.n_retry_old = d_cnt_old;
-        const uint32_t wpb = st == 0 ? WAVES_PER_BLOCK : st == 1 ? 2u : 1u;
-        hipLaunchKernelGGL(k_simplex_wave2, dim3((n_v2 + wpb - 1) / wpb), dim3(64 * wpb), (size_t)wpb * stages[st], s, PS, n_v2);
-        hip_check(hipGetLastError(), "k_simplex_wave2 launch");
+        const uint32_t fpb = S.wpb * (uint32_t)S.fam_per_wave;      // families per workgroup
+        const dim3 grid((n_v2 + fpb - 1) / fpb), block(64 * S.wpb);
+        const size_t lds = (size_t)S.wpb * S.bytes;
+        if (S.fam_per_wave == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_simplex_seg<4>), grid, block, lds, s, PS, n_v2);
+        else if (S.fam_per_wave == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_simplex_seg<2>), grid, block, lds, s, PS, n_v2);
+        else hipLaunchKernelGGL(k_simplex_wave2, grid, block, lds, s, PS, n_v2);
+        hip_check(hipGetLastError(), "k_simplex launch");
         uint32_t n_next = 0;
         hip_check(hipMemcpyAsync(&n_next, d_cnt, 4, hipMemcpyDeviceToHost, s), "D2H");
         hip_check(hipStreamSynchronize(s), "sync");

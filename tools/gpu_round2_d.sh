@@ -1,0 +1,29 @@
+#!/bin/bash
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r02d; mkdir -p $OUT
+cd $R
+b() { local name=$1; shift; local envs=$1; shift
+  env $envs timeout 300 python bench.py "$@" --steps 5 --warmup 1 --no-cpu-baseline > $OUT/$name.log 2>&1
+  grep '^{' $OUT/$name.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$name', 'k_family_ms=%.2f k_emit_ms=%.2f ms_step=%.2f reads/s=%.3g def=%s'%(d['roofline']['kernel_ms'], d['roofline']['k_emit_ms'], d['ms_per_step'], d['value'], d['config']['deferred_families']))" || tail -5 $OUT/$name.log
+}
+b d8_seg1 FGX_SEG=1 --families 1000000
+b d8_seg0 FGX_SEG=0 --families 1000000
+cd /tmp; export TMPDIR=/tmp
+pm() { local tag=$1; shift
+  i=0
+  for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY"; do
+    i=$((i+1))
+    timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$tag -o pmc$i -- python $R/bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline > $OUT/${tag}_pmc$i.log 2>&1
+  done
+  python $R/tools/pmc_parse.py $OUT/$tag > $OUT/pmc_$tag.json
+  python - $OUT/pmc_$tag.json <<'PY'
+import json,sys
+d=json.load(open(sys.argv[1]))
+for k,v in d.items():
+    if k.startswith('k_simplex') or k.startswith('k_emit') or k.startswith('k_family'):
+        print(k, {c: round(x/1e6,1) for c,x in v.items()})
+PY
+  rm -rf $OUT/$tag
+}
+pm d8 --families 1000000
+pm d3 --families 2000000 --depth 3

@@ -8,7 +8,7 @@ acc = defaultdict(lambda: defaultdict(list))
 for f in sorted(glob.glob(os.path.join(d, "*_counter_collection.csv"))):
     per = defaultdict(lambda: defaultdict(float))   # (dispatch id, kernel) -> counter -> sum over dimensions
     for row in csv.DictReader(open(f)):
-        m = re.search(r"(k_[a-z_]+)", row["Kernel_Name"]); k = m.group(1) if m else row["Kernel_Name"][:40]
+        m = re.search(r"(k_[a-z_0-9]+)", row["Kernel_Name"]); k = m.group(1) if m else row["Kernel_Name"][:40]
         per[(row["Dispatch_Id"], k)][row["Counter_Name"]] += float(row["Counter_Value"])
     for (_, k), cs in per.items():
         for c, v in cs.items():
