@@ -7,11 +7,17 @@ torch.distributed.run (backend nccl = RCCL).  One "step" = one pass of the conse
 `simulate grouped-reads`-shaped families.  Rank 0 prints ONE JSON line.
 
 Workload at N=1: BASELINE.json configs[1] — simplex, 5 M families, depth 8 (pairs), 150 bp paired.
-Weak scaling: every rank processes its own contiguous shard of the family stream (families are
-independent → no data-path collective); the only collective is the gather of the per-rank
-consensus payload sizes + stats (what a writer needs to concatenate shards in input order).
+
+N>1 (families are independent → no collective on the data path):
+  --scaling weak    (default) every rank processes its own 5 M-family shard of the family stream
+  --scaling strong  ONE 5 M-family stream is cut into contiguous shards of equal record bytes
+                    (`distributed.balanced_shards` over the per-family weights), one per rank
+  --reassemble root (default for N>1) every step also ships the shard payloads to rank 0 in rank (= input)
+                    order over RCCL point-to-point — the north star's reassembly step — INSIDE the timed
+                    region; `value_without_reassembly` comes from a second timed loop without it.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -20,72 +26,76 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+F64_LANE_OPS_PER_S = 64 * 1024 * 2.4e9 / 4   # one f64 add per lane per 4 cycles, 1024 SIMDs at 2.4 GHz = 39.3 T/s
+F64_OPS_PER_OBSERVATION = 8     # two Kahan chains (the base seen, any other base) x 4 dependent add/sub
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(n_families, family_size, read_length, threads, duplex=False, codec=False):
-    """Bounded sample of the same workload through the ORACLE (C++ restatement of the reference CPU
-    caller; `--threads`-style batches of 50 MI groups, one caller object per batch) on this box's
-    host cores.  A reported baseline, not the optimisation target."""
+    """Bounded sample of the same workload through the ORACLE (C++ restatement of the reference CPU caller;
+    `--threads`-style batches of MI groups, one caller object per batch, Phred tables cached process-wide like the
+    reference's OnceLock caches) on this box's host cores: once on ONE thread, once on all of them.
+    A reported baseline (kind "port"), not the optimisation target, and not `fgumi` itself."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import fgx_opts
     import orc
     from fgumi_amd import simulate_grouped_reads
     extra = dict(insert_mean=350, insert_sd=60, codec=1) if codec else {}
-    g = simulate_grouped_reads(n_families, family_size=family_size, read_length=read_length, duplex=int(duplex), **extra)
     o = fgx_opts.defaults(min_reads=1, kind=2 if codec else 1 if duplex else 0)
     if codec:
         o.overlapping_consensus = 0
     if duplex:
         o.duplex_min_reads[0], o.duplex_min_reads[1], o.duplex_min_reads[2] = 1, 1, 1
-    best, res = None, None
-    for _ in range(3):
-        t0 = time.perf_counter()
-        res = orc.process(o, g.blob, g.rec_off, g.rec_len, g.grp_first, batch_groups=1000 if codec else 100 if duplex else 50, threads=threads)
-        dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
-    return dict(value=g.n_rec / best, unit="raw reads/s", cores=threads, kind="port",
-                sample=f"{n_families} families x {family_size} pairs x {read_length}bp{' (--duplex)' if duplex else ' (CODEC pairs, insert N(350,60))' if codec else ''}, compute-only (records in RAM → "
-                       f"ConsensusOutput bytes), batches of {1000 if codec else 100 if duplex else 50} MI groups over {threads} threads, best of 3",
-                consensus_reads_per_s=res["count"] / best)
+    bg = 1000 if codec else 100 if duplex else 50
+
+    def run(nf, T, reps):
+        g = simulate_grouped_reads(nf, family_size=family_size, read_length=read_length, duplex=int(duplex), **extra)
+        best, res = None, None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            res = orc.process(o, g.blob, g.rec_off, g.rec_len, g.grp_first, batch_groups=bg, threads=T)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        return g.n_rec / best, res["count"] / best, g.n_rec
+
+    n1 = max(1000, min(n_families, 40000))
+    v1, c1, r1 = run(n1, 1, 2)
+    vall, call, rall = run(n_families, threads, 3)
+    shape = f"{family_size} pairs x {read_length}bp" + (" (--duplex)" if duplex else " (CODEC pairs, insert N(350,60))" if codec else "")
+    return dict(value=vall, unit="raw reads/s", cores=threads, kind="port", cpu_model=cpu_model(),
+                value_1_thread=v1, speedup_all_over_1=vall / v1 if v1 else None,
+                consensus_reads_per_s=call, consensus_reads_per_s_1_thread=c1,
+                sample=f"T={threads}: {n_families} families x {shape} = {rall} reads, best of 3; T=1: {n1} families = {r1} reads, best of 2; "
+                       f"compute-only (records in RAM -> ConsensusOutput bytes), batches of {bg} MI groups pulled by the worker threads")
 
 
-def pmc_traffic(families, depth, read_length):
-    """HBM bytes of one k_family_wave launch from the committed rocprofv3 PMC passes of THIS workload (collected by
-    tools/profile_round.sh in separate --pmc runs, summarised by tools/pmc_parse.py): 2 x FETCH_SIZE (the gfx950
-    correction for wide coalesced reads, MI355X_MICROARCH.md "HBM") + WRITE_SIZE, both in KiB.  WRITE_SIZE tallies a
-    full request granule per partial-line store, so it over-states the kernel's many small descriptor stores; k_emit's
-    streaming stores calibrate it at 0.99 of the true byte count.  None when no profile matches the workload."""
+def pmc_profile(families, depth, read_length):
+    """Counters of ONE launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS workload (separate --pmc
+    runs by tools/profile_round.sh, summarised by tools/pmc_parse.py into profiles/*pmc_<N>M_families.json).  Returns
+    (counters, file name) or (None, None): these numbers are read from a committed file, not measured in this run."""
     if (depth, read_length) != (8, 150):
-        return None
-    import glob
+        return None, None
     tag = f"{families // 1000000}M" if families % 1000000 == 0 else str(families)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*pmc_{tag}_families.json")))
-    if not files:
-        return None
-    try:
-        k = json.load(open(files[-1]))["k_family_wave"]
-        return (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
-    except (KeyError, ValueError):
-        return None
-
-
-def pmc_valu_busy(families, depth, read_length, kernel_ms):
-    """Fraction of the launch during which the vector ALUs of a SIMD were issuing (SQ_ACTIVE_INST_VALU counts quad-cycles,
-    summed over the 1024 SIMDs of the chip at 2.4 GHz) — the bound that actually binds this kernel.  From the same committed
-    PMC passes as `traffic`; None when no profile matches the workload."""
-    if (depth, read_length) != (8, 150) or kernel_ms <= 0:
-        return None
-    import glob
-    tag = f"{families // 1000000}M" if families % 1000000 == 0 else str(families)
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*pmc_{tag}_families.json")))
-    if not files:
-        return None
-    try:
-        k = json.load(open(files[-1]))["k_family_wave"]
-        return min(1.0, k["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / 2.4e9 / (kernel_ms * 1e-3))
-    except (KeyError, ValueError):
-        return None
+    for f in reversed(files):
+        try:
+            d = json.load(open(f))
+        except ValueError:
+            continue
+        for k in ("k_simplex_wave2", "k_family_wave"):
+            if k in d:
+                return dict(d[k], kernel=k), os.path.relpath(f, ROOT)
+    return None, None
 
 
 def main():
@@ -96,16 +106,17 @@ def main():
     ap.add_argument("--caller", choices=["simplex", "duplex", "codec"], default="simplex",
                     help="simplex = BASELINE configs[1] (the headline metric); duplex = configs[2] shape (2M molecules, 6+6 pairs); "
                          "codec = configs[4] shape (1M molecules, 4 pairs of 2x300bp)")
-    ap.add_argument("--families", type=int, default=None)
+    ap.add_argument("--families", type=int, default=None, help="families per GPU (weak) or in total (strong)")
     ap.add_argument("--depth", type=int, default=None)
     ap.add_argument("--read-length", type=int, default=None)
     ap.add_argument("--depth-max", type=int, default=0,
                     help="simplex only: long-tail family sizes in [depth, depth-max] pairs, count ~ size^-1.5 (BASELINE configs[3] shape: --depth 2 --depth-max 50)")
     ap.add_argument("--cpu-sample-families", type=int, default=300000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--reassemble", choices=["none", "root"], default="none",
-                    help="root: every step also gathers the shard payloads to rank 0 in rank (= input) order over RCCL, inside the timed region "
-                         "(the north star's reassembly step; off by default: shard outputs are already in input order, see DESIGN.md 6)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--reassemble", choices=["auto", "none", "root"], default="auto",
+                    help="root: every step also gathers the shard payloads to rank 0 in rank (= input) order over RCCL, inside the timed region; "
+                         "auto = root when N > 1")
     args = ap.parse_args()
     duplex, codec = args.caller == "duplex", args.caller == "codec"
     if args.families is None:
@@ -124,11 +135,12 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl")
+    reassemble = args.reassemble if args.reassemble != "auto" else ("root" if world > 1 else "none")
 
     from fgumi_amd import (CodecConsensusCaller, CodecConsensusOptions, DuplexConsensusCaller, VanillaUmiConsensusCaller,
-                           VanillaUmiConsensusOptions)
+                           VanillaUmiConsensusOptions, simulated_family_bytes)
+    from fgumi_amd.distributed import balanced_shards, gather_payload_to_root, gather_sizes, max_over_ranks
 
-    fam = args.families
     sim_extra = dict(family_size_max=args.depth_max) if (args.depth_max and args.caller == "simplex") else {}
     if codec:
         caller = CodecConsensusCaller("", "A", CodecConsensusOptions(produce_per_base_tags=True, cell_tag="CB"), device=local_rank)
@@ -138,38 +150,57 @@ def main():
     else:
         caller = VanillaUmiConsensusCaller("", "A", VanillaUmiConsensusOptions(min_reads=1, min_consensus_base_quality=2, cell_tag="CB"),
                                            overlapping_consensus=True, device=local_rank)
-    # synthetic families generated straight into HBM; rank r owns molecules [r*fam, (r+1)*fam)
-    dg = caller.simulate_on_device(fam, family_size=args.depth, read_length=args.read_length, first_family=rank * fam, duplex=int(duplex), **sim_extra)
+    # synthetic families generated straight into HBM
+    if args.scaling == "strong" and world > 1:
+        # one stream of `families` molecules, cut where the running record bytes reach k/world of the total
+        w = simulated_family_bytes(args.families, family_size=args.depth, read_length=args.read_length, duplex=int(duplex), **sim_extra)
+        lo, hi = balanced_shards(w, world)[rank]
+        shard_bytes = int(w[lo:hi].sum())
+    else:
+        lo, hi = (rank * args.families, (rank + 1) * args.families) if args.scaling == "weak" else (0, args.families)
+        shard_bytes = None
+    fam = hi - lo
+    dg = caller.simulate_on_device(fam, family_size=args.depth, read_length=args.read_length, first_family=lo, duplex=int(duplex), **sim_extra)
+    if shard_bytes is None:
+        shard_bytes = int(dg.blob_len)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_loop(steps, with_gather):
+        k_family_ms = k_emit_ms = k_total_ms = 0.0
+        gathered = 0
+        out = None
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = caller.process_batch_device(dg)
+            k_family_ms += caller.last_timing["k_family"]
+            k_emit_ms += caller.last_timing["k_emit"]
+            k_total_ms += caller.last_timing["kernels"]
+            if with_gather:
+                whole = gather_payload_to_root(out.as_tensor(local_rank), root=0)
+                if whole is not None:
+                    gathered = int(whole.numel())
+                del whole
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0, "cuda")                            # MAX over ranks
+        return dt, out, k_family_ms, k_emit_ms, k_total_ms, gathered
+
     out = None
     for _ in range(args.warmup):
         out = caller.process_batch_device(dg)
-    barrier()
-    t0 = time.perf_counter()
-    k_family_ms = k_emit_ms = k_total_ms = 0.0
-    gathered_bytes = 0
-    for _ in range(args.steps):
-        out = caller.process_batch_device(dg)
-        k_family_ms += caller.last_timing["k_family"]
-        k_emit_ms += caller.last_timing["k_emit"]
-        k_total_ms += caller.last_timing["kernels"]
-        if args.reassemble == "root":
-            from fgumi_amd.distributed import gather_payload_to_root
-            whole = gather_payload_to_root(out.as_tensor(local_rank), root=0)
-            if whole is not None:
-                gathered_bytes = int(whole.numel())
-            del whole
-    barrier()
-    dt = time.perf_counter() - t0
-    from fgumi_amd.distributed import gather_sizes, max_over_ranks
-    dt = max_over_ranks(dt, "cuda")                                                   # MAX over ranks
-    per_rank = gather_sizes([out.data_len, out.count, dg.n_rec, out.n_deferred], "cuda")   # shard payload sizes, rank (= input) order
-    total_bytes, total_cons, total_raw, total_def = [int(v) for v in per_rank.sum(0).tolist()]
+        if reassemble == "root":
+            del_me = gather_payload_to_root(out.as_tensor(local_rank), root=0)
+            del del_me
+    dt, out, k_family_ms, k_emit_ms, k_total_ms, gathered_bytes = timed_loop(args.steps, reassemble == "root")
+    dt_plain = None
+    if reassemble == "root":                                                              # the same K steps without the gather
+        dt_plain = timed_loop(args.steps, False)[0]
+    per_rank = gather_sizes([out.data_len, out.count, dg.n_rec, out.n_deferred, fam, shard_bytes], "cuda")   # rank (= input) order
+    total_bytes, total_cons, total_raw, total_def = [int(v) for v in per_rank[:, :4].sum(0).tolist()]
 
     if rank == 0:
         L = args.read_length
@@ -181,6 +212,17 @@ def main():
         alg_write = out.count * 6 * L * (2 if (duplex or codec) else 1)
         k_avg_s = k_family_ms / steps / 1e3
         achieved = (alg_read + alg_write) / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
+        plain = not (duplex or codec or args.depth_max)
+        pmc, pmc_file = pmc_profile(fam, args.depth, L) if plain else (None, None)
+        # the arithmetic floor of the dominant kernel: every observation (read x position) costs two Kahan chains = 8 dependent
+        # f64 add/sub on the vector ALUs (full rate: one per lane per 4 cycles)
+        valu_floor_ms = dg.n_rec * L * F64_OPS_PER_OBSERVATION / F64_LANE_OPS_PER_S * 1e3
+        shape = (f"CODEC consensus, {args.depth} pairs of 2x{L}bp, insert N(350,60) (BASELINE configs[4] shape)" if codec else
+                 f"duplex consensus, {args.depth} pairs split over /A and /B, {L}bp paired (BASELINE configs[2] shape)" if duplex else
+                 f"simplex consensus, depth {args.depth}..{args.depth_max} pairs (long tail), {L}bp paired (BASELINE configs[3] shape)" if args.depth_max else
+                 f"simplex consensus, depth={args.depth} pairs, {L}bp paired (BASELINE configs[1] shape)")
+        sizing = (f"{args.families} families in total, cut into {world} shards of equal record bytes" if (args.scaling == "strong" and world > 1)
+                  else f"{args.families} families per GPU")
         line = {
             "metric": ("CODEC consensus throughput, input raw reads/s (4 pairs x 2x300bp)" if codec
                        else "duplex consensus throughput, input raw reads/s (depth 6+6 x 150bp)" if duplex
@@ -189,32 +231,46 @@ def main():
             "value": total_raw * steps / dt, "unit": "raw reads/s",
             "consensus_reads_per_s": total_cons * steps / dt,
             "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": dt / steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": (f"CODEC consensus, {fam} molecules per GPU, {args.depth} pairs of 2x{L}bp, insert N(350,60) (BASELINE configs[4] shape), " if codec else
-                                    f"duplex consensus, {fam} molecules per GPU, {args.depth} pairs split over /A and /B, {L}bp paired (BASELINE configs[2] shape), "
-                                    if duplex else f"simplex consensus, {fam} families per GPU, depth {args.depth}..{args.depth_max} pairs (long tail), {L}bp paired (BASELINE configs[3] shape), "
-                                    if args.depth_max else f"simplex consensus, {fam} families per GPU, depth={args.depth} pairs, {L}bp paired (BASELINE configs[1] shape), ")
-                                   + "device-resident: raw BAM records in HBM -> consensus BAM records in HBM",
-                       "min_reads": 1, "overlapping_consensus": True, "families_per_gpu": fam, "raw_reads_per_gpu": dg.n_rec,
-                       "deferred_families": total_def, "output_bytes": total_bytes, "reassemble": args.reassemble,
-                       "reassembled_bytes_on_rank0": gathered_bytes,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{shape}, {sizing}, device-resident: raw BAM records in HBM -> consensus BAM records in HBM",
+                       "min_reads": 1, "overlapping_consensus": True, "families_total": int(per_rank[:, 4].sum()),
+                       "families_per_rank": [int(v) for v in per_rank[:, 4].tolist()], "raw_reads_per_rank": [int(v) for v in per_rank[:, 2].tolist()],
+                       "input_bytes_per_rank": [int(v) for v in per_rank[:, 5].tolist()], "output_bytes_per_rank": [int(v) for v in per_rank[:, 0].tolist()],
+                       "deferred_families": total_def, "output_bytes": total_bytes,
+                       "reassemble": reassemble, "reassembled_bytes_on_rank0": gathered_bytes,
+                       "value_without_reassembly": (total_raw * steps / dt_plain) if dt_plain else None,
+                       "ms_per_step_without_reassembly": (dt_plain / steps * 1e3) if dt_plain else None,
                        "columns_needing_call_full_per_step": caller.last_timing.get("full_columns")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None if (duplex or codec or args.depth_max) else pmc_traffic(fam, args.depth, L), "kernel": "k_family", "kernel_ms": k_family_ms / steps, "k_emit_ms": k_emit_ms / steps,
+                         # HBM bytes of one launch: 2 x FETCH_SIZE (gfx950 correction for wide coalesced reads) + WRITE_SIZE, KiB → bytes,
+                         # from the committed PMC passes (`traffic_source`), NOT measured in this run
+                         "traffic": ((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0) if (pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc) else None,
+                         "traffic_source": pmc_file,
+                         "kernel": "k_family stage (k_simplex_seg / k_simplex_wave2 / k_family_wave + k_call_full)" if not (duplex or codec) else "k_family stage (k_family_wave + k_call_full)",
+                         "kernel_ms": k_family_ms / steps, "k_emit_ms": k_emit_ms / steps,
                          "device_ms_per_step": k_total_ms / steps, "algorithmic_bytes_per_launch": alg_read + alg_write,
                          "read_only_GBs": alg_read / k_avg_s / 1e9 if k_avg_s > 0 else 0.0,
-                         "valu_busy_frac": None if (duplex or codec or args.depth_max) else pmc_valu_busy(fam, args.depth, L, k_family_ms / steps)},
+                         # the bound that binds this kernel is vector-ALU issue, not HBM:
+                         "f64_ops_per_observation": F64_OPS_PER_OBSERVATION,
+                         "valu_floor_ms": valu_floor_ms,
+                         "frac_of_valu_floor": valu_floor_ms / (k_family_ms / steps) if k_family_ms > 0 else None,
+                         "valu_insts_per_family": (pmc["SQ_INSTS_VALU"] / fam) if (pmc and "SQ_INSTS_VALU" in pmc) else None,
+                         "salu_insts_per_family": (pmc["SQ_INSTS_SALU"] / fam) if (pmc and "SQ_INSTS_SALU" in pmc) else None,
+                         # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the chip's 1024 SIMDs at 2.4 GHz (committed PMC file / this run's time)
+                         "valu_busy_frac": (min(1.0, pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / 2.4e9 / k_avg_s)
+                                            if (pmc and "SQ_ACTIVE_INST_VALU" in pmc and k_avg_s > 0) else None),
+                         "pmc_kernel": pmc["kernel"] if pmc else None, "pmc_source": pmc_file},
         }
         if not args.no_cpu_baseline and world == 1 and not args.depth_max:
             line["cpu_baseline"] = cpu_baseline(min(fam, args.cpu_sample_families), args.depth, L, os.cpu_count() or 1, duplex, codec)
         print(json.dumps(line))
-    if rank == 0:   # profiling builds (-DFGX_PHASE_TIMING=1) expose per-phase cycle totals of k_family_wave
+    if rank == 0:   # profiling builds (-DFGX_PHASE_TIMING=1) expose per-phase cycle totals of the family kernels
         import ctypes
         from fgumi_amd import lib
         if hasattr(lib, "fgx_debug_phase_cycles"):
             ph = (ctypes.c_uint64 * 16)()
             lib.fgx_debug_phase_cycles(ph, 1)
-            tot = float(sum(ph)) or 1.0
+            tot = float(sum(ph[1:9])) or 1.0
             names = ["-", "stage", "parse", "overlap", "geometry", "gates", "columns", "umi", "descriptors"]
             print("phase share: " + "  ".join(f"{names[i]}={100.0 * ph[i] / tot:.1f}%" for i in range(1, 9)), file=sys.stderr)
             bn = ["raw->lds", "parse", "unpack", "overlap", "geometry", "gates", "columns(to umi)"]

@@ -66,7 +66,7 @@ class SimParams(C.Structure):
 
 # every symbol include/fgumi_amd.h declares
 EXPORTS = ["fgx_options_default", "fgx_create", "fgx_destroy", "fgx_last_error", "fgx_global_error", "fgx_process_batch",
-           "fgx_process_batch_device", "fgx_call_columns", "fgx_device_libm", "fgx_get_table", "fgx_sim_sizes",
+           "fgx_process_batch_device", "fgx_call_columns", "fgx_device_libm", "fgx_get_table", "fgx_sim_sizes", "fgx_sim_family_bytes", "fgx_libm_self_check", "fgx_record_boundaries",
            "fgx_sim_generate_host", "fgx_sim_generate_device", "fgx_group_records", "fgx_group_records_device", "fgx_filter_options_default",
            "fgx_filter_records", "fgx_filter_records_device", "fgx_filter_last_output_device"]
 
@@ -113,6 +113,12 @@ def load():
     L.fgx_get_table.restype = I
     L.fgx_sim_sizes.argtypes = [P(SimParams), P(U64), P(U64)]
     L.fgx_sim_sizes.restype = I
+    L.fgx_record_boundaries.argtypes = [VP, U64, U64, VP, VP, U64, P(U64)]
+    L.fgx_record_boundaries.restype = I
+    L.fgx_libm_self_check.argtypes = [C.c_char_p, U64]
+    L.fgx_libm_self_check.restype = I
+    L.fgx_sim_family_bytes.argtypes = [P(SimParams), VP]
+    L.fgx_sim_family_bytes.restype = I
     L.fgx_sim_generate_host.argtypes = [P(SimParams), VP, VP, VP, VP]
     L.fgx_sim_generate_host.restype = I
     L.fgx_sim_generate_device.argtypes = [VP, P(SimParams), VP, VP, VP, VP]

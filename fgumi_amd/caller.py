@@ -216,6 +216,20 @@ def simulate_grouped_reads(n_families, family_size=3, read_length=150, seed=42, 
     return GroupedReads(blob, rec_off, rec_len, grp_first)
 
 
+def simulated_family_bytes(n_families, family_size=3, read_length=150, seed=42, **kw) -> np.ndarray:
+    """Record bytes of each simulated family (uint64[n_families]) without generating the records: the weights a reader
+    cuts the family stream by when it shards a FIXED total over several GPUs (`distributed.balanced_shards`)."""
+    p = SimParams()
+    p.seed, p.n_families, p.read_length, p.family_size = seed, n_families, read_length, family_size
+    p.insert_mean, p.insert_sd, p.error_rate_ppm = 300, 50, 1000
+    for k, v in kw.items():
+        setattr(p, k, v)
+    out = np.zeros(n_families, dtype=np.uint64)
+    if lib.fgx_sim_family_bytes(C.byref(p), out.ctypes.data) != 0:
+        raise ValueError("fgx_sim_family_bytes failed")
+    return out
+
+
 class ConsensusCaller:
     """The `ConsensusCaller` trait (caller.rs:220-252)."""
 

@@ -6,6 +6,8 @@
 #include <string>
 #include <thread>
 #include "engine.h"
+#include <gnu/libc-version.h>
+#include <cmath>
 #include "fastpath.h"
 #include "host_common.h"
 #include "simgen.h"
@@ -99,6 +101,53 @@ void fgx_options_default(fgx_options* o) {
 const char* fgx_global_error(void) { return g_global_err.c_str(); }
 const char* fgx_last_error(const fgx_caller* c) { return c ? c->err.c_str() : g_global_err.c_str(); }
 
+// "Identical to the reference" means identical to a Rust build on glibc 2.35 (the FMA ifunc variants x86-64 selects): the
+// transcendentals of `call_full` are glibc's (glibc_libm.h).  An integration box with another libm would silently change what the
+// reference itself computes, so the port is compared with the process's own libm on a fixed sample before a caller is handed out.
+// Returns an empty string when they agree bit for bit.
+static std::string libm_self_check() {
+  static int verdict = 0;                   // 0 unknown, 1 agree, 2 differ
+  static std::string detail;
+  if (verdict == 0) {
+    uint64_t r = 0x9E3779B97F4A7C15ull;
+    auto next = [&]() { r ^= r << 13; r ^= r >> 7; r ^= r << 17; return (double)(r >> 11) * (1.0 / 9007199254740992.0); };
+    uint32_t bad = 0;
+    char first[160] = {0};
+    auto cmp = [&](const char* fn, double x, double mine, double theirs) {
+      if (fgx_asuint64(mine) != fgx_asuint64(theirs) && !(mine != mine && theirs != theirs)) {
+        if (!bad) snprintf(first, sizeof(first), "%s(%a): port %a, libm %a", fn, x, mine, theirs);
+        bad++;
+      }
+    };
+    for (int i = 0; i < 1024; i++) {
+      const double u = next();
+      const double xe = -745.0 + 760.0 * u;          // exp over the whole finite range of log-probabilities
+      const double xs = -40.0 * u;                   // the range call_full lives in
+      const double xl = std::ldexp(0.5 + u, (i % 80) - 60);
+      cmp("exp", xe, g_exp(xe), std::exp(xe));
+      cmp("exp", xs, g_exp(xs), std::exp(xs));
+      cmp("log", xl, g_log(xl), std::log(xl));
+      cmp("log1p", -u * 0.999, g_log1p(-u * 0.999), std::log1p(-u * 0.999));
+      cmp("log1p", xl, g_log1p(xl), std::log1p(xl));
+      cmp("expm1", xs, g_expm1(xs), std::expm1(xs));
+      cmp("expm1", -u * 0.7, g_expm1(-u * 0.7), std::expm1(-u * 0.7));
+    }
+    if (bad) {
+      detail = std::string("the bit-exact libm port (glibc 2.35, FMA variants) disagrees with this process's libm (glibc ") + gnu_get_libc_version() +
+               ") on " + std::to_string(bad) + " of 7168 sample points, first: " + first +
+               " — consensus qualities would no longer be those of a reference build on this box; set FGX_ALLOW_LIBM_MISMATCH=1 to run anyway";
+      verdict = 2;
+    } else verdict = 1;
+  }
+  return verdict == 2 ? detail : std::string();
+}
+
+int fgx_libm_self_check(char* msg, uint64_t msg_cap) {
+  const std::string m = libm_self_check();
+  if (msg && msg_cap) { snprintf(msg, (size_t)msg_cap, "%s", m.c_str()); }
+  return m.empty() ? 0 : 1;
+}
+
 fgx_caller* fgx_create(const fgx_options* opts) {
   if (!opts || opts->struct_size != sizeof(fgx_options)) { g_global_err = "fgx_create: bad options struct_size (ABI mismatch)"; return nullptr; }
   fgx_caller* c = nullptr;
@@ -109,6 +158,11 @@ fgx_caller* fgx_create(const fgx_options* opts) {
       g_global_err = std::string("fgx_create: no usable HIP device (") + (e != hipSuccess ? hipGetErrorString(e) : "device count 0") +
                      "); this engine has no CPU fallback";
       return nullptr;
+    }
+    {
+      const std::string mismatch = libm_self_check();
+      const char* allow = getenv("FGX_ALLOW_LIBM_MISMATCH");
+      if (!mismatch.empty() && !(allow && allow[0] == '1')) { g_global_err = "fgx_create: " + mismatch; return nullptr; }
     }
     c = new fgx_caller();
     c->opt = *opts;
@@ -630,6 +684,32 @@ int fgx_sim_sizes(const fgx_sim_params* p, uint64_t* blob_len, uint64_t* n_rec) 
   std::vector<uint32_t> rf;
   sim_layout(p, bo, rf, blob_len, n_rec);
   return *n_rec > 0xFFFFFFFFull ? 1 : 0;
+}
+
+int fgx_record_boundaries(const uint8_t* stream, uint64_t stream_len, uint64_t start, uint64_t* rec_off, uint32_t* rec_len, uint64_t cap,
+                          uint64_t* n_rec) {
+  if (!stream || !n_rec) return 1;
+  uint64_t p = start, n = 0;
+  while (p < stream_len) {
+    if (stream_len - p < 4) { *n_rec = n; return 1; }
+    const uint32_t ln = (uint32_t)stream[p] | ((uint32_t)stream[p + 1] << 8) | ((uint32_t)stream[p + 2] << 16) | ((uint32_t)stream[p + 3] << 24);
+    if (ln > stream_len - p - 4) { *n_rec = n; return 1; }
+    if (n < cap) { rec_off[n] = p + 4; rec_len[n] = ln; }
+    n++;
+    p += 4ull + ln;
+  }
+  *n_rec = n;
+  return 0;
+}
+
+int fgx_sim_family_bytes(const fgx_sim_params* p, uint64_t* bytes_per_family) {
+  if (!p || !bytes_per_family) return 1;
+  std::vector<uint64_t> bo;
+  std::vector<uint32_t> rf;
+  uint64_t bl, nr;
+  sim_layout(p, bo, rf, &bl, &nr);
+  for (uint32_t f = 0; f < p->n_families; f++) bytes_per_family[f] = (f + 1 < p->n_families ? bo[f + 1] : bl) - bo[f];
+  return 0;
 }
 
 int fgx_sim_generate_host(const fgx_sim_params* p, uint8_t* blob, uint64_t* rec_off, uint32_t* rec_len, uint32_t* grp_first) {

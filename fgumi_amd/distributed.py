@@ -19,18 +19,20 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
 
 def balanced_shards(weights: Sequence[int], world: int) -> List[Tuple[int, int]]:
     """Contiguous shards of a weighted family stream (weight = record bytes or reads×length) with roughly
-    equal total weight: long-tail family sizes make equal-count shards unbalanced."""
-    total = sum(weights)
-    bounds, acc, k = [0], 0, 1
-    for i, w in enumerate(weights):
-        acc += w
-        while k < world and acc >= total * k / world:
-            bounds.append(i + 1)
-            k += 1
-    while len(bounds) < world:
-        bounds.append(len(weights))
-    bounds.append(len(weights))
-    return [(bounds[i], max(bounds[i], bounds[i + 1])) for i in range(world)]
+    equal total weight: long-tail family sizes make equal-count shards unbalanced.
+    Shard k ends after the first family at which the running weight reaches k/world of the total."""
+    import numpy as np
+    w = np.asarray(weights, dtype=np.float64)
+    n = int(w.shape[0])
+    if n == 0:
+        return [(0, 0)] * world
+    acc = np.cumsum(w)
+    total = float(acc[-1])
+    cuts = [0]
+    for k in range(1, world):
+        cuts.append(max(cuts[-1], min(n, int(np.searchsorted(acc, total * k / world, side="left")) + 1)))
+    cuts.append(n)
+    return [(cuts[i], max(cuts[i], cuts[i + 1])) for i in range(world)]
 
 
 def gather_sizes(values: Sequence[int], device) -> torch.Tensor:

@@ -117,6 +117,11 @@ void fgx_options_default(fgx_options* o);
  * no HIP device is usable — there is no CPU fallback. */
 fgx_caller* fgx_create(const fgx_options* opts);
 void fgx_destroy(fgx_caller* c);
+/* The check fgx_create runs first: the engine's bit-exact libm port (glibc 2.35 exp / log / log1p / expm1, what a reference
+ * build links on this image — phred.rs:158-187 through Rust std) against THIS process's libm on 7168 fixed points.
+ * 0 = identical; 1 = they differ, `msg` names the glibc version and the first differing point, and fgx_create refuses to
+ * hand out a caller unless FGX_ALLOW_LIBM_MISMATCH=1 (results would no longer equal a reference build on this box). */
+int fgx_libm_self_check(char* msg, uint64_t msg_cap);
 const char* fgx_last_error(const fgx_caller* c);
 const char* fgx_global_error(void);
 
@@ -252,8 +257,17 @@ int fgx_filter_records_device(fgx_caller* c, const fgx_filter_options* f, void* 
  * without leaving the device: the hand-over the reference does through a BAM file or a pipe). */
 int fgx_filter_last_output_device(fgx_caller* c, const fgx_filter_options* f, fgx_filter_output* out);
 
+/* FindBoundaries (src/lib/unified_pipeline/bam.rs): walks the `block_size` chain of an uncompressed BAM record stream from
+ * byte `start`; fills rec_off (BODY offsets, past the 4-byte prefix) and rec_len for up to `cap` records and sets *n_rec to
+ * the number of records in the stream (call with cap = 0 to count).  Returns 0, or 1 when the stream ends inside a record. */
+int fgx_record_boundaries(const uint8_t* stream, uint64_t stream_len, uint64_t start, uint64_t* rec_off, uint32_t* rec_len,
+                          uint64_t cap, uint64_t* n_rec);
+
 /* Sizes for a parameter set: total blob bytes (records WITH block_size prefixes) and record count. */
 int fgx_sim_sizes(const fgx_sim_params* p, uint64_t* blob_len, uint64_t* n_rec);
+/* Record bytes of each of the p->n_families simulated families (what a reader would weigh a family by when it cuts the
+ * family stream into shards of equal work: a family's bytes are proportional to reads x length). */
+int fgx_sim_family_bytes(const fgx_sim_params* p, uint64_t* bytes_per_family);
 /* Host generation into caller-provided arrays (blob_len bytes; n_rec offsets/lengths; n_families+1 firsts). */
 int fgx_sim_generate_host(const fgx_sim_params* p, uint8_t* blob, uint64_t* rec_off, uint32_t* rec_len,
                           uint32_t* grp_first);

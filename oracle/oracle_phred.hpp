@@ -16,6 +16,7 @@
 #pragma once
 #include <cfloat>
 #include <cmath>
+#include <mutex>
 #include <cstdint>
 #include <cstring>
 #include <limits>
@@ -242,16 +243,29 @@ inline int unique_max_index(const double* ll) {
   return tied == 1 ? max_index : -1;
 }
 
+// Process-wide table caches, one slot per Phred value, built once on first use — the reference keeps both table
+// sets in `OnceLock` caches of 256 slots (`adjusted_tables`, base_builder.rs:384-387; `unanimous_gap_tables`, :756-773):
+// a caller object per batch of 50 MI groups must not pay for the 64-step bisections again.
+template <class T>
+inline const T& cached_tables(uint8_t key) {
+  static std::once_flag once[256];
+  static T* slot[256];
+  std::call_once(once[key], [key] { slot[key] = new T(key); });
+  return *slot[key];
+}
+inline const AdjustedTables& adjusted_tables(uint8_t post) { return cached_tables<AdjustedTables>(post); }
+inline const GapTables& unanimous_gap_tables(uint8_t pre) { return cached_tables<GapTables>(pre); }
+
 struct ConsensusBaseBuilder {
   double likelihoods[4];
   double compensations[4];
   uint32_t observations[4];
   TieRule tie_rule = TieRule::FgbioCompat;
-  AdjustedTables adj;
-  GapTables gap;
+  const AdjustedTables& adj;
+  const GapTables& gap;
   double ln_error_pre_umi;
 
-  ConsensusBaseBuilder(uint8_t pre, uint8_t post) : adj(post), gap(pre) {
+  ConsensusBaseBuilder(uint8_t pre, uint8_t post) : adj(adjusted_tables(post)), gap(unanimous_gap_tables(pre)) {
     ln_error_pre_umi = phred_to_ln_error_prob(pre);
     reset();
   }

@@ -84,6 +84,13 @@ def test_glibc_port_matches_box_libm(op, fn, lo, hi):
     assert np.array_equal(y.view(np.uint64), ref.view(np.uint64))
 
 
+def test_libm_self_check_of_fgx_create_agrees_on_this_box():
+    # what fgx_create runs before handing out a caller: port vs the process's own libm (this image: glibc 2.35)
+    msg = C.create_string_buffer(512)
+    rc = lib.fgx_libm_self_check(msg, 512)
+    assert rc == 0 and msg.value == b"", msg.value
+
+
 @pytest.mark.parametrize("pre,post", [(45, 40), (90, 90), (93, 93), (2, 2), (20, 10), (70, 5), (0, 0), (45, 255)])
 def test_host_table_builders_match_oracle_bitwise(pre, post):
     b = orc.Builder(pre, post)

@@ -76,3 +76,47 @@ def test_shard_helpers():
     assert sh[0][0] == 0 and sh[-1][1] == len(w) and all(a[1] == b[0] for a, b in zip(sh, sh[1:]))
     tot = [sum(w[a:b]) for a, b in sh]
     assert max(tot) <= 1.5 * sum(w) / 4 + 50
+
+
+# ---- strong scaling: ONE long-tail family stream cut into shards of equal record bytes ------------------------------
+F_TOTAL = 400
+LONG_TAIL = dict(family_size=1, family_size_max=20)
+
+
+def _strong_worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import fgx_opts
+    import orc
+    from fgumi_amd import simulate_grouped_reads, simulated_family_bytes
+    from fgumi_amd.distributed import balanced_shards, gather_payload_to_root, gather_sizes
+    w = simulated_family_bytes(F_TOTAL, **LONG_TAIL)                       # every rank derives the same cut points
+    lo, hi = balanced_shards(w, world)[rank]
+    g = simulate_grouped_reads(hi - lo, first_family=lo, **LONG_TAIL)      # this rank's contiguous shard of the one stream
+    assert int(w[lo:hi].sum()) == len(g.blob)
+    res = orc.process(fgx_opts.defaults(min_reads=1), g.blob, g.rec_off, g.rec_len, g.grp_first)
+    local = torch.frombuffer(bytearray(res["data"]) or bytearray(1), dtype=torch.uint8)[:len(res["data"])]
+    sizes = gather_sizes([local.numel(), res["count"], g.n_rec, hi - lo, len(g.blob)], "cpu")
+    payload = gather_payload_to_root(local, root=0)
+    if rank == 0:
+        np.save(os.path.join(outdir, "payload.npy"), payload.numpy())
+        np.save(os.path.join(outdir, "sizes.npy"), sizes.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_strong_scaling_weighted_shards_reassemble_to_the_whole_stream(tmp_path):
+    world = 2
+    mp.spawn(_strong_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    import fgx_opts
+    import orc
+    from fgumi_amd import simulate_grouped_reads
+    g = simulate_grouped_reads(F_TOTAL, **LONG_TAIL)
+    want = orc.process(fgx_opts.defaults(min_reads=1), g.blob, g.rec_off, g.rec_len, g.grp_first)
+    payload = np.load(tmp_path / "payload.npy").tobytes()
+    sizes = np.load(tmp_path / "sizes.npy")
+    assert payload == want["data"]
+    assert sizes[:, 3].sum() == F_TOTAL and sizes[:, 2].sum() == g.n_rec and sizes[:, 4].sum() == len(g.blob)
+    # equal work, not equal family counts: the byte split is within one (largest) family of even
+    assert abs(int(sizes[0, 4]) - int(sizes[1, 4])) <= 2 * 40 * 340
+    assert sizes[0, 3] != sizes[1, 3]
