@@ -10,3 +10,4 @@ from .caller import (ConsensusCaller, VanillaUmiConsensusCaller, DuplexConsensus
                      ConsensusCallingStats, RejectionReason, GroupedReads, DeviceGroupedReads, DeviceOutput,
                      simulate_grouped_reads, simulated_family_bytes, split_records)
 from .filter import ConsensusFilter, FilterConfig, FilterThresholds, FilterResult, DeviceFilterResult, record_offsets  # noqa: F401,E402
+from . import bgzf  # noqa: F401,E402

@@ -3090,6 +3090,7 @@ __global__ __launch_bounds__(256) void k_emit_codec_fast(CodecEmitParams P) {
 
 #include "simplex_wave2.inc"
 #include "simplex_seg.inc"
+#include "simplex_blk.inc"
 
 // Upper bound on the consensus columns a batch can produce: a family yields at most three ends, each no
 // longer than its longest read, and l_seq <= (block_size - 33) * 2 / 3.
@@ -3242,6 +3243,7 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
         (void)hipFuncSetAttribute((const void*)k_simplex_wave2, hipFuncAttributeMaxDynamicSharedMemorySize, WAVES_PER_BLOCK * 22016);
         (void)hipFuncSetAttribute((const void*)k_simplex_seg<2>, hipFuncAttributeMaxDynamicSharedMemorySize, WAVES_PER_BLOCK * 32768);
         (void)hipFuncSetAttribute((const void*)k_simplex_seg<4>, hipFuncAttributeMaxDynamicSharedMemorySize, WAVES_PER_BLOCK * 32768);
+        (void)hipFuncSetAttribute((const void*)k_simplex_blk, hipFuncAttributeMaxDynamicSharedMemorySize, WAVES_PER_BLOCK * 16384);
         (void)hipGetLastError();
         v2_attr_set = true;
       }
@@ -3253,6 +3255,14 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
       // the same per family and a CU holds 12 instead of 20 wavefronts; kept behind FGX_SEG2=1 for experiments)
       static const bool use_seg2 = [] { const char* e = getenv("FGX_SEG2"); return e && e[0] == '1'; }();
       if (use_seg && use_seg2 && mean_span + (32 * 8 + 64) <= seg_bytes / 2) chain.push_back({2, seg_bytes, (uint32_t)WAVES_PER_BLOCK});
+      // k_simplex_blk: four families per workgroup, their record phases on one wavefront (families of at most 16 records)
+      // (measured slower than k_simplex_wave2 — 11.9 vs 10.2 ms per 1 M depth-8 families, profiles/r02c_pmc_1M_blk.json: 20 % fewer
+      // vector and 43 % fewer scalar instructions, but three wavefronts of four wait at the barrier while one runs the record
+      // phases, 70 % of the wave-cycles; opt-in with FGX_BLK=1)
+      static const bool use_blk = [] { const char* e = getenv("FGX_BLK"); return e && e[0] == '1'; }();
+      uint32_t blk_bytes = 5632;
+      if (const char* e = getenv("FGX_BLK_BYTES")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 2048 && v <= 16384) blk_bytes = v & ~15u; }
+      if (use_blk && mean_span <= 2.0 * blk_bytes) chain.push_back({-4, blk_bytes, (uint32_t)WAVES_PER_BLOCK});
       for (int st = 0; st < 3; st++) if (st == 0 || stages[st] > stages[st - 1]) chain.push_back({1, stages[st], st == 0 ? (uint32_t)WAVES_PER_BLOCK : st == 1 ? 2u : 1u});
       d_retry_old.reserve((size_t)n_grp * 4);
       uint32_t* d_cnt_old = (uint32_t*)(misc + 32);
@@ -3267,10 +3277,11 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
         PS.group_list = v2_list; PS.lds_wave_bytes = S.bytes;
         PS.retry = last ? nullptr : lists[v2_out]; PS.n_retry = d_cnt;
         PS.retry_old = d_retry_old.as<uint32_t>(); PS.n_retry_old = d_cnt_old;
-        const uint32_t fpb = S.wpb * (uint32_t)S.fam_per_wave;      // families per workgroup
+        const uint32_t fpb = S.fam_per_wave < 0 ? (uint32_t)(-S.fam_per_wave) : S.wpb * (uint32_t)S.fam_per_wave;      // families per workgroup
         const dim3 grid((n_v2 + fpb - 1) / fpb), block(64 * S.wpb);
         const size_t lds = (size_t)S.wpb * S.bytes;
-        if (S.fam_per_wave == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_simplex_seg<4>), grid, block, lds, s, PS, n_v2);
+        if (S.fam_per_wave == -4) hipLaunchKernelGGL(k_simplex_blk, grid, block, lds, s, PS, n_v2);
+        else if (S.fam_per_wave == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_simplex_seg<4>), grid, block, lds, s, PS, n_v2);
         else if (S.fam_per_wave == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_simplex_seg<2>), grid, block, lds, s, PS, n_v2);
         else hipLaunchKernelGGL(k_simplex_wave2, grid, block, lds, s, PS, n_v2);
         hip_check(hipGetLastError(), "k_simplex launch");
