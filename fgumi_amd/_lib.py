@@ -67,6 +67,7 @@ class SimParams(C.Structure):
 # every symbol include/fgumi_amd.h declares
 EXPORTS = ["fgx_options_default", "fgx_create", "fgx_destroy", "fgx_last_error", "fgx_global_error", "fgx_process_batch",
            "fgx_process_batch_device", "fgx_call_columns", "fgx_device_libm", "fgx_get_table", "fgx_sim_sizes", "fgx_sim_family_bytes", "fgx_libm_self_check", "fgx_record_boundaries",
+           "fgx_bgzf_inflate", "fgx_bgzf_deflate", "fgx_bgzf_free", "fgx_bgzf_last_error",
            "fgx_sim_generate_host", "fgx_sim_generate_device", "fgx_group_records", "fgx_group_records_device", "fgx_filter_options_default",
            "fgx_filter_records", "fgx_filter_records_device", "fgx_filter_last_output_device"]
 
@@ -113,6 +114,14 @@ def load():
     L.fgx_get_table.restype = I
     L.fgx_sim_sizes.argtypes = [P(SimParams), P(U64), P(U64)]
     L.fgx_sim_sizes.restype = I
+    L.fgx_bgzf_inflate.argtypes = [VP, U64, U32, P(VP), P(U64)]
+    L.fgx_bgzf_inflate.restype = I
+    L.fgx_bgzf_deflate.argtypes = [VP, U64, I, U32, I, P(VP), P(U64)]
+    L.fgx_bgzf_deflate.restype = I
+    L.fgx_bgzf_free.argtypes = [VP]
+    L.fgx_bgzf_free.restype = None
+    L.fgx_bgzf_last_error.argtypes = []
+    L.fgx_bgzf_last_error.restype = C.c_char_p
     L.fgx_record_boundaries.argtypes = [VP, U64, U64, VP, VP, U64, P(U64)]
     L.fgx_record_boundaries.restype = I
     L.fgx_libm_self_check.argtypes = [C.c_char_p, U64]

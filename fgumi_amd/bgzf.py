@@ -46,6 +46,66 @@ def _pool(threads: Optional[int]) -> ThreadPoolExecutor:
     return ThreadPoolExecutor(max_workers=max(1, threads or (os.cpu_count() or 1)))
 
 
+class _NativeBuffer:
+    """A malloc'ed result of the library's BGZF entries, exposed as a uint8 numpy view and released with the view."""
+
+    def __init__(self, L, ptr, n):
+        self._L, self._ptr, self.n = L, ptr, n
+
+    def array(self) -> np.ndarray:
+        import ctypes as C
+        if self.n == 0:
+            return np.zeros(0, dtype=np.uint8)
+        buf = (C.c_uint8 * self.n).from_address(self._ptr.value)
+        buf._owner = self                      # the view keeps the allocation alive (numpy holds `buf`, `buf` holds this object)
+        a = np.frombuffer(buf, dtype=np.uint8)
+        a.flags.writeable = False
+        return a
+
+    def __del__(self):
+        try:
+            self._L.fgx_bgzf_free(self._ptr)
+        except Exception:
+            pass
+
+
+def _native():
+    try:
+        from ._lib import load
+        L = load()
+        return L if hasattr(L, "fgx_bgzf_inflate") else None
+    except (ImportError, OSError, RuntimeError):
+        return None
+
+
+def native_inflate(raw, threads: Optional[int] = None):
+    """Whole BGZF file image → uncompressed bytes through the library's block-parallel zlib inflate (CRC32 / ISIZE checked).
+    Returns (uint8 array, owner) — keep `owner` alive as long as the array is used — or None when the library is absent."""
+    L = _native()
+    if L is None:
+        return None
+    import ctypes as C
+    buf = np.frombuffer(raw, dtype=np.uint8)
+    out, n = C.c_void_p(), C.c_uint64()
+    if L.fgx_bgzf_inflate(buf.ctypes.data, buf.size, threads or 0, C.byref(out), C.byref(n)) != 0:
+        raise ValueError(L.fgx_bgzf_last_error().decode())
+    own = _NativeBuffer(L, out, n.value)
+    return own.array(), own
+
+
+def native_deflate(stream, level: int = 1, threads: Optional[int] = None, with_eof: bool = False):
+    L = _native()
+    if L is None:
+        return None
+    import ctypes as C
+    buf = np.frombuffer(stream, dtype=np.uint8)
+    out, n = C.c_void_p(), C.c_uint64()
+    if L.fgx_bgzf_deflate(buf.ctypes.data if buf.size else None, buf.size, level, threads or 0, 1 if with_eof else 0, C.byref(out), C.byref(n)) != 0:
+        raise ValueError(L.fgx_bgzf_last_error().decode())
+    own = _NativeBuffer(L, out, n.value)
+    return own.array(), own
+
+
 def bgzf_compress(stream, level: int = 1, threads: Optional[int] = None) -> List[bytes]:
     """Cuts `stream` (bytes-like) into BGZF blocks; returns them in order (EOF marker not included)."""
     mv = memoryview(stream)
@@ -88,6 +148,14 @@ def write_bam(path: str, header_text: str, refs: Sequence[Tuple[str, int]], reco
     """Writes header + `records` (a record stream with block_size prefixes) as a BGZF BAM.  The header gets its own blocks,
     the record stream is cut every 0xff00 bytes (records may straddle blocks, as in any BAM).  Returns the file size."""
     hdr_blocks = bgzf_compress(bam_header_bytes(header_text, refs), level, threads)
+    nat = native_deflate(records, level, threads, with_eof=True)
+    if nat is not None:                       # the library's block-parallel deflate (same framing, checked by tests/test_bgzf.py)
+        size = 0
+        with open(path, "wb") as f:
+            for b in hdr_blocks:
+                f.write(b); size += len(b)
+            f.write(memoryview(nat[0])); size += int(nat[0].size)
+        return size
     rec_blocks = bgzf_compress(records, level, threads)
     size = 0
     with open(path, "wb") as f:
@@ -175,7 +243,8 @@ def read_bam(path: str, threads: Optional[int] = None):
     addressed by (rec_off, rec_len) inside it (no copy of the record bytes)."""
     with open(path, "rb") as f:
         raw = f.read()
-    data = bgzf_decompress(raw, threads)
+    nat = native_inflate(raw, threads)
+    data = nat[0].tobytes() if nat is not None else bgzf_decompress(raw, threads)
     if data[:4] != b"BAM\x01":
         raise ValueError("not a BAM file")
     (l_text,) = struct.unpack_from("<i", data, 4)

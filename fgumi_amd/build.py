@@ -16,7 +16,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
 
 
 def sources():
-    extra = [f for f in ("fastpath.hip", "grouping.hip", "filter.hip", "duplex_host.cpp", "codec_host.cpp") if os.path.exists(os.path.join(CSRC, f))]
+    extra = [f for f in ("fastpath.hip", "grouping.hip", "filter.hip", "duplex_host.cpp", "codec_host.cpp", "bgzf_host.cpp") if os.path.exists(os.path.join(CSRC, f))]
     return [os.path.join(CSRC, f) for f in SOURCES + extra]
 
 
@@ -38,7 +38,7 @@ def build(force=False, verbose=True, out=OUT, extra_flags=()):
         cmd.append("-DFGX_HAVE_CODEC")
     for s in sources():
         cmd += ["-x", "hip", s]
-    cmd += ["-o", out]
+    cmd += ["-lz", "-o", out]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -1,0 +1,136 @@
+// bgzf_host.cpp — BGZF container work on the host cores: what sits between a BAM file and the
+// engine's uncompressed record streams.  Replaces, for this path, crates/fgumi-bgzf/src/{reader,writer}.rs (block framing,
+// inflate / deflate, CRC32) with a block-parallel implementation over zlib: BGZF blocks are independent gzip members of at
+// most 64 KiB, so T threads take blocks from a shared counter; output positions come from a prefix sum of the ISIZE trailers
+// (inflate) or of the compressed sizes (deflate).  Level 1 is the reference's default for consensus output.
+#include <zlib.h>
+#include <atomic>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+#include "../../include/fgumi_amd.h"
+
+namespace {
+constexpr uint32_t BGZF_PAYLOAD = 0xFF00;     // uncompressed bytes per block (htslib / noodles / fgumi-bgzf)
+struct Block { uint64_t in_off; uint32_t in_size; uint32_t isize; uint64_t out_off; };
+
+thread_local std::string t_err;
+
+unsigned pick_threads(uint32_t threads, size_t n_blocks) {
+  unsigned T = threads ? threads : std::thread::hardware_concurrency();
+  if (T == 0) T = 1;
+  if (T > n_blocks) T = (unsigned)(n_blocks ? n_blocks : 1);
+  return T;
+}
+template <class F> void run_pool(unsigned T, size_t n, F fn) {
+  std::atomic<size_t> next(0);
+  auto worker = [&]() { for (;;) { size_t i = next.fetch_add(16); if (i >= n) return; size_t e = i + 16 < n ? i + 16 : n; for (; i < e; i++) fn(i); } };
+  if (T <= 1) { worker(); return; }
+  std::vector<std::thread> ts;
+  for (unsigned t = 0; t < T; t++) ts.emplace_back(worker);
+  for (auto& t : ts) t.join();
+}
+}  // namespace
+
+extern "C" {
+
+const char* fgx_bgzf_last_error(void) { return t_err.c_str(); }
+void fgx_bgzf_free(uint8_t* p) { free(p); }
+
+int fgx_bgzf_inflate(const uint8_t* raw, uint64_t raw_len, uint32_t threads, uint8_t** out, uint64_t* out_len) {
+  if (!raw || !out || !out_len) { t_err = "fgx_bgzf_inflate: null argument"; return 1; }
+  std::vector<Block> blocks;
+  uint64_t p = 0, total = 0;
+  while (p < raw_len) {                        // BSIZE chain
+    if (raw_len - p < 26 || raw[p] != 0x1F || raw[p + 1] != 0x8B || raw[p + 2] != 8 || !(raw[p + 3] & 4)) { t_err = "not a BGZF block at offset " + std::to_string(p); return 1; }
+    const uint32_t xlen = raw[p + 10] | (raw[p + 11] << 8);
+    uint64_t q = p + 12, end = p + 12 + xlen;
+    uint32_t bsize = 0;
+    while (q + 4 <= end && end <= raw_len) {
+      const uint32_t slen = raw[q + 2] | (raw[q + 3] << 8);
+      if (raw[q] == 'B' && raw[q + 1] == 'C' && slen == 2) bsize = (uint32_t)(raw[q + 4] | (raw[q + 5] << 8)) + 1;
+      q += 4 + slen;
+    }
+    if (bsize < 12 + xlen + 8 || p + bsize > raw_len) { t_err = "BGZF block at offset " + std::to_string(p) + " has no BC subfield or is truncated"; return 1; }
+    uint32_t isize;
+    memcpy(&isize, raw + p + bsize - 4, 4);
+    if (isize > 0x10000) { t_err = "BGZF block at offset " + std::to_string(p) + " claims more than 64 KiB"; return 1; }
+    blocks.push_back(Block{p, bsize, isize, total});
+    total += isize;
+    p += bsize;
+  }
+  uint8_t* dst = (uint8_t*)malloc(total ? total : 1);
+  if (!dst) { t_err = "out of memory"; return 1; }
+  std::atomic<int> bad(0);
+  run_pool(pick_threads(threads, blocks.size()), blocks.size(), [&](size_t i) {
+    const Block& b = blocks[i];
+    if (b.isize == 0) return;
+    const uint32_t xlen = raw[b.in_off + 10] | (raw[b.in_off + 11] << 8);
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; return; }
+    zs.next_in = (Bytef*)(raw + b.in_off + 12 + xlen); zs.avail_in = b.in_size - 12 - xlen - 8;
+    zs.next_out = dst + b.out_off; zs.avail_out = b.isize;
+    const int rc = inflate(&zs, Z_FINISH);
+    inflateEnd(&zs);
+    uint32_t crc;
+    memcpy(&crc, raw + b.in_off + b.in_size - 8, 4);
+    if (rc != Z_STREAM_END || zs.total_out != b.isize || (uint32_t)crc32(0L, dst + b.out_off, b.isize) != crc) bad = 1;
+  });
+  if (bad) { free(dst); t_err = "BGZF block failed to inflate or its CRC32 / ISIZE does not match"; return 1; }
+  *out = dst; *out_len = total;
+  return 0;
+}
+
+int fgx_bgzf_deflate(const uint8_t* in, uint64_t len, int level, uint32_t threads, int with_eof, uint8_t** out, uint64_t* out_len) {
+  if ((!in && len) || !out || !out_len) { t_err = "fgx_bgzf_deflate: null argument"; return 1; }
+  const size_t nb = (size_t)((len + BGZF_PAYLOAD - 1) / BGZF_PAYLOAD);
+  constexpr size_t SLOT = 0x10000;             // a BGZF block never exceeds 64 KiB
+  uint8_t* tmp = (uint8_t*)malloc(nb ? nb * SLOT : 1);
+  std::vector<uint32_t> sizes(nb, 0);
+  if (!tmp) { t_err = "out of memory"; return 1; }
+  std::atomic<int> bad(0);
+  const unsigned T = pick_threads(threads, nb);
+  run_pool(T, nb, [&](size_t i) {
+    const uint8_t* src = in + i * (uint64_t)BGZF_PAYLOAD;
+    const uint32_t n = (uint32_t)((len - i * (uint64_t)BGZF_PAYLOAD) < BGZF_PAYLOAD ? (len - i * (uint64_t)BGZF_PAYLOAD) : BGZF_PAYLOAD);
+    uint8_t* blk = tmp + i * SLOT;
+    uint32_t csize = 0;
+    for (int lv = level; ; lv = 0) {          // an incompressible payload falls back to stored blocks (always fits)
+      z_stream zs;
+      memset(&zs, 0, sizeof(zs));
+      if (deflateInit2(&zs, lv, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { bad = 1; return; }
+      zs.next_in = (Bytef*)src; zs.avail_in = n;
+      zs.next_out = blk + 18; zs.avail_out = (uInt)(SLOT - 18 - 8);
+      const int rc = deflate(&zs, Z_FINISH);
+      csize = (uint32_t)zs.total_out;
+      deflateEnd(&zs);
+      if (rc == Z_STREAM_END) break;
+      if (lv == 0) { bad = 1; return; }
+    }
+    const uint32_t bsize = 18 + csize + 8 - 1;
+    const uint8_t hdr[18] = {0x1F, 0x8B, 8, 4, 0, 0, 0, 0, 0, 0xFF, 6, 0, 'B', 'C', 2, 0, (uint8_t)bsize, (uint8_t)(bsize >> 8)};
+    memcpy(blk, hdr, 18);
+    const uint32_t crc = (uint32_t)crc32(0L, src, n);
+    memcpy(blk + 18 + csize, &crc, 4);
+    memcpy(blk + 18 + csize + 4, &n, 4);
+    sizes[i] = bsize + 1;
+  });
+  if (bad) { free(tmp); t_err = "deflate failed"; return 1; }
+  std::vector<uint64_t> offs(nb + 1, 0);
+  for (size_t i = 0; i < nb; i++) offs[i + 1] = offs[i] + sizes[i];
+  static const uint8_t EOF_BLOCK[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const uint64_t total = offs[nb] + (with_eof ? 28 : 0);
+  uint8_t* dst = (uint8_t*)malloc(total ? total : 1);
+  if (!dst) { free(tmp); t_err = "out of memory"; return 1; }
+  run_pool(T, nb, [&](size_t i) { memcpy(dst + offs[i], tmp + i * SLOT, sizes[i]); });
+  if (with_eof) memcpy(dst + offs[nb], EOF_BLOCK, 28);
+  free(tmp);
+  *out = dst; *out_len = total;
+  return 0;
+}
+
+}  // extern "C"

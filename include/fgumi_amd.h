@@ -257,6 +257,16 @@ int fgx_filter_records_device(fgx_caller* c, const fgx_filter_options* f, void* 
  * without leaving the device: the hand-over the reference does through a BAM file or a pipe). */
 int fgx_filter_last_output_device(fgx_caller* c, const fgx_filter_options* f, fgx_filter_output* out);
 
+/* ---- BGZF container on the host cores (crates/fgumi-bgzf/src/{reader,writer}.rs for this path) ------------------------------
+ * Block-parallel over zlib: `threads` workers (0 = all cores) take the independent <= 64 KiB gzip members of a BGZF file image.
+ * Both return 0 and a malloc'ed buffer the caller releases with fgx_bgzf_free, or 1 (fgx_bgzf_last_error, thread-local).
+ * inflate verifies every block's CRC32 and ISIZE; deflate cuts the stream every 0xff00 bytes, level 1 being the reference's
+ * default for consensus output, and appends the 28-byte EOF marker when `with_eof`. */
+int fgx_bgzf_inflate(const uint8_t* raw, uint64_t raw_len, uint32_t threads, uint8_t** out, uint64_t* out_len);
+int fgx_bgzf_deflate(const uint8_t* in, uint64_t len, int level, uint32_t threads, int with_eof, uint8_t** out, uint64_t* out_len);
+void fgx_bgzf_free(uint8_t* p);
+const char* fgx_bgzf_last_error(void);
+
 /* FindBoundaries (src/lib/unified_pipeline/bam.rs): walks the `block_size` chain of an uncompressed BAM record stream from
  * byte `start`; fills rec_off (BODY offsets, past the 4-byte prefix) and rec_len for up to `cap` records and sets *n_rec to
  * the number of records in the stream (call with cap = 0 to count).  Returns 0, or 1 when the stream ends inside a record. */

@@ -90,3 +90,26 @@ def test_export_bam_tool_writes_the_pin_input(tmp_path):
     assert rep["grouped_records"] == len(rec_off) == 1200 and len(refs) == 24
     g = simulate_grouped_reads(200, family_size=3)
     assert stream[int(rec_off[0]) - 4:] == g.blob.tobytes()
+
+
+def test_native_bgzf_entries_match_the_python_container_code():
+    """The library's block-parallel zlib inflate / deflate (csrc/bgzf_host.cpp) against the pure-Python framing above."""
+    rng = np.random.default_rng(11)
+    payload = bytes(rng.integers(0, 6, 500000, dtype=np.uint8)) + bytes(rng.integers(0, 256, 70000, dtype=np.uint8))
+    nat = bgzf.native_deflate(payload, level=1, threads=3, with_eof=True)
+    assert nat is not None, "libfgumi_amd.so is built in-tree: the native entries must be there"
+    blob = nat[0].tobytes()
+    assert blob.endswith(bgzf.BGZF_EOF) and _gunzip_members(blob) == payload
+    table = bgzf.bgzf_block_table(blob)
+    assert len(table) == -(-len(payload) // bgzf.BGZF_MAX_PAYLOAD) + 1 and all(sz <= 0x10000 for _, sz in table)
+    assert bgzf.bgzf_decompress(blob, threads=2) == payload                       # Python reader takes the native writer's file
+    py_blocks = b"".join(bgzf.bgzf_compress(payload, level=1, threads=2)) + bgzf.BGZF_EOF
+    back = bgzf.native_inflate(py_blocks, threads=4)                              # native reader takes the Python writer's file
+    assert back[0].tobytes() == payload
+    assert bgzf.native_inflate(bgzf.BGZF_EOF)[0].size == 0 and bgzf.native_deflate(b"", with_eof=True)[0].tobytes() == bgzf.BGZF_EOF
+    bad = bytearray(blob)
+    bad[len(bad) // 2] ^= 0x55
+    with pytest.raises(ValueError):
+        bgzf.native_inflate(bytes(bad))
+    with pytest.raises(ValueError):
+        bgzf.native_inflate(blob[:-40] + blob[-28:])
