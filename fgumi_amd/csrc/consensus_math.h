@@ -244,6 +244,50 @@ struct ColumnAcc {
   FGX_HD uint32_t contributions() const { return obs[0] + obs[1] + obs[2] + obs[3]; }
 };
 
+// The same accumulation with Kahan chains BY ORDER OF APPEARANCE instead of one chain per base: chain 1 = the first base seen,
+// chains 2 / 3 = the second / third distinct base, chain R = every base not seen yet.  base_builder.rs:836-868 adds `correct`
+// to the observed lane and `error_per_alt` to the other three, lane by lane, in read order — so the lanes of the bases not yet
+// observed receive identical additions and hold bit-identical (sum, compensation) pairs: one chain stands for all of them, a
+// new base opens its chain as a copy of chain R, and once three bases have been seen chain R IS the fourth base.  A column
+// that shows a single base (99 % of them) costs two chains = 8 f64 operations per observation instead of 16; the lanes come
+// out bit-identical to ColumnAcc's.  `code` is the BAM 4-bit code in read orientation; only the one-hot codes A C G T count.
+struct ChainAcc {
+  double s1, c1, sR, cR, s2, c2, s3, c3;
+  uint32_t st;                 // 0: nothing seen; a one-hot code: that base only, so far; 16: several bases
+  uint32_t b1, b2, b3;         // several bases: codes of chains 1..3, 0 = not opened
+  uint32_t n1, n2, n3, nR;     // observations per chain
+  FGX_HD void reset() { s1 = c1 = sR = cR = s2 = c2 = s3 = c3 = 0.0; st = b1 = b2 = b3 = n1 = n2 = n3 = nR = 0; }
+  static FGX_HD void kahan(double& s, double& c, double v) { const double y = v - c; const double t = s + y; c = (t - s) - y; s = t; }
+  FGX_HD void add(bool valid, uint32_t code, double ln_correct, double ln_err) {
+    const uint32_t sc = st | code;
+    const bool hot = valid && sc == code;              // nothing seen yet, or this very base only
+    if (hot) { st = sc; n1++; kahan(s1, c1, ln_correct); kahan(sR, cR, ln_err); }
+    if (valid && !hot) {
+      if (st != 16) { b1 = st; st = 16; }
+      if (code != b1 && code != b2 && code != b3) {
+        if (b2 == 0) { b2 = code; s2 = sR; c2 = cR; }
+        else if (b3 == 0) { b3 = code; s3 = sR; c3 = cR; }
+      }
+      const bool h1 = code == b1, h2 = code == b2, h3 = code == b3;
+      kahan(s1, c1, h1 ? ln_correct : ln_err);
+      kahan(s2, c2, h2 ? ln_correct : ln_err);          // (chains 2 / 3 hold nothing of value until opened: overwritten then)
+      kahan(s3, c3, h3 ? ln_correct : ln_err);
+      kahan(sR, cR, (h1 || h2 || h3) ? ln_err : ln_correct);
+      n1 += h1; n2 += h2; n3 += h3; nR += !(h1 || h2 || h3);
+    }
+  }
+  // lanes of A, C, G, T (codes 1, 2, 4, 8); bases never seen read chain R
+  FGX_HD void finish(double* ll, uint32_t* obs) const {
+    const uint32_t f1 = st != 16 ? st : b1;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) {
+      const uint32_t code = 1u << i;
+      ll[i] = code == f1 ? s1 : code == b2 ? s2 : code == b3 ? s3 : sR;
+      obs[i] = code == f1 ? n1 : code == b2 ? n2 : code == b3 ? n3 : nR;
+    }
+  }
+};
+
 // try_unanimous_fast_path; returns true when the table answer is established.
 FGX_HD bool unanimous_fast_path(const ConsensusTables& T, const double* ll, const uint32_t* obs, int* base_idx, uint8_t* qual) {
   int observed = -1, n_obs = 0;

@@ -777,26 +777,27 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
       depth = code != 15 ? 1 : 0;
       err = 0;
     } else {
-      ColumnAcc acc;
+      ChainAcc acc;                             // two Kahan chains while the column shows one base (consensus_math.h)
       acc.reset();
       for (uint32_t a = 0; a < mc; a++) {
         const ReadInfo& R = S.ri[S.members[m0 + a]];
         if (p < R.final_len) {
           uint8_t code, q;
           oriented(S, lb, lq, R, p, P.min_input_bq, &code, &q);
-          int lane = bam::code_to_lane(code);   // N (incl. masked) and IUPAC codes contribute nothing
-          if (lane != 255) {
-            uint32_t qq = q < FGX_MAX_PHRED ? q : FGX_MAX_PHRED;
-            const double2 pr = *(const double2*)&sPairB[qq][0];
-            acc.add(lane, pr.x, pr.y);
-          }
+          // N (incl. masked) and IUPAC codes contribute nothing: only the one-hot codes A C G T are observations
+          const uint32_t qq = q < FGX_MAX_PHRED ? q : FGX_MAX_PHRED;
+          const double2 pr = *(const double2*)&sPairB[qq][0];
+          acc.add(__popc((uint32_t)code) == 1, code, pr.x, pr.y);
         }
       }
+      double ll[4];
+      uint32_t obs[4];
+      acc.finish(ll, obs);
       int bi;
       uint8_t q;
-      column_call(T->t, acc.s, acc.obs, &bi, &q);
-      depth = acc.contributions();
-      err = depth - acc.obs_of(bi);
+      column_call(T->t, ll, obs, &bi, &q);
+      depth = obs[0] + obs[1] + obs[2] + obs[3];
+      err = depth - (bi == 0 ? obs[0] : bi == 1 ? obs[1] : bi == 2 ? obs[2] : bi == 3 ? obs[3] : 0u);
       const uint8_t LANE_CODE[4] = {1, 2, 4, 8};
       uint8_t code = bi >= 0 ? LANE_CODE[bi] : 15;
       if (depth < P.min_reads) { ob = 15; oq = 0; }
@@ -1521,8 +1522,7 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
         depth = code != 15 ? 1 : 0;
         err = 0;
       } else {
-        struct { ColumnAcc a; __device__ void reset() { a.reset(); } __device__ void add(bool v, uint32_t bl, double c, double e) { if (v) a.add((int)bl, c, e); }
-                 __device__ void finish(double* ll, uint32_t* ob) const { for (int i = 0; i < 4; i++) { ll[i] = a.s[i]; ob[i] = a.obs[i]; } } } acc;
+        ChainAcc acc;                           // two Kahan chains while the column shows one base (consensus_math.h)
         acc.reset();
         for (unsigned long long m = members; m; m &= m - 1) {
           const uint32_t r = (uint32_t)__builtin_ctzll(m);
@@ -1533,14 +1533,13 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
           const uint32_t bb = W[(x0 & 0xFFFF) + (idx >> 1)];
           const uint32_t c = (bb >> ((~idx & 1) << 2)) & 15;
           const uint32_t q = W[(x0 >> 16) + idx];
-          // code → accumulator lane (A,C,G,T = 0..3, anything else 15), complemented for reverse reads
-          const unsigned long long LUT = rv ? 0xFFFFFFF0FFF1F23FULL : 0xFFFFFFF3FFF2F10FULL;
-          const uint32_t bl = (uint32_t)(LUT >> (4 * c)) & 15;
+          // the code in read orientation (complement = bit reversal of the 4-bit code); only the one-hot codes A C G T count
+          const uint32_t co = rv ? __builtin_bitreverse32(c) >> 28 : c;
           const bool masked = p < (x2 & 0xFFFF) && q < min_bq;
-          valid = valid && bl < 4 && !masked;
+          valid = valid && __popc(co) == 1 && !masked;
           const uint32_t qq = q < FGX_MAX_PHRED ? q : FGX_MAX_PHRED;
           const double2 pr = *(const double2*)&sPair[qq][0];
-          acc.add(valid, bl, pr.x, pr.y);
+          acc.add(valid, co, pr.x, pr.y);
         }
         double ll[4];
         uint32_t obs[4];
@@ -1776,7 +1775,7 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
         depth = code != 15 ? 1u : 0u;
         if (depth && !(obs[0] | obs[1] | obs[2] | obs[3])) odd_base = true;     // IUPAC code in a lone read: general path
       } else {
-        ColumnAcc acc;
+        ChainAcc acc;                           // two Kahan chains while the column shows one base (consensus_math.h)
         acc.reset();
         for (unsigned long long m = members; m; m &= m - 1) {
           const uint32_t r = (uint32_t)__builtin_ctzll(m);
@@ -1787,16 +1786,15 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
           const uint32_t bb = W[(x0 & 0xFFFF) + (idx >> 1)];
           const uint32_t c = (bb >> ((~idx & 1) << 2)) & 15;
           const uint32_t q = W[(x0 >> 16) + idx];
-          const unsigned long long LUT = rv ? 0xFFFFFFF0FFF1F23FULL : 0xFFFFFFF3FFF2F10FULL;
-          const uint32_t bl = (uint32_t)(LUT >> (4 * c)) & 15;
+          const uint32_t co = rv ? __builtin_bitreverse32(c) >> 28 : c;     // read orientation: complement = bit reversal of the code
           const bool masked = p < (x2 & 0xFFFF) && q < min_bq;
-          valid = valid && bl < 4 && !masked;
+          valid = valid && __popc(co) == 1 && !masked;                      // only the one-hot codes A C G T are observations
           const uint32_t qq = q < FGX_MAX_PHRED ? q : FGX_MAX_PHRED;
           const double2 pr = *(const double2*)&sPair[qq][0];
-          if (valid) acc.add((int)bl, pr.x, pr.y);
+          acc.add(valid, co, pr.x, pr.y);
         }
-        double ll[4] = {acc.s[0], acc.s[1], acc.s[2], acc.s[3]};
-        obs[0] = acc.obs[0]; obs[1] = acc.obs[1]; obs[2] = acc.obs[2]; obs[3] = acc.obs[3];
+        double ll[4];
+        acc.finish(ll, obs);
         int bi;
         uint8_t q;
         const bool resolved = column_call_fast_lds(sT, KC, ll, obs, &bi, &q);
@@ -2107,7 +2105,7 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
         P.col_code[o] = (uint8_t)code; P.col_qual[o] = adjq; P.col_depth[o] = code != 15 ? 1 : 0; P.col_err[o] = 0;
         if (code != 15 && code != 1 && code != 2 && code != 4 && code != 8) odd_base = true;   // IUPAC code in a lone read: general path
       } else {
-        ColumnAcc acc;
+        ChainAcc acc;                           // two Kahan chains while the column shows one base (consensus_math.h)
         acc.reset();
         for (unsigned long long m = members; m; m &= m - 1) {
           const uint32_t r = (uint32_t)__builtin_ctzll(m);
@@ -2118,15 +2116,15 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
           const uint32_t bb = W[(x0 & 0xFFFF) + (idx >> 1)];
           const uint32_t c = (bb >> ((~idx & 1) << 2)) & 15;
           const uint32_t q = W[(x0 >> 16) + idx];
-          const unsigned long long LUT = rv ? 0xFFFFFFF0FFF1F23FULL : 0xFFFFFFF3FFF2F10FULL;
-          const uint32_t bl = (uint32_t)(LUT >> (4 * c)) & 15;
-          valid = valid && bl < 4;
+          const uint32_t co = rv ? __builtin_bitreverse32(c) >> 28 : c;     // read orientation: complement = bit reversal of the code
+          valid = valid && __popc(co) == 1;                                 // only the one-hot codes A C G T are observations
           const uint32_t qq = q < FGX_MAX_PHRED ? q : FGX_MAX_PHRED;
           const double2 pr = *(const double2*)&sPair[qq][0];
-          if (valid) acc.add((int)bl, pr.x, pr.y);
+          acc.add(valid, co, pr.x, pr.y);
         }
-        double ll[4] = {acc.s[0], acc.s[1], acc.s[2], acc.s[3]};
-        uint32_t obs[4] = {acc.obs[0], acc.obs[1], acc.obs[2], acc.obs[3]};
+        double ll[4];
+        uint32_t obs[4];
+        acc.finish(ll, obs);
         int bi;
         uint8_t q;
         const bool resolved = column_call_fast_lds(sT, KC, ll, obs, &bi, &q);
