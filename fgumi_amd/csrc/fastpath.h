@@ -6,14 +6,14 @@ namespace fgx {
 
 constexpr int FAST_RX_CAP = 48;   // longest RX value handled on the device (longer → general path)
 
-struct EndDesc {            // one consensus read (a family end), written by k_family, consumed by k_emit
+struct EndDesc {            // one consensus read (a family end), written by the family kernels, consumed by k_emit
   uint64_t col_off;         // first column in the per-position arrays
+  uint64_t first_off;       // blob offset (record body) of the first record of the MI group: MI value → read name + MI tag
+  uint64_t kept_off;        // blob offset of the first retained source read: cell-barcode tag
+                            // (offsets, not record indices: k_emit goes from the descriptor straight to the bytes, one dependent
+                            // memory round trip less per record)
   uint32_t cons_len;
-  uint32_t first_rec;       // first record of the MI group (MI value → read name + MI tag)
-  uint32_t first_kept_rec;  // first retained source read (cell-barcode tag)
   uint32_t rec_size;        // BAM block_size of the record to emit
-  float ce;
-  uint16_t maxd, mind;
   uint16_t mi_off, cb_off;
   uint8_t mi_len, cb_len, rx_len, type;   // type: 0 fragment, 1 R1, 2 R2
   uint8_t has_cb, has_rx, valid, _pad;

@@ -856,13 +856,10 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
     uint32_t Lc = S.end_len[k];
     D.col_off = S.col_base + S.end_coloff[k];
     D.cons_len = Lc;
-    D.first_rec = r0;
-    D.first_kept_rec = r0 + S.members[S.end_first[k]];
+    D.first_off = S.ri[0].goff;
+    D.kept_off = S.ri[S.members[S.end_first[k]]].goff;
     D.type = (uint8_t)S.end_type[k];
-    uint32_t maxd = Lc ? S.end_maxd[k] : 0, mind = Lc ? S.end_mind[k] : 0;
-    D.maxd = (uint16_t)maxd; D.mind = (uint16_t)mind;
-    uint32_t te = S.end_sume[k], td = S.end_sumd[k];
-    D.ce = td > 0 ? (float)te / (float)td : 0.0f;
+    const uint32_t maxd = Lc ? S.end_maxd[k] : 0, mind = Lc ? S.end_mind[k] : 0;   // widths of the cD / cM integer tags
     D.mi_off = S.ri[0].mi_off; D.mi_len = S.ri[0].mi_len;
     const ReadInfo& F = S.ri[S.members[S.end_first[k]]];
     D.has_cb = (P.cell0 && F.has_cb) ? 1 : 0; D.cb_off = F.cb_off; D.cb_len = F.cb_len;
@@ -1646,10 +1643,12 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
     if (lane < e_rx_len[k] && e_rx_cnt[k]) D->rx[lane] = my_rx[k];
     uint32_t fk = (uint32_t)__builtin_ctzll(e_mem[k]);     // first retained read (cell barcode source)
     uint32_t fk_has_cb = (uint32_t)((cbmask >> fk) & 1), fk_cb_lo = rlane(cb_lo, fk), fk_cb_len = rlane(cb_len, fk), fk_lo = rlane(lo, fk);
+    const unsigned long long off0 = (unsigned long long)rlane((uint32_t)off, 0) | ((unsigned long long)rlane((uint32_t)(off >> 32), 0) << 32);
+    const unsigned long long off_fk = (unsigned long long)rlane((uint32_t)off, fk) | ((unsigned long long)rlane((uint32_t)(off >> 32), fk) << 32);
     if (lane == 0) {
       D->col_off = col_base + e_coloff[k];
       D->cons_len = Lc;
-      D->first_rec = r0; D->first_kept_rec = r0 + fk;
+      D->first_off = off0; D->kept_off = off_fk;
       D->type = (uint8_t)e_type[k];
       D->mi_off = (uint16_t)(mi0_lo - lo); D->mi_len = (uint8_t)mi0_len;          // lane 0: lo = record 0
       bool hcb = P.cell0 && fk_has_cb;
@@ -2363,7 +2362,7 @@ __device__ void emit_generic(const EmitParams& P, const EndDesc& D, const EmitCt
   for (uint32_t i = lane; i < 3 + mi_len + 1; i += 64) q[i] = i == 0 ? (uint8_t)P.tag0 : i == 1 ? (uint8_t)P.tag1 : i == 2 ? 'Z' : i - 3 < mi_len ? X.first[mi_off + i - 3] : 0;
   q += 3 + mi_len + 1;
   if (D.has_cb) {
-    const uint8_t* fk = P.blob + P.rec_off[D.first_kept_rec];
+    const uint8_t* fk = P.blob + D.kept_off;
     const uint32_t cb_len = D.cb_len, cb_off = D.cb_off;
     for (uint32_t i = lane; i < 3 + cb_len + 1; i += 64) q[i] = i == 0 ? (uint8_t)P.cell0 : i == 1 ? (uint8_t)P.cell1 : i == 2 ? 'Z' : i - 3 < cb_len ? fk[cb_off + i - 3] : 0;
     q += 3 + cb_len + 1;
@@ -2374,16 +2373,30 @@ __device__ void emit_generic(const EmitParams& P, const EndDesc& D, const EmitCt
   }
 }
 
+// One wavefront per FAMILY: its (up to three) records one after the other.  A third of the slots is empty on paired data (the
+// fragment slot), and a wavefront that only finds `valid == 0` still costs a launch and a memory round trip; the descriptor
+// carries blob OFFSETS, so the record's strings are one dependent load away instead of two (2.35 → 2.20 ms per 2 M records).
+// (Assembling the record through LDS — whole-record image with byte writes, or dword-staged column arrays with dword payload
+// copies — was measured three times, rounds 1 and 2: 3.4 – 4.0 ms.  The wave's lifetime is a chain of memory round trips, and
+// every LDS hop adds one; registers-only streaming below is the fastest form found.)
+__device__ __forceinline__ void emit_one(const EmitParams& P, uint32_t slot, uint32_t lane);
 __global__ __launch_bounds__(256) void k_emit(EmitParams P) {
-  const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(P.slot0 + ((blockIdx.x * blockDim.x + threadIdx.x) >> 6)));
+  const uint32_t fam = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
   const uint32_t lane = threadIdx.x & 63;
-  if (slot >= P.slot_end) return;
+  const uint32_t s0 = P.slot0 + 3 * fam;
+  if (s0 >= P.slot_end) return;
+  // the three `valid` flags first (independent scalar loads), then the records
+  const bool v0 = P.ends[s0].valid != 0, v1 = s0 + 1 < P.slot_end && P.ends[s0 + 1].valid != 0, v2 = s0 + 2 < P.slot_end && P.ends[s0 + 2].valid != 0;
+  if (v0) emit_one(P, s0, lane);            // (three inlined copies: a rolled loop measured 2.8 instead of 2.2 ms per 2 M records)
+  if (v1) emit_one(P, s0 + 1, lane);
+  if (v2) emit_one(P, s0 + 2, lane);
+}
+__device__ __forceinline__ void emit_one(const EmitParams& P, uint32_t slot, uint32_t lane) {
   const EndDesc& D = P.ends[slot];
-  if (!D.valid) return;
   EmitCtx X;
   X.q = P.out + (P.out_off[slot] - P.out_base);
   X.Lc = D.cons_len;
-  X.first = P.blob + P.rec_off[D.first_rec];
+  X.first = P.blob + D.first_off;
   X.mi_len = D.mi_len; X.mi_off = D.mi_off;
   X.name_len = P.prefix_len + 1 + X.mi_len;
   X.rec_size = D.rec_size;
@@ -2425,7 +2438,7 @@ __global__ __launch_bounds__(256) void k_emit(EmitParams P) {
   const uint8_t nb = lane < P.prefix_len ? pfx : lane == P.prefix_len ? (uint8_t)':' : lane < name_len ? nmb : (uint8_t)0;
   const uint8_t rgb = (uint8_t)P.rg[j3 < P.rg_len ? j3 : 0];
   const uint8_t mib = X.first[mi_off + (j3 < mi_len ? j3 : mi_len)];
-  const uint8_t* fk = has_cb ? P.blob + P.rec_off[D.first_kept_rec] + D.cb_off : X.first;
+  const uint8_t* fk = has_cb ? P.blob + D.kept_off + D.cb_off : X.first;
   const uint8_t cbb = fk[j3 < cb_len ? j3 : 0];
   const uint8_t rxb = (uint8_t)D.rx[j3 < FAST_RX_CAP ? j3 : 0];
 
@@ -3088,7 +3101,6 @@ __global__ __launch_bounds__(256) void k_emit_codec_fast(CodecEmitParams P) {
 
 #include "simplex_wave2.inc"
 #include "simplex_seg.inc"
-#include "simplex_blk.inc"
 
 // Upper bound on the consensus columns a batch can produce: a family yields at most three ends, each no
 // longer than its longest read, and l_seq <= (block_size - 33) * 2 / 3.
@@ -3241,7 +3253,6 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
         (void)hipFuncSetAttribute((const void*)k_simplex_wave2, hipFuncAttributeMaxDynamicSharedMemorySize, WAVES_PER_BLOCK * 22016);
         (void)hipFuncSetAttribute((const void*)k_simplex_seg<2>, hipFuncAttributeMaxDynamicSharedMemorySize, WAVES_PER_BLOCK * 32768);
         (void)hipFuncSetAttribute((const void*)k_simplex_seg<4>, hipFuncAttributeMaxDynamicSharedMemorySize, WAVES_PER_BLOCK * 32768);
-        (void)hipFuncSetAttribute((const void*)k_simplex_blk, hipFuncAttributeMaxDynamicSharedMemorySize, WAVES_PER_BLOCK * 16384);
         (void)hipGetLastError();
         v2_attr_set = true;
       }
@@ -3253,14 +3264,11 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
       // the same per family and a CU holds 12 instead of 20 wavefronts; kept behind FGX_SEG2=1 for experiments)
       static const bool use_seg2 = [] { const char* e = getenv("FGX_SEG2"); return e && e[0] == '1'; }();
       if (use_seg && use_seg2 && mean_span + (32 * 8 + 64) <= seg_bytes / 2) chain.push_back({2, seg_bytes, (uint32_t)WAVES_PER_BLOCK});
-      // k_simplex_blk: four families per workgroup, their record phases on one wavefront (families of at most 16 records)
-      // (measured slower than k_simplex_wave2 — 11.9 vs 10.2 ms per 1 M depth-8 families, profiles/r02c_pmc_1M_blk.json: 20 % fewer
-      // vector and 43 % fewer scalar instructions, but three wavefronts of four wait at the barrier while one runs the record
-      // phases, 70 % of the wave-cycles; opt-in with FGX_BLK=1)
-      static const bool use_blk = [] { const char* e = getenv("FGX_BLK"); return e && e[0] == '1'; }();
-      uint32_t blk_bytes = 5632;
-      if (const char* e = getenv("FGX_BLK_BYTES")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 2048 && v <= 16384) blk_bytes = v & ~15u; }
-      if (use_blk && mean_span <= 2.0 * blk_bytes) chain.push_back({-4, blk_bytes, (uint32_t)WAVES_PER_BLOCK});
+      // (Two workgroup-cooperative variants were built, verified byte-identical and measured slower — the record phases of four
+      // families on ONE wavefront while the other three wait at a barrier, 11.9 ms, and the same as a producer / consumer pipeline
+      // in persistent workgroups, 19.3 ms, against 10.2 ms per 1 M depth-8 families here: they execute 20 % fewer vector and 43 %
+      // fewer scalar instructions, but a lone wavefront retires an instruction every ~30 cycles, and the CU is fed by the number of
+      // independent wavefronts, not by lane utilisation.  profiles/r02c_pmc_1M_blk.json, r02d_pmc_1M_pipe.json)
       for (int st = 0; st < 3; st++) if (st == 0 || stages[st] > stages[st - 1]) chain.push_back({1, stages[st], st == 0 ? (uint32_t)WAVES_PER_BLOCK : st == 1 ? 2u : 1u});
       d_retry_old.reserve((size_t)n_grp * 4);
       uint32_t* d_cnt_old = (uint32_t*)(misc + 32);
@@ -3275,11 +3283,10 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
         PS.group_list = v2_list; PS.lds_wave_bytes = S.bytes;
         PS.retry = last ? nullptr : lists[v2_out]; PS.n_retry = d_cnt;
         PS.retry_old = d_retry_old.as<uint32_t>(); PS.n_retry_old = d_cnt_old;
-        const uint32_t fpb = S.fam_per_wave < 0 ? (uint32_t)(-S.fam_per_wave) : S.wpb * (uint32_t)S.fam_per_wave;      // families per workgroup
+        const uint32_t fpb = S.wpb * (uint32_t)S.fam_per_wave;      // families per workgroup
         const dim3 grid((n_v2 + fpb - 1) / fpb), block(64 * S.wpb);
         const size_t lds = (size_t)S.wpb * S.bytes;
-        if (S.fam_per_wave == -4) hipLaunchKernelGGL(k_simplex_blk, grid, block, lds, s, PS, n_v2);
-        else if (S.fam_per_wave == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_simplex_seg<4>), grid, block, lds, s, PS, n_v2);
+        if (S.fam_per_wave == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_simplex_seg<4>), grid, block, lds, s, PS, n_v2);
         else if (S.fam_per_wave == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_simplex_seg<2>), grid, block, lds, s, PS, n_v2);
         else hipLaunchKernelGGL(k_simplex_wave2, grid, block, lds, s, PS, n_v2);
         hip_check(hipGetLastError(), "k_simplex launch");
@@ -3391,7 +3398,7 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
     DE.per_base_tags = P.per_base_tags; DE.cell0 = P.cell0; DE.cell1 = P.cell1;
     hipLaunchKernelGGL(k_emit_duplex_fast, dim3((n_slots + 3) / 4), dim3(256), 0, s, DE);
     hipLaunchKernelGGL(k_emit_duplex, dim3((n_slots + 3) / 4), dim3(256), 0, s, DE);
-  } else hipLaunchKernelGGL(k_emit, dim3((n_slots + 3) / 4), dim3(256), 0, s, E);
+  } else hipLaunchKernelGGL(k_emit, dim3((n_grp + 3) / 4), dim3(256), 0, s, E);   // one wavefront per family (slots 3g .. 3g + 2)
   hip_check(hipGetLastError(), "k_emit launch");
   hip_check(hipEventRecord(ev[3], s), "event");
   hip_check(hipEventRecord(c->ev1, s), "event");
