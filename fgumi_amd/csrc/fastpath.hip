@@ -38,6 +38,7 @@
 #include "bamrec.h"
 #include "engine.h"
 #include <cstdlib>
+#include <type_traits>
 #include "fastpath.h"
 
 namespace fgx {
