@@ -44,9 +44,9 @@ struct CodecDesc {          // one CODEC consensus record (slot 3g+1), written b
 
 struct FullItem {           // a column (or UMI character) whose call needs the full log-sum-exp chain
   uint64_t dest;            // bit 63 clear: scratch column index; set: (slot << 8 | char index) of an RX character
-  double ll[4];
-  uint32_t obs;             // per-base observation counts, one byte each (A,C,G,T)
-  uint32_t _pad;
+  double ll[4];             // chains == 0: log-likelihoods of A, C, G, T; else: Kahan chains 1, 2, 3 and R as the kernel holds them
+  uint32_t obs;             // observation counts, one byte each, in the order of ll
+  uint32_t chains;          // 0, or the one-hot BAM codes of chains 1 | 2 << 4 | 3 << 8 (0 = chain not opened); every other base reads chain R
 };
 constexpr int N_LISTS = 1024;
 

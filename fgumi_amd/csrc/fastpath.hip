@@ -1031,7 +1031,7 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
         if (idx < P.full_cap) {
           FullItem* it = &P.full_items[(size_t)l * P.full_cap + idx];
           it->dest = dest; it->ll[0] = ll[0]; it->ll[1] = ll[1]; it->ll[2] = ll[2]; it->ll[3] = ll[3];
-          it->obs = obs[0] | (obs[1] << 8) | (obs[2] << 16) | (obs[3] << 24);
+          it->obs = obs[0] | (obs[1] << 8) | (obs[2] << 16) | (obs[3] << 24); it->chains = 0;
           pending = false;
         }
       }
@@ -2258,7 +2258,20 @@ __global__ __launch_bounds__(256) void k_call_full(FullParams P) {
   if (cnt > P.cap) cnt = P.cap;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= cnt) return;
-  const FullItem it = P.items[(size_t)list * P.cap + i];
+  FullItem it = P.items[(size_t)list * P.cap + i];
+  if (it.chains) {   // chains by order of appearance (k_simplex_wave2 / k_simplex_seg): the bases are sorted out here, once per item
+    const uint32_t b1 = it.chains & 15, b2 = (it.chains >> 4) & 15, b3 = (it.chains >> 8) & 15;
+    const double c1 = it.ll[0], c2 = it.ll[1], c3 = it.ll[2], cR = it.ll[3];
+    const uint32_t n1 = it.obs & 0xFF, n2 = (it.obs >> 8) & 0xFF, n3 = (it.obs >> 16) & 0xFF, nR = it.obs >> 24;
+    uint32_t packed = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+      const uint32_t code = 1u << k;
+      it.ll[k] = code == b1 ? c1 : code == b2 ? c2 : code == b3 ? c3 : cR;
+      packed |= (code == b1 ? n1 : code == b2 ? n2 : code == b3 ? n3 : nR) << (8 * k);
+    }
+    it.obs = packed;
+  }
   const bool is_rx = (it.dest >> 63) != 0;
   const ConsensusTables& T = is_rx ? P.TU->t : P.T->t;
   int bi;
