@@ -2310,6 +2310,11 @@ struct EmitCtx {
   uint32_t Lc, name_len, mi_len, mi_off, flag, rec_size;
 };
 
+// unaligned global dwords (gfx950 takes them in one instruction)
+__device__ __forceinline__ uint32_t gld32u(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+__device__ __forceinline__ uint2 gld64u(const uint8_t* p) { uint2 v; __builtin_memcpy(&v, p, 8); return v; }
+__device__ __forceinline__ void gst32u(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+
 __device__ __forceinline__ void emit_core(uint8_t* q, uint32_t lane, const EmitCtx& X) {
   // block_size + fixed core: ref_id -1, pos -1, l_read_name, mapq 0, bin 4680, n_cigar_op 0, flag, l_seq, next_ref -1, next_pos -1, tlen 0
   if (lane < 36) {
@@ -2421,29 +2426,21 @@ __device__ __forceinline__ void emit_one(const EmitParams& P, uint32_t slot, uin
   const uint32_t Lc = X.Lc, name_len = X.name_len, mi_len = X.mi_len, mi_off = X.mi_off;
   const bool has_cb = D.has_cb != 0, has_rx = D.has_rx != 0;
   const uint32_t cb_len = has_cb ? D.cb_len : 0, rx_len = has_rx ? D.rx_len : 0;
-  if (Lc > 192 || name_len + 1 > 64 || P.rg_len + 4 > 64 || cb_len + 4 > 64) { emit_generic(P, D, X, lane); return; }
+  if (Lc > 192 || Lc < 8 || name_len + 1 > 64 || P.rg_len + 4 > 64 || cb_len + 4 > 64) { emit_generic(P, D, X, lane); return; }
 
   // ---- every load of the record, back to back ----------------------------------------------------------------
-  // (unconditional, indices clamped into the record's own arrays: no branch, hence no wait, between the loads)
-  uint32_t dv[3], ev[3], qv[3], sh[2], sl[2], ad[7], ae[7];
-  const uint32_t last_col = Lc ? Lc - 1 : 0;
-#pragma unroll
-  for (int t = 0; t < 3; t++) {
-    const uint32_t i = lane + 64 * t, ic = i < last_col ? i : last_col;
-    dv[t] = X.cd[ic]; ev[t] = X.ce[ic]; qv[t] = X.cq[ic];
-  }
+  // Payloads move as (unaligned) dwords: lane l owns bytes [4l, 4l + 4) of a field, and the lane past the last whole dword
+  // takes the field's LAST four bytes instead (an overlapping store of the same values) — no byte-granular tail.
+  const uint32_t seq_bytes = (Lc + 1) / 2;
+  const uint32_t so = min(4 * lane, seq_bytes - 4);                                    // sequence: 4 output bytes = 8 columns
+  const uint32_t qo = min(4 * lane, Lc - 4);                                           // qualities: 4 columns
+  const uint2 cw = gld64u(X.code + 2 * so);                                            // (column Lc may be read: one byte of slack)
+  const uint32_t qw = gld32u(X.cq + qo);
+  uint32_t dw[2], ew[2], ao[2];                                                        // per-base arrays: 4 bytes = 2 columns
 #pragma unroll
   for (int t = 0; t < 2; t++) {
-    const uint32_t i = 2 * (lane + 64 * t), i0 = i < last_col ? i : last_col, i1 = i + 1 < last_col ? i + 1 : last_col;
-    sh[t] = X.code[i0]; sl[t] = i + 1 < Lc ? X.code[i1] : 0;
-  }
-  const uint32_t n_arr = P.per_base_tags ? 8 + 2 * Lc : 0;
-#pragma unroll
-  for (int t = 0; t < 7; t++) {
-    const uint32_t i = lane + 64 * t;
-    uint32_t k = i >= 8 ? (i - 8) >> 1 : 0;
-    k = k < last_col ? k : last_col;
-    ad[t] = X.cd[k]; ae[t] = X.ce[k];
+    ao[t] = min(4 * (lane + 64 * t), 2 * Lc - 4);
+    dw[t] = gld32u((const uint8_t*)X.cd + ao[t]); ew[t] = gld32u((const uint8_t*)X.ce + ao[t]);
   }
   const uint32_t j3 = lane >= 3 ? lane - 3 : 0;
   const uint32_t ni = lane > P.prefix_len ? lane - P.prefix_len - 1 : 0;
@@ -2457,48 +2454,65 @@ __device__ __forceinline__ void emit_one(const EmitParams& P, uint32_t slot, uin
   const uint8_t rxb = (uint8_t)D.rx[j3 < FAST_RX_CAP ? j3 : 0];
 
   // ---- cD / cM / cE (vanilla_caller.rs:1800-1810): max / min depth, Σerrors / Σdepth as f32 ---------------------
+  // every column counted once: a lane's low half is a duplicate when its offset was pulled back to the field's last dword
   uint32_t maxd = 0, mind = 0xFFFFFFFFu, sumd = 0, sume = 0;
 #pragma unroll
-  for (int t = 0; t < 3; t++) if (lane + 64 * t < Lc) { maxd = dv[t] > maxd ? dv[t] : maxd; mind = dv[t] < mind ? dv[t] : mind; sumd += dv[t]; sume += ev[t]; }
+  for (int t = 0; t < 2; t++) {
+    const uint32_t nat = 4 * (lane + 64 * t);
+    const bool in = nat < 2 * Lc, lo_own = in && nat == ao[t];
+    const uint32_t dl = dw[t] & 0xFFFF, dh = dw[t] >> 16, el = ew[t] & 0xFFFF, eh = ew[t] >> 16;
+    if (lo_own) { maxd = dl > maxd ? dl : maxd; mind = dl < mind ? dl : mind; sumd += dl; sume += el; }
+    if (in) { maxd = dh > maxd ? dh : maxd; mind = dh < mind ? dh : mind; sumd += dh; sume += eh; }
+  }
   for (int o = 32; o > 0; o >>= 1) {
     uint32_t a = __shfl_xor(maxd, o), b = __shfl_xor(mind, o);
     maxd = a > maxd ? a : maxd; mind = b < mind ? b : mind;
     sumd += __shfl_xor(sumd, o); sume += __shfl_xor(sume, o);
   }
-  if (Lc == 0) { maxd = 0; mind = 0; }
   const float ce_rate = sumd > 0 ? (float)sume / (float)sumd : 0.0f;
   const uint32_t n_cd = 3 + int_tag_width(maxd), n_cm = 3 + int_tag_width(mind);
 
   // ---- stores -----------------------------------------------------------------------------------------------------------
   uint8_t* q = X.q;
-  emit_core(q, lane, X);
+  if (lane < 9) {   // block_size + fixed core: ref_id -1, pos -1, l_read_name, mapq 0, bin 4680, n_cigar_op 0, flag, l_seq, next_ref -1, next_pos -1, tlen 0
+    const uint32_t v = lane == 0 ? X.rec_size : lane == 3 ? ((name_len + 1) | (4680u << 16)) : lane == 4 ? (X.flag << 16) : lane == 5 ? Lc : lane == 8 ? 0u : 0xFFFFFFFFu;
+    gst32u(q + 4 * lane, v);
+  }
   q += 36;
   if (lane < name_len + 1) q[lane] = nb;
   q += name_len + 1;
-#pragma unroll
-  for (int t = 0; t < 2; t++) { const uint32_t i = lane + 64 * t; if (i < (Lc + 1) / 2) q[i] = (uint8_t)((sh[t] << 4) | sl[t]); }
-  q += (Lc + 1) / 2;
-#pragma unroll
-  for (int t = 0; t < 3; t++) { const uint32_t i = lane + 64 * t; if (i < Lc) q[i] = (uint8_t)qv[t]; }
+  if (4 * lane < seq_bytes) {   // eight columns → four bytes, high nibble first; a column past the end packs as 0
+    const uint32_t c0 = 2 * so;
+    uint32_t lo4 = cw.x, hi4 = cw.y;                                                   // codes of columns c0..c0+3 / c0+4..c0+7, one byte each
+    if (c0 + 7 >= Lc) hi4 &= 0x00FFFFFFu;                                              // (only column c0 + 7 can be past the end: Lc odd)
+    const uint32_t b0 = ((lo4 << 4) | (lo4 >> 8)) & 0xFF, b1 = ((lo4 >> 12) | (lo4 >> 24)) & 0xFF;
+    const uint32_t b2 = ((hi4 << 4) | (hi4 >> 8)) & 0xFF, b3 = ((hi4 >> 12) | (hi4 >> 24)) & 0xFF;
+    gst32u(q + so, b0 | (b1 << 8) | (b2 << 16) | (b3 << 24));
+  }
+  q += seq_bytes;
+  if (4 * lane < Lc) gst32u(q + qo, qw);
   q += Lc;
   if (lane < 3 + P.rg_len + 1) q[lane] = lane == 0 ? 'R' : lane == 1 ? 'G' : lane == 2 ? 'Z' : j3 < P.rg_len ? rgb : (uint8_t)0;
   q += 3 + P.rg_len + 1;
-  if (lane < n_cd + n_cm + 7) q[lane] = cdcmce_byte(lane, n_cd, n_cm, maxd, mind, ce_rate);
-  q += n_cd + n_cm + 7;
-  if (P.per_base_tags) {
-#pragma unroll
-    for (int pass = 0; pass < 2; pass++) {
-#pragma unroll
-      for (int t = 0; t < 7; t++) {
-        const uint32_t i = lane + 64 * t;
-        if (i < n_arr) {
-          const uint32_t w = pass == 0 ? ad[t] : ae[t];
-          q[i] = i < 8 ? (i == 0 ? 'c' : i == 1 ? (pass == 0 ? 'd' : 'e') : i == 2 ? 'B' : i == 3 ? 's' : (uint8_t)(Lc >> (8 * (i - 4))))
-                       : (uint8_t)(((i - 8) & 1) ? (w >> 8) : w);
-        }
-      }
-      q += n_arr;
+  {   // cD cM cE and, when asked for, the header of the cd array right behind them: one store
+    const uint32_t n3 = n_cd + n_cm + 7, nh = P.per_base_tags ? 8u : 0u;
+    if (lane < n3 + nh) {
+      const uint32_t i = lane - n3;
+      q[lane] = lane < n3 ? cdcmce_byte(lane, n_cd, n_cm, maxd, mind, ce_rate)
+                          : (uint8_t)(i == 0 ? 'c' : i == 1 ? 'd' : i == 2 ? 'B' : i == 3 ? 's' : (Lc >> (8 * (i - 4))));
     }
+    q += n3;
+  }
+  if (P.per_base_tags) {
+    q += 8;
+#pragma unroll
+    for (int t = 0; t < 2; t++) if (4 * (lane + 64 * t) < 2 * Lc) gst32u(q + ao[t], dw[t]);
+    q += 2 * Lc;
+    if (lane < 2) gst32u(q + 4 * lane, lane == 0 ? ('c' | ('e' << 8) | ('B' << 16) | ('s' << 24)) : Lc);
+    q += 8;
+#pragma unroll
+    for (int t = 0; t < 2; t++) if (4 * (lane + 64 * t) < 2 * Lc) gst32u(q + ao[t], ew[t]);
+    q += 2 * Lc;
   }
   if (lane < 3 + mi_len + 1) q[lane] = lane == 0 ? (uint8_t)P.tag0 : lane == 1 ? (uint8_t)P.tag1 : lane == 2 ? 'Z' : j3 < mi_len ? mib : (uint8_t)0;
   q += 3 + mi_len + 1;
@@ -3187,8 +3201,8 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
   hip_check(hipMemcpyAsync(&lastb[1], d_bound.as<uint64_t>() + (n_grp - 1), 8, hipMemcpyDeviceToHost, s), "D2H");
   hip_check(hipStreamSynchronize(s), "sync");
   uint64_t col_cap = lastb[0] + lastb[1] + 64;
-  d_code.reserve(col_cap); d_qual.reserve(col_cap); d_err.reserve(col_cap * 2);
-  if (duplex) d_obs.reserve(col_cap * 4); else d_depth.reserve(col_cap * 2);
+  d_code.reserve(col_cap + 64); d_qual.reserve(col_cap + 64); d_err.reserve(col_cap * 2 + 64);   // (+ slack: k_emit reads whole dwords)
+  if (duplex) d_obs.reserve(col_cap * 4); else d_depth.reserve(col_cap * 2 + 64);
 
   FastParams P;
   memset(&P, 0, sizeof(P));
