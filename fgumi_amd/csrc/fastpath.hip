@@ -937,6 +937,60 @@ __device__ __forceinline__ int find_nul64(const uint8_t* W, uint32_t o, uint32_t
   return -1;
 }
 
+// Aux walk of one record per lane, in LDS (tags.rs:13-34): first occurrence of MC / <tag> / RX / <cell tag>.
+// The walk keeps its state in integer lanes (bit 0 MC, 1 <tag>, 2 RX, 3 <cell tag>) and picks with selects: boolean state
+// would live in scalar lane masks, and every `if` on it costs scalar mask instructions for all 64 records.
+struct AuxTags {
+  uint32_t got, oddw;                          // keys found with a Z value ; <tag> / RX / <cell tag> values longer than 255 bytes
+  uint32_t pk_mc, pk_mi, pk_rx, pk_cb;         // value offset in LDS | value length << 16
+};
+// cls: aux value type -> 1 / 2 / 4 (fixed size), 8 (Z), 16 (H), 32 (B), 0 (unknown)
+__device__ __forceinline__ void fill_tag_classes(uint8_t* cls) {
+  for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
+    const int fx = bam::tag_fixed_size((uint8_t)i);
+    cls[i] = (uint8_t)(fx ? fx : i == 'Z' ? 8 : i == 'H' ? 16 : i == 'B' ? 32 : 0);
+  }
+}
+__device__ __forceinline__ void aux_walk(const uint8_t* W, const uint8_t* cls_of, uint32_t a0, uint32_t an, const FastParams& P, AuxTags& A) {
+  uint32_t q = 0, seen = 0, got = 0, oddw = 0;
+  uint32_t pk_mc = 0, pk_mi = 0, pk_rx = 0, pk_cb = 0;
+  const uint32_t key_mi = (uint32_t)(uint8_t)P.tag0 | ((uint32_t)(uint8_t)P.tag1 << 8);
+  const uint32_t key_cb = P.cell0 ? ((uint32_t)(uint8_t)P.cell0 | ((uint32_t)(uint8_t)P.cell1 << 8)) : 0xFFFFFFFFu;   // (no key is > 0xFFFF)
+  while (q + 3 <= an) {
+    const uint32_t hd = ld32u(W, a0 + q);
+    const uint32_t key = hd & 0xFFFF, cls = cls_of[(hd >> 16) & 0xFF];
+    const uint32_t rem = an - (q + 3);
+    uint32_t size = cls & 7, zend = 0;
+    uint32_t stop = cls == 0 ? 1u : 0u;                    // a key match at an entry of unknown size still counts as seen
+    if (cls & 24) {
+      const int z = find_nul64(W, a0 + q + 3, rem);
+      if (z < 0) break;                                    // unterminated: nothing here or after it is reachable
+      zend = (uint32_t)z; size = zend + 1;
+    }
+    if (cls & 32) {
+      if (rem < 5) break;
+      const uint32_t es = cls_of[hd >> 24] & 7;
+      const unsigned long long sz = 5ull + (unsigned long long)ld32u(W, a0 + q + 4) * (unsigned long long)es;
+      if (sz > 0xFFFFFFFFull) break;
+      size = (uint32_t)sz;
+      stop = es == 0 ? 1u : 0u;
+    }
+    const uint32_t kb = (key == ('M' | ('C' << 8)) ? 1u : 0u) | (key == key_mi ? 2u : 0u) | (key == ('R' | ('X' << 8)) ? 4u : 0u) | (key == key_cb ? 8u : 0u);
+    const uint32_t fresh = kb & ~seen;                     // first occurrence of its key
+    seen |= kb;
+    const uint32_t zb = cls == 8 ? fresh : 0u;             // ... with a Z value
+    const uint32_t rec = zend > 255 ? (zb & 1u) : zb;      // values longer than 255 bytes: only MC may be (it is then not `<n>M`)
+    oddw |= zb & ~rec;
+    got |= rec;
+    const uint32_t pk = (a0 + q + 3) | ((zend < 0xFFFFu ? zend : 0xFFFFu) << 16);
+    pk_mc = (rec & 1u) ? pk : pk_mc; pk_mi = (rec & 2u) ? pk : pk_mi; pk_rx = (rec & 4u) ? pk : pk_rx; pk_cb = (rec & 8u) ? pk : pk_cb;
+    const unsigned long long nq = (unsigned long long)q + 3 + size;
+    if (stop || nq > an) break;
+    q = (uint32_t)nq;
+  }
+  A.got = got; A.oddw = oddw; A.pk_mc = pk_mc; A.pk_mi = pk_mi; A.pk_rx = pk_rx; A.pk_cb = pk_cb;
+}
+
 // column_call_fast for the wave kernel: same decisions as consensus_math.h's unanimous_fast_path, arranged for the
 // GPU — the four likelihoods stay in registers (selects instead of dynamic indexing, which would go through scratch
 // memory) and the bracket q with thresholds[q] <= gap < thresholds[q+1] comes from the qguess hint plus ONE parallel
@@ -1000,7 +1054,9 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
   extern __shared__ __align__(16) uint8_t dyn[];
   __shared__ ConsensusTables sT;          // thresholds / cerr_min / scalars (and the plain tables for reference)
   __shared__ __align__(16) double sPair[94][2];   // {correct[q], error_per_alt[q]} interleaved: one ds_read_b128 per observation
+  __shared__ uint8_t sTagCls[256];                // aux value type classes (aux_walk)
   {
+    fill_tag_classes(sTagCls);
     const uint64_t* src = (const uint64_t*)&P.T->t;
     uint64_t* dst = (uint64_t*)&sT;
     for (uint32_t i = threadIdx.x; i < sizeof(ConsensusTables) / 8; i += blockDim.x) dst[i] = src[i];
@@ -1129,36 +1185,14 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
       }
       // aux walk in LDS (tags.rs:13-34): first occurrence of MC / <tag> / RX / <cell tag>
       const uint32_t a0 = lo + (uint32_t)aux_off, an = len - (uint32_t)aux_off;
-      uint32_t q = 0, mc_lo = 0, mc_len = 0;
-      bool has_mc = false, seen_mc = false, seen_mi = false, seen_rx = false, seen_cb = false;
-      const uint32_t key_mi = (uint32_t)(uint8_t)P.tag0 | ((uint32_t)(uint8_t)P.tag1 << 8);
-      const uint32_t key_cb = (uint32_t)(uint8_t)P.cell0 | ((uint32_t)(uint8_t)P.cell1 << 8);
-      while (q + 3 <= an) {
-        const uint32_t hd = ld32u(W, a0 + q);
-        const uint32_t key = hd & 0xFFFF, vt = (hd >> 16) & 0xFF;
-        uint32_t size = 0;
-        int fixed = bam::tag_fixed_size((uint8_t)vt);
-        int zend = -1;
-        bool stop = false;
-        if (fixed > 0) size = (uint32_t)fixed;
-        else if (vt == 'Z' || vt == 'H') { zend = find_nul64(W, a0 + q + 3, an - (q + 3)); if (zend < 0) break; size = (uint32_t)zend + 1; }
-        else if (vt == 'B') {
-          if (an - (q + 3) < 5) break;
-          int es = bam::tag_fixed_size((uint8_t)(hd >> 24));
-          if (es == 0) stop = true;
-          else { unsigned long long sz = 5ull + (unsigned long long)ld32u(W, a0 + q + 4) * (unsigned long long)es; if (sz > 0xFFFFFFFFull) break; size = (uint32_t)sz; }
-        } else stop = true;
-        const bool isz = (vt == 'Z') && !stop;
-        const uint32_t vlo = a0 + q + 3;
-        if (!seen_mc && key == ('M' | ('C' << 8))) { seen_mc = true; if (isz) { has_mc = true; mc_lo = vlo; mc_len = (uint32_t)zend; } }
-        if (!seen_mi && key == key_mi) { seen_mi = true; if (isz) { if (zend > 255) bad = true; else { has_mi = true; mi_lo = vlo; mi_len = (uint32_t)zend; } } }
-        if (!seen_rx && key == ('R' | ('X' << 8))) { seen_rx = true; if (isz) { if (zend > 255) bad = true; else { has_rx = true; rx_lo = vlo; rx_len = (uint32_t)zend; } } }
-        if (!seen_cb && P.cell0 && key == key_cb) { seen_cb = true; if (isz) { if (zend > 255) bad = true; else { has_cb = true; cb_lo = vlo; cb_len = (uint32_t)zend; } } }
-        if (stop) break;
-        unsigned long long nq = (unsigned long long)q + 3 + size;
-        if (nq > an) break;
-        q = (uint32_t)nq;
-      }
+      AuxTags ax;
+      aux_walk(W, sTagCls, a0, an, P, ax);
+      if (ax.oddw) bad = true;
+      const bool has_mc = (ax.got & 1u) != 0;
+      const uint32_t mc_lo = ax.pk_mc & 0xFFFF, mc_len = ax.pk_mc >> 16;
+      has_mi = (ax.got & 2u) != 0; mi_lo = ax.pk_mi & 0xFFFF; mi_len = ax.pk_mi >> 16;
+      has_rx = (ax.got & 4u) != 0; rx_lo = ax.pk_rx & 0xFFFF; rx_len = ax.pk_rx >> 16;
+      has_cb = (ax.got & 8u) != 0; cb_lo = ax.pk_cb & 0xFFFF; cb_len = ax.pk_cb >> 16;
       if (MODE == 1) {   // strand from the MI suffix; every paired read needs `<id>/A` or `<id>/B` (duplex_caller.rs:2557-2566: fatal otherwise)
         if (has_mi && mi_len >= 2 && W[mi_lo + mi_len - 2] == '/') { const uint8_t sc = W[mi_lo + mi_len - 1]; strand = sc == 'A' ? 1u : sc == 'B' ? 2u : 0u; }
         if ((flags & bam::F_PAIRED) && (strand == 0 || P.prefix_len + 1 + (mi_len - 2) >= 255)) bad = true;
