@@ -19,9 +19,15 @@
 //
 // The translation unit that includes this header MUST be compiled with
 // -ffp-contract=off (hipcc defaults to `fast`), otherwise the compiler would fuse the
-// non-fused expressions and break bit-exactness.  `tests/test_glibc_libm.py` checks these
-// functions against the box's real libm over many millions of arguments (host build) and
-// `tests/test_gpu_libm.py` does the same for the device build.
+// non-fused expressions and break bit-exactness.  `tests/test_cpu_library.py`
+// (test_glibc_port_matches_box_libm) checks these functions against the box's real libm
+// (host build), `tests/test_gpu_parity.py` (test_device_libm_bit_exact) does the same for the
+// device build, and `fgx_create` repeats a 7 168-point comparison in every process.
+//
+// Licence note: these routines restate glibc's algorithms and carry its constants (glibc is
+// LGPL-2.1-or-later; Szabolcs Nagy's exp / log come from ARM optimized-routines, MIT OR
+// Apache-2.0 WITH LLVM-exception; log1p / expm1 are fdlibm-derived, Sun Microsystems permissive
+// notice).  Treat this file and glibc_tables.h as derived from those sources.
 #pragma once
 #include <stdint.h>
 #include <string.h>
