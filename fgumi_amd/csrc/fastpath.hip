@@ -224,6 +224,111 @@ __device__ inline void alignment_filter(Shared& S, uint32_t e, uint32_t n) {
 }
 
 
+// ---- wavefront helpers, unaligned LDS words, the aux walk (shared by every family kernel) ----------------------------
+constexpr int WAVES_PER_BLOCK = 4;
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ uint32_t rlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) { for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_xor(v, o); v = t > v ? t : v; } return v; }
+__device__ __forceinline__ uint32_t wave_min(uint32_t v) { for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_xor(v, o); v = t < v ? t : v; } return v; }
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
+__device__ __forceinline__ unsigned long long wave_max64(unsigned long long v) { for (int o = 32; o > 0; o >>= 1) { unsigned long long t = __shfl_xor(v, o); v = t > v ? t : v; } return v; }
+__device__ __forceinline__ unsigned long long wave_min64(unsigned long long v) { for (int o = 32; o > 0; o >>= 1) { unsigned long long t = __shfl_xor(v, o); v = t < v ? t : v; } return v; }
+__device__ __forceinline__ uint8_t comp_code(uint8_t c) { return (uint8_t)((0xF7B3D591E6A2C480ULL >> (4 * (c & 15))) & 15); }
+
+// unaligned LDS reads built from aligned dwords (v_alignbyte_b32)
+__device__ __forceinline__ uint32_t ldsw(const uint8_t* W, uint32_t o) { return *(const uint32_t*)(W + o); }
+#ifndef FGX_LDS_UNALIGNED
+#define FGX_LDS_UNALIGNED 1   /* gfx950 LDS takes unaligned ds_read_b32 / b64: one instruction instead of two or three aligned reads + alignbyte */
+#endif
+__device__ __forceinline__ uint32_t ld32u(const uint8_t* W, uint32_t o) {
+#if FGX_LDS_UNALIGNED
+  uint32_t v;
+  __builtin_memcpy(&v, W + o, 4);
+  return v;
+#else
+  uint32_t a = o & ~3u;
+  return __builtin_amdgcn_alignbyte(ldsw(W, a + 4), ldsw(W, a), o & 3);
+#endif
+}
+__device__ __forceinline__ unsigned long long ld64u(const uint8_t* W, uint32_t o) {
+#if FGX_LDS_UNALIGNED
+  unsigned long long v;
+  __builtin_memcpy(&v, W + o, 8);
+  return v;
+#else
+  uint32_t a = o & ~3u, sh = o & 3;
+  uint32_t w0 = ldsw(W, a), w1 = ldsw(W, a + 4), w2 = ldsw(W, a + 8);
+  return (unsigned long long)__builtin_amdgcn_alignbyte(w1, w0, sh) | ((unsigned long long)__builtin_amdgcn_alignbyte(w2, w1, sh) << 32);
+#endif
+}
+// offset of the first NUL in W[o, o+n), 8 bytes per step; -1 if none
+__device__ __forceinline__ int find_nul64(const uint8_t* W, uint32_t o, uint32_t n) {
+  for (uint32_t i = 0; i < n; i += 8) {
+    unsigned long long v = ld64u(W, o + i);
+    unsigned long long t = (v - 0x0101010101010101ULL) & ~v & 0x8080808080808080ULL;
+    if (t) { uint32_t k = i + ((uint32_t)__builtin_ctzll(t) >> 3); return k < n ? (int)k : -1; }
+  }
+  return -1;
+}
+
+// Aux walk of one record per lane, in LDS (tags.rs:13-34): first occurrence of MC / <tag> / RX / <cell tag>.
+// The walk keeps its state in integer lanes (bit 0 MC, 1 <tag>, 2 RX, 3 <cell tag>) and picks with selects: boolean state
+// would live in scalar lane masks, and every `if` on it costs scalar mask instructions for all 64 records.
+struct AuxTags {
+  uint32_t got, oddw;                          // keys found with a Z value ; <tag> / RX / <cell tag> values longer than 255 bytes
+  uint32_t pk_mc, pk_mi, pk_rx, pk_cb;         // value offset in LDS | value length << 16
+};
+// cls: aux value type -> 1 / 2 / 4 (fixed size), 8 (Z), 16 (H), 32 (B), 0 (unknown)
+__device__ __forceinline__ void fill_tag_classes(uint8_t* cls) {
+  for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
+    const int fx = bam::tag_fixed_size((uint8_t)i);
+    cls[i] = (uint8_t)(fx ? fx : i == 'Z' ? 8 : i == 'H' ? 16 : i == 'B' ? 32 : 0);
+  }
+}
+__device__ __forceinline__ void aux_walk(const uint8_t* W, const uint8_t* cls_of, uint32_t a0, uint32_t an, const FastParams& P, AuxTags& A) {
+  uint32_t q = 0, seen = 0, got = 0, oddw = 0;
+  uint32_t pk_mc = 0, pk_mi = 0, pk_rx = 0, pk_cb = 0;
+  const uint32_t key_mi = (uint32_t)(uint8_t)P.tag0 | ((uint32_t)(uint8_t)P.tag1 << 8);
+  const uint32_t key_cb = P.cell0 ? ((uint32_t)(uint8_t)P.cell0 | ((uint32_t)(uint8_t)P.cell1 << 8)) : 0xFFFFFFFFu;   // (no key is > 0xFFFF)
+  while (q + 3 <= an) {
+    const uint32_t hd = ld32u(W, a0 + q);
+    const uint32_t key = hd & 0xFFFF, cls = cls_of[(hd >> 16) & 0xFF];
+    const uint32_t rem = an - (q + 3);
+    uint32_t size = cls & 7, zend = 0;
+    uint32_t stop = cls == 0 ? 1u : 0u;                    // a key match at an entry of unknown size still counts as seen
+    if (cls & 24) {
+      const int z = find_nul64(W, a0 + q + 3, rem);
+      if (z < 0) break;                                    // unterminated: nothing here or after it is reachable
+      zend = (uint32_t)z; size = zend + 1;
+    }
+    if (cls & 32) {
+      if (rem < 5) break;
+      const uint32_t es = cls_of[hd >> 24] & 7;
+      const unsigned long long sz = 5ull + (unsigned long long)ld32u(W, a0 + q + 4) * (unsigned long long)es;
+      if (sz > 0xFFFFFFFFull) break;
+      size = (uint32_t)sz;
+      stop = es == 0 ? 1u : 0u;
+    }
+    const uint32_t kb = (key == ('M' | ('C' << 8)) ? 1u : 0u) | (key == key_mi ? 2u : 0u) | (key == ('R' | ('X' << 8)) ? 4u : 0u) | (key == key_cb ? 8u : 0u);
+    const uint32_t fresh = kb & ~seen;                     // first occurrence of its key
+    seen |= kb;
+    const uint32_t zb = cls == 8 ? fresh : 0u;             // ... with a Z value
+    const uint32_t rec = zend > 255 ? (zb & 1u) : zb;      // values longer than 255 bytes: only MC may be (it is then not `<n>M`)
+    oddw |= zb & ~rec;
+    got |= rec;
+    const uint32_t pk = (a0 + q + 3) | ((zend < 0xFFFFu ? zend : 0xFFFFu) << 16);
+    pk_mc = (rec & 1u) ? pk : pk_mc; pk_mi = (rec & 2u) ? pk : pk_mi; pk_rx = (rec & 4u) ? pk : pk_rx; pk_cb = (rec & 8u) ? pk : pk_cb;
+    const unsigned long long nq = (unsigned long long)q + 3 + size;
+    if (stop || nq > an) break;
+    q = (uint32_t)nq;
+  }
+  A.got = got; A.oddw = oddw; A.pk_mc = pk_mc; A.pk_mi = pk_mi; A.pk_rx = pk_rx; A.pk_cb = pk_cb;
+}
+
 #ifndef FGX_PHASE_TIMING
 #define FGX_PHASE_TIMING 0   /* 1: per-phase s_memtime deltas of k_family_wave into g_phase (profiling builds only) */
 #endif
@@ -242,8 +347,10 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
   extern __shared__ __align__(16) uint8_t dyn[];
   __shared__ Shared S;
   __shared__ __align__(16) double sPairB[94][2];   // {correct[q], error_per_alt[q]}: one LDS read per observation instead of two global ones
+  __shared__ uint8_t sTagCls[256];                 // aux value type classes (aux_walk)
   const uint32_t tid = threadIdx.x;
   if (tid < 94) { sPairB[tid][0] = P.T->t.correct[tid]; sPairB[tid][1] = P.T->t.error_per_alt[tid]; }
+  fill_tag_classes(sTagCls);
   const uint32_t g = P.group_list ? P.group_list[blockIdx.x] : P.g0 + blockIdx.x;
   const uint32_t r0 = P.grp_first[g], r1 = P.grp_first[g + 1];
   const uint32_t n = r1 - r0;
@@ -339,62 +446,18 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
           }
         }
         // aux walk: first occurrence of MC / <tag> / RX / <cell tag>; malformed aux stops the walk (tags.rs:13-34)
-        const uint8_t* aux = p + aux_off;
-        uint32_t an = (uint32_t)(len - aux_off);
-        uint32_t q = 0;
+        const uint32_t lo_r = (uint32_t)(off - base16);            // LDS offset of this record
+        if ((unsigned long long)lo_r + len > 65535ull) bad = true;  // (the walk packs LDS offsets into 16 bits: tiles beyond 64 KB defer)
         int mc_off = -1; uint32_t mc_len = 0;
-        bool seen_mc = false, seen_mi = false, seen_rx = false, seen_cb = false;
-        while (q + 3 <= an) {
-          uint8_t t0 = aux[q], t1 = aux[q + 1], vt = aux[q + 2];
-          uint32_t size = 0;
-          int fixed = bam::tag_fixed_size(vt);
-          int64_t zend = -1;
-          if (fixed > 0) size = (uint32_t)fixed;
-          else if (vt == 'Z' || vt == 'H') {
-            zend = bam::find_nul(aux + q + 3, an - (q + 3));
-            if (zend < 0) {   // unterminated: a matching key reads as None, everything after is unreachable
-              break;
-            }
-            size = (uint32_t)zend + 1;
-          } else if (vt == 'B') {
-            if (an - (q + 3) < 5) break;
-            int es = bam::tag_fixed_size(aux[q + 3]);
-            if (es == 0) {
-              // value size unknown: a key match at this position is still found first (type != Z → None)
-              if (t0 == 'M' && t1 == 'C') seen_mc = true;
-              if (t0 == (uint8_t)P.tag0 && t1 == (uint8_t)P.tag1) seen_mi = true;
-              if (t0 == 'R' && t1 == 'X') seen_rx = true;
-              if (t0 == (uint8_t)P.cell0 && t1 == (uint8_t)P.cell1) seen_cb = true;
-              break;
-            }
-            uint64_t s = 5ull + (uint64_t)rd32(aux + q + 4) * (uint64_t)es;
-            if (s > 0xFFFFFFFFull) break;
-            size = (uint32_t)s;
-          } else {
-            if (t0 == 'M' && t1 == 'C') seen_mc = true;
-            if (t0 == (uint8_t)P.tag0 && t1 == (uint8_t)P.tag1) seen_mi = true;
-            if (t0 == 'R' && t1 == 'X') seen_rx = true;
-            if (t0 == (uint8_t)P.cell0 && t1 == (uint8_t)P.cell1) seen_cb = true;
-            break;
-          }
-          bool isz = (vt == 'Z');
-          uint32_t voff = (uint32_t)aux_off + q + 3;
-          if (!seen_mc && t0 == 'M' && t1 == 'C') { seen_mc = true; if (isz) { mc_off = (int)voff; mc_len = (uint32_t)zend; } }
-          if (!seen_mi && t0 == (uint8_t)P.tag0 && t1 == (uint8_t)P.tag1) {
-            seen_mi = true;
-            if (isz) { if (zend > 255 || voff > 65535) bad = true; else { R.has_mi = 1; R.mi_off = (uint16_t)voff; R.mi_len = (uint8_t)zend; } }
-          }
-          if (!seen_rx && t0 == 'R' && t1 == 'X') {
-            seen_rx = true;
-            if (isz) { if (zend > 255 || voff > 65535) bad = true; else { R.has_rx = 1; R.rx_off = (uint16_t)voff; R.rx_len = (uint8_t)zend; } }
-          }
-          if (!seen_cb && P.cell0 && t0 == (uint8_t)P.cell0 && t1 == (uint8_t)P.cell1) {
-            seen_cb = true;
-            if (isz) { if (zend > 255 || voff > 65535) bad = true; else { R.has_cb = 1; R.cb_off = (uint16_t)voff; R.cb_len = (uint8_t)zend; } }
-          }
-          uint64_t nq = (uint64_t)q + 3 + size;
-          if (nq > an) break;
-          q = (uint32_t)nq;
+        {
+          AuxTags ax;
+          aux_walk(dyn, sTagCls, lo_r + (uint32_t)aux_off, (uint32_t)(len - aux_off), P, ax);
+          if (ax.oddw) bad = true;                                  // <tag> / RX / <cell tag> value longer than 255 bytes
+          if (ax.got & 1u) { mc_off = (int)((ax.pk_mc & 0xFFFF) - lo_r); mc_len = ax.pk_mc >> 16; }
+          const uint32_t mi_o = (ax.pk_mi & 0xFFFF) - lo_r, rx_o = (ax.pk_rx & 0xFFFF) - lo_r, cb_o = (ax.pk_cb & 0xFFFF) - lo_r;
+          if (ax.got & 2u) { R.has_mi = 1; R.mi_off = (uint16_t)mi_o; R.mi_len = (uint8_t)(ax.pk_mi >> 16); }
+          if (ax.got & 4u) { R.has_rx = 1; R.rx_off = (uint16_t)rx_o; R.rx_len = (uint8_t)(ax.pk_rx >> 16); }
+          if (ax.got & 8u) { R.has_cb = 1; R.cb_off = (uint16_t)cb_o; R.cb_len = (uint8_t)(ax.pk_cb >> 16); }
         }
         if (!bad && !R.excluded) {
           // mate-overlap clip (raw-bam/overlap.rs:181-207)
@@ -404,10 +467,20 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
           uint64_t clip = bam::mate_clip(v, ops, n_ops, mc_off >= 0 ? p + mc_off : nullptr, mc_len, mops, MAX_MC_OPS, &overflow);
           if (overflow) bad = true;
           R.clip = (uint16_t)(clip > 65535 ? 65535 : clip);
-          // FNV-1a over the read name, for mate pairing
-          uint32_t h = 2166136261u;
-          for (uint32_t i = 0; i < R.name_len; i++) { h ^= p[32 + i]; h *= 16777619u; }
-          R.name_hash = h;
+          // name hash for mate pairing (a filter: candidates are compared word by word below): whole 8-byte steps, then one step
+          // over the LAST 8 bytes (it may overlap)
+          {
+            const uint32_t nl = R.name_len;
+            uint32_t h = nl, i = 0;
+            for (; i + 8 <= nl; i += 8) { h = __builtin_rotateleft32(h, 5) ^ ld32u(dyn, lo_r + 32 + i); h = __builtin_rotateleft32(h, 11) + ld32u(dyn, lo_r + 36 + i); }
+            if (i < nl) {
+              uint32_t w0, w1;
+              if (nl >= 8) { w0 = ld32u(dyn, lo_r + 24 + nl); w1 = ld32u(dyn, lo_r + 28 + nl); }
+              else { const unsigned long long v = ld64u(dyn, lo_r + 32) & ((1ULL << (8 * nl)) - 1ULL); w0 = (uint32_t)v; w1 = (uint32_t)(v >> 32); }
+              h = __builtin_rotateleft32(h, 5) ^ w0; h = __builtin_rotateleft32(h, 11) + w1;
+            }
+            R.name_hash = h ^ (h >> 15) ^ (h << 7);
+          }
         }
       }
     }
@@ -477,7 +550,6 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
       for (uint32_t a = wave_p; a < n; a += NT / 64) {
         const ReadInfo& R = S.ri[a];
         if (R.excluded || !(R.flags & bam::F_FIRST)) continue;
-        const uint8_t* nm = blobL + R.goff + 32;
         const uint32_t rh = R.name_hash, rl_ = R.name_len;
         uint64_t later_r1[2], r2s[2];
         for (int c = 0; c < 2; c++) {
@@ -489,9 +561,15 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
               const bool first = (O.flags & bam::F_FIRST) != 0;
               const bool cand = first ? (u > a) : ((O.flags & bam::F_LAST) != 0);
               if (cand) {
-                const uint8_t* on = blobL + O.goff + 32;
-                bool same = true;
-                for (uint32_t i = 0; i < rl_ && same; i++) same = on[i] == nm[i];
+                const uint32_t on = (uint32_t)(O.goff - base16) + 32, nn = (uint32_t)(R.goff - base16) + 32;
+                unsigned long long diff = 0;                  // whole 8-byte steps + the last 8 bytes (names of one length)
+                uint32_t i = 0;
+                for (; i + 8 <= rl_; i += 8) diff |= ld64u(dyn, on + i) ^ ld64u(dyn, nn + i);
+                if (i < rl_) {
+                  if (rl_ >= 8) diff |= ld64u(dyn, on + rl_ - 8) ^ ld64u(dyn, nn + rl_ - 8);
+                  else diff |= (ld64u(dyn, on) ^ ld64u(dyn, nn)) & ((1ULL << (8 * rl_)) - 1ULL);
+                }
+                const bool same = diff == 0;
                 is_later_r1 = same && first; is_r2 = same && !first;
               }
             }
@@ -533,8 +611,11 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
       if (rla == 0 || rlb == 0) continue;
       const int64_t s1 = (int64_t)A.pos + 1, e1 = (int64_t)A.pos + rla, s2 = (int64_t)B.pos + 1, e2 = (int64_t)B.pos + rlb;
       const int64_t lo = s1 > s2 ? s1 : s2, hi = e1 < e2 ? e1 : e2;
+      const bool plain = !S.any_complex;                     // both reads are one aligned block: query offset = x - start
       for (int64_t x = lo + lane; x <= hi; x += 64) {
-        const int32_t i1 = map_ref_to_query(oa, na, s1, x, A.l_seq), i2 = map_ref_to_query(ob, nb, s2, x, B.l_seq);
+        int32_t i1, i2;
+        if (plain) { i1 = (int32_t)(x - s1); i2 = (int32_t)(x - s2); }
+        else { i1 = map_ref_to_query(oa, na, s1, x, A.l_seq); i2 = map_ref_to_query(ob, nb, s2, x, B.l_seq); }
         if (i1 < 0 || i2 < 0) continue;
         const uint32_t ia = A.row + (uint32_t)i1, ib = B.row + (uint32_t)i2;
         uint8_t c1 = lb[ia], c2 = lb[ib];
@@ -887,110 +968,6 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
 // state lives in lane r's registers and is broadcast with v_readlane, the family gates are ballots and
 // popcounts — no serial lane-0 section and no block barrier.  Semantics identical to k_family below.
 // -----------------------------------------------------------------------------------------------------
-constexpr int WAVES_PER_BLOCK = 4;
-
-__device__ __forceinline__ void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
-__device__ __forceinline__ uint32_t rlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
-__device__ __forceinline__ uint32_t wave_max(uint32_t v) { for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_xor(v, o); v = t > v ? t : v; } return v; }
-__device__ __forceinline__ uint32_t wave_min(uint32_t v) { for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_xor(v, o); v = t < v ? t : v; } return v; }
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
-__device__ __forceinline__ unsigned long long wave_max64(unsigned long long v) { for (int o = 32; o > 0; o >>= 1) { unsigned long long t = __shfl_xor(v, o); v = t > v ? t : v; } return v; }
-__device__ __forceinline__ unsigned long long wave_min64(unsigned long long v) { for (int o = 32; o > 0; o >>= 1) { unsigned long long t = __shfl_xor(v, o); v = t < v ? t : v; } return v; }
-__device__ __forceinline__ uint8_t comp_code(uint8_t c) { return (uint8_t)((0xF7B3D591E6A2C480ULL >> (4 * (c & 15))) & 15); }
-
-// unaligned LDS reads built from aligned dwords (v_alignbyte_b32)
-__device__ __forceinline__ uint32_t ldsw(const uint8_t* W, uint32_t o) { return *(const uint32_t*)(W + o); }
-#ifndef FGX_LDS_UNALIGNED
-#define FGX_LDS_UNALIGNED 1   /* gfx950 LDS takes unaligned ds_read_b32 / b64: one instruction instead of two or three aligned reads + alignbyte */
-#endif
-__device__ __forceinline__ uint32_t ld32u(const uint8_t* W, uint32_t o) {
-#if FGX_LDS_UNALIGNED
-  uint32_t v;
-  __builtin_memcpy(&v, W + o, 4);
-  return v;
-#else
-  uint32_t a = o & ~3u;
-  return __builtin_amdgcn_alignbyte(ldsw(W, a + 4), ldsw(W, a), o & 3);
-#endif
-}
-__device__ __forceinline__ unsigned long long ld64u(const uint8_t* W, uint32_t o) {
-#if FGX_LDS_UNALIGNED
-  unsigned long long v;
-  __builtin_memcpy(&v, W + o, 8);
-  return v;
-#else
-  uint32_t a = o & ~3u, sh = o & 3;
-  uint32_t w0 = ldsw(W, a), w1 = ldsw(W, a + 4), w2 = ldsw(W, a + 8);
-  return (unsigned long long)__builtin_amdgcn_alignbyte(w1, w0, sh) | ((unsigned long long)__builtin_amdgcn_alignbyte(w2, w1, sh) << 32);
-#endif
-}
-// offset of the first NUL in W[o, o+n), 8 bytes per step; -1 if none
-__device__ __forceinline__ int find_nul64(const uint8_t* W, uint32_t o, uint32_t n) {
-  for (uint32_t i = 0; i < n; i += 8) {
-    unsigned long long v = ld64u(W, o + i);
-    unsigned long long t = (v - 0x0101010101010101ULL) & ~v & 0x8080808080808080ULL;
-    if (t) { uint32_t k = i + ((uint32_t)__builtin_ctzll(t) >> 3); return k < n ? (int)k : -1; }
-  }
-  return -1;
-}
-
-// Aux walk of one record per lane, in LDS (tags.rs:13-34): first occurrence of MC / <tag> / RX / <cell tag>.
-// The walk keeps its state in integer lanes (bit 0 MC, 1 <tag>, 2 RX, 3 <cell tag>) and picks with selects: boolean state
-// would live in scalar lane masks, and every `if` on it costs scalar mask instructions for all 64 records.
-struct AuxTags {
-  uint32_t got, oddw;                          // keys found with a Z value ; <tag> / RX / <cell tag> values longer than 255 bytes
-  uint32_t pk_mc, pk_mi, pk_rx, pk_cb;         // value offset in LDS | value length << 16
-};
-// cls: aux value type -> 1 / 2 / 4 (fixed size), 8 (Z), 16 (H), 32 (B), 0 (unknown)
-__device__ __forceinline__ void fill_tag_classes(uint8_t* cls) {
-  for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
-    const int fx = bam::tag_fixed_size((uint8_t)i);
-    cls[i] = (uint8_t)(fx ? fx : i == 'Z' ? 8 : i == 'H' ? 16 : i == 'B' ? 32 : 0);
-  }
-}
-__device__ __forceinline__ void aux_walk(const uint8_t* W, const uint8_t* cls_of, uint32_t a0, uint32_t an, const FastParams& P, AuxTags& A) {
-  uint32_t q = 0, seen = 0, got = 0, oddw = 0;
-  uint32_t pk_mc = 0, pk_mi = 0, pk_rx = 0, pk_cb = 0;
-  const uint32_t key_mi = (uint32_t)(uint8_t)P.tag0 | ((uint32_t)(uint8_t)P.tag1 << 8);
-  const uint32_t key_cb = P.cell0 ? ((uint32_t)(uint8_t)P.cell0 | ((uint32_t)(uint8_t)P.cell1 << 8)) : 0xFFFFFFFFu;   // (no key is > 0xFFFF)
-  while (q + 3 <= an) {
-    const uint32_t hd = ld32u(W, a0 + q);
-    const uint32_t key = hd & 0xFFFF, cls = cls_of[(hd >> 16) & 0xFF];
-    const uint32_t rem = an - (q + 3);
-    uint32_t size = cls & 7, zend = 0;
-    uint32_t stop = cls == 0 ? 1u : 0u;                    // a key match at an entry of unknown size still counts as seen
-    if (cls & 24) {
-      const int z = find_nul64(W, a0 + q + 3, rem);
-      if (z < 0) break;                                    // unterminated: nothing here or after it is reachable
-      zend = (uint32_t)z; size = zend + 1;
-    }
-    if (cls & 32) {
-      if (rem < 5) break;
-      const uint32_t es = cls_of[hd >> 24] & 7;
-      const unsigned long long sz = 5ull + (unsigned long long)ld32u(W, a0 + q + 4) * (unsigned long long)es;
-      if (sz > 0xFFFFFFFFull) break;
-      size = (uint32_t)sz;
-      stop = es == 0 ? 1u : 0u;
-    }
-    const uint32_t kb = (key == ('M' | ('C' << 8)) ? 1u : 0u) | (key == key_mi ? 2u : 0u) | (key == ('R' | ('X' << 8)) ? 4u : 0u) | (key == key_cb ? 8u : 0u);
-    const uint32_t fresh = kb & ~seen;                     // first occurrence of its key
-    seen |= kb;
-    const uint32_t zb = cls == 8 ? fresh : 0u;             // ... with a Z value
-    const uint32_t rec = zend > 255 ? (zb & 1u) : zb;      // values longer than 255 bytes: only MC may be (it is then not `<n>M`)
-    oddw |= zb & ~rec;
-    got |= rec;
-    const uint32_t pk = (a0 + q + 3) | ((zend < 0xFFFFu ? zend : 0xFFFFu) << 16);
-    pk_mc = (rec & 1u) ? pk : pk_mc; pk_mi = (rec & 2u) ? pk : pk_mi; pk_rx = (rec & 4u) ? pk : pk_rx; pk_cb = (rec & 8u) ? pk : pk_cb;
-    const unsigned long long nq = (unsigned long long)q + 3 + size;
-    if (stop || nq > an) break;
-    q = (uint32_t)nq;
-  }
-  A.got = got; A.oddw = oddw; A.pk_mc = pk_mc; A.pk_mi = pk_mi; A.pk_rx = pk_rx; A.pk_cb = pk_cb;
-}
-
 // column_call_fast for the wave kernel: same decisions as consensus_math.h's unanimous_fast_path, arranged for the
 // GPU — the four likelihoods stay in registers (selects instead of dynamic indexing, which would go through scratch
 // memory) and the bracket q with thresholds[q] <= gap < thresholds[q+1] comes from the qguess hint plus ONE parallel
