@@ -226,6 +226,9 @@ __device__ inline void alignment_filter(Shared& S, uint32_t e, uint32_t n) {
 
 // ---- wavefront helpers, unaligned LDS words, the aux walk (shared by every family kernel) ----------------------------
 constexpr int WAVES_PER_BLOCK = 4;
+#ifndef FGX_W2_WPB_DEFAULT
+#define FGX_W2_WPB_DEFAULT 3
+#endif
 
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -289,7 +292,8 @@ __device__ __forceinline__ void fill_tag_classes(uint8_t* cls) {
     cls[i] = (uint8_t)(fx ? fx : i == 'Z' ? 8 : i == 'H' ? 16 : i == 'B' ? 32 : 0);
   }
 }
-__device__ __forceinline__ void aux_walk(const uint8_t* W, const uint8_t* cls_of, uint32_t a0, uint32_t an, const FastParams& P, AuxTags& A) {
+template <class ParamsT>
+__device__ __forceinline__ void aux_walk(const uint8_t* W, const uint8_t* cls_of, uint32_t a0, uint32_t an, const ParamsT& P, AuxTags& A) {
   uint32_t q = 0, seen = 0, got = 0, oddw = 0;
   uint32_t pk_mc = 0, pk_mi = 0, pk_rx = 0, pk_cb = 0;
   const uint32_t key_mi = (uint32_t)(uint8_t)P.tag0 | ((uint32_t)(uint8_t)P.tag1 << 8);
@@ -1085,6 +1089,9 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
   // simplex families go to the workgroup-per-family kernel, duplex / CODEC molecules to the general path
   auto to_retry = [&]() { if (!P.retry) { to_defer(); return; } if (lane == 0) { uint32_t k = atomicAdd(P.n_retry, 1u); P.retry[k] = g; } };
   if (n > 64) { if (MODE == 0) to_retry(); else to_defer(); return; }
+  // an empty group has no byte span (the minimum below would be ~0 and the staging loop would read the 16 bytes BEFORE the blob —
+  // a fault when the blob starts an allocation): the general path emits its nothing
+  if (n == 0) { to_defer(); return; }
 
 #if FGX_PHASE_TIMING
   unsigned long long _t = __builtin_amdgcn_s_memtime();
@@ -3169,7 +3176,7 @@ __global__ void k_reduce_stats(const unsigned long long* __restrict__ slots, uns
 // -----------------------------------------------------------------------------------------------------
 void FastPath::release() {
   for (DevBuf* b : {&d_ends, &d_sizes, &d_offsets, &d_code, &d_qual, &d_depth, &d_err, &d_misc, &d_deferred, &d_out, &d_scan_tmp, &d_strings, &d_obs, &d_retry2,
-                    &d_retry, &d_bound, &d_colbase, &d_statslots, &d_full_items, &d_full_count, &d_retry_old})
+                    &d_retry, &d_bound, &d_colbase, &d_statslots, &d_full_items, &d_full_count, &d_retry_old, &d_w2img})
     b->free_();
   for (int i = 0; i < 4; i++) if (ev[i]) { (void)hipEventDestroy(ev[i]); ev[i] = nullptr; }
 }
@@ -3295,6 +3302,14 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
         (void)hipGetLastError();
         v2_attr_set = true;
       }
+      if (!d_w2img.p) {   // the tables of a caller never change: one image per FastPath
+        W2Lds img;
+        build_w2_image(img, c->h_tables.t);
+        d_w2img.reserve(sizeof(W2Lds));
+        hip_check(hipMemcpyAsync(d_w2img.p, &img, sizeof(W2Lds), hipMemcpyHostToDevice, s), "H2D w2 image");
+        hip_check(hipStreamSynchronize(s), "sync");             // (`img` is on this stack frame)
+      }
+      P.w2_image = d_w2img.p;
       struct Stage { int fam_per_wave; uint32_t bytes; uint32_t wpb; };
       std::vector<Stage> chain;
       const double mean_span = (double)blob_len / (double)n_grp + 48.0;   // mean bytes of a family + alignment / read-ahead slack
@@ -3308,7 +3323,10 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
       // in persistent workgroups, 19.3 ms, against 10.2 ms per 1 M depth-8 families here: they execute 20 % fewer vector and 43 %
       // fewer scalar instructions, but a lone wavefront retires an instruction every ~30 cycles, and the CU is fed by the number of
       // independent wavefronts, not by lane utilisation.  profiles/r02c_pmc_1M_blk.json, r02d_pmc_1M_pipe.json)
-      for (int st = 0; st < 3; st++) if (st == 0 || stages[st] > stages[st - 1]) chain.push_back({1, stages[st], st == 0 ? (uint32_t)WAVES_PER_BLOCK : st == 1 ? 2u : 1u});
+      // wavefronts per workgroup of k_simplex_wave2's first launch: the LDS of a workgroup is freed when its SLOWEST wavefront is
+      // done, so small workgroups keep more wavefronts running (FGX_W2_WPB: measurement knob)
+      static const uint32_t w2_wpb = [] { const char* e = getenv("FGX_W2_WPB"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= WAVES_PER_BLOCK ? v : FGX_W2_WPB_DEFAULT); }();
+      for (int st = 0; st < 3; st++) if (st == 0 || stages[st] > stages[st - 1]) chain.push_back({1, stages[st], st == 0 ? w2_wpb : st == 1 ? 2u : 1u});
       d_retry_old.reserve((size_t)n_grp * 4);
       uint32_t* d_cnt_old = (uint32_t*)(misc + 32);
       uint32_t n_v2 = n_grp;

@@ -215,6 +215,20 @@ def test_simplex_depth8_and_long_tail(handle):
     _assert_same(simulate_grouped_reads(300, family_size=3, read_length=151, insert_mean=120, insert_sd=30))   # read-through clips
 
 
+@pytest.mark.parametrize("read_length", [20, 32, 33, 64, 65, 96, 97, 129, 160, 161, 200])
+def test_column_pass_schedule_over_read_lengths(handle, read_length):
+    """k_simplex_wave2 walks 64 columns per pass and takes the two tails of a pair family in ONE merged pass when both are at most
+    32 columns long: lengths on either side of every boundary (no full pass at all, tail of exactly 32 / 33, no tail), with mates
+    that overlap (lengths change with the mate clip) and mates that do not, at depths 2 and 5."""
+    for insert_mean in (read_length * 3, read_length + read_length // 3):
+        for depth in (2, 5):
+            g = simulate_grouped_reads(120, family_size=depth, read_length=read_length, insert_mean=insert_mean, insert_sd=max(2, read_length // 8),
+                                       error_rate_ppm=15000, seed=read_length * 7 + depth)
+            _assert_same(g, min_reads=1)
+    _assert_same(simulate_grouped_reads(120, family_size=4, read_length=read_length, insert_mean=read_length * 3, insert_sd=5, seed=read_length), min_reads=2,
+                 overlapping=False, min_input_base_quality=25)
+
+
 @pytest.mark.parametrize("kw", [dict(min_reads=1), dict(min_reads=3), dict(min_reads=40), dict(overlapping=False, min_reads=2), dict(trim=True), dict(max_reads=20),
                                 dict(min_reads=2, min_input_base_quality=30, produce_per_base_tags=False)])
 def test_large_families_workgroup_kernel(handle, kw):
