@@ -3150,8 +3150,11 @@ __global__ __launch_bounds__(256) void k_emit_codec_fast(CodecEmitParams P) {
 
 // Upper bound on the consensus columns a batch can produce: a family yields at most three ends, each no
 // longer than its longest read, and l_seq <= (block_size - 33) * 2 / 3.
-__global__ void k_col_bound(const uint32_t* __restrict__ grp_first, const uint32_t* __restrict__ rec_len, uint32_t n_grp,
-                            uint64_t* __restrict__ bound, uint32_t max_ends) {
+// Per family: the scratch-column bound, and a descriptor {byte offset of its first record, bytes up to the end of its last record,
+// record count} — with it k_simplex_wave2 starts loading the family's bytes one memory round trip earlier (it needs neither
+// grp_first nor rec_off to know where they are; it checks afterwards that every record lies inside that span).
+__global__ void k_col_bound(const uint32_t* __restrict__ grp_first, const uint32_t* __restrict__ rec_len, const uint64_t* __restrict__ rec_off, uint32_t n_grp,
+                            uint64_t* __restrict__ bound, uint32_t max_ends, uint4* __restrict__ fam_desc) {
   uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n_grp) return;
   uint32_t a = grp_first[g], b = grp_first[g + 1], mx = 0;
@@ -3159,6 +3162,14 @@ __global__ void k_col_bound(const uint32_t* __restrict__ grp_first, const uint32
   uint32_t lb = mx > 33 ? (mx - 33) * 2 / 3 + 1 : 1;
   uint32_t ends = (b - a) < max_ends ? (b - a) : max_ends;
   bound[g] = (uint64_t)ends * lb;
+  uint64_t lo = 0;
+  uint32_t span = 0xFFFFFFFFu;                               // no usable span (empty group, descending or far-apart records)
+  if (b > a) {
+    lo = rec_off[a];
+    const uint64_t hi = rec_off[b - 1] + rec_len[b - 1];
+    if (hi >= lo && hi - lo < 0xFFFFFFFFull) span = (uint32_t)(hi - lo);
+  }
+  fam_desc[g] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), span, b - a);
 }
 
 __global__ void k_reduce_stats(const unsigned long long* __restrict__ slots, unsigned long long* __restrict__ out) {
@@ -3176,7 +3187,7 @@ __global__ void k_reduce_stats(const unsigned long long* __restrict__ slots, uns
 // -----------------------------------------------------------------------------------------------------
 void FastPath::release() {
   for (DevBuf* b : {&d_ends, &d_sizes, &d_offsets, &d_code, &d_qual, &d_depth, &d_err, &d_misc, &d_deferred, &d_out, &d_scan_tmp, &d_strings, &d_obs, &d_retry2,
-                    &d_retry, &d_bound, &d_colbase, &d_statslots, &d_full_items, &d_full_count, &d_retry_old, &d_w2img})
+                    &d_retry, &d_bound, &d_colbase, &d_statslots, &d_full_items, &d_full_count, &d_retry_old, &d_w2img, &d_famdesc})
     b->free_();
   for (int i = 0; i < 4; i++) if (ev[i]) { (void)hipEventDestroy(ev[i]); ev[i] = nullptr; }
 }
@@ -3207,7 +3218,9 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
   d_bound.reserve((size_t)n_grp * 8); d_colbase.reserve((size_t)n_grp * 8);
   d_statslots.reserve((size_t)STAT_SLOTS * 32 * 8);
   hip_check(hipMemsetAsync(d_statslots.p, 0, (size_t)STAT_SLOTS * 32 * 8, s), "memset");
-  hipLaunchKernelGGL(k_col_bound, dim3((n_grp + 255) / 256), dim3(256), 0, s, d_grp_first, d_rec_len, n_grp, d_bound.as<uint64_t>(), duplex ? 4u : codec ? 2u : 3u);
+  d_famdesc.reserve((size_t)n_grp * 16);
+  hipLaunchKernelGGL(k_col_bound, dim3((n_grp + 255) / 256), dim3(256), 0, s, d_grp_first, d_rec_len, d_rec_off, n_grp, d_bound.as<uint64_t>(), duplex ? 4u : codec ? 2u : 3u,
+                     d_famdesc.as<uint4>());
   {
     size_t tb = 0;
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_bound.as<uint64_t>(), d_colbase.as<uint64_t>(), (int)n_grp, s);
@@ -3310,6 +3323,7 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
         hip_check(hipStreamSynchronize(s), "sync");             // (`img` is on this stack frame)
       }
       P.w2_image = d_w2img.p;
+      P.fam_desc = d_famdesc.as<uint4>();
       struct Stage { int fam_per_wave; uint32_t bytes; uint32_t wpb; };
       std::vector<Stage> chain;
       const double mean_span = (double)blob_len / (double)n_grp + 48.0;   // mean bytes of a family + alignment / read-ahead slack
