@@ -55,8 +55,8 @@ struct FastParams {
   uint32_t g0;
   const DeviceTables* T; const DeviceTables* TU;
   uint32_t min_reads; int64_t max_reads;
-  uint8_t min_input_bq, min_cons_bq, trim, overlap, per_base_tags, track_rejects;
-  char tag0, tag1, cell0, cell1;
+  char tag0, tag1, cell0, cell1;   // (dword-aligned: the kernels read them with scalar loads; at odd offsets they came through vector memory)
+  uint32_t min_input_bq, min_cons_bq, trim, overlap, per_base_tags, track_rejects;   // (one dword each: adjacent bytes were fetched as one unaligned vector load)
   uint32_t prefix_len, rg_len;
   EndDesc* ends; uint64_t* rec_sizes;
   uint8_t* col_code; uint8_t* col_qual; uint16_t* col_depth; uint16_t* col_err;
