@@ -67,6 +67,7 @@ struct FastParams {
   uint32_t* retry; uint32_t* n_retry;   // families needing more LDS than this launch provides (nullptr: defer them)
   uint32_t* retry_old; uint32_t* n_retry_old;   // k_simplex_wave2: families outside its record shape → k_family_wave<0>
   const void* w2_image;            // k_simplex_wave2: image of its LDS tables (W2Lds, simplex_wave2.inc)
+  const void* fw_image;            // k_family_wave: image of its LDS tables (FwLds, fastpath.hip)
   const uint4* fam_desc;           // per family {first record offset lo, hi, bytes to the end of the last record (~0: none), records} (k_col_bound)
   uint64_t blob_len;               // records must end inside the blob (checked before the family's bytes are staged)
   uint32_t lds_tile_bytes;
@@ -123,6 +124,7 @@ struct FastPath {
   DevBuf d_retry, d_bound, d_colbase, d_statslots, d_full_items, d_full_count, d_obs, d_retry2, d_retry_old;
   DevBuf d_w2img;                         // W2Lds image, built from the caller's tables at the first batch
   DevBuf d_famdesc;                       // k_col_bound's family descriptors
+  DevBuf d_fwimg;                         // FwLds image (k_family_wave)
   uint32_t lds_wave_bytes = 6144;         // wave-per-family kernel: LDS copy of one family's raw records
   uint32_t lds_wave_bytes_duplex = 8704;  // duplex molecules carry both strands (config 3: 24 records x ~330 B)
   uint32_t lds_wave_bytes_codec = 5120;   // CODEC (config 5: 8 records x ~570 B): its kernel needs 71 VGPRs, so the smaller slice buys a sixth wave per SIMD (+3 %)

@@ -1030,24 +1030,40 @@ __device__ __forceinline__ bool column_call_fast_lds(const ConsensusTables& T, c
 #endif
 // MODE 0: simplex (vanilla caller).  MODE 1: duplex — phases 1-4 are shared, the strand partition, the four single-strand
 // column sets and the descriptors of the two duplex records replace phases 5-8 (see the MODE == 1 branch).
+// What k_family_wave keeps in LDS beside the wave slices, as one block with a host-built image (FastPath::d_fwimg), copied like
+// k_simplex_wave2's (W2Lds): 16-byte loads that leave with the family's first loads, LDS writes after the records are staged.
+struct FwLds {
+  ConsensusTables t;                 // thresholds / cerr_min / scalars (and the plain tables for reference)
+  alignas(16) double pair[94][2];    // {correct[q], error_per_alt[q]} interleaved: one ds_read_b128 per observation
+  uint8_t tagcls[256];               // aux value type classes (aux_walk)
+};
+static_assert(sizeof(FwLds) % 16 == 0 && sizeof(FwLds) <= 6 * 64 * 16, "FwLds is copied in 16-byte pieces, six per thread at most");
+inline void build_fw_image(FwLds& L, const ConsensusTables& t) {
+  memset(&L, 0, sizeof(L));
+  L.t = t;
+  for (uint32_t i = 0; i < 94; i++) { L.pair[i][0] = t.correct[i]; L.pair[i][1] = t.error_per_alt[i]; }
+  for (uint32_t i = 0; i < 256; i++) { const int fx = bam::tag_fixed_size((uint8_t)i); L.tagcls[i] = (uint8_t)(fx ? fx : i == 'Z' ? 8 : i == 'H' ? 16 : i == 'B' ? 32 : 0); }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P, uint32_t n_grp_total) {
   extern __shared__ __align__(16) uint8_t dyn[];
-  __shared__ ConsensusTables sT;          // thresholds / cerr_min / scalars (and the plain tables for reference)
-  __shared__ __align__(16) double sPair[94][2];   // {correct[q], error_per_alt[q]} interleaved: one ds_read_b128 per observation
-  __shared__ uint8_t sTagCls[256];                // aux value type classes (aux_walk)
-  {
-    fill_tag_classes(sTagCls);
-    const uint64_t* src = (const uint64_t*)&P.T->t;
-    uint64_t* dst = (uint64_t*)&sT;
-    for (uint32_t i = threadIdx.x; i < sizeof(ConsensusTables) / 8; i += blockDim.x) dst[i] = src[i];
-    for (uint32_t i = threadIdx.x; i < 94; i += blockDim.x) { sPair[i][0] = P.T->t.correct[i]; sPair[i][1] = P.T->t.error_per_alt[i]; }
-  }
-  __syncthreads();
+  __shared__ __align__(16) FwLds sL;
+  ConsensusTables& sT = sL.t;
+  double (&sPair)[94][2] = sL.pair;
+  uint8_t* const sTagCls = sL.tagcls;
   const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const uint32_t gi = blockIdx.x * (blockDim.x >> 6) + wv;    // n_grp_total counts the groups of this launch (all of them, or a retry list)
-  if (gi >= n_grp_total) return;
-  const uint32_t g = P.group_list ? P.group_list[gi] : P.g0 + gi;
+  const uint32_t gi_raw = blockIdx.x * (blockDim.x >> 6) + wv;   // n_grp_total counts the groups of this launch (all of them, or a retry list)
+  bool bail = gi_raw >= n_grp_total;                          // a wavefront without a group still takes part in the table copy
+  const uint32_t gi = bail ? 0u : gi_raw;
+  const uint32_t g = P.group_list ? P.group_list[gi] : P.g0 + gi;   // (asked for before the image: waiting for it does not wait for the image)
+  // the table image: global -> registers now, registers -> LDS after the records have been staged (one barrier for both)
+  constexpr uint32_t IMG_V = (uint32_t)(sizeof(FwLds) / 16);
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4* const img_src = (const u32x4*)P.fw_image;
+  const uint32_t ii0 = threadIdx.x, ii1 = ii0 + blockDim.x, ii2 = ii1 + blockDim.x, ii3 = ii2 + blockDim.x, ii4 = ii3 + blockDim.x, ii5 = ii4 + blockDim.x;
+  const u32x4 im0 = img_src[ii0 < IMG_V ? ii0 : 0u], im1 = img_src[ii1 < IMG_V ? ii1 : 0u], im2 = img_src[ii2 < IMG_V ? ii2 : 0u],
+              im3 = img_src[ii3 < IMG_V ? ii3 : 0u], im4 = img_src[ii4 < IMG_V ? ii4 : 0u], im5 = img_src[ii5 < IMG_V ? ii5 : 0u];
   uint8_t* W = dyn + (size_t)wv * P.lds_wave_bytes;
   const uint32_t my_list = blockIdx.x & (N_LISTS - 1);
   bool list_overflow = false;
@@ -1078,40 +1094,50 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
   unsigned long long* st = P.stats + (size_t)(blockIdx.x & (STAT_SLOTS - 1)) * 32;
   const uint32_t r0 = P.grp_first[g], n = P.grp_first[g + 1] - r0;
   const uint32_t slot0 = 3 * g;
-  if (lane < 3) { if (MODE == 0) P.ends[slot0 + lane].valid = 0; else if (MODE == 1) P.dends[slot0 + lane].valid = 0; else P.cends[slot0 + lane].valid = 0; P.rec_sizes[slot0 + lane] = 0; }
+  if (!bail && lane < 3) { if (MODE == 0) P.ends[slot0 + lane].valid = 0; else if (MODE == 1) P.dends[slot0 + lane].valid = 0; else P.cends[slot0 + lane].valid = 0; P.rec_sizes[slot0 + lane] = 0; }
 
-  if (MODE == 0 && n < P.min_reads) {   // simplex.rs:673-683
+  if (MODE == 0 && !bail && n < P.min_reads) {   // simplex.rs:673-683
     if (lane == 0) { atomicAdd(&st[0], (unsigned long long)n); atomicAdd(&st[2], (unsigned long long)n); atomicAdd(&st[3 + FGX_REJ_INSUFFICIENT_READS], (unsigned long long)n); }
-    return;
+    bail = true;
   }
   auto to_defer = [&]() { if (lane == 0) { uint32_t k = atomicAdd(P.n_deferred, 1u); P.deferred[k] = g; } };
   // does not fit this launch's LDS slice: the next launch (bigger slices, fewer waves per CU) picks it up; after the last one
   // simplex families go to the workgroup-per-family kernel, duplex / CODEC molecules to the general path
   auto to_retry = [&]() { if (!P.retry) { to_defer(); return; } if (lane == 0) { uint32_t k = atomicAdd(P.n_retry, 1u); P.retry[k] = g; } };
-  if (n > 64) { if (MODE == 0) to_retry(); else to_defer(); return; }
+  if (!bail && n > 64) { if (MODE == 0) to_retry(); else to_defer(); bail = true; }
   // an empty group has no byte span (the minimum below would be ~0 and the staging loop would read the 16 bytes BEFORE the blob —
   // a fault when the blob starts an allocation): the general path emits its nothing
-  if (n == 0) { to_defer(); return; }
+  if (!bail && n == 0) { to_defer(); bail = true; }
 
 #if FGX_PHASE_TIMING
   unsigned long long _t = __builtin_amdgcn_s_memtime();
 #endif
   // ---- 1. stage the family's raw records into LDS ------------------------------------------------------
-  const bool act = lane < n;
+  const bool act = !bail && lane < n;
   unsigned long long off = act ? P.rec_off[r0 + lane] : ~0ull;
   uint32_t len = act ? P.rec_len[r0 + lane] : 0;
   unsigned long long lo_off = wave_min64(off);
   unsigned long long hi_end = wave_max64(act ? off + len : 0ull);
-  if (__any(act && len < 32) || hi_end > P.blob_len) { to_defer(); return; }   // a record outside the blob: the general path raises the error
+  if (!bail && (__any(act && len < 32) || hi_end > P.blob_len)) { to_defer(); bail = true; }   // a record outside the blob: the general path raises the error
   unsigned long long base16 = lo_off & ~15ull;
   unsigned long long span = hi_end - base16;
-  if (span + 16 > (unsigned long long)P.lds_wave_bytes) { to_retry(); return; }   // +16: slack for the dword-composed reads
-  const uint32_t span16 = ((uint32_t)span + 15) & ~15u;
+  if (!bail && span + 16 > (unsigned long long)P.lds_wave_bytes) { to_retry(); bail = true; }   // +16: slack for the dword-composed reads
+  const uint32_t span16 = bail ? 0u : ((uint32_t)span + 15) & ~15u;
   {
     const uint8_t* src = P.blob + base16;
     for (uint32_t i = lane * 16; i < span16; i += 64 * 16) *(uint4*)(W + i) = *(const uint4*)(src + i);
   }
-  wave_sync();
+  {
+    u32x4* const img_dst = (u32x4*)&sL;
+    if (ii0 < IMG_V) img_dst[ii0] = im0;
+    if (ii1 < IMG_V) img_dst[ii1] = im1;
+    if (ii2 < IMG_V) img_dst[ii2] = im2;
+    if (ii3 < IMG_V) img_dst[ii3] = im3;
+    if (ii4 < IMG_V) img_dst[ii4] = im4;
+    if (ii5 < IMG_V) img_dst[ii5] = im5;
+  }
+  __syncthreads();                                            // the tables (workgroup) and this wavefront's records are in LDS
+  if (bail) return;
 
   PH(1)
   // ---- 2. parse: lane r owns record r ---------------------------------------------------------------------
@@ -3187,7 +3213,7 @@ __global__ void k_reduce_stats(const unsigned long long* __restrict__ slots, uns
 // -----------------------------------------------------------------------------------------------------
 void FastPath::release() {
   for (DevBuf* b : {&d_ends, &d_sizes, &d_offsets, &d_code, &d_qual, &d_depth, &d_err, &d_misc, &d_deferred, &d_out, &d_scan_tmp, &d_strings, &d_obs, &d_retry2,
-                    &d_retry, &d_bound, &d_colbase, &d_statslots, &d_full_items, &d_full_count, &d_retry_old, &d_w2img, &d_famdesc})
+                    &d_retry, &d_bound, &d_colbase, &d_statslots, &d_full_items, &d_full_count, &d_retry_old, &d_w2img, &d_famdesc, &d_fwimg})
     b->free_();
   for (int i = 0; i < 4; i++) if (ev[i]) { (void)hipEventDestroy(ev[i]); ev[i] = nullptr; }
 }
@@ -3241,6 +3267,15 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
   P.blob_len = blob_len;
   P.g0 = 0;
   P.T = c->d_tables.as<DeviceTables>(); P.TU = c->d_umi_tables.as<DeviceTables>();
+  if (!d_fwimg.p) {   // the tables of a caller never change: one image per FastPath (k_family_wave's LDS block)
+    FwLds* img = new FwLds;
+    build_fw_image(*img, c->h_tables.t);
+    d_fwimg.reserve(sizeof(FwLds));
+    hip_check(hipMemcpyAsync(d_fwimg.p, img, sizeof(FwLds), hipMemcpyHostToDevice, s), "H2D fw image");
+    hip_check(hipStreamSynchronize(s), "sync");
+    delete img;
+  }
+  P.fw_image = d_fwimg.p;
   P.min_reads = o.min_reads; P.max_reads = o.max_reads;
   P.min_input_bq = o.min_input_base_quality; P.min_cons_bq = o.min_consensus_base_quality;
   P.trim = o.trim; P.overlap = o.overlapping_consensus;
@@ -3327,7 +3362,8 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
       struct Stage { int fam_per_wave; uint32_t bytes; uint32_t wpb; };
       std::vector<Stage> chain;
       const double mean_span = (double)blob_len / (double)n_grp + 48.0;   // mean bytes of a family + alignment / read-ahead slack
-      if (use_seg && mean_span + (16 * 8 + 64) <= seg_bytes / 4) chain.push_back({4, seg_bytes, (uint32_t)WAVES_PER_BLOCK});
+      static const uint32_t seg_wpb = [] { const char* e = getenv("FGX_SEG_WPB"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= WAVES_PER_BLOCK ? v : WAVES_PER_BLOCK); }();   // (measurement knob)
+      if (use_seg && mean_span + (16 * 8 + 64) <= seg_bytes / 4) chain.push_back({4, seg_bytes, seg_wpb});
       // (two families per wavefront measured slower than one at depth 8 — 14.9 vs 10.7 ms per 1 M families: the column phase costs
       // the same per family and a CU holds 12 instead of 20 wavefronts; kept behind FGX_SEG2=1 for experiments)
       static const bool use_seg2 = [] { const char* e = getenv("FGX_SEG2"); return e && e[0] == '1'; }();
@@ -3381,7 +3417,8 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
       PS.retry = (last && (duplex || codec)) ? nullptr : lists[out_list]; PS.n_retry = d_cnt;
       // fewer wavefronts per workgroup as the slices grow: the LDS a workgroup asks for is what limits the wavefronts a CU holds
       // (4 x 22 KB = one workgroup = 4 waves per CU; 1 x 22 KB = six workgroups = 6 waves)
-      const uint32_t wpb = st == 0 ? WAVES_PER_BLOCK : st == 1 ? 2u : 1u;
+      static const uint32_t fw_wpb = [] { const char* e = getenv("FGX_FW_WPB"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= WAVES_PER_BLOCK ? v : WAVES_PER_BLOCK); }();   // (measurement knob)
+      const uint32_t wpb = st == 0 ? fw_wpb : st == 1 ? 2u : 1u;
       const dim3 grid((n_cur + wpb - 1) / wpb), block(64 * wpb);
       const size_t lds = (size_t)wpb * stages[st];
       if (codec) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_family_wave<2>), grid, block, lds, s, PS, n_cur);
