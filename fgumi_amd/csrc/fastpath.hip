@@ -2442,22 +2442,36 @@ __device__ void emit_generic(const EmitParams& P, const EndDesc& D, const EmitCt
 // (Assembling the record through LDS — whole-record image with byte writes, or dword-staged column arrays with dword payload
 // copies — was measured three times, rounds 1 and 2: 3.4 – 4.0 ms.  The wave's lifetime is a chain of memory round trips, and
 // every LDS hop adds one; registers-only streaming below is the fastest form found.)
-__device__ __forceinline__ void emit_one(const EmitParams& P, uint32_t slot, uint32_t lane);
+__device__ __forceinline__ void emit_one(const EmitParams& P, const EndDesc& D, uint64_t out_off, uint32_t lane);
 __global__ __launch_bounds__(256) void k_emit(EmitParams P) {
+  // the family's (up to) three descriptors, copied once with 16-byte loads: every field read below is an LDS read — as global
+  // loads, the valid flags and then each record's fields were dependent memory round trips of their own
+  __shared__ __align__(16) EndDesc sD[4][3];
+  static_assert(sizeof(EndDesc) == 96, "EndDesc is copied as six 16-byte pieces");
   const uint32_t fam = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
-  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t lane = threadIdx.x & 63, wv = (threadIdx.x >> 6) & 3;
   const uint32_t s0 = P.slot0 + 3 * fam;
   if (s0 >= P.slot_end) return;
-  // the three `valid` flags first (independent scalar loads), then the records
-  const bool v0 = P.ends[s0].valid != 0, v1 = s0 + 1 < P.slot_end && P.ends[s0 + 1].valid != 0, v2 = s0 + 2 < P.slot_end && P.ends[s0 + 2].valid != 0;
-  if (v0) emit_one(P, s0, lane);            // (three inlined copies: a rolled loop measured 2.8 instead of 2.2 ms per 2 M records)
-  if (v1) emit_one(P, s0 + 1, lane);
-  if (v2) emit_one(P, s0 + 2, lane);
+  // (every kernel argument the records need is asked for here, in one batch: fetched where first used they were five separate
+  // scalar-load round trips along the way)
+#define K_EMIT_PIN(x) asm volatile("" :: "s"(x))
+  K_EMIT_PIN(P.blob); K_EMIT_PIN(P.out); K_EMIT_PIN(P.out_base); K_EMIT_PIN(P.col_code); K_EMIT_PIN(P.col_qual); K_EMIT_PIN(P.col_depth);
+  K_EMIT_PIN(P.col_err); K_EMIT_PIN(P.prefix); K_EMIT_PIN(P.prefix_len); K_EMIT_PIN(P.rg); K_EMIT_PIN(P.rg_len);
+#undef K_EMIT_PIN
+  const uint32_t ns = P.slot_end - s0 < 3 ? P.slot_end - s0 : 3;
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 piece = ((const u32x4*)&P.ends[s0])[lane < 6 * ns ? lane : 0u];
+  const uint64_t oo = P.out_off[s0 + (lane < ns ? lane : 0u)];   // (both loads leave before either is waited for)
+  if (lane < 6 * ns) ((u32x4*)&sD[wv][0])[lane] = piece;
+  wave_sync();
+  const bool v0 = sD[wv][0].valid != 0, v1 = ns > 1 && sD[wv][1].valid != 0, v2 = ns > 2 && sD[wv][2].valid != 0;
+  if (v0) emit_one(P, sD[wv][0], __shfl(oo, 0), lane);            // (three inlined copies: a rolled loop measured 2.8 instead of 2.2 ms per 2 M records)
+  if (v1) emit_one(P, sD[wv][1], __shfl(oo, 1), lane);
+  if (v2) emit_one(P, sD[wv][2], __shfl(oo, 2), lane);
 }
-__device__ __forceinline__ void emit_one(const EmitParams& P, uint32_t slot, uint32_t lane) {
-  const EndDesc& D = P.ends[slot];
+__device__ __forceinline__ void emit_one(const EmitParams& P, const EndDesc& D, uint64_t out_off, uint32_t lane) {
   EmitCtx X;
-  X.q = P.out + (P.out_off[slot] - P.out_base);
+  X.q = P.out + (out_off - P.out_base);
   X.Lc = D.cons_len;
   X.first = P.blob + D.first_off;
   X.mi_len = D.mi_len; X.mi_off = D.mi_off;
