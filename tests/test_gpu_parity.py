@@ -215,6 +215,21 @@ def test_simplex_depth8_and_long_tail(handle):
     _assert_same(simulate_grouped_reads(300, family_size=3, read_length=151, insert_mean=120, insert_sd=30))   # read-through clips
 
 
+def test_reference_caller_unit_test_inputs(handle):
+    """The inputs of the reference's own caller-level unit tests (vanilla_caller.rs `mod tests`; their assertions are replayed on the
+    oracle in tests/test_oracle_vanilla_pins.py) through the HIP path: byte-identical records and statistics — including the
+    40 000-read family whose depths saturate at i16::MAX, pairs without MC tags, indel minorities and orphan ends."""
+    import test_oracle_vanilla_pins as pins
+    cases = pins.replay_cases()
+    assert len(cases) >= 25
+    for kw, groups in cases:
+        o = dict(kw)
+        _assert_same(GroupedReads.from_groups(groups), min_reads=o.pop("min_reads"), overlapping=bool(o.pop("overlapping_consensus")),
+                     track_rejects=bool(o.pop("track_rejects", 0)), prefix=o.pop("read_name_prefix").decode(),
+                     produce_per_base_tags=bool(o.pop("produce_per_base_tags", 1)), trim=bool(o.pop("trim", 0)),
+                     **{k: v for k, v in o.items() if k != "cell_tag"})
+
+
 @pytest.mark.parametrize("read_length", [20, 32, 33, 64, 65, 96, 97, 129, 160, 161, 200])
 def test_column_pass_schedule_over_read_lengths(handle, read_length):
     """k_simplex_wave2 walks 64 columns per pass and takes the two tails of a pair family in ONE merged pass when both are at most
