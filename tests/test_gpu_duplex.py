@@ -62,6 +62,20 @@ def _same(g, min_reads=(1,), overlapping=True, track_rejects=False, cell_tag="CB
     return out
 
 
+def test_reference_duplex_unit_test_inputs():
+    """The inputs of the reference's own process-level duplex unit tests (duplex_caller.rs `mod tests`; their assertions are replayed
+    on the oracle in tests/test_oracle_duplex_pins.py) through the HIP path: byte-identical records, statistics and rejects —
+    minority alignments, zero-length-after-trimming reads, whole-group rejections, stray fragments, lone strands, absent UMI halves."""
+    import test_oracle_duplex_pins as pins
+    cases = pins.replay_cases()
+    assert len(cases) >= 15
+    for kw, groups in cases:
+        _same(GroupedReads.from_groups(groups), min_reads=kw["duplex_min_reads"], overlapping=False, track_rejects=bool(kw["track_rejects"]),
+              cell_tag=(kw["cell_tag"].decode() if kw["cell_tag"] != b"\0\0" else None), prefix="consensus", trim=bool(kw["trim"]),
+              produce_per_base_tags=bool(kw["produce_per_base_tags"]), min_input_base_quality=kw["min_input_base_quality"],
+              error_rate_pre_umi=kw["error_rate_pre_umi"], error_rate_post_umi=kw["error_rate_post_umi"])
+
+
 def test_duplex_simulated_config3_shape():
     """BASELINE.json configs[2] shape (duplex A/B, 6+6 pairs, 150 bp) at a size the oracle finishes in seconds."""
     out = _same(simulate_grouped_reads(1500, family_size=12, duplex=1), min_reads=(1,))
