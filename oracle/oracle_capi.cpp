@@ -413,6 +413,16 @@ int orc_overlap_pair(uint8_t* r1, uint32_t n1, uint8_t* r2, uint32_t n2, uint64_
   return ok ? 1 : 0;
 }
 
+// apply_overlapping_consensus (overlapping.rs:627-684) over one group's records, modified in place (lengths do not change).
+void orc_apply_overlapping(uint8_t* blob, const uint64_t* rec_off, const uint32_t* rec_len, uint32_t n, uint64_t* stats4) {
+  std::vector<Bytes> recs(n);
+  for (uint32_t i = 0; i < n; i++) recs[i].assign(blob + rec_off[i], blob + rec_off[i] + rec_len[i]);
+  CorrectionStats cs;
+  apply_overlapping_consensus(recs, cs);
+  for (uint32_t i = 0; i < n; i++) memcpy(blob + rec_off[i], recs[i].data(), rec_len[i]);
+  stats4[0] = cs.overlapping_bases; stats4[1] = cs.bases_agreeing; stats4[2] = cs.bases_disagreeing; stats4[3] = cs.bases_corrected;
+}
+
 // Replays the reference's fast-path ≡ call_full sweeps (base_builder.rs:1986-2012, 2042-2083,
 // 2092-2123).  which: 0 broad (30 720 cases), 1 dense contiguous-depth, 2 deep cap region.
 // Returns the number of mismatches; *n_cases = cases evaluated.
