@@ -338,6 +338,15 @@ def test_consensus_umis():  # simple_umi.rs tests
     assert cu(["ACGT", "ACGA"]) == "ACGN"
     assert cu(["ACGT", "ACG"]) is None
     assert cu(["NNNN", "NNNN"]) == "NNNN"
+    # SimpleConsensusCaller::call_consensus, the reference's own cases (simple_umi.rs `mod tests`):
+    assert cu(["A", "AC"]) is None                                            # test_fail_if_sequences_have_different_lengths (panics)
+    assert cu(["GATT-ACA", "GATT-ACA", "GATTAACA"]) is None                   # test_fail_if_mixed_dna_and_non_dna
+    assert cu(["GATT-ACA", "GATT+ACA"]) is None                               # test_fail_if_non_dna_chars_differ
+    assert cu(["A", "A"]) == "A" and cu(["GATTACA", "GATTACA"]) == "GATTACA"  # test_consensus_from_sequences_that_agree
+    assert cu(["A", "C", "G", "T"]) == "N"                                    # test_consensus_from_sequences_that_differ
+    assert cu(["A", "C", "C", "C"]) == "C" and cu(["C", "C", "C", "A"]) == "C"
+    assert cu(["GATTACA", "GATTACA", "GATTACA", "NNNNNNN"]) == "GATTACA"
+    assert cu(["GATT-ACA"] * 3) == "GATT-ACA" and cu(["XGAT", "XGAT"]) == "XGAT" and cu(["GATY", "GATY"]) == "GATY"   # test_gracefully_handle_non_acgtn_bases
 
 
 def test_quality_trim_point():  # vanilla_caller.rs:992-1016 (htsjdk TrimmingUtil semantics)
