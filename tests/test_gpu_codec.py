@@ -61,6 +61,22 @@ def _same(g, track_rejects=False, prefix="codec", rg="A", **kw):
     return out, want
 
 
+def test_reference_codec_geometry_inputs():
+    """The overlap-geometry fixtures of the reference's own CODEC unit tests (indel at the overlap boundary, dovetailed starts,
+    terminal indel outside / indel inside the shared region, R1 running past R2, cross-template overlap; codec_caller.rs:3875-4322 —
+    tests/test_oracle_codec.py pins their exact consensus bases on the oracle) through the HIP path: byte-identical."""
+    fams = [sum((toc.fr_pair(f"t{i}", 200, 200, 35, "2S124M1D3M", "3S125M", mi="mi", rx="ACC-TGA", ref=toc.REF_BASES) for i in range(2)), []),
+            toc._codec_template(*toc._DOVETAIL), toc._codec_template(201, "2S124M1D3M", 200, "3S124M2S"),
+            toc._codec_template(201, "2S60M1D67M", 200, "3S124M2S"), toc._window_end_past_r2_fixture(),
+            toc.fr_pair("tA", 200, 200, 35, "50M", "50M", mi="mi", rx="ACC-TGA", ref=toc.REF_BASES) +
+            toc.fr_pair("tB", 199, 199, 35, "40M", "102M", mi="mi", rx="ACC-TGA", ref=toc.REF_BASES)]
+    for recs in fams:
+        _same(GroupedReads.from_groups([recs]), rg="RG1", min_reads_per_strand=1, min_duplex_length=1)
+    for mdl in (126, 127):
+        _same(GroupedReads.from_groups([toc._codec_template(*toc._DOVETAIL)]), rg="RG1", min_reads_per_strand=1, min_duplex_length=mdl)
+    _same(GroupedReads.from_groups(fams), rg="RG1", track_rejects=True, min_reads_per_strand=1, min_duplex_length=1)   # one batch, six molecules
+
+
 def crafted_groups():
     P = toc.fr_pair
     groups = [

@@ -303,3 +303,90 @@ def test_nocall_and_low_quality_inputs_are_not_masked():
     out = one(run([r1, r[1]]))
     assert out["seq"] == REF[:30]
     assert out["quals"][3] < out["quals"][4]
+
+
+# ---- overlap geometry with indels and dovetails (codec_caller.rs:3911-4330): EXACT consensus bases --------------------------
+# These cases assert the emitted bases against the reference's own test sequence (`REF_BASES`, codec_caller.rs:2392 — fixture data
+# of the reference's tests, copied as a golden vector), built by the same `create_fr_pair` rules as above (placeholder 'A').
+REF_BASES = (
+    "TGGGTGTTGTTTGGGTTCCTGCTTAAAGAGCTACTGTTCTTCACAGAAACTTCCAACTCACCCAGACTGAGATTTGTACTGAGACTACGATCCACATGTTCAATATCTGATATCTGATGG"
+    "GAAATAGGCTTTACTGAATTATCCATTTGGGCTGTAATTAATTTCAGTGATGAGCGGGAGATGTTGTTAGTTGTGCTCAGTAACTTTTTGATAGTAGCGGGAGTAGGAGTAAATCTTGTA"
+    "CTAATTAGTGAATATTCTGTTGATGGTGGCTGAAAATTTATAGCTACACAACCAAAAAAATAAAAAACGTTAGTCAATAGCATTTATAAATAGTCTTCTCTACCTGAAATATTTTACATT"
+    "AAGTAATTCATTCCTTCATTTAGTATCTACACATGTCTAACATTGTAGTAGGAGCTGTGTACTAACAAGAAATCATGACACTGTTTCTGCCTTCAAGGAGCTTATAATCTTTTGGGGTAC"
+    "ACAAGATAACCCAGAATGTTAAATAGTATAAAAGTCAAAGTACAATAATTTATTTCATTAAGATTTTGAAATGGCTAACAAACACCTGTTGATCACCTCATACACATGAGCCTCAAAACA"
+    "AAGGAAAGCACAGCCCCTATGCCTGAGCAATTTAGAATATTGTCAAGGATAGAGACATGTGAGCCATTCACTATGAAACAATCATTGAGAACTACTACAAGAGTGATAAATATAAAATGA"
+    "AACCTACAGAAACACAGAAGAGTAAGTAATTTTCCCTATAAAGAAGACAGGAACTAAATGTATAAGCAAAAATTGGGAAATTATATAAATGCTATTTTATATGAGAGGCAAAGAACCACA"
+    "GGTCTAATAATTTTACAAATGTGATAAAATCAGATTTTATGTCCCCATCTTTCTTGACTGCTCAGCTAGAAATTAAAACATTTTTACACATCTTTTTGGCGGGGGCGGGGGGGATCATTA"
+    "TTTATTTCACCTGCCAAAATACTTCATTTCCTTATTGCACTTTTTTACTTCTTTGGTATGGAAAAATCTAACGGGTTTTAGAGTATGAACACATTTTAAGCAGTGATTAGATACGTTTTT"
+    "CTTGTTATGCTTTCTATTGCAAATTTAGGATTTGATTTTGCACTGTCTTCATGCAAAGCTCTTCTCAAAGGTCTTAAAATATAAAAAACACTTAATGCTTCTCAAAGCATTAAGATTTTA"
+    "TGTAAATCAAACCAAAACCAGAAAAAGACAGAAGAAAATGAACCAAAAACAACAAAAATAATCCTTAACATAGTTGGCAACAAGTGCAATGAAAGATTTTT"
+)
+
+
+def _codec_template(pos_start, pos_cigar, neg_start, neg_cigar, name="t0"):  # codec_template :3983-4001
+    return fr_pair(name, pos_start, neg_start, 35, pos_cigar, neg_cigar, mi="mi", rx="ACC-TGA", ref=REF_BASES)
+
+
+def _call_family(recs, min_duplex_length=1):  # call_codec_family :4003-4024
+    return run(recs, codec_min_reads_per_strand=1, codec_min_duplex_length=min_duplex_length, min_consensus_base_quality=0)
+
+
+def _rejected_whole_family(res, n, reason):  # assert_rejected_whole_family :4218-4242
+    assert res["count"] == 0 and res["stats"][1] == 0 and res["stats"][0] == n
+    only_rejection(res, reason, n)
+
+
+def test_indel_at_overlap_boundary_still_calls_a_consensus():  # :3960-3981 (fgumi#752): 2S124M1D3M at 200 against 3S125M at 200, two templates
+    recs = []
+    for i in range(2):
+        recs += fr_pair(f"t{i}", 200, 200, 35, "2S124M1D3M", "3S125M", mi="mi", rx="ACC-TGA", ref=REF_BASES)
+    res = _call_family(recs)
+    c = one(res)
+    assert len(c["seq"]) == 127
+    assert c["seq"] == "AAGTAACTTTTTGATAGTAGCGGGAGTAGGAGTAAATCTTGTACTAATTAGTGAATATTCTGTTGATGGTGGCTGAAAATTTATAGCTACACAACCAAAAAAATAAAAAACGTTAGTCAATAGCATT"
+    assert sum(res["stats"][3:24]) == 0 and res["stats"][2] == 0 and res["stats"][0] == len(recs)
+
+
+_DOVETAIL = (201, "2S126M", 200, "3S127M")       # dovetailed_start_template :4030-4037
+
+
+def test_dovetailed_starts_without_an_indel_call_a_consensus():  # :4051-4078 (fgumi#761)
+    res = _call_family(_codec_template(*_DOVETAIL))
+    c = one(res)
+    assert sum(res["stats"][3:24]) == 0 and len(c["seq"]) == 128
+    assert c["seq"] == "ANTAACTTTTTGATAGTAGCGGGAGTAGGAGTAAATCTTGTACTAATTAGTGAATATTCTGTTGATGGTGGCTGAAAATTTATAGCTACACAACCAAAAAAATAAAAAACGTTAGTCAATAGCATTTA"
+
+
+def test_min_duplex_length_is_measured_over_the_shared_region():  # :4089-4106: 126 shared positions pass 126, fail 127
+    assert _call_family(_codec_template(*_DOVETAIL), 126)["count"] == 1
+    _rejected_whole_family(_call_family(_codec_template(*_DOVETAIL), 127), 2, "InsufficientOverlap")
+
+
+def test_terminal_indel_outside_the_shared_region_calls_a_consensus():  # :4126-4158
+    res = _call_family(_codec_template(201, "2S124M1D3M", 200, "3S124M2S"))
+    c = one(res)
+    assert sum(res["stats"][3:24]) == 0 and len(c["seq"]) == 127
+    assert c["seq"] == "ANTAACTTTTTGATAGTAGCGGGAGTAGGAGTAAATCTTGTACTAATTAGTGAATATTCTGTTGATGGTGGCTGAAAATTTATAGCTACACAACCAAAAAAATAAAAAACGTTAGTCAATAGCATNA"
+
+
+def test_indel_inside_the_shared_region_is_still_rejected():  # :4171-4188
+    _rejected_whole_family(_call_family(_codec_template(201, "2S60M1D67M", 200, "3S124M2S")), 2, "IndelErrorBetweenStrands")
+
+
+def _window_end_past_r2_fixture():  # :4254-4284: tA R1 100M at 100 / R2 40M at 160; tB R1 30M at 120 / R2 50M at 120
+    return (fr_pair("tA", 100, 160, 35, "100M", "40M", mi="mi", rx="ACC-TGA", ref=REF_BASES) +
+            fr_pair("tB", 120, 120, 35, "30M", "50M", mi="mi", rx="ACC-TGA", ref=REF_BASES))
+
+
+def test_r1_running_past_r2_is_not_an_indel_error():  # :4306-4322, and test_clip_overlap_failed_counted_and_labeled :3806-3841
+    res = _call_family(_window_end_past_r2_fixture())
+    assert res["stats"][REJ["IndelErrorBetweenStrands"]] == 0
+    _rejected_whole_family(res, 4, "ClipOverlapFailed")
+
+
+def test_clip_overlap_failed_attribution_matches_fgbio():  # :3875-3909: tA 50M / 50M at 200, tB R1 40M / R2 102M at 199
+    recs = (fr_pair("tA", 200, 200, 35, "50M", "50M", mi="mi", rx="ACC-TGA", ref=REF_BASES) +
+            fr_pair("tB", 199, 199, 35, "40M", "102M", mi="mi", rx="ACC-TGA", ref=REF_BASES))
+    res = _call_family(recs)
+    assert res["stats"][REJ["IndelErrorBetweenStrands"]] == 0
+    _rejected_whole_family(res, 4, "ClipOverlapFailed")
