@@ -423,6 +423,33 @@ void orc_apply_overlapping(uint8_t* blob, const uint64_t* rec_off, const uint32_
   stats4[0] = cs.overlapping_bases; stats4[1] = cs.bases_agreeing; stats4[2] = cs.bases_disagreeing; stats4[3] = cs.bases_corrected;
 }
 
+#ifdef ORC_WITH_DUPLEX
+// duplex_consensus (duplex_caller.rs:931-1108) on two single-strand consensus reads given as plain arrays (n == 0: that strand is
+// absent); no source reads (the approximate error recount).  Returns the duplex length, -1 when no duplex read comes out;
+// flags: bit 0 = a BA consensus is attached, bit 1 = the lone strand was BA.
+int orc_duplex_consensus(const uint8_t* ab_b, const uint8_t* ab_q, const uint16_t* ab_d, const uint16_t* ab_e, uint32_t n_ab,
+                         const uint8_t* ba_b, const uint8_t* ba_q, const uint16_t* ba_d, const uint16_t* ba_e, uint32_t n_ba,
+                         uint8_t* out_b, uint8_t* out_q, uint16_t* out_e, uint32_t cap, uint32_t* flags) {
+  auto mk = [](const uint8_t* b, const uint8_t* q, const uint16_t* d, const uint16_t* e, uint32_t n) {
+    VanillaConsensusRead v;
+    v.id = "UMI123";
+    v.bases.assign(b, b + n); v.quals.assign(q, q + n); v.depths.assign(d, d + n); v.errors.assign(e, e + n);
+    return v;
+  };
+  VanillaConsensusRead a, b;
+  if (n_ab) a = mk(ab_b, ab_q, ab_d, ab_e, n_ab);
+  if (n_ba) b = mk(ba_b, ba_q, ba_d, ba_e, n_ba);
+  DuplexConsensusRead out;
+  if (!duplex_consensus(n_ab ? &a : nullptr, n_ba ? &b : nullptr, nullptr, out)) return -1;
+  if (out.len() > cap) return -2;
+  memcpy(out_b, out.bases.data(), out.len()); memcpy(out_q, out.quals.data(), out.len());
+  for (size_t i = 0; i < out.len(); i++) out_e[i] = out.errors[i];
+  *flags = (out.has_ba ? 1u : 0u) | (out.is_ba_only ? 2u : 0u);
+  return (int)out.len();
+}
+uint8_t orc_duplex_cap_quality(int32_t s) { return cap_quality(s); }
+#endif
+
 // Replays the reference's fast-path ≡ call_full sweeps (base_builder.rs:1986-2012, 2042-2083,
 // 2092-2123).  which: 0 broad (30 720 cases), 1 dense contiguous-depth, 2 deep cap region.
 // Returns the number of mismatches; *n_cases = cases evaluated.

@@ -224,3 +224,50 @@ def replay_cases():
             seen.add(key)
             out.append((kw, groups))
     return out
+
+
+# ---- duplex_consensus on two single-strand reads (duplex_caller.rs:931-1108): the reference's direct tests --------------------------
+import numpy as np
+
+
+def _duplex(ab, ba):
+    """ab / ba = (bases, quals, depths, errors) or None → (bases, quals, errors, has_ba, ba_only) or None."""
+    def arr(v):
+        if v is None:
+            z8, z16 = np.zeros(1, np.uint8), np.zeros(1, np.uint16)
+            return z8, z8, z16, z16, 0
+        b, q, d, e = v
+        return np.frombuffer(b.encode(), np.uint8).copy(), np.array(q, np.uint8), np.array(d, np.uint16), np.array(e, np.uint16), len(b)
+    a, b = arr(ab), arr(ba)
+    ob, oq, oe = np.zeros(64, np.uint8), np.zeros(64, np.uint8), np.zeros(64, np.uint16)
+    import ctypes as C
+    fl = C.c_uint32()
+    n = orc.lib.orc_duplex_consensus(orc.ptr(a[0]), orc.ptr(a[1]), orc.ptr(a[2]), orc.ptr(a[3]), a[4], orc.ptr(b[0]), orc.ptr(b[1]), orc.ptr(b[2]), orc.ptr(b[3]), b[4],
+                                     orc.ptr(ob), orc.ptr(oq), orc.ptr(oe), 64, C.byref(fl))
+    if n < 0:
+        return None
+    return bytes(ob[:n]).decode(), oq[:n].tolist(), oe[:n].tolist(), bool(fl.value & 1), bool(fl.value & 2)
+
+
+def test_duplex_consensus_single_strands_pass_through():  # duplex_caller.rs:5196-5238 (ab_only, ba_only), :5241-5245 (none_none)
+    ab = ("ACGT", [30, 31, 32, 33], [5] * 4, [0, 1, 0, 1])
+    assert _duplex(ab, None) == ("ACGT", [30, 31, 32, 33], [0, 1, 0, 1], False, False)
+    ba = ("TGCA", [25, 26, 27, 28], [4] * 4, [1, 0, 1, 0])
+    assert _duplex(None, ba) == ("TGCA", [25, 26, 27, 28], [1, 0, 1, 0], False, True)          # the lone BA strand becomes the AB of the output
+    assert _duplex(None, None) is None
+
+
+def test_duplex_consensus_different_lengths():  # duplex_caller.rs:5248-5276: the shorter strand decides
+    r = _duplex(("ACGTAC", [30] * 6, [5] * 6, [0] * 6), ("ACGT", [25] * 4, [4] * 4, [0] * 4))
+    assert len(r[0]) == 4 and len(r[1]) == 4
+
+
+def test_duplex_consensus_error_calculation():  # duplex_caller.rs:5279-5310 (agreement), :5313-5345 (disagreement)
+    r = _duplex(("ACGT", [30] * 4, [5] * 4, [1, 0, 2, 0]), ("ACGT", [25] * 4, [4] * 4, [0, 1, 0, 2]))
+    assert r[2] == [1, 1, 2, 2]
+    r = _duplex(("AT", [30, 40], [5, 5], [1, 2]), ("AC", [25, 30], [4, 4], [0, 1]))
+    assert r[0] == "AT" and r[2][1] == 5          # AB wins position 1: its 2 errors + the 3 BA reads that agree with BA's own call
+
+
+def test_cap_quality():  # duplex_caller.rs:5420-5427
+    assert [orc.lib.orc_duplex_cap_quality(v) for v in (-5, 0, 2, 50, 93, 100)] == [2, 2, 2, 50, 93, 93]
