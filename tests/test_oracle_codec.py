@@ -390,3 +390,19 @@ def test_clip_overlap_failed_attribution_matches_fgbio():  # :3875-3909: tA 50M 
     res = _call_family(recs)
     assert res["stats"][REJ["IndelErrorBetweenStrands"]] == 0
     _rejected_whole_family(res, 4, "ClipOverlapFailed")
+
+
+def test_consensus_bases_emitted_totals_emitted_consensus_bases():  # :3393-3415 (permissive thresholds, one built-in disagreement)
+    res = run(disagreement_fixture(1), codec_min_reads_per_strand=1, codec_min_duplex_length=1)
+    p = one(res)
+    assert len(p["seq"]) > 0 and res["stats"][24] == len(p["seq"])
+
+
+@pytest.mark.parametrize("max_dis,max_rate", [(0, 1.0), (0xFFFFFFFF, 0.0)])
+def test_rejected_molecules_contribute_no_emitted_bases(max_dis, max_rate):  # :3418-3457, and the typed errors :3460-3512 (1 disagreement over 20 duplex positions)
+    res = run(disagreement_fixture(1), codec_min_reads_per_strand=1, codec_min_duplex_length=1, codec_max_duplex_disagreements=max_dis,
+              codec_max_duplex_disagreement_rate=max_rate)
+    assert res["count"] == 0 and res["stats"][24] == 0 and res["stats"][25] == 0 and res["stats"][26] == 0 and res["stats"][27] == 1
+    # the thresholds are exactly where the reference puts them: one disagreement / a rate of 1/20 passes
+    ok = run(disagreement_fixture(1), codec_min_reads_per_strand=1, codec_min_duplex_length=1, codec_max_duplex_disagreements=1, codec_max_duplex_disagreement_rate=1.0 / 20.0)
+    assert ok["count"] == 1 and ok["stats"][26] == 1 and ok["stats"][25] == 20
