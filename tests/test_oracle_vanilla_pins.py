@@ -39,10 +39,10 @@ test_read.__test__ = False
 _REPLAY = []   # (option keywords, reads) of every run below that succeeded: see replay_cases()
 
 
-def call_groups(opts, groups):
+def call_groups(opts, groups, replay=True):
     g = GroupedReads.from_groups(groups)
     res = orc.process(opts, g.blob, g.rec_off, g.rec_len, g.grp_first)
-    if hasattr(opts, "_kw"):
+    if replay and hasattr(opts, "_kw"):
         _REPLAY.append((dict(opts._kw), [list(x) for x in groups]))
     return res, [bamutil.parse(r) for r in split_records(res["data"])]
 
@@ -335,3 +335,53 @@ def replay_cases():
             seen.add(key)
             out.append((kw, reads))
     return out
+
+
+# ---- the alignment filter (select_most_common_alignment_group, vanilla_caller.rs:48-120) ----------------------------------------
+# The reference tests it on bare `SourceRead`s (`create_source_read_with_cigar`, :3713-3730: 'A' x query length at Q30); here the
+# same CIGAR mixes go through the caller as fragment records, and what the filter kept shows as the consensus depth (cD) and
+# the MinorityAlignment count.
+
+def _cigar_family(cigars):
+    reads = []
+    for i, c in enumerate(cigars):
+        qlen = sum(o >> 4 for o in bamutil.cigar_ops(c) if (o & 15) in (0, 1, 4, 7, 8))
+        reads.append(bamutil.make_record(f"r{i:02d}", "A" * qlen, [30] * qlen, flag=0, ref_id=0, pos=99, cigar=c, tags=[("MI", "Z", "UMI1")]))
+    return reads
+
+
+def _kept(cigars):
+    # (not handed to the GPU replay: added after the round's last GPU run; tests/test_gpu_indels.py covers the device filter)
+    res, recs = call_groups(ref_defaults(min_reads=1, min_consensus_base_quality=0, track_rejects=1), [_cigar_family(cigars)], replay=False)
+    names = _reason_names()
+    rej = int(res["stats"][ST_REASON0 + names["MinorityAlignment"]])
+    assert res["count"] == 1 and res["n_rejects"] == rej and int(res["stats"][ST_FILTERED]) == rej
+    return recs[0]["tags"]["cD"][1], rej
+
+
+def test_filter_all_reads_same_cigar():  # vanilla_caller.rs:3760-3777 (50M), :3781-3798 (10M5D10M5I20M5S), :3884-3897 (a single read)
+    assert _kept(["50M"] * 10) == (10, 0)
+    assert _kept(["10M5D10M5I20M5S"] * 10) == (10, 0)
+    assert _kept(["50M"]) == (1, 0)
+
+
+def test_filter_keeps_most_common_alignment():  # vanilla_caller.rs:3802-3838
+    assert _kept(["25M1D25M"] * 3 + ["50M"] * 10 + ["25M2I23M"] * 3) == (10, 6)
+
+
+def test_filter_compatible_with_deletion():  # vanilla_caller.rs:3842-3880: clips fold into M, 11 of 17 are compatible with 25M1D25M
+    good = ["25M1D25M"] * 5 + ["5S20M1D25M"] * 2 + ["5S20M1D20M5H"] * 2 + ["25M1D20M5S"] * 2
+    other = ["25M2D25M"] * 2 + ["25M1I24M"] * 2 + ["20M1D5M1D25M"] * 2
+    assert _kept(good + other) == (11, 6)
+
+
+def test_filter_compatible_with_2bp_deletion():  # vanilla_caller.rs:4262-4314: prefixes of the 25M2D... pattern stay, other deletions go
+    assert _kept(["25M2D75M", "25M2D65M", "25M2D50M5S", "25M", "24M", "10M"] + ["30M", "25M1D25M", "25M4D25M"]) == (6, 3)
+
+
+def test_filter_reads_added_to_multiple_cigar_groups():  # vanilla_caller.rs:4664-4699: the 40M read joins the 40M1I9M group, which then wins 4 : 3
+    assert _kept(["50M"] * 2 + ["40M1I9M"] * 3 + ["40M"]) == (4, 2)
+
+
+def test_filter_preserves_input_order():  # vanilla_caller.rs:4703-4740: prefix-compatible lengths are all kept
+    assert _kept(["100M", "80M", "90M", "70M", "85M"]) == (5, 0)
