@@ -385,3 +385,33 @@ def test_filter_reads_added_to_multiple_cigar_groups():  # vanilla_caller.rs:466
 
 def test_filter_preserves_input_order():  # vanilla_caller.rs:4703-4740: prefix-compatible lengths are all kept
     assert _kept(["100M", "80M", "90M", "70M", "85M"]) == (5, 0)
+
+
+# ---- create_source_read (vanilla_caller.rs:1080-1160) seen through a single-read family ------------------------------------------
+# With min_reads 1, no error-rate adjustment and no consensus-quality floor, the consensus of ONE fragment is its source read: the
+# reference's `to_source_read` unit tests (masking, trailing trims, strand) read off the emitted record.
+
+def _source_read(seq, quals, flag=0, cigar=None, min_input_base_quality=20):
+    rec = bamutil.make_record("test", seq, list(quals), flag=flag, ref_id=0, pos=0, cigar=cigar, tags=[("MI", "Z", "UMI1")])
+    o = ref_defaults(min_reads=1, min_consensus_base_quality=0, min_input_base_quality=min_input_base_quality, error_rate_pre_umi=93, error_rate_post_umi=93, track_rejects=1)
+    return call_groups(o, [[rec]], replay=False)
+
+
+def test_to_source_read_masks_low_quality_bases():  # vanilla_caller.rs:3901-3929
+    res, recs = _source_read("AAAAAAAAAA", [2, 30, 19, 21, 18, 20, 0, 30, 2, 30])
+    assert res["count"] == 1 and recs[0]["seq"] == "NANANANANA" and recs[0]["tags"]["cd"][1] == [0, 1] * 5
+
+
+def test_to_source_read_trims_trailing_low_quality_and_ns():  # vanilla_caller.rs:3957-3980, 3984-4007
+    assert _source_read("AAAAAAAAAA", [30] * 6 + [2] * 4)[1][0]["seq"] == "AAAAAA"
+    assert _source_read("AAAAAANNNN", [30] * 10)[1][0]["seq"] == "AAAAAA"
+
+
+def test_to_source_read_trims_ns_on_negative_strand():  # vanilla_caller.rs:4011-4040: reverse-complemented first, then trimmed at ITS end
+    assert _source_read("NNNNAAAAAA", [30] * 10, flag=F_REVERSE, cigar="4S1M1D5M")[1][0]["seq"] == "TTTTTT"
+
+
+def test_to_source_read_returns_none_for_all_low_quality():  # vanilla_caller.rs:4044-4064
+    res, recs = _source_read("NANANANANA", [30, 2] * 5)
+    names = _reason_names()
+    assert res["count"] == 0 and res["stats"][ST_REASON0 + names["ZeroLengthAfterTrimming"]] == 1 and res["n_rejects"] == 1
