@@ -376,7 +376,7 @@ class _HandleCaller(ConsensusCaller):
         if lib.fgx_sim_sizes(C.byref(p), C.byref(bl), C.byref(nr)) != 0:
             raise ValueError("simulated input too large for 32-bit record indices")
         dev = torch.device("cuda", self._opts.device if self._opts.device >= 0 else torch.cuda.current_device())
-        blob = torch.empty(max(16, bl.value), dtype=torch.uint8, device=dev)
+        blob = torch.empty(max(16, bl.value) + 16, dtype=torch.uint8, device=dev)   # (the kernels read whole 16-byte pieces: see fgx_process_batch_device)
         rec_off = torch.empty(max(1, nr.value), dtype=torch.int64, device=dev)
         rec_len = torch.empty(max(1, nr.value), dtype=torch.int32, device=dev)
         grp_first = torch.empty(n_families + 1, dtype=torch.int32, device=dev)

@@ -148,7 +148,9 @@ int fgx_process_batch(fgx_caller* c, const uint8_t* records, uint64_t records_le
  * pipelines do not decide (reads with more than 6 CIGAR ops, unmapped reads, malformed records; for
  * duplex / CODEC also molecules with indels or a biting per-strand read cap) are reported in
  * *n_deferred / d_deferred_groups and must be re-submitted through fgx_process_batch; 0 for
- * `simulate`-shaped input. */
+ * `simulate`-shaped input.  The kernels stage a family's bytes in whole 16-byte pieces: `d_records` must be
+ * READABLE for 16 bytes past `records_len` (any allocation larger than the stream by 16 bytes will do; the
+ * bytes are never interpreted).  The host entry above pads its own device copy. */
 int fgx_process_batch_device(fgx_caller* c, const void* d_records, uint64_t records_len, const void* d_rec_off,
                              const void* d_rec_len, uint32_t n_rec, const void* d_grp_first, uint32_t n_grp,
                              fgx_output* out, uint32_t* n_deferred, const void** d_deferred_groups);
