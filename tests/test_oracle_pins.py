@@ -369,3 +369,45 @@ def test_single_input_quals():  # vanilla_caller.rs:469-501
     lib.orc_single_input_quals(C.addressof(o), ptr(out))
     assert out[60] <= 42 and out[2] == 2 and np.all(np.diff(out.astype(int)) >= 0)
     assert out[30] in (29, 30)
+
+
+def _murmur3_unencoded_chars(units, seed=42):
+    """htsjdk `Murmur3.hashUnencodedChars` (Guava's Murmur3_32 over UTF-16 code units, two per block), as a signed 32-bit int."""
+    M = 0xFFFFFFFF
+
+    def rotl(x, r):
+        return ((x << r) | (x >> (32 - r))) & M
+
+    def mix_k1(k1):
+        k1 = (k1 * 0xCC9E2D51) & M
+        k1 = rotl(k1, 15)
+        return (k1 * 0x1B873593) & M
+
+    h1 = seed
+    for i in range(0, len(units) - 1, 2):
+        k1 = mix_k1(units[i] | (units[i + 1] << 16))
+        h1 ^= k1
+        h1 = rotl(h1, 13)
+        h1 = (h1 * 5 + 0xE6546B64) & M
+    if len(units) & 1:
+        h1 ^= mix_k1(units[-1])
+    h1 ^= 2 * len(units)
+    h1 ^= h1 >> 16
+    h1 = (h1 * 0x85EBCA6B) & M
+    h1 ^= h1 >> 13
+    h1 = (h1 * 0xC2B2AE35) & M
+    h1 ^= h1 >> 16
+    return h1 - (1 << 32) if h1 & 0x80000000 else h1
+
+
+@pytest.mark.parametrize("name", ["A", "H0164ALXX140820:2:1101:10003:23260", "abc", "abcd", "q0", "read5"])
+def test_read_name_rank_matches_utf16_murmur3(name):  # raw-bam/hash.rs:114-127 (ascii_fast_path_matches_utf16_widening)
+    units = [ord(c) for c in name]
+    assert lib.orc_read_name_rank(name.encode(), len(name)) == _murmur3_unencoded_chars(units)
+
+
+@pytest.mark.parametrize("left,right", [("H0164ALXX140820:2:1101:10003:23260", "H0164ALXX140820:2:1101:10003:23261"),
+                                        ("A0164ALXX140820:2:1101:10003:23260", "B0164ALXX140820:2:1101:10003:23260"),
+                                        ("H0164ALXX140820:2:1101:10003:23260", "H0164ALXX140820:2:2101:10003:23260"), ("frag:1", "frag:10")])
+def test_distinct_names_rank_distinctly(left, right):  # raw-bam/hash.rs:129-141
+    assert lib.orc_read_name_rank(left.encode(), len(left)) != lib.orc_read_name_rank(right.encode(), len(right))
