@@ -423,6 +423,22 @@ void orc_apply_overlapping(uint8_t* blob, const uint64_t* rec_off, const uint32_
   stats4[0] = cs.overlapping_bases; stats4[1] = cs.bases_agreeing; stats4[2] = cs.bases_disagreeing; stats4[3] = cs.bases_corrected;
 }
 
+#ifdef ORC_WITH_CODEC
+// clip_cigar_ops_raw (raw-bam/cigar.rs:404-446): the virtual hard clip of the CODEC caller.  Returns the number of ops written.
+uint32_t orc_clip_cigar_ops(const uint32_t* ops, uint32_t n, uint32_t clip, int from_start, uint32_t* out, uint32_t cap, uint64_t* ref_consumed) {
+  size_t rc = 0;
+  std::vector<uint32_t> r = clip_cigar_ops_raw(std::vector<uint32_t>(ops, ops + n), clip, from_start != 0, rc);
+  *ref_consumed = rc;
+  for (size_t i = 0; i < r.size() && i < cap; i++) out[i] = r[i];
+  return (uint32_t)r.size();
+}
+// read_pos_at_ref_pos_raw (raw-bam/cigar.rs:461-500): 1-based read position, 0 for None.
+uint64_t orc_read_pos_at_ref_pos(const uint32_t* ops, uint32_t n, uint64_t aln_start, uint64_t ref_pos, int last_if_deleted) {
+  size_t out = 0;
+  return read_pos_at_ref_pos_raw(std::vector<uint32_t>(ops, ops + n), aln_start, ref_pos, last_if_deleted != 0, out) ? out : 0;
+}
+#endif
+
 #ifdef ORC_WITH_DUPLEX
 // duplex_consensus (duplex_caller.rs:931-1108) on two single-strand consensus reads given as plain arrays (n == 0: that strand is
 // absent); no source reads (the approximate error recount).  Returns the duplex length, -1 when no duplex read comes out;

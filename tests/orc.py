@@ -37,6 +37,7 @@ def _load():
         "orc_quality_trim_point": (U32, [VP, U32, U8]), "orc_consensus_umis": (C.c_int, [CP, VP, U32]),
         "orc_overlap_pair": (C.c_int, [VP, U32, VP, U32, VP]),
         "orc_apply_overlapping": (None, [VP, VP, VP, U32, VP]),
+        "orc_clip_cigar_ops": (U32, [VP, U32, U32, C.c_int, VP, U32, VP]), "orc_read_pos_at_ref_pos": (U64, [VP, U32, U64, U64, C.c_int]),
         "orc_duplex_consensus": (C.c_int, [VP, VP, VP, VP, U32, VP, VP, VP, VP, U32, VP, VP, VP, U32, P(U32)]), "orc_duplex_cap_quality": (U8, [I32]),
         "orc_sweep_fast_vs_full": (U64, [C.c_int, P(U64)]),
         "orc_group_records": (U32, [VP, VP, VP, VP, U32, VP, VP, VP, P(U32)]),
