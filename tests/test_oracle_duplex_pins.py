@@ -271,3 +271,30 @@ def test_duplex_consensus_error_calculation():  # duplex_caller.rs:5279-5310 (ag
 
 def test_cap_quality():  # duplex_caller.rs:5420-5427
     assert [orc.lib.orc_duplex_cap_quality(v) for v in (-5, 0, 2, 50, 93, 100)] == [2, 2, 2, 50, 93, 93]
+
+
+def _ss(seq, quals, depth):
+    """`create_ss_consensus` (duplex_caller.rs:2953-2968) as a single-strand read: depth cD at every position, no errors."""
+    return (seq, list(quals), [depth] * len(seq), [0] * len(seq))
+
+
+@pytest.mark.parametrize("a,b,seq,quals", [
+    (_ss("AAAA", [20, 30, 40, 50], 3), _ss("AAAA", [20, 30, 40, 50], 2), "AAAA", [40, 60, 80, 93]),     # ..._quality_scores_agreement :2971-2996 (sum, capped at 93)
+    (_ss("ACGT", [30] * 4, 3), _ss("TGCA", [10, 15, 20, 25], 2), "ACGT", [20, 15, 10, 5]),               # ..._disagreement_unequal :2999-3026 (higher wins, difference)
+    (_ss("ACGT", [20] * 4, 3), _ss("TGCA", [20] * 4, 2), "NNNN", [2] * 4),                               # ..._disagreement_equal :3029-3054
+    (_ss("AAA", [50, 60, 93], 3), _ss("AAA", [50, 60, 93], 2), "AAA", [93] * 3),                         # ..._quality_capping :3160-3183
+    (_ss("ACGT", [5, 4, 3, 10], 3), _ss("TGCA", [3, 2, 2, 8], 2), "NNNN", [2] * 4),                      # ..._quality_difference_at_threshold :3186-3214 (a difference of 2 is the floor: masked)
+    (_ss("AAAA", [45] * 4, 50), _ss("AAAA", [20] * 4, 1), "AAAA", [65] * 4),                             # ..._with_deep_coverage :3217-3243
+    (_ss("AAAA", [25] * 4, 3), _ss("TTTT", [25] * 4, 2), "NNNN", [2] * 4),                               # ..._zero_quality_difference :3449-3474
+])
+def test_duplex_consensus_quality_rules(a, b, seq, quals):  # the `call_duplex_from_ss_pair` tests whose subject is the A/B combine
+    r = _duplex(a, b)
+    assert r[0] == seq and r[1] == quals
+
+
+def test_duplex_consensus_n_bases_and_lengths():  # :3093-3125 (n_bases), :3128-3157 (length_mismatch), :3420-3446 (mixed_bases_and_n)
+    r = _duplex(_ss("ANAA", [20] * 4, 3), _ss("AANA", [20] * 4, 2))
+    assert r[0] == "ANNA" and r[1][1] == 2 and r[1][2] == 2
+    assert _duplex(_ss("AAAA", [20] * 4, 3), _ss("AAA", [20] * 3, 2))[0] == "AAA"
+    r = _duplex(_ss("ANGT", [30] * 4, 3), _ss("TNCG", [25] * 4, 2))
+    assert r[0] == "ANGT" and r[1] == [5, 2, 5, 5]
