@@ -49,6 +49,39 @@ struct FullItem {           // a column (or UMI character) whose call needs the 
   uint32_t chains;          // 0, or the one-hot BAM codes of chains 1 | 2 << 4 | 3 << 8 (0 = chain not opened); every other base reads chain R
 };
 constexpr int N_LISTS = 1024;
+// FullItem.chains with this bit set: the column did not stay with one base — `ll` holds its observations instead of chains,
+// 16-bit each (4-bit code in consensus orientation << 8 | quality), chains & 0xFF of them in file order (at most 16);
+// k_call_full accumulates them with the four-lane Kahan loop (base_builder.rs:836-868) and calls the column
+constexpr uint32_t FULL_ITEM_OBS = 0x80000000u;
+
+// ---- split simplex pipeline (simplex_split.inc): k_split_parse leaves one SplitRec per record and one SplitFam per family;
+// k_split_cols (one wavefront per family) reads them instead of parsing, pairing and walking tags itself --------------------------
+struct SplitRec {           // 32 bytes
+  uint32_t body_off;        // record body offset minus the body offset of the family's first record
+  uint16_t seq_rel;         // SEQ offset inside the body (qualities follow at + (l_seq + 1) / 2)
+  uint16_t l_seq;
+  uint16_t clip;            // bases past the mate's start (raw-bam/overlap.rs:181-357), <= l_seq
+  uint16_t ov_off1, ov_off2, ov_cnt;   // an R1 with a mate: first shared base in this read / in the mate, number of shared bases (0: none)
+  uint8_t slot, mate_slot;  // row of this read / of its mate in the family's LDS tile (rows of end A first, then end B, file order inside an end)
+  uint8_t bits;             // end type (0 fragment, 1 R1, 2 R2) | reverse strand << 2 | has the cell tag << 3
+  uint8_t cb_len;
+  uint16_t cb_rel, mi_rel;  // tag values: offsets inside the body
+  uint8_t mi_len, rx_len;
+  uint16_t rx_rel;
+  uint32_t _pad;
+};
+struct SplitFam {           // 32 bytes
+  uint32_t flags;           // bit 0: k_split_cols takes the family (else it goes to k_simplex_wave2 untouched)
+  uint32_t need_bytes;      // LDS bytes of the family's tile: rows x (qs + ss)
+  uint16_t qs, ss;          // row strides of the quality / sequence tiles (multiples of 16)
+  uint8_t n, m_a, m_b, type_a;   // records; rows of end A / end B; type of end A (0 fragment, 1 R1) — end B is R2
+  uint8_t rev_a, rev_b;     // strand of the rows of end A / end B (a regular end has one)
+  uint8_t rx_len, rx_all;   // rx_all 1: every record carries the same RX value of rx_len bytes; 0: no record has one
+  uint16_t len_a, len_b;    // longest read of end A / end B (reverse ends: THE read length)
+  uint32_t inv_cpr;         // ceil(2^24 / chunks per row): row of flat chunk t = (t * inv_cpr) >> 24
+  uint16_t qc, sc;          // 16-byte chunks per row: qualities, sequence
+};
+static_assert(sizeof(SplitRec) == 32 && sizeof(SplitFam) == 32, "split descriptors are moved as two 16-byte pieces");
 
 struct FastParams {
   const uint8_t* blob; const uint64_t* rec_off; const uint32_t* rec_len; const uint32_t* grp_first;
@@ -68,6 +101,9 @@ struct FastParams {
   uint32_t* retry_old; uint32_t* n_retry_old;   // k_simplex_wave2: families outside its record shape → k_family_wave<0>
   const void* w2_image;            // k_simplex_wave2: image of its LDS tables (W2Lds, simplex_wave2.inc)
   const void* fw_image;            // k_family_wave: image of its LDS tables (FwLds, fastpath.hip)
+  SplitRec* split_rec; SplitFam* split_fam;   // split simplex pipeline: k_split_parse → k_split_cols
+  uint32_t* route; uint32_t* n_route;         // k_split_cols: families it does not take → k_simplex_wave2
+  const void* s2_image;            // k_split_cols: image of its LDS tables (S2Lds, simplex_split.inc)
   const uint4* fam_desc;           // per family {first record offset lo, hi, bytes to the end of the last record (~0: none), records} (k_col_bound)
   uint64_t blob_len;               // records must end inside the blob (checked before the family's bytes are staged)
   uint32_t lds_tile_bytes;
@@ -125,6 +161,7 @@ struct FastPath {
   DevBuf d_w2img;                         // W2Lds image, built from the caller's tables at the first batch
   DevBuf d_famdesc;                       // k_col_bound's family descriptors
   DevBuf d_fwimg;                         // FwLds image (k_family_wave)
+  DevBuf d_split_rec, d_split_fam, d_route, d_s2img;   // split simplex pipeline
   uint32_t lds_wave_bytes = 6144;         // wave-per-family kernel: LDS copy of one family's raw records
   uint32_t lds_wave_bytes_duplex = 8704;  // duplex molecules carry both strands (config 3: 24 records x ~330 B)
   uint32_t lds_wave_bytes_codec = 5120;   // CODEC (config 5: 8 records x ~570 B): its kernel needs 71 VGPRs, so the smaller slice buys a sixth wave per SIMD (+3 %)

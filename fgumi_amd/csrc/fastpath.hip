@@ -2294,6 +2294,7 @@ struct FullParams {
   uint32_t min_reads; uint8_t min_cons_bq;
   uint8_t* col_code; uint8_t* col_qual; uint16_t* col_err;
   char* rx_base; uint32_t rx_stride;   // consensus-UMI characters: rx_base + slot * rx_stride + index
+  uint16_t* col_depth; uint32_t min_input_bq;   // observation items (k_split_cols): the column's depth is counted here
 };
 
 __global__ __launch_bounds__(256) void k_call_full(FullParams P) {
@@ -2303,6 +2304,37 @@ __global__ __launch_bounds__(256) void k_call_full(FullParams P) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= cnt) return;
   FullItem it = P.items[(size_t)list * P.cap + i];
+  if (it.chains & FULL_ITEM_OBS) {
+    // a column that showed a second base (k_split_cols): its observations in file order, 16 bits each — the four-lane Kahan sum of
+    // ConsensusBaseBuilder::add (base_builder.rs:836-868), then the call
+    const uint32_t m = it.chains & 0xFF;
+    uint16_t ob16[16];
+    __builtin_memcpy(ob16, it.ll, 32);
+    ColumnAcc acc;
+    acc.reset();
+    const ConsensusTables& TT = P.T->t;
+#pragma unroll
+    for (uint32_t j = 0; j < 16; j++) {
+      if (j < m) {
+        const uint32_t o = ob16[j], q = o & 0xFF, code = (o >> 8) & 15;
+        const int bl = bam::code_to_lane((uint8_t)code);
+        if (bl != 255 && q >= P.min_input_bq) { const uint32_t qq = q < 93 ? q : 93; acc.add(bl, TT.correct[qq], TT.error_per_alt[qq]); }
+      }
+    }
+    int bi;
+    uint8_t q;
+    column_call(TT, acc.s, acc.obs, &bi, &q);
+    const uint32_t depth = acc.contributions();
+    const uint32_t err = depth - (bi >= 0 ? acc.obs_of(bi) : 0);
+    const uint8_t code = bi >= 0 ? (uint8_t)(1u << bi) : 15;
+    uint8_t ob, oq;
+    if (depth < P.min_reads) { ob = 15; oq = 0; }
+    else if (q < P.min_cons_bq) { ob = 15; oq = FGX_MIN_PHRED; }
+    else { ob = code; oq = q; }
+    P.col_code[it.dest] = ob; P.col_qual[it.dest] = oq; P.col_err[it.dest] = (uint16_t)(err < 32767u ? err : 32767u);
+    P.col_depth[it.dest] = (uint16_t)depth;
+    return;
+  }
   if (it.chains) {   // chains by order of appearance (k_simplex_wave2 / k_simplex_seg): the bases are sorted out here, once per item
     const uint32_t b1 = it.chains & 15, b2 = (it.chains >> 4) & 15, b3 = (it.chains >> 8) & 15;
     const double c1 = it.ll[0], c2 = it.ll[1], c3 = it.ll[2], cR = it.ll[3];
@@ -3187,6 +3219,7 @@ __global__ __launch_bounds__(256) void k_emit_codec_fast(CodecEmitParams P) {
 
 #include "simplex_wave2.inc"
 #include "simplex_seg.inc"
+#include "simplex_split.inc"
 
 // Upper bound on the consensus columns a batch can produce: a family yields at most three ends, each no
 // longer than its longest read, and l_seq <= (block_size - 33) * 2 / 3.
@@ -3227,7 +3260,8 @@ __global__ void k_reduce_stats(const unsigned long long* __restrict__ slots, uns
 // -----------------------------------------------------------------------------------------------------
 void FastPath::release() {
   for (DevBuf* b : {&d_ends, &d_sizes, &d_offsets, &d_code, &d_qual, &d_depth, &d_err, &d_misc, &d_deferred, &d_out, &d_scan_tmp, &d_strings, &d_obs, &d_retry2,
-                    &d_retry, &d_bound, &d_colbase, &d_statslots, &d_full_items, &d_full_count, &d_retry_old, &d_w2img, &d_famdesc, &d_fwimg})
+                    &d_retry, &d_bound, &d_colbase, &d_statslots, &d_full_items, &d_full_count, &d_retry_old, &d_w2img, &d_famdesc, &d_fwimg,
+                    &d_split_rec, &d_split_fam, &d_route, &d_s2img})
     b->free_();
   for (int i = 0; i < 4; i++) if (ev[i]) { (void)hipEventDestroy(ev[i]); ev[i] = nullptr; }
 }
@@ -3259,6 +3293,37 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
   d_statslots.reserve((size_t)STAT_SLOTS * 32 * 8);
   hip_check(hipMemsetAsync(d_statslots.p, 0, (size_t)STAT_SLOTS * 32 * 8, s), "memset");
   d_famdesc.reserve((size_t)n_grp * 16);
+  // Simplex without --trim: which head of the launch chain?  Shallow families (the mean family fits a quarter of a wave's LDS
+  // slice) start at k_simplex_seg<4>; everything else at the split pipeline (k_split_parse + k_split_cols, simplex_split.inc),
+  // whose record kernel also leaves what k_col_bound would (column bound, byte-span descriptor).
+  static const bool use_v2 = [] { const char* e = getenv("FGX_V2"); return !(e && e[0] == '0'); }();
+  static const bool use_seg = [] { const char* e = getenv("FGX_SEG"); return !(e && e[0] == '0'); }();
+  static const bool use_split_env = [] { const char* e = getenv("FGX_SPLIT"); return !(e && e[0] == '0'); }();
+  uint32_t seg_bytes = 11776;   // 4 wavefronts x 11776 B + the static tables = 3 workgroups per CU
+  if (const char* e = getenv("FGX_SEG_BYTES")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 4096 && v <= 32768) seg_bytes = v & ~63u; }
+  const double mean_span = (double)blob_len / (double)n_grp + 48.0;   // mean bytes of a family + alignment / read-ahead slack
+  const bool simplex_v2 = !duplex && !codec && !o.trim && use_v2;
+  const bool seg4 = simplex_v2 && use_seg && mean_span + (16 * 8 + 64) <= seg_bytes / 4;
+  const bool use_split = simplex_v2 && use_split_env && !seg4;
+  if (use_split) {
+    d_split_rec.reserve((size_t)n_rec * sizeof(SplitRec) + 64);
+    d_split_fam.reserve((size_t)n_grp * sizeof(SplitFam) + 64);
+    FastParams PK;
+    memset(&PK, 0, sizeof(PK));
+    PK.blob = d_blob; PK.rec_off = d_rec_off; PK.rec_len = d_rec_len; PK.grp_first = d_grp_first; PK.blob_len = blob_len;
+    PK.min_reads = o.min_reads; PK.max_reads = o.max_reads; PK.overlap = o.overlapping_consensus;
+    PK.tag0 = o.tag[0]; PK.tag1 = o.tag[1]; PK.cell0 = o.cell_tag[0]; PK.cell1 = o.cell_tag[1];
+    PK.prefix_len = (uint32_t)c->prefix.size();
+    PK.split_rec = d_split_rec.as<SplitRec>(); PK.split_fam = d_split_fam.as<SplitFam>();
+    // families per wavefront of the record kernel: as many as fill its 64 lanes on average
+    const double mean_recs = (double)n_rec / (double)n_grp;
+    uint32_t fpw = mean_recs >= 1.0 ? (uint32_t)(64.0 / mean_recs) : 16u;
+    fpw = fpw < 1u ? 1u : fpw > 16u ? 16u : fpw;
+    if (const char* e = getenv("FGX_SPLIT_FPW")) { const int v = atoi(e); if (v >= 1 && v <= 32) fpw = (uint32_t)v; }   // (measurement knob)
+    const uint64_t waves = ((uint64_t)n_grp + fpw - 1) / fpw;
+    hipLaunchKernelGGL(k_split_parse, dim3((uint32_t)((waves + 3) / 4)), dim3(256), 0, s, PK, n_grp, fpw, d_bound.as<uint64_t>(), 3u, d_famdesc.as<uint4>());
+    hip_check(hipGetLastError(), "k_split_parse launch");
+  } else
   hipLaunchKernelGGL(k_col_bound, dim3((n_grp + 255) / 256), dim3(256), 0, s, d_grp_first, d_rec_len, d_rec_off, n_grp, d_bound.as<uint64_t>(), duplex ? 4u : codec ? 2u : 3u,
                      d_famdesc.as<uint4>());
   {
@@ -3349,13 +3414,72 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
     int out_list = 0;
     // Simplex, no --trim: k_simplex_wave2 (two-accumulator column loop) takes the families of the common record shape over the same
     // growing LDS slices; what is outside its shape is collected in `retry_old` and goes through the k_family_wave<0> launches below.
-    static const bool use_v2 = [] { const char* e = getenv("FGX_V2"); return !(e && e[0] == '0'); }();
-    if (!duplex && !codec && !o.trim && use_v2) {
+    uint32_t n_v2 = n_grp;
+    const uint32_t* v2_list = nullptr;
+    if (use_split) {
+      // k_split_cols over growing LDS slices (4 / 2 / 1 / 1 wavefronts per workgroup); what it does not take is collected in
+      // `route` and starts the k_simplex_wave2 chain below
+      static bool s2_attr_set = false;
+      if (!s2_attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_split_cols<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        (void)hipFuncSetAttribute((const void*)k_split_cols<160, 80>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        (void)hipGetLastError();
+        s2_attr_set = true;
+      }
+      if (!d_s2img.p) {   // the tables of a caller never change: one image per FastPath
+        S2Lds* img = new S2Lds;
+        build_s2_image(*img, c->h_tables.t);
+        d_s2img.reserve(sizeof(S2Lds));
+        hip_check(hipMemcpyAsync(d_s2img.p, img, sizeof(S2Lds), hipMemcpyHostToDevice, s), "H2D s2 image");
+        hip_check(hipStreamSynchronize(s), "sync");
+        delete img;
+      }
+      d_route.reserve((size_t)n_grp * 4);
+      uint32_t* d_cnt_route = (uint32_t*)(misc + 33);
+      P.s2_image = d_s2img.p; P.fam_desc = d_famdesc.as<uint4>();
+      P.split_rec = d_split_rec.as<SplitRec>(); P.split_fam = d_split_fam.as<SplitFam>();
+      P.route = d_route.as<uint32_t>(); P.n_route = d_cnt_route;
+      static const uint32_t s2_bytes0 = [] { const char* e = getenv("FGX_S2_BYTES"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 2048 && v <= 32768 ? (v & ~15) : 4352); }();
+      static const uint32_t s2_wpb = [] { const char* e = getenv("FGX_S2_WPB"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= 4 ? v : 4); }();
+      static const bool s2_fixed = [] { const char* e = getenv("FGX_S2_FIXED"); return e && e[0] == '1'; }();
+      struct S2Stage { uint32_t bytes, wpb; bool fixed; };
+      std::vector<S2Stage> st2;
+      if (s2_fixed) st2.push_back({s2_bytes0, s2_wpb, true});
+      st2.push_back({s2_bytes0, s2_wpb, false});
+      st2.push_back({2 * s2_bytes0 > 8704u ? 2 * s2_bytes0 : 8704u, 2u, false});
+      st2.push_back({17408u, 1u, false});
+      st2.push_back({34816u, 1u, false});
+      uint32_t n_s2 = n_grp;
+      const uint32_t* s2_list = nullptr;
+      int s2_out = 0;
+      for (size_t ci = 0; ci < st2.size() && n_s2; ci++) {
+        if (ci > 0 && !st2[ci - 1].fixed && st2[ci].bytes <= st2[ci - 1].bytes) continue;
+        const bool last = ci + 1 == st2.size();
+        hip_check(hipMemsetAsync(d_cnt, 0, 4, s), "memset");
+        FastParams PS = P;
+        PS.group_list = s2_list; PS.lds_wave_bytes = st2[ci].bytes;
+        PS.retry = last ? nullptr : lists[s2_out]; PS.n_retry = d_cnt;
+        const uint32_t wpb = st2[ci].wpb;
+        const dim3 grid((n_s2 + wpb - 1) / wpb), block(64 * wpb);
+        const size_t lds = (size_t)wpb * st2[ci].bytes;
+        if (st2[ci].fixed) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<160, 80>), grid, block, lds, s, PS, n_s2);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<0, 0>), grid, block, lds, s, PS, n_s2);
+        hip_check(hipGetLastError(), "k_split_cols launch");
+        uint32_t n_next = 0;
+        hip_check(hipMemcpyAsync(&n_next, d_cnt, 4, hipMemcpyDeviceToHost, s), "D2H");
+        hip_check(hipStreamSynchronize(s), "sync");
+        s2_list = lists[s2_out]; n_s2 = PS.retry ? n_next : 0; s2_out ^= 1;
+      }
+      uint32_t n_route = 0;
+      hip_check(hipMemcpyAsync(&n_route, d_cnt_route, 4, hipMemcpyDeviceToHost, s), "D2H");
+      hip_check(hipStreamSynchronize(s), "sync");
+      n_v2 = n_route; v2_list = d_route.as<uint32_t>();
+      static const bool s2_verbose = [] { const char* e = getenv("FGX_S2_VERBOSE"); return e && e[0] == '1'; }();
+      if (s2_verbose) fprintf(stderr, "[fgx] split pipeline: %u families, %u routed to k_simplex_wave2\n", n_grp, n_route);
+    }
+    if (simplex_v2) {
       // Launch chain: k_simplex_seg<4> / <2> (4 / 2 families per wavefront, while the mean family fits a quarter / half of the
       // wave's LDS) → k_simplex_wave2 over the growing slices.  A family that does not fit a launch moves to the next one.
-      static const bool use_seg = [] { const char* e = getenv("FGX_SEG"); return !(e && e[0] == '0'); }();
-      uint32_t seg_bytes = 11776;   // 4 wavefronts x 11776 B + the static tables = 3 workgroups per CU
-      if (const char* e = getenv("FGX_SEG_BYTES")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 4096 && v <= 32768) seg_bytes = v & ~63u; }
       static bool v2_attr_set = false;
       if (!v2_attr_set) {
         (void)hipFuncSetAttribute((const void*)k_simplex_wave2, hipFuncAttributeMaxDynamicSharedMemorySize, WAVES_PER_BLOCK * 22016);
@@ -3375,7 +3499,6 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
       P.fam_desc = d_famdesc.as<uint4>();
       struct Stage { int fam_per_wave; uint32_t bytes; uint32_t wpb; };
       std::vector<Stage> chain;
-      const double mean_span = (double)blob_len / (double)n_grp + 48.0;   // mean bytes of a family + alignment / read-ahead slack
       static const uint32_t seg_wpb = [] { const char* e = getenv("FGX_SEG_WPB"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= WAVES_PER_BLOCK ? v : WAVES_PER_BLOCK); }();   // (measurement knob)
       if (use_seg && mean_span + (16 * 8 + 64) <= seg_bytes / 4) chain.push_back({4, seg_bytes, seg_wpb});
       // (two families per wavefront measured slower than one at depth 8 — 14.9 vs 10.7 ms per 1 M families: the column phase costs
@@ -3393,8 +3516,6 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
       for (int st = 0; st < 3; st++) if (st == 0 || stages[st] > stages[st - 1]) chain.push_back({1, stages[st], st == 0 ? w2_wpb : st == 1 ? 2u : 1u});
       d_retry_old.reserve((size_t)n_grp * 4);
       uint32_t* d_cnt_old = (uint32_t*)(misc + 32);
-      uint32_t n_v2 = n_grp;
-      const uint32_t* v2_list = nullptr;
       int v2_out = 0;
       for (size_t ci = 0; ci < chain.size() && n_v2; ci++) {
         const Stage& S = chain[ci];
@@ -3467,6 +3588,7 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
       F.items = d_full_items.as<FullItem>(); F.count = d_full_count.as<uint32_t>(); F.cap = full_cap;
       F.T = P.T; F.TU = P.TU; F.min_reads = P.min_reads; F.min_cons_bq = P.min_cons_bq;
       F.col_code = P.col_code; F.col_qual = P.col_qual; F.col_err = P.col_err;
+      F.col_depth = P.col_depth; F.min_input_bq = P.min_input_bq;
       if (duplex) { F.rx_base = (char*)P.dends + offsetof(DuplexDesc, rx); F.rx_stride = sizeof(DuplexDesc); }
       else if (codec) { F.rx_base = (char*)P.cends + offsetof(CodecDesc, rx); F.rx_stride = sizeof(CodecDesc); }
       else { F.rx_base = (char*)P.ends + offsetof(EndDesc, rx); F.rx_stride = sizeof(EndDesc); }
