@@ -3293,6 +3293,8 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
   d_statslots.reserve((size_t)STAT_SLOTS * 32 * 8);
   hip_check(hipMemsetAsync(d_statslots.p, 0, (size_t)STAT_SLOTS * 32 * 8, s), "memset");
   d_famdesc.reserve((size_t)n_grp * 16);
+  hip_check(hipEventRecord(c->ev0, s), "event");
+  hip_check(hipEventRecord(ev[0], s), "event");   // the family stage: record kernel / column bound, scan, family kernels, k_call_full
   // Simplex without --trim: which head of the launch chain?  Shallow families (the mean family fits a quarter of a wave's LDS
   // slice) start at k_simplex_seg<4>; everything else at the split pipeline (k_split_parse + k_split_cols, simplex_split.inc),
   // whose record kernel also leaves what k_col_bound would (column bound, byte-span descriptor).
@@ -3321,7 +3323,7 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
     fpw = fpw < 1u ? 1u : fpw > 16u ? 16u : fpw;
     if (const char* e = getenv("FGX_SPLIT_FPW")) { const int v = atoi(e); if (v >= 1 && v <= 32) fpw = (uint32_t)v; }   // (measurement knob)
     const uint64_t waves = ((uint64_t)n_grp + fpw - 1) / fpw;
-    hipLaunchKernelGGL(k_split_parse, dim3((uint32_t)((waves + 3) / 4)), dim3(256), 0, s, PK, n_grp, fpw, d_bound.as<uint64_t>(), 3u, d_famdesc.as<uint4>());
+    hipLaunchKernelGGL(k_split_parse, dim3((uint32_t)((waves + 1) / 2)), dim3(128), 0, s, PK, n_grp, fpw, d_bound.as<uint64_t>(), 3u, d_famdesc.as<uint4>());
     hip_check(hipGetLastError(), "k_split_parse launch");
   } else
   hipLaunchKernelGGL(k_col_bound, dim3((n_grp + 255) / 256), dim3(256), 0, s, d_grp_first, d_rec_len, d_rec_off, n_grp, d_bound.as<uint64_t>(), duplex ? 4u : codec ? 2u : 3u,
@@ -3332,6 +3334,10 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
     d_scan_tmp.reserve(tb);
     hip_check(hipcub::DeviceScan::ExclusiveSum(d_scan_tmp.p, tb, d_bound.as<uint64_t>(), d_colbase.as<uint64_t>(), (int)n_grp, s), "scan bound");
   }
+  // (split pipeline: the tile strides of the first families decide which build of k_split_cols goes first)
+  SplitFam fam_sample[64];
+  const uint32_t n_sample = use_split ? (n_grp < 64u ? n_grp : 64u) : 0u;
+  if (n_sample) hip_check(hipMemcpyAsync(fam_sample, d_split_fam.p, (size_t)n_sample * sizeof(SplitFam), hipMemcpyDeviceToHost, s), "D2H");
   uint64_t lastb[2];
   hip_check(hipMemcpyAsync(&lastb[0], d_colbase.as<uint64_t>() + (n_grp - 1), 8, hipMemcpyDeviceToHost, s), "D2H");
   hip_check(hipMemcpyAsync(&lastb[1], d_bound.as<uint64_t>() + (n_grp - 1), 8, hipMemcpyDeviceToHost, s), "D2H");
@@ -3392,8 +3398,6 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
   P.lds_wave_bytes = wave_bytes;
   P.lds_tile_bytes = lds_tile_bytes_large;
 
-  hip_check(hipEventRecord(c->ev0, s), "event");
-  hip_check(hipEventRecord(ev[0], s), "event");
   // Wave-per-family launches over growing LDS slices: everything first, then only the groups whose records did not fit
   // (long-tail families: 6 KB holds ~18 records of 150 bp, 12 KB ~36, 22 KB all 64 a wavefront can take).
   {
@@ -3441,7 +3445,11 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
       P.route = d_route.as<uint32_t>(); P.n_route = d_cnt_route;
       static const uint32_t s2_bytes0 = [] { const char* e = getenv("FGX_S2_BYTES"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 2048 && v <= 32768 ? (v & ~15) : 4352); }();
       static const uint32_t s2_wpb = [] { const char* e = getenv("FGX_S2_WPB"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= 4 ? v : 4); }();
-      static const bool s2_fixed = [] { const char* e = getenv("FGX_S2_FIXED"); return e && e[0] == '1'; }();
+      // rows of 160 + 80 bytes (reads up to 160 bases) have their own build: member rows at immediate offsets in the column loop
+      static const int s2_fixed_env = [] { const char* e = getenv("FGX_S2_FIXED"); return e ? atoi(e) : -1; }();   // (measurement knob: 0 / 1)
+      uint32_t n160 = 0;
+      for (uint32_t i = 0; i < n_sample; i++) n160 += (fam_sample[i].qs == 160 && fam_sample[i].ss == 80) ? 1u : 0u;
+      const bool s2_fixed = s2_fixed_env >= 0 ? s2_fixed_env != 0 : 2 * n160 > n_sample;
       struct S2Stage { uint32_t bytes, wpb; bool fixed; };
       std::vector<S2Stage> st2;
       if (s2_fixed) st2.push_back({s2_bytes0, s2_wpb, true});
