@@ -81,7 +81,20 @@ struct SplitFam {           // 32 bytes
   uint32_t inv_cpr;         // ceil(2^24 / chunks per row): row of flat chunk t = (t * inv_cpr) >> 24
   uint16_t qc, sc;          // 16-byte chunks per row: qualities, sequence
 };
-static_assert(sizeof(SplitRec) == 32 && sizeof(SplitFam) == 32, "split descriptors are moved as two 16-byte pieces");
+struct SplitOut {           // 32 bytes: what k_split_cols decided for a family; k_split_finish (a thread per family) turns it into the
+                            // EndDescs, record sizes and counters
+  uint8_t status;           // 0: not finished by k_split_cols (another kernel's family); 1: finished; 2: fewer records than --min-reads
+  uint8_t ne;               // consensus reads: 0, 1 (fragment) or 2 (R1 + R2)
+  uint8_t type_a;           // end A: 0 fragment, 1 R1
+  uint8_t fk_a, fk_b;       // first retained record of end A / end B (index inside the family): cell-barcode source
+  uint8_t kept_a, kept_b;   // retained reads per end (the UMI rule: one read = its bytes, several = normalised)
+  uint8_t n;                // records of the family
+  uint16_t lc_a, lc_b;      // consensus lengths
+  uint32_t rej;             // rejected reads: insufficient | zero length << 8 | orphan << 16
+  uint32_t ov_agree, ov_dis, ov_corr;   // overlapping-bases counters
+  uint32_t _pad;
+};
+static_assert(sizeof(SplitRec) == 32 && sizeof(SplitFam) == 32 && sizeof(SplitOut) == 32, "split descriptors are moved as two 16-byte pieces");
 
 struct FastParams {
   const uint8_t* blob; const uint64_t* rec_off; const uint32_t* rec_len; const uint32_t* grp_first;
@@ -101,7 +114,7 @@ struct FastParams {
   uint32_t* retry_old; uint32_t* n_retry_old;   // k_simplex_wave2: families outside its record shape → k_family_wave<0>
   const void* w2_image;            // k_simplex_wave2: image of its LDS tables (W2Lds, simplex_wave2.inc)
   const void* fw_image;            // k_family_wave: image of its LDS tables (FwLds, fastpath.hip)
-  SplitRec* split_rec; SplitFam* split_fam;   // split simplex pipeline: k_split_parse → k_split_cols
+  SplitRec* split_rec; SplitFam* split_fam; SplitOut* split_out;   // split simplex pipeline: k_split_parse → k_split_cols → k_split_finish
   uint32_t* route; uint32_t* n_route;         // k_split_cols: families it does not take → k_simplex_wave2
   const void* s2_image;            // k_split_cols: image of its LDS tables (S2Lds, simplex_split.inc)
   const uint4* fam_desc;           // per family {first record offset lo, hi, bytes to the end of the last record (~0: none), records} (k_col_bound)
@@ -161,7 +174,7 @@ struct FastPath {
   DevBuf d_w2img;                         // W2Lds image, built from the caller's tables at the first batch
   DevBuf d_famdesc;                       // k_col_bound's family descriptors
   DevBuf d_fwimg;                         // FwLds image (k_family_wave)
-  DevBuf d_split_rec, d_split_fam, d_route, d_s2img;   // split simplex pipeline
+  DevBuf d_split_rec, d_split_fam, d_split_out, d_route, d_s2img;   // split simplex pipeline
   uint32_t lds_wave_bytes = 6144;         // wave-per-family kernel: LDS copy of one family's raw records
   uint32_t lds_wave_bytes_duplex = 8704;  // duplex molecules carry both strands (config 3: 24 records x ~330 B)
   uint32_t lds_wave_bytes_codec = 5120;   // CODEC (config 5: 8 records x ~570 B): its kernel needs 71 VGPRs, so the smaller slice buys a sixth wave per SIMD (+3 %)

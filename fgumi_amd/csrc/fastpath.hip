@@ -3261,7 +3261,7 @@ __global__ void k_reduce_stats(const unsigned long long* __restrict__ slots, uns
 void FastPath::release() {
   for (DevBuf* b : {&d_ends, &d_sizes, &d_offsets, &d_code, &d_qual, &d_depth, &d_err, &d_misc, &d_deferred, &d_out, &d_scan_tmp, &d_strings, &d_obs, &d_retry2,
                     &d_retry, &d_bound, &d_colbase, &d_statslots, &d_full_items, &d_full_count, &d_retry_old, &d_w2img, &d_famdesc, &d_fwimg,
-                    &d_split_rec, &d_split_fam, &d_route, &d_s2img})
+                    &d_split_rec, &d_split_fam, &d_split_out, &d_route, &d_s2img})
     b->free_();
   for (int i = 0; i < 4; i++) if (ev[i]) { (void)hipEventDestroy(ev[i]); ev[i] = nullptr; }
 }
@@ -3442,6 +3442,8 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
       uint32_t* d_cnt_route = (uint32_t*)(misc + 33);
       P.s2_image = d_s2img.p; P.fam_desc = d_famdesc.as<uint4>();
       P.split_rec = d_split_rec.as<SplitRec>(); P.split_fam = d_split_fam.as<SplitFam>();
+      d_split_out.reserve((size_t)n_grp * sizeof(SplitOut));
+      P.split_out = d_split_out.as<SplitOut>();
       P.route = d_route.as<uint32_t>(); P.n_route = d_cnt_route;
       static const uint32_t s2_bytes0 = [] { const char* e = getenv("FGX_S2_BYTES"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 2048 && v <= 32768 ? (v & ~15) : 4352); }();
       static const uint32_t s2_wpb = [] { const char* e = getenv("FGX_S2_WPB"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= 4 ? v : 4); }();
@@ -3478,6 +3480,9 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
         hip_check(hipStreamSynchronize(s), "sync");
         s2_list = lists[s2_out]; n_s2 = PS.retry ? n_next : 0; s2_out ^= 1;
       }
+      // EndDescs, record sizes and counters of the families k_split_cols finished: a thread per family
+      hipLaunchKernelGGL(k_split_finish, dim3((n_grp + 255) / 256), dim3(256), 0, s, P, n_grp);
+      hip_check(hipGetLastError(), "k_split_finish launch");
       uint32_t n_route = 0;
       hip_check(hipMemcpyAsync(&n_route, d_cnt_route, 4, hipMemcpyDeviceToHost, s), "D2H");
       hip_check(hipStreamSynchronize(s), "sync");
