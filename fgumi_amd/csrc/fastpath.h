@@ -179,6 +179,10 @@ struct FastPath {
   uint32_t lds_wave_bytes_duplex = 8704;  // duplex molecules carry both strands (config 3: 24 records x ~330 B)
   uint32_t lds_wave_bytes_codec = 5120;   // CODEC (config 5: 8 records x ~570 B): its kernel needs 71 VGPRs, so the smaller slice buys a sixth wave per SIMD (+3 %)
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  // split simplex pipeline: the record kernel runs chunk by chunk on a second stream, under the column kernel of the chunk before
+  static constexpr int MAX_CHUNKS = 16;
+  hipStream_t s2 = nullptr;
+  hipEvent_t ev_chunk[MAX_CHUNKS] = {}, ev_sample = nullptr;
   int run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const uint64_t* d_rec_off, const uint32_t* d_rec_len, uint32_t n_rec,
           const uint32_t* d_grp_first, uint32_t n_grp, FastResult* res);
   void release();

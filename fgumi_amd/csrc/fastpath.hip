@@ -2475,7 +2475,11 @@ __device__ void emit_generic(const EmitParams& P, const EndDesc& D, const EmitCt
 // copies — was measured three times, rounds 1 and 2: 3.4 – 4.0 ms.  The wave's lifetime is a chain of memory round trips, and
 // every LDS hop adds one; registers-only streaming below is the fastest form found.)
 __device__ __forceinline__ void emit_one(const EmitParams& P, const EndDesc& D, uint64_t out_off, uint32_t lane);
-__global__ __launch_bounds__(256) void k_emit(EmitParams P) {
+#ifndef FGX_EMIT_OCC
+#define FGX_EMIT_OCC 7   /* wavefronts per SIMD the register allocation of k_emit aims at (the kernel waits on memory two thirds of its time: 6 -> 7
+                            1.77 -> 1.57 ms per 2 M records; 8 spills 26 registers: 3.4 ms) */
+#endif
+__global__ __launch_bounds__(256, FGX_EMIT_OCC) void k_emit(EmitParams P) {
   // the family's (up to) three descriptors, copied once with 16-byte loads: every field read below is an LDS read — as global
   // loads, the valid flags and then each record's fields were dependent memory round trips of their own
   __shared__ __align__(16) EndDesc sD[4][3];
@@ -3264,6 +3268,11 @@ void FastPath::release() {
                     &d_split_rec, &d_split_fam, &d_split_out, &d_route, &d_s2img})
     b->free_();
   for (int i = 0; i < 4; i++) if (ev[i]) { (void)hipEventDestroy(ev[i]); ev[i] = nullptr; }
+  if (s2) {
+    (void)hipStreamDestroy(s2); s2 = nullptr;
+    for (int i = 0; i < MAX_CHUNKS; i++) if (ev_chunk[i]) { (void)hipEventDestroy(ev_chunk[i]); ev_chunk[i] = nullptr; }
+    if (ev_sample) { (void)hipEventDestroy(ev_sample); ev_sample = nullptr; }
+  }
 }
 
 int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const uint64_t* d_rec_off, const uint32_t* d_rec_len,
@@ -3307,25 +3316,6 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
   const bool simplex_v2 = !duplex && !codec && !o.trim && use_v2;
   const bool seg4 = simplex_v2 && use_seg && mean_span + (16 * 8 + 64) <= seg_bytes / 4;
   const bool use_split = simplex_v2 && use_split_env && !seg4;
-  if (use_split) {
-    d_split_rec.reserve((size_t)n_rec * sizeof(SplitRec) + 64);
-    d_split_fam.reserve((size_t)n_grp * sizeof(SplitFam) + 64);
-    FastParams PK;
-    memset(&PK, 0, sizeof(PK));
-    PK.blob = d_blob; PK.rec_off = d_rec_off; PK.rec_len = d_rec_len; PK.grp_first = d_grp_first; PK.blob_len = blob_len;
-    PK.min_reads = o.min_reads; PK.max_reads = o.max_reads; PK.overlap = o.overlapping_consensus;
-    PK.tag0 = o.tag[0]; PK.tag1 = o.tag[1]; PK.cell0 = o.cell_tag[0]; PK.cell1 = o.cell_tag[1];
-    PK.prefix_len = (uint32_t)c->prefix.size();
-    PK.split_rec = d_split_rec.as<SplitRec>(); PK.split_fam = d_split_fam.as<SplitFam>();
-    // families per wavefront of the record kernel: as many as fill its 64 lanes on average
-    const double mean_recs = (double)n_rec / (double)n_grp;
-    uint32_t fpw = mean_recs >= 1.0 ? (uint32_t)(64.0 / mean_recs) : 16u;
-    fpw = fpw < 1u ? 1u : fpw > 16u ? 16u : fpw;
-    if (const char* e = getenv("FGX_SPLIT_FPW")) { const int v = atoi(e); if (v >= 1 && v <= 32) fpw = (uint32_t)v; }   // (measurement knob)
-    const uint64_t waves = ((uint64_t)n_grp + fpw - 1) / fpw;
-    hipLaunchKernelGGL(k_split_parse, dim3((uint32_t)((waves + 1) / 2)), dim3(128), 0, s, PK, n_grp, fpw, d_bound.as<uint64_t>(), 3u, d_famdesc.as<uint4>());
-    hip_check(hipGetLastError(), "k_split_parse launch");
-  } else
   hipLaunchKernelGGL(k_col_bound, dim3((n_grp + 255) / 256), dim3(256), 0, s, d_grp_first, d_rec_len, d_rec_off, n_grp, d_bound.as<uint64_t>(), duplex ? 4u : codec ? 2u : 3u,
                      d_famdesc.as<uint4>());
   {
@@ -3334,10 +3324,6 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
     d_scan_tmp.reserve(tb);
     hip_check(hipcub::DeviceScan::ExclusiveSum(d_scan_tmp.p, tb, d_bound.as<uint64_t>(), d_colbase.as<uint64_t>(), (int)n_grp, s), "scan bound");
   }
-  // (split pipeline: the tile strides of the first families decide which build of k_split_cols goes first)
-  SplitFam fam_sample[64];
-  const uint32_t n_sample = use_split ? (n_grp < 64u ? n_grp : 64u) : 0u;
-  if (n_sample) hip_check(hipMemcpyAsync(fam_sample, d_split_fam.p, (size_t)n_sample * sizeof(SplitFam), hipMemcpyDeviceToHost, s), "D2H");
   uint64_t lastb[2];
   hip_check(hipMemcpyAsync(&lastb[0], d_colbase.as<uint64_t>() + (n_grp - 1), 8, hipMemcpyDeviceToHost, s), "D2H");
   hip_check(hipMemcpyAsync(&lastb[1], d_bound.as<uint64_t>() + (n_grp - 1), 8, hipMemcpyDeviceToHost, s), "D2H");
@@ -3445,6 +3431,47 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
       d_split_out.reserve((size_t)n_grp * sizeof(SplitOut));
       P.split_out = d_split_out.as<SplitOut>();
       P.route = d_route.as<uint32_t>(); P.n_route = d_cnt_route;
+      // ---- the record kernel, chunk by chunk on a second stream: chunk i + 1 (waiting on memory most of its time) runs under the column
+      //      kernel of chunk i (bound by vector-instruction issue) ----------------------------------------------------------------------
+      d_split_rec.reserve((size_t)n_rec * sizeof(SplitRec) + 64);
+      d_split_fam.reserve((size_t)n_grp * sizeof(SplitFam) + 64);
+      P.split_rec = d_split_rec.as<SplitRec>(); P.split_fam = d_split_fam.as<SplitFam>();
+      if (!s2) { hip_check(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking), "hipStreamCreate"); for (int i = 0; i < MAX_CHUNKS; i++) hip_check(hipEventCreateWithFlags(&ev_chunk[i], hipEventDisableTiming), "hipEventCreate"); hip_check(hipEventCreateWithFlags(&ev_sample, hipEventDisableTiming), "hipEventCreate"); }
+      FastParams PK;
+      memset(&PK, 0, sizeof(PK));
+      PK.blob = d_blob; PK.rec_off = d_rec_off; PK.rec_len = d_rec_len; PK.grp_first = d_grp_first; PK.blob_len = blob_len;
+      PK.min_reads = o.min_reads; PK.max_reads = o.max_reads; PK.overlap = o.overlapping_consensus;
+      PK.tag0 = o.tag[0]; PK.tag1 = o.tag[1]; PK.cell0 = o.cell_tag[0]; PK.cell1 = o.cell_tag[1];
+      PK.prefix_len = (uint32_t)c->prefix.size();
+      PK.split_rec = P.split_rec; PK.split_fam = P.split_fam;
+      // families per wavefront of the record kernel: as many as fill its 64 lanes on average
+      const double mean_recs = (double)n_rec / (double)n_grp;
+      uint32_t fpw = mean_recs >= 1.0 ? (uint32_t)(64.0 / mean_recs) : 16u;
+      fpw = fpw < 1u ? 1u : fpw > 16u ? 16u : fpw;
+      if (const char* e = getenv("FGX_SPLIT_FPW")) { const int v = atoi(e); if (v >= 1 && v <= 32) fpw = (uint32_t)v; }   // (measurement knob)
+      static const int chunks_env = [] { const char* e = getenv("FGX_SPLIT_CHUNKS"); return e ? atoi(e) : 0; }();      // (measurement knob)
+      uint32_t n_chunks = chunks_env >= 1 ? (uint32_t)chunks_env : (n_grp >= 400000u ? 8u : n_grp >= 100000u ? 4u : 1u);
+      if (n_chunks > (uint32_t)MAX_CHUNKS - 1) n_chunks = MAX_CHUNKS - 1;   // (the last event marks where the second stream starts)
+      uint32_t chunk_fam = (n_grp + n_chunks - 1) / n_chunks;
+      chunk_fam = ((chunk_fam + 4 * fpw - 1) / (4 * fpw)) * (4 * fpw);      // whole workgroups of both kernels per chunk
+      hip_check(hipEventRecord(ev_chunk[MAX_CHUNKS - 1], s), "event");      // (the second stream starts where this one is: buffers, memsets)
+      hip_check(hipStreamWaitEvent(s2, ev_chunk[MAX_CHUNKS - 1], 0), "wait");
+      auto launch_parse = [&](uint32_t ci) {
+        const uint32_t ga = ci * chunk_fam, gb = std::min<uint64_t>((uint64_t)ga + chunk_fam, n_grp);
+        if (ga >= gb) return;
+        const uint64_t waves = ((uint64_t)(gb - ga) + fpw - 1) / fpw;
+        hipLaunchKernelGGL(k_split_parse, dim3((uint32_t)((waves + 1) / 2)), dim3(128), 0, s2, PK, ga, gb, fpw, (uint64_t*)nullptr, 3u, (uint4*)nullptr);
+        hip_check(hipGetLastError(), "k_split_parse launch");
+        hip_check(hipEventRecord(ev_chunk[ci], s2), "event");
+      };
+      launch_parse(0);
+      // the tile strides of the first families decide which build of k_split_cols goes first
+      SplitFam fam_sample[64];
+      const uint32_t n_sample = n_grp < 64u ? n_grp : 64u;
+      hip_check(hipMemcpyAsync(fam_sample, d_split_fam.p, (size_t)n_sample * sizeof(SplitFam), hipMemcpyDeviceToHost, s2), "D2H");
+      hip_check(hipEventRecord(ev_sample, s2), "event");
+      for (uint32_t ci = 1; ci < n_chunks; ci++) launch_parse(ci);
+      hip_check(hipEventSynchronize(ev_sample), "sync");
       static const uint32_t s2_bytes0 = [] { const char* e = getenv("FGX_S2_BYTES"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 2048 && v <= 32768 ? (v & ~15) : 4352); }();
       static const uint32_t s2_wpb = [] { const char* e = getenv("FGX_S2_WPB"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= 4 ? v : 4); }();
       // rows of 160 + 80 bytes (reads up to 160 bases) have their own build: member rows at immediate offsets in the column loop
@@ -3470,10 +3497,21 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
         PS.group_list = s2_list; PS.lds_wave_bytes = st2[ci].bytes;
         PS.retry = last ? nullptr : lists[s2_out]; PS.n_retry = d_cnt;
         const uint32_t wpb = st2[ci].wpb;
-        const dim3 grid((n_s2 + wpb - 1) / wpb), block(64 * wpb);
         const size_t lds = (size_t)wpb * st2[ci].bytes;
-        if (st2[ci].fixed) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<160, 80>), grid, block, lds, s, PS, n_s2);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<0, 0>), grid, block, lds, s, PS, n_s2);
+        auto launch_cols = [&](uint32_t g_first, uint32_t count) {
+          PS.g0 = g_first;
+          const dim3 grid((count + wpb - 1) / wpb), block(64 * wpb);
+          if (st2[ci].fixed) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<160, 80>), grid, block, lds, s, PS, count);
+          else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<0, 0>), grid, block, lds, s, PS, count);
+        };
+        if (ci == 0) {   // the first stage takes the families in file order, chunk by chunk behind the record kernel
+          for (uint32_t k = 0; k < n_chunks; k++) {
+            const uint32_t ga = k * chunk_fam, gb = (uint32_t)std::min<uint64_t>((uint64_t)ga + chunk_fam, n_grp);
+            if (ga >= gb) break;
+            hip_check(hipStreamWaitEvent(s, ev_chunk[k], 0), "wait");
+            launch_cols(ga, gb - ga);
+          }
+        } else launch_cols(0u, n_s2);
         hip_check(hipGetLastError(), "k_split_cols launch");
         uint32_t n_next = 0;
         hip_check(hipMemcpyAsync(&n_next, d_cnt, 4, hipMemcpyDeviceToHost, s), "D2H");
