@@ -12,9 +12,11 @@ N>1 (families are independent → no collective on the data path):
   --scaling weak    (default) every rank processes its own 5 M-family shard of the family stream
   --scaling strong  ONE 5 M-family stream is cut into contiguous shards of equal record bytes
                     (`distributed.balanced_shards` over the per-family weights), one per rank
-  --reassemble root (default for N>1) every step also ships the shard payloads to rank 0 in rank (= input)
-                    order over RCCL point-to-point — the north star's reassembly step — INSIDE the timed
-                    region; `value_without_reassembly` comes from a second timed loop without it.
+  --reassemble      N>1: `value` is the rate with the shard payloads left on their ranks (a writer per rank; output is
+                    SO:unsorted in input order, so rank order IS file order).  `auto` / `root` also time a second loop
+                    in which every step ships the payloads to rank 0 in rank order over RCCL point-to-point — the north
+                    star's single-writer reassembly — and report it beside (`value_with_reassembly_on_root`): one root
+                    receiving 9 GB per rank and step is bound by its xGMI links, not by the kernels.
 """
 import argparse
 import glob
@@ -41,6 +43,24 @@ def cpu_model():
     return "unknown"
 
 
+def physical_cores():
+    try:
+        seen = set()
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        return len(seen) or None
+    except OSError:
+        return None
+
+
 def cpu_baseline(n_families, family_size, read_length, threads, duplex=False, codec=False):
     """Bounded sample of the same workload through the ORACLE (C++ restatement of the reference CPU caller;
     `--threads`-style batches of MI groups, one caller object per batch, Phred tables cached process-wide like the
@@ -59,12 +79,13 @@ def cpu_baseline(n_families, family_size, read_length, threads, duplex=False, co
     bg = 1000 if codec else 100 if duplex else 50
 
     def run(nf, T, reps):
+        # timed: the worker section inside the oracle (every batch's ConsensusOutput bytes ready: what the reference's Process step
+        # hands to its writer) — NOT the harness's single-threaded join of the batches into one buffer, nor the copy into Python
         g = simulate_grouped_reads(nf, family_size=family_size, read_length=read_length, duplex=int(duplex), **extra)
         best, res = None, None
         for _ in range(reps):
-            t0 = time.perf_counter()
             res = orc.process(o, g.blob, g.rec_off, g.rec_len, g.grp_first, batch_groups=bg, threads=T)
-            dt = time.perf_counter() - t0
+            dt = res["seconds_workers"]
             best = dt if best is None else min(best, dt)
         return g.n_rec / best, res["count"] / best, g.n_rec
 
@@ -72,11 +93,15 @@ def cpu_baseline(n_families, family_size, read_length, threads, duplex=False, co
     v1, c1, r1 = run(n1, 1, 2)
     vall, call, rall = run(n_families, threads, 3)
     shape = f"{family_size} pairs x {read_length}bp" + (" (--duplex)" if duplex else " (CODEC pairs, insert N(350,60))" if codec else "")
+    phys = physical_cores() or threads
     return dict(value=vall, unit="raw reads/s", cores=threads, kind="port", cpu_model=cpu_model(),
                 value_1_thread=v1, speedup_all_over_1=vall / v1 if v1 else None,
+                # what perfect scaling of the one-thread figure over the box's physical cores would give: the number to hold the GPU
+                # against when the measured multi-thread leg falls short of it (memory allocator, SMT, NUMA)
+                physical_cores=phys, linear_bound=v1 * phys,
                 consensus_reads_per_s=call, consensus_reads_per_s_1_thread=c1,
                 sample=f"T={threads}: {n_families} families x {shape} = {rall} reads, best of 3; T=1: {n1} families = {r1} reads, best of 2; "
-                       f"compute-only (records in RAM -> ConsensusOutput bytes), batches of {bg} MI groups pulled by the worker threads")
+                       f"compute-only (records in RAM -> per-batch ConsensusOutput bytes), batches of {bg} MI groups pulled by the worker threads")
 
 
 def pmc_profile(families, depth, read_length):
@@ -92,9 +117,16 @@ def pmc_profile(families, depth, read_length):
             d = json.load(open(f))
         except ValueError:
             continue
-        for k in ("k_simplex_wave2", "k_family_wave"):
+        for k in ("k_split_cols", "k_simplex_wave2", "k_family_wave"):
             if k in d:
-                return dict(d[k], kernel=k), os.path.relpath(f, ROOT)
+                # the file holds means per launch and the launches per step (`_launches_per_step`, 1 when absent): per step = mean x launches
+                n = float(d[k].get("_launches_per_step", 1.0))
+                prof = {c: v * n for c, v in d[k].items() if not c.startswith("_")}
+                stage = {}
+                for kk in ("k_split_parse", "k_split_cols", "k_split_finish", "k_call_full"):
+                    if kk in d and "SQ_INSTS_VALU" in d[kk]:
+                        stage[kk] = d[kk]["SQ_INSTS_VALU"] * float(d[kk].get("_launches_per_step", 1.0))
+                return dict(prof, kernel=k, stage_valu=stage), os.path.relpath(f, ROOT)
     return None, None
 
 
@@ -111,11 +143,11 @@ def main():
     ap.add_argument("--read-length", type=int, default=None)
     ap.add_argument("--depth-max", type=int, default=0,
                     help="simplex only: long-tail family sizes in [depth, depth-max] pairs, count ~ size^-1.5 (BASELINE configs[3] shape: --depth 2 --depth-max 50)")
-    ap.add_argument("--cpu-sample-families", type=int, default=300000)
+    ap.add_argument("--cpu-sample-families", type=int, default=320000, help="families of the multi-thread CPU leg (320000 x 16 = 5.12 M reads at depth 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--reassemble", choices=["auto", "none", "root"], default="auto",
-                    help="root: every step also gathers the shard payloads to rank 0 in rank (= input) order over RCCL, inside the timed region; "
+                    help="root: a second timed loop also gathers the shard payloads to rank 0 in rank (= input) order over RCCL, reported beside `value`; "
                          "auto = root when N > 1")
     args = ap.parse_args()
     duplex, codec = args.caller == "duplex", args.caller == "codec"
@@ -139,7 +171,7 @@ def main():
 
     from fgumi_amd import (CodecConsensusCaller, CodecConsensusOptions, DuplexConsensusCaller, VanillaUmiConsensusCaller,
                            VanillaUmiConsensusOptions, simulated_family_bytes)
-    from fgumi_amd.distributed import balanced_shards, gather_payload_to_root, gather_sizes, max_over_ranks
+    from fgumi_amd.distributed import balanced_shards, gather_payload_to_root, gather_sizes, max_over_ranks, sum_over_ranks
 
     sim_extra = dict(family_size_max=args.depth_max) if (args.depth_max and args.caller == "simplex") else {}
     if codec:
@@ -192,15 +224,16 @@ def main():
     out = None
     for _ in range(args.warmup):
         out = caller.process_batch_device(dg)
-        if reassemble == "root":
-            del_me = gather_payload_to_root(out.as_tensor(local_rank), root=0)
-            del del_me
-    dt, out, k_family_ms, k_emit_ms, k_total_ms, gathered_bytes = timed_loop(args.steps, reassemble == "root")
-    dt_plain = None
-    if reassemble == "root":                                                              # the same K steps without the gather
-        dt_plain = timed_loop(args.steps, False)[0]
-    per_rank = gather_sizes([out.data_len, out.count, dg.n_rec, out.n_deferred, fam, shard_bytes], "cuda")   # rank (= input) order
+    dt, out, k_family_ms, k_emit_ms, k_total_ms, _ = timed_loop(args.steps, False)       # the K timed steps: `value`
+    dt_gather, gathered_bytes = None, 0
+    if reassemble == "root":                                                              # the same K steps with the gather to rank 0
+        r = timed_loop(args.steps, True)
+        dt_gather, gathered_bytes = r[0], r[5]
+    per_rank = gather_sizes([out.data_len, out.count, dg.n_rec, out.n_deferred, fam, shard_bytes,
+                             int(round(k_family_ms / args.steps * 1e3)), int(round(k_emit_ms / args.steps * 1e3))], "cuda")   # rank (= input) order
     total_bytes, total_cons, total_raw, total_def = [int(v) for v in per_rank[:, :4].sum(0).tolist()]
+    # the batch counters (ConsensusCallingStats / RejectionReason order, then the overlap CorrectionStats) summed over the ranks
+    counters = sum_over_ranks(caller.last_stats_array, "cuda")
 
     if rank == 0:
         L = args.read_length
@@ -208,8 +241,7 @@ def main():
         # algorithmic bytes of ONE k_family launch on ONE GPU: per raw read ceil(L/2)+L read,
         # per consensus read 6*Lc written (bases, quals, depth i16, errors i16)
         alg_read = dg.n_rec * ((L + 1) // 2 + L)
-        # duplex / CODEC: each record is built from two single-strand column sets (CODEC strands are about one read long)
-        alg_write = out.count * 6 * L * (2 if (duplex or codec) else 1)
+        alg_write = out.count * 6 * L          # (per consensus read, once — also for duplex / CODEC records)
         k_avg_s = k_family_ms / steps / 1e3
         achieved = (alg_read + alg_write) / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
         plain = not (duplex or codec or args.depth_max)
@@ -220,7 +252,8 @@ def main():
         shape = (f"CODEC consensus, {args.depth} pairs of 2x{L}bp, insert N(350,60) (BASELINE configs[4] shape)" if codec else
                  f"duplex consensus, {args.depth} pairs split over /A and /B, {L}bp paired (BASELINE configs[2] shape)" if duplex else
                  f"simplex consensus, depth {args.depth}..{args.depth_max} pairs (long tail), {L}bp paired (BASELINE configs[3] shape)" if args.depth_max else
-                 f"simplex consensus, depth={args.depth} pairs, {L}bp paired (BASELINE configs[1] shape)")
+                 f"simplex consensus, depth={args.depth} pairs, {L}bp paired" + (" (BASELINE configs[1] shape)" if (args.depth, L) == (8, 150) else
+                                                                                  " (BASELINE configs[0] shape)" if (args.depth, L) == (3, 150) else ""))
         sizing = (f"{args.families} families in total, cut into {world} shards of equal record bytes" if (args.scaling == "strong" and world > 1)
                   else f"{args.families} families per GPU")
         line = {
@@ -237,16 +270,22 @@ def main():
                        "families_per_rank": [int(v) for v in per_rank[:, 4].tolist()], "raw_reads_per_rank": [int(v) for v in per_rank[:, 2].tolist()],
                        "input_bytes_per_rank": [int(v) for v in per_rank[:, 5].tolist()], "output_bytes_per_rank": [int(v) for v in per_rank[:, 0].tolist()],
                        "deferred_families": total_def, "output_bytes": total_bytes,
-                       "reassemble": reassemble, "reassembled_bytes_on_rank0": gathered_bytes,
-                       "value_without_reassembly": (total_raw * steps / dt_plain) if dt_plain else None,
-                       "ms_per_step_without_reassembly": (dt_plain / steps * 1e3) if dt_plain else None,
+                       "reassemble": ("none" if reassemble == "none" else "none in `value` (payloads stay on their ranks); gather to rank 0 timed beside"),
+                       "reassembled_bytes_on_rank0": gathered_bytes,
+                       "value_with_reassembly_on_root": (total_raw * steps / dt_gather) if dt_gather else None,
+                       "ms_per_step_with_reassembly_on_root": (dt_gather / steps * 1e3) if dt_gather else None,
+                       "gather_GBs_into_root": ((gathered_bytes - int(per_rank[0, 0])) * steps / max(dt_gather - dt, 1e-9) / 1e9) if (dt_gather and dt_gather > dt) else None,
+                       "k_family_ms_per_rank": [v / 1e3 for v in per_rank[:, 6].tolist()], "k_emit_ms_per_rank": [v / 1e3 for v in per_rank[:, 7].tolist()],
+                       "counters_all_ranks": {"total_reads": counters[0], "consensus_reads": counters[1], "filtered_reads": counters[2],
+                                              "rejected_by_reason": counters[3:24], "overlap_correction": counters[24:28]},
                        "columns_needing_call_full_per_step": caller.last_timing.get("full_columns")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          # HBM bytes of one launch: 2 x FETCH_SIZE (gfx950 correction for wide coalesced reads) + WRITE_SIZE, KiB → bytes,
                          # from the committed PMC passes (`traffic_source`), NOT measured in this run
                          "traffic": ((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0) if (pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc) else None,
                          "traffic_source": pmc_file,
-                         "kernel": "k_family stage (k_simplex_seg / k_simplex_wave2 / k_family_wave + k_call_full)" if not (duplex or codec) else "k_family stage (k_family_wave + k_call_full)",
+                         "kernel": ("k_family stage (k_split_parse + k_split_cols + k_split_finish | k_simplex_seg, then k_simplex_wave2 / k_family_wave / k_family for what is left, + k_call_full)"
+                                    if not (duplex or codec) else "k_family stage (k_family_wave + k_call_full)"),
                          "kernel_ms": k_family_ms / steps, "k_emit_ms": k_emit_ms / steps,
                          "device_ms_per_step": k_total_ms / steps, "algorithmic_bytes_per_launch": alg_read + alg_write,
                          "read_only_GBs": alg_read / k_avg_s / 1e9 if k_avg_s > 0 else 0.0,
@@ -255,6 +294,8 @@ def main():
                          "valu_floor_ms": valu_floor_ms,
                          "frac_of_valu_floor": valu_floor_ms / (k_family_ms / steps) if k_family_ms > 0 else None,
                          "valu_insts_per_family": (pmc["SQ_INSTS_VALU"] / fam) if (pmc and "SQ_INSTS_VALU" in pmc) else None,
+                         "valu_insts_per_family_by_kernel": ({k: v / fam for k, v in pmc["stage_valu"].items()} if (pmc and pmc.get("stage_valu")) else None),
+                         "valu_insts_per_family_stage": (sum(pmc["stage_valu"].values()) / fam if (pmc and pmc.get("stage_valu")) else None),
                          "salu_insts_per_family": (pmc["SQ_INSTS_SALU"] / fam) if (pmc and "SQ_INSTS_SALU" in pmc) else None,
                          # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the chip's 1024 SIMDs at 2.4 GHz (committed PMC file / this run's time)
                          "valu_busy_frac": (min(1.0, pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / 2.4e9 / k_avg_s)

@@ -362,6 +362,7 @@ class _HandleCaller(ConsensusCaller):
             raise RuntimeError(lib.fgx_last_error(self._h).decode())
         self._last_stats = ConsensusCallingStats.from_array(out.stats)
         self._stats.merge(self._last_stats)
+        self.last_stats_array = [int(v) for v in out.stats]          # the raw counters of this batch (fgx_output.stats order)
         self.last_timing = dict(kernels=out.ms_kernels, k_family=out.ms_k_family, k_emit=out.ms_k_emit, full_columns=int(out.ms_emit))
         return DeviceOutput(out.data, int(out.data_len), int(out.count), int(n_def.value), d_def.value)
 

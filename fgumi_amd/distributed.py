@@ -54,21 +54,33 @@ def gather_payload_to_root(local: torch.Tensor, root: int = 0) -> Optional[torch
         return local
     rank = dist.get_rank()
     sizes = gather_sizes([local.numel()], local.device)[:, 0].tolist()
+    # ONE batch of point-to-point operations per rank (`batch_isend_irecv`): on RCCL the root's receives are posted as one group —
+    # posted one by one, each irecv is its own group and a sender can wait behind another peer's unfinished transfer
     if rank == root:
         out = torch.empty(sum(sizes), dtype=torch.uint8, device=local.device)
-        offs, reqs = 0, []
+        offs, ops = 0, []
         for r, n in enumerate(sizes):
             if r == root:
                 out[offs:offs + n] = local
             elif n:
-                reqs.append(dist.irecv(out[offs:offs + n], src=r))
+                ops.append(dist.P2POp(dist.irecv, out[offs:offs + n], r))
             offs += n
-        for q in reqs:
-            q.wait()
+        if ops:
+            for q in dist.batch_isend_irecv(ops):
+                q.wait()
         return out
     if local.numel():
-        dist.send(local, dst=root)
+        for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, local, root)]):
+            q.wait()
     return None
+
+
+def sum_over_ranks(values: Sequence[int], device) -> List[int]:
+    """all_reduce(SUM) of a vector of int64 counters (the batch statistics: families are independent, counters add up)."""
+    t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [int(v) for v in t.tolist()]
 
 
 def max_over_ranks(seconds: float, device) -> float:

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <chrono>
 #include <thread>
 #include "../include/fgumi_amd.h"
 #include "oracle_vanilla.hpp"
@@ -26,6 +27,7 @@ struct OrcResult {
   uint64_t stats[FGX_STATS_LEN] = {0};
   Bytes rejects;
   uint64_t n_rejects = 0;
+  double seconds_workers = 0.0;   // orc_process: wall time of the worker section alone (per-batch outputs ready; before they are joined into one buffer)
 };
 
 static VanillaOptions vanilla_options_from(const fgx_options* o) {
@@ -287,14 +289,17 @@ void* orc_process(const fgx_options* o, const uint8_t* blob, const uint64_t* rec
       catch (const OracleError& e) { if (!failed.exchange(true)) err = e.what; return; }
     }
   };
+  const auto t_begin = std::chrono::steady_clock::now();
   if (threads <= 1) worker();
   else {
     std::vector<std::thread> ts;
     for (uint32_t t = 0; t < threads; t++) ts.emplace_back(worker);
     for (auto& t : ts) t.join();
   }
+  const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
   if (failed.load()) { g_err = err; return nullptr; }
   OrcResult* res = new OrcResult();
+  res->seconds_workers = secs;
   size_t total = 0, rtotal = 0;
   for (auto& p : parts) { total += p.data.size(); rtotal += p.rejects.size(); }
   res->data.reserve(total);
@@ -315,6 +320,9 @@ void orc_result_stats(void* r, uint64_t* out) { memcpy(out, ((OrcResult*)r)->sta
 const uint8_t* orc_result_rejects(void* r) { return ((OrcResult*)r)->rejects.data(); }
 uint64_t orc_result_rejects_len(void* r) { return ((OrcResult*)r)->rejects.size(); }
 uint64_t orc_result_n_rejects(void* r) { return ((OrcResult*)r)->n_rejects; }
+// the worker section of orc_process alone: what the reference's Process step does (each batch's ConsensusOutput handed to the
+// writer as it is); joining the batches into ONE buffer afterwards is this harness's convenience, single-threaded
+double orc_result_seconds(void* r) { return ((OrcResult*)r)->seconds_workers; }
 void orc_result_free(void* r) { delete (OrcResult*)r; }
 
 // ---- scalar / column level, for the known-answer tests ---------------------------------------

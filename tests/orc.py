@@ -19,7 +19,7 @@ def _load():
         "orc_process": (VP, [VP, VP, VP, VP, U32, VP, U32, U32, U32]),
         "orc_result_data": (VP, [VP]), "orc_result_len": (U64, [VP]), "orc_result_count": (U64, [VP]),
         "orc_result_stats": (None, [VP, VP]), "orc_result_rejects": (VP, [VP]), "orc_result_rejects_len": (U64, [VP]),
-        "orc_result_n_rejects": (U64, [VP]), "orc_result_free": (None, [VP]),
+        "orc_result_n_rejects": (U64, [VP]), "orc_result_free": (None, [VP]), "orc_result_seconds": (C.c_double, [VP]),
         "orc_phred_to_ln_error_prob": (D, [U8]), "orc_phred_to_ln_correct_prob": (D, [U8]), "orc_ln_prob_to_phred": (U8, [D]),
         "orc_log1pexp": (D, [D]), "orc_ln_sum_exp": (D, [D, D]), "orc_ln_sum_exp_array": (D, [VP, U32]), "orc_ln_not": (D, [D]),
         "orc_ln_error_prob_two_trials": (D, [D, D]), "orc_ln_a_minus_b": (C.c_int, [D, D, P(D)]),
@@ -127,7 +127,8 @@ def process(opts, blob, rec_off, rec_len, grp_first, batch_groups=50, threads=1)
         lib.orc_result_stats(h, ptr(stats))
         rn = lib.orc_result_rejects_len(h)
         rej = C.string_at(lib.orc_result_rejects(h), rn) if rn else b""
-        return dict(data=data, count=lib.orc_result_count(h), stats=stats, rejects=rej, n_rejects=lib.orc_result_n_rejects(h))
+        return dict(data=data, count=lib.orc_result_count(h), stats=stats, rejects=rej, n_rejects=lib.orc_result_n_rejects(h),
+                    seconds_workers=lib.orc_result_seconds(h))
     finally:
         lib.orc_result_free(h)
 

@@ -31,13 +31,12 @@ def _worker(rank, world, port, outdir):
     import fgx_opts
     import orc
     from fgumi_amd import simulate_grouped_reads
-    from fgumi_amd.distributed import gather_payload_to_root, gather_sizes, max_over_ranks
+    from fgumi_amd.distributed import gather_payload_to_root, gather_sizes, max_over_ranks, sum_over_ranks
     g = simulate_grouped_reads(F_PER_RANK, family_size=3, first_family=rank * F_PER_RANK)      # weak-scaling shard
     res = orc.process(fgx_opts.defaults(min_reads=1), g.blob, g.rec_off, g.rec_len, g.grp_first)
     local = torch.frombuffer(bytearray(res["data"]), dtype=torch.uint8)
     sizes = gather_sizes([local.numel(), res["count"], g.n_rec], "cpu")
-    stats = torch.from_numpy(res["stats"].astype(np.int64))
-    dist.all_reduce(stats)                                                                     # additive counters
+    stats = torch.tensor(sum_over_ranks(res["stats"].tolist(), "cpu"), dtype=torch.int64)     # additive counters (bench.py's all-reduce)
     payload = gather_payload_to_root(local, root=0)
     t = max_over_ranks(0.001 * (rank + 1), "cpu")
     if rank == 0:

@@ -9,7 +9,7 @@ for C in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INS
   i=$((i+1))
   timeout 200 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc -o pmc$i -- python $R/bench.py --families $FAM --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc$i.log 2>&1 || tail -3 $OUT/pmc$i.log
 done
-python $R/tools/pmc_parse.py $OUT/pmc > $OUT/pmc.json
+python $R/tools/pmc_parse.py $OUT/pmc 3 > $OUT/pmc.json
 rm -rf $OUT/pmc
 python - $OUT/pmc.json $FAM <<'PY'
 import json,sys

@@ -15,7 +15,7 @@ for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_
   i=$((i+1))
   timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc -o pmc$i -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc$i.log 2>&1
 done
-python $R/tools/pmc_parse.py $OUT/pmc > $OUT/pmc_5M_families.json
+python $R/tools/pmc_parse.py $OUT/pmc 3 > $OUT/pmc_5M_families.json
 cp $OUT/pmc_5M_families.json $R/profiles/${TAG}_pmc_5M_families.json
 rm -rf $OUT/pmc
 cd $R
