@@ -182,7 +182,7 @@ struct FastPath {
   // split simplex pipeline: the record kernel runs chunk by chunk on a second stream, under the column kernel of the chunk before
   static constexpr int MAX_CHUNKS = 16;
   hipStream_t s2 = nullptr;
-  hipEvent_t ev_chunk[MAX_CHUNKS] = {}, ev_sample = nullptr;
+  hipEvent_t ev_chunk[MAX_CHUNKS] = {}, ev_cols[MAX_CHUNKS] = {}, ev_fin = nullptr, ev_sample = nullptr;
   int run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const uint64_t* d_rec_off, const uint32_t* d_rec_len, uint32_t n_rec,
           const uint32_t* d_grp_first, uint32_t n_grp, FastResult* res);
   void release();

@@ -234,6 +234,7 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }   // v is the same in every lane: say so
 __device__ __forceinline__ uint32_t rlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 __device__ __forceinline__ uint32_t wave_max(uint32_t v) { for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_xor(v, o); v = t > v ? t : v; } return v; }
 __device__ __forceinline__ uint32_t wave_min(uint32_t v) { for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_xor(v, o); v = t < v ? t : v; } return v; }
@@ -2474,11 +2475,143 @@ __device__ void emit_generic(const EmitParams& P, const EndDesc& D, const EmitCt
 // (Assembling the record through LDS — whole-record image with byte writes, or dword-staged column arrays with dword payload
 // copies — was measured three times, rounds 1 and 2: 3.4 – 4.0 ms.  The wave's lifetime is a chain of memory round trips, and
 // every LDS hop adds one; registers-only streaming below is the fastest form found.)
-__device__ __forceinline__ void emit_one(const EmitParams& P, const EndDesc& D, uint64_t out_off, uint32_t lane);
+// A record in two halves: everything it reads (emit_load: every load of the record issued back to back, nothing waited for), and
+// the reductions + stores (emit_store).  k_emit issues the loads of ALL the family's records before the first store: a wavefront's
+// life is a chain of memory round trips, and the records' round trips now run side by side instead of one after the other.
+struct EmitLoads {
+  EmitCtx X;
+  uint2 cw; uint32_t qw, dw[2], ew[2], ao[2], so, qo, j3;
+  uint8_t nb, rgb, mib, cbb, rxb;
+  uint32_t cb_len, rx_len;
+  bool has_cb, has_rx, generic;
+};
+__device__ __forceinline__ void emit_load(const EmitParams& P, const EndDesc& D, uint64_t out_off, uint32_t lane, EmitLoads& R) {
+  // the descriptor's fields come out of LDS into vector registers; they are the same in every lane, and saying so (readfirstlane)
+  // turns every address below into scalar base + 32-bit lane offset
+  EmitCtx& X = R.X;
+  X.q = P.out + (out_off - P.out_base);
+  X.Lc = uni(D.cons_len);
+  X.first = P.blob + uniform_u64(D.first_off);
+  X.mi_len = uni(D.mi_len); X.mi_off = uni(D.mi_off);
+  X.name_len = P.prefix_len + 1 + X.mi_len;
+  X.rec_size = uni(D.rec_size);
+  X.flag = bam::F_UNMAPPED;
+  const uint32_t d_type = uni(D.type);
+  if (d_type == 1) X.flag |= bam::F_PAIRED | bam::F_FIRST | bam::F_MATE_UNMAPPED;
+  else if (d_type == 2) X.flag |= bam::F_PAIRED | bam::F_LAST | bam::F_MATE_UNMAPPED;
+  const uint64_t col_off = uniform_u64(D.col_off);
+  X.code = P.col_code + col_off; X.cq = P.col_qual + col_off; X.cd = P.col_depth + col_off; X.ce = P.col_err + col_off;
+  const uint32_t Lc = X.Lc, name_len = X.name_len, mi_len = X.mi_len, mi_off = X.mi_off;
+  R.has_cb = uni(D.has_cb) != 0; R.has_rx = uni(D.has_rx) != 0;
+  R.cb_len = R.has_cb ? uni(D.cb_len) : 0; R.rx_len = R.has_rx ? uni(D.rx_len) : 0;
+  R.generic = Lc > 192 || Lc < 8 || name_len + 1 > 64 || P.rg_len + 4 > 64 || R.cb_len + 4 > 64;
+  if (R.generic) return;                                       // (any length: emit_generic, field after field)
+
+  // Payloads move as (unaligned) dwords: lane l owns bytes [4l, 4l + 4) of a field, and the lane past the last whole dword
+  // takes the field's LAST four bytes instead (an overlapping store of the same values) — no byte-granular tail.
+  const uint32_t seq_bytes = (Lc + 1) / 2;
+  R.so = min(4 * lane, seq_bytes - 4);                                                  // sequence: 4 output bytes = 8 columns
+  R.qo = min(4 * lane, Lc - 4);                                                         // qualities: 4 columns
+  R.cw = gld64u(X.code + 2 * R.so);                                                     // (column Lc may be read: one byte of slack)
+  R.qw = gld32u(X.cq + R.qo);
+#pragma unroll
+  for (int t = 0; t < 2; t++) {                                                         // per-base arrays: 4 bytes = 2 columns
+    R.ao[t] = min(4 * (lane + 64 * t), 2 * Lc - 4);
+    R.dw[t] = gld32u((const uint8_t*)X.cd + R.ao[t]); R.ew[t] = gld32u((const uint8_t*)X.ce + R.ao[t]);
+  }
+  const uint32_t j3 = lane >= 3 ? lane - 3 : 0;
+  R.j3 = j3;
+  const uint32_t ni = lane > P.prefix_len ? lane - P.prefix_len - 1 : 0;
+  const uint8_t pfx = (uint8_t)P.prefix[lane < P.prefix_len ? lane : 0];                       // d_strings keeps 16 bytes of slack
+  const uint8_t nmb = X.first[mi_off + (ni < mi_len ? ni : mi_len)];                            // index mi_len is the tag's NUL
+  R.nb = lane < P.prefix_len ? pfx : lane == P.prefix_len ? (uint8_t)':' : lane < name_len ? nmb : (uint8_t)0;
+  R.rgb = (uint8_t)P.rg[j3 < P.rg_len ? j3 : 0];
+  R.mib = X.first[mi_off + (j3 < mi_len ? j3 : mi_len)];
+  const uint8_t* fk = R.has_cb ? P.blob + uniform_u64(D.kept_off) + uni(D.cb_off) : X.first;
+  R.cbb = fk[j3 < R.cb_len ? j3 : 0];
+  R.rxb = (uint8_t)D.rx[j3 < FAST_RX_CAP ? j3 : 0];
+}
+__device__ __forceinline__ void emit_store(const EmitParams& P, const EndDesc& D, uint32_t lane, const EmitLoads& R) {
+  const EmitCtx& X = R.X;
+  if (R.generic) { emit_generic(P, D, X, lane); return; }
+  const uint32_t Lc = X.Lc, name_len = X.name_len, mi_len = X.mi_len, seq_bytes = (Lc + 1) / 2, j3 = R.j3;
+  const uint32_t so = R.so, qo = R.qo, cb_len = R.cb_len, rx_len = R.rx_len;
+  const bool has_cb = R.has_cb, has_rx = R.has_rx;
+  // ---- cD / cM / cE (vanilla_caller.rs:1800-1810): max / min depth, Σerrors / Σdepth as f32 ---------------------
+  // every column counted once: a lane's low half is a duplicate when its offset was pulled back to the field's last dword
+  uint32_t maxd = 0, mind = 0xFFFFFFFFu, sumd = 0, sume = 0;
+#pragma unroll
+  for (int t = 0; t < 2; t++) {
+    const uint32_t nat = 4 * (lane + 64 * t);
+    const bool in = nat < 2 * Lc, lo_own = in && nat == R.ao[t];
+    const uint32_t dl = R.dw[t] & 0xFFFF, dh = R.dw[t] >> 16, el = R.ew[t] & 0xFFFF, eh = R.ew[t] >> 16;
+    if (lo_own) { maxd = dl > maxd ? dl : maxd; mind = dl < mind ? dl : mind; sumd += dl; sume += el; }
+    if (in) { maxd = dh > maxd ? dh : maxd; mind = dh < mind ? dh : mind; sumd += dh; sume += eh; }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    uint32_t a = __shfl_xor(maxd, o), b = __shfl_xor(mind, o);
+    maxd = a > maxd ? a : maxd; mind = b < mind ? b : mind;
+    sumd += __shfl_xor(sumd, o); sume += __shfl_xor(sume, o);
+  }
+  maxd = uni(maxd); mind = uni(mind); sumd = uni(sumd); sume = uni(sume);   // (every lane holds the totals: the tag widths below, and with them every later address, are scalar)
+  const float ce_rate = sumd > 0 ? (float)sume / (float)sumd : 0.0f;
+  const uint32_t n_cd = 3 + int_tag_width(maxd), n_cm = 3 + int_tag_width(mind);
+
+  // ---- stores -----------------------------------------------------------------------------------------------------------
+  uint8_t* q = X.q;
+  if (lane < 9) {   // block_size + fixed core: ref_id -1, pos -1, l_read_name, mapq 0, bin 4680, n_cigar_op 0, flag, l_seq, next_ref -1, next_pos -1, tlen 0
+    const uint32_t v = lane == 0 ? X.rec_size : lane == 3 ? ((name_len + 1) | (4680u << 16)) : lane == 4 ? (X.flag << 16) : lane == 5 ? Lc : lane == 8 ? 0u : 0xFFFFFFFFu;
+    gst32u(q + 4 * lane, v);
+  }
+  q += 36;
+  if (lane < name_len + 1) q[lane] = R.nb;
+  q += name_len + 1;
+  if (4 * lane < seq_bytes) {   // eight columns → four bytes, high nibble first; a column past the end packs as 0
+    const uint32_t c0 = 2 * so;
+    uint32_t lo4 = R.cw.x, hi4 = R.cw.y;                                               // codes of columns c0..c0+3 / c0+4..c0+7, one byte each
+    if (c0 + 7 >= Lc) hi4 &= 0x00FFFFFFu;                                              // (only column c0 + 7 can be past the end: Lc odd)
+    const uint32_t b0 = ((lo4 << 4) | (lo4 >> 8)) & 0xFF, b1 = ((lo4 >> 12) | (lo4 >> 24)) & 0xFF;
+    const uint32_t b2 = ((hi4 << 4) | (hi4 >> 8)) & 0xFF, b3 = ((hi4 >> 12) | (hi4 >> 24)) & 0xFF;
+    gst32u(q + so, b0 | (b1 << 8) | (b2 << 16) | (b3 << 24));
+  }
+  q += seq_bytes;
+  if (4 * lane < Lc) gst32u(q + qo, R.qw);
+  q += Lc;
+  if (lane < 3 + P.rg_len + 1) q[lane] = lane == 0 ? 'R' : lane == 1 ? 'G' : lane == 2 ? 'Z' : j3 < P.rg_len ? R.rgb : (uint8_t)0;
+  q += 3 + P.rg_len + 1;
+  {   // cD cM cE and, when asked for, the header of the cd array right behind them: one store
+    const uint32_t n3 = n_cd + n_cm + 7, nh = P.per_base_tags ? 8u : 0u;
+    if (lane < n3 + nh) {
+      const uint32_t i = lane - n3;
+      q[lane] = lane < n3 ? cdcmce_byte(lane, n_cd, n_cm, maxd, mind, ce_rate)
+                          : (uint8_t)(i == 0 ? 'c' : i == 1 ? 'd' : i == 2 ? 'B' : i == 3 ? 's' : (Lc >> (8 * (i - 4))));
+    }
+    q += n3;
+  }
+  if (P.per_base_tags) {
+    q += 8;
+#pragma unroll
+    for (int t = 0; t < 2; t++) if (4 * (lane + 64 * t) < 2 * Lc) gst32u(q + R.ao[t], R.dw[t]);
+    q += 2 * Lc;
+    if (lane < 2) gst32u(q + 4 * lane, lane == 0 ? ('c' | ('e' << 8) | ('B' << 16) | ('s' << 24)) : Lc);
+    q += 8;
+#pragma unroll
+    for (int t = 0; t < 2; t++) if (4 * (lane + 64 * t) < 2 * Lc) gst32u(q + R.ao[t], R.ew[t]);
+    q += 2 * Lc;
+  }
+  if (lane < 3 + mi_len + 1) q[lane] = lane == 0 ? (uint8_t)P.tag0 : lane == 1 ? (uint8_t)P.tag1 : lane == 2 ? 'Z' : j3 < mi_len ? R.mib : (uint8_t)0;
+  q += 3 + mi_len + 1;
+  if (has_cb) { if (lane < 3 + cb_len + 1) q[lane] = lane == 0 ? (uint8_t)P.cell0 : lane == 1 ? (uint8_t)P.cell1 : lane == 2 ? 'Z' : j3 < cb_len ? R.cbb : (uint8_t)0; q += 3 + cb_len + 1; }
+  if (has_rx) { if (lane < 3 + rx_len + 1) q[lane] = lane == 0 ? 'R' : lane == 1 ? 'X' : lane == 2 ? 'Z' : j3 < rx_len ? R.rxb : (uint8_t)0; }
+}
 #ifndef FGX_EMIT_OCC
-#define FGX_EMIT_OCC 7   /* wavefronts per SIMD the register allocation of k_emit aims at (the kernel waits on memory two thirds of its time: 6 -> 7
-                            1.77 -> 1.57 ms per 2 M records; 8 spills 26 registers: 3.4 ms) */
+#define FGX_EMIT_OCC 7   /* wavefronts per SIMD the register allocation of k_emit aims at */
 #endif
+// One wavefront per FAMILY: its (up to three) records.  A third of the slots is empty on paired data (the fragment slot), and a
+// wavefront that only finds `valid == 0` still costs a launch and a memory round trip; the descriptor carries blob OFFSETS, so the
+// record's strings are one dependent load away instead of two.
+// (Assembling the record through LDS — whole-record image with byte writes, or dword-staged column arrays with dword payload
+// copies — was measured three times, rounds 1 and 2: 3.4 – 4.0 ms against 2.2 ms per 2 M records; registers-only streaming it is.)
 __global__ __launch_bounds__(256, FGX_EMIT_OCC) void k_emit(EmitParams P) {
   // the family's (up to) three descriptors, copied once with 16-byte loads: every field read below is an LDS read — as global
   // loads, the valid flags and then each record's fields were dependent memory round trips of their own
@@ -2500,118 +2633,19 @@ __global__ __launch_bounds__(256, FGX_EMIT_OCC) void k_emit(EmitParams P) {
   const uint64_t oo = P.out_off[s0 + (lane < ns ? lane : 0u)];   // (both loads leave before either is waited for)
   if (lane < 6 * ns) ((u32x4*)&sD[wv][0])[lane] = piece;
   wave_sync();
-  const bool v0 = sD[wv][0].valid != 0, v1 = ns > 1 && sD[wv][1].valid != 0, v2 = ns > 2 && sD[wv][2].valid != 0;
-  if (v0) emit_one(P, sD[wv][0], __shfl(oo, 0), lane);            // (three inlined copies: a rolled loop measured 2.8 instead of 2.2 ms per 2 M records)
-  if (v1) emit_one(P, sD[wv][1], __shfl(oo, 1), lane);
-  if (v2) emit_one(P, sD[wv][2], __shfl(oo, 2), lane);
-}
-__device__ __forceinline__ void emit_one(const EmitParams& P, const EndDesc& D, uint64_t out_off, uint32_t lane) {
-  EmitCtx X;
-  X.q = P.out + (out_off - P.out_base);
-  X.Lc = D.cons_len;
-  X.first = P.blob + D.first_off;
-  X.mi_len = D.mi_len; X.mi_off = D.mi_off;
-  X.name_len = P.prefix_len + 1 + X.mi_len;
-  X.rec_size = D.rec_size;
-  X.flag = bam::F_UNMAPPED;
-  if (D.type == 1) X.flag |= bam::F_PAIRED | bam::F_FIRST | bam::F_MATE_UNMAPPED;
-  else if (D.type == 2) X.flag |= bam::F_PAIRED | bam::F_LAST | bam::F_MATE_UNMAPPED;
-  X.code = P.col_code + D.col_off; X.cq = P.col_qual + D.col_off; X.cd = P.col_depth + D.col_off; X.ce = P.col_err + D.col_off;
-  const uint32_t Lc = X.Lc, name_len = X.name_len, mi_len = X.mi_len, mi_off = X.mi_off;
-  const bool has_cb = D.has_cb != 0, has_rx = D.has_rx != 0;
-  const uint32_t cb_len = has_cb ? D.cb_len : 0, rx_len = has_rx ? D.rx_len : 0;
-  if (Lc > 192 || Lc < 8 || name_len + 1 > 64 || P.rg_len + 4 > 64 || cb_len + 4 > 64) { emit_generic(P, D, X, lane); return; }
-
-  // ---- every load of the record, back to back ----------------------------------------------------------------
-  // Payloads move as (unaligned) dwords: lane l owns bytes [4l, 4l + 4) of a field, and the lane past the last whole dword
-  // takes the field's LAST four bytes instead (an overlapping store of the same values) — no byte-granular tail.
-  const uint32_t seq_bytes = (Lc + 1) / 2;
-  const uint32_t so = min(4 * lane, seq_bytes - 4);                                    // sequence: 4 output bytes = 8 columns
-  const uint32_t qo = min(4 * lane, Lc - 4);                                           // qualities: 4 columns
-  const uint2 cw = gld64u(X.code + 2 * so);                                            // (column Lc may be read: one byte of slack)
-  const uint32_t qw = gld32u(X.cq + qo);
-  uint32_t dw[2], ew[2], ao[2];                                                        // per-base arrays: 4 bytes = 2 columns
-#pragma unroll
-  for (int t = 0; t < 2; t++) {
-    ao[t] = min(4 * (lane + 64 * t), 2 * Lc - 4);
-    dw[t] = gld32u((const uint8_t*)X.cd + ao[t]); ew[t] = gld32u((const uint8_t*)X.ce + ao[t]);
-  }
-  const uint32_t j3 = lane >= 3 ? lane - 3 : 0;
-  const uint32_t ni = lane > P.prefix_len ? lane - P.prefix_len - 1 : 0;
-  const uint8_t pfx = (uint8_t)P.prefix[lane < P.prefix_len ? lane : 0];                       // d_strings keeps 16 bytes of slack
-  const uint8_t nmb = X.first[mi_off + (ni < mi_len ? ni : mi_len)];                            // index mi_len is the tag's NUL
-  const uint8_t nb = lane < P.prefix_len ? pfx : lane == P.prefix_len ? (uint8_t)':' : lane < name_len ? nmb : (uint8_t)0;
-  const uint8_t rgb = (uint8_t)P.rg[j3 < P.rg_len ? j3 : 0];
-  const uint8_t mib = X.first[mi_off + (j3 < mi_len ? j3 : mi_len)];
-  const uint8_t* fk = has_cb ? P.blob + D.kept_off + D.cb_off : X.first;
-  const uint8_t cbb = fk[j3 < cb_len ? j3 : 0];
-  const uint8_t rxb = (uint8_t)D.rx[j3 < FAST_RX_CAP ? j3 : 0];
-
-  // ---- cD / cM / cE (vanilla_caller.rs:1800-1810): max / min depth, Σerrors / Σdepth as f32 ---------------------
-  // every column counted once: a lane's low half is a duplicate when its offset was pulled back to the field's last dword
-  uint32_t maxd = 0, mind = 0xFFFFFFFFu, sumd = 0, sume = 0;
-#pragma unroll
-  for (int t = 0; t < 2; t++) {
-    const uint32_t nat = 4 * (lane + 64 * t);
-    const bool in = nat < 2 * Lc, lo_own = in && nat == ao[t];
-    const uint32_t dl = dw[t] & 0xFFFF, dh = dw[t] >> 16, el = ew[t] & 0xFFFF, eh = ew[t] >> 16;
-    if (lo_own) { maxd = dl > maxd ? dl : maxd; mind = dl < mind ? dl : mind; sumd += dl; sume += el; }
-    if (in) { maxd = dh > maxd ? dh : maxd; mind = dh < mind ? dh : mind; sumd += dh; sume += eh; }
-  }
-  for (int o = 32; o > 0; o >>= 1) {
-    uint32_t a = __shfl_xor(maxd, o), b = __shfl_xor(mind, o);
-    maxd = a > maxd ? a : maxd; mind = b < mind ? b : mind;
-    sumd += __shfl_xor(sumd, o); sume += __shfl_xor(sume, o);
-  }
-  const float ce_rate = sumd > 0 ? (float)sume / (float)sumd : 0.0f;
-  const uint32_t n_cd = 3 + int_tag_width(maxd), n_cm = 3 + int_tag_width(mind);
-
-  // ---- stores -----------------------------------------------------------------------------------------------------------
-  uint8_t* q = X.q;
-  if (lane < 9) {   // block_size + fixed core: ref_id -1, pos -1, l_read_name, mapq 0, bin 4680, n_cigar_op 0, flag, l_seq, next_ref -1, next_pos -1, tlen 0
-    const uint32_t v = lane == 0 ? X.rec_size : lane == 3 ? ((name_len + 1) | (4680u << 16)) : lane == 4 ? (X.flag << 16) : lane == 5 ? Lc : lane == 8 ? 0u : 0xFFFFFFFFu;
-    gst32u(q + 4 * lane, v);
-  }
-  q += 36;
-  if (lane < name_len + 1) q[lane] = nb;
-  q += name_len + 1;
-  if (4 * lane < seq_bytes) {   // eight columns → four bytes, high nibble first; a column past the end packs as 0
-    const uint32_t c0 = 2 * so;
-    uint32_t lo4 = cw.x, hi4 = cw.y;                                                   // codes of columns c0..c0+3 / c0+4..c0+7, one byte each
-    if (c0 + 7 >= Lc) hi4 &= 0x00FFFFFFu;                                              // (only column c0 + 7 can be past the end: Lc odd)
-    const uint32_t b0 = ((lo4 << 4) | (lo4 >> 8)) & 0xFF, b1 = ((lo4 >> 12) | (lo4 >> 24)) & 0xFF;
-    const uint32_t b2 = ((hi4 << 4) | (hi4 >> 8)) & 0xFF, b3 = ((hi4 >> 12) | (hi4 >> 24)) & 0xFF;
-    gst32u(q + so, b0 | (b1 << 8) | (b2 << 16) | (b3 << 24));
-  }
-  q += seq_bytes;
-  if (4 * lane < Lc) gst32u(q + qo, qw);
-  q += Lc;
-  if (lane < 3 + P.rg_len + 1) q[lane] = lane == 0 ? 'R' : lane == 1 ? 'G' : lane == 2 ? 'Z' : j3 < P.rg_len ? rgb : (uint8_t)0;
-  q += 3 + P.rg_len + 1;
-  {   // cD cM cE and, when asked for, the header of the cd array right behind them: one store
-    const uint32_t n3 = n_cd + n_cm + 7, nh = P.per_base_tags ? 8u : 0u;
-    if (lane < n3 + nh) {
-      const uint32_t i = lane - n3;
-      q[lane] = lane < n3 ? cdcmce_byte(lane, n_cd, n_cm, maxd, mind, ce_rate)
-                          : (uint8_t)(i == 0 ? 'c' : i == 1 ? 'd' : i == 2 ? 'B' : i == 3 ? 's' : (Lc >> (8 * (i - 4))));
-    }
-    q += n3;
-  }
-  if (P.per_base_tags) {
-    q += 8;
-#pragma unroll
-    for (int t = 0; t < 2; t++) if (4 * (lane + 64 * t) < 2 * Lc) gst32u(q + ao[t], dw[t]);
-    q += 2 * Lc;
-    if (lane < 2) gst32u(q + 4 * lane, lane == 0 ? ('c' | ('e' << 8) | ('B' << 16) | ('s' << 24)) : Lc);
-    q += 8;
-#pragma unroll
-    for (int t = 0; t < 2; t++) if (4 * (lane + 64 * t) < 2 * Lc) gst32u(q + ao[t], ew[t]);
-    q += 2 * Lc;
-  }
-  if (lane < 3 + mi_len + 1) q[lane] = lane == 0 ? (uint8_t)P.tag0 : lane == 1 ? (uint8_t)P.tag1 : lane == 2 ? 'Z' : j3 < mi_len ? mib : (uint8_t)0;
-  q += 3 + mi_len + 1;
-  if (has_cb) { if (lane < 3 + cb_len + 1) q[lane] = lane == 0 ? (uint8_t)P.cell0 : lane == 1 ? (uint8_t)P.cell1 : lane == 2 ? 'Z' : j3 < cb_len ? cbb : (uint8_t)0; q += 3 + cb_len + 1; }
-  if (has_rx) { if (lane < 3 + rx_len + 1) q[lane] = lane == 0 ? 'R' : lane == 1 ? 'X' : lane == 2 ? 'Z' : j3 < rx_len ? rxb : (uint8_t)0; }
+  const bool v0 = uni(sD[wv][0].valid) != 0, v1 = ns > 1 && uni(sD[wv][1].valid) != 0, v2 = ns > 2 && uni(sD[wv][2].valid) != 0;
+  // (the record's output offset as a SCALAR: with it in a vector register every store of the record formed a 64-bit vector
+  // address of its own — a third of the kernel's vector instructions were address adds and register moves)
+  auto off_of = [&](int k) -> uint64_t {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(oo >> 32), k) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)oo, k);
+  };
+  if (v0) { EmitLoads R0; emit_load(P, sD[wv][0], off_of(0), lane, R0); emit_store(P, sD[wv][0], lane, R0); }   // a fragment record: families of single reads
+  // the two records of a pair family: both records' loads, then both records' stores
+  EmitLoads R1, R2;
+  if (v1) emit_load(P, sD[wv][1], off_of(1), lane, R1);
+  if (v2) emit_load(P, sD[wv][2], off_of(2), lane, R2);
+  if (v1) emit_store(P, sD[wv][1], lane, R1);
+  if (v2) emit_store(P, sD[wv][2], lane, R2);
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -3270,7 +3304,8 @@ void FastPath::release() {
   for (int i = 0; i < 4; i++) if (ev[i]) { (void)hipEventDestroy(ev[i]); ev[i] = nullptr; }
   if (s2) {
     (void)hipStreamDestroy(s2); s2 = nullptr;
-    for (int i = 0; i < MAX_CHUNKS; i++) if (ev_chunk[i]) { (void)hipEventDestroy(ev_chunk[i]); ev_chunk[i] = nullptr; }
+    for (int i = 0; i < MAX_CHUNKS; i++) { if (ev_chunk[i]) { (void)hipEventDestroy(ev_chunk[i]); ev_chunk[i] = nullptr; } if (ev_cols[i]) { (void)hipEventDestroy(ev_cols[i]); ev_cols[i] = nullptr; } }
+    if (ev_fin) { (void)hipEventDestroy(ev_fin); ev_fin = nullptr; }
     if (ev_sample) { (void)hipEventDestroy(ev_sample); ev_sample = nullptr; }
   }
 }
@@ -3436,7 +3471,7 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
       d_split_rec.reserve((size_t)n_rec * sizeof(SplitRec) + 64);
       d_split_fam.reserve((size_t)n_grp * sizeof(SplitFam) + 64);
       P.split_rec = d_split_rec.as<SplitRec>(); P.split_fam = d_split_fam.as<SplitFam>();
-      if (!s2) { hip_check(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking), "hipStreamCreate"); for (int i = 0; i < MAX_CHUNKS; i++) hip_check(hipEventCreateWithFlags(&ev_chunk[i], hipEventDisableTiming), "hipEventCreate"); hip_check(hipEventCreateWithFlags(&ev_sample, hipEventDisableTiming), "hipEventCreate"); }
+      if (!s2) { hip_check(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking), "hipStreamCreate"); for (int i = 0; i < MAX_CHUNKS; i++) { hip_check(hipEventCreateWithFlags(&ev_chunk[i], hipEventDisableTiming), "hipEventCreate"); hip_check(hipEventCreateWithFlags(&ev_cols[i], hipEventDisableTiming), "hipEventCreate"); } hip_check(hipEventCreateWithFlags(&ev_fin, hipEventDisableTiming), "hipEventCreate"); hip_check(hipEventCreateWithFlags(&ev_sample, hipEventDisableTiming), "hipEventCreate"); }
       FastParams PK;
       memset(&PK, 0, sizeof(PK));
       PK.blob = d_blob; PK.rec_off = d_rec_off; PK.rec_len = d_rec_len; PK.grp_first = d_grp_first; PK.blob_len = blob_len;
@@ -3510,17 +3545,28 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
             if (ga >= gb) break;
             hip_check(hipStreamWaitEvent(s, ev_chunk[k], 0), "wait");
             launch_cols(ga, gb - ga);
+            // the chunk's EndDescs / record sizes / counters (a thread per family: waits on memory, few instructions) on the second
+            // stream, under the next chunk's column kernel
+            hip_check(hipEventRecord(ev_cols[k], s), "event");
+            hip_check(hipStreamWaitEvent(s2, ev_cols[k], 0), "wait");
+            FastParams PF = P;
+            PF.group_list = nullptr; PF.g0 = ga;
+            hipLaunchKernelGGL(k_split_finish, dim3((gb - ga + 255) / 256), dim3(256), 0, s2, PF, gb - ga);
           }
-        } else launch_cols(0u, n_s2);
+        } else {
+          launch_cols(0u, n_s2);
+          FastParams PF = P;                       // the families this (larger-slice) launch finished: the list it was given
+          PF.group_list = s2_list; PF.g0 = 0;
+          hipLaunchKernelGGL(k_split_finish, dim3((n_s2 + 255) / 256), dim3(256), 0, s, PF, n_s2);
+        }
         hip_check(hipGetLastError(), "k_split_cols launch");
         uint32_t n_next = 0;
         hip_check(hipMemcpyAsync(&n_next, d_cnt, 4, hipMemcpyDeviceToHost, s), "D2H");
         hip_check(hipStreamSynchronize(s), "sync");
         s2_list = lists[s2_out]; n_s2 = PS.retry ? n_next : 0; s2_out ^= 1;
       }
-      // EndDescs, record sizes and counters of the families k_split_cols finished: a thread per family
-      hipLaunchKernelGGL(k_split_finish, dim3((n_grp + 255) / 256), dim3(256), 0, s, P, n_grp);
-      hip_check(hipGetLastError(), "k_split_finish launch");
+      hip_check(hipEventRecord(ev_fin, s2), "event");          // the per-chunk k_split_finish launches
+      hip_check(hipStreamWaitEvent(s, ev_fin, 0), "wait");
       uint32_t n_route = 0;
       hip_check(hipMemcpyAsync(&n_route, d_cnt_route, 4, hipMemcpyDeviceToHost, s), "D2H");
       hip_check(hipStreamSynchronize(s), "sync");
