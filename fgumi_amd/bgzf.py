@@ -127,14 +127,16 @@ def bam_header_bytes(text: str, refs: Sequence[Tuple[str, int]]) -> bytes:
 
 
 def consensus_header(read_group_id: str = "A", comment_prefix: str = "Read group", n_input_read_groups: int = 0,
-                     command_line: str = "", rg_attrs: Sequence[Tuple[str, str]] = ()) -> str:
+                     command_line: str = "", rg_attrs: Sequence[Tuple[str, str]] = (), program_version: str = "0.0.0") -> str:
     """`create_unmapped_consensus_header` (consensus_runner.rs:130-173): sort order unsorted, group order query, one read
-    group with the collapsed attributes of the input read groups, the comment line, a @PG record."""
+    group with the collapsed attributes of the input read groups, a @PG record (ID / PN / VN / CL, before the comment as the
+    reference's writer orders them), the comment line.  `program_version` is the reference build's version string: a whole-file
+    comparison against a reference binary needs its VN here; tools/ref_pin.sh compares records only."""
     rg = "@RG\tID:" + read_group_id + "".join(f"\t{k}:{v}" for k, v in rg_attrs)
-    lines = ["@HD\tVN:1.6\tSO:unsorted\tGO:query", rg,
-             f"@CO\t{comment_prefix} {read_group_id} contains consensus reads generated from {n_input_read_groups} input read groups."]
-    if command_line:
-        lines.append("@PG\tID:fgumi\tPN:fgumi\tCL:" + command_line)
+    lines = ["@HD\tVN:1.6\tSO:unsorted\tGO:query", rg]
+    if command_line:      # the noodles writer serialises @PG before @CO; the record carries VN (add_pg_to_builder)
+        lines.append(f"@PG\tID:fgumi\tPN:fgumi\tVN:{program_version}\tCL:" + command_line)
+    lines.append(f"@CO\t{comment_prefix} {read_group_id} contains consensus reads generated from {n_input_read_groups} input read groups.")
     return "\n".join(lines) + "\n"
 
 
@@ -178,6 +180,8 @@ def bgzf_block_table(raw) -> List[Tuple[int, int]]:
         q, end, bsize = p + 12, p + 12 + xlen, None
         while q + 4 <= end:
             slen = mv[q + 2] | (mv[q + 3] << 8)
+            if q + 4 + slen > end:                      # a subfield that overruns XLEN
+                break
             if mv[q] == 0x42 and mv[q + 1] == 0x43 and slen == 2:
                 bsize = (mv[q + 4] | (mv[q + 5] << 8)) + 1
             q += 4 + slen
@@ -221,7 +225,7 @@ def record_boundaries(stream, start: int = 0) -> Tuple[np.ndarray, np.ndarray]:
         ln = np.empty(n.value, dtype=np.uint32)
         L.fgx_record_boundaries(buf.ctypes.data, buf.size, start, off.ctypes.data, ln.ctypes.data, n.value, C.byref(n))
         return off, ln
-    except (ImportError, OSError):
+    except (ImportError, OSError, RuntimeError, AttributeError):   # no library (LibraryMissing is a RuntimeError) or a stale one without this entry
         pass
     mv = memoryview(stream)
     n = len(mv)

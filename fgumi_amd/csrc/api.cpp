@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <stdexcept>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include "engine.h"
@@ -108,7 +109,8 @@ const char* fgx_last_error(const fgx_caller* c) { return c ? c->err.c_str() : g_
 static std::string libm_self_check() {
   static int verdict = 0;                   // 0 unknown, 1 agree, 2 differ
   static std::string detail;
-  if (verdict == 0) {
+  static std::once_flag once;               // (fgx_create is called from one thread per GPU: the first calls race)
+  std::call_once(once, [&]() {
     uint64_t r = 0x9E3779B97F4A7C15ull;
     auto next = [&]() { r ^= r << 13; r ^= r >> 7; r ^= r << 17; return (double)(r >> 11) * (1.0 / 9007199254740992.0); };
     uint32_t bad = 0;
@@ -138,7 +140,7 @@ static std::string libm_self_check() {
                " — consensus qualities would no longer be those of a reference build on this box; set FGX_ALLOW_LIBM_MISMATCH=1 to run anyway";
       verdict = 2;
     } else verdict = 1;
-  }
+  });
   return verdict == 2 ? detail : std::string();
 }
 

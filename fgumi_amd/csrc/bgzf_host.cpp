@@ -51,6 +51,7 @@ int fgx_bgzf_inflate(const uint8_t* raw, uint64_t raw_len, uint32_t threads, uin
     uint32_t bsize = 0;
     while (q + 4 <= end && end <= raw_len) {
       const uint32_t slen = raw[q + 2] | (raw[q + 3] << 8);
+      if (q + 4 + slen > end) break;           // a subfield that overruns XLEN: no BC taken from it (the block is refused below)
       if (raw[q] == 'B' && raw[q + 1] == 'C' && slen == 2) bsize = (uint32_t)(raw[q + 4] | (raw[q + 5] << 8)) + 1;
       q += 4 + slen;
     }

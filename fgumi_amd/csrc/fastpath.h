@@ -180,6 +180,8 @@ struct FastPath {
   uint32_t lds_wave_bytes_codec = 5120;   // CODEC (config 5: 8 records x ~570 B): its kernel needs 71 VGPRs, so the smaller slice buys a sixth wave per SIMD (+3 %)
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   // split simplex pipeline: the record kernel runs chunk by chunk on a second stream, under the column kernel of the chunk before
+  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: one flag per FastPath (= per caller = per device), not per process
+  bool lds_attr_set = false, s2_attr_set = false, v2_attr_set = false;
   static constexpr int MAX_CHUNKS = 16;
   hipStream_t s2 = nullptr;
   hipEvent_t ev_chunk[MAX_CHUNKS] = {}, ev_cols[MAX_CHUNKS] = {}, ev_fin = nullptr, ev_sample = nullptr;

@@ -3423,7 +3423,6 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
   // (long-tail families: 6 KB holds ~18 records of 150 bp, 12 KB ~36, 22 KB all 64 a wavefront can take).
   {
     const uint32_t stages[3] = {wave_bytes, 12288u, 22016u};
-    static bool lds_attr_set = false;
     if (!lds_attr_set) {
       (void)hipFuncSetAttribute((const void*)k_family_wave<0>, hipFuncAttributeMaxDynamicSharedMemorySize, WAVES_PER_BLOCK * 22016);
       (void)hipFuncSetAttribute((const void*)k_family_wave<1>, hipFuncAttributeMaxDynamicSharedMemorySize, WAVES_PER_BLOCK * 22016);
@@ -3444,8 +3443,7 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
     if (use_split) {
       // k_split_cols over growing LDS slices (4 / 2 / 1 / 1 wavefronts per workgroup); what it does not take is collected in
       // `route` and starts the k_simplex_wave2 chain below
-      static bool s2_attr_set = false;
-      if (!s2_attr_set) {
+        if (!s2_attr_set) {
         (void)hipFuncSetAttribute((const void*)k_split_cols<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         (void)hipFuncSetAttribute((const void*)k_split_cols<160, 80>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         (void)hipGetLastError();
@@ -3577,8 +3575,7 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
     if (simplex_v2) {
       // Launch chain: k_simplex_seg<4> / <2> (4 / 2 families per wavefront, while the mean family fits a quarter / half of the
       // wave's LDS) → k_simplex_wave2 over the growing slices.  A family that does not fit a launch moves to the next one.
-      static bool v2_attr_set = false;
-      if (!v2_attr_set) {
+        if (!v2_attr_set) {
         (void)hipFuncSetAttribute((const void*)k_simplex_wave2, hipFuncAttributeMaxDynamicSharedMemorySize, WAVES_PER_BLOCK * 22016);
         (void)hipFuncSetAttribute((const void*)k_simplex_seg<2>, hipFuncAttributeMaxDynamicSharedMemorySize, WAVES_PER_BLOCK * 32768);
         (void)hipFuncSetAttribute((const void*)k_simplex_seg<4>, hipFuncAttributeMaxDynamicSharedMemorySize, WAVES_PER_BLOCK * 32768);

@@ -78,8 +78,9 @@ def test_consensus_header_is_the_reference_shape():
     lines = h.strip().split("\n")
     assert lines[0] == "@HD\tVN:1.6\tSO:unsorted\tGO:query"               # consensus_runner.rs:156-161
     assert lines[1] == "@RG\tID:A"
-    assert lines[2] == "@CO\tRead group A contains consensus reads generated from 2 input read groups."
-    assert lines[3].startswith("@PG\t")
+    # the noodles header writer serialises @HD, @SQ, @RG, @PG, @CO in that order; the @PG record carries ID / PN / VN / CL
+    assert lines[2].startswith("@PG\tID:fgumi\tPN:fgumi\tVN:") and "\tCL:fgumi simplex" in lines[2]
+    assert lines[3] == "@CO\tRead group A contains consensus reads generated from 2 input read groups."
 
 
 def test_export_bam_tool_writes_the_pin_input(tmp_path):
@@ -113,3 +114,28 @@ def test_native_bgzf_entries_match_the_python_container_code():
         bgzf.native_inflate(bytes(bad))
     with pytest.raises(ValueError):
         bgzf.native_inflate(blob[:-40] + blob[-28:])
+
+
+def test_record_boundaries_falls_back_without_the_library(monkeypatch):
+    """`load()` raises LibraryMissing (a RuntimeError) when libfgumi_amd.so is absent, AttributeError when it is stale: both
+    must reach the pure-Python chain walk."""
+    from fgumi_amd import _lib
+    g = simulate_grouped_reads(20, family_size=2)
+    want_off, want_len = np.asarray(g.rec_off, dtype=np.uint64), np.asarray(g.rec_len, dtype=np.uint32)
+    stream = bytes(g.blob[:int(want_off[-1]) + int(want_len[-1])])
+    for exc in (_lib.LibraryMissing("no library"), AttributeError("fgx_record_boundaries")):
+        def boom(*a, _e=exc, **k):
+            raise _e
+        monkeypatch.setattr(_lib, "load", boom)
+        off, ln = bgzf.record_boundaries(stream, 0)
+        assert np.array_equal(off, want_off) and np.array_equal(ln, want_len)
+
+
+def test_block_table_refuses_a_subfield_that_overruns_xlen():
+    blk = bytearray(bgzf.bgzf_compress(b"x" * 100, 1, 1)[0])
+    # BC subfield header moved so that its payload would lie past XLEN: SI1 SI2 SLEN=2 at end-4 .. end
+    xlen = blk[10] | (blk[11] << 8)
+    assert xlen == 6
+    blk[10] = 4                       # XLEN now ends right behind the subfield HEADER
+    with pytest.raises(ValueError):
+        bgzf.bgzf_block_table(bytes(blk))
