@@ -61,6 +61,15 @@ def physical_cores():
         return None
 
 
+def cgroup_cpu_quota():
+    """CPUs' worth of time the container's cgroup grants (cpu.max = "<quota> <period>"), or None when unlimited / unknown."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else max(1, -(-int(q) // int(p)))
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(n_families, family_size, read_length, threads, duplex=False, codec=False):
     """Bounded sample of the same workload through the ORACLE (C++ restatement of the reference CPU caller;
     `--threads`-style batches of MI groups, one caller object per batch, Phred tables cached process-wide like the
@@ -94,7 +103,10 @@ def cpu_baseline(n_families, family_size, read_length, threads, duplex=False, co
     vall, call, rall = run(n_families, threads, 3)
     shape = f"{family_size} pairs x {read_length}bp" + (" (--duplex)" if duplex else " (CODEC pairs, insert N(350,60))" if codec else "")
     phys = physical_cores() or threads
-    return dict(value=vall, unit="raw reads/s", cores=threads, kind="port", cpu_model=cpu_model(),
+    quota = cgroup_cpu_quota()
+    if quota is not None:
+        phys = min(phys, quota)                  # what the box lets this process use, whatever /proc/cpuinfo lists
+    return dict(value=vall, unit="raw reads/s", cores=threads, kind="port", cpu_model=cpu_model(), cgroup_cpu_quota=quota,
                 value_1_thread=v1, speedup_all_over_1=vall / v1 if v1 else None,
                 # what perfect scaling of the one-thread figure over the box's physical cores would give: the number to hold the GPU
                 # against when the measured multi-thread leg falls short of it (memory allocator, SMT, NUMA)
@@ -303,7 +315,8 @@ def main():
                          "pmc_kernel": pmc["kernel"] if pmc else None, "pmc_source": pmc_file},
         }
         if not args.no_cpu_baseline and world == 1 and not args.depth_max:
-            line["cpu_baseline"] = cpu_baseline(min(fam, args.cpu_sample_families), args.depth, L, os.cpu_count() or 1, duplex, codec)
+            # threads = the CPUs the container may really use (cgroup quota): oversubscribing a throttled cgroup only adds queueing
+            line["cpu_baseline"] = cpu_baseline(min(fam, args.cpu_sample_families), args.depth, L, min(os.cpu_count() or 1, cgroup_cpu_quota() or 1 << 30), duplex, codec)
         print(json.dumps(line))
     if rank == 0:   # profiling builds (-DFGX_PHASE_TIMING=1) expose per-phase cycle totals of the family kernels
         import ctypes

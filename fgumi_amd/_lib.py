@@ -65,11 +65,22 @@ class SimParams(C.Structure):
 
 
 # every symbol include/fgumi_amd.h declares
+class BamRunStats(C.Structure):
+    """include/fgumi_amd.h fgx_bam_run_stats."""
+    _fields_ = [("kept_records", C.c_uint64), ("groups", C.c_uint64), ("consensus_records", C.c_uint64), ("deferred_groups", C.c_uint64),
+                ("chunks", C.c_uint64), ("in_bytes", C.c_uint64), ("inflated_bytes", C.c_uint64), ("out_bytes", C.c_uint64),
+                ("out_file_bytes", C.c_uint64), ("stats", C.c_uint64 * 28), ("seconds_total", C.c_double),
+                ("seconds_read", C.c_double), ("seconds_inflate", C.c_double), ("seconds_device", C.c_double), ("seconds_deflate", C.c_double),
+                ("seconds_write", C.c_double), ("seconds_h2d", C.c_double), ("seconds_boundaries", C.c_double), ("seconds_grouping", C.c_double),
+                ("seconds_consensus", C.c_double), ("seconds_d2h", C.c_double), ("boundary_repair_rounds", C.c_uint32), ("_pad", C.c_uint32)]
+
+
 EXPORTS = ["fgx_options_default", "fgx_create", "fgx_destroy", "fgx_last_error", "fgx_global_error", "fgx_process_batch",
            "fgx_process_batch_device", "fgx_call_columns", "fgx_device_libm", "fgx_get_table", "fgx_sim_sizes", "fgx_sim_family_bytes", "fgx_libm_self_check", "fgx_record_boundaries",
            "fgx_bgzf_inflate", "fgx_bgzf_deflate", "fgx_bgzf_free", "fgx_bgzf_last_error",
            "fgx_sim_generate_host", "fgx_sim_generate_device", "fgx_group_records", "fgx_group_records_device", "fgx_filter_options_default",
-           "fgx_filter_records", "fgx_filter_records_device", "fgx_filter_last_output_device"]
+           "fgx_filter_records", "fgx_filter_records_device", "fgx_filter_last_output_device",
+           "fgx_record_boundaries_device", "fgx_run_bam", "fgx_bgzf_recompress_file", "fgx_pipeline_last_error"]
 
 _lib = None
 
@@ -136,6 +147,14 @@ def load():
     L.fgx_group_records.restype = I
     L.fgx_group_records_device.argtypes = [VP, P(GroupOptions), VP, U64, VP, VP, U32, VP, VP, VP, P(U32), P(U32)]
     L.fgx_group_records_device.restype = I
+    L.fgx_record_boundaries_device.argtypes = [VP, VP, U64, U64, VP, VP, U64, P(U64), P(U64)]
+    L.fgx_record_boundaries_device.restype = I
+    L.fgx_run_bam.argtypes = [VP, C.c_char_p, C.c_char_p, VP, U64, P(GroupOptions), U32, I, U64, P(BamRunStats)]
+    L.fgx_run_bam.restype = I
+    L.fgx_bgzf_recompress_file.argtypes = [C.c_char_p, C.c_char_p, U32, I, U64, P(U64)]
+    L.fgx_bgzf_recompress_file.restype = I
+    L.fgx_pipeline_last_error.argtypes = []
+    L.fgx_pipeline_last_error.restype = C.c_char_p
     L.fgx_filter_options_default.argtypes = [P(FilterOptions)]
     L.fgx_filter_options_default.restype = None
     L.fgx_filter_records.argtypes = [VP, P(FilterOptions), VP, U64, VP, VP, U32, P(FilterOutput)]

@@ -93,6 +93,18 @@ def native_inflate(raw, threads: Optional[int] = None):
     return own.array(), own
 
 
+def recompress_file(in_path: str, out_path: str, level: int = 1, threads: Optional[int] = None, chunk_raw_bytes: int = 0) -> int:
+    """The host stages of the streaming pipeline (read, block-parallel inflate, deflate, write) around a copy: re-blocks a BGZF
+    file.  Returns the number of uncompressed bytes that went through."""
+    import ctypes as C
+    from ._lib import load
+    L = load()
+    n = C.c_uint64()
+    if L.fgx_bgzf_recompress_file(in_path.encode(), out_path.encode(), threads or 0, level, chunk_raw_bytes, C.byref(n)) != 0:
+        raise ValueError(L.fgx_pipeline_last_error().decode())
+    return int(n.value)
+
+
 def native_deflate(stream, level: int = 1, threads: Optional[int] = None, with_eof: bool = False):
     L = _native()
     if L is None:

@@ -387,6 +387,31 @@ class _HandleCaller(ConsensusCaller):
             raise RuntimeError(lib.fgx_last_error(self._h).decode())
         return DeviceGroupedReads(blob, bl.value, rec_off, rec_len, grp_first, nr.value, n_families)
 
+    # ---- a BAM file in, a consensus BAM file out (the streaming pipeline of csrc/pipeline.cpp) ---------
+    def run_bam(self, in_path: str, out_path: str, header_text: Optional[str] = None, level: int = 1, threads: Optional[int] = None,
+                chunk_raw_bytes: int = 0, tag: str = "MI", cell_tag: Optional[str] = "CB", strip_strand_suffix: bool = False,
+                allow_unmapped: bool = False) -> dict:
+        """Reads the grouped BAM `in_path` chunk by chunk (BGZF inflate on the host cores, record boundaries + MI grouping + the
+        consensus batch on the device, BGZF deflate on the host cores) and writes the consensus BAM `out_path`; the stages of
+        successive chunks overlap.  Returns the pipeline's counters and stage times."""
+        from . import bgzf
+        from ._lib import BamRunStats
+        if header_text is None:
+            header_text = bgzf.consensus_header(self._rg.decode())
+        hdr = bgzf.bam_header_bytes(header_text, [])
+        hb = np.frombuffer(hdr, dtype=np.uint8)
+        o = GroupOptions(tag.encode(), cell_tag.encode() if cell_tag else b"\0\0", int(strip_strand_suffix), int(allow_unmapped))
+        st = BamRunStats()
+        rc = lib.fgx_run_bam(self._h, in_path.encode(), out_path.encode(), hb.ctypes.data, hb.size, C.byref(o), threads or 0, level,
+                             chunk_raw_bytes, C.byref(st))
+        if rc != 0:
+            raise RuntimeError(lib.fgx_last_error(self._h).decode())
+        self._last_stats = ConsensusCallingStats.from_array(st.stats)
+        self._stats.merge(self._last_stats)
+        out = {k: getattr(st, k) for k, _ in BamRunStats._fields_ if k not in ("stats", "_pad")}
+        out["stats"] = [int(v) for v in st.stats]
+        return out
+
     # ---- the trait -----------------------------------------------------------------------------
     def consensus_reads(self, records: Sequence[bytes]) -> ConsensusOutput:
         if not records:

@@ -205,6 +205,7 @@ void fgx_destroy(fgx_caller* c) {
     b->free_();
   if (c->fast) { c->fast->fp.release(); c->fast->pin_out.free_(); delete c->fast; }
   if (c->filt) { c->filt->release(); delete c->filt; }
+  pipeline_release(c);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -469,6 +470,16 @@ int fgx_group_records_device(fgx_caller* c, const fgx_group_options* g, const vo
     hip_check(hipSetDevice(c->device), "hipSetDevice");
     return group_records_device(c, g, (const uint8_t*)d_records, records_len, (const uint64_t*)d_rec_off, (const uint32_t*)d_rec_len, n_rec,
                                 (uint64_t*)d_out_rec_off, (uint32_t*)d_out_rec_len, (uint32_t*)d_grp_first, n_kept, n_grp);
+  } catch (const std::exception& ex) { c->err = ex.what(); return 3; }
+}
+
+int fgx_record_boundaries_device(fgx_caller* c, const void* d_stream, uint64_t stream_len, uint64_t start, void* d_rec_off, void* d_rec_len,
+                                 uint64_t cap, uint64_t* n_rec, uint64_t* consumed) {
+  if (!c || !n_rec || !consumed) return 1;
+  c->err.clear();
+  try {
+    hip_check(hipSetDevice(c->device), "hipSetDevice");
+    return record_boundaries_device(c, (const uint8_t*)d_stream, stream_len, start, (uint64_t*)d_rec_off, (uint32_t*)d_rec_len, cap, n_rec, consumed);
   } catch (const std::exception& ex) { c->err = ex.what(); return 3; }
 }
 

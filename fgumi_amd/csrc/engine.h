@@ -123,6 +123,8 @@ struct fgx_caller {
   struct FastState* fast = nullptr;        // device-resident pipeline state (fastpath.hip)
   fgx::DevBuf d_in_blob, d_in_off, d_in_len, d_in_grp;   // host-input staging for fgx_process_batch
   fgx::FilterBuffers* filt = nullptr;      // fgx_filter_records[_device] state (filter.hip)
+  void* pipe_state = nullptr;              // buffers of fgx_run_bam, kept from run to run (pipeline.cpp: fgx_pipeline_release)
+  uint32_t last_boundary_rounds = 0;       // repair rounds of the last fgx_record_boundaries_device call (boundaries.hip; 0 = every guess was right)
 
   // Runs the staged column jobs of `b` on the device and fills b.ob/oq/od/oe. Returns kernel ms.
   double run_columns(fgx::ColumnBatch& b, fgx::ColParams prm);
@@ -139,6 +141,11 @@ int duplex_process_general(fgx_caller* c, const uint8_t* blob, const uint64_t* r
 int group_records_device(fgx_caller* c, const fgx_group_options* o, const uint8_t* d_blob, uint64_t blob_len, const uint64_t* d_rec_off,
                          const uint32_t* d_rec_len, uint32_t n, uint64_t* d_out_off, uint32_t* d_out_len, uint32_t* d_grp_first, uint32_t* n_kept,
                          uint32_t* n_grp);
+// boundaries.hip — FindBoundaries on the device
+int record_boundaries_device(fgx_caller* c, const uint8_t* d_stream, uint64_t len, uint64_t start, uint64_t* d_rec_off, uint32_t* d_rec_len,
+                             uint64_t cap, uint64_t* n_rec, uint64_t* consumed);
+// pipeline.cpp — frees what fgx_run_bam keeps in c->pipe_state
+void pipeline_release(fgx_caller* c);
 // filter.hip — `fgumi filter` on the device
 int filter_records_device(fgx_caller* c, FilterBuffers& B, const fgx_filter_options* o, uint8_t* d_blob, uint64_t blob_len, const uint64_t* d_rec_off,
                           const uint32_t* d_rec_len, uint32_t n, fgx_filter_output* out);

@@ -1,0 +1,632 @@
+// pipeline.cpp — a BAM file in, a consensus BAM file out: the container work on BOTH sides of the device path as one streaming
+// pipeline.  What it stands in for, for this path: the reader / decompress / find-boundaries / group /
+// process / compress / write steps of the reference's unified pipeline (src/lib/unified_pipeline/bam.rs; BGZF framing
+// crates/fgumi-bgzf/src/{reader,writer}.rs; FindBoundaries bam.rs:193-260; MiGrouper src/lib/mi_group.rs:227-310), as five stages
+// over a ring of chunks:
+//
+//   read      the file, RAW_CHUNK compressed bytes at a time, cut at the last whole BGZF block (the BSIZE chain)
+//   inflate   every block of the chunk in parallel on the worker pool (zlib raw inflate, one z_stream per worker, CRC32 / ISIZE
+//             checked) straight into a PINNED buffer that is reused chunk after chunk (no page faults, full-rate DMA)
+//   device    upload behind what the previous chunk left over, record boundaries (boundaries.hip), MI grouping (grouping.hip), the
+//             consensus batch of every group but the last (it may continue in the next chunk; its bytes move to the front of the other
+//             device buffer), records back into a pinned buffer
+//   deflate   the consensus records, 0xff00 bytes per block, in parallel on the same pool (level 1: the reference's default)
+//   write     header blocks, the chunks' blocks in order, the EOF marker
+//
+// Each stage is a thread; chunk s enters a stage when the stage before has finished it, and the reader reuses a chunk's buffers when
+// the writer is done with them.  The stages of different chunks overlap: the file is read and inflated while the device works on the
+// previous chunk and the pool compresses the one before.
+#include <hip/hip_runtime.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+#include "engine.h"
+#include "../../include/fgumi_amd.h"
+
+namespace {
+
+using Clock = std::chrono::steady_clock;
+double since(Clock::time_point t) { return std::chrono::duration<double>(Clock::now() - t).count(); }
+
+constexpr uint32_t BGZF_PAYLOAD = 0xFF00;
+constexpr size_t BGZF_SLOT = 0x10000;
+
+// CPUs this process may actually use: the hardware threads, capped by the cgroup's CPU quota (a container that shows 256 logical
+// CPUs with `cpu.max = 1600000 100000` runs 16 cores' worth of threads; 256 workers there only queue behind the throttle)
+unsigned usable_cpus() {
+  unsigned n = std::thread::hardware_concurrency();
+  if (n == 0) n = 1;
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[64] = {0};
+    unsigned long long period = 0;
+    if (fscanf(f, "%63s %llu", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+      const unsigned long long quota = strtoull(q, nullptr, 10);
+      const unsigned c = (unsigned)((quota + period - 1) / period);
+      if (c >= 1 && c < n) n = c;
+    }
+    fclose(f);
+  }
+  return n;
+}
+
+// ---- worker pool: parallel_for from several stage threads at once ---------------------------------------------------------------
+class Pool {
+ public:
+  explicit Pool(unsigned n) {
+    if (n == 0) n = 1;
+    for (unsigned i = 0; i < n; i++) ts_.emplace_back([this, i] { run(i); });
+  }
+  ~Pool() {
+    { std::lock_guard<std::mutex> l(m_); stop_ = true; }
+    cv_.notify_all();
+    for (auto& t : ts_) t.join();
+  }
+  unsigned size() const { return (unsigned)ts_.size(); }
+  // fn(index, worker id); worker ids are 0 .. size() (the calling thread helps as worker `size()`)
+  void parallel_for(size_t n, size_t grain, const std::function<void(size_t, unsigned)>& fn) {
+    if (n == 0) return;
+    auto job = std::make_shared<Job>();
+    job->n = n; job->grain = grain ? grain : 1; job->fn = &fn;
+    { std::lock_guard<std::mutex> l(m_); jobs_.push_back(job); }
+    cv_.notify_all();
+    work(*job, size());
+    std::unique_lock<std::mutex> l(m_);
+    job->cv.wait(l, [&] { return job->done.load() >= job->n; });
+    for (size_t i = 0; i < jobs_.size(); i++) if (jobs_[i] == job) { jobs_.erase(jobs_.begin() + (long)i); break; }
+  }
+
+ private:
+  struct Job {
+    size_t n = 0, grain = 1;
+    std::atomic<size_t> next{0}, done{0};
+    const std::function<void(size_t, unsigned)>* fn = nullptr;
+    std::condition_variable cv;
+  };
+  void work(Job& j, unsigned wid) {
+    for (;;) {
+      const size_t i0 = j.next.fetch_add(j.grain);
+      if (i0 >= j.n) return;
+      const size_t i1 = i0 + j.grain < j.n ? i0 + j.grain : j.n;
+      for (size_t i = i0; i < i1; i++) (*j.fn)(i, wid);
+      if (j.done.fetch_add(i1 - i0) + (i1 - i0) >= j.n) { std::lock_guard<std::mutex> l(m_); j.cv.notify_all(); }
+    }
+  }
+  void run(unsigned wid) {
+    for (;;) {
+      std::shared_ptr<Job> job;
+      {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [&] {
+          if (stop_) return true;
+          for (auto& j : jobs_) if (j->next.load() < j->n) return true;
+          return false;
+        });
+        if (stop_) return;
+        for (auto& j : jobs_) if (j->next.load() < j->n) { job = j; break; }
+      }
+      if (job) work(*job, wid);
+    }
+  }
+  std::vector<std::thread> ts_;
+  std::vector<std::shared_ptr<Job>> jobs_;
+  std::mutex m_;
+  std::condition_variable cv_;
+  bool stop_ = false;
+};
+
+// ---- host buffers: pinned when a HIP device is there, plain otherwise ------------------------------------------------------------
+struct HostBuf {
+  uint8_t* p = nullptr;
+  size_t cap = 0;
+  bool pinned = false;
+  void reserve(size_t n, bool want_pinned) {
+    if (n <= cap) return;
+    release();
+    const size_t want = n + n / 8 + 4096;
+    if (want_pinned && hipHostMalloc((void**)&p, want, hipHostMallocDefault) == hipSuccess && p) { pinned = true; cap = want; return; }
+    (void)hipGetLastError();
+    p = (uint8_t*)malloc(want);
+    if (!p) throw std::runtime_error("out of host memory");
+    memset(p, 0, want);                                     // (touch the pages now, not inside a timed stage)
+    pinned = false; cap = want;
+  }
+  void release() {
+    if (!p) return;
+    if (pinned) (void)hipHostFree(p); else free(p);
+    p = nullptr; cap = 0;
+  }
+  ~HostBuf() { release(); }
+};
+
+struct Block { uint64_t in_off; uint32_t in_size, isize; uint64_t out_off; };
+
+struct Chunk {
+  const uint8_t* raw = nullptr;             // compressed bytes: whole BGZF blocks of the (memory-mapped) input file
+  size_t raw_len = 0;
+  std::vector<Block> blocks;
+  HostBuf inf;                              // inflated bytes
+  uint64_t inf_len = 0;
+  HostBuf out;                              // the records to write (uncompressed)
+  uint64_t out_len = 0;
+  HostBuf comp;                             // BGZF blocks, one 64 KiB slot each (reused: a vector would zero 64 KiB per block every chunk)
+  std::vector<uint32_t> comp_size;
+  HostBuf packed;                           // the chunk's BGZF blocks back to back: what the writer writes
+  uint64_t packed_len = 0;
+  bool last = false;                        // the file's last chunk
+};
+
+// parses the BSIZE chain of raw[0 .. len): whole blocks into `blocks`; returns the bytes they cover
+size_t block_table(const uint8_t* raw, size_t len, std::vector<Block>& blocks, uint64_t* inflated, std::string* err) {
+  blocks.clear();
+  size_t p = 0;
+  uint64_t total = 0;
+  while (len - p >= 18) {
+    if (raw[p] != 0x1F || raw[p + 1] != 0x8B || raw[p + 2] != 8 || !(raw[p + 3] & 4)) { *err = "not a BGZF block at chunk offset " + std::to_string(p); return (size_t)-1; }
+    const uint32_t xlen = raw[p + 10] | (raw[p + 11] << 8);
+    if (len - p < 12 + (size_t)xlen) break;
+    size_t q = p + 12;
+    const size_t end = p + 12 + xlen;
+    uint32_t bsize = 0;
+    while (q + 4 <= end) {
+      const uint32_t slen = raw[q + 2] | (raw[q + 3] << 8);
+      if (q + 4 + slen > end) break;
+      if (raw[q] == 'B' && raw[q + 1] == 'C' && slen == 2) bsize = (uint32_t)(raw[q + 4] | (raw[q + 5] << 8)) + 1;
+      q += 4 + slen;
+    }
+    if (bsize < 12 + xlen + 8) { *err = "BGZF block without a BC subfield at chunk offset " + std::to_string(p); return (size_t)-1; }
+    if (len - p < bsize) break;                               // the block continues in the next read
+    uint32_t isize;
+    memcpy(&isize, raw + p + bsize - 4, 4);
+    if (isize > 0x10000) { *err = "BGZF block claims more than 64 KiB"; return (size_t)-1; }
+    blocks.push_back(Block{p, bsize, isize, total});
+    total += isize;
+    p += bsize;
+  }
+  *inflated = total;
+  return p;
+}
+
+// the five stages over a ring of chunks; `middle` turns chunk.inf into chunk.out (the device stage, or a copy)
+struct Pipeline {
+  static constexpr int N_CHUNKS = 3, N_STAGES = 5;
+  Chunk chunks[N_CHUNKS];
+  std::mutex m;
+  std::condition_variable cv;
+  uint64_t progress[N_STAGES] = {0, 0, 0, 0, 0};   // chunks each stage has finished
+  uint64_t n_chunks_total = ~0ull;                 // known once the reader has seen the end of the file
+  bool failed = false;
+  std::string err;
+  double busy[N_STAGES] = {0, 0, 0, 0, 0};
+  uint64_t in_bytes = 0, inflated_bytes = 0, out_bytes = 0, out_file_bytes = 0;
+
+  void reset() {                                     // before a run (the chunks keep their buffers)
+    for (int k = 0; k < N_STAGES; k++) { progress[k] = 0; busy[k] = 0; }
+    n_chunks_total = ~0ull; failed = false; err.clear();
+    in_bytes = inflated_bytes = out_bytes = out_file_bytes = 0;
+  }
+  void fail(const std::string& e) {
+    std::lock_guard<std::mutex> l(m);
+    if (!failed) { failed = true; err = e; }
+    cv.notify_all();
+  }
+  // wait until chunk `s` may enter stage `k`; false = nothing more to do (or failure)
+  bool enter(int k, uint64_t s) {
+    std::unique_lock<std::mutex> l(m);
+    cv.wait(l, [&] {
+      if (failed) return true;
+      if (s >= n_chunks_total) return true;
+      if (k == 0) return s < progress[N_STAGES - 1] + N_CHUNKS;          // the chunk's buffers are free again
+      return progress[k - 1] > s;
+    });
+    return !failed && s < n_chunks_total;
+  }
+  void leave(int k) {
+    std::lock_guard<std::mutex> l(m);
+    progress[k]++;
+    cv.notify_all();
+  }
+
+  int run(const char* in_path, const char* out_path, const uint8_t* out_header, uint64_t out_header_len, unsigned threads, int level,
+          uint64_t raw_chunk, bool pinned, const std::function<void(Chunk&, uint64_t)>& middle) {
+    // the input is memory-mapped: the inflate workers read the compressed blocks where the page cache holds them (reading the file
+    // into a buffer first was a single-threaded copy of every byte: the slowest stage)
+    const int fd = open(in_path, O_RDONLY);
+    if (fd < 0) { err = std::string("cannot open ") + in_path; return 1; }
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) { close(fd); err = std::string("cannot stat ") + in_path; return 1; }
+    const size_t file_len = (size_t)sb.st_size;
+    const uint8_t* file = nullptr;
+    if (file_len) {
+      void* m = mmap(nullptr, file_len, PROT_READ, MAP_PRIVATE, fd, 0);
+      if (m == MAP_FAILED) { close(fd); err = std::string("cannot map ") + in_path; return 1; }
+      (void)madvise(m, file_len, MADV_SEQUENTIAL);
+      file = (const uint8_t*)m;
+    }
+    FILE* fout = fopen(out_path, "wb");
+    if (!fout) { if (file) munmap((void*)file, file_len); close(fd); err = std::string("cannot create ") + out_path; return 1; }
+    if (raw_chunk < (1u << 16)) raw_chunk = 1u << 16;             // (a BGZF block is at most 64 KiB: every chunk holds at least one)
+    Pool pool(threads ? threads : usable_cpus());
+    const unsigned n_workers = pool.size() + 8;                 // (+ the stage threads that help)
+
+    std::thread t_read([&] {
+      try {
+        size_t pos = 0;
+        bool eof = false;
+        for (uint64_t s = 0; !eof; s++) {
+          if (!enter(0, s)) return;
+          const auto t0 = Clock::now();
+          Chunk& c = chunks[s % N_CHUNKS];
+          const size_t have = file_len - pos < raw_chunk ? file_len - pos : (size_t)raw_chunk;
+          eof = pos + have == file_len;
+          std::string e;
+          uint64_t infl = 0;
+          const size_t used = block_table(file + pos, have, c.blocks, &infl, &e);
+          if (used == (size_t)-1) { fail(e); return; }
+          if (eof && used != have) { fail("the file ends inside a BGZF block"); return; }
+          if (!eof && used == 0) { fail("no whole BGZF block inside a chunk"); return; }
+          c.raw = file + pos; c.raw_len = used; c.inf_len = infl; c.last = eof;
+          pos += used; in_bytes += used;
+          busy[0] += since(t0);
+          if (eof) { std::lock_guard<std::mutex> l(m); n_chunks_total = s + 1; }
+          leave(0);
+        }
+      } catch (const std::exception& ex) { fail(ex.what()); }
+    });
+
+    std::thread t_inflate([&] {
+      try {
+        std::vector<z_stream> zs(n_workers);
+        std::vector<char> zs_init(n_workers, 0);
+        std::vector<uint8_t> scratch((size_t)n_workers * BGZF_SLOT);
+        for (uint64_t s = 0;; s++) {
+          if (!enter(1, s)) break;
+          const auto t0 = Clock::now();
+          Chunk& c = chunks[s % N_CHUNKS];
+          c.inf.reserve(c.inf_len + 64, pinned);
+          std::atomic<int> bad(0);
+          pool.parallel_for(c.blocks.size(), 8, [&](size_t i, unsigned w) {
+            const Block& b = c.blocks[i];
+            if (b.isize == 0) return;
+            const uint8_t* raw = c.raw;
+            const uint32_t xlen = raw[b.in_off + 10] | (raw[b.in_off + 11] << 8);
+            z_stream& z = zs[w];
+            if (!zs_init[w]) { memset(&z, 0, sizeof(z)); if (inflateInit2(&z, -15) != Z_OK) { bad = 1; return; } zs_init[w] = 1; }
+            else if (inflateReset(&z) != Z_OK) { bad = 1; return; }
+            // inflate into the worker's own 64 KiB block, then ONE copy into the pinned chunk buffer: LZ77 matches are copies out of
+            // what was just written, and reading pinned (device-visible) memory back is far slower than reading a block that sits in L2
+            uint8_t* tmp = scratch.data() + (size_t)w * BGZF_SLOT;
+            z.next_in = (Bytef*)(raw + b.in_off + 12 + xlen); z.avail_in = b.in_size - 12 - xlen - 8;
+            z.next_out = tmp; z.avail_out = b.isize;
+            const int rc = inflate(&z, Z_FINISH);
+            uint32_t crc;
+            memcpy(&crc, raw + b.in_off + b.in_size - 8, 4);
+            if (rc != Z_STREAM_END || z.total_out != b.isize || (uint32_t)crc32(0L, tmp, b.isize) != crc) { bad = 1; return; }
+            memcpy(c.inf.p + b.out_off, tmp, b.isize);
+          });
+          if (bad) { fail("a BGZF block failed to inflate or its CRC32 / ISIZE does not match"); break; }
+          inflated_bytes += c.inf_len;
+          busy[1] += since(t0);
+          leave(1);
+        }
+        for (unsigned w = 0; w < n_workers; w++) if (zs_init[w]) inflateEnd(&zs[w]);
+      } catch (const std::exception& ex) { fail(ex.what()); }
+    });
+
+    std::thread t_middle([&] {
+      try {
+        for (uint64_t s = 0;; s++) {
+          if (!enter(2, s)) return;
+          const auto t0 = Clock::now();
+          middle(chunks[s % N_CHUNKS], s);
+          out_bytes += chunks[s % N_CHUNKS].out_len;
+          busy[2] += since(t0);
+          leave(2);
+        }
+      } catch (const std::exception& ex) { fail(ex.what()); }
+    });
+
+    // cuts `src` into BGZF blocks (parallel, one 64 KiB slot each), then packs them back to back into `packed` (parallel copies):
+    // the writer hands the file system one large buffer per chunk instead of tens of thousands of 8 KB pieces
+    std::vector<uint8_t> dscratch((size_t)n_workers * BGZF_SLOT);
+    auto deflate_stream = [&](const uint8_t* src, uint64_t len, HostBuf& comp, std::vector<uint32_t>& sizes, HostBuf& packed, uint64_t* packed_len,
+                              bool use_scratch) -> bool {
+      const size_t nb = (size_t)((len + BGZF_PAYLOAD - 1) / BGZF_PAYLOAD);
+      comp.reserve(nb * BGZF_SLOT + 64, false);
+      sizes.assign(nb, 0);
+      std::atomic<int> bad(0);
+      pool.parallel_for(nb, 4, [&](size_t i, unsigned w) {
+        const uint8_t* in = src + i * (uint64_t)BGZF_PAYLOAD;
+        const uint32_t n = (uint32_t)((len - i * (uint64_t)BGZF_PAYLOAD) < BGZF_PAYLOAD ? (len - i * (uint64_t)BGZF_PAYLOAD) : BGZF_PAYLOAD);
+        if (use_scratch) {                         // (the records come out of pinned memory: one read of it, not zlib's several)
+          uint8_t* tmp = dscratch.data() + (size_t)w * BGZF_SLOT;
+          memcpy(tmp, in, n);
+          in = tmp;
+        }
+        uint8_t* blk = comp.p + i * BGZF_SLOT;
+        uint32_t csize = 0;
+        for (int lv = level;; lv = 0) {         // an incompressible payload falls back to stored blocks (always fits)
+          z_stream z;
+          memset(&z, 0, sizeof(z));
+          if (deflateInit2(&z, lv, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { bad = 1; return; }
+          z.next_in = (Bytef*)in; z.avail_in = n;
+          z.next_out = blk + 18; z.avail_out = (uInt)(BGZF_SLOT - 18 - 8);
+          const int rc = deflate(&z, Z_FINISH);
+          csize = (uint32_t)z.total_out;
+          deflateEnd(&z);
+          if (rc == Z_STREAM_END) break;
+          if (lv == 0) { bad = 1; return; }
+        }
+        const uint32_t bsize = 18 + csize + 8 - 1;
+        const uint8_t hdr[18] = {0x1F, 0x8B, 8, 4, 0, 0, 0, 0, 0, 0xFF, 6, 0, 'B', 'C', 2, 0, (uint8_t)bsize, (uint8_t)(bsize >> 8)};
+        memcpy(blk, hdr, 18);
+        const uint32_t crc = (uint32_t)crc32(0L, in, n);
+        memcpy(blk + 18 + csize, &crc, 4);
+        memcpy(blk + 18 + csize + 4, &n, 4);
+        sizes[i] = bsize + 1;
+      });
+      if (bad) return false;
+      std::vector<uint64_t> offs(nb + 1, 0);
+      for (size_t i = 0; i < nb; i++) offs[i + 1] = offs[i] + sizes[i];
+      packed.reserve(offs[nb] + 64, false);
+      pool.parallel_for(nb, 16, [&](size_t i, unsigned) { memcpy(packed.p + offs[i], comp.p + i * BGZF_SLOT, sizes[i]); });
+      *packed_len = offs[nb];
+      return true;
+    };
+
+    std::thread t_deflate([&] {
+      try {
+        for (uint64_t s = 0;; s++) {
+          if (!enter(3, s)) return;
+          const auto t0 = Clock::now();
+          Chunk& c = chunks[s % N_CHUNKS];
+          if (!deflate_stream(c.out.p, c.out_len, c.comp, c.comp_size, c.packed, &c.packed_len, c.out.pinned)) { fail("deflate failed"); return; }
+          busy[3] += since(t0);
+          leave(3);
+        }
+      } catch (const std::exception& ex) { fail(ex.what()); }
+    });
+
+    std::thread t_write([&] {
+      try {
+        auto put = [&](const uint8_t* p, size_t n) { if (n && fwrite(p, 1, n, fout) != n) throw std::runtime_error("write failed"); out_file_bytes += n; };
+        {
+          HostBuf hc, hp; std::vector<uint32_t> hs;
+          uint64_t hl = 0;
+          if (out_header_len) {
+            if (!deflate_stream(out_header, out_header_len, hc, hs, hp, &hl, false)) { fail("deflate failed"); return; }
+            put(hp.p, hl);
+          }
+        }
+        for (uint64_t s = 0;; s++) {
+          if (!enter(4, s)) break;
+          const auto t0 = Clock::now();
+          Chunk& c = chunks[s % N_CHUNKS];
+          put(c.packed.p, c.packed_len);
+          busy[4] += since(t0);
+          leave(4);
+        }
+        static const uint8_t EOF_BLOCK[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (!failed) put(EOF_BLOCK, 28);
+      } catch (const std::exception& ex) { fail(ex.what()); }
+    });
+
+    t_read.join(); t_inflate.join(); t_middle.join(); t_deflate.join(); t_write.join();
+    if (file) munmap((void*)file, file_len);
+    close(fd);
+    if (fclose(fout) != 0 && !failed) { failed = true; err = "closing the output file failed"; }
+    return failed ? 1 : 0;
+  }
+};
+
+// size of the BAM header at the start of an uncompressed stream, or 0 when the data does not hold all of it
+uint64_t bam_header_size(const uint8_t* p, uint64_t n) {
+  if (n < 12 || memcmp(p, "BAM\1", 4) != 0) return 0;
+  uint32_t l_text;
+  memcpy(&l_text, p + 4, 4);
+  uint64_t o = 8ull + l_text;
+  if (o + 4 > n) return 0;
+  uint32_t n_ref;
+  memcpy(&n_ref, p + o, 4);
+  o += 4;
+  for (uint32_t i = 0; i < n_ref; i++) {
+    if (o + 4 > n) return 0;
+    uint32_t l_name;
+    memcpy(&l_name, p + o, 4);
+    o += 8ull + l_name;
+    if (o > n) return 0;
+  }
+  return o;
+}
+
+thread_local std::string t_perr;
+
+// what fgx_run_bam keeps between runs: the pinned chunk buffers and the device buffers (allocating 3 x ~1 GB of pinned memory takes
+// longer than a whole chunk's work)
+struct PipeState {
+  Pipeline P;
+  fgx::DevBuf D[2], d_off, d_len, d_koff, d_klen, d_grp;
+};
+
+}  // namespace
+
+namespace fgx {
+void pipeline_release(fgx_caller* c) {
+  if (!c || !c->pipe_state) return;
+  PipeState* S = (PipeState*)c->pipe_state;
+  for (auto* b : {&S->D[0], &S->D[1], &S->d_off, &S->d_len, &S->d_koff, &S->d_klen, &S->d_grp}) b->free_();
+  delete S;
+  c->pipe_state = nullptr;
+}
+}  // namespace fgx
+
+extern "C" {
+
+// reader / inflate / deflate / writer around an identity middle stage: re-blocks a BGZF file (no device needed)
+int fgx_bgzf_recompress_file(const char* in_path, const char* out_path, uint32_t threads, int level, uint64_t chunk_raw_bytes, uint64_t* inflated_bytes) {
+  if (!in_path || !out_path) { t_perr = "fgx_bgzf_recompress_file: null argument"; return 1; }
+  auto P = std::make_unique<Pipeline>();
+  const int rc = P->run(in_path, out_path, nullptr, 0, threads, level, chunk_raw_bytes ? chunk_raw_bytes : (64ull << 20), false, [&](Chunk& c, uint64_t) {
+    c.out.reserve(c.inf_len + 64, false);
+    memcpy(c.out.p, c.inf.p, c.inf_len);
+    c.out_len = c.inf_len;
+  });
+  if (inflated_bytes) *inflated_bytes = P->inflated_bytes;
+  if (rc != 0) t_perr = P->err;
+  return rc;
+}
+const char* fgx_pipeline_last_error(void) { return t_perr.c_str(); }
+
+int fgx_run_bam(fgx_caller* c, const char* in_path, const char* out_path, const uint8_t* out_header, uint64_t out_header_len,
+                const fgx_group_options* g, uint32_t threads, int level, uint64_t chunk_raw_bytes, fgx_bam_run_stats* st) {
+  if (!c || !in_path || !out_path || !g || !st) return 1;
+  c->err.clear();
+  memset(st, 0, sizeof(*st));
+  const auto t_begin = Clock::now();
+  try {
+    fgx::hip_check(hipSetDevice(c->device), "hipSetDevice");
+    hipStream_t s = c->stream;
+    if (!c->pipe_state) c->pipe_state = new PipeState();
+    PipeState* S = (PipeState*)c->pipe_state;
+    fgx::DevBuf* D = S->D;
+    fgx::DevBuf &d_off = S->d_off, &d_len = S->d_len, &d_koff = S->d_koff, &d_klen = S->d_klen, &d_grp = S->d_grp;
+    uint64_t left_len = 0;                 // bytes the previous chunk left at the front of D[cur]
+    int cur = 0;
+    bool header_done = false;
+    double sec_h2d = 0, sec_bound = 0, sec_group = 0, sec_cons = 0, sec_d2h = 0;
+    std::vector<uint8_t> h_blob; std::vector<uint64_t> h_off; std::vector<uint32_t> h_len, h_grp;   // (only for chunks with deferred families)
+    Pipeline* P = &S->P;
+    P->reset();
+    const int rc = P->run(in_path, out_path, out_header, out_header_len, threads, level, chunk_raw_bytes ? chunk_raw_bytes : (256ull << 20), true,
+                          [&](Chunk& ch, uint64_t seq) {
+      fgx::hip_check(hipSetDevice(c->device), "hipSetDevice");
+      ch.out_len = 0;
+      uint64_t start = 0;
+      const uint8_t* src = ch.inf.p;
+      uint64_t src_len = ch.inf_len;
+      if (!header_done) {
+        const uint64_t h = bam_header_size(src, src_len);
+        if (h == 0) {
+          if (ch.last && src_len == 0) return;                 // an empty file
+          throw std::runtime_error("the first chunk does not hold the whole BAM header (not a BAM file, or chunk_raw_bytes too small)");
+        }
+        src += h; src_len -= h;
+        header_done = true;
+      }
+      const uint64_t total = left_len + src_len;
+      if (total + 64 > D[cur].cap) {                           // grow, keeping what the previous chunk left at the front
+        fgx::DevBuf bigger;
+        bigger.reserve(total + total / 4 + 64);
+        if (left_len) fgx::hip_check(hipMemcpy(bigger.p, D[cur].p, left_len, hipMemcpyDeviceToDevice), "D2D leftover");
+        D[cur].free_();
+        D[cur] = bigger;
+      }
+      auto t0 = Clock::now();
+      if (src_len) fgx::hip_check(hipMemcpyAsync((uint8_t*)D[cur].p + left_len, src, src_len, hipMemcpyHostToDevice, s), "H2D chunk");
+      fgx::hip_check(hipStreamSynchronize(s), "sync");
+      sec_h2d += since(t0);
+      // ---- record boundaries ----
+      t0 = Clock::now();
+      uint64_t n_rec = 0, consumed = 0;
+      const uint64_t cap_guess = total / 64 + 16;              // (a record is at least 36 bytes; typical libraries: 200 - 400)
+      d_off.reserve(cap_guess * 8); d_len.reserve(cap_guess * 4);
+      int brc = fgx::record_boundaries_device(c, D[cur].as<uint8_t>(), total, start, d_off.as<uint64_t>(), d_len.as<uint32_t>(), cap_guess, &n_rec, &consumed);
+      if (brc == 2) {
+        d_off.reserve(n_rec * 8 + 64); d_len.reserve(n_rec * 4 + 64);
+        brc = fgx::record_boundaries_device(c, D[cur].as<uint8_t>(), total, start, d_off.as<uint64_t>(), d_len.as<uint32_t>(), n_rec, &n_rec, &consumed);
+      }
+      if (brc != 0) throw std::runtime_error(c->err);
+      st->boundary_repair_rounds += c->last_boundary_rounds;
+      sec_bound += since(t0);
+      if (ch.last && consumed != total) throw std::runtime_error("the BAM stream ends inside a record");
+      if (n_rec > 0xFFFFFFFFull) throw std::runtime_error("more than 2^32 records in one chunk: lower chunk_raw_bytes");
+      // ---- MI groups ----
+      t0 = Clock::now();
+      uint32_t n_kept = 0, n_grp = 0;
+      d_koff.reserve(n_rec * 8 + 64); d_klen.reserve(n_rec * 4 + 64); d_grp.reserve((n_rec + 2) * 4);
+      if (n_rec) {
+        const int grc = fgx::group_records_device(c, g, D[cur].as<uint8_t>(), total, d_off.as<uint64_t>(), d_len.as<uint32_t>(), (uint32_t)n_rec,
+                                                  d_koff.as<uint64_t>(), d_klen.as<uint32_t>(), d_grp.as<uint32_t>(), &n_kept, &n_grp);
+        if (grc != 0) throw std::runtime_error(c->err);
+      }
+      sec_group += since(t0);
+      // the last group may continue in the next chunk: it stays behind (with whatever follows it), unless this is the end of the file
+      uint32_t batch_grp = n_grp, batch_rec = n_kept;
+      uint64_t batch_end = consumed;                           // bytes of D[cur] the batch covers
+      if (!ch.last) {
+        if (n_grp >= 1) {
+          uint32_t first_of_last = 0;
+          fgx::hip_check(hipMemcpy(&first_of_last, d_grp.as<uint32_t>() + (n_grp - 1), 4, hipMemcpyDeviceToHost), "D2H");
+          uint64_t o = 0;
+          fgx::hip_check(hipMemcpy(&o, d_koff.as<uint64_t>() + first_of_last, 8, hipMemcpyDeviceToHost), "D2H");
+          batch_grp = n_grp - 1; batch_rec = first_of_last; batch_end = o - 4;
+        } else { batch_grp = 0; batch_rec = 0; batch_end = 0; }
+      }
+      // ---- consensus ----
+      t0 = Clock::now();
+      if (batch_grp) {
+        fgx_output out;
+        memset(&out, 0, sizeof(out));
+        uint32_t n_def = 0;
+        const void* d_def = nullptr;
+        int prc = fgx_process_batch_device(c, D[cur].p, batch_end, d_koff.p, d_klen.p, batch_rec, d_grp.p, batch_grp, &out, &n_def, &d_def);
+        if (prc != 0) throw std::runtime_error(c->err);
+        if (n_def == 0) {
+          sec_cons += since(t0);
+          t0 = Clock::now();
+          ch.out.reserve(out.data_len + 64, true);
+          if (out.data_len) fgx::hip_check(hipMemcpy(ch.out.p, out.data, out.data_len, hipMemcpyDeviceToHost), "D2H records");
+          ch.out_len = out.data_len;
+          sec_d2h += since(t0);
+        } else {
+          // families the device pipelines do not decide: the whole batch through the host entry (it splices both paths in group order)
+          st->deferred_groups += n_def;
+          h_blob.resize(batch_end + 16); h_off.resize(batch_rec); h_len.resize(batch_rec); h_grp.resize((size_t)batch_grp + 1);
+          fgx::hip_check(hipMemcpy(h_blob.data(), D[cur].p, batch_end, hipMemcpyDeviceToHost), "D2H");
+          fgx::hip_check(hipMemcpy(h_off.data(), d_koff.p, (size_t)batch_rec * 8, hipMemcpyDeviceToHost), "D2H");
+          fgx::hip_check(hipMemcpy(h_len.data(), d_klen.p, (size_t)batch_rec * 4, hipMemcpyDeviceToHost), "D2H");
+          fgx::hip_check(hipMemcpy(h_grp.data(), d_grp.p, ((size_t)batch_grp + 1) * 4, hipMemcpyDeviceToHost), "D2H");
+          memset(&out, 0, sizeof(out));
+          prc = fgx_process_batch(c, h_blob.data(), batch_end, h_off.data(), h_len.data(), batch_rec, h_grp.data(), batch_grp, &out);
+          if (prc != 0) throw std::runtime_error(c->err);
+          ch.out.reserve(out.data_len + 64, true);
+          if (out.data_len) memcpy(ch.out.p, out.data, out.data_len);
+          ch.out_len = out.data_len;
+          sec_cons += since(t0);
+        }
+        for (int i = 0; i < FGX_STATS_LEN; i++) st->stats[i] += out.stats[i];
+        st->consensus_records += out.count;
+        st->groups += batch_grp;
+        st->kept_records += batch_rec;
+      }
+      // ---- what stays behind moves to the front of the other buffer ----
+      const uint64_t keep = total - batch_end;
+      D[cur ^ 1].reserve(keep + ch.inf_len + ch.inf_len / 4 + 64);   // (room for a next chunk of this one's size: no regrowth in the steady state)
+      if (keep) fgx::hip_check(hipMemcpyAsync(D[cur ^ 1].p, (const uint8_t*)D[cur].p + batch_end, keep, hipMemcpyDeviceToDevice, s), "D2D leftover");
+      fgx::hip_check(hipStreamSynchronize(s), "sync");
+      left_len = keep; cur ^= 1;
+      st->chunks = seq + 1;
+    });
+    st->in_bytes = P->in_bytes; st->inflated_bytes = P->inflated_bytes; st->out_bytes = P->out_bytes; st->out_file_bytes = P->out_file_bytes;
+    st->seconds_read = P->busy[0]; st->seconds_inflate = P->busy[1]; st->seconds_device = P->busy[2]; st->seconds_deflate = P->busy[3]; st->seconds_write = P->busy[4];
+    st->seconds_h2d = sec_h2d; st->seconds_boundaries = sec_bound; st->seconds_grouping = sec_group; st->seconds_consensus = sec_cons; st->seconds_d2h = sec_d2h;
+    st->seconds_total = since(t_begin);
+    if (rc != 0) { c->err = P->err; return 1; }
+    return 0;
+  } catch (const std::exception& ex) { c->err = ex.what(); return 3; }
+}
+
+}  // extern "C"

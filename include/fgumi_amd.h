@@ -275,6 +275,38 @@ const char* fgx_bgzf_last_error(void);
 int fgx_record_boundaries(const uint8_t* stream, uint64_t stream_len, uint64_t start, uint64_t* rec_off, uint32_t* rec_len,
                           uint64_t cap, uint64_t* n_rec);
 
+/* FindBoundaries with the stream resident in HBM (fgumi_amd/csrc/boundaries.hip): the same chain, found by a thread per 16 KiB
+ * segment — each proposes where its first record starts, walks on from there, and the walks are checked against each other
+ * from the (given) first record on until the table is exactly the sequential walk's.  A record that does not end inside the
+ * stream is NOT an error here (streaming: it continues in the next chunk): *consumed = the offset just past the last whole
+ * record.  Returns 0; 1 = a record with block_size < 32 (fgx_last_error); 2 = `cap` too small (*n_rec = records present;
+ * cap = 0 with null arrays just counts). */
+int fgx_record_boundaries_device(fgx_caller* c, const void* d_stream, uint64_t stream_len, uint64_t start, void* d_rec_off,
+                                 void* d_rec_len, uint64_t cap, uint64_t* n_rec, uint64_t* consumed);
+
+/* A BAM file in, a consensus BAM file out (fgumi_amd/csrc/pipeline.cpp): read -> BGZF inflate (worker pool, pinned buffers) ->
+ * upload -> record boundaries -> MI grouping -> consensus batch -> download -> BGZF deflate -> write, as five overlapping stages
+ * over chunks of `chunk_raw_bytes` compressed bytes (0 = 256 MiB).  Stands in, for this path, for the reader / FindBoundaries /
+ * group / process / compress / write steps of src/lib/unified_pipeline/bam.rs around `process_fn`.  `out_header` = the
+ * uncompressed BAM header of the output ("BAM\1", l_text, text, n_ref = 0): written as its own BGZF block(s).  A group that
+ * reaches the end of a chunk waits for the next chunk (it may continue there).  `threads` = pool size (0 = all cores).
+ * Returns 0, or non-zero with fgx_last_error(c). */
+typedef struct fgx_bam_run_stats {
+  uint64_t kept_records, groups, consensus_records, deferred_groups, chunks;
+  uint64_t in_bytes, inflated_bytes, out_bytes, out_file_bytes;
+  uint64_t stats[FGX_STATS_LEN];
+  double seconds_total;
+  double seconds_read, seconds_inflate, seconds_device, seconds_deflate, seconds_write;     /* busy time of the five stage threads */
+  double seconds_h2d, seconds_boundaries, seconds_grouping, seconds_consensus, seconds_d2h; /* inside the device stage */
+  uint32_t boundary_repair_rounds, _pad;
+} fgx_bam_run_stats;
+int fgx_run_bam(fgx_caller* c, const char* in_path, const char* out_path, const uint8_t* out_header, uint64_t out_header_len,
+                const fgx_group_options* g, uint32_t threads, int level, uint64_t chunk_raw_bytes, fgx_bam_run_stats* st);
+/* The host stages alone (read, inflate, deflate, write) around a copy: re-blocks a BGZF file; needs no device. */
+int fgx_bgzf_recompress_file(const char* in_path, const char* out_path, uint32_t threads, int level, uint64_t chunk_raw_bytes,
+                             uint64_t* inflated_bytes);
+const char* fgx_pipeline_last_error(void);
+
 /* Sizes for a parameter set: total blob bytes (records WITH block_size prefixes) and record count. */
 int fgx_sim_sizes(const fgx_sim_params* p, uint64_t* blob_len, uint64_t* n_rec);
 /* Record bytes of each of the p->n_families simulated families (what a reader would weigh a family by when it cuts the

@@ -139,3 +139,23 @@ def test_block_table_refuses_a_subfield_that_overruns_xlen():
     blk[10] = 4                       # XLEN now ends right behind the subfield HEADER
     with pytest.raises(ValueError):
         bgzf.bgzf_block_table(bytes(blk))
+
+
+def test_streaming_host_stages_reblock_a_bam_file(tmp_path):
+    """fgx_bgzf_recompress_file = the reader / inflate / deflate / writer stages of the streaming pipeline around a copy: what
+    comes out must inflate to the same bytes, for chunk sizes that cut the file inside BGZF blocks."""
+    g = simulate_grouped_reads(300, family_size=4)
+    src, dst = str(tmp_path / "in.bam"), str(tmp_path / "out.bam")
+    refs = [("chr1", 1000000)]
+    bgzf.write_bam(src, bgzf.grouped_input_header(refs), refs, g.blob)
+    want = bgzf.bgzf_decompress(open(src, "rb").read())
+    for chunk in (0, 1 << 16):
+        n = bgzf.recompress_file(src, dst, level=1, threads=3, chunk_raw_bytes=chunk)
+        raw = open(dst, "rb").read()
+        assert raw[-28:] == bgzf.BGZF_EOF and n == len(want)
+        assert bgzf.bgzf_decompress(raw) == want
+    with open(src, "rb") as f:
+        cut = f.read()[:-40]
+    open(src, "wb").write(cut)
+    with pytest.raises(ValueError):
+        bgzf.recompress_file(src, dst)

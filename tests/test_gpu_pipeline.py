@@ -1,0 +1,133 @@
+"""GPU parity of the input side: FindBoundaries on the device against the sequential chain walk, and the
+streaming pipeline BAM file -> consensus BAM file against the oracle run over the same records."""
+import ctypes as C
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import bamutil
+import fgx_opts
+import orc
+from fgumi_amd import (CodecConsensusCaller, CodecConsensusOptions, DuplexConsensusCaller, VanillaUmiConsensusCaller, VanillaUmiConsensusOptions, bgzf,
+                       lib, simulate_grouped_reads)
+
+pytestmark = pytest.mark.gpu
+
+
+def _caller():
+    return VanillaUmiConsensusCaller("", "A", VanillaUmiConsensusOptions(min_reads=1, min_consensus_base_quality=2, cell_tag="CB"), overlapping_consensus=True)
+
+
+def _device_boundaries(c, stream: bytes, start: int):
+    """fgx_record_boundaries_device over `stream` uploaded to HBM: (rec_off, rec_len, consumed, repair rounds are in the caller)."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    d = torch.frombuffer(bytearray(stream) + bytearray(64), dtype=torch.uint8).to(dev)
+    n, used = C.c_uint64(), C.c_uint64()
+    rc = lib.fgx_record_boundaries_device(c._h, d.data_ptr(), len(stream), start, None, None, 0, C.byref(n), C.byref(used))   # count
+    assert rc == 0, lib.fgx_last_error(c._h)
+    off = torch.empty(max(1, n.value), dtype=torch.int64, device=dev)
+    ln = torch.empty(max(1, n.value), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    n2 = C.c_uint64()
+    rc = lib.fgx_record_boundaries_device(c._h, d.data_ptr(), len(stream), start, off.data_ptr(), ln.data_ptr(), n.value, C.byref(n2), C.byref(used))
+    assert rc == 0 and n2.value == n.value
+    return off[:n.value].cpu().numpy().astype(np.uint64), ln[:n.value].cpu().numpy().astype(np.uint32), used.value
+
+
+def _host_chain(stream: bytes, start: int):
+    offs, lens, p = [], [], start
+    while p + 4 <= len(stream):
+        bs = int.from_bytes(stream[p:p + 4], "little")
+        if p + 4 + bs > len(stream):
+            break
+        offs.append(p + 4); lens.append(bs)
+        p += 4 + bs
+    return np.asarray(offs, dtype=np.uint64), np.asarray(lens, dtype=np.uint32), p
+
+
+def test_device_boundaries_equal_the_sequential_chain():
+    c = _caller()
+    g = simulate_grouped_reads(3000, family_size=2, family_size_max=9)
+    stream = bytes(g.blob[:int(g.rec_off[-1]) + int(g.rec_len[-1])])
+    # the whole stream; behind a "header" of 1237 bytes; cut inside a record, inside a block_size prefix, and right at a record's end
+    for prefix, cut in ((0, 0), (1237, 0), (0, 100), (0, int(g.rec_len[-1]) + 2), (5, int(g.rec_len[-1]) + 4)):
+        s = bytes(prefix) + (stream[:len(stream) - cut] if cut else stream)
+        off, ln, used = _device_boundaries(c, s, prefix)
+        woff, wln, wused = _host_chain(s, prefix)
+        assert np.array_equal(off, woff) and np.array_equal(ln, wln) and used == wused
+    c.close()
+
+
+def test_device_boundaries_with_records_longer_than_a_segment_and_record_like_payloads():
+    """Segments without any record start (records of 40 KB), and payload bytes that look like record headers: the walks are checked
+    against each other, so a wrong guess costs a repair round and nothing else."""
+    rng = random.Random(11)
+    recs = []
+    fake = bamutil.make_record("fake", "ACGT" * 10, [30] * 40, flag=0x4, ref_id=-1, pos=-1)
+    fake = len(fake).to_bytes(4, "little") + fake
+    for i in range(400):
+        L = 30000 if i % 37 == 5 else rng.choice([50, 150, 151, 300])
+        seq = "".join(rng.choice("ACGT") for _ in range(L))
+        tags = [("MI", "Z", str(i // 4))]
+        if i % 11 == 3:                                   # a B:C array whose bytes are three whole fake records
+            tags.append(("zz", "raw", b"BC" + (3 * len(fake)).to_bytes(4, "little") + fake * 3))
+        recs.append(bamutil.make_record("r%05d" % i, seq, [rng.randrange(2, 41) for _ in range(L)], flag=0x4D, ref_id=0, pos=100 + i, tags=tags))
+    stream = b"".join(len(r).to_bytes(4, "little") + r for r in recs)
+    c = _caller()
+    off, ln, used = _device_boundaries(c, stream, 0)
+    woff, wln, wused = _host_chain(stream, 0)
+    assert np.array_equal(off, woff) and np.array_equal(ln, wln) and used == wused == len(stream)
+    c.close()
+
+
+def _run_and_compare(tmp_path, caller, opts, g, batch_groups, chunk, **run_kw):
+    refs = [("chr%d" % (i + 1), 2147483647) for i in range(24)]
+    src, dst = str(tmp_path / "grouped.bam"), str(tmp_path / "consensus.bam")
+    bgzf.write_bam(src, bgzf.grouped_input_header(refs), refs, g.blob)
+    st = caller.run_bam(src, dst, chunk_raw_bytes=chunk, threads=8, **run_kw)
+    want = orc.process(opts, g.blob, g.rec_off, g.rec_len, g.grp_first, batch_groups=batch_groups)
+    text, orefs, stream, off, ln = bgzf.read_bam(dst)
+    got = b"".join(bytes(stream[int(o) - 4:int(o) + int(l)]) for o, l in zip(off, ln))
+    assert text.startswith("@HD\tVN:1.6\tSO:unsorted\tGO:query") and orefs == []
+    assert st["consensus_records"] == want["count"] == len(off)
+    assert got == want["data"], "the consensus BAM's records differ from the oracle's"
+    assert st["stats"][:len(want["stats"])] == [int(v) for v in want["stats"]]
+    assert st["groups"] == len(g.grp_first) - 1 and st["kept_records"] == g.n_rec
+    return st
+
+
+def test_bam_file_to_consensus_bam_file_simplex(tmp_path):
+    g = simulate_grouped_reads(6000, family_size=2, family_size_max=12)
+    c = _caller()
+    one = _run_and_compare(tmp_path, c, fgx_opts.defaults(min_reads=1), g, 50, 0)               # one chunk
+    many = _run_and_compare(tmp_path, c, fgx_opts.defaults(min_reads=1), g, 50, 1 << 16)        # 64 KiB of compressed bytes per chunk: groups cross chunks
+    assert one["chunks"] == 1 and many["chunks"] > 20
+    c.close()
+
+
+def test_bam_file_to_consensus_bam_file_duplex_and_codec(tmp_path):
+    g = simulate_grouped_reads(1500, family_size=6, duplex=1)
+    o = fgx_opts.defaults(kind=1)
+    o.duplex_min_reads[0], o.duplex_min_reads[1], o.duplex_min_reads[2] = 1, 1, 0
+    c = DuplexConsensusCaller("", "A", [1, 1, 0], cell_tag="CB", overlapping_consensus=True)
+    _run_and_compare(tmp_path, c, o, g, 100, 1 << 17, strip_strand_suffix=True)
+    c.close()
+    g = simulate_grouped_reads(800, family_size=3, read_length=300, insert_mean=350, insert_sd=60, codec=1)
+    o = fgx_opts.defaults(kind=2, overlapping_consensus=0, cell_tag=b"\0\0", produce_per_base_tags=1)
+    c = CodecConsensusCaller("", "A", CodecConsensusOptions(produce_per_base_tags=True))
+    _run_and_compare(tmp_path, c, o, g, 1000, 1 << 17, cell_tag=None)
+    c.close()
+
+
+def test_run_bam_reports_a_truncated_file(tmp_path):
+    g = simulate_grouped_reads(200, family_size=3)
+    refs = [("chr1", 1000000)]
+    src = str(tmp_path / "in.bam")
+    bgzf.write_bam(src, bgzf.grouped_input_header(refs), refs, g.blob[:len(g.blob) - 37])    # the stream ends inside the last record
+    c = _caller()
+    with pytest.raises(RuntimeError, match="ends inside a record"):
+        c.run_bam(src, str(tmp_path / "out.bam"))
+    c.close()
