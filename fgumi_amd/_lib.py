@@ -72,7 +72,8 @@ class BamRunStats(C.Structure):
                 ("out_file_bytes", C.c_uint64), ("stats", C.c_uint64 * 28), ("seconds_total", C.c_double),
                 ("seconds_read", C.c_double), ("seconds_inflate", C.c_double), ("seconds_device", C.c_double), ("seconds_deflate", C.c_double),
                 ("seconds_write", C.c_double), ("seconds_h2d", C.c_double), ("seconds_boundaries", C.c_double), ("seconds_grouping", C.c_double),
-                ("seconds_consensus", C.c_double), ("seconds_d2h", C.c_double), ("boundary_repair_rounds", C.c_uint32), ("_pad", C.c_uint32)]
+                ("seconds_consensus", C.c_double), ("seconds_d2h", C.c_double), ("seconds_device_inflate", C.c_double),
+                ("boundary_repair_rounds", C.c_uint32), ("device_inflate", C.c_uint32)]
 
 
 EXPORTS = ["fgx_options_default", "fgx_create", "fgx_destroy", "fgx_last_error", "fgx_global_error", "fgx_process_batch",
@@ -80,7 +81,7 @@ EXPORTS = ["fgx_options_default", "fgx_create", "fgx_destroy", "fgx_last_error",
            "fgx_bgzf_inflate", "fgx_bgzf_deflate", "fgx_bgzf_free", "fgx_bgzf_last_error",
            "fgx_sim_generate_host", "fgx_sim_generate_device", "fgx_group_records", "fgx_group_records_device", "fgx_filter_options_default",
            "fgx_filter_records", "fgx_filter_records_device", "fgx_filter_last_output_device",
-           "fgx_record_boundaries_device", "fgx_run_bam", "fgx_bgzf_recompress_file", "fgx_pipeline_last_error"]
+           "fgx_record_boundaries_device", "fgx_inflate_block_host", "fgx_run_bam", "fgx_bgzf_recompress_file", "fgx_pipeline_last_error"]
 
 _lib = None
 
@@ -149,7 +150,7 @@ def load():
     L.fgx_group_records_device.restype = I
     L.fgx_record_boundaries_device.argtypes = [VP, VP, U64, U64, VP, VP, U64, P(U64), P(U64)]
     L.fgx_record_boundaries_device.restype = I
-    L.fgx_run_bam.argtypes = [VP, C.c_char_p, C.c_char_p, VP, U64, P(GroupOptions), U32, I, U64, P(BamRunStats)]
+    L.fgx_run_bam.argtypes = [VP, C.c_char_p, C.c_char_p, VP, U64, P(GroupOptions), U32, I, U64, U32, P(BamRunStats)]
     L.fgx_run_bam.restype = I
     L.fgx_bgzf_recompress_file.argtypes = [C.c_char_p, C.c_char_p, U32, I, U64, P(U64)]
     L.fgx_bgzf_recompress_file.restype = I

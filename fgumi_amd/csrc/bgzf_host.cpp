@@ -12,6 +12,7 @@
 #include <thread>
 #include <vector>
 #include "../../include/fgumi_amd.h"
+#include "inflate_core.h"
 
 namespace {
 constexpr uint32_t BGZF_PAYLOAD = 0xFF00;     // uncompressed bytes per block (htslib / noodles / fgumi-bgzf)
@@ -84,6 +85,33 @@ int fgx_bgzf_inflate(const uint8_t* raw, uint64_t raw_len, uint32_t threads, uin
   if (bad) { free(dst); t_err = "BGZF block failed to inflate or its CRC32 / ISIZE does not match"; return 1; }
   *out = dst; *out_len = total;
   return 0;
+}
+
+// the device's DEFLATE decoder (inflate_core.h) run on the host: the same source, for the CPU tests.  `in` must be readable for
+// 8 bytes past in_len.  Returns its status (0 = ok) and the CRC-32 of the output computed with the device's fold (slices of 1/64).
+int fgx_inflate_block_host(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, uint32_t* crc_out) {
+  static thread_local fgx::InflateTables T;
+  const int st = fgx::inflate_block(in, in_len, out, out_len, T);
+  if (crc_out) {
+    uint32_t tab[256];
+    for (uint32_t i = 0; i < 256; i++) tab[i] = fgx::crc32_table_entry(i);
+    uint32_t lane_crc[64];
+    const uint32_t S = (out_len + 63u) / 64u;
+    for (uint32_t lane = 0; lane < 64; lane++) {
+      const int64_t hi_s = (int64_t)out_len - (int64_t)(63u - lane) * S, lo_s = hi_s - (int64_t)S;
+      const uint32_t hi = hi_s > 0 ? (uint32_t)hi_s : 0u, lo = lo_s > 0 ? (uint32_t)lo_s : 0u;
+      uint32_t crc = 0;
+      if (hi > lo) { crc = 0xFFFFFFFFu; for (uint32_t i = lo; i < hi; i++) crc = tab[(crc ^ out[i]) & 0xFFu] ^ (crc >> 8); crc ^= 0xFFFFFFFFu; }
+      lane_crc[lane] = crc;
+    }
+    uint32_t op = out_len ? fgx::crc32_shift_op(S) : 0u;
+    for (uint32_t step = 1; step < 64; step <<= 1) {
+      for (uint32_t lane = 0; lane < 64; lane += 2 * step) lane_crc[lane] = fgx::crc32_multmodp(op, lane_crc[lane]) ^ lane_crc[lane + step];
+      op = fgx::crc32_multmodp(op, op);
+    }
+    *crc_out = out_len ? lane_crc[0] : 0u;
+  }
+  return st;
 }
 
 int fgx_bgzf_deflate(const uint8_t* in, uint64_t len, int level, uint32_t threads, int with_eof, uint8_t** out, uint64_t* out_len) {

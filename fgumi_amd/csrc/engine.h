@@ -144,6 +144,9 @@ int group_records_device(fgx_caller* c, const fgx_group_options* o, const uint8_
 // boundaries.hip — FindBoundaries on the device
 int record_boundaries_device(fgx_caller* c, const uint8_t* d_stream, uint64_t len, uint64_t start, uint64_t* d_rec_off, uint32_t* d_rec_len,
                              uint64_t cap, uint64_t* n_rec, uint64_t* consumed);
+// bgzf_device.hip — BGZF inflate on the device: one descriptor per block (offsets into the compressed bytes / the inflated stream)
+struct BgzfDevBlock { uint64_t in_off, out_off; uint32_t in_len, isize, crc, _pad; };   // in_off / in_len: the raw DEFLATE payload
+int bgzf_inflate_device(fgx_caller* c, const uint8_t* d_raw, const BgzfDevBlock* d_blk, uint32_t n, uint8_t* d_out, uint32_t* d_status);
 // pipeline.cpp — frees what fgx_run_bam keeps in c->pipe_state
 void pipeline_release(fgx_caller* c);
 // filter.hip — `fgumi filter` on the device

@@ -1,0 +1,226 @@
+// inflate_core.h — a raw DEFLATE (RFC 1951) decoder for ONE BGZF block, written to run as one GPU lane per block (and, the same
+// source, on the host for its unit tests).  It stands in, on the device, for what crates/fgumi-bgzf/src/reader.rs:346-479
+// (`decompress_block*`) asks libdeflater to do.  A BGZF block is at most 64 KiB either way, so everything is 32-bit.
+//
+// Shape: a 64-bit bit buffer refilled with one unaligned 8-byte load (the input buffer must be READABLE 8 bytes past its end);
+// literal / length and distance codes through small first-level tables (9 and 7 bits: 1.25 KB) with the canonical bit-by-bit
+// walk (count[] / symbol[]) for the rare longer codes — the whole per-block state is 2 KB, so sixteen lanes of a wavefront keep
+// theirs in LDS; output bytes go straight to the destination (matches are copied from there: the window IS the output).
+#pragma once
+#include <cstdint>
+#include <cstring>
+
+#if defined(__HIPCC__)
+#define FGX_HD __host__ __device__
+#else
+#define FGX_HD
+#endif
+
+namespace fgx {
+
+struct InflateTables {
+  uint16_t lit_fast[512];      // 9 peeked bits -> (symbol << 4) | code length; 0 = longer than 9 bits
+  uint16_t dist_fast[128];     // 7 peeked bits
+  uint16_t lit_count[16], dist_count[16];
+  uint16_t lit_sym[288];
+  uint16_t dist_sym[32];
+};
+static_assert(sizeof(InflateTables) == 1024 + 256 + 64 + 576 + 64, "InflateTables is the per-lane LDS slice");
+
+enum InflateStatus : int {
+  INFL_OK = 0, INFL_BAD_BLOCK_TYPE = 1, INFL_BAD_STORED = 2, INFL_BAD_CODE_LENGTHS = 3, INFL_BAD_SYMBOL = 4, INFL_BAD_DISTANCE = 5,
+  INFL_OUTPUT_OVERFLOW = 6, INFL_INPUT_OVERRUN = 7, INFL_SIZE_MISMATCH = 8
+};
+
+struct BitReader {
+  const uint8_t* base; uint32_t len;   // the deflate payload
+  uint32_t pos;                        // next byte to load
+  uint64_t bb; uint32_t bc;            // bit buffer, valid bits
+};
+
+FGX_HD inline uint64_t infl_load64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
+FGX_HD inline void infl_refill(BitReader& r) {       // at least 56 valid bits afterwards (reads up to 8 bytes past the payload)
+  r.bb |= infl_load64(r.base + r.pos) << r.bc;
+  r.pos += (63u - r.bc) >> 3;
+  r.bc |= 56u;
+}
+FGX_HD inline uint32_t infl_bits(BitReader& r, uint32_t n) {   // n <= 16, bc >= n
+  const uint32_t v = (uint32_t)(r.bb & ((1ull << n) - 1ull));
+  r.bb >>= n; r.bc -= n;
+  return v;
+}
+FGX_HD inline uint32_t infl_rev(uint32_t code, uint32_t len) {
+  uint32_t r = 0;
+  for (uint32_t i = 0; i < len; i++) { r = (r << 1) | (code & 1u); code >>= 1; }
+  return r;
+}
+
+// canonical Huffman tables from code lengths (RFC 1951 3.2.2).  Returns false for an over-subscribed set; an incomplete set is
+// allowed only for a single code (the one-distance-code case) — what zlib accepts.
+FGX_HD inline bool infl_build(const uint8_t* lens, uint32_t n, uint16_t* count, uint16_t* sym, uint16_t* fast, uint32_t fast_bits) {
+  for (uint32_t l = 0; l < 16; l++) count[l] = 0;
+  for (uint32_t s = 0; s < n; s++) count[lens[s]]++;
+  for (uint32_t i = 0; i < (1u << fast_bits); i++) fast[i] = 0;
+  if (count[0] == n) return true;                    // no codes at all (legal for the distance set of an all-literal block)
+  int32_t left = 1;
+  for (uint32_t l = 1; l < 16; l++) { left <<= 1; left -= (int32_t)count[l]; if (left < 0) return false; }
+  if (left > 0 && !(n - count[0] == 1 && count[1] == 1)) return false;
+  uint16_t offs[16];
+  offs[1] = 0;
+  for (uint32_t l = 1; l < 15; l++) offs[l + 1] = (uint16_t)(offs[l] + count[l]);
+  for (uint32_t s = 0; s < n; s++) if (lens[s]) sym[offs[lens[s]]++] = (uint16_t)s;
+  // first-level table: every symbol of length <= fast_bits at all the indices whose low bits are its (bit-reversed) code
+  uint32_t code = 0, idx = 0;
+  for (uint32_t l = 1; l <= fast_bits; l++) {
+    for (uint32_t k = 0; k < count[l]; k++, code++, idx++) {
+      const uint32_t r = infl_rev(code, l);
+      const uint16_t e = (uint16_t)((sym[idx] << 4) | l);
+      for (uint32_t hi = 0; hi < (1u << (fast_bits - l)); hi++) fast[r | (hi << l)] = e;
+    }
+    code <<= 1;
+  }
+  return true;
+}
+
+// one symbol: the first-level table, else the canonical walk (puff.c's decode), bit by bit.  Returns the symbol or -1.
+FGX_HD inline int32_t infl_decode(BitReader& r, const uint16_t* fast, uint32_t fast_bits, const uint16_t* count, const uint16_t* sym) {
+  const uint32_t e = fast[(uint32_t)r.bb & ((1u << fast_bits) - 1u)];
+  if (e & 15u) { const uint32_t l = e & 15u; r.bb >>= l; r.bc -= l; return (int32_t)(e >> 4); }
+  int32_t code = 0, first = 0, index = 0;
+  for (uint32_t l = 1; l <= 15; l++) {
+    code |= (int32_t)(r.bb & 1u);
+    r.bb >>= 1; r.bc -= 1;
+    const int32_t cnt = (int32_t)count[l];
+    if (code - cnt < first) return (int32_t)sym[index + (code - first)];
+    index += cnt; first += cnt; first <<= 1; code <<= 1;
+  }
+  return -1;
+}
+
+// inflates `in[0 .. in_len)` into `out[0 .. out_len)`; the stream must produce exactly out_len bytes (the block's ISIZE).
+// `in` must be readable for 8 bytes past in_len.  T: this lane's tables (LDS on the device).
+FGX_HD inline int inflate_block(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, InflateTables& T) {
+  static constexpr uint16_t LEN_BASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+  static constexpr uint8_t LEN_EXTRA[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+  static constexpr uint16_t DIST_BASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+  static constexpr uint8_t DIST_EXTRA[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+  static constexpr uint8_t CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+  BitReader r{in, in_len, 0u, 0ull, 0u};
+  uint32_t pos = 0;
+  for (;;) {
+    infl_refill(r);
+    const uint32_t bfinal = infl_bits(r, 1), btype = infl_bits(r, 2);
+    if (btype == 0) {
+      // stored: back to the byte boundary, LEN, NLEN, bytes
+      const uint32_t drop = r.bc & 7u;
+      r.bb >>= drop; r.bc -= drop;
+      infl_refill(r);
+      const uint32_t len = infl_bits(r, 16), nlen = infl_bits(r, 16);
+      if ((len ^ 0xFFFFu) != nlen) return INFL_BAD_STORED;
+      // the bytes still in the bit buffer belong to the payload: step the byte position back over them
+      const uint32_t src = r.pos - (r.bc >> 3);
+      if (src + len > in_len) return INFL_INPUT_OVERRUN;
+      if (pos + len > out_len) return INFL_OUTPUT_OVERFLOW;
+      for (uint32_t i = 0; i < len; i++) out[pos + i] = in[src + i];
+      pos += len;
+      r.pos = src + len; r.bb = 0; r.bc = 0;
+    } else if (btype == 1 || btype == 2) {
+      uint8_t lens[320];
+      uint32_t hlit, hdist;
+      if (btype == 1) {
+        hlit = 288; hdist = 32;                        // (the fixed distance code is 32 five-bit codes; 30 and 31 never appear in valid data)
+        for (uint32_t s = 0; s < 144; s++) lens[s] = 8;
+        for (uint32_t s = 144; s < 256; s++) lens[s] = 9;
+        for (uint32_t s = 256; s < 280; s++) lens[s] = 7;
+        for (uint32_t s = 280; s < 288; s++) lens[s] = 8;
+        for (uint32_t s = 0; s < 32; s++) lens[288 + s] = 5;
+      } else {
+        hlit = infl_bits(r, 5) + 257; hdist = infl_bits(r, 5) + 1;
+        const uint32_t hclen = infl_bits(r, 4) + 4;
+        if (hlit > 286 || hdist > 30) return INFL_BAD_CODE_LENGTHS;
+        uint8_t cl[19];
+        for (uint32_t i = 0; i < 19; i++) cl[i] = 0;
+        infl_refill(r);
+        for (uint32_t i = 0; i < hclen; i++) { if (r.bc < 3) infl_refill(r); cl[CL_ORDER[i]] = (uint8_t)infl_bits(r, 3); }
+        // the code-length code: its tables live in the distance slots for the moment (19 symbols, up to 7 bits)
+        if (!infl_build(cl, 19, T.dist_count, T.dist_sym, T.dist_fast, 7)) return INFL_BAD_CODE_LENGTHS;
+        uint32_t n = 0;
+        while (n < hlit + hdist) {
+          if (r.bc < 32) infl_refill(r);
+          const int32_t s = infl_decode(r, T.dist_fast, 7, T.dist_count, T.dist_sym);
+          if (s < 0) return INFL_BAD_CODE_LENGTHS;
+          if (s < 16) lens[n++] = (uint8_t)s;
+          else {
+            uint32_t rep, val = 0;
+            if (s == 16) { if (n == 0) return INFL_BAD_CODE_LENGTHS; val = lens[n - 1]; rep = 3 + infl_bits(r, 2); }
+            else if (s == 17) rep = 3 + infl_bits(r, 3);
+            else rep = 11 + infl_bits(r, 7);
+            if (n + rep > hlit + hdist) return INFL_BAD_CODE_LENGTHS;
+            for (uint32_t i = 0; i < rep; i++) lens[n++] = (uint8_t)val;
+          }
+        }
+        if (lens[256] == 0) return INFL_BAD_CODE_LENGTHS;        // no end-of-block code
+      }
+      if (!infl_build(lens, hlit, T.lit_count, T.lit_sym, T.lit_fast, 9)) return INFL_BAD_CODE_LENGTHS;
+      if (!infl_build(lens + hlit, hdist, T.dist_count, T.dist_sym, T.dist_fast, 7)) return INFL_BAD_CODE_LENGTHS;
+      for (;;) {
+        if (r.bc < 48) infl_refill(r);                 // a length + distance pair takes at most 15 + 5 + 15 + 13 = 48 bits
+        int32_t s = infl_decode(r, T.lit_fast, 9, T.lit_count, T.lit_sym);
+        if (s < 0) return INFL_BAD_SYMBOL;
+        if (s < 256) {
+          if (pos >= out_len) return INFL_OUTPUT_OVERFLOW;
+          out[pos++] = (uint8_t)s;
+          continue;
+        }
+        if (s == 256) break;
+        s -= 257;
+        if (s >= 29) return INFL_BAD_SYMBOL;
+        const uint32_t len = LEN_BASE[s] + infl_bits(r, LEN_EXTRA[s]);
+        const int32_t d = infl_decode(r, T.dist_fast, 7, T.dist_count, T.dist_sym);
+        if (d < 0 || d >= 30) return INFL_BAD_DISTANCE;
+        const uint32_t dist = DIST_BASE[d] + infl_bits(r, DIST_EXTRA[d]);
+        if (dist > pos) return INFL_BAD_DISTANCE;
+        if (pos + len > out_len) return INFL_OUTPUT_OVERFLOW;
+        uint8_t* dst = out + pos;
+        const uint8_t* src = dst - dist;
+        uint32_t i = 0;
+        if (dist >= 8) for (; i + 8 <= len; i += 8) { const uint64_t v = infl_load64(src + i); memcpy(dst + i, &v, 8); }   // (no overlap inside a piece)
+        for (; i < len; i++) dst[i] = src[i];
+        pos += len;
+      }
+    } else return INFL_BAD_BLOCK_TYPE;
+    if (r.pos - (r.bc >> 3) > in_len) return INFL_INPUT_OVERRUN;   // bits were taken from beyond the payload
+    if (bfinal) break;
+  }
+  return pos == out_len ? INFL_OK : INFL_SIZE_MISMATCH;
+}
+
+// CRC-32 (IEEE 802.3, reflected, as gzip uses it): the byte-wise table and the pieces of zlib's crc32_combine (multiplication
+// modulo the polynomial) that let 64 lanes check one block together.
+FGX_HD inline uint32_t crc32_table_entry(uint32_t i) {
+  uint32_t c = i;
+  for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+  return c;
+}
+FGX_HD inline uint32_t crc32_multmodp(uint32_t a, uint32_t b) {   // a(x) * b(x) mod p(x), reflected
+  uint32_t p = 0;
+  for (uint32_t m = 1u << 31; m; m >>= 1) {             // (32 steps at most: a == 0 gives 0)
+    if (a & m) { p ^= b; if ((a & (m - 1)) == 0) break; }
+    b = (b & 1u) ? (b >> 1) ^ 0xEDB88320u : b >> 1;
+  }
+  return p;
+}
+// x^(8 n) mod p(x): the operator that moves a CRC past n more bytes
+FGX_HD inline uint32_t crc32_shift_op(uint32_t n_bytes) {
+  uint32_t p = 1u << 31;                 // x^0
+  uint32_t sq = 0x00800000u;             // x^8 (one byte), squared per bit of n
+  uint32_t n = n_bytes;
+  while (n) {
+    if (n & 1u) p = crc32_multmodp(sq, p);
+    sq = crc32_multmodp(sq, sq);
+    n >>= 1;
+  }
+  return p;
+}
+
+}  // namespace fgx

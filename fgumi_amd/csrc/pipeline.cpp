@@ -167,6 +167,9 @@ struct Chunk {
   HostBuf packed;                           // the chunk's BGZF blocks back to back: what the writer writes
   uint64_t packed_len = 0;
   bool last = false;                        // the file's last chunk
+  // device inflate: `inf` holds the chunk's COMPRESSED bytes (staged in pinned memory), `dev_blocks` one descriptor per block
+  std::vector<fgx::BgzfDevBlock> dev_blocks;
+  uint64_t header_size = 0;                 // first chunk: bytes of the BAM header at the start of the inflated stream (0 = not found)
 };
 
 // parses the BSIZE chain of raw[0 .. len): whole blocks into `blocks`; returns the bytes they cover
@@ -199,6 +202,8 @@ size_t block_table(const uint8_t* raw, size_t len, std::vector<Block>& blocks, u
   *inflated = total;
   return p;
 }
+
+uint64_t bam_header_size(const uint8_t* p, uint64_t n);
 
 // the five stages over a ring of chunks; `middle` turns chunk.inf into chunk.out (the device stage, or a copy)
 struct Pipeline {
@@ -241,7 +246,7 @@ struct Pipeline {
   }
 
   int run(const char* in_path, const char* out_path, const uint8_t* out_header, uint64_t out_header_len, unsigned threads, int level,
-          uint64_t raw_chunk, bool pinned, const std::function<void(Chunk&, uint64_t)>& middle) {
+          uint64_t raw_chunk, bool pinned, bool device_inflate, const std::function<void(Chunk&, uint64_t)>& middle) {
     // the input is memory-mapped: the inflate workers read the compressed blocks where the page cache holds them (reading the file
     // into a buffer first was a single-threaded copy of every byte: the slowest stage)
     const int fd = open(in_path, O_RDONLY);
@@ -296,6 +301,50 @@ struct Pipeline {
           if (!enter(1, s)) break;
           const auto t0 = Clock::now();
           Chunk& c = chunks[s % N_CHUNKS];
+          if (device_inflate) {
+            // the blocks are inflated on the device: here the compressed bytes only move into pinned memory (parallel copy), and the
+            // descriptors are written.  The first chunk's leading blocks are inflated here as well, just to measure the BAM header.
+            c.inf.reserve(c.raw_len + 64, pinned);
+            const size_t piece = 1u << 20, np = (c.raw_len + piece - 1) / piece;
+            pool.parallel_for(np, 1, [&](size_t i, unsigned) { const size_t o = i * piece, n = c.raw_len - o < piece ? c.raw_len - o : piece; memcpy(c.inf.p + o, c.raw + o, n); });
+            memset(c.inf.p + c.raw_len, 0, 64);
+            c.dev_blocks.resize(c.blocks.size());
+            for (size_t i = 0; i < c.blocks.size(); i++) {
+              const Block& b = c.blocks[i];
+              const uint32_t xlen = c.raw[b.in_off + 10] | (c.raw[b.in_off + 11] << 8);
+              fgx::BgzfDevBlock d;
+              d.in_off = b.in_off + 12 + xlen; d.out_off = b.out_off; d.in_len = b.in_size - 12 - xlen - 8; d.isize = b.isize;
+              memcpy(&d.crc, c.raw + b.in_off + b.in_size - 8, 4);
+              d._pad = 0;
+              c.dev_blocks[i] = d;
+            }
+            c.header_size = 0;
+            if (s == 0) {
+              std::vector<uint8_t> head;
+              for (size_t i = 0; i < c.blocks.size() && c.header_size == 0; i++) {
+                const Block& b = c.blocks[i];
+                const size_t at = head.size();
+                head.resize(at + b.isize);
+                if (b.isize) {
+                  const uint32_t xlen = c.raw[b.in_off + 10] | (c.raw[b.in_off + 11] << 8);
+                  z_stream z;
+                  memset(&z, 0, sizeof(z));
+                  if (inflateInit2(&z, -15) != Z_OK) { fail("zlib"); break; }
+                  z.next_in = (Bytef*)(c.raw + b.in_off + 12 + xlen); z.avail_in = b.in_size - 12 - xlen - 8;
+                  z.next_out = head.data() + at; z.avail_out = b.isize;
+                  const int rc = inflate(&z, Z_FINISH);
+                  inflateEnd(&z);
+                  if (rc != Z_STREAM_END) { fail("a BGZF block of the header failed to inflate"); break; }
+                }
+                c.header_size = bam_header_size(head.data(), head.size());
+                if (head.size() > (64u << 20)) break;
+              }
+            }
+            inflated_bytes += c.inf_len;
+            busy[1] += since(t0);
+            leave(1);
+            continue;
+          }
           c.inf.reserve(c.inf_len + 64, pinned);
           std::atomic<int> bad(0);
           pool.parallel_for(c.blocks.size(), 8, [&](size_t i, unsigned w) {
@@ -458,7 +507,7 @@ thread_local std::string t_perr;
 // longer than a whole chunk's work)
 struct PipeState {
   Pipeline P;
-  fgx::DevBuf D[2], d_off, d_len, d_koff, d_klen, d_grp;
+  fgx::DevBuf D[2], d_off, d_len, d_koff, d_klen, d_grp, d_raw, d_blk;
 };
 
 }  // namespace
@@ -467,7 +516,7 @@ namespace fgx {
 void pipeline_release(fgx_caller* c) {
   if (!c || !c->pipe_state) return;
   PipeState* S = (PipeState*)c->pipe_state;
-  for (auto* b : {&S->D[0], &S->D[1], &S->d_off, &S->d_len, &S->d_koff, &S->d_klen, &S->d_grp}) b->free_();
+  for (auto* b : {&S->D[0], &S->D[1], &S->d_off, &S->d_len, &S->d_koff, &S->d_klen, &S->d_grp, &S->d_raw, &S->d_blk}) b->free_();
   delete S;
   c->pipe_state = nullptr;
 }
@@ -479,7 +528,7 @@ extern "C" {
 int fgx_bgzf_recompress_file(const char* in_path, const char* out_path, uint32_t threads, int level, uint64_t chunk_raw_bytes, uint64_t* inflated_bytes) {
   if (!in_path || !out_path) { t_perr = "fgx_bgzf_recompress_file: null argument"; return 1; }
   auto P = std::make_unique<Pipeline>();
-  const int rc = P->run(in_path, out_path, nullptr, 0, threads, level, chunk_raw_bytes ? chunk_raw_bytes : (64ull << 20), false, [&](Chunk& c, uint64_t) {
+  const int rc = P->run(in_path, out_path, nullptr, 0, threads, level, chunk_raw_bytes ? chunk_raw_bytes : (64ull << 20), false, false, [&](Chunk& c, uint64_t) {
     c.out.reserve(c.inf_len + 64, false);
     memcpy(c.out.p, c.inf.p, c.inf_len);
     c.out_len = c.inf_len;
@@ -491,7 +540,7 @@ int fgx_bgzf_recompress_file(const char* in_path, const char* out_path, uint32_t
 const char* fgx_pipeline_last_error(void) { return t_perr.c_str(); }
 
 int fgx_run_bam(fgx_caller* c, const char* in_path, const char* out_path, const uint8_t* out_header, uint64_t out_header_len,
-                const fgx_group_options* g, uint32_t threads, int level, uint64_t chunk_raw_bytes, fgx_bam_run_stats* st) {
+                const fgx_group_options* g, uint32_t threads, int level, uint64_t chunk_raw_bytes, uint32_t flags, fgx_bam_run_stats* st) {
   if (!c || !in_path || !out_path || !g || !st) return 1;
   c->err.clear();
   memset(st, 0, sizeof(*st));
@@ -506,24 +555,27 @@ int fgx_run_bam(fgx_caller* c, const char* in_path, const char* out_path, const 
     uint64_t left_len = 0;                 // bytes the previous chunk left at the front of D[cur]
     int cur = 0;
     bool header_done = false;
-    double sec_h2d = 0, sec_bound = 0, sec_group = 0, sec_cons = 0, sec_d2h = 0;
+    double sec_h2d = 0, sec_bound = 0, sec_group = 0, sec_cons = 0, sec_d2h = 0, sec_infl = 0;
+    const bool device_inflate = !(flags & FGX_RUN_HOST_INFLATE);
+    fgx::DevBuf &d_raw = S->d_raw, &d_blk = S->d_blk;
     std::vector<uint8_t> h_blob; std::vector<uint64_t> h_off; std::vector<uint32_t> h_len, h_grp;   // (only for chunks with deferred families)
     Pipeline* P = &S->P;
     P->reset();
-    const int rc = P->run(in_path, out_path, out_header, out_header_len, threads, level, chunk_raw_bytes ? chunk_raw_bytes : (256ull << 20), true,
+    const int rc = P->run(in_path, out_path, out_header, out_header_len, threads, level, chunk_raw_bytes ? chunk_raw_bytes : (256ull << 20), true, device_inflate,
                           [&](Chunk& ch, uint64_t seq) {
       fgx::hip_check(hipSetDevice(c->device), "hipSetDevice");
       ch.out_len = 0;
       uint64_t start = 0;
       const uint8_t* src = ch.inf.p;
-      uint64_t src_len = ch.inf_len;
+      uint64_t src_len = ch.inf_len;                           // inflated bytes this chunk adds
       if (!header_done) {
-        const uint64_t h = bam_header_size(src, src_len);
+        const uint64_t h = device_inflate ? ch.header_size : bam_header_size(src, src_len);
         if (h == 0) {
           if (ch.last && src_len == 0) return;                 // an empty file
           throw std::runtime_error("the first chunk does not hold the whole BAM header (not a BAM file, or chunk_raw_bytes too small)");
         }
-        src += h; src_len -= h;
+        if (device_inflate) start = h;                         // (the header is inflated with the rest and skipped by offset)
+        else { src += h; src_len -= h; }
         header_done = true;
       }
       const uint64_t total = left_len + src_len;
@@ -535,9 +587,25 @@ int fgx_run_bam(fgx_caller* c, const char* in_path, const char* out_path, const 
         D[cur] = bigger;
       }
       auto t0 = Clock::now();
-      if (src_len) fgx::hip_check(hipMemcpyAsync((uint8_t*)D[cur].p + left_len, src, src_len, hipMemcpyHostToDevice, s), "H2D chunk");
-      fgx::hip_check(hipStreamSynchronize(s), "sync");
-      sec_h2d += since(t0);
+      if (device_inflate) {
+        // compressed bytes + block descriptors over PCIe, DEFLATE + CRC-32 on the device, straight behind the leftover
+        d_raw.reserve(ch.raw_len + 64);
+        d_blk.reserve(ch.dev_blocks.size() * sizeof(fgx::BgzfDevBlock) + 64);
+        fgx::hip_check(hipMemcpyAsync(d_raw.p, ch.inf.p, ch.raw_len + 64, hipMemcpyHostToDevice, s), "H2D compressed chunk");
+        if (!ch.dev_blocks.empty())
+          fgx::hip_check(hipMemcpyAsync(d_blk.p, ch.dev_blocks.data(), ch.dev_blocks.size() * sizeof(fgx::BgzfDevBlock), hipMemcpyHostToDevice, s), "H2D block table");
+        fgx::hip_check(hipStreamSynchronize(s), "sync");
+        sec_h2d += since(t0);
+        t0 = Clock::now();
+        if (fgx::bgzf_inflate_device(c, d_raw.as<uint8_t>(), d_blk.as<fgx::BgzfDevBlock>(), (uint32_t)ch.dev_blocks.size(), (uint8_t*)D[cur].p + left_len,
+                                     (uint32_t*)((uint8_t*)d_blk.p + ((ch.dev_blocks.size() * sizeof(fgx::BgzfDevBlock) + 15) & ~(size_t)15))) != 0)
+          throw std::runtime_error(c->err);
+        sec_infl += since(t0);
+      } else {
+        if (src_len) fgx::hip_check(hipMemcpyAsync((uint8_t*)D[cur].p + left_len, src, src_len, hipMemcpyHostToDevice, s), "H2D chunk");
+        fgx::hip_check(hipStreamSynchronize(s), "sync");
+        sec_h2d += since(t0);
+      }
       // ---- record boundaries ----
       t0 = Clock::now();
       uint64_t n_rec = 0, consumed = 0;
@@ -622,6 +690,7 @@ int fgx_run_bam(fgx_caller* c, const char* in_path, const char* out_path, const 
     });
     st->in_bytes = P->in_bytes; st->inflated_bytes = P->inflated_bytes; st->out_bytes = P->out_bytes; st->out_file_bytes = P->out_file_bytes;
     st->seconds_read = P->busy[0]; st->seconds_inflate = P->busy[1]; st->seconds_device = P->busy[2]; st->seconds_deflate = P->busy[3]; st->seconds_write = P->busy[4];
+    st->seconds_device_inflate = sec_infl; st->device_inflate = device_inflate ? 1u : 0u;
     st->seconds_h2d = sec_h2d; st->seconds_boundaries = sec_bound; st->seconds_grouping = sec_group; st->seconds_consensus = sec_cons; st->seconds_d2h = sec_d2h;
     st->seconds_total = since(t_begin);
     if (rc != 0) { c->err = P->err; return 1; }

@@ -298,10 +298,16 @@ typedef struct fgx_bam_run_stats {
   double seconds_total;
   double seconds_read, seconds_inflate, seconds_device, seconds_deflate, seconds_write;     /* busy time of the five stage threads */
   double seconds_h2d, seconds_boundaries, seconds_grouping, seconds_consensus, seconds_d2h; /* inside the device stage */
-  uint32_t boundary_repair_rounds, _pad;
+  double seconds_device_inflate;                                                            /* inside the device stage (0 with FGX_RUN_HOST_INFLATE) */
+  uint32_t boundary_repair_rounds, device_inflate;
 } fgx_bam_run_stats;
+#define FGX_RUN_HOST_INFLATE 1u   /* flags: inflate the BGZF blocks on the host cores (zlib) instead of on the device */
 int fgx_run_bam(fgx_caller* c, const char* in_path, const char* out_path, const uint8_t* out_header, uint64_t out_header_len,
-                const fgx_group_options* g, uint32_t threads, int level, uint64_t chunk_raw_bytes, fgx_bam_run_stats* st);
+                const fgx_group_options* g, uint32_t threads, int level, uint64_t chunk_raw_bytes, uint32_t flags, fgx_bam_run_stats* st);
+/* The device's DEFLATE decoder (fgumi_amd/csrc/inflate_core.h, one GPU lane per BGZF block) run on the host — the same source, for
+ * tests without a device.  `in` must be readable for 8 bytes past in_len; `out_len` = the block's ISIZE.  Returns the decoder's
+ * status (0 = ok) and, in *crc_out, the CRC-32 of the output computed with the device's 64-slice fold. */
+int fgx_inflate_block_host(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, uint32_t* crc_out);
 /* The host stages alone (read, inflate, deflate, write) around a copy: re-blocks a BGZF file; needs no device. */
 int fgx_bgzf_recompress_file(const char* in_path, const char* out_path, uint32_t threads, int level, uint64_t chunk_raw_bytes,
                              uint64_t* inflated_bytes);

@@ -99,12 +99,31 @@ def _run_and_compare(tmp_path, caller, opts, g, batch_groups, chunk, **run_kw):
     return st
 
 
-def test_bam_file_to_consensus_bam_file_simplex(tmp_path):
+@pytest.mark.parametrize("host_inflate", [False, True])
+def test_bam_file_to_consensus_bam_file_simplex(tmp_path, host_inflate):
+    """BGZF inflate on the device (one lane per block, CRC-32 checked there) and on the host cores: the same records either way."""
     g = simulate_grouped_reads(6000, family_size=2, family_size_max=12)
     c = _caller()
-    one = _run_and_compare(tmp_path, c, fgx_opts.defaults(min_reads=1), g, 50, 0)               # one chunk
-    many = _run_and_compare(tmp_path, c, fgx_opts.defaults(min_reads=1), g, 50, 1 << 16)        # 64 KiB of compressed bytes per chunk: groups cross chunks
+    one = _run_and_compare(tmp_path, c, fgx_opts.defaults(min_reads=1), g, 50, 0, host_inflate=host_inflate)               # one chunk
+    many = _run_and_compare(tmp_path, c, fgx_opts.defaults(min_reads=1), g, 50, 1 << 16, host_inflate=host_inflate)        # 64 KiB of compressed bytes per chunk: groups cross chunks
     assert one["chunks"] == 1 and many["chunks"] > 20
+    assert one["device_inflate"] == (0 if host_inflate else 1)
+    c.close()
+
+
+def test_device_inflate_refuses_a_corrupted_block(tmp_path):
+    g = simulate_grouped_reads(500, family_size=3)
+    refs = [("chr1", 1000000)]
+    src = str(tmp_path / "in.bam")
+    bgzf.write_bam(src, bgzf.grouped_input_header(refs), refs, g.blob)
+    raw = bytearray(open(src, "rb").read())
+    blocks = bgzf.bgzf_block_table(bytes(raw))
+    off, size = blocks[len(blocks) // 2]
+    raw[off + 18 + (size - 26) // 2] ^= 0x10                     # one bit inside the DEFLATE payload of a middle block
+    open(src, "wb").write(raw)
+    c = _caller()
+    with pytest.raises(RuntimeError, match="failed to inflate on the device"):
+        c.run_bam(src, str(tmp_path / "out.bam"))
     c.close()
 
 
