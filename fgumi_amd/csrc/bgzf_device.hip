@@ -4,7 +4,7 @@
 //
 //   k_bgzf_inflate   a LANE per BGZF block (blocks are independent raw DEFLATE streams of at most 64 KiB), sixteen lanes per
 //                    workgroup: a DEFLATE stream is sequential, so the parallelism is across blocks — a 5 GB chunk has 80 000 of them.
-//                    Each lane keeps its decode tables (inflate_core.h, 2 KB) in LDS; 5 workgroups = 80 blocks per CU in flight.
+//                    Each lane keeps its first-level decode tables (inflate_core.h, 1.1 KB) in LDS; 8 workgroups = 128 blocks per CU in flight.
 //                    The lanes of a wavefront diverge (every stream takes its own path); the kernel is bound by the latency of a
 //                    lane's chain of bit-buffer refills and match copies, which is what many blocks in flight hide.
 //   k_bgzf_crc       a WAVEFRONT per block: every lane runs the table-driven CRC-32 over its 1/64 of the block, and the 64 values
@@ -17,16 +17,21 @@ namespace fgx {
 
 namespace {
 
-constexpr uint32_t INFL_LANES = 16;
+#ifndef FGX_INFL_LANES
+#define FGX_INFL_LANES 16
+#endif
+constexpr uint32_t INFL_LANES = FGX_INFL_LANES;
 
 __global__ __launch_bounds__(INFL_LANES) void k_bgzf_inflate(const uint8_t* __restrict__ raw, const BgzfDevBlock* __restrict__ blk, uint32_t n,
                                                              uint8_t* __restrict__ out, uint32_t* __restrict__ status) {
-  __shared__ InflateTables sT[INFL_LANES];
+  __shared__ InflateFast sF[INFL_LANES];
+  InflateSlow W;                                                // (private: touched by the rare codes longer than the first-level tables)
   const uint32_t b = blockIdx.x * INFL_LANES + threadIdx.x;
   if (b >= n) return;
   const BgzfDevBlock B = blk[b];
   if (B.isize == 0) return;
-  const int st = inflate_block(raw + B.in_off, B.in_len, out + B.out_off, B.isize, sT[threadIdx.x]);
+  typedef __attribute__((address_space(3))) uint16_t* LdsPtr;     // (typed LDS pointers: table lookups are ds_read, not flat loads)
+  const int st = inflate_block_t<LdsPtr>(raw + B.in_off, B.in_len, out + B.out_off, B.isize, (LdsPtr)sF[threadIdx.x].lit, (LdsPtr)sF[threadIdx.x].dist, W);
   if (st != INFL_OK) atomicMax(status, ((b + 1u) << 4) | (uint32_t)st);      // (which block, why: the highest failing block wins)
 }
 
@@ -46,8 +51,20 @@ __global__ __launch_bounds__(256) void k_bgzf_crc(const uint8_t* __restrict__ ou
   const uint8_t* p = out + B.out_off;
   uint32_t crc = 0;
   if (hi > lo) {
+    // sixteen bytes per load, the next piece asked for before this one is folded in (a byte per load was a memory round trip per byte)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    auto ld16 = [&](uint32_t i) { u32x4 v; __builtin_memcpy(&v, p + i, 16); return v; };   // (may read up to 15 bytes past `hi`: inside the stream or its slack)
     crc = 0xFFFFFFFFu;
-    for (uint32_t i = lo; i < hi; i++) crc = tab[(crc ^ p[i]) & 0xFFu] ^ (crc >> 8);
+    uint32_t i = lo;
+    u32x4 cur = ld16(i);
+    while (i < hi) {
+      const uint32_t n = hi - i < 16u ? hi - i : 16u;
+      const u32x4 nxt = (i + 16 < hi) ? ld16(i + 16) : cur;
+      const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+      for (uint32_t k = 0; k < 16; k++) if (k < n) crc = tab[(crc ^ (w[k >> 2] >> (8 * (k & 3)))) & 0xFFu] ^ (crc >> 8);
+      cur = nxt; i += 16;
+    }
     crc ^= 0xFFFFFFFFu;
   }
   // fold: at every level the left lane of a pair takes crc(left || right) = left * x^(8 * |right|) + right

@@ -91,7 +91,7 @@ int fgx_bgzf_inflate(const uint8_t* raw, uint64_t raw_len, uint32_t threads, uin
 // 8 bytes past in_len.  Returns its status (0 = ok) and the CRC-32 of the output computed with the device's fold (slices of 1/64).
 int fgx_inflate_block_host(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, uint32_t* crc_out) {
   static thread_local fgx::InflateTables T;
-  const int st = fgx::inflate_block(in, in_len, out, out_len, T);
+  const int st = fgx::inflate_block(in, in_len, out, out_len, T.f, T.w);
   if (crc_out) {
     uint32_t tab[256];
     for (uint32_t i = 0; i < 256; i++) tab[i] = fgx::crc32_table_entry(i);

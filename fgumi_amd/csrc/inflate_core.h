@@ -2,10 +2,10 @@
 // source, on the host for its unit tests).  It stands in, on the device, for what crates/fgumi-bgzf/src/reader.rs:346-479
 // (`decompress_block*`) asks libdeflater to do.  A BGZF block is at most 64 KiB either way, so everything is 32-bit.
 //
-// Shape: a 64-bit bit buffer refilled with one unaligned 8-byte load (the input buffer must be READABLE 8 bytes past its end);
-// literal / length and distance codes through small first-level tables (9 and 7 bits: 1.25 KB) with the canonical bit-by-bit
-// walk (count[] / symbol[]) for the rare longer codes — the whole per-block state is 2 KB, so sixteen lanes of a wavefront keep
-// theirs in LDS; output bytes go straight to the destination (matches are copied from there: the window IS the output).
+// Shape: a 64-bit bit buffer refilled with one unaligned 8-byte load, asked for one refill ahead (the input buffer must be READABLE
+// 16 bytes past its end);
+// literal / length and distance codes through small first-level tables (9 and 6 bits: 1.1 KB, in LDS on the device) with the
+// canonical bit-by-bit walk (count[] / symbol[], private memory) for the rare longer codes; output bytes go straight to the destination (matches are copied from there: the window IS the output).
 #pragma once
 #include <cstdint>
 #include <cstring>
@@ -18,14 +18,24 @@
 
 namespace fgx {
 
-struct InflateTables {
-  uint16_t lit_fast[512];      // 9 peeked bits -> (symbol << 4) | code length; 0 = longer than 9 bits
-  uint16_t dist_fast[128];     // 7 peeked bits
+#ifndef FGX_INFL_LIT_BITS
+#define FGX_INFL_LIT_BITS 9    /* peeked bits of the literal / length first-level table */
+#endif
+#ifndef FGX_INFL_DIST_BITS
+#define FGX_INFL_DIST_BITS 6   /* ... of the distance table (also holds the 19-symbol code-length code while a header is read) */
+#endif
+// the first-level tables: the part of a block's state every symbol touches (LDS on the device: this is what bounds the blocks in flight)
+struct InflateFast {
+  uint16_t lit[1u << FGX_INFL_LIT_BITS];     // peeked bits -> (symbol << 4) | code length; 0 = a longer code
+  uint16_t dist[1u << FGX_INFL_DIST_BITS];
+};
+// the canonical tables behind them, walked bit by bit for the rare longer codes (private memory on the device)
+struct InflateSlow {
   uint16_t lit_count[16], dist_count[16];
   uint16_t lit_sym[288];
   uint16_t dist_sym[32];
 };
-static_assert(sizeof(InflateTables) == 1024 + 256 + 64 + 576 + 64, "InflateTables is the per-lane LDS slice");
+struct InflateTables { InflateFast f; InflateSlow w; };   // (both together: the host entry)
 
 enum InflateStatus : int {
   INFL_OK = 0, INFL_BAD_BLOCK_TYPE = 1, INFL_BAD_STORED = 2, INFL_BAD_CODE_LENGTHS = 3, INFL_BAD_SYMBOL = 4, INFL_BAD_DISTANCE = 5,
@@ -36,14 +46,20 @@ struct BitReader {
   const uint8_t* base; uint32_t len;   // the deflate payload
   uint32_t pos;                        // next byte to load
   uint64_t bb; uint32_t bc;            // bit buffer, valid bits
+  uint64_t nxt;                        // the eight bytes at `pos`, loaded ahead of their use
 };
 
 FGX_HD inline uint64_t infl_load64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
-FGX_HD inline void infl_refill(BitReader& r) {       // at least 56 valid bits afterwards (reads up to 8 bytes past the payload)
-  r.bb |= infl_load64(r.base + r.pos) << r.bc;
+// at least 56 valid bits afterwards.  The bytes come from `nxt`, which was asked for at the PREVIOUS refill: on the device a refill is a
+// global-memory round trip, and this way it runs under the five or so symbols decoded in between instead of in front of them.
+// (Reads up to 16 bytes past the payload.)
+FGX_HD inline void infl_refill(BitReader& r) {
+  r.bb |= r.nxt << r.bc;
   r.pos += (63u - r.bc) >> 3;
   r.bc |= 56u;
+  r.nxt = infl_load64(r.base + r.pos);
 }
+FGX_HD inline void infl_seek(BitReader& r, uint32_t pos) { r.pos = pos; r.bb = 0; r.bc = 0; r.nxt = infl_load64(r.base + pos); }
 FGX_HD inline uint32_t infl_bits(BitReader& r, uint32_t n) {   // n <= 16, bc >= n
   const uint32_t v = (uint32_t)(r.bb & ((1ull << n) - 1ull));
   r.bb >>= n; r.bc -= n;
@@ -57,7 +73,8 @@ FGX_HD inline uint32_t infl_rev(uint32_t code, uint32_t len) {
 
 // canonical Huffman tables from code lengths (RFC 1951 3.2.2).  Returns false for an over-subscribed set; an incomplete set is
 // allowed only for a single code (the one-distance-code case) — what zlib accepts.
-FGX_HD inline bool infl_build(const uint8_t* lens, uint32_t n, uint16_t* count, uint16_t* sym, uint16_t* fast, uint32_t fast_bits) {
+template <class FastPtr>   // uint16_t* on the host; an LDS (address space 3) pointer on the device: ds_read instead of a flat load
+FGX_HD inline bool infl_build(const uint8_t* lens, uint32_t n, uint16_t* count, uint16_t* sym, FastPtr fast, uint32_t fast_bits) {
   for (uint32_t l = 0; l < 16; l++) count[l] = 0;
   for (uint32_t s = 0; s < n; s++) count[lens[s]]++;
   for (uint32_t i = 0; i < (1u << fast_bits); i++) fast[i] = 0;
@@ -83,7 +100,8 @@ FGX_HD inline bool infl_build(const uint8_t* lens, uint32_t n, uint16_t* count, 
 }
 
 // one symbol: the first-level table, else the canonical walk (puff.c's decode), bit by bit.  Returns the symbol or -1.
-FGX_HD inline int32_t infl_decode(BitReader& r, const uint16_t* fast, uint32_t fast_bits, const uint16_t* count, const uint16_t* sym) {
+template <class FastPtr>
+FGX_HD inline int32_t infl_decode(BitReader& r, FastPtr fast, uint32_t fast_bits, const uint16_t* count, const uint16_t* sym) {
   const uint32_t e = fast[(uint32_t)r.bb & ((1u << fast_bits) - 1u)];
   if (e & 15u) { const uint32_t l = e & 15u; r.bb >>= l; r.bc -= l; return (int32_t)(e >> 4); }
   int32_t code = 0, first = 0, index = 0;
@@ -97,15 +115,53 @@ FGX_HD inline int32_t infl_decode(BitReader& r, const uint16_t* fast, uint32_t f
   return -1;
 }
 
+// A match: `len` bytes (3 .. 258) from `dist` bytes back.  Written so that NO load depends on a store of the same match — on the
+// device every dependent load -> store -> load step is a memory round trip of most of a microsecond, and a byte-by-byte copy made
+// the matches nine tenths of the decoder's time:
+//   dist >= len   the source lies wholly before the match: pieces of up to 32 bytes, their loads first, then their stores (whole
+//                 8-byte words while they fit, the tail byte by byte OUT OF THE REGISTERS);
+//   dist <  len   the match repeats its own beginning: the `dist` bytes before it are the period; periods of up to 8 bytes are
+//                 replicated out of one loaded word, longer ones re-read the period (which again lies before the match).
+// Loads may run up to 7 bytes past the bytes they need (inside the output buffer or its slack, never stored).
+FGX_HD inline void infl_store_bytes(uint8_t* dst, uint64_t v, uint32_t n) {          // n < 8 low bytes of v
+  for (uint32_t k = 0; k < n; k++) dst[k] = (uint8_t)(v >> (8 * k));
+}
+FGX_HD inline void infl_copy_match(uint8_t* dst, uint32_t dist, uint32_t len) {
+  const uint8_t* src = dst - dist;
+  if (dist >= len) {
+    for (uint32_t i = 0; i < len; i += 32) {
+      const uint32_t n = len - i < 32u ? len - i : 32u;
+      const uint64_t v0 = infl_load64(src + i), v1 = n > 8 ? infl_load64(src + i + 8) : 0ull, v2 = n > 16 ? infl_load64(src + i + 16) : 0ull,
+                     v3 = n > 24 ? infl_load64(src + i + 24) : 0ull;
+      if (n >= 8) memcpy(dst + i, &v0, 8); else { infl_store_bytes(dst + i, v0, n); return; }
+      if (n >= 16) memcpy(dst + i + 8, &v1, 8); else { infl_store_bytes(dst + i + 8, v1, n - 8); continue; }
+      if (n >= 24) memcpy(dst + i + 16, &v2, 8); else { infl_store_bytes(dst + i + 16, v2, n - 16); continue; }
+      if (n >= 32) memcpy(dst + i + 24, &v3, 8); else infl_store_bytes(dst + i + 24, v3, n - 24);
+    }
+    return;
+  }
+  if (dist <= 8) {
+    const uint64_t pat = infl_load64(src);                      // the period: its low `dist` bytes
+    uint32_t ph = 0;
+    for (uint32_t i = 0; i < len; i++) { dst[i] = (uint8_t)(pat >> (8 * ph)); ph = ph + 1 == dist ? 0 : ph + 1; }
+    return;
+  }
+  uint32_t ph = 0;                                              // 8 < dist < len: rare (a long match over a medium period)
+  for (uint32_t i = 0; i < len; i++) { dst[i] = src[ph]; ph = ph + 1 == dist ? 0 : ph + 1; }
+}
+
 // inflates `in[0 .. in_len)` into `out[0 .. out_len)`; the stream must produce exactly out_len bytes (the block's ISIZE).
-// `in` must be readable for 8 bytes past in_len.  T: this lane's tables (LDS on the device).
-FGX_HD inline int inflate_block(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, InflateTables& T) {
+// `in` must be readable for 16 bytes past in_len.  F / W: this lane's tables (LDS / private memory on the device).
+template <class FastPtr>
+FGX_HD inline int inflate_block_t(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, FastPtr f_lit, FastPtr f_dist, InflateSlow& W) {
+  constexpr uint32_t LB = FGX_INFL_LIT_BITS, DB = FGX_INFL_DIST_BITS;
   static constexpr uint16_t LEN_BASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
   static constexpr uint8_t LEN_EXTRA[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
   static constexpr uint16_t DIST_BASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
   static constexpr uint8_t DIST_EXTRA[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
   static constexpr uint8_t CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-  BitReader r{in, in_len, 0u, 0ull, 0u};
+  BitReader r{in, in_len, 0u, 0ull, 0u, 0ull};
+  infl_seek(r, 0);
   uint32_t pos = 0;
   for (;;) {
     infl_refill(r);
@@ -123,7 +179,7 @@ FGX_HD inline int inflate_block(const uint8_t* in, uint32_t in_len, uint8_t* out
       if (pos + len > out_len) return INFL_OUTPUT_OVERFLOW;
       for (uint32_t i = 0; i < len; i++) out[pos + i] = in[src + i];
       pos += len;
-      r.pos = src + len; r.bb = 0; r.bc = 0;
+      infl_seek(r, src + len);
     } else if (btype == 1 || btype == 2) {
       uint8_t lens[320];
       uint32_t hlit, hdist;
@@ -143,11 +199,11 @@ FGX_HD inline int inflate_block(const uint8_t* in, uint32_t in_len, uint8_t* out
         infl_refill(r);
         for (uint32_t i = 0; i < hclen; i++) { if (r.bc < 3) infl_refill(r); cl[CL_ORDER[i]] = (uint8_t)infl_bits(r, 3); }
         // the code-length code: its tables live in the distance slots for the moment (19 symbols, up to 7 bits)
-        if (!infl_build(cl, 19, T.dist_count, T.dist_sym, T.dist_fast, 7)) return INFL_BAD_CODE_LENGTHS;
+        if (!infl_build(cl, 19, W.dist_count, W.dist_sym, f_dist, DB)) return INFL_BAD_CODE_LENGTHS;
         uint32_t n = 0;
         while (n < hlit + hdist) {
           if (r.bc < 32) infl_refill(r);
-          const int32_t s = infl_decode(r, T.dist_fast, 7, T.dist_count, T.dist_sym);
+          const int32_t s = infl_decode(r, f_dist, DB, W.dist_count, W.dist_sym);
           if (s < 0) return INFL_BAD_CODE_LENGTHS;
           if (s < 16) lens[n++] = (uint8_t)s;
           else {
@@ -161,11 +217,11 @@ FGX_HD inline int inflate_block(const uint8_t* in, uint32_t in_len, uint8_t* out
         }
         if (lens[256] == 0) return INFL_BAD_CODE_LENGTHS;        // no end-of-block code
       }
-      if (!infl_build(lens, hlit, T.lit_count, T.lit_sym, T.lit_fast, 9)) return INFL_BAD_CODE_LENGTHS;
-      if (!infl_build(lens + hlit, hdist, T.dist_count, T.dist_sym, T.dist_fast, 7)) return INFL_BAD_CODE_LENGTHS;
+      if (!infl_build(lens, hlit, W.lit_count, W.lit_sym, f_lit, LB)) return INFL_BAD_CODE_LENGTHS;
+      if (!infl_build(lens + hlit, hdist, W.dist_count, W.dist_sym, f_dist, DB)) return INFL_BAD_CODE_LENGTHS;
       for (;;) {
         if (r.bc < 48) infl_refill(r);                 // a length + distance pair takes at most 15 + 5 + 15 + 13 = 48 bits
-        int32_t s = infl_decode(r, T.lit_fast, 9, T.lit_count, T.lit_sym);
+        int32_t s = infl_decode(r, f_lit, LB, W.lit_count, W.lit_sym);
         if (s < 0) return INFL_BAD_SYMBOL;
         if (s < 256) {
           if (pos >= out_len) return INFL_OUTPUT_OVERFLOW;
@@ -176,16 +232,12 @@ FGX_HD inline int inflate_block(const uint8_t* in, uint32_t in_len, uint8_t* out
         s -= 257;
         if (s >= 29) return INFL_BAD_SYMBOL;
         const uint32_t len = LEN_BASE[s] + infl_bits(r, LEN_EXTRA[s]);
-        const int32_t d = infl_decode(r, T.dist_fast, 7, T.dist_count, T.dist_sym);
+        const int32_t d = infl_decode(r, f_dist, DB, W.dist_count, W.dist_sym);
         if (d < 0 || d >= 30) return INFL_BAD_DISTANCE;
         const uint32_t dist = DIST_BASE[d] + infl_bits(r, DIST_EXTRA[d]);
         if (dist > pos) return INFL_BAD_DISTANCE;
         if (pos + len > out_len) return INFL_OUTPUT_OVERFLOW;
-        uint8_t* dst = out + pos;
-        const uint8_t* src = dst - dist;
-        uint32_t i = 0;
-        if (dist >= 8) for (; i + 8 <= len; i += 8) { const uint64_t v = infl_load64(src + i); memcpy(dst + i, &v, 8); }   // (no overlap inside a piece)
-        for (; i < len; i++) dst[i] = src[i];
+        infl_copy_match(out + pos, dist, len);
         pos += len;
       }
     } else return INFL_BAD_BLOCK_TYPE;
@@ -193,6 +245,10 @@ FGX_HD inline int inflate_block(const uint8_t* in, uint32_t in_len, uint8_t* out
     if (bfinal) break;
   }
   return pos == out_len ? INFL_OK : INFL_SIZE_MISMATCH;
+}
+
+FGX_HD inline int inflate_block(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, InflateFast& F, InflateSlow& W) {
+  return inflate_block_t<uint16_t*>(in, in_len, out, out_len, F.lit, F.dist, W);
 }
 
 // CRC-32 (IEEE 802.3, reflected, as gzip uses it): the byte-wise table and the pieces of zlib's crc32_combine (multiplication

@@ -561,7 +561,7 @@ int fgx_run_bam(fgx_caller* c, const char* in_path, const char* out_path, const 
     std::vector<uint8_t> h_blob; std::vector<uint64_t> h_off; std::vector<uint32_t> h_len, h_grp;   // (only for chunks with deferred families)
     Pipeline* P = &S->P;
     P->reset();
-    const int rc = P->run(in_path, out_path, out_header, out_header_len, threads, level, chunk_raw_bytes ? chunk_raw_bytes : (256ull << 20), true, device_inflate,
+    const int rc = P->run(in_path, out_path, out_header, out_header_len, threads, level, chunk_raw_bytes ? chunk_raw_bytes : (512ull << 20), true, device_inflate,
                           [&](Chunk& ch, uint64_t seq) {
       fgx::hip_check(hipSetDevice(c->device), "hipSetDevice");
       ch.out_len = 0;

@@ -18,7 +18,7 @@ def main():
     ap.add_argument("--families", type=int, default=1000000)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--threads", type=int, default=None)
-    ap.add_argument("--chunk-mb", type=int, default=256)
+    ap.add_argument("--chunk-mb", type=int, default=512)
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--dir", default="/tmp/fgx_e2e")
     ap.add_argument("--host-inflate", action="store_true", help="inflate the BGZF blocks with zlib on the host cores instead of on the device")
