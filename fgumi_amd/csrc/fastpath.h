@@ -180,6 +180,11 @@ struct FastPath {
   uint32_t lds_wave_bytes_codec = 5120;   // CODEC (config 5: 8 records x ~570 B): its kernel needs 71 VGPRs, so the smaller slice buys a sixth wave per SIMD (+3 %)
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   // split simplex pipeline: the record kernel runs chunk by chunk on a second stream, under the column kernel of the chunk before
+  uint32_t pool_slack = 256; bool pool_init = false;
+  uint32_t pool_div = 8;                  // k_call_full's append lists hold 1 / pool_div of the column bound (halved when a batch exhausts them)
+  static constexpr int RUN_AGAIN_LARGER_POOL = -77;
+  int run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const uint64_t* d_rec_off, const uint32_t* d_rec_len, uint32_t n_rec,
+               const uint32_t* d_grp_first, uint32_t n_grp, FastResult* res);
   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: one flag per FastPath (= per caller = per device), not per process
   bool lds_attr_set = false, s2_attr_set = false, v2_attr_set = false;
   static constexpr int MAX_CHUNKS = 16;

@@ -3310,8 +3310,25 @@ void FastPath::release() {
   }
 }
 
+// The columns whose call needs the log-sum-exp chain wait in append lists for k_call_full.  Their room is a fraction of the column
+// bound (1/8: clean libraries need under 1 %); when a batch fills EVERY list — a noisy library: a few per cent of disagreeing bases
+// at depth 8 — the batch is run again with twice the room (and the caller keeps the larger fraction for its next batches) instead
+// of handing the families that found no room to the host path.
 int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const uint64_t* d_rec_off, const uint32_t* d_rec_len,
                   uint32_t n_rec, const uint32_t* d_grp_first, uint32_t n_grp, FastResult* res) {
+  if (!pool_init) {   // (test knobs: a tiny pool makes a small batch exhaust it)
+    if (const char* e = getenv("FGX_POOL_DIV")) { const long v = atol(e); if (v >= 1 && v <= (1 << 20)) pool_div = (uint32_t)v; }
+    if (const char* e = getenv("FGX_POOL_SLACK")) { const long v = atol(e); if (v >= 1 && v <= 4096) pool_slack = (uint32_t)v; }
+    pool_init = true;
+  }
+  for (;;) {
+    const int rc = run_once(c, d_blob, blob_len, d_rec_off, d_rec_len, n_rec, d_grp_first, n_grp, res);
+    if (rc != RUN_AGAIN_LARGER_POOL) return rc;
+  }
+}
+
+int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const uint64_t* d_rec_off, const uint32_t* d_rec_len,
+                       uint32_t n_rec, const uint32_t* d_grp_first, uint32_t n_grp, FastResult* res) {
   const fgx_options& o = c->opt;
   const bool duplex = o.caller_kind == FGX_CALLER_DUPLEX, codec = o.caller_kind == FGX_CALLER_CODEC;
   hipStream_t s = c->stream;
@@ -3408,7 +3425,7 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
   P.retry = d_retry.as<uint32_t>(); P.n_retry = (uint32_t*)(misc + 31);
   P.group_list = nullptr;
   // append lists for the columns that need call_full: room for 1/8 of the column bound (overflow → general path)
-  uint64_t full_total = col_cap / 8 + (uint64_t)N_LISTS * 256;
+  uint64_t full_total = col_cap / pool_div + (uint64_t)N_LISTS * pool_slack;
   uint32_t full_cap = (uint32_t)std::min<uint64_t>(full_total / N_LISTS, 0x7FFFFFFFull);
   d_full_items.reserve((size_t)full_cap * N_LISTS * sizeof(FullItem));
   d_full_count.reserve((size_t)N_LISTS * 4);
@@ -3674,8 +3691,20 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
     std::vector<uint32_t> counts(N_LISTS);
     hip_check(hipMemcpyAsync(counts.data(), d_full_count.p, (size_t)N_LISTS * 4, hipMemcpyDeviceToHost, s), "D2H");
     hip_check(hipStreamSynchronize(s), "sync");
-    uint32_t mx = 0;
-    for (uint32_t v : counts) { uint32_t vv = v < full_cap ? v : full_cap; mx = vv > mx ? vv : mx; n_full += vv; }
+    uint32_t mx = 0, mn = 0xFFFFFFFFu;
+    for (uint32_t v : counts) { uint32_t vv = v < full_cap ? v : full_cap; mx = vv > mx ? vv : mx; mn = v < mn ? v : mn; n_full += vv; }
+    if (mn >= full_cap && pool_div > 1) {
+      // every list is full: some family found no room (and was deferred).  Twice the room, if the device has it, and the batch again.
+      size_t free_b = 0, total_b = 0;
+      (void)hipMemGetInfo(&free_b, &total_b);
+      const uint64_t want = (col_cap / (pool_div / 2) + (uint64_t)N_LISTS * pool_slack) * sizeof(FullItem);
+      if (want < (uint64_t)free_b + (uint64_t)d_full_items.cap) {
+        pool_div /= 2;
+        static const bool verbose = [] { const char* e = getenv("FGX_S2_VERBOSE"); return e && e[0] == '1'; }();
+        if (verbose) fprintf(stderr, "[fgx] call_full pool exhausted: the batch again with 1/%u of the column bound\n", pool_div);
+        return RUN_AGAIN_LARGER_POOL;
+      }
+    }
     if (mx) {
       FullParams F;
       memset(&F, 0, sizeof(F));

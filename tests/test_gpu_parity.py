@@ -378,3 +378,17 @@ def test_full_size_config2_properties():
     assert off == len(full) and total_reads == st.total_reads and overlap == st.overlapping["bases_corrected"]
     c.close()
 
+
+
+def test_noisy_batch_grows_the_call_full_pool_instead_of_deferring(monkeypatch):
+    """3 % substitution errors at depth 8: a fifth of the columns needs `call_full`.  With a pool far too small for that (test knobs)
+    every list fills up; the batch must be run again with more room until nothing is deferred — and still equal the oracle."""
+    monkeypatch.setenv("FGX_POOL_DIV", "4096")
+    monkeypatch.setenv("FGX_POOL_SLACK", "1")
+    g = simulate_grouped_reads(3000, family_size=8, error_rate_ppm=30000)
+    want = orc.process(fgx_opts.defaults(min_reads=1), g.blob, g.rec_off, g.rec_len, g.grp_first)
+    c = VanillaUmiConsensusCaller("", "A", VanillaUmiConsensusOptions(min_reads=1, min_consensus_base_quality=2, cell_tag="CB"), overlapping_consensus=True)
+    out = c.process_batch_device(g.to_device())
+    assert out.n_deferred == 0
+    assert out.to_host() == want["data"]
+    c.close()
