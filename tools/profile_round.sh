@@ -42,6 +42,6 @@ for f in glob.glob(sys.argv[1]+'/*kernel_stats.csv'):
     for r in list(csv.DictReader(open(f)))[:7]: print(r['Name'][:70], r['Calls'], r['AverageNs'], r['Percentage'])
 d=json.load(open(sys.argv[1]+'/pmc_5M_families.json'))
 for k,v in d.items():
-    if k.startswith('k_simplex') or k=='k_emit': print(k, {c: round(x/1e6,1) for c,x in v.items()})
+    if k.startswith('k_split') or k=='k_emit' or k=='k_call_full': print(k, {c: round(x*v.get('_launches_per_step',1)/5e6,1) for c,x in v.items() if not c.startswith('_')})
 PY
 ls $OUT
