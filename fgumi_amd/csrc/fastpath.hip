@@ -3264,9 +3264,16 @@ __global__ __launch_bounds__(256) void k_emit_codec_fast(CodecEmitParams P) {
 // Per family: the scratch-column bound, and a descriptor {byte offset of its first record, bytes up to the end of its last record,
 // record count} — with it k_simplex_wave2 starts loading the family's bytes one memory round trip earlier (it needs neither
 // grp_first nor rec_off to know where they are; it checks afterwards that every record lies inside that span).
+// (+ how many records sit in families of at most 32 records: what decides between the two heads of the simplex launch chain)
 __global__ void k_col_bound(const uint32_t* __restrict__ grp_first, const uint32_t* __restrict__ rec_len, const uint64_t* __restrict__ rec_off, uint32_t n_grp,
-                            uint64_t* __restrict__ bound, uint32_t max_ends, uint4* __restrict__ fam_desc) {
+                            uint64_t* __restrict__ bound, uint32_t max_ends, uint4* __restrict__ fam_desc, unsigned long long* __restrict__ small_recs) {
   uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  {
+    uint32_t mine = 0;
+    if (g < n_grp) { const uint32_t n = grp_first[g + 1] - grp_first[g]; mine = (grp_first[g + 1] >= grp_first[g] && n <= 32u) ? n : 0u; }
+    const uint32_t tot = wave_sum(mine);
+    if ((threadIdx.x & 63) == 0 && tot) atomicAdd(small_recs, (unsigned long long)tot);
+  }
   if (g >= n_grp) return;
   uint32_t a = grp_first[g], b = grp_first[g + 1], mx = 0;
   for (uint32_t r = a; r < b; r++) { uint32_t l = rec_len[r]; mx = l > mx ? l : mx; }
@@ -3367,9 +3374,8 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
   const double mean_span = (double)blob_len / (double)n_grp + 48.0;   // mean bytes of a family + alignment / read-ahead slack
   const bool simplex_v2 = !duplex && !codec && !o.trim && use_v2;
   const bool seg4 = simplex_v2 && use_seg && mean_span + (16 * 8 + 64) <= seg_bytes / 4;
-  const bool use_split = simplex_v2 && use_split_env && !seg4;
   hipLaunchKernelGGL(k_col_bound, dim3((n_grp + 255) / 256), dim3(256), 0, s, d_grp_first, d_rec_len, d_rec_off, n_grp, d_bound.as<uint64_t>(), duplex ? 4u : codec ? 2u : 3u,
-                     d_famdesc.as<uint4>());
+                     d_famdesc.as<uint4>(), misc + 35);
   {
     size_t tb = 0;
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_bound.as<uint64_t>(), d_colbase.as<uint64_t>(), (int)n_grp, s);
@@ -3379,7 +3385,15 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
   uint64_t lastb[2];
   hip_check(hipMemcpyAsync(&lastb[0], d_colbase.as<uint64_t>() + (n_grp - 1), 8, hipMemcpyDeviceToHost, s), "D2H");
   hip_check(hipMemcpyAsync(&lastb[1], d_bound.as<uint64_t>() + (n_grp - 1), 8, hipMemcpyDeviceToHost, s), "D2H");
+  unsigned long long small_recs = 0;
+  hip_check(hipMemcpyAsync(&small_recs, misc + 35, 8, hipMemcpyDeviceToHost, s), "D2H");
   hip_check(hipStreamSynchronize(s), "sync");
+  // The split pipeline is the faster head for families of moderate size (depth 8: 25.7 against 37 ms per 5 M families); on long-tail
+  // sizes — most reads in families of dozens of records, which the split pipeline only parses and hands on — the k_simplex_wave2 chain
+  // alone is (27.3 against 30.6 ms per 1 M families of 2 .. 50 pairs).  Split when at least 90 % of the reads sit in families of at
+  // most 32 records (FGX_SPLIT=0 / 2: never / always).
+  static const int split_mode = [] { const char* e = getenv("FGX_SPLIT"); return e ? atoi(e) : 1; }();
+  const bool use_split = simplex_v2 && use_split_env && !seg4 && (split_mode == 2 || (double)small_recs >= 0.9 * (double)n_rec);
   uint64_t col_cap = lastb[0] + lastb[1] + 64;
   d_code.reserve(col_cap + 64); d_qual.reserve(col_cap + 64); d_err.reserve(col_cap * 2 + 64);   // (+ slack: k_emit reads whole dwords)
   if (duplex) d_obs.reserve(col_cap * 4); else d_depth.reserve(col_cap * 2 + 64);
@@ -3522,8 +3536,18 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       hip_check(hipEventRecord(ev_sample, s2), "event");
       for (uint32_t ci = 1; ci < n_chunks; ci++) launch_parse(ci);
       hip_check(hipEventSynchronize(ev_sample), "sync");
-      static const uint32_t s2_bytes0 = [] { const char* e = getenv("FGX_S2_BYTES"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 2048 && v <= 32768 ? (v & ~15) : 4352); }();
-      static const uint32_t s2_wpb = [] { const char* e = getenv("FGX_S2_WPB"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= 4 ? v : 4); }();
+      // LDS slice of the first launch: the MEAN family's tile (rows of 160 + 80 bytes) + room for its k_call_full items, at least the
+      // 4352 bytes of a 16-record family — a deeper library starts at the slice its families need instead of failing the first launch
+      // as a whole (depth 12: every family took two launches, 32 ms per 1 M families)
+      static const uint32_t s2_bytes_env = [] { const char* e = getenv("FGX_S2_BYTES"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 2048 && v <= 32768 ? (v & ~15) : 0); }();
+      static const uint32_t s2_wpb_env = [] { const char* e = getenv("FGX_S2_WPB"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= 4 ? v : 0); }();
+      uint32_t s2_bytes0 = 4352;
+      {
+        const uint32_t mean_need = (uint32_t)(mean_recs + 0.999) * 240u + 16u + 400u;
+        if (mean_need > s2_bytes0) s2_bytes0 = std::min<uint32_t>((mean_need + 15u) & ~15u, 17408u);
+      }
+      if (s2_bytes_env) s2_bytes0 = s2_bytes_env;
+      const uint32_t s2_wpb = s2_wpb_env ? s2_wpb_env : (s2_bytes0 <= 6528u ? 4u : s2_bytes0 <= 13056u ? 2u : 1u);
       // rows of 160 + 80 bytes (reads up to 160 bases) have their own build: member rows at immediate offsets in the column loop
       static const int s2_fixed_env = [] { const char* e = getenv("FGX_S2_FIXED"); return e ? atoi(e) : -1; }();   // (measurement knob: 0 / 1)
       uint32_t n160 = 0;
