@@ -13,6 +13,7 @@
 #include <vector>
 #include "../../include/fgumi_amd.h"
 #include "inflate_core.h"
+#include "deflate_core.h"
 
 namespace {
 constexpr uint32_t BGZF_PAYLOAD = 0xFF00;     // uncompressed bytes per block (htslib / noodles / fgumi-bgzf)
@@ -112,6 +113,14 @@ int fgx_inflate_block_host(const uint8_t* in, uint32_t in_len, uint8_t* out, uin
     *crc_out = out_len ? lane_crc[0] : 0u;
   }
   return st;
+}
+
+// the device's DEFLATE compressor (deflate_core.h) run on the host: the same source, for the CPU tests.  `in` must be readable for
+// 8 bytes past n.  Returns the compressed size, 0 when the stream does not fit `cap` (a block to be stored).
+uint32_t fgx_deflate_block_host(const uint8_t* in, uint32_t n, uint8_t* out, uint32_t cap) {
+  static thread_local fgx::DeflateScratch* S = nullptr;
+  if (!S) S = new fgx::DeflateScratch();
+  return fgx::deflate_block(in, n, out, cap, *S);
 }
 
 int fgx_bgzf_deflate(const uint8_t* in, uint64_t len, int level, uint32_t threads, int with_eof, uint8_t** out, uint64_t* out_len) {

@@ -35,6 +35,7 @@
 #include <thread>
 #include <vector>
 #include "engine.h"
+#include "deflate_core.h"
 #include "../../include/fgumi_amd.h"
 
 namespace {
@@ -390,7 +391,8 @@ struct Pipeline {
 
     // cuts `src` into BGZF blocks (parallel, one 64 KiB slot each), then packs them back to back into `packed` (parallel copies):
     // the writer hands the file system one large buffer per chunk instead of tens of thousands of 8 KB pieces
-    std::vector<uint8_t> dscratch((size_t)n_workers * BGZF_SLOT);
+    std::vector<uint8_t> dscratch((size_t)n_workers * BGZF_SLOT + 64);
+    std::vector<std::unique_ptr<fgx::DeflateScratch>> dstate(n_workers);
     auto deflate_stream = [&](const uint8_t* src, uint64_t len, HostBuf& comp, std::vector<uint32_t>& sizes, HostBuf& packed, uint64_t* packed_len,
                               bool use_scratch) -> bool {
       const size_t nb = (size_t)((len + BGZF_PAYLOAD - 1) / BGZF_PAYLOAD);
@@ -407,16 +409,23 @@ struct Pipeline {
         }
         uint8_t* blk = comp.p + i * BGZF_SLOT;
         uint32_t csize = 0;
-        for (int lv = level;; lv = 0) {         // an incompressible payload falls back to stored blocks (always fits)
+        // level 1 (the reference's default for consensus output): this repository's own block compressor (deflate_core.h — the one the
+        // device runs a lane per block; on the host it is about twice as fast as zlib level 1 and a little smaller on consensus records)
+        if (level == 1) {
+          if (!dstate[w]) dstate[w].reset(new fgx::DeflateScratch());
+          if (in != dscratch.data() + (size_t)w * BGZF_SLOT) { memcpy(dscratch.data() + (size_t)w * BGZF_SLOT, in, n); in = dscratch.data() + (size_t)w * BGZF_SLOT; }   // (8 readable bytes behind the block)
+          csize = fgx::deflate_block(in, n, blk + 18, (uint32_t)(BGZF_SLOT - 18 - 8), *dstate[w]);
+        }
+        for (int lv = level == 1 ? 0 : level; csize == 0; lv = 0) {   // zlib for the other levels; a payload that does not fit is stored (always fits)
           z_stream z;
           memset(&z, 0, sizeof(z));
           if (deflateInit2(&z, lv, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { bad = 1; return; }
           z.next_in = (Bytef*)in; z.avail_in = n;
           z.next_out = blk + 18; z.avail_out = (uInt)(BGZF_SLOT - 18 - 8);
           const int rc = deflate(&z, Z_FINISH);
-          csize = (uint32_t)z.total_out;
+          const uint32_t got = (uint32_t)z.total_out;
           deflateEnd(&z);
-          if (rc == Z_STREAM_END) break;
+          if (rc == Z_STREAM_END) { csize = got; break; }
           if (lv == 0) { bad = 1; return; }
         }
         const uint32_t bsize = 18 + csize + 8 - 1;

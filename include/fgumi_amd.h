@@ -308,6 +308,10 @@ int fgx_run_bam(fgx_caller* c, const char* in_path, const char* out_path, const 
  * tests without a device.  `in` must be readable for 8 bytes past in_len; `out_len` = the block's ISIZE.  Returns the decoder's
  * status (0 = ok) and, in *crc_out, the CRC-32 of the output computed with the device's 64-slice fold. */
 int fgx_inflate_block_host(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, uint32_t* crc_out);
+/* The device's DEFLATE compressor (fgumi_amd/csrc/deflate_core.h, one GPU lane per BGZF block: greedy LZ77 + one dynamic Huffman
+ * code per block) run on the host, for tests without a device.  `in` readable for 8 bytes past n (n <= 65535).  Returns the bytes
+ * written to `out`, or 0 when they do not fit `cap` (the caller stores the block). */
+uint32_t fgx_deflate_block_host(const uint8_t* in, uint32_t n, uint8_t* out, uint32_t cap);
 /* The host stages alone (read, inflate, deflate, write) around a copy: re-blocks a BGZF file; needs no device. */
 int fgx_bgzf_recompress_file(const char* in_path, const char* out_path, uint32_t threads, int level, uint64_t chunk_raw_bytes,
                              uint64_t* inflated_bytes);
