@@ -10,8 +10,10 @@
 //   k_bgzf_crc       a WAVEFRONT per block: every lane runs the table-driven CRC-32 over its 1/64 of the block, and the 64 values
 //                    are folded with the polynomial arithmetic of zlib's crc32_combine (slices are aligned to the END of the
 //                    block, so every right-hand operand of the fold is a whole number of full slices).
+#include <hipcub/hipcub.hpp>
 #include "engine.h"
 #include "inflate_core.h"
+#include "deflate_core.h"
 
 namespace fgx {
 
@@ -35,20 +37,12 @@ __global__ __launch_bounds__(INFL_LANES) void k_bgzf_inflate(const uint8_t* __re
   if (st != INFL_OK) atomicMax(status, ((b + 1u) << 4) | (uint32_t)st);      // (which block, why: the highest failing block wins)
 }
 
-__global__ __launch_bounds__(256) void k_bgzf_crc(const uint8_t* __restrict__ out, const BgzfDevBlock* __restrict__ blk, uint32_t n,
-                                                  uint32_t* __restrict__ status) {
-  __shared__ uint32_t tab[256];
-  tab[threadIdx.x] = crc32_table_entry(threadIdx.x);
-  __syncthreads();
-  const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-  if (b >= n) return;
-  const BgzfDevBlock B = blk[b];
-  const uint32_t len = B.isize;
-  if (len == 0) { if (lane == 0 && B.crc != 0) atomicMax(status, ((b + 1u) << 4) | 9u); return; }
-  const uint32_t S = (len + 63u) / 64u;                                    // bytes per lane; slices end at the block's end
+// CRC-32 of p[0 .. len) by one wavefront (len > 0): every lane its 1/64 slice (slices end at the block's end), then the fold.  The
+// result is valid in lane 0.
+__device__ __forceinline__ uint32_t wave_crc32(const uint8_t* p, uint32_t len, const uint32_t* tab, uint32_t lane) {
+  const uint32_t S = (len + 63u) / 64u;                                    // bytes per lane
   const int64_t hi_s = (int64_t)len - (int64_t)(63u - lane) * S, lo_s = hi_s - (int64_t)S;
   const uint32_t hi = hi_s > 0 ? (uint32_t)hi_s : 0u, lo = lo_s > 0 ? (uint32_t)lo_s : 0u;
-  const uint8_t* p = out + B.out_off;
   uint32_t crc = 0;
   if (hi > lo) {
     // sixteen bytes per load, the next piece asked for before this one is folded in (a byte per load was a memory round trip per byte)
@@ -74,7 +68,76 @@ __global__ __launch_bounds__(256) void k_bgzf_crc(const uint8_t* __restrict__ ou
     if ((lane & (2 * step - 1)) == 0) crc = crc32_multmodp(op, crc) ^ right;
     op = crc32_multmodp(op, op);
   }
+  return crc;
+}
+
+__global__ __launch_bounds__(256) void k_bgzf_crc(const uint8_t* __restrict__ out, const BgzfDevBlock* __restrict__ blk, uint32_t n,
+                                                  uint32_t* __restrict__ status) {
+  __shared__ uint32_t tab[256];
+  tab[threadIdx.x] = crc32_table_entry(threadIdx.x);
+  __syncthreads();
+  const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (b >= n) return;
+  const BgzfDevBlock B = blk[b];
+  const uint32_t len = B.isize;
+  if (len == 0) { if (lane == 0 && B.crc != 0) atomicMax(status, ((b + 1u) << 4) | 9u); return; }
+  const uint32_t crc = wave_crc32(out + B.out_off, len, tab, lane);
   if (lane == 0 && crc != B.crc) atomicMax(status, ((b + 1u) << 4) | 9u);   // 9 = CRC-32 mismatch
+}
+
+// ---- deflate: the consensus records, 0xff00 bytes per BGZF block ---------------------------------------------------------------------
+constexpr uint32_t BGZF_PAYLOAD = 0xFF00, BGZF_SLOT = 0x10000;
+
+// a LANE per block (deflate_core.h: greedy LZ77 + a dynamic Huffman code per block; hash table and token list in the lane's slice of a
+// global scratch); the block lands in its 64 KiB slot as [18-byte header][DEFLATE stream][CRC-32 (k_bgzf_crc_write)][ISIZE]
+__global__ __launch_bounds__(64) void k_bgzf_deflate(const uint8_t* __restrict__ in, uint64_t len, uint32_t b0, uint32_t nb, uint8_t* __restrict__ slots,
+                                                     uint32_t* __restrict__ sizes, DeflateScratch* __restrict__ scratch) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nb) return;
+  const uint32_t b = b0 + t;
+  const uint64_t off = (uint64_t)b * BGZF_PAYLOAD;
+  const uint32_t n = (uint32_t)(len - off < BGZF_PAYLOAD ? len - off : BGZF_PAYLOAD);
+  const uint8_t* src = in + off;
+  uint8_t* blk = slots + (size_t)b * BGZF_SLOT;
+  uint32_t csize = deflate_block(src, n, blk + 18, BGZF_SLOT - 18 - 8, scratch[t]);
+  if (csize == 0) {                                             // stored (a payload that does not compress into the slot)
+    uint8_t* q = blk + 18;
+    q[0] = 1; q[1] = (uint8_t)n; q[2] = (uint8_t)(n >> 8); q[3] = (uint8_t)~n; q[4] = (uint8_t)(~n >> 8);
+    for (uint32_t i = 0; i < n; i++) q[5 + i] = src[i];
+    csize = 5 + n;
+  }
+  const uint32_t bsize = 18 + csize + 8 - 1;
+  const uint8_t hdr[18] = {0x1F, 0x8B, 8, 4, 0, 0, 0, 0, 0, 0xFF, 6, 0, 'B', 'C', 2, 0, (uint8_t)bsize, (uint8_t)(bsize >> 8)};
+  for (int i = 0; i < 18; i++) blk[i] = hdr[i];
+  uint8_t* f = blk + 18 + csize + 4;
+  f[0] = (uint8_t)n; f[1] = (uint8_t)(n >> 8); f[2] = 0; f[3] = 0;      // ISIZE
+  sizes[b] = 18 + csize + 8;
+}
+// a wavefront per block: the CRC-32 of the block's uncompressed bytes into its footer
+__global__ __launch_bounds__(256) void k_bgzf_crc_write(const uint8_t* __restrict__ in, uint64_t len, uint32_t nb, uint8_t* __restrict__ slots,
+                                                        const uint32_t* __restrict__ sizes) {
+  __shared__ uint32_t tab[256];
+  tab[threadIdx.x] = crc32_table_entry(threadIdx.x);
+  __syncthreads();
+  const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (b >= nb) return;
+  const uint64_t off = (uint64_t)b * BGZF_PAYLOAD;
+  const uint32_t n = (uint32_t)(len - off < BGZF_PAYLOAD ? len - off : BGZF_PAYLOAD);
+  const uint32_t crc = n ? wave_crc32(in + off, n, tab, lane) : 0u;
+  if (lane == 0) { uint8_t* f = slots + (size_t)b * BGZF_SLOT + sizes[b] - 8; f[0] = (uint8_t)crc; f[1] = (uint8_t)(crc >> 8); f[2] = (uint8_t)(crc >> 16); f[3] = (uint8_t)(crc >> 24); }
+}
+// a wavefront per block: the slot's bytes to their place in the packed stream
+__global__ __launch_bounds__(256) void k_bgzf_pack(const uint8_t* __restrict__ slots, const uint32_t* __restrict__ sizes, const uint64_t* __restrict__ offs, uint32_t nb,
+                                                   uint8_t* __restrict__ packed) {
+  const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (b >= nb) return;
+  const uint8_t* s = slots + (size_t)b * BGZF_SLOT;
+  uint8_t* d = packed + offs[b];
+  const uint32_t n = sizes[b];
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  uint32_t i = 16 * lane;
+  for (; i + 16 <= n; i += 16 * 64) { u32x4 v; __builtin_memcpy(&v, s + i, 16); __builtin_memcpy(d + i, &v, 16); }
+  if (i < n) for (uint32_t k = i; k < n && k < i + 16; k++) d[k] = s[k];
 }
 
 }  // namespace
@@ -98,6 +161,52 @@ int bgzf_inflate_device(fgx_caller* c, const uint8_t* d_raw, const BgzfDevBlock*
     c->err = "BGZF block " + std::to_string((st >> 4) - 1) + " of the chunk failed to inflate on the device: " + (code < 10 ? why[code] : "?");
     return 1;
   }
+  return 0;
+}
+
+
+// compresses d_in[0 .. len) into BGZF blocks packed back to back in `packed` (device); `scratch` / `slots` / `meta` are working buffers
+// the caller keeps.  d_in must be readable for 16 bytes past len.  Returns 0 and *packed_len.
+int bgzf_deflate_device(fgx_caller* c, const uint8_t* d_in, uint64_t len, DevBuf& slots, DevBuf& scratch, DevBuf& meta, DevBuf& packed, uint64_t* packed_len) {
+  *packed_len = 0;
+  if (len == 0) return 0;
+  hipStream_t s = c->stream;
+  const uint64_t nb64 = (len + BGZF_PAYLOAD - 1) / BGZF_PAYLOAD;
+  if (nb64 > 0x7FFFFFFFull) { c->err = "bgzf_deflate_device: too many blocks"; return 1; }
+  const uint32_t nb = (uint32_t)nb64;
+  slots.reserve((size_t)nb * BGZF_SLOT + 64);
+  meta.reserve((size_t)nb * 12 + 256);                          // sizes (u32) | offsets (u64)
+  uint32_t* d_sizes = meta.as<uint32_t>();
+  uint64_t* d_offs = (uint64_t*)(((uintptr_t)(d_sizes + nb) + 15) & ~(uintptr_t)15);
+  meta.reserve((size_t)((uint8_t*)(d_offs + nb) - (uint8_t*)meta.p) + 64);
+  d_sizes = meta.as<uint32_t>(); d_offs = (uint64_t*)(((uintptr_t)(d_sizes + nb) + 15) & ~(uintptr_t)15);
+  // lanes in flight per launch: what the scratch holds (267 KB per lane)
+  const uint32_t lanes = nb < 16384u ? nb : 16384u;
+  scratch.reserve((size_t)lanes * sizeof(DeflateScratch));
+  for (uint32_t b0 = 0; b0 < nb; b0 += lanes) {
+    const uint32_t n = nb - b0 < lanes ? nb - b0 : lanes;
+    hipLaunchKernelGGL(k_bgzf_deflate, dim3((n + 63) / 64), dim3(64), 0, s, d_in, len, b0, n, slots.as<uint8_t>(), d_sizes, scratch.as<DeflateScratch>());
+  }
+  hipLaunchKernelGGL(k_bgzf_crc_write, dim3((nb + 3) / 4), dim3(256), 0, s, d_in, len, nb, slots.as<uint8_t>(), (const uint32_t*)d_sizes);
+  // offsets: exclusive scan of the block sizes (widened)
+  {
+    struct Widen { __device__ uint64_t operator()(uint32_t v) const { return (uint64_t)v; } };
+    hipcub::TransformInputIterator<uint64_t, Widen, const uint32_t*> it(d_sizes, Widen());
+    size_t tb = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, it, d_offs, (int)nb, s);
+    c->d_tiles.reserve(tb + 64);
+    hip_check(hipcub::DeviceScan::ExclusiveSum(c->d_tiles.p, tb, it, d_offs, (int)nb, s), "scan block sizes");
+  }
+  uint64_t last_off = 0; uint32_t last_size = 0;
+  hip_check(hipMemcpyAsync(&last_off, d_offs + (nb - 1), 8, hipMemcpyDeviceToHost, s), "D2H");
+  hip_check(hipMemcpyAsync(&last_size, d_sizes + (nb - 1), 4, hipMemcpyDeviceToHost, s), "D2H");
+  hip_check(hipStreamSynchronize(s), "sync");
+  const uint64_t total = last_off + last_size;
+  packed.reserve(total + 64);
+  hipLaunchKernelGGL(k_bgzf_pack, dim3((nb + 3) / 4), dim3(256), 0, s, (const uint8_t*)slots.p, (const uint32_t*)d_sizes, (const uint64_t*)d_offs, nb, packed.as<uint8_t>());
+  hip_check(hipStreamSynchronize(s), "sync");
+  hip_check(hipGetLastError(), "bgzf deflate kernels");
+  *packed_len = total;
   return 0;
 }
 
