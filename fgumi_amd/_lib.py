@@ -73,7 +73,8 @@ class BamRunStats(C.Structure):
                 ("seconds_read", C.c_double), ("seconds_inflate", C.c_double), ("seconds_device", C.c_double), ("seconds_deflate", C.c_double),
                 ("seconds_write", C.c_double), ("seconds_h2d", C.c_double), ("seconds_boundaries", C.c_double), ("seconds_grouping", C.c_double),
                 ("seconds_consensus", C.c_double), ("seconds_d2h", C.c_double), ("seconds_device_inflate", C.c_double),
-                ("boundary_repair_rounds", C.c_uint32), ("device_inflate", C.c_uint32)]
+                ("boundary_repair_rounds", C.c_uint32), ("device_inflate", C.c_uint32), ("seconds_device_deflate", C.c_double),
+                ("device_deflate", C.c_uint32), ("_pad", C.c_uint32)]
 
 
 EXPORTS = ["fgx_options_default", "fgx_create", "fgx_destroy", "fgx_last_error", "fgx_global_error", "fgx_process_batch",

@@ -390,7 +390,7 @@ class _HandleCaller(ConsensusCaller):
     # ---- a BAM file in, a consensus BAM file out (the streaming pipeline of csrc/pipeline.cpp) ---------
     def run_bam(self, in_path: str, out_path: str, header_text: Optional[str] = None, level: int = 1, threads: Optional[int] = None,
                 chunk_raw_bytes: int = 0, tag: str = "MI", cell_tag: Optional[str] = "CB", strip_strand_suffix: bool = False,
-                allow_unmapped: bool = False, host_inflate: bool = False) -> dict:
+                allow_unmapped: bool = False, host_inflate: bool = False, device_deflate: bool = False) -> dict:
         """Reads the grouped BAM `in_path` chunk by chunk (BGZF inflate on the host cores, record boundaries + MI grouping + the
         consensus batch on the device — and the BGZF inflate itself, unless `host_inflate` — BGZF deflate on the host cores) and writes the consensus BAM `out_path`; the stages of
         successive chunks overlap.  Returns the pipeline's counters and stage times."""
@@ -403,7 +403,7 @@ class _HandleCaller(ConsensusCaller):
         o = GroupOptions(tag.encode(), cell_tag.encode() if cell_tag else b"\0\0", int(strip_strand_suffix), int(allow_unmapped))
         st = BamRunStats()
         rc = lib.fgx_run_bam(self._h, in_path.encode(), out_path.encode(), hb.ctypes.data, hb.size, C.byref(o), threads or 0, level,
-                             chunk_raw_bytes, 1 if host_inflate else 0, C.byref(st))
+                             chunk_raw_bytes, (1 if host_inflate else 0) | (2 if device_deflate else 0), C.byref(st))
         if rc != 0:
             raise RuntimeError(lib.fgx_last_error(self._h).decode())
         self._last_stats = ConsensusCallingStats.from_array(st.stats)

@@ -170,6 +170,7 @@ struct Chunk {
   bool last = false;                        // the file's last chunk
   // device inflate: `inf` holds the chunk's COMPRESSED bytes (staged in pinned memory), `dev_blocks` one descriptor per block
   std::vector<fgx::BgzfDevBlock> dev_blocks;
+  bool precompressed = false;               // `packed` already holds the chunk's BGZF blocks (device deflate): the deflate stage passes it on
   uint64_t header_size = 0;                 // first chunk: bytes of the BAM header at the start of the inflated stream (0 = not found)
 };
 
@@ -451,7 +452,7 @@ struct Pipeline {
           if (!enter(3, s)) return;
           const auto t0 = Clock::now();
           Chunk& c = chunks[s % N_CHUNKS];
-          if (!deflate_stream(c.out.p, c.out_len, c.comp, c.comp_size, c.packed, &c.packed_len, c.out.pinned)) { fail("deflate failed"); return; }
+          if (!c.precompressed && !deflate_stream(c.out.p, c.out_len, c.comp, c.comp_size, c.packed, &c.packed_len, c.out.pinned)) { fail("deflate failed"); return; }
           busy[3] += since(t0);
           leave(3);
         }
@@ -516,7 +517,7 @@ thread_local std::string t_perr;
 // longer than a whole chunk's work)
 struct PipeState {
   Pipeline P;
-  fgx::DevBuf D[2], d_off, d_len, d_koff, d_klen, d_grp, d_raw, d_blk;
+  fgx::DevBuf D[2], d_off, d_len, d_koff, d_klen, d_grp, d_raw, d_blk, d_slots, d_dscratch, d_dmeta, d_packed;
 };
 
 }  // namespace
@@ -525,7 +526,7 @@ namespace fgx {
 void pipeline_release(fgx_caller* c) {
   if (!c || !c->pipe_state) return;
   PipeState* S = (PipeState*)c->pipe_state;
-  for (auto* b : {&S->D[0], &S->D[1], &S->d_off, &S->d_len, &S->d_koff, &S->d_klen, &S->d_grp, &S->d_raw, &S->d_blk}) b->free_();
+  for (auto* b : {&S->D[0], &S->D[1], &S->d_off, &S->d_len, &S->d_koff, &S->d_klen, &S->d_grp, &S->d_raw, &S->d_blk, &S->d_slots, &S->d_dscratch, &S->d_dmeta, &S->d_packed}) b->free_();
   delete S;
   c->pipe_state = nullptr;
 }
@@ -566,6 +567,8 @@ int fgx_run_bam(fgx_caller* c, const char* in_path, const char* out_path, const 
     bool header_done = false;
     double sec_h2d = 0, sec_bound = 0, sec_group = 0, sec_cons = 0, sec_d2h = 0, sec_infl = 0;
     const bool device_inflate = !(flags & FGX_RUN_HOST_INFLATE);
+    const bool device_deflate = (flags & FGX_RUN_DEVICE_DEFLATE) != 0 && level == 1;
+    double sec_defl = 0;
     fgx::DevBuf &d_raw = S->d_raw, &d_blk = S->d_blk;
     std::vector<uint8_t> h_blob; std::vector<uint64_t> h_off; std::vector<uint32_t> h_len, h_grp;   // (only for chunks with deferred families)
     Pipeline* P = &S->P;
@@ -573,7 +576,7 @@ int fgx_run_bam(fgx_caller* c, const char* in_path, const char* out_path, const 
     const int rc = P->run(in_path, out_path, out_header, out_header_len, threads, level, chunk_raw_bytes ? chunk_raw_bytes : (512ull << 20), true, device_inflate,
                           [&](Chunk& ch, uint64_t seq) {
       fgx::hip_check(hipSetDevice(c->device), "hipSetDevice");
-      ch.out_len = 0;
+      ch.out_len = 0; ch.packed_len = 0; ch.precompressed = false;
       uint64_t start = 0;
       const uint8_t* src = ch.inf.p;
       uint64_t src_len = ch.inf_len;                           // inflated bytes this chunk adds
@@ -661,7 +664,19 @@ int fgx_run_bam(fgx_caller* c, const char* in_path, const char* out_path, const 
         const void* d_def = nullptr;
         int prc = fgx_process_batch_device(c, D[cur].p, batch_end, d_koff.p, d_klen.p, batch_rec, d_grp.p, batch_grp, &out, &n_def, &d_def);
         if (prc != 0) throw std::runtime_error(c->err);
-        if (n_def == 0) {
+        if (n_def == 0 && device_deflate) {
+          // the records are cut into BGZF blocks and compressed where they lie; an eighth of the bytes comes back
+          sec_cons += since(t0);
+          t0 = Clock::now();
+          uint64_t plen = 0;
+          if (fgx::bgzf_deflate_device(c, (const uint8_t*)out.data, out.data_len, S->d_slots, S->d_dscratch, S->d_dmeta, S->d_packed, &plen) != 0) throw std::runtime_error(c->err);
+          sec_defl += since(t0);
+          t0 = Clock::now();
+          ch.packed.reserve(plen + 64, true);
+          if (plen) fgx::hip_check(hipMemcpy(ch.packed.p, S->d_packed.p, plen, hipMemcpyDeviceToHost), "D2H blocks");
+          ch.packed_len = plen; ch.out_len = out.data_len; ch.precompressed = true;
+          sec_d2h += since(t0);
+        } else if (n_def == 0) {
           sec_cons += since(t0);
           t0 = Clock::now();
           ch.out.reserve(out.data_len + 64, true);
@@ -700,6 +715,7 @@ int fgx_run_bam(fgx_caller* c, const char* in_path, const char* out_path, const 
     st->in_bytes = P->in_bytes; st->inflated_bytes = P->inflated_bytes; st->out_bytes = P->out_bytes; st->out_file_bytes = P->out_file_bytes;
     st->seconds_read = P->busy[0]; st->seconds_inflate = P->busy[1]; st->seconds_device = P->busy[2]; st->seconds_deflate = P->busy[3]; st->seconds_write = P->busy[4];
     st->seconds_device_inflate = sec_infl; st->device_inflate = device_inflate ? 1u : 0u;
+    st->seconds_device_deflate = sec_defl; st->device_deflate = device_deflate ? 1u : 0u;
     st->seconds_h2d = sec_h2d; st->seconds_boundaries = sec_bound; st->seconds_grouping = sec_group; st->seconds_consensus = sec_cons; st->seconds_d2h = sec_d2h;
     st->seconds_total = since(t_begin);
     if (rc != 0) { c->err = P->err; return 1; }

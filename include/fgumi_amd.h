@@ -300,8 +300,13 @@ typedef struct fgx_bam_run_stats {
   double seconds_h2d, seconds_boundaries, seconds_grouping, seconds_consensus, seconds_d2h; /* inside the device stage */
   double seconds_device_inflate;                                                            /* inside the device stage (0 with FGX_RUN_HOST_INFLATE) */
   uint32_t boundary_repair_rounds, device_inflate;
+  double seconds_device_deflate;                                                            /* inside the device stage (FGX_RUN_DEVICE_DEFLATE) */
+  uint32_t device_deflate, _pad;
 } fgx_bam_run_stats;
-#define FGX_RUN_HOST_INFLATE 1u   /* flags: inflate the BGZF blocks on the host cores (zlib) instead of on the device */
+#define FGX_RUN_HOST_INFLATE   1u   /* flags: inflate the BGZF blocks on the host cores (zlib) instead of on the device */
+#define FGX_RUN_DEVICE_DEFLATE 2u   /* flags: compress the consensus records on the device too (level 1 only; fgumi_amd/csrc/deflate_core.h, a lane
+                                       per block): an eighth of the bytes comes back over PCIe and the host only writes.  Off by default: with
+                                       the same compressor on the host's cores the device stage is the one that bounds the pipeline */
 int fgx_run_bam(fgx_caller* c, const char* in_path, const char* out_path, const uint8_t* out_header, uint64_t out_header_len,
                 const fgx_group_options* g, uint32_t threads, int level, uint64_t chunk_raw_bytes, uint32_t flags, fgx_bam_run_stats* st);
 /* The device's DEFLATE decoder (fgumi_amd/csrc/inflate_core.h, one GPU lane per BGZF block) run on the host — the same source, for

@@ -111,6 +111,20 @@ def test_bam_file_to_consensus_bam_file_simplex(tmp_path, host_inflate):
     c.close()
 
 
+def test_bam_file_to_consensus_bam_file_with_device_deflate(tmp_path):
+    """The output side on the device as well (deflate_core.h, a lane per BGZF block, CRC-32 by a wavefront per block): the file must be a
+    valid BGZF BAM whose records equal the oracle's."""
+    g = simulate_grouped_reads(6000, family_size=2, family_size_max=12)
+    c = _caller()
+    st = _run_and_compare(tmp_path, c, fgx_opts.defaults(min_reads=1), g, 50, 1 << 20, device_deflate=True)
+    assert st["device_deflate"] == 1 and st["chunks"] > 1
+    raw = open(str(tmp_path / "consensus.bam"), "rb").read()
+    assert raw[-28:] == bgzf.BGZF_EOF
+    blocks = bgzf.bgzf_block_table(raw)
+    assert len(blocks) > 5 and all(size <= 65536 for _, size in blocks)
+    c.close()
+
+
 def test_device_inflate_refuses_a_corrupted_block(tmp_path):
     g = simulate_grouped_reads(500, family_size=3)
     refs = [("chr1", 1000000)]

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--chunk-mb", type=int, default=512)
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--dir", default="/tmp/fgx_e2e")
+    ap.add_argument("--device-deflate", action="store_true", help="compress the consensus records on the device as well (level 1)")
     ap.add_argument("--host-inflate", action="store_true", help="inflate the BGZF blocks with zlib on the host cores instead of on the device")
     a = ap.parse_args()
     from fgumi_amd import VanillaUmiConsensusCaller, VanillaUmiConsensusOptions, bgzf, simulate_grouped_reads
@@ -46,7 +47,7 @@ def main():
     best = None
     for _ in range(a.reps):
         t = time.perf_counter()
-        st = caller.run_bam(gin, gout, header_text=bgzf.consensus_header("A", "Read group", 0, "fgumi simplex"), threads=T, chunk_raw_bytes=a.chunk_mb << 20, host_inflate=a.host_inflate)
+        st = caller.run_bam(gin, gout, header_text=bgzf.consensus_header("A", "Read group", 0, "fgumi simplex"), threads=T, chunk_raw_bytes=a.chunk_mb << 20, host_inflate=a.host_inflate, device_deflate=a.device_deflate)
         wall = time.perf_counter() - t
         print(f"rep: {wall:.3f} s, boundaries {st['seconds_boundaries']:.3f} s, repair rounds {st['boundary_repair_rounds']}, inflate {st['seconds_inflate']:.3f}, "
               f"deflate {st['seconds_deflate']:.3f}, device {st['seconds_device']:.3f} (inflate there {st['seconds_device_inflate']:.3f}), read {st['seconds_read']:.3f}, write {st['seconds_write']:.3f}", file=sys.stderr)
@@ -54,7 +55,7 @@ def main():
             best = (wall, st)
     wall, st = best
     stages = {k: st["seconds_" + k] for k in ("read", "inflate", "device", "deflate", "write")}
-    inside = {k: st["seconds_" + k] for k in ("h2d", "device_inflate", "boundaries", "grouping", "consensus", "d2h")}
+    inside = {k: st["seconds_" + k] for k in ("h2d", "device_inflate", "boundaries", "grouping", "consensus", "device_deflate", "d2h")}
     print(json.dumps(dict(metric="BAM file in -> consensus BAM file out, simplex, raw reads/s end to end (streaming pipeline)", value=n_rec / wall, unit="raw reads/s",
                           bgzf_inflate=("host cores (zlib)" if a.host_inflate else "device (one lane per block, CRC-32 checked)"), families=a.families, depth=a.depth, raw_reads=n_rec, host_threads=T or "auto (cgroup quota)", chunk_raw_mb=a.chunk_mb, chunks=st["chunks"], total_s=wall,
                           stage_busy_s=stages, device_stage_s=inside, bottleneck=max(stages, key=stages.get),
