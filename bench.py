@@ -13,10 +13,10 @@ N>1 (families are independent → no collective on the data path):
   --scaling strong  ONE 5 M-family stream is cut into contiguous shards of equal record bytes
                     (`distributed.balanced_shards` over the per-family weights), one per rank
   --reassemble      N>1: `value` is the rate with the shard payloads left on their ranks (a writer per rank; output is
-                    SO:unsorted in input order, so rank order IS file order).  `auto` / `root` also time a second loop
-                    in which every step ships the payloads to rank 0 in rank order over RCCL point-to-point — the north
-                    star's single-writer reassembly — and report it beside (`value_with_reassembly_on_root`): one root
-                    receiving 9 GB per rank and step is bound by its xGMI links, not by the kernels.
+                    SO:unsorted in input order, so rank order IS file order).  `root` also times a second loop in which
+                    every step ships the payloads to rank 0 in rank order over RCCL point-to-point — the north star's
+                    single-writer reassembly — and reports it beside (`value_with_reassembly_on_root`): one root receiving
+                    9 GB per rank and step is bound by its xGMI links, not by the kernels.  `auto` (default) = none.
 """
 import argparse
 import glob
@@ -160,7 +160,7 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--reassemble", choices=["auto", "none", "root"], default="auto",
                     help="root: a second timed loop also gathers the shard payloads to rank 0 in rank (= input) order over RCCL, reported beside `value`; "
-                         "auto = root when N > 1")
+                         "auto = none")
     args = ap.parse_args()
     duplex, codec = args.caller == "duplex", args.caller == "codec"
     if args.families is None:
@@ -179,7 +179,9 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl")
-    reassemble = args.reassemble if args.reassemble != "auto" else ("root" if world > 1 else "none")
+    # `auto` = none: the single-writer gather is a second timed loop over RCCL point-to-point that no multi-GPU box has run yet — the
+    # driver's scaling runs get the compute line unconditionally; `--reassemble root` adds the gather figures beside it
+    reassemble = args.reassemble if args.reassemble != "auto" else "none"
 
     from fgumi_amd import (CodecConsensusCaller, CodecConsensusOptions, DuplexConsensusCaller, VanillaUmiConsensusCaller,
                            VanillaUmiConsensusOptions, simulated_family_bytes)
@@ -282,7 +284,8 @@ def main():
                        "families_per_rank": [int(v) for v in per_rank[:, 4].tolist()], "raw_reads_per_rank": [int(v) for v in per_rank[:, 2].tolist()],
                        "input_bytes_per_rank": [int(v) for v in per_rank[:, 5].tolist()], "output_bytes_per_rank": [int(v) for v in per_rank[:, 0].tolist()],
                        "deferred_families": total_def, "output_bytes": total_bytes,
-                       "reassemble": ("none" if reassemble == "none" else "none in `value` (payloads stay on their ranks); gather to rank 0 timed beside"),
+                       "reassemble": ("none (payloads stay on their ranks: a writer per rank; --reassemble root times the single-writer gather beside)" if reassemble == "none"
+                                      else "none in `value` (payloads stay on their ranks); gather to rank 0 timed beside"),
                        "reassembled_bytes_on_rank0": gathered_bytes,
                        "value_with_reassembly_on_root": (total_raw * steps / dt_gather) if dt_gather else None,
                        "ms_per_step_with_reassembly_on_root": (dt_gather / steps * 1e3) if dt_gather else None,
