@@ -164,3 +164,33 @@ def test_run_bam_reports_a_truncated_file(tmp_path):
     with pytest.raises(RuntimeError, match="ends inside a record"):
         c.run_bam(src, str(tmp_path / "out.bam"))
     c.close()
+
+
+def test_run_bam_edge_files(tmp_path):
+    """A header-only file; one family of 300 records (larger than any device kernel takes: the batch goes through the host entry, and with
+    64 KiB chunks the group is the leftover of chunk after chunk until the file ends); records without the group tag in between."""
+    refs = [("chr1", 1000000)]
+    src, dst = str(tmp_path / "in.bam"), str(tmp_path / "out.bam")
+    c = _caller()
+    # header only
+    bgzf.write_bam(src, bgzf.grouped_input_header(refs), refs, b"")
+    st = c.run_bam(src, dst)
+    text, orefs, stream, off, ln = bgzf.read_bam(dst)
+    assert st["consensus_records"] == 0 and len(off) == 0 and text.startswith("@HD")
+    # one big family
+    g = simulate_grouped_reads(1, family_size=150)
+    st = _run_and_compare(tmp_path, c, fgx_opts.defaults(min_reads=1), g, 50, 1 << 16)
+    assert st["chunks"] >= 1 and st["deferred_groups"] == 1
+    # untagged records between the families: MiGrouper skips them (mi_group.rs:285-290)
+    g = simulate_grouped_reads(400, family_size=3)
+    recs = [bytes(g.blob[int(o) - 4:int(o) + int(l)]) for o, l in zip(g.rec_off, g.rec_len)]
+    plain = bamutil.make_record("untagged", "ACGT" * 10, [30] * 40, flag=0, ref_id=0, pos=5)
+    plain = len(plain).to_bytes(4, "little") + plain
+    mixed = b"".join(r + (plain if i % 7 == 3 else b"") for i, r in enumerate(recs))
+    bgzf.write_bam(src, bgzf.grouped_input_header(refs), refs, mixed)
+    st = c.run_bam(src, dst, chunk_raw_bytes=1 << 16)
+    want = orc.process(fgx_opts.defaults(min_reads=1), g.blob, g.rec_off, g.rec_len, g.grp_first)
+    text, orefs, stream, off, ln = bgzf.read_bam(dst)
+    got = b"".join(bytes(stream[int(o) - 4:int(o) + int(l)]) for o, l in zip(off, ln))
+    assert got == want["data"] and st["kept_records"] == g.n_rec
+    c.close()
