@@ -141,7 +141,19 @@ FGX_HD inline void infl_copy_match(uint8_t* dst, uint32_t dist, uint32_t len) {
     return;
   }
   if (dist <= 8) {
-    const uint64_t pat = infl_load64(src);                      // the period: its low `dist` bytes
+    uint64_t pat = infl_load64(src);                            // the period: its low `dist` bytes
+    if ((dist & (dist - 1)) == 0) {
+      // a period of 1, 2, 4 or 8 bytes — byte runs, runs of 16- and 32-bit values: the usual long matches of BAM data — divides the
+      // 8-byte word: the word is the period repeated, and the match is that word stored over and over (the lanes of a wavefront wait
+      // for the one that is copying: a 258-byte run written byte by byte held the other fifteen up for 258 steps)
+      if (dist == 1) pat = (pat & 0xFFull) * 0x0101010101010101ull;
+      else if (dist == 2) pat = (pat & 0xFFFFull) * 0x0001000100010001ull;
+      else if (dist == 4) pat = (pat & 0xFFFFFFFFull) | (pat << 32);
+      uint32_t i = 0;
+      for (; i + 8 <= len; i += 8) memcpy(dst + i, &pat, 8);
+      infl_store_bytes(dst + i, pat, len - i);
+      return;
+    }
     uint32_t ph = 0;
     for (uint32_t i = 0; i < len; i++) { dst[i] = (uint8_t)(pat >> (8 * ph)); ph = ph + 1 == dist ? 0 : ph + 1; }
     return;
