@@ -48,3 +48,26 @@ def test_full_size_sharding_invariance_and_idempotence(kind):
         del dk
     assert off == len(full) and count == out.count and reads == st.total_reads
     c.close()
+
+
+def test_noisy_million_family_batch_stays_on_the_device():
+    """1 M depth-8 families with 3 % substitution errors: a fifth of the columns needs `call_full`, more than the default pool (1/8 of the
+    column bound) holds.  The pool must grow and the batch be run again on the device: nothing deferred, every family two records, and
+    a second pass (with the pool it has learned) identical."""
+    if os.environ.get("FGX_SKIP_FULL_SIZE"):
+        pytest.skip("FGX_SKIP_FULL_SIZE set")
+    import torch
+    from fgumi_amd import VanillaUmiConsensusCaller, VanillaUmiConsensusOptions
+    if torch.cuda.mem_get_info()[1] < 120 * 2**30:
+        pytest.skip("needs a 288 GB-class GPU")
+    c = VanillaUmiConsensusCaller("", "A", VanillaUmiConsensusOptions(min_reads=1, min_consensus_base_quality=2, cell_tag="CB"), overlapping_consensus=True)
+    n = 1_000_000
+    dg = c.simulate_on_device(n, family_size=8, error_rate_ppm=30000)
+    out = c.process_batch_device(dg)
+    assert out.n_deferred == 0 and out.count == 2 * n
+    assert c.last_batch_statistics().total_reads == 16 * n
+    first = out.to_host()
+    again = c.process_batch_device(dg)
+    assert again.n_deferred == 0 and again.to_host() == first
+    c.close()
+
