@@ -2,11 +2,13 @@
 // record stream is produced where the consensus kernels read it.  Stands in, on the device, for the decompress step of
 // crates/fgumi-bgzf/src/reader.rs:346-479 (`decompress_block*`: libdeflater inflate + CRC32 / ISIZE check per block).
 //
-//   k_bgzf_inflate   a LANE per BGZF block (blocks are independent raw DEFLATE streams of at most 64 KiB), sixteen lanes per
+//   k_bgzf_inflate   a LANE per BGZF block (blocks are independent raw DEFLATE streams of at most 64 KiB), eight lanes per
 //                    workgroup: a DEFLATE stream is sequential, so the parallelism is across blocks — a 5 GB chunk has 80 000 of them.
-//                    Each lane keeps its first-level decode tables (inflate_core.h, 1.1 KB) in LDS; 8 workgroups = 128 blocks per CU in flight.
-//                    The lanes of a wavefront diverge (every stream takes its own path); the kernel is bound by the latency of a
-//                    lane's chain of bit-buffer refills and match copies, which is what many blocks in flight hide.
+//                    Each lane keeps its first-level decode tables (inflate_core.h, 1.1 KB) in LDS: 128 blocks per CU in flight, whatever
+//                    the workgroup size.  The lanes of a wavefront diverge (every stream takes its own path) and wait for one another's
+//                    loads, so FEWER lanes per wavefront and more wavefronts per SIMD is the faster split of those 128 (measured,
+//                    5.1 GB in four chunks: 64 lanes 0.196 s, 32 0.165 s, 16 0.144 s, 8 0.129 s); the kernel is bound by the latency
+//                    of one lane's chain of symbols (a 64 KiB block takes ~30 ms), which the blocks in flight hide.
 //   k_bgzf_crc       a WAVEFRONT per block: every lane runs the table-driven CRC-32 over its 1/64 of the block, and the 64 values
 //                    are folded with the polynomial arithmetic of zlib's crc32_combine (slices are aligned to the END of the
 //                    block, so every right-hand operand of the fold is a whole number of full slices).
@@ -20,10 +22,11 @@ namespace fgx {
 namespace {
 
 #ifndef FGX_INFL_LANES
-#define FGX_INFL_LANES 16
+#define FGX_INFL_LANES 8
 #endif
 constexpr uint32_t INFL_LANES = FGX_INFL_LANES;
 
+template <uint32_t INFL_LANES>
 __global__ __launch_bounds__(INFL_LANES) void k_bgzf_inflate(const uint8_t* __restrict__ raw, const BgzfDevBlock* __restrict__ blk, uint32_t n,
                                                              uint8_t* __restrict__ out, uint32_t* __restrict__ status) {
   __shared__ InflateFast sF[INFL_LANES];
@@ -126,6 +129,19 @@ __global__ __launch_bounds__(256) void k_bgzf_crc_write(const uint8_t* __restric
   const uint32_t crc = n ? wave_crc32(in + off, n, tab, lane) : 0u;
   if (lane == 0) { uint8_t* f = slots + (size_t)b * BGZF_SLOT + sizes[b] - 8; f[0] = (uint8_t)crc; f[1] = (uint8_t)(crc >> 8); f[2] = (uint8_t)(crc >> 16); f[3] = (uint8_t)(crc >> 24); }
 }
+// the CRC-32 of every 0xff00-byte piece of `in` (what the HOST's deflate stage would otherwise compute: zlib's crc32 runs at ~1 GB/s
+// per core, half of that stage's time; here the records are still in HBM and a wavefront per block takes a millisecond per gigabyte)
+__global__ __launch_bounds__(256) void k_bgzf_crc_blocks(const uint8_t* __restrict__ in, uint64_t len, uint32_t nb, uint32_t* __restrict__ crcs) {
+  __shared__ uint32_t tab[256];
+  tab[threadIdx.x] = crc32_table_entry(threadIdx.x);
+  __syncthreads();
+  const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (b >= nb) return;
+  const uint64_t off = (uint64_t)b * BGZF_PAYLOAD;
+  const uint32_t n = (uint32_t)(len - off < BGZF_PAYLOAD ? len - off : BGZF_PAYLOAD);
+  const uint32_t crc = n ? wave_crc32(in + off, n, tab, lane) : 0u;
+  if (lane == 0) crcs[b] = crc;
+}
 // a wavefront per block: the slot's bytes to their place in the packed stream
 __global__ __launch_bounds__(256) void k_bgzf_pack(const uint8_t* __restrict__ slots, const uint32_t* __restrict__ sizes, const uint64_t* __restrict__ offs, uint32_t nb,
                                                    uint8_t* __restrict__ packed) {
@@ -142,28 +158,41 @@ __global__ __launch_bounds__(256) void k_bgzf_pack(const uint8_t* __restrict__ s
 
 }  // namespace
 
-// inflates `n` blocks (descriptors in device memory) from d_raw into d_out and checks every block's CRC-32.  Returns 0, or 1 with
-// c->err naming the first failing block.
-int bgzf_inflate_device(fgx_caller* c, const uint8_t* d_raw, const BgzfDevBlock* d_blk, uint32_t n, uint8_t* d_out, uint32_t* d_status) {
-  if (n == 0) return 0;
-  hipStream_t s = c->stream;
+// inflates `n` blocks (descriptors in device memory) from d_raw into d_out and checks every block's CRC-32: the kernels and the
+// copy of the status word (into PINNED host memory, `h_status`) are queued on `s`; nothing waits.  After `s` has drained,
+// bgzf_inflate_status() turns the word into 0, or 1 with c->err naming the first failing block.
+void bgzf_inflate_launch(hipStream_t s, const uint8_t* d_raw, const BgzfDevBlock* d_blk, uint32_t n, uint8_t* d_out, uint32_t* d_status, uint32_t* h_status) {
+  *h_status = 0;
+  if (n == 0) return;
   hip_check(hipMemsetAsync(d_status, 0, 4, s), "memset");
-  hipLaunchKernelGGL(k_bgzf_inflate, dim3((n + INFL_LANES - 1) / INFL_LANES), dim3(INFL_LANES), 0, s, d_raw, d_blk, n, d_out, d_status);
+  static const uint32_t lanes = [] { const char* e = getenv("FGX_INFL_LANES"); const int v = e ? atoi(e) : 0; return (v == 4 || v == 16 || v == 32 || v == 64) ? (uint32_t)v : INFL_LANES; }();   // (a measuring knob: profiles/r03_experiments.md)
+  if (lanes == 4) hipLaunchKernelGGL(k_bgzf_inflate<4>, dim3((n + 3) / 4), dim3(4), 0, s, d_raw, d_blk, n, d_out, d_status);
+  else if (lanes == 16) hipLaunchKernelGGL(k_bgzf_inflate<16>, dim3((n + 15) / 16), dim3(16), 0, s, d_raw, d_blk, n, d_out, d_status);
+  else if (lanes == 32) hipLaunchKernelGGL(k_bgzf_inflate<32>, dim3((n + 31) / 32), dim3(32), 0, s, d_raw, d_blk, n, d_out, d_status);
+  else if (lanes == 64) hipLaunchKernelGGL(k_bgzf_inflate<64>, dim3((n + 63) / 64), dim3(64), 0, s, d_raw, d_blk, n, d_out, d_status);
+  else hipLaunchKernelGGL(k_bgzf_inflate<INFL_LANES>, dim3((n + INFL_LANES - 1) / INFL_LANES), dim3(INFL_LANES), 0, s, d_raw, d_blk, n, d_out, d_status);
   hipLaunchKernelGGL(k_bgzf_crc, dim3((n + 3) / 4), dim3(256), 0, s, (const uint8_t*)d_out, d_blk, n, d_status);
-  uint32_t st = 0;
-  hip_check(hipMemcpyAsync(&st, d_status, 4, hipMemcpyDeviceToHost, s), "D2H");
-  hip_check(hipStreamSynchronize(s), "sync");
+  hip_check(hipMemcpyAsync(h_status, d_status, 4, hipMemcpyDeviceToHost, s), "D2H");
   hip_check(hipGetLastError(), "bgzf inflate kernels");
-  if (st) {
-    static const char* why[] = {"", "bad block type", "bad stored block", "bad code lengths", "bad symbol", "bad distance", "more output than ISIZE",
-                                "input overrun", "fewer bytes than ISIZE", "CRC-32 mismatch"};
-    const uint32_t code = st & 15u;
-    c->err = "BGZF block " + std::to_string((st >> 4) - 1) + " of the chunk failed to inflate on the device: " + (code < 10 ? why[code] : "?");
-    return 1;
-  }
-  return 0;
+}
+int bgzf_inflate_status(fgx_caller* c, uint32_t st) {
+  if (!st) return 0;
+  static const char* why[] = {"", "bad block type", "bad stored block", "bad code lengths", "bad symbol", "bad distance", "more output than ISIZE",
+                              "input overrun", "fewer bytes than ISIZE", "CRC-32 mismatch"};
+  const uint32_t code = st & 15u;
+  c->err = "BGZF block " + std::to_string((st >> 4) - 1) + " of the chunk failed to inflate on the device: " + (code < 10 ? why[code] : "?");
+  return 1;
 }
 
+
+// CRC-32 of every BGZF payload (0xff00 bytes, the last one shorter) of d_in[0 .. len) into d_crcs (device), queued on c->stream.
+// d_in must be readable for 16 bytes past len.
+void bgzf_crc_blocks_device(fgx_caller* c, const uint8_t* d_in, uint64_t len, uint32_t* d_crcs) {
+  const uint32_t nb = (uint32_t)((len + BGZF_PAYLOAD - 1) / BGZF_PAYLOAD);
+  if (!nb) return;
+  hipLaunchKernelGGL(k_bgzf_crc_blocks, dim3((nb + 3) / 4), dim3(256), 0, c->stream, d_in, len, nb, d_crcs);
+  hip_check(hipGetLastError(), "k_bgzf_crc_blocks");
+}
 
 // compresses d_in[0 .. len) into BGZF blocks packed back to back in `packed` (device); `scratch` / `slots` / `meta` are working buffers
 // the caller keeps.  d_in must be readable for 16 bytes past len.  Returns 0 and *packed_len.

@@ -5,7 +5,7 @@
 // Shape: a 64-bit bit buffer refilled with one unaligned 8-byte load, asked for one refill ahead (the input buffer must be READABLE
 // 16 bytes past its end);
 // literal / length and distance codes through small first-level tables (9 and 6 bits: 1.1 KB, in LDS on the device) with the
-// canonical bit-by-bit walk (count[] / symbol[], private memory) for the rare longer codes; output bytes go straight to the destination (matches are copied from there: the window IS the output).
+// canonical bit-by-bit walk for the rare longer codes (its state after the table's bits and the longer lengths' counts in registers, symbol[] in private memory); output bytes go straight to the destination (matches are copied from there: the window IS the output).
 #pragma once
 #include <cstdint>
 #include <cstring>
@@ -99,21 +99,59 @@ FGX_HD inline bool infl_build(const uint8_t* lens, uint32_t n, uint16_t* count, 
   return true;
 }
 
-// one symbol: the first-level table, else the canonical walk (puff.c's decode), bit by bit.  Returns the symbol or -1.
-template <class FastPtr>
-FGX_HD inline int32_t infl_decode(BitReader& r, FastPtr fast, uint32_t fast_bits, const uint16_t* count, const uint16_t* sym) {
-  const uint32_t e = fast[(uint32_t)r.bb & ((1u << fast_bits) - 1u)];
+// What the canonical walk (puff.c's decode) needs for the codes LONGER than the first-level table, held in registers: the walk's state
+// after the table's K bits (first code / first symbol index of length K + 1) and the counts of the lengths K + 1 .. 15, two per word.
+// (The walk used to start at bit 1 and read count[] from private memory — a global-memory round trip per bit, and with sixteen lanes
+// decoding in step nearly every step had a lane on it.)
+struct InflWalk { uint32_t first, index; uint32_t cnt[5]; };
+FGX_HD inline void infl_walk_setup(const uint16_t* count, uint32_t K, InflWalk& w) {
+  uint32_t first = 0, index = 0;
+  for (uint32_t l = 1; l <= K; l++) { index += count[l]; first = (first + count[l]) << 1; }
+  w.first = first; w.index = index;
+  for (uint32_t j = 0; j < 5; j++) {
+    const uint32_t l0 = K + 1 + 2 * j, l1 = l0 + 1;
+    w.cnt[j] = (l0 <= 15 ? (uint32_t)count[l0] : 0u) | ((l1 <= 15 ? (uint32_t)count[l1] : 0u) << 16);
+  }
+}
+// one symbol: the first-level table (K peeked bits), else the walk from bit K + 1 on.  Returns the symbol or -1.
+template <uint32_t K, class FastPtr>
+FGX_HD inline int32_t infl_decode(BitReader& r, FastPtr fast, const InflWalk& w, const uint16_t* sym) {
+  static_assert(K >= 5 && K <= 14, "InflWalk holds the counts of at most ten lengths");
+  const uint32_t e = fast[(uint32_t)r.bb & ((1u << K) - 1u)];
   if (e & 15u) { const uint32_t l = e & 15u; r.bb >>= l; r.bc -= l; return (int32_t)(e >> 4); }
-  int32_t code = 0, first = 0, index = 0;
-  for (uint32_t l = 1; l <= 15; l++) {
+  // the K bits already seen, first bit highest (a Huffman code is read from its most significant bit), times two: where the walk stands
+  int32_t code = (int32_t)((__builtin_bitreverse32((uint32_t)r.bb) >> (32u - K)) << 1);
+  r.bb >>= K; r.bc -= K;
+  int32_t first = (int32_t)w.first, index = (int32_t)w.index;
+#pragma unroll
+  for (uint32_t j = 0; j < 15u - K; j++) {
     code |= (int32_t)(r.bb & 1u);
     r.bb >>= 1; r.bc -= 1;
-    const int32_t cnt = (int32_t)count[l];
+    const int32_t cnt = (int32_t)((w.cnt[j >> 1] >> (16u * (j & 1u))) & 0xFFFFu);
     if (code - cnt < first) return (int32_t)sym[index + (code - first)];
     index += cnt; first += cnt; first <<= 1; code <<= 1;
   }
   return -1;
 }
+
+// base value and extra bits of a length symbol (257 .. 285, here minus 257) and of a distance symbol (RFC 1951 3.2.5), computed: a
+// table indexed by a lane's own symbol is a global-memory load on the device, two dependent ones per match.
+FGX_HD constexpr uint32_t infl_len_extra(uint32_t s) { return (s < 8u || s == 28u) ? 0u : (s - 4u) >> 2; }
+FGX_HD constexpr uint32_t infl_len_base(uint32_t s) { return s < 8u ? 3u + s : s == 28u ? 258u : 3u + ((4u + (s & 3u)) << ((s - 4u) >> 2)); }
+FGX_HD constexpr uint32_t infl_dist_extra(uint32_t d) { return d < 4u ? 0u : (d - 2u) >> 1; }
+FGX_HD constexpr uint32_t infl_dist_base(uint32_t d) { return d < 4u ? 1u + d : 1u + ((2u + (d & 1u)) << ((d - 2u) >> 1)); }
+namespace infl_detail {
+constexpr uint16_t LEN_BASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+constexpr uint8_t LEN_EXTRA[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+constexpr uint16_t DIST_BASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+constexpr uint8_t DIST_EXTRA[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+constexpr bool formulas_match_rfc1951() {
+  for (uint32_t s = 0; s < 29; s++) if (infl_len_base(s) != LEN_BASE[s] || infl_len_extra(s) != LEN_EXTRA[s]) return false;
+  for (uint32_t d = 0; d < 30; d++) if (infl_dist_base(d) != DIST_BASE[d] || infl_dist_extra(d) != DIST_EXTRA[d]) return false;
+  return true;
+}
+static_assert(formulas_match_rfc1951(), "length / distance formulas against the RFC's tables");
+}  // namespace infl_detail
 
 // A match: `len` bytes (3 .. 258) from `dist` bytes back.  Written so that NO load depends on a store of the same match — on the
 // device every dependent load -> store -> load step is a memory round trip of most of a microsecond, and a byte-by-byte copy made
@@ -162,18 +200,23 @@ FGX_HD inline void infl_copy_match(uint8_t* dst, uint32_t dist, uint32_t len) {
   for (uint32_t i = 0; i < len; i++) { dst[i] = src[ph]; ph = ph + 1 == dist ? 0 : ph + 1; }
 }
 
+FGX_HD inline void infl_store_pending(uint8_t* dst, uint32_t n, uint64_t v0, uint64_t v1, uint64_t v2, uint64_t v3) {     // n <= 32 bytes
+  if (n >= 8) memcpy(dst, &v0, 8); else { infl_store_bytes(dst, v0, n); return; }
+  if (n >= 16) memcpy(dst + 8, &v1, 8); else { infl_store_bytes(dst + 8, v1, n - 8); return; }
+  if (n >= 24) memcpy(dst + 16, &v2, 8); else { infl_store_bytes(dst + 16, v2, n - 16); return; }
+  if (n >= 32) memcpy(dst + 24, &v3, 8); else infl_store_bytes(dst + 24, v3, n - 24);
+}
+
 // inflates `in[0 .. in_len)` into `out[0 .. out_len)`; the stream must produce exactly out_len bytes (the block's ISIZE).
 // `in` must be readable for 16 bytes past in_len.  F / W: this lane's tables (LDS / private memory on the device).
 template <class FastPtr>
 FGX_HD inline int inflate_block_t(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, FastPtr f_lit, FastPtr f_dist, InflateSlow& W) {
   constexpr uint32_t LB = FGX_INFL_LIT_BITS, DB = FGX_INFL_DIST_BITS;
-  static constexpr uint16_t LEN_BASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-  static constexpr uint8_t LEN_EXTRA[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-  static constexpr uint16_t DIST_BASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-  static constexpr uint8_t DIST_EXTRA[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
   static constexpr uint8_t CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
   BitReader r{in, in_len, 0u, 0ull, 0u, 0ull};
   infl_seek(r, 0);
+  uint64_t pv0 = 0, pv1 = 0, pv2 = 0, pv3 = 0;                                  // a match whose bytes are loaded and not stored yet (p_len of them at p_pos)
+  uint32_t p_pos = 0, p_len = 0;
   uint32_t pos = 0;
   for (;;) {
     infl_refill(r);
@@ -212,10 +255,12 @@ FGX_HD inline int inflate_block_t(const uint8_t* in, uint32_t in_len, uint8_t* o
         for (uint32_t i = 0; i < hclen; i++) { if (r.bc < 3) infl_refill(r); cl[CL_ORDER[i]] = (uint8_t)infl_bits(r, 3); }
         // the code-length code: its tables live in the distance slots for the moment (19 symbols, up to 7 bits)
         if (!infl_build(cl, 19, W.dist_count, W.dist_sym, f_dist, DB)) return INFL_BAD_CODE_LENGTHS;
+        InflWalk wc;
+        infl_walk_setup(W.dist_count, DB, wc);
         uint32_t n = 0;
         while (n < hlit + hdist) {
           if (r.bc < 32) infl_refill(r);
-          const int32_t s = infl_decode(r, f_dist, DB, W.dist_count, W.dist_sym);
+          const int32_t s = infl_decode<DB>(r, f_dist, wc, W.dist_sym);
           if (s < 0) return INFL_BAD_CODE_LENGTHS;
           if (s < 16) lens[n++] = (uint8_t)s;
           else {
@@ -231,25 +276,44 @@ FGX_HD inline int inflate_block_t(const uint8_t* in, uint32_t in_len, uint8_t* o
       }
       if (!infl_build(lens, hlit, W.lit_count, W.lit_sym, f_lit, LB)) return INFL_BAD_CODE_LENGTHS;
       if (!infl_build(lens + hlit, hdist, W.dist_count, W.dist_sym, f_dist, DB)) return INFL_BAD_CODE_LENGTHS;
+      InflWalk wl, wd;
+      infl_walk_setup(W.lit_count, LB, wl);
+      infl_walk_setup(W.dist_count, DB, wd);
       for (;;) {
         if (r.bc < 48) infl_refill(r);                 // a length + distance pair takes at most 15 + 5 + 15 + 13 = 48 bits
-        int32_t s = infl_decode(r, f_lit, LB, W.lit_count, W.lit_sym);
+        int32_t s = infl_decode<LB>(r, f_lit, wl, W.lit_sym);
         if (s < 0) return INFL_BAD_SYMBOL;
         if (s < 256) {
           if (pos >= out_len) return INFL_OUTPUT_OVERFLOW;
           out[pos++] = (uint8_t)s;
           continue;
         }
-        if (s == 256) break;
+        if (s == 256) { if (p_len) { infl_store_pending(out + p_pos, p_len, pv0, pv1, pv2, pv3); p_len = 0; } break; }
         s -= 257;
         if (s >= 29) return INFL_BAD_SYMBOL;
-        const uint32_t len = LEN_BASE[s] + infl_bits(r, LEN_EXTRA[s]);
-        const int32_t d = infl_decode(r, f_dist, DB, W.dist_count, W.dist_sym);
+        const uint32_t len = infl_len_base((uint32_t)s) + infl_bits(r, infl_len_extra((uint32_t)s));
+        const int32_t d = infl_decode<DB>(r, f_dist, wd, W.dist_sym);
         if (d < 0 || d >= 30) return INFL_BAD_DISTANCE;
-        const uint32_t dist = DIST_BASE[d] + infl_bits(r, DIST_EXTRA[d]);
+        const uint32_t dist = infl_dist_base((uint32_t)d) + infl_bits(r, infl_dist_extra((uint32_t)d));
         if (dist > pos) return INFL_BAD_DISTANCE;
         if (pos + len > out_len) return INFL_OUTPUT_OVERFLOW;
-        infl_copy_match(out + pos, dist, len);
+        if (dist >= len && len <= 32) {
+          // a short match whose source lies wholly before it (most matches): its bytes are LOADED now and STORED when the next match
+          // arrives (or the block ends) — a wavefront's lanes run the loop in step, nearly every step has a lane with a match, and
+          // waiting for the match's source inside the step made every step a global-memory round trip.  The stores of the match
+          // before go out first, so a source that overlaps that match's destination reads what was just stored (a wavefront's memory
+          // operations keep their order).
+          if (p_len) infl_store_pending(out + p_pos, p_len, pv0, pv1, pv2, pv3);
+          const uint8_t* src = out + pos - dist;
+          pv0 = infl_load64(src);
+          pv1 = len > 8 ? infl_load64(src + 8) : 0ull;
+          pv2 = len > 16 ? infl_load64(src + 16) : 0ull;
+          pv3 = len > 24 ? infl_load64(src + 24) : 0ull;
+          p_pos = pos; p_len = len;
+        } else {
+          if (p_len) { infl_store_pending(out + p_pos, p_len, pv0, pv1, pv2, pv3); p_len = 0; }
+          infl_copy_match(out + pos, dist, len);
+        }
         pos += len;
       }
     } else return INFL_BAD_BLOCK_TYPE;

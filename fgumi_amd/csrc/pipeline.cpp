@@ -170,6 +170,8 @@ struct Chunk {
   bool last = false;                        // the file's last chunk
   // device inflate: `inf` holds the chunk's COMPRESSED bytes (staged in pinned memory), `dev_blocks` one descriptor per block
   std::vector<fgx::BgzfDevBlock> dev_blocks;
+  std::vector<uint32_t> crcs;               // CRC-32 of every 0xff00-byte piece of `out`, computed on the device while the records were still there
+  bool have_crcs = false;
   bool precompressed = false;               // `packed` already holds the chunk's BGZF blocks (device deflate): the deflate stage passes it on
   uint64_t header_size = 0;                 // first chunk: bytes of the BAM header at the start of the inflated stream (0 = not found)
 };
@@ -245,6 +247,11 @@ struct Pipeline {
     std::lock_guard<std::mutex> l(m);
     progress[k]++;
     cv.notify_all();
+  }
+  // has chunk `s` left the stage / inflate stage already?  (the device stage looks one chunk ahead without waiting for it)
+  bool staged(uint64_t s) {
+    std::lock_guard<std::mutex> l(m);
+    return !failed && s < n_chunks_total && progress[1] > s;
   }
 
   int run(const char* in_path, const char* out_path, const uint8_t* out_header, uint64_t out_header_len, unsigned threads, int level,
@@ -395,7 +402,7 @@ struct Pipeline {
     std::vector<uint8_t> dscratch((size_t)n_workers * BGZF_SLOT + 64);
     std::vector<std::unique_ptr<fgx::DeflateScratch>> dstate(n_workers);
     auto deflate_stream = [&](const uint8_t* src, uint64_t len, HostBuf& comp, std::vector<uint32_t>& sizes, HostBuf& packed, uint64_t* packed_len,
-                              bool use_scratch) -> bool {
+                              bool use_scratch, const uint32_t* crcs) -> bool {
       const size_t nb = (size_t)((len + BGZF_PAYLOAD - 1) / BGZF_PAYLOAD);
       comp.reserve(nb * BGZF_SLOT + 64, false);
       sizes.assign(nb, 0);
@@ -432,7 +439,7 @@ struct Pipeline {
         const uint32_t bsize = 18 + csize + 8 - 1;
         const uint8_t hdr[18] = {0x1F, 0x8B, 8, 4, 0, 0, 0, 0, 0, 0xFF, 6, 0, 'B', 'C', 2, 0, (uint8_t)bsize, (uint8_t)(bsize >> 8)};
         memcpy(blk, hdr, 18);
-        const uint32_t crc = (uint32_t)crc32(0L, in, n);
+        const uint32_t crc = crcs ? crcs[i] : (uint32_t)crc32(0L, in, n);   // (zlib's crc32: ~1 GB/s per core — as much time as the compressor takes)
         memcpy(blk + 18 + csize, &crc, 4);
         memcpy(blk + 18 + csize + 4, &n, 4);
         sizes[i] = bsize + 1;
@@ -452,7 +459,7 @@ struct Pipeline {
           if (!enter(3, s)) return;
           const auto t0 = Clock::now();
           Chunk& c = chunks[s % N_CHUNKS];
-          if (!c.precompressed && !deflate_stream(c.out.p, c.out_len, c.comp, c.comp_size, c.packed, &c.packed_len, c.out.pinned)) { fail("deflate failed"); return; }
+          if (!c.precompressed && !deflate_stream(c.out.p, c.out_len, c.comp, c.comp_size, c.packed, &c.packed_len, c.out.pinned, c.have_crcs ? c.crcs.data() : nullptr)) { fail("deflate failed"); return; }
           busy[3] += since(t0);
           leave(3);
         }
@@ -466,7 +473,7 @@ struct Pipeline {
           HostBuf hc, hp; std::vector<uint32_t> hs;
           uint64_t hl = 0;
           if (out_header_len) {
-            if (!deflate_stream(out_header, out_header_len, hc, hs, hp, &hl, false)) { fail("deflate failed"); return; }
+            if (!deflate_stream(out_header, out_header_len, hc, hs, hp, &hl, false, nullptr)) { fail("deflate failed"); return; }
             put(hp.p, hl);
           }
         }
@@ -517,7 +524,11 @@ thread_local std::string t_perr;
 // longer than a whole chunk's work)
 struct PipeState {
   Pipeline P;
-  fgx::DevBuf D[2], d_off, d_len, d_koff, d_klen, d_grp, d_raw, d_blk, d_slots, d_dscratch, d_dmeta, d_packed;
+  fgx::DevBuf D[2], d_off, d_len, d_koff, d_klen, d_grp, d_raw, d_blk, d_slots, d_dscratch, d_dmeta, d_packed, d_crcs;
+  uint64_t pad[2] = {0, 0};          // bytes of D[i] in front of a chunk's inflated stream: room for what the chunk before it leaves over
+  hipStream_t s_in = nullptr;        // uploads and inflates the NEXT chunk while the device stage works on this one
+  hipEvent_t ev_up0 = nullptr, ev_up1 = nullptr, ev_in = nullptr;   // upload begins / upload done / stream inflated and checked
+  uint32_t* h_status = nullptr;      // (pinned) the inflate kernels' status word
 };
 
 }  // namespace
@@ -526,7 +537,10 @@ namespace fgx {
 void pipeline_release(fgx_caller* c) {
   if (!c || !c->pipe_state) return;
   PipeState* S = (PipeState*)c->pipe_state;
-  for (auto* b : {&S->D[0], &S->D[1], &S->d_off, &S->d_len, &S->d_koff, &S->d_klen, &S->d_grp, &S->d_raw, &S->d_blk, &S->d_slots, &S->d_dscratch, &S->d_dmeta, &S->d_packed}) b->free_();
+  for (auto* b : {&S->D[0], &S->D[1], &S->d_off, &S->d_len, &S->d_koff, &S->d_klen, &S->d_grp, &S->d_raw, &S->d_blk, &S->d_slots, &S->d_dscratch, &S->d_dmeta, &S->d_packed, &S->d_crcs}) b->free_();
+  if (S->s_in) { (void)hipStreamSynchronize(S->s_in); (void)hipStreamDestroy(S->s_in); }
+  for (hipEvent_t e : {S->ev_up0, S->ev_up1, S->ev_in}) if (e) (void)hipEventDestroy(e);
+  if (S->h_status) (void)hipHostFree(S->h_status);
   delete S;
   c->pipe_state = nullptr;
 }
@@ -562,7 +576,16 @@ int fgx_run_bam(fgx_caller* c, const char* in_path, const char* out_path, const 
     PipeState* S = (PipeState*)c->pipe_state;
     fgx::DevBuf* D = S->D;
     fgx::DevBuf &d_off = S->d_off, &d_len = S->d_len, &d_koff = S->d_koff, &d_klen = S->d_klen, &d_grp = S->d_grp;
-    uint64_t left_len = 0;                 // bytes the previous chunk left at the front of D[cur]
+    if (!S->s_in) {
+      fgx::hip_check(hipStreamCreateWithFlags(&S->s_in, hipStreamNonBlocking), "hipStreamCreate");
+      for (hipEvent_t* e : {&S->ev_up0, &S->ev_up1, &S->ev_in}) fgx::hip_check(hipEventCreate(e), "hipEventCreate");
+      fgx::hip_check(hipHostMalloc((void**)&S->h_status, 64, hipHostMallocDefault), "hipHostMalloc");
+    }
+    // Layout of D[i]: [ front pad | the chunk's inflated stream | slack ].  What a chunk leaves over (its last MI group and the
+    // partial record behind it) is copied to the END of the other buffer's pad, so the next chunk's stream can be uploaded and
+    // inflated to a fixed place BEFORE that length is known — on s_in, under this chunk's boundaries / grouping / consensus / download.
+    const uint64_t FRONT_PAD = [] { const char* e = getenv("FGX_FRONT_PAD"); const long long v = e ? atoll(e) : 0; return v >= 256 ? ((uint64_t)v + 255) & ~255ull : 8ull << 20; }();   // (the variable: for the test of the widening path)
+    uint64_t left_len = 0;                 // bytes the previous chunk left in front of D[cur]'s stream
     int cur = 0;
     bool header_done = false;
     double sec_h2d = 0, sec_bound = 0, sec_group = 0, sec_cons = 0, sec_d2h = 0, sec_infl = 0;
@@ -573,60 +596,99 @@ int fgx_run_bam(fgx_caller* c, const char* in_path, const char* out_path, const 
     std::vector<uint8_t> h_blob; std::vector<uint64_t> h_off; std::vector<uint32_t> h_len, h_grp;   // (only for chunks with deferred families)
     Pipeline* P = &S->P;
     P->reset();
+    bool ahead = false;                    // the chunk after the one in the device stage is already on its way into D[cur ^ 1]
+    uint64_t ahead_seq = 0, ahead_inf_len = 0;
+    // room for a stream of inf_len bytes behind the pad of D[buf]; `preserve` bytes at the end of the pad survive a regrowth
+    auto ensure_room = [&](int buf, uint64_t inf_len, uint64_t preserve) {
+      if (!S->pad[buf] || !D[buf].cap) S->pad[buf] = FRONT_PAD;
+      if (S->pad[buf] + inf_len + 64 <= D[buf].cap) return;
+      fgx::DevBuf bigger;
+      bigger.reserve(S->pad[buf] + inf_len + inf_len / 4 + 64);
+      if (preserve) fgx::hip_check(hipMemcpy((uint8_t*)bigger.p + S->pad[buf] - preserve, (const uint8_t*)D[buf].p + S->pad[buf] - preserve, preserve, hipMemcpyDeviceToDevice), "D2D leftover");
+      D[buf].free_();
+      D[buf] = bigger;
+    };
+    // a wider pad for D[buf] (a leftover larger than the pad: one enormous MI group); `stream_len` bytes of stream are kept
+    auto widen_pad = [&](int buf, uint64_t keep, uint64_t stream_len, uint64_t next_len) {
+      const uint64_t new_pad = (keep + keep / 4 + 255) & ~255ull;
+      fgx::DevBuf bigger;
+      bigger.reserve(new_pad + next_len + next_len / 4 + 64);
+      if (stream_len) fgx::hip_check(hipMemcpy((uint8_t*)bigger.p + new_pad, (const uint8_t*)D[buf].p + S->pad[buf], stream_len, hipMemcpyDeviceToDevice), "D2D stream");
+      D[buf].free_();
+      D[buf] = bigger;
+      S->pad[buf] = new_pad;
+    };
+    // chunk `ch` into D[buf]: the compressed bytes and block descriptors over PCIe, DEFLATE + CRC-32 on the device (or, with
+    // FGX_RUN_HOST_INFLATE, the inflated bytes over PCIe) — queued on s_in, ev_in marks the end
+    auto launch_fill = [&](Chunk& ch, int buf, uint64_t preserve) {
+      ensure_room(buf, ch.inf_len, preserve);
+      uint8_t* dst = (uint8_t*)D[buf].p + S->pad[buf];
+      hipStream_t si = S->s_in;
+      fgx::hip_check(hipEventRecord(S->ev_up0, si), "hipEventRecord");
+      if (device_inflate) {
+        const size_t blk_bytes = ch.dev_blocks.size() * sizeof(fgx::BgzfDevBlock);
+        d_raw.reserve(ch.raw_len + 64);
+        d_blk.reserve(blk_bytes + 64 + 16);
+        fgx::hip_check(hipMemcpyAsync(d_raw.p, ch.inf.p, ch.raw_len + 64, hipMemcpyHostToDevice, si), "H2D compressed chunk");
+        if (blk_bytes) fgx::hip_check(hipMemcpyAsync(d_blk.p, ch.dev_blocks.data(), blk_bytes, hipMemcpyHostToDevice, si), "H2D block table");
+        fgx::hip_check(hipEventRecord(S->ev_up1, si), "hipEventRecord");
+        fgx::bgzf_inflate_launch(si, d_raw.as<uint8_t>(), d_blk.as<fgx::BgzfDevBlock>(), (uint32_t)ch.dev_blocks.size(), dst,
+                                 (uint32_t*)((uint8_t*)d_blk.p + ((blk_bytes + 15) & ~(size_t)15)), S->h_status);
+      } else {
+        *S->h_status = 0;
+        if (ch.inf_len) fgx::hip_check(hipMemcpyAsync(dst, ch.inf.p, ch.inf_len, hipMemcpyHostToDevice, si), "H2D chunk");
+        fgx::hip_check(hipEventRecord(S->ev_up1, si), "hipEventRecord");
+      }
+      fgx::hip_check(hipEventRecord(S->ev_in, si), "hipEventRecord");
+    };
     const int rc = P->run(in_path, out_path, out_header, out_header_len, threads, level, chunk_raw_bytes ? chunk_raw_bytes : (512ull << 20), true, device_inflate,
                           [&](Chunk& ch, uint64_t seq) {
       fgx::hip_check(hipSetDevice(c->device), "hipSetDevice");
-      ch.out_len = 0; ch.packed_len = 0; ch.precompressed = false;
-      uint64_t start = 0;
-      const uint8_t* src = ch.inf.p;
-      uint64_t src_len = ch.inf_len;                           // inflated bytes this chunk adds
+      ch.out_len = 0; ch.packed_len = 0; ch.precompressed = false; ch.have_crcs = false;
+      // ---- this chunk's stream: started while the chunk before was worked on, or now ----
+      if (!(ahead && ahead_seq == seq)) launch_fill(ch, cur, left_len);
+      ahead = false;
+      fgx::hip_check(hipEventSynchronize(S->ev_in), "hipEventSynchronize");
+      {
+        float ms_up = 0, ms_in = 0;
+        fgx::hip_check(hipEventElapsedTime(&ms_up, S->ev_up0, S->ev_up1), "hipEventElapsedTime");
+        fgx::hip_check(hipEventElapsedTime(&ms_in, S->ev_up1, S->ev_in), "hipEventElapsedTime");
+        sec_h2d += ms_up * 1e-3;
+        if (device_inflate) sec_infl += ms_in * 1e-3;
+      }
+      if (fgx::bgzf_inflate_status(c, *S->h_status) != 0) throw std::runtime_error(c->err);
+      uint64_t h = 0;
       if (!header_done) {
-        const uint64_t h = device_inflate ? ch.header_size : bam_header_size(src, src_len);
+        h = device_inflate ? ch.header_size : bam_header_size(ch.inf.p, ch.inf_len);
         if (h == 0) {
-          if (ch.last && src_len == 0) return;                 // an empty file
+          if (ch.last && ch.inf_len == 0) return;              // an empty file
           throw std::runtime_error("the first chunk does not hold the whole BAM header (not a BAM file, or chunk_raw_bytes too small)");
         }
-        if (device_inflate) start = h;                         // (the header is inflated with the rest and skipped by offset)
-        else { src += h; src_len -= h; }
-        header_done = true;
+        header_done = true;                                    // (the header is uploaded / inflated with the rest and skipped by offset)
       }
-      const uint64_t total = left_len + src_len;
-      if (total + 64 > D[cur].cap) {                           // grow, keeping what the previous chunk left at the front
-        fgx::DevBuf bigger;
-        bigger.reserve(total + total / 4 + 64);
-        if (left_len) fgx::hip_check(hipMemcpy(bigger.p, D[cur].p, left_len, hipMemcpyDeviceToDevice), "D2D leftover");
-        D[cur].free_();
-        D[cur] = bigger;
-      }
+      // the stream the kernels see starts at a 256-byte boundary at or before the leftover; `start` skips what lies in between
+      const uint64_t lead = S->pad[cur] - left_len, base_off = lead & ~255ull;
+      uint8_t* const base = (uint8_t*)D[cur].p + base_off;
+      const uint64_t start = (lead - base_off) + h;
+      const uint64_t total = (lead - base_off) + left_len + ch.inf_len;
+      // ---- the next chunk, if the host stages have it ready: upload + inflate under everything below ----
+      auto try_ahead = [&] {
+        if (ahead || ch.last || !P->staged(seq + 1)) return;
+        Chunk& nx = P->chunks[(seq + 1) % Pipeline::N_CHUNKS];
+        launch_fill(nx, cur ^ 1, 0);
+        ahead = true; ahead_seq = seq + 1; ahead_inf_len = nx.inf_len;
+      };
+      try_ahead();
       auto t0 = Clock::now();
-      if (device_inflate) {
-        // compressed bytes + block descriptors over PCIe, DEFLATE + CRC-32 on the device, straight behind the leftover
-        d_raw.reserve(ch.raw_len + 64);
-        d_blk.reserve(ch.dev_blocks.size() * sizeof(fgx::BgzfDevBlock) + 64);
-        fgx::hip_check(hipMemcpyAsync(d_raw.p, ch.inf.p, ch.raw_len + 64, hipMemcpyHostToDevice, s), "H2D compressed chunk");
-        if (!ch.dev_blocks.empty())
-          fgx::hip_check(hipMemcpyAsync(d_blk.p, ch.dev_blocks.data(), ch.dev_blocks.size() * sizeof(fgx::BgzfDevBlock), hipMemcpyHostToDevice, s), "H2D block table");
-        fgx::hip_check(hipStreamSynchronize(s), "sync");
-        sec_h2d += since(t0);
-        t0 = Clock::now();
-        if (fgx::bgzf_inflate_device(c, d_raw.as<uint8_t>(), d_blk.as<fgx::BgzfDevBlock>(), (uint32_t)ch.dev_blocks.size(), (uint8_t*)D[cur].p + left_len,
-                                     (uint32_t*)((uint8_t*)d_blk.p + ((ch.dev_blocks.size() * sizeof(fgx::BgzfDevBlock) + 15) & ~(size_t)15))) != 0)
-          throw std::runtime_error(c->err);
-        sec_infl += since(t0);
-      } else {
-        if (src_len) fgx::hip_check(hipMemcpyAsync((uint8_t*)D[cur].p + left_len, src, src_len, hipMemcpyHostToDevice, s), "H2D chunk");
-        fgx::hip_check(hipStreamSynchronize(s), "sync");
-        sec_h2d += since(t0);
-      }
       // ---- record boundaries ----
       t0 = Clock::now();
       uint64_t n_rec = 0, consumed = 0;
       const uint64_t cap_guess = total / 64 + 16;              // (a record is at least 36 bytes; typical libraries: 200 - 400)
       d_off.reserve(cap_guess * 8); d_len.reserve(cap_guess * 4);
-      int brc = fgx::record_boundaries_device(c, D[cur].as<uint8_t>(), total, start, d_off.as<uint64_t>(), d_len.as<uint32_t>(), cap_guess, &n_rec, &consumed);
+      int brc = fgx::record_boundaries_device(c, base, total, start, d_off.as<uint64_t>(), d_len.as<uint32_t>(), cap_guess, &n_rec, &consumed);
       if (brc == 2) {
         d_off.reserve(n_rec * 8 + 64); d_len.reserve(n_rec * 4 + 64);
-        brc = fgx::record_boundaries_device(c, D[cur].as<uint8_t>(), total, start, d_off.as<uint64_t>(), d_len.as<uint32_t>(), n_rec, &n_rec, &consumed);
+        brc = fgx::record_boundaries_device(c, base, total, start, d_off.as<uint64_t>(), d_len.as<uint32_t>(), n_rec, &n_rec, &consumed);
       }
       if (brc != 0) throw std::runtime_error(c->err);
       st->boundary_repair_rounds += c->last_boundary_rounds;
@@ -638,7 +700,7 @@ int fgx_run_bam(fgx_caller* c, const char* in_path, const char* out_path, const 
       uint32_t n_kept = 0, n_grp = 0;
       d_koff.reserve(n_rec * 8 + 64); d_klen.reserve(n_rec * 4 + 64); d_grp.reserve((n_rec + 2) * 4);
       if (n_rec) {
-        const int grc = fgx::group_records_device(c, g, D[cur].as<uint8_t>(), total, d_off.as<uint64_t>(), d_len.as<uint32_t>(), (uint32_t)n_rec,
+        const int grc = fgx::group_records_device(c, g, base, total, d_off.as<uint64_t>(), d_len.as<uint32_t>(), (uint32_t)n_rec,
                                                   d_koff.as<uint64_t>(), d_klen.as<uint32_t>(), d_grp.as<uint32_t>(), &n_kept, &n_grp);
         if (grc != 0) throw std::runtime_error(c->err);
       }
@@ -662,7 +724,7 @@ int fgx_run_bam(fgx_caller* c, const char* in_path, const char* out_path, const 
         memset(&out, 0, sizeof(out));
         uint32_t n_def = 0;
         const void* d_def = nullptr;
-        int prc = fgx_process_batch_device(c, D[cur].p, batch_end, d_koff.p, d_klen.p, batch_rec, d_grp.p, batch_grp, &out, &n_def, &d_def);
+        int prc = fgx_process_batch_device(c, base, batch_end, d_koff.p, d_klen.p, batch_rec, d_grp.p, batch_grp, &out, &n_def, &d_def);
         if (prc != 0) throw std::runtime_error(c->err);
         if (n_def == 0 && device_deflate) {
           // the records are cut into BGZF blocks and compressed where they lie; an eighth of the bytes comes back
@@ -679,15 +741,25 @@ int fgx_run_bam(fgx_caller* c, const char* in_path, const char* out_path, const 
         } else if (n_def == 0) {
           sec_cons += since(t0);
           t0 = Clock::now();
+          // the records come back into pinned memory, and with them the CRC-32 of every BGZF payload they will be cut into (a
+          // wavefront per 0xff00 bytes while they are still in HBM: the host's deflate stage is left with the compressor alone)
           ch.out.reserve(out.data_len + 64, true);
-          if (out.data_len) fgx::hip_check(hipMemcpy(ch.out.p, out.data, out.data_len, hipMemcpyDeviceToHost), "D2H records");
-          ch.out_len = out.data_len;
+          const size_t nb = (size_t)((out.data_len + BGZF_PAYLOAD - 1) / BGZF_PAYLOAD);
+          ch.crcs.resize(nb);
+          if (nb) {
+            S->d_crcs.reserve(nb * 4 + 64);
+            fgx::bgzf_crc_blocks_device(c, (const uint8_t*)out.data, out.data_len, S->d_crcs.as<uint32_t>());
+            fgx::hip_check(hipMemcpyAsync(ch.out.p, out.data, out.data_len, hipMemcpyDeviceToHost, s), "D2H records");
+            fgx::hip_check(hipMemcpyAsync(ch.crcs.data(), S->d_crcs.p, nb * 4, hipMemcpyDeviceToHost, s), "D2H block CRCs");
+            fgx::hip_check(hipStreamSynchronize(s), "sync");
+          }
+          ch.out_len = out.data_len; ch.have_crcs = true;
           sec_d2h += since(t0);
         } else {
           // families the device pipelines do not decide: the whole batch through the host entry (it splices both paths in group order)
           st->deferred_groups += n_def;
           h_blob.resize(batch_end + 16); h_off.resize(batch_rec); h_len.resize(batch_rec); h_grp.resize((size_t)batch_grp + 1);
-          fgx::hip_check(hipMemcpy(h_blob.data(), D[cur].p, batch_end, hipMemcpyDeviceToHost), "D2H");
+          fgx::hip_check(hipMemcpy(h_blob.data(), base, batch_end, hipMemcpyDeviceToHost), "D2H");
           fgx::hip_check(hipMemcpy(h_off.data(), d_koff.p, (size_t)batch_rec * 8, hipMemcpyDeviceToHost), "D2H");
           fgx::hip_check(hipMemcpy(h_len.data(), d_klen.p, (size_t)batch_rec * 4, hipMemcpyDeviceToHost), "D2H");
           fgx::hip_check(hipMemcpy(h_grp.data(), d_grp.p, ((size_t)batch_grp + 1) * 4, hipMemcpyDeviceToHost), "D2H");
@@ -704,14 +776,28 @@ int fgx_run_bam(fgx_caller* c, const char* in_path, const char* out_path, const 
         st->groups += batch_grp;
         st->kept_records += batch_rec;
       }
-      // ---- what stays behind moves to the front of the other buffer ----
+      // ---- what stays behind moves in front of the other buffer's stream ----
       const uint64_t keep = total - batch_end;
-      D[cur ^ 1].reserve(keep + ch.inf_len + ch.inf_len / 4 + 64);   // (room for a next chunk of this one's size: no regrowth in the steady state)
-      if (keep) fgx::hip_check(hipMemcpyAsync(D[cur ^ 1].p, (const uint8_t*)D[cur].p + batch_end, keep, hipMemcpyDeviceToDevice, s), "D2D leftover");
+      const int nb = cur ^ 1;
+      if (!ch.last) {
+        try_ahead();
+        if (ahead) {
+          if (keep > S->pad[nb]) {                               // (an enormous last group: wait for the stream, move it behind a wider pad)
+            fgx::hip_check(hipEventSynchronize(S->ev_in), "hipEventSynchronize");
+            widen_pad(nb, keep, ahead_inf_len, ahead_inf_len);   // (`ahead` stays: the stream is in place, its events have fired)
+          }
+        } else {
+          if (!S->pad[nb] || !D[nb].cap) S->pad[nb] = FRONT_PAD;
+          if (keep > S->pad[nb]) widen_pad(nb, keep, 0, ch.inf_len);
+          else ensure_room(nb, ch.inf_len, 0);
+        }
+        if (keep) fgx::hip_check(hipMemcpyAsync((uint8_t*)D[nb].p + S->pad[nb] - keep, base + batch_end, keep, hipMemcpyDeviceToDevice, s), "D2D leftover");
+      }
       fgx::hip_check(hipStreamSynchronize(s), "sync");
       left_len = keep; cur ^= 1;
       st->chunks = seq + 1;
     });
+    (void)hipStreamSynchronize(S->s_in);   // (a failed run may leave the next chunk's upload in flight)
     st->in_bytes = P->in_bytes; st->inflated_bytes = P->inflated_bytes; st->out_bytes = P->out_bytes; st->out_file_bytes = P->out_file_bytes;
     st->seconds_read = P->busy[0]; st->seconds_inflate = P->busy[1]; st->seconds_device = P->busy[2]; st->seconds_deflate = P->busy[3]; st->seconds_write = P->busy[4];
     st->seconds_device_inflate = sec_infl; st->device_inflate = device_inflate ? 1u : 0u;

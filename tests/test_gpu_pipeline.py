@@ -111,6 +111,21 @@ def test_bam_file_to_consensus_bam_file_simplex(tmp_path, host_inflate):
     c.close()
 
 
+@pytest.mark.parametrize("host_inflate", [False, True])
+def test_a_leftover_larger_than_the_front_pad_widens_it(tmp_path, monkeypatch, host_inflate):
+    """The next chunk is uploaded and inflated behind a front pad while this one is worked on; what this chunk leaves over (its last MI
+    group) goes into that pad.  With a pad of 256 bytes every leftover is larger than it: the stream already in place moves behind a
+    wider pad, and the records stay the oracle's."""
+    monkeypatch.setenv("FGX_FRONT_PAD", "256")
+    g = simulate_grouped_reads(4000, family_size=3, family_size_max=40)
+    c = _caller()                                             # (a fresh caller: the pad belongs to its pipeline state)
+    st = _run_and_compare(tmp_path, c, fgx_opts.defaults(min_reads=1), g, 50, 1 << 16, host_inflate=host_inflate)
+    assert st["chunks"] > 10
+    again = _run_and_compare(tmp_path, c, fgx_opts.defaults(min_reads=1), g, 50, 1 << 17, host_inflate=host_inflate)   # the same state, other chunk sizes
+    assert again["chunks"] > 5
+    c.close()
+
+
 def test_bam_file_to_consensus_bam_file_with_device_deflate(tmp_path):
     """The output side on the device as well (deflate_core.h, a lane per BGZF block, CRC-32 by a wavefront per block): the file must be a
     valid BGZF BAM whose records equal the oracle's."""

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
-"""BAM file in -> consensus BAM file out through the streaming pipeline (fgx_run_bam, csrc/pipeline.cpp): BGZF inflate on the host
-cores into pinned buffers, upload, record boundaries + MI grouping + consensus on the MI355X, download, BGZF level-1 deflate, write —
-five overlapping stages over chunks.  Prints one JSON line: whole-file raw reads/s, the busy time of every stage, the slowest one.
-usage: python tools/bench_end_to_end.py [--families 1000000] [--depth 8] [--threads N] [--chunk-mb 256] [--reps 2]"""
+"""BAM file in -> consensus BAM file out through the streaming pipeline (fgx_run_bam, csrc/pipeline.cpp): the compressed BGZF blocks
+into pinned buffers, upload + inflate + CRC-32 on the MI355X one chunk ahead (or zlib on the host cores: --host-inflate), record
+boundaries + MI grouping + consensus + the output blocks' CRC-32 there, download, BGZF level-1 deflate on the host cores (or on the
+device: --device-deflate), write — five overlapping stages over chunks.  Prints one JSON line: whole-file raw reads/s, the busy time
+of every stage, the slowest one.
+usage: python tools/bench_end_to_end.py [--families 1000000] [--depth 8] [--threads N] [--chunk-mb 512] [--reps 2] [--reuse-input]"""
 import argparse
 import json
 import os
@@ -21,6 +23,7 @@ def main():
     ap.add_argument("--chunk-mb", type=int, default=512)
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--dir", default="/tmp/fgx_e2e")
+    ap.add_argument("--reuse-input", action="store_true", help="keep the input file of an earlier call with the same --families / --depth")
     ap.add_argument("--device-deflate", action="store_true", help="compress the consensus records on the device as well (level 1)")
     ap.add_argument("--host-inflate", action="store_true", help="inflate the BGZF blocks with zlib on the host cores instead of on the device")
     a = ap.parse_args()
@@ -32,7 +35,15 @@ def main():
     # the input file, in slabs of families (the simulator's blob of a 5 M-family file would not fit a Python bytes object comfortably)
     slab, n_rec, raw_bytes = 250000, 0, 0
     t0 = time.perf_counter()
-    with open(gin, "wb") as f:
+    meta_path, key = gin + ".json", dict(families=a.families, depth=a.depth)
+    have = None
+    if a.reuse_input and os.path.exists(meta_path) and os.path.exists(gin):
+        have = json.load(open(meta_path))
+        have = have if {k: have.get(k) for k in key} == key else None
+    if have:
+        n_rec, raw_bytes = have["n_rec"], have["raw_bytes"]
+    else:
+      with open(gin, "wb") as f:
         for b in bgzf.bgzf_compress(bgzf.bam_header_bytes(bgzf.grouped_input_header(refs), refs), 1, T or None):
             f.write(b)
         for lo in range(0, a.families, slab):
@@ -42,6 +53,7 @@ def main():
             f.write(memoryview(nat[0]))
             del g, nat
         f.write(bgzf.BGZF_EOF)
+      json.dump(dict(key, n_rec=n_rec, raw_bytes=raw_bytes), open(meta_path, "w"))
     t_make = time.perf_counter() - t0
     caller = VanillaUmiConsensusCaller("", "A", VanillaUmiConsensusOptions(min_reads=1, min_consensus_base_quality=2, cell_tag="CB"), overlapping_consensus=True)
     best = None
@@ -63,7 +75,7 @@ def main():
                           output_bam_bytes=st["out_file_bytes"], consensus_records=st["consensus_records"], groups=st["groups"],
                           deferred_groups=st["deferred_groups"], boundary_repair_rounds=st["boundary_repair_rounds"], input_file_written_in_s=t_make,
                           note="stage_busy_s = busy time of each stage thread (the stages of successive chunks overlap: total_s is well below their sum); "
-                               "host side zlib (no libdeflate in the image); input file in the page cache")))
+                               "host side: this repository's own level-1 compressor (zlib for other levels; no libdeflate in the image); input file in the page cache")))
     caller.close()
 
 
