@@ -296,6 +296,7 @@ class _HandleCaller(ConsensusCaller):
             raise RuntimeError(lib.fgx_last_error(self._h).decode())  # every error is fatal to the run (simplex.rs:699-701)
         self._last_stats = ConsensusCallingStats.from_array(out.stats)
         self._stats.merge(self._last_stats)
+        self.last_stats_array = [int(v) for v in out.stats]          # the raw counters of this batch (fgx_output.stats order)
         if out.n_rejects:
             self._rejected.extend(split_records(C.string_at(out.rejects, out.rejects_len)))
         self.last_timing = dict(host_prep=out.ms_host_prep, h2d=out.ms_h2d, kernels=out.ms_kernels, d2h=out.ms_d2h, emit=out.ms_emit)

@@ -1,0 +1,71 @@
+"""N>1 path with the PRODUCT on every rank (tests/test_distributed_cpu.py runs the oracle per rank: there is no GPU where the CPU suite
+runs).  Two processes share the test box's one MI355X — gloo for the rendezvous, RCCL refuses two ranks on one device — each runs its
+contiguous shard of the family stream through the HIP engine behind the C ABI, and the shard payloads gathered in rank order, with the
+summed counters, must equal the oracle's output for the whole stream, byte for byte."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+pytestmark = pytest.mark.gpu
+
+F_PER_RANK = 400
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from fgumi_amd import VanillaUmiConsensusCaller, VanillaUmiConsensusOptions, simulate_grouped_reads
+    from fgumi_amd.distributed import gather_payload_to_root, gather_sizes, sum_over_ranks
+    g = simulate_grouped_reads(F_PER_RANK, family_size=3, first_family=rank * F_PER_RANK)      # this rank's shard of the stream
+    c = VanillaUmiConsensusCaller("", "A", VanillaUmiConsensusOptions(min_reads=1, min_consensus_base_quality=2, cell_tag="CB"), overlapping_consensus=True)
+    out = c.process_batch(g)                                                                     # the HIP engine; it has no CPU fallback
+    local = torch.frombuffer(bytearray(out.data), dtype=torch.uint8)
+    sizes = gather_sizes([local.numel(), out.count, g.n_rec], "cpu")
+    stats = torch.tensor(sum_over_ranks(c.last_stats_array, "cpu"), dtype=torch.int64)
+    payload = gather_payload_to_root(local, root=0)
+    c.close()
+    if rank == 0:
+        np.save(os.path.join(outdir, "payload.npy"), payload.numpy())
+        np.save(os.path.join(outdir, "sizes.npy"), sizes.numpy())
+        np.save(os.path.join(outdir, "stats.npy"), stats.numpy())
+    else:
+        assert payload is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_on_one_gpu_concatenate_to_the_oracle_output_of_the_whole_stream(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    import fgx_opts
+    import orc
+    from fgumi_amd import simulate_grouped_reads
+    g = simulate_grouped_reads(world * F_PER_RANK, family_size=3)
+    want = orc.process(fgx_opts.defaults(min_reads=1), g.blob, g.rec_off, g.rec_len, g.grp_first)
+    payload = np.load(tmp_path / "payload.npy").tobytes()
+    sizes = np.load(tmp_path / "sizes.npy")
+    stats = np.load(tmp_path / "stats.npy")
+    assert payload == want["data"]
+    assert sizes[:, 1].sum() == want["count"] and sizes[:, 2].sum() == g.n_rec and sizes[:, 0].sum() == len(want["data"])
+    n = len(want["stats"])
+    assert np.array_equal(stats[:n], want["stats"].astype(np.int64))
