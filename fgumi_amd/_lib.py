@@ -16,7 +16,7 @@ class Options(C.Structure):
         ("struct_size", C.c_uint32), ("caller_kind", C.c_uint32), ("tag", C.c_char * 2), ("cell_tag", C.c_char * 2),
         ("error_rate_pre_umi", C.c_uint8), ("error_rate_post_umi", C.c_uint8), ("min_input_base_quality", C.c_uint8),
         ("min_consensus_base_quality", C.c_uint8), ("produce_per_base_tags", C.c_uint8), ("trim", C.c_uint8),
-        ("tie_rule", C.c_uint8), ("overlapping_consensus", C.c_uint8), ("track_rejects", C.c_uint8), ("_pad0", C.c_uint8 * 3),
+        ("tie_rule", C.c_uint8), ("overlapping_consensus", C.c_uint8), ("track_rejects", C.c_uint8), ("methylation_mode", C.c_uint8), ("_pad0", C.c_uint8 * 2),
         ("min_reads", C.c_uint32), ("max_reads", C.c_int64), ("read_name_prefix", C.c_char_p), ("read_group_id", C.c_char_p),
         ("duplex_min_reads", C.c_uint32 * 3), ("duplex_max_reads_per_strand", C.c_int64),
         ("codec_min_reads_per_strand", C.c_uint32), ("codec_max_reads_per_strand", C.c_int64), ("codec_min_duplex_length", C.c_uint32),

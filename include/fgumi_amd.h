@@ -46,6 +46,7 @@ enum {
 
 enum { FGX_CALLER_SIMPLEX = 0, FGX_CALLER_DUPLEX = 1, FGX_CALLER_CODEC = 2 };
 enum { FGX_TIE_FGBIO_COMPAT = 0, FGX_TIE_ULP_RELATIVE = 1 };  /* base_builder.rs:418-438 */
+enum { FGX_METHYLATION_DISABLED = 0, FGX_METHYLATION_EM_SEQ = 1, FGX_METHYLATION_TAPS = 2 };  /* MethylationMode, crates/fgumi-consensus/src/lib.rs:45-68 */
 
 /* Options = VanillaUmiConsensusOptions (vanilla_caller.rs:292-334) + the command-level knobs the
  * process_fn closure captures (read_name_prefix, read_group_id, overlapping on/off, rejects
@@ -65,7 +66,9 @@ typedef struct fgx_options {
   uint8_t  tie_rule;                    /* FGX_TIE_FGBIO_COMPAT */
   uint8_t  overlapping_consensus;       /* 1: simplex/duplex default on */
   uint8_t  track_rejects;               /* 0 */
-  uint8_t  _pad0[3];
+  uint8_t  methylation_mode;            /* FGX_METHYLATION_* (vanilla_caller.rs:323-326; --methylation-mode, simplex.rs:240-245); needs fgx_set_reference.
+                                           simplex and duplex only — CODEC has no methylation mode (codec_caller.rs:425) */
+  uint8_t  _pad0[2];
   uint32_t min_reads;                   /* simplex --min-reads (required by the CLI) */
   int64_t  max_reads;                   /* -1 = None */
   const char* read_name_prefix;         /* "" when the header has no @RG (caller.rs:612-645) */
@@ -122,6 +125,15 @@ void fgx_destroy(fgx_caller* c);
  * 0 = identical; 1 = they differ, `msg` names the glibc version and the first differing point, and fgx_create refuses to
  * hand out a caller unless FGX_ALLOW_LIBM_MISMATCH=1 (results would no longer equal a reference build on this box). */
 int fgx_libm_self_check(char* msg, uint64_t msg_cap);
+
+/* Replaces `VanillaUmiConsensusCaller::set_reference(reference, ref_names)` (vanilla_caller.rs:512-522) and
+ * `DuplexConsensusCaller::set_reference` (duplex_caller.rs:524-536) after `load_methylation_reference` (src/lib/commands/common.rs:108-144):
+ * the reference genome of the methylation-aware mode.  Contig i of the BAM header (= a record's ref_id) is seqs[i], lens[i] bases as the
+ * FASTA holds them (any case; every header contig must be present, as the reference's loader requires).  The sequences are copied into
+ * HBM once (one byte per base; a human genome is 3.1 GB of the 288) and every batch's annotation kernel reads them there.  n_ref = 0
+ * drops the reference.  With a methylation mode set and no reference, reads are called without annotation or tags, as the reference
+ * does (annotate_and_normalize, vanilla_caller.rs:792-797).  Returns 0, or non-zero with fgx_last_error(c). */
+int fgx_set_reference(fgx_caller* c, uint32_t n_ref, const uint8_t* const* seqs, const uint64_t* lens);
 const char* fgx_last_error(const fgx_caller* c);
 const char* fgx_global_error(void);
 
@@ -163,6 +175,29 @@ int fgx_process_batch_device(fgx_caller* c, const void* d_records, uint64_t reco
  * mirror base_builder.rs's own unit tests. */
 int fgx_call_columns(fgx_caller* c, const uint8_t* bases, const uint8_t* quals, uint32_t n_cols, uint32_t depth,
                      uint8_t* out_base, uint8_t* out_qual, uint32_t* out_depth, uint32_t* out_errors);
+
+/* ---- methylation-aware mode, host-side test hooks (fgumi_amd/csrc/methylation_core.h) ---------------------------------------
+ * The annotation kernel's per-position body (reference base lookup through the anchor read's aligned runs, unconverted / converted
+ * counts over the source reads, in-place normalisation of converted bases: methylation.rs:116-178, 193-242; vanilla_caller.rs:838-852)
+ * run on the host, lane by lane — the same source the device compiles, for tests without a device.
+ *   stage        : the staged source reads (bases at [off, off+len) of each read), normalised IN PLACE
+ *   read_off/len : n_reads staged reads
+ *   runs         : n_runs aligned runs of the anchor, 4 int64 each: query start, length, reference position of the first base
+ *                  (0-based, may lie outside the contig), step (+1 forward read, -1 reverse read)
+ *   contig       : the anchor's contig (contig_len bases); top_strand as `is_top_strand` (methylation.rs:392-398)
+ * Fills is_ref_c / unconverted / converted [n_pos]. */
+int fgx_methylation_annotate_host(uint8_t* stage, const uint64_t* read_off, const uint32_t* read_len, uint32_t n_reads, const int64_t* runs, uint32_t n_runs,
+                                  const uint8_t* contig, uint64_t contig_len, int top_strand, uint32_t n_pos, uint8_t* is_ref_c, uint32_t* unconverted,
+                                  uint32_t* converted);
+/* The aligned runs the host side derives from a SourceRead (query_to_ref_positions, methylation.rs:116-178): `simplified` = the
+ * read's simplified CIGAR after reversal and truncation, `original` = before, both as BAM-encoded ops (len << 4 | code).  Writes up
+ * to `cap` runs of 4 int64 and returns the number of runs. */
+uint32_t fgx_methylation_runs_host(const uint32_t* simplified, uint32_t n_s, int64_t alignment_start, int is_reverse, const uint32_t* original, uint32_t n_o,
+                                   int64_t* runs, uint32_t cap);
+/* build_mm_ml_tags (methylation.rs:264-329) as the record assembly uses it: returns the ML length and the MM string (NUL-terminated),
+ * or -1 when no tag is written. */
+int fgx_methylation_mm_ml_host(const uint8_t* bases, uint32_t n, const uint8_t* is_ref_c, const uint32_t* unconverted, const uint32_t* converted, int top_strand,
+                               int mode, char* mm, uint32_t mm_cap, uint8_t* ml, uint32_t ml_cap);
 
 /* Device self-test of the glibc-compatible libm: op 0 exp, 1 log, 2 log1p, 3 expm1. */
 int fgx_device_libm(fgx_caller* c, int op, const double* x, double* y, uint64_t n);

@@ -20,6 +20,7 @@
 using namespace orc;
 
 static thread_local std::string g_err;
+static std::shared_ptr<const Reference> g_reference;   // orc_set_reference: what `set_reference` hands the callers (methylation mode)
 
 struct OrcResult {
   Bytes data;
@@ -46,6 +47,7 @@ static VanillaOptions vanilla_options_from(const fgx_options* o) {
   v.cell_tag[0] = o->cell_tag[0];
   v.cell_tag[1] = o->cell_tag[1];
   v.tie_rule = o->tie_rule == FGX_TIE_ULP_RELATIVE ? TieRule::UlpRelative : TieRule::FgbioCompat;
+  v.methylation_mode = o->methylation_mode;
   return v;
 }
 
@@ -68,6 +70,7 @@ static void simplex_groups(const fgx_options* o, const uint8_t* blob, const uint
   VanillaOptions vo = vanilla_options_from(o);
   VanillaCaller caller(o->read_name_prefix ? o->read_name_prefix : "", o->read_group_id ? o->read_group_id : "A", vo,
                        o->track_rejects != 0);
+  if (vo.methylation_mode != MethDisabled) caller.reference = g_reference;   // simplex.rs:405-408
   Stats batch_stats;
   CorrectionStats batch_overlap;
   for (uint32_t g = g0; g < g1; g++) {
@@ -108,8 +111,10 @@ static void duplex_groups(const fgx_options* o, const uint8_t* blob, const uint6
   d.has_cell_tag = o->cell_tag[0] != 0; d.cell_tag[0] = o->cell_tag[0]; d.cell_tag[1] = o->cell_tag[1];
   d.pre = o->error_rate_pre_umi; d.post = o->error_rate_post_umi;
   d.tie_rule = o->tie_rule == FGX_TIE_ULP_RELATIVE ? TieRule::UlpRelative : TieRule::FgbioCompat;
+  d.methylation_mode = o->methylation_mode;
   if (d.min_xy > d.min_total || d.min_yx > d.min_xy) throw OracleError{"min-reads values must be specified high to low"};
   DuplexCaller caller(o->read_name_prefix ? o->read_name_prefix : "", o->read_group_id ? o->read_group_id : "A", d, o->track_rejects != 0);
+  if (d.methylation_mode != MethDisabled) caller.ss.reference = g_reference;   // duplex.rs:465-471
   const bool single_strand_allowed = d.min_yx == 0;
   Stats batch_stats;
   CorrectionStats batch_overlap;
@@ -195,6 +200,60 @@ static groups_fn pick(const fgx_options* o) {
 extern "C" {
 
 const char* orc_last_error() { return g_err.c_str(); }
+
+// ---- methylation-aware mode (oracle_methylation.hpp) ------------------------------------------------------------------------
+// `set_reference(reference, ref_names)`: contig i of the BAM header = seqs[i]; n_ref == 0 clears it.  Applies to the callers
+// orc_process creates afterwards when the options carry a methylation mode.
+void orc_set_reference(uint32_t n_ref, const uint8_t* const* seqs, const uint64_t* lens) {
+  if (n_ref == 0) { g_reference.reset(); return; }
+  auto r = std::make_shared<Reference>();
+  for (uint32_t i = 0; i < n_ref; i++) r->seqs.emplace_back(seqs[i], seqs[i] + lens[i]);
+  g_reference = r;
+}
+// the single functions, for replaying the reference's unit tests
+static SimpCigar simp_from(const uint32_t* ops, uint32_t n) { SimpCigar c; for (uint32_t i = 0; i < n; i++) c.push_back({(uint8_t)(ops[i] & 0xF), (size_t)(ops[i] >> 4)}); return c; }
+// ops as BAM-encoded (len << 4 | code) simplified CIGAR ops; out[i] = ref position or INT64_MIN for None; returns the count
+uint32_t orc_meth_query_to_ref_positions(const uint32_t* simplified, uint32_t n_s, int64_t alignment_start, int is_reverse, const uint32_t* original, uint32_t n_o,
+                                         int64_t* out, uint32_t cap) {
+  std::vector<int64_t> p = query_to_ref_positions(simp_from(simplified, n_s), alignment_start, is_reverse != 0, simp_from(original, n_o));
+  for (size_t i = 0; i < p.size() && i < cap; i++) out[i] = p[i];
+  return (uint32_t)p.size();
+}
+int orc_meth_is_cpg_context(const uint8_t* ref, uint64_t n, uint64_t pos, int top) { return is_cpg_context(ref, n, pos, top != 0) ? 1 : 0; }
+int orc_meth_is_top_strand(uint16_t flg) { return is_top_strand(flg) ? 1 : 0; }
+// reads: n_reads strings of read_lens[r] bases, concatenated; ref_bases[i] == 0 = None.  Fills is_ref_c / unconverted / converted[len].
+void orc_meth_annotate(uint32_t len, const uint8_t* reads, const uint32_t* read_lens, uint32_t n_reads, const uint8_t* ref_bases, uint32_t n_ref_bases, int top,
+                       uint8_t* is_ref_c, uint32_t* unconverted, uint32_t* converted) {
+  std::vector<Bytes> rb(n_reads);
+  size_t off = 0;
+  for (uint32_t r = 0; r < n_reads; r++) { rb[r].assign(reads + off, reads + off + read_lens[r]); off += read_lens[r]; }
+  std::vector<const Bytes*> ptr;
+  for (auto& b : rb) ptr.push_back(&b);
+  MethylationAnnotation a = annotate_simplex_methylation(len, ptr, Bytes(ref_bases, ref_bases + n_ref_bases), top != 0);
+  for (uint32_t i = 0; i < len; i++) { is_ref_c[i] = a.evidence[i].is_ref_c; unconverted[i] = a.evidence[i].unconverted; converted[i] = a.evidence[i].converted; }
+}
+static MethylationAnnotation annot_from(uint32_t n, const uint8_t* is_ref_c, const uint32_t* unconverted, const uint32_t* converted) {
+  MethylationAnnotation a;
+  a.evidence.resize(n);
+  for (uint32_t i = 0; i < n; i++) { a.evidence[i].is_ref_c = is_ref_c[i] != 0; a.evidence[i].unconverted = unconverted[i]; a.evidence[i].converted = converted[i]; }
+  return a;
+}
+// returns the ML length (MM written NUL-terminated into mm), -1 for None, -2 when the reference would panic (length mismatch)
+int orc_meth_build_mm_ml(const uint8_t* bases, uint32_t n_bases, uint32_t n_ev, const uint8_t* is_ref_c, const uint32_t* unconverted, const uint32_t* converted, int top, int mode,
+                         char* mm, uint32_t mm_cap, uint8_t* ml, uint32_t ml_cap) {
+  std::string s; Bytes m;
+  try { if (!build_mm_ml_tags(Bytes(bases, bases + n_bases), annot_from(n_ev, is_ref_c, unconverted, converted), top != 0, mode, s, m)) return -1; }
+  catch (const OracleError&) { return -2; }
+  if (s.size() + 1 > mm_cap || m.size() > ml_cap) return -3;
+  memcpy(mm, s.c_str(), s.size() + 1);
+  memcpy(ml, m.data(), m.size());
+  return (int)m.size();
+}
+void orc_meth_combine(uint32_t n_ab, const uint8_t* a_ref, const uint32_t* a_u, const uint32_t* a_t, uint32_t n_ba, const uint8_t* b_ref, const uint32_t* b_u, const uint32_t* b_t,
+                      uint32_t len, uint8_t* o_ref, uint32_t* o_u, uint32_t* o_t) {
+  MethylationAnnotation c = combine_methylation_annotations(annot_from(n_ab, a_ref, a_u, a_t), annot_from(n_ba, b_ref, b_u, b_t), len);
+  for (uint32_t i = 0; i < len; i++) { o_ref[i] = c.evidence[i].is_ref_c; o_u[i] = c.evidence[i].unconverted; o_t[i] = c.evidence[i].converted; }
+}
 
 // MiGrouper::add_records with the consensus commands' record filter (src/lib/mi_group.rs:227-310;
 // src/lib/commands/common.rs:384-397; crates/fgumi-umi/src/lib.rs:370-375).  Fills the kept records' offsets / lengths and

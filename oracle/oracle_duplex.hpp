@@ -18,6 +18,8 @@ struct DuplexConsensusRead {
   bool has_ba = false;
   VanillaConsensusRead ba;
   bool is_ba_only = false;
+  bool has_methylation = false;          // combined annotation (duplex_caller.rs:261-262, 1086-1094)
+  MethylationAnnotation methylation;
   size_t len() const { return bases.size(); }
 };
 
@@ -25,7 +27,18 @@ inline int32_t clamp_per_base_short(uint16_t d) { return (int32_t)std::min<uint1
 inline uint16_t clamp_combined_error(int64_t e) { return (uint16_t)std::min<int64_t>(std::max<int64_t>(e, 0), 32767); }   // :363-368
 inline uint8_t cap_quality(int32_t s) { return s < 2 ? 2 : s > 93 ? 93 : (uint8_t)s; }   // duplex_caller.rs:873-881
 
-// duplex_consensus :931-1108 (methylation off)
+inline bool is_conversion_pair(uint8_t x, uint8_t y) {   // :897-903
+  x = upper(x); y = upper(y);
+  return (x == 'C' && y == 'T') || (x == 'T' && y == 'C') || (x == 'G' && y == 'A') || (x == 'A' && y == 'G');
+}
+inline uint8_t unconverted_base(uint8_t x, uint8_t y) {   // :907-913
+  uint8_t a = upper(x), b = upper(y);
+  if ((a == 'C' && b == 'T') || (a == 'T' && b == 'C')) return 'C';
+  if ((a == 'G' && b == 'A') || (a == 'A' && b == 'G')) return 'G';
+  return x;
+}
+
+// duplex_consensus :931-1108
 inline bool duplex_consensus(const VanillaConsensusRead* ab, const VanillaConsensusRead* ba, const std::vector<SourceRead>* srcs,
                              DuplexConsensusRead& out) {
   size_t len = std::min(ab ? ab->bases.size() : SIZE_MAX, ba ? ba->bases.size() : SIZE_MAX);
@@ -36,8 +49,8 @@ inline bool duplex_consensus(const VanillaConsensusRead* ab, const VanillaConsen
   };
   const VanillaConsensusRead* a = covered(ab) ? ab : nullptr;
   const VanillaConsensusRead* b = covered(ba) ? ba : nullptr;
-  if (a && !b) { out = DuplexConsensusRead(); out.id = a->id; out.bases = a->bases; out.quals = a->quals; out.errors = a->errors; out.ab = *a; out.ab.source_reads.clear(); out.has_ba = false; out.is_ba_only = false; return true; }
-  if (!a && b) { out = DuplexConsensusRead(); out.id = b->id; out.bases = b->bases; out.quals = b->quals; out.errors = b->errors; out.ab = *b; out.ab.source_reads.clear(); out.has_ba = false; out.is_ba_only = true; return true; }
+  if (a && !b) { out = DuplexConsensusRead(); out.id = a->id; out.bases = a->bases; out.quals = a->quals; out.errors = a->errors; out.ab = *a; out.ab.source_reads.clear(); out.has_ba = false; out.is_ba_only = false; out.has_methylation = a->has_methylation; out.methylation = a->methylation; return true; }
+  if (!a && b) { out = DuplexConsensusRead(); out.id = b->id; out.bases = b->bases; out.quals = b->quals; out.errors = b->errors; out.ab = *b; out.ab.source_reads.clear(); out.has_ba = false; out.is_ba_only = true; out.has_methylation = b->has_methylation; out.methylation = b->methylation; return true; }
   if (!a && !b) return false;
   out = DuplexConsensusRead();
   out.id = a->id;
@@ -45,14 +58,20 @@ inline bool duplex_consensus(const VanillaConsensusRead* ab, const VanillaConsen
     uint8_t ab_b = a->bases[i], ba_b = b->bases[i];
     int32_t aq = a->quals[i], bq = b->quals[i];
     uint8_t raw_base, raw_qual;
-    if (ab_b == ba_b) { raw_base = ab_b; raw_qual = cap_quality(aq + bq); }
+    // a C/T (G/A) disagreement at a reference cytosine of either strand is a conversion event, not an error (:988-1005)
+    const bool is_ref_c = (a->has_methylation && i < a->methylation.evidence.size() && a->methylation.evidence[i].is_ref_c) ||
+                          (b->has_methylation && i < b->methylation.evidence.size() && b->methylation.evidence[i].is_ref_c);
+    const bool artifact = ab_b != ba_b && is_ref_c && is_conversion_pair(ab_b, ba_b);
+    if (artifact) { raw_base = unconverted_base(ab_b, ba_b); raw_qual = cap_quality(aq + bq); }
+    else if (ab_b == ba_b) { raw_base = ab_b; raw_qual = cap_quality(aq + bq); }
     else if (aq > bq) { raw_base = ab_b; raw_qual = cap_quality(aq - bq); }
     else if (bq > aq) { raw_base = ba_b; raw_qual = cap_quality(bq - aq); }
     else { raw_base = ab_b; raw_qual = MIN_PHRED; }
     if (ab_b == 'N' || ba_b == 'N' || raw_qual == MIN_PHRED) { out.bases.push_back('N'); out.quals.push_back(MIN_PHRED); }
     else { out.bases.push_back(raw_base); out.quals.push_back(raw_qual); }
     uint16_t ec;
-    if (srcs) {
+    if (artifact) ec = 0;
+    else if (srcs) {
       int32_t ne = 0;
       for (auto& sr : *srcs) if (sr.bases.size() > i && sr.bases[i] != 'N' && raw_base != 'N' && sr.bases[i] != raw_base) ne++;
       ec = clamp_combined_error(ne);
@@ -68,9 +87,13 @@ inline bool duplex_consensus(const VanillaConsensusRead* ab, const VanillaConsen
     t.id = v.id;
     t.bases.assign(v.bases.begin(), v.bases.begin() + len); t.quals.assign(v.quals.begin(), v.quals.begin() + len);
     t.depths.assign(v.depths.begin(), v.depths.begin() + len); t.errors.assign(v.errors.begin(), v.errors.begin() + len);
+    t.has_methylation = v.has_methylation;
+    if (v.has_methylation) t.methylation = v.methylation.truncate(len);
     return t;
   };
   out.ab = trunc(*a); out.has_ba = true; out.ba = trunc(*b); out.is_ba_only = false;
+  if (a->has_methylation && b->has_methylation) { out.has_methylation = true; out.methylation = combine_methylation_annotations(a->methylation, b->methylation, len); }
+  else if (a->has_methylation || b->has_methylation) { out.has_methylation = true; out.methylation = (a->has_methylation ? a->methylation : b->methylation).truncate(len); }
   return true;
 }
 
@@ -82,6 +105,7 @@ struct DuplexOptions {
   bool has_cell_tag = true; char cell_tag[2] = {'C', 'B'};
   uint8_t pre = 45, post = 40;
   TieRule tie_rule = TieRule::FgbioCompat;
+  int methylation_mode = MethDisabled;   // set_reference :524-536
 };
 
 class DuplexCaller {
@@ -99,6 +123,7 @@ class DuplexCaller {
     v.has_max_reads = d.has_max_reads; v.max_reads = d.max_reads; v.error_rate_pre_umi = d.pre; v.error_rate_post_umi = d.post;
     v.min_consensus_base_quality = MIN_PHRED; v.has_cell_tag = d.has_cell_tag; v.cell_tag[0] = d.cell_tag[0]; v.cell_tag[1] = d.cell_tag[1];
     v.tie_rule = d.tie_rule;
+    v.methylation_mode = d.methylation_mode;
     return v;
   }
   DuplexCaller(std::string p, std::string r, DuplexOptions d, bool track_rejects)
@@ -184,6 +209,28 @@ class DuplexCaller {
     };
     add_umis(src_a); add_umis(src_b);
     if (!umis.empty()) { std::string cu = consensus_umis(umis); append_string_tag(rec, "RX", (const uint8_t*)cu.data(), cu.size()); }
+    if (c.has_methylation) {   // :1338-1398
+      const bool top = !c.is_ba_only;
+      auto counts = [&](const MethylationAnnotation& m, const char* tu, const char* tt) {
+        std::vector<int16_t> u = m.unconverted_counts(), t = m.converted_counts();
+        append_i16_array_tag(rec, tu, u.data(), u.size());
+        append_i16_array_tag(rec, tt, t.data(), t.size());
+      };
+      std::string mm; Bytes ml;
+      if (c.ab.has_methylation) {
+        if (build_mm_ml_tags(c.ab.bases, c.ab.methylation, top, o.methylation_mode, mm, ml)) append_string_tag(rec, top ? "am" : "bm", (const uint8_t*)mm.data(), mm.size());
+        counts(c.ab.methylation, top ? "au" : "bu", top ? "at" : "bt");
+      }
+      if (c.has_ba && c.ba.has_methylation) {
+        if (build_mm_ml_tags(c.ba.bases, c.ba.methylation, false, o.methylation_mode, mm, ml)) append_string_tag(rec, "bm", (const uint8_t*)mm.data(), mm.size());
+        counts(c.ba.methylation, "bu", "bt");
+      }
+      if (build_mm_ml_tags(c.bases, c.methylation, top, o.methylation_mode, mm, ml)) {
+        append_string_tag(rec, "MM", (const uint8_t*)mm.data(), mm.size());
+        append_u8_array_tag(rec, "ML", ml.data(), ml.size());
+      }
+      counts(c.methylation, "cu", "ct");
+    }
     write_with_block_size(rec, out.data);
     out.count += 1;
   }

@@ -7,6 +7,7 @@
 //   crates/fgumi-consensus/src/simple_umi.rs:9-131, 236-245
 //   crates/fgumi-consensus/src/overlapping.rs:14-17, 111-336, 382-684
 //   src/lib/commands/simplex.rs:637-718 (process_fn: per-group min-reads skip + overlap pre-step)
+// Methylation-aware mode (vanilla_caller.rs:715-724, 781-860, 1612-1625, 1853-1876) over oracle_methylation.hpp.
 #pragma once
 #include <algorithm>
 #include <map>
@@ -15,6 +16,7 @@
 #include <unordered_map>
 #include "oracle_bam.hpp"
 #include "oracle_phred.hpp"
+#include "oracle_methylation.hpp"
 
 namespace orc {
 
@@ -58,6 +60,7 @@ struct VanillaOptions {  // vanilla_caller.rs:292-353
   bool has_cell_tag = false;
   char cell_tag[2] = {'C', 'B'};
   TieRule tie_rule = TieRule::FgbioCompat;
+  int methylation_mode = MethDisabled;   // :323-326
 };
 
 struct SourceRead {  // vanilla_caller.rs:129-154
@@ -66,6 +69,9 @@ struct SourceRead {  // vanilla_caller.rs:129-154
   SimpCigar simplified_cigar;
   uint16_t flags;
   int32_t name_hash;
+  int32_t ref_id = -1;           // methylation annotation: reference sequence id, 0-based alignment start and the
+  int64_t alignment_start = -1;  // simplified CIGAR before reversal / truncation (:1176-1190)
+  SimpCigar original_cigar;
 };
 
 struct VanillaConsensusRead {
@@ -73,6 +79,8 @@ struct VanillaConsensusRead {
   Bytes bases, quals;
   std::vector<uint16_t> depths, errors;
   std::vector<SourceRead> source_reads;
+  bool has_methylation = false;
+  MethylationAnnotation methylation;
   uint16_t max_depth() const { uint16_t m = 0; for (auto d : depths) m = std::max(m, d); return m; }
   uint16_t min_depth() const { if (depths.empty()) return 0; uint16_t m = 0xFFFF; for (auto d : depths) m = std::min(m, d); return m; }
 };
@@ -160,6 +168,7 @@ class VanillaCaller {
   std::vector<Bytes> rejected_reads;
   bool track_rejects;
   uint8_t single_input_quals[94];
+  std::shared_ptr<const Reference> reference;   // set_reference :512-522 (contig i of the header = reference->seqs[i])
 
   VanillaCaller(std::string prefix, std::string rg, VanillaOptions o, bool track = false)
       : read_name_prefix(std::move(prefix)), read_group_id(std::move(rg)), opt(std::move(o)),
@@ -240,6 +249,9 @@ class VanillaCaller {
     out.quals.swap(quals);
     out.simplified_cigar.swap(simp);
     out.flags = flg;
+    out.ref_id = v.ref_id();
+    out.alignment_start = (int64_t)v.pos();
+    out.original_cigar.swap(orig);
     Slice nm = v.read_name();
     out.name_hash = opt.has_max_reads ? fgbio_read_name_rank(nm.p, nm.n) : 0;
     return true;
@@ -329,15 +341,41 @@ class VanillaCaller {
     }
   }
 
+  // annotate_and_normalize :781-860.  Returns false for a None annotation (no reference, unplaced anchor, ref_id outside the header).
+  bool annotate_and_normalize(std::vector<SourceRead>& srs, MethylationAnnotation& annot) const {
+    if (!reference) return false;
+    if (srs.empty()) return false;
+    size_t anchor_idx = 0;   // Iterator::max_by_key returns the LAST maximal element
+    for (size_t i = 1; i < srs.size(); i++) if (srs[i].bases.size() >= srs[anchor_idx].bases.size()) anchor_idx = i;
+    const SourceRead& anchor = srs[anchor_idx];
+    if (anchor.ref_id < 0 || anchor.alignment_start < 0) return false;
+    if ((size_t)anchor.ref_id >= reference->seqs.size()) return false;
+    const bool top = is_top_strand(anchor.flags);
+    std::vector<int64_t> ref_positions = query_to_ref_positions(anchor.simplified_cigar, anchor.alignment_start, (anchor.flags & flags::REVERSE) != 0, anchor.original_cigar);
+    Bytes ref_bases = fetch_ref_bases_at_positions(ref_positions, reference->seqs[(size_t)anchor.ref_id]);
+    std::vector<const Bytes*> rb;
+    for (auto& s : srs) rb.push_back(&s.bases);
+    annot = annotate_simplex_methylation(anchor.bases.size(), rb, ref_bases, top);
+    const uint8_t unconv = top ? 'C' : 'G', conv = top ? 'T' : 'A';
+    for (auto& s : srs)
+      for (size_t i = 0; i < annot.evidence.size(); i++)
+        if (annot.evidence[i].is_ref_c && i < s.bases.size() && upper(s.bases[i]) == conv) s.bases[i] = unconv;
+    return true;
+  }
+
   // consensus_call :706-779 (used by duplex / codec). Returns false for None.
   bool consensus_call(const std::string& umi, std::vector<SourceRead> srs, VanillaConsensusRead& out) {
     if (srs.empty() || srs.size() < opt.min_reads) return false;
+    MethylationAnnotation annot;
+    bool has_annot = opt.methylation_mode != MethDisabled && annotate_and_normalize(srs, annot);
     std::vector<SourceRead> capped;
     const std::vector<SourceRead>* use = &srs;
     if (opt.has_max_reads && srs.size() > opt.max_reads) { capped = downsample_source_reads(srs); use = &capped; }
     if (use->size() < opt.min_reads) return false;
     out.id = umi;
     create_consensus_from_source_reads(*use, out.bases, out.quals, out.depths, out.errors);
+    out.has_methylation = has_annot;
+    out.methylation = has_annot ? annot.truncate(out.bases.size()) : MethylationAnnotation();
     out.source_reads = std::move(srs);
     return true;
   }
@@ -345,7 +383,8 @@ class VanillaCaller {
   // build_consensus_record_into :1767-1881
   void build_consensus_record_into(ConsensusOutput& output, const std::string& umi, ReadType rt,
                                    const std::vector<RecView>& original_raws, const Bytes& bases, const Bytes& quals,
-                                   const std::vector<uint16_t>& depths, const std::vector<uint16_t>& errors) {
+                                   const std::vector<uint16_t>& depths, const std::vector<uint16_t>& errors,
+                                   const MethylationAnnotation* methylation = nullptr) {
     std::string name = read_name_prefix + ":" + umi;  // write_consensus_read_name caller.rs:560-566
     uint16_t flag = flags::UNMAPPED;
     if (rt == R1) flag |= flags::PAIRED | flags::FIRST_SEGMENT | flags::MATE_UNMAPPED;
@@ -378,6 +417,17 @@ class VanillaCaller {
     std::vector<std::string> umis;
     for (auto& r : original_raws) { Slice rx = find_string_tag(r.aux(), "RX"); if (rx.some) umis.push_back(rx.str()); }
     if (!umis.empty()) { std::string cu = consensus_umis(umis); append_string_tag(rec, "RX", (const uint8_t*)cu.data(), cu.size()); }
+    if (methylation) {   // :1853-1876
+      bool top = original_raws.empty() ? true : is_top_strand(original_raws[0].flags());
+      std::string mm; Bytes ml;
+      if (build_mm_ml_tags(bases, *methylation, top, opt.methylation_mode, mm, ml)) {
+        append_string_tag(rec, "MM", (const uint8_t*)mm.data(), mm.size());
+        append_u8_array_tag(rec, "ML", ml.data(), ml.size());
+      }
+      std::vector<int16_t> cu = methylation->unconverted_counts(), ct = methylation->converted_counts();
+      append_i16_array_tag(rec, "cu", cu.data(), cu.size());
+      append_i16_array_tag(rec, "ct", ct.data(), ct.size());
+    }
     write_with_block_size(rec, output.data);
     output.count += 1;
   }
@@ -444,12 +494,15 @@ class VanillaCaller {
     surviving_count = filtered.size();
     if (track_rejects)
       for (auto& s : filtered) surviving_reads.push_back({group_reads[s.original_idx].pos, Bytes(group_reads[s.original_idx].p, group_reads[s.original_idx].p + group_reads[s.original_idx].n)});
+    MethylationAnnotation annot;   // :1612-1625
+    bool has_annot = opt.methylation_mode != MethDisabled && annotate_and_normalize(filtered, annot);
     Bytes cb, cq;
     std::vector<uint16_t> depths, errors;
     create_consensus_from_source_reads(filtered, cb, cq, depths, errors);
+    if (has_annot) annot = annot.truncate(cb.size());
     std::vector<RecView> raws;
     for (auto& s : filtered) raws.push_back(RecView(group_reads[s.original_idx].p, group_reads[s.original_idx].n));
-    build_consensus_record_into(output, umi, rt, raws, cb, cq, depths, errors);
+    build_consensus_record_into(output, umi, rt, raws, cb, cq, depths, errors, has_annot ? &annot : nullptr);
     return true;
   }
 

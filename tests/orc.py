@@ -46,6 +46,11 @@ def _load():
         "orc_filter_mask_bases": (C.c_int64, [VP, U32, VP, C.c_int, U8]), "orc_filter_mask_duplex_bases": (C.c_int64, [VP, U32, VP, VP, VP, C.c_int, U8, C.c_int]),
         "orc_filter_read": (C.c_int, [VP, U32, VP]), "orc_filter_duplex_read": (C.c_int, [VP, U32, VP, VP, VP]), "orc_filter_is_duplex": (C.c_int, [VP, U32]),
         "orc_filter_process_record": (C.c_int, [VP, VP, U32, P(U64), P(C.c_int)]), "orc_filter_reverse_tags": (None, [VP, U32]),
+        "orc_set_reference": (None, [U32, VP, VP]),
+        "orc_meth_query_to_ref_positions": (U32, [VP, U32, C.c_int64, C.c_int, VP, U32, VP, U32]), "orc_meth_is_cpg_context": (C.c_int, [CP, U64, U64, C.c_int]),
+        "orc_meth_is_top_strand": (C.c_int, [C.c_uint16]), "orc_meth_annotate": (None, [U32, VP, VP, U32, VP, U32, C.c_int, VP, VP, VP]),
+        "orc_meth_build_mm_ml": (C.c_int, [VP, U32, U32, VP, VP, VP, C.c_int, C.c_int, VP, U32, VP, U32]),
+        "orc_meth_combine": (None, [U32, VP, VP, VP, U32, VP, VP, VP, U32, VP, VP, VP]),
     }
     for name, (res, args) in sig.items():
         if hasattr(lib, name):
@@ -236,3 +241,72 @@ def filter_reverse_tags(rec):
     a = (C.c_uint8 * len(buf)).from_buffer(buf)
     lib.orc_filter_reverse_tags(a, len(buf))
     return bytes(buf)
+
+
+# ---- methylation-aware mode (oracle/oracle_methylation.hpp) -----------------------------------------------------------------
+NO_REF_POS = -(1 << 63)
+METH_DISABLED, METH_EM_SEQ, METH_TAPS = 0, 1, 2
+
+
+def set_reference(seqs):
+    """`set_reference(reference, ref_names)`: seqs[i] = the bases of header contig i (bytes); None / [] clears it."""
+    seqs = list(seqs or [])
+    if not seqs:
+        lib.orc_set_reference(0, None, None)
+        return
+    bufs = [C.create_string_buffer(bytes(s), len(s)) for s in seqs]
+    ptrs = (C.c_void_p * len(seqs))(*[C.cast(b, C.c_void_p).value for b in bufs])
+    lens = (C.c_uint64 * len(seqs))(*[len(s) for s in seqs])
+    lib.orc_set_reference(len(seqs), ptrs, lens)          # (the oracle copies the sequences)
+
+
+def _ops(cigar):
+    import bamutil
+    return np.array(bamutil.cigar_ops(cigar), dtype=np.uint32)
+
+
+def meth_query_to_ref_positions(simplified, alignment_start, is_reverse, original):
+    """CIGAR strings of simplified ops (M / I / D / N / P); None for insertions."""
+    s, o = _ops(simplified), _ops(original)
+    out = np.zeros(int(sum(x >> 4 for x in s)) + 1, dtype=np.int64)
+    n = lib.orc_meth_query_to_ref_positions(ptr(s), len(s), alignment_start, int(is_reverse), ptr(o), len(o), ptr(out), len(out))
+    return [None if v == NO_REF_POS else int(v) for v in out[:n]]
+
+
+def meth_annotate(length, reads, ref_bases, top):
+    """reads: list of base strings; ref_bases: list of one-character strings or None.  Returns (is_ref_c, unconverted, converted)."""
+    cat = np.frombuffer("".join(reads).encode(), dtype=np.uint8) if reads else np.zeros(0, np.uint8)
+    cat = np.ascontiguousarray(cat) if len(cat) else np.zeros(1, np.uint8)
+    lens = np.array([len(r) for r in reads], dtype=np.uint32)
+    rb = np.array([0 if b is None else ord(b) for b in ref_bases], dtype=np.uint8)
+    is_c, u, t = np.zeros(max(1, length), np.uint8), np.zeros(max(1, length), np.uint32), np.zeros(max(1, length), np.uint32)
+    lib.orc_meth_annotate(length, ptr(cat), ptr(lens) if len(lens) else None, len(reads), ptr(rb) if len(rb) else None, len(rb), int(top), ptr(is_c), ptr(u), ptr(t))
+    return [bool(x) for x in is_c[:length]], [int(x) for x in u[:length]], [int(x) for x in t[:length]]
+
+
+def _ev(evidence):
+    n = len(evidence)
+    return (np.array([int(e[0]) for e in evidence] + [0], dtype=np.uint8), np.array([e[1] for e in evidence] + [0], dtype=np.uint32),
+            np.array([e[2] for e in evidence] + [0], dtype=np.uint32), n)
+
+
+def meth_build_mm_ml(bases, evidence, top, mode):
+    """evidence: list of (is_ref_c, unconverted, converted).  Returns (MM string, ML list) or None; raises where the reference panics."""
+    b = np.frombuffer(bases.encode() + b"\0", dtype=np.uint8).copy()
+    c, u, t, n = _ev(evidence)
+    mm = C.create_string_buffer(16 + 12 * (len(bases) + 1))
+    ml = np.zeros(len(bases) + 1, dtype=np.uint8)
+    r = lib.orc_meth_build_mm_ml(ptr(b), len(bases), n, ptr(c), ptr(u), ptr(t), int(top), mode, mm, len(mm), ptr(ml), len(ml))
+    if r == -1:
+        return None
+    if r < 0:
+        raise RuntimeError("build_mm_ml_tags: the reference panics (length mismatch)" if r == -2 else "buffer")
+    return mm.value.decode(), [int(x) for x in ml[:r]]
+
+
+def meth_combine(ab, ba, length):
+    ac, au, at, na = _ev(ab)
+    bc, bu, bt, nb = _ev(ba)
+    oc, ou, ot = np.zeros(length + 1, np.uint8), np.zeros(length + 1, np.uint32), np.zeros(length + 1, np.uint32)
+    lib.orc_meth_combine(na, ptr(ac), ptr(au), ptr(at), nb, ptr(bc), ptr(bu), ptr(bt), length, ptr(oc), ptr(ou), ptr(ot))
+    return [(bool(oc[i]), int(ou[i]), int(ot[i])) for i in range(length)]
