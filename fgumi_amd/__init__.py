@@ -8,6 +8,6 @@ from ._lib import lib, load, Options, Output, SimParams, default_options, Librar
 from .caller import (ConsensusCaller, VanillaUmiConsensusCaller, DuplexConsensusCaller, CodecConsensusCaller, CodecConsensusOptions,  # noqa: F401
                      CodecConsensusStats, VanillaUmiConsensusOptions, ConsensusOutput,
                      ConsensusCallingStats, RejectionReason, GroupedReads, DeviceGroupedReads, DeviceOutput,
-                     simulate_grouped_reads, simulated_family_bytes, split_records)
+                     simulate_grouped_reads, simulated_family_bytes, split_records, MethylationMode)
 from .filter import ConsensusFilter, FilterConfig, FilterThresholds, FilterResult, DeviceFilterResult, record_offsets  # noqa: F401,E402
 from . import bgzf  # noqa: F401,E402

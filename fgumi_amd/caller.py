@@ -97,6 +97,7 @@ class VanillaUmiConsensusOptions:
     min_consensus_base_quality: int = 40
     cell_tag: Optional[str] = None
     tie_rule: int = 0  # 0 FgbioCompat (default), 1 UlpRelative
+    methylation_mode: int = 0  # MethylationMode (lib.rs:45-68): 0 Disabled, 1 EmSeq, 2 Taps; needs set_reference()
 
 
 @dataclass
@@ -306,6 +307,24 @@ class _HandleCaller(ConsensusCaller):
     def last_batch_statistics(self) -> ConsensusCallingStats:
         return self._last_stats
 
+    # ---- methylation-aware mode ---------------------------------------------------------------------
+    def set_reference(self, reference, ref_names: Sequence[str]):
+        """`set_reference(reference, ref_names)` (vanilla_caller.rs:512-522): `reference` maps a contig name to its bases (the
+        in-memory `RefBaseProvider`), `ref_names[i]` = the name of header contig i (a record's ref_id).  The sequences go to HBM
+        once.  A name the mapping lacks is an empty contig: every base of it is unknown, as with the reference's per-base
+        lookups.  `set_reference(None, [])` drops the reference."""
+        names = list(ref_names or [])
+        if reference is None or not names:
+            rc = lib.fgx_set_reference(self._h, 0, None, None)
+        else:
+            seqs = [bytes(reference.get(n, b"")) for n in names]
+            bufs = [C.create_string_buffer(s, max(1, len(s))) for s in seqs]
+            ptrs = (C.c_void_p * len(seqs))(*[C.cast(b, C.c_void_p).value for b in bufs])
+            lens = (C.c_uint64 * len(seqs))(*[len(s) for s in seqs])
+            rc = lib.fgx_set_reference(self._h, len(seqs), ptrs, lens)
+        if rc != 0:
+            raise RuntimeError(lib.fgx_last_error(self._h).decode())
+
     def set_general_only(self, on: bool = True):
         """Route every family through the general host-orchestrated path (default: device-resident fast
         path, general path only for the families it defers)."""
@@ -441,6 +460,14 @@ def _fill_vanilla(o: Options, v: VanillaUmiConsensusOptions):
     o.min_reads = v.min_reads
     o.max_reads = -1 if v.max_reads is None else v.max_reads
     o.produce_per_base_tags, o.trim, o.tie_rule = int(v.produce_per_base_tags), int(v.trim), v.tie_rule
+    o.methylation_mode = int(v.methylation_mode)
+
+
+class MethylationMode(enum.IntEnum):
+    """crates/fgumi-consensus/src/lib.rs:45-68."""
+    Disabled = 0
+    EmSeq = 1
+    Taps = 2
 
 
 class VanillaUmiConsensusCaller(_HandleCaller):
@@ -472,7 +499,7 @@ class DuplexConsensusCaller(_HandleCaller):
     def __init__(self, read_name_prefix: str, read_group_id: str, min_reads: Sequence[int], min_input_base_quality: int = 10,
                  produce_per_base_tags: bool = True, trim: bool = False, max_reads_per_strand: Optional[int] = None,
                  cell_tag: Optional[str] = None, track_rejects: bool = False, error_rate_pre_umi: int = 45, error_rate_post_umi: int = 40,
-                 tie_rule: int = 0, overlapping_consensus: bool = False, device: int = -1):
+                 tie_rule: int = 0, overlapping_consensus: bool = False, device: int = -1, methylation_mode: int = 0):
         from ._lib import default_options
         mr = list(min_reads)
         if not mr:
@@ -493,7 +520,19 @@ class DuplexConsensusCaller(_HandleCaller):
         o.cell_tag = cell_tag.encode() if cell_tag else b"\0\0"
         o.error_rate_pre_umi, o.error_rate_post_umi = error_rate_pre_umi, error_rate_post_umi
         o.track_rejects, o.overlapping_consensus, o.device = int(track_rejects), int(overlapping_consensus), device
+        o.methylation_mode = int(methylation_mode)
         super().__init__(o, read_name_prefix, read_group_id)
+
+    def set_reference(self, reference, ref_names: Sequence[str], methylation_mode: Optional[int] = None):
+        """`DuplexConsensusCaller::set_reference(reference, ref_names, methylation_mode)` (duplex_caller.rs:524-536): the mode
+        goes to the single-strand caller's options (a new engine handle when it differs from the constructor's)."""
+        if methylation_mode is not None and int(methylation_mode) != self._opts.methylation_mode:
+            self.close()
+            self._opts.methylation_mode = int(methylation_mode)
+            self._h = lib.fgx_create(C.byref(self._opts))
+            if not self._h:
+                raise RuntimeError(lib.fgx_global_error().decode())
+        super().set_reference(reference, ref_names)
 
 
 @dataclass

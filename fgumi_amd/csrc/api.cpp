@@ -49,6 +49,7 @@ void PinnedBuf::free_() { if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
 
 double fgx_caller::run_columns(ColumnBatch& b, ColParams prm) {
   b.ob.assign(b.n_cols, 0); b.oq.assign(b.n_cols, 0); b.od.assign(b.n_cols, 0); b.oe.assign(b.n_cols, 0);
+  b.mflag.clear(); b.mu.clear(); b.mt.clear();
   if (b.jobs.empty() || b.n_cols == 0) return 0.0;
   std::vector<Tile> tiles;
   for (uint32_t j = 0; j < b.jobs.size(); j++)
@@ -63,7 +64,24 @@ double fgx_caller::run_columns(ColumnBatch& b, ColParams prm) {
   hip_check(hipMemcpyAsync(d_reads.p, b.reads.data(), b.reads.size() * sizeof(ReadDesc), hipMemcpyHostToDevice, stream), "H2D reads");
   hip_check(hipMemcpyAsync(d_jobs.p, b.jobs.data(), b.jobs.size() * sizeof(ColJob), hipMemcpyHostToDevice, stream), "H2D jobs");
   hip_check(hipMemcpyAsync(d_tiles.p, tiles.data(), tiles.size() * sizeof(Tile), hipMemcpyHostToDevice, stream), "H2D tiles");
+  const bool meth = !b.mjobs.empty() && b.n_mpos > 0 && genome;
   hip_check(hipEventRecord(ev0, stream), "event");
+  if (meth) {   // annotate_and_normalize of every call, on the staged reads, before they are called
+    std::vector<MethTile> mtiles;
+    for (uint32_t j = 0; j < b.mjobs.size(); j++)
+      for (uint32_t p0 = 0; p0 < b.mjobs[j].n_pos; p0 += 64) mtiles.push_back(MethTile{j, p0});
+    d_mjobs.reserve(b.mjobs.size() * sizeof(MethJob));
+    d_mruns.reserve(b.mruns.size() * sizeof(MethRun) + 32);
+    d_mtiles.reserve(mtiles.size() * sizeof(MethTile));
+    d_mflag.reserve(b.n_mpos); d_mu.reserve(4ull * b.n_mpos); d_mt.reserve(4ull * b.n_mpos);
+    hip_check(hipMemcpyAsync(d_mjobs.p, b.mjobs.data(), b.mjobs.size() * sizeof(MethJob), hipMemcpyHostToDevice, stream), "H2D meth jobs");
+    if (!b.mruns.empty()) hip_check(hipMemcpyAsync(d_mruns.p, b.mruns.data(), b.mruns.size() * sizeof(MethRun), hipMemcpyHostToDevice, stream), "H2D meth runs");
+    hip_check(hipMemcpyAsync(d_mtiles.p, mtiles.data(), mtiles.size() * sizeof(MethTile), hipMemcpyHostToDevice, stream), "H2D meth tiles");
+    hip_check(hipStreamSynchronize(stream), "sync");   // (mtiles is a local)
+    launch_meth_annotate(stream, d_stage.as<uint8_t>(), d_reads.as<ReadDesc>(), d_mjobs.as<MethJob>(), d_mruns.as<MethRun>(), d_mtiles.as<MethTile>(),
+                         (uint32_t)mtiles.size(), genome->d_genome.as<uint8_t>(), d_mflag.as<uint8_t>(), d_mu.as<uint32_t>(), d_mt.as<uint32_t>());
+    hip_check(hipGetLastError(), "k_meth_annotate launch");
+  }
   launch_column_jobs(stream, d_stage.as<uint8_t>(), d_reads.as<ReadDesc>(), d_jobs.as<ColJob>(), d_tiles.as<Tile>(), (uint32_t)tiles.size(),
                      d_tables.as<DeviceTables>(), prm, d_ob.as<uint8_t>(), d_oq.as<uint8_t>(), d_od.as<uint16_t>(), d_oe.as<uint16_t>());
   hip_check(hipGetLastError(), "k_column_jobs launch");
@@ -72,6 +90,13 @@ double fgx_caller::run_columns(ColumnBatch& b, ColParams prm) {
   hip_check(hipMemcpyAsync(b.oq.data(), d_oq.p, b.n_cols, hipMemcpyDeviceToHost, stream), "D2H");
   hip_check(hipMemcpyAsync(b.od.data(), d_od.p, 2ull * b.n_cols, hipMemcpyDeviceToHost, stream), "D2H");
   hip_check(hipMemcpyAsync(b.oe.data(), d_oe.p, 2ull * b.n_cols, hipMemcpyDeviceToHost, stream), "D2H");
+  if (meth) {
+    b.mflag.assign(b.n_mpos, 0); b.mu.assign(b.n_mpos, 0); b.mt.assign(b.n_mpos, 0);
+    hip_check(hipMemcpyAsync(b.mflag.data(), d_mflag.p, b.n_mpos, hipMemcpyDeviceToHost, stream), "D2H meth");
+    hip_check(hipMemcpyAsync(b.mu.data(), d_mu.p, 4ull * b.n_mpos, hipMemcpyDeviceToHost, stream), "D2H meth");
+    hip_check(hipMemcpyAsync(b.mt.data(), d_mt.p, 4ull * b.n_mpos, hipMemcpyDeviceToHost, stream), "D2H meth");
+    if (b.want_stage_back) hip_check(hipMemcpyAsync(b.stage.data(), d_stage.p, b.stage.size(), hipMemcpyDeviceToHost, stream), "D2H normalised reads");
+  }
   hip_check(hipStreamSynchronize(stream), "sync");
   float ms = 0;
   hip_check(hipEventElapsedTime(&ms, ev0, ev1), "elapsed");
@@ -166,6 +191,10 @@ fgx_caller* fgx_create(const fgx_options* opts) {
       const char* allow = getenv("FGX_ALLOW_LIBM_MISMATCH");
       if (!mismatch.empty() && !(allow && allow[0] == '1')) { g_global_err = "fgx_create: " + mismatch; return nullptr; }
     }
+    if (opts->methylation_mode > FGX_METHYLATION_TAPS) { g_global_err = "fgx_create: unknown methylation mode"; return nullptr; }
+    if (opts->methylation_mode != FGX_METHYLATION_DISABLED && opts->caller_kind == FGX_CALLER_CODEC) {
+      g_global_err = "fgx_create: the CODEC caller has no methylation-aware mode (codec_caller.rs:425)"; return nullptr;
+    }
     c = new fgx_caller();
     c->opt = *opts;
     c->prefix = opts->read_name_prefix ? opts->read_name_prefix : "";
@@ -201,8 +230,10 @@ void fgx_destroy(fgx_caller* c) {
   c->workers.clear();
   (void)hipSetDevice(c->device);
   for (DevBuf* b : {&c->d_tables, &c->d_umi_tables, &c->d_stage, &c->d_reads, &c->d_jobs, &c->d_tiles, &c->d_ob, &c->d_oq, &c->d_od,
-                    &c->d_oe, &c->d_scratch_a, &c->d_scratch_b, &c->d_in_blob, &c->d_in_off, &c->d_in_len, &c->d_in_grp})
+                    &c->d_oe, &c->d_scratch_a, &c->d_scratch_b, &c->d_in_blob, &c->d_in_off, &c->d_in_len, &c->d_in_grp, &c->d_mjobs, &c->d_mruns,
+                    &c->d_mtiles, &c->d_mflag, &c->d_mu, &c->d_mt})
     b->free_();
+  c->genome.reset();
   if (c->fast) { c->fast->fp.release(); c->fast->pin_out.free_(); delete c->fast; }
   if (c->filt) { c->filt->release(); delete c->filt; }
   pipeline_release(c);
@@ -210,6 +241,62 @@ void fgx_destroy(fgx_caller* c) {
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
+}
+
+// set_reference (vanilla_caller.rs:512-522, duplex_caller.rs:524-536): the genome goes to HBM once, one byte per base, contig after contig.
+int fgx_set_reference(fgx_caller* c, uint32_t n_ref, const uint8_t* const* seqs, const uint64_t* lens) {
+  if (!c) return 1;
+  c->err.clear();
+  try {
+    if (n_ref == 0) { c->genome.reset(); for (fgx_caller* w : c->workers) w->genome.reset(); return 0; }
+    if (!seqs || !lens) { c->err = "fgx_set_reference: null sequence table"; return 1; }
+    for (uint32_t i = 0; i < n_ref; i++) if (!seqs[i] && lens[i]) { c->err = "fgx_set_reference: contig " + std::to_string(i) + " of the header has no sequence (every header contig must be in the FASTA)"; return 1; }
+    hip_check(hipSetDevice(c->device), "hipSetDevice");
+    auto g = std::make_shared<GenomeRef>();
+    g->device = c->device;
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n_ref; i++) { g->off.push_back(total); g->len.push_back(lens[i]); total += lens[i]; }
+    g->d_genome.reserve(total + 64);
+    for (uint32_t i = 0; i < n_ref; i++)
+      if (lens[i]) hip_check(hipMemcpy((uint8_t*)g->d_genome.p + g->off[i], seqs[i], lens[i], hipMemcpyHostToDevice), "genome H2D");
+    c->genome = g;
+    for (fgx_caller* w : c->workers) w->genome = g;
+    return 0;
+  } catch (const std::exception& ex) { c->err = ex.what(); return 3; }
+}
+
+// ---- methylation-aware mode: the device code's per-position body and the host-side pieces, callable without a device ----------
+int fgx_methylation_annotate_host(uint8_t* stage, const uint64_t* read_off, const uint32_t* read_len, uint32_t n_reads, const int64_t* runs, uint32_t n_runs,
+                                  const uint8_t* contig, uint64_t contig_len, int top_strand, uint32_t n_pos, uint8_t* is_ref_c, uint32_t* unconverted,
+                                  uint32_t* converted) {
+  if (!stage || !is_ref_c || !unconverted || !converted) return 1;
+  std::vector<MethRead> reads(n_reads);
+  for (uint32_t r = 0; r < n_reads; r++) { reads[r].off = read_off[r]; reads[r].len = read_len[r]; reads[r]._pad = 0; }
+  std::vector<MethRun> rr(n_runs);
+  for (uint32_t r = 0; r < n_runs; r++) rr[r] = MethRun{runs[4 * r], runs[4 * r + 1], runs[4 * r + 2], runs[4 * r + 3]};
+  for (uint32_t i = 0; i < n_pos; i++)     // the kernel's lanes, one after the other
+    meth_annotate_position(stage, reads.data(), n_reads, rr.data(), n_runs, contig, contig_len, top_strand != 0, i, &is_ref_c[i], &unconverted[i], &converted[i]);
+  return 0;
+}
+uint32_t fgx_methylation_runs_host(const uint32_t* simplified, uint32_t n_s, int64_t alignment_start, int is_reverse, const uint32_t* original, uint32_t n_o,
+                                   int64_t* runs, uint32_t cap) {
+  SimpCigar s, o;
+  for (uint32_t i = 0; i < n_s; i++) s.push_back({(uint8_t)(simplified[i] & 0xF), (uint64_t)(simplified[i] >> 4)});
+  for (uint32_t i = 0; i < n_o; i++) o.push_back({(uint8_t)(original[i] & 0xF), (uint64_t)(original[i] >> 4)});
+  std::vector<MethRun> rr;
+  meth_runs(s, alignment_start, is_reverse != 0, o, rr);
+  for (uint32_t r = 0; r < rr.size() && r < cap; r++) { runs[4 * r] = rr[r].q0; runs[4 * r + 1] = rr[r].len; runs[4 * r + 2] = rr[r].ref0; runs[4 * r + 3] = rr[r].step; }
+  return (uint32_t)rr.size();
+}
+int fgx_methylation_mm_ml_host(const uint8_t* bases, uint32_t n, const uint8_t* is_ref_c, const uint32_t* unconverted, const uint32_t* converted, int top_strand,
+                               int mode, char* mm, uint32_t mm_cap, uint8_t* ml, uint32_t ml_cap) {
+  std::string s;
+  std::vector<uint8_t> m;
+  if (!meth_build_mm_ml(bases, n, is_ref_c, unconverted, converted, top_strand != 0, mode, s, m)) return -1;
+  if (s.size() + 1 > mm_cap || m.size() > ml_cap) return -3;
+  memcpy(mm, s.c_str(), s.size() + 1);
+  if (!m.empty()) memcpy(ml, m.data(), m.size());
+  return (int)m.size();
 }
 
 // Host-input entry: upload once, run the device-resident pipeline, bring the records back, and send
@@ -234,6 +321,7 @@ static bool ensure_workers(fgx_caller* c, unsigned T) {
     if (!w) { c->err = std::string("helper caller: ") + fgx_global_error(); return false; }
     c->workers.push_back(w);
   }
+  for (fgx_caller* w : c->workers) w->genome = c->genome;   // (read-only, resident once)
   return true;
 }
 
@@ -320,7 +408,9 @@ static int hybrid_after_upload(fgx_caller* c, general_fn general, const uint8_t*
 
 static int process_hybrid(fgx_caller* c, general_fn general, const uint8_t* records, uint64_t records_len, const uint64_t* rec_off,
                           const uint32_t* rec_len, uint32_t n_rec, const uint32_t* grp_first, uint32_t n_grp, fgx_output* out) {
-  if (c->opt.track_rejects || n_grp == 0) return run_general(c, general, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
+  // --rejects (record copies in input order) and the methylation-aware mode (reference lookups per source read) are decided by the
+  // general path: host orchestration, device kernels for the per-base work
+  if (c->opt.track_rejects || c->opt.methylation_mode != FGX_METHYLATION_DISABLED || n_grp == 0) return run_general(c, general, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
   if (!c->fast) c->fast = new FastState();
   auto t0 = clk::now();
   hybrid_upload(c, records, records_len, rec_off, rec_len, n_rec, grp_first, n_grp);
@@ -443,6 +533,7 @@ int fgx_process_batch_device(fgx_caller* c, const void* d_records, uint64_t reco
       c->err = "fgx_process_batch_device: CODEC duplex-disagreement thresholds need the host path (fgx_process_batch)"; return 1;
     }
     if (c->opt.track_rejects) { c->err = "fgx_process_batch_device: --rejects needs the host path (fgx_process_batch)"; return 1; }
+    if (c->opt.methylation_mode != FGX_METHYLATION_DISABLED) { c->err = "fgx_process_batch_device: the methylation-aware mode needs the host entry (fgx_process_batch)"; return 1; }
     if (!c->fast) c->fast = new FastState();
     c->fast->has_last = false;   // set again only when this batch succeeds
     hip_check(hipSetDevice(c->device), "hipSetDevice");

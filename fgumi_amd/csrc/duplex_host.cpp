@@ -27,6 +27,7 @@ struct RawRef { const uint8_t* p; uint32_t n; };
 
 struct SsCall {            // one ss_caller.consensus_call
   int64_t job = -1;        // column job (None when < 0)
+  int64_t meth = -1;       // methylation-aware mode: the call's annotation job (-1: none)
   std::vector<uint32_t> src_rd;   // ReadDescs of ALL (uncapped) source reads, for the duplex error recount
   std::vector<RawRef> raws;       // alignment-filtered raw records (RX source)
 };
@@ -47,6 +48,15 @@ struct Molecule {
 
 struct View {              // arrays of one single-strand consensus
   const uint8_t* bases; const uint8_t* quals; const uint16_t* depths; const uint16_t* errors; uint32_t len;
+  // its methylation annotation, cut to the consensus length (null: none) — VanillaConsensusRead::methylation
+  const uint8_t* mflag = nullptr; const uint32_t* mu = nullptr; const uint32_t* mt = nullptr;
+};
+
+struct Annot {             // MethylationAnnotation
+  bool some = false;
+  std::vector<uint8_t> flag;
+  std::vector<uint32_t> u, t;
+  void from(const View& v, uint32_t n) { some = v.mflag != nullptr; if (some) { flag.assign(v.mflag, v.mflag + n); u.assign(v.mu, v.mu + n); t.assign(v.mt, v.mt + n); } }
 };
 
 struct Duplex {            // DuplexConsensusRead
@@ -55,12 +65,25 @@ struct Duplex {            // DuplexConsensusRead
   std::vector<uint8_t> ab_b, ab_q, ba_b, ba_q;
   std::vector<uint16_t> ab_d, ab_e, ba_d, ba_e;
   bool has_ba = false;
+  bool is_ba_only = false;
+  Annot meth, ab_meth, ba_meth;      // combined and per-strand annotations (duplex_caller.rs:1086-1094)
   uint16_t ab_max() const { uint16_t m = 0; for (auto d : ab_d) m = std::max(m, d); return m; }
   uint16_t ba_max() const { uint16_t m = 0; for (auto d : ba_d) m = std::max(m, d); return m; }
 };
 
 inline uint8_t cap_quality(int32_t s) { return s < 2 ? 2 : s > 93 ? 93 : (uint8_t)s; }
 inline int32_t clamp_short(uint16_t v) { return v > 32767 ? 32767 : v; }
+inline bool is_conversion_pair(uint8_t x, uint8_t y) {   // duplex_caller.rs:897-903
+  x = meth_upper(x); y = meth_upper(y);
+  return (x == 'C' && y == 'T') || (x == 'T' && y == 'C') || (x == 'G' && y == 'A') || (x == 'A' && y == 'G');
+}
+inline uint8_t unconverted_base(uint8_t x, uint8_t y) {   // :907-913
+  const uint8_t a = meth_upper(x), b = meth_upper(y);
+  if ((a == 'C' && b == 'T') || (a == 'T' && b == 'C')) return 'C';
+  if ((a == 'G' && b == 'A') || (a == 'A' && b == 'G')) return 'G';
+  return x;
+}
+inline uint32_t sat_add_u32(uint32_t a, uint32_t b) { const uint64_t v = (uint64_t)a + b; return v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)v; }
 
 // duplex_consensus (duplex_caller.rs:931-1108).  srcs: ReadDescs of the source reads of both strands, or null.
 bool duplex_consensus(const ColumnBatch& B, const View* ab, const View* ba, const std::vector<uint32_t>* srcs, Duplex& out) {
@@ -78,20 +101,28 @@ bool duplex_consensus(const ColumnBatch& B, const View* ab, const View* ba, cons
     out.bases.assign(s.bases, s.bases + s.len); out.quals.assign(s.quals, s.quals + s.len); out.errors.assign(s.errors, s.errors + s.len);
     copy_strand(s, s.len, out.ab_b, out.ab_q, out.ab_d, out.ab_e);
     out.has_ba = false;
+    out.is_ba_only = !a;
+    out.ab_meth.from(s, s.len);
+    out.meth = out.ab_meth;
     return true;
   }
   for (uint32_t i = 0; i < len; i++) {
     uint8_t ab_b = a->bases[i], ba_b = b->bases[i];
     int32_t aq = a->quals[i], bq = b->quals[i];
     uint8_t raw_base, raw_qual;
-    if (ab_b == ba_b) { raw_base = ab_b; raw_qual = cap_quality(aq + bq); }
+    // a C/T (G/A) disagreement at a reference cytosine of either strand is a conversion event, not an error (:988-1005)
+    const bool is_ref_c = (a->mflag && a->mflag[i]) || (b->mflag && b->mflag[i]);
+    const bool artifact = ab_b != ba_b && is_ref_c && is_conversion_pair(ab_b, ba_b);
+    if (artifact) { raw_base = unconverted_base(ab_b, ba_b); raw_qual = cap_quality(aq + bq); }
+    else if (ab_b == ba_b) { raw_base = ab_b; raw_qual = cap_quality(aq + bq); }
     else if (aq > bq) { raw_base = ab_b; raw_qual = cap_quality(aq - bq); }
     else if (bq > aq) { raw_base = ba_b; raw_qual = cap_quality(bq - aq); }
     else { raw_base = ab_b; raw_qual = FGX_MIN_PHRED; }
     if (ab_b == 'N' || ba_b == 'N' || raw_qual == FGX_MIN_PHRED) { out.bases.push_back('N'); out.quals.push_back(FGX_MIN_PHRED); }
     else { out.bases.push_back(raw_base); out.quals.push_back(raw_qual); }
     int64_t err;
-    if (srcs) {
+    if (artifact) err = 0;
+    else if (srcs) {
       err = 0;
       for (uint32_t rd : *srcs) {
         const ReadDesc& d = B.reads[rd];
@@ -106,6 +137,17 @@ bool duplex_consensus(const ColumnBatch& B, const View* ab, const View* ba, cons
   copy_strand(*a, len, out.ab_b, out.ab_q, out.ab_d, out.ab_e);
   copy_strand(*b, len, out.ba_b, out.ba_q, out.ba_d, out.ba_e);
   out.has_ba = true;
+  out.ab_meth.from(*a, len);
+  out.ba_meth.from(*b, len);
+  if (out.ab_meth.some && out.ba_meth.some) {   // combine_methylation_annotations (methylation.rs:404-427)
+    out.meth.some = true;
+    for (uint32_t i = 0; i < len; i++) {
+      out.meth.flag.push_back(out.ab_meth.flag[i] | out.ba_meth.flag[i]);
+      out.meth.u.push_back(sat_add_u32(out.ab_meth.u[i], out.ba_meth.u[i]));
+      out.meth.t.push_back(sat_add_u32(out.ab_meth.t[i], out.ba_meth.t[i]));
+    }
+  } else if (out.ab_meth.some) out.meth = out.ab_meth;
+  else if (out.ba_meth.some) out.meth = out.ba_meth;
   return true;
 }
 
@@ -203,6 +245,26 @@ bool duplex_read_into(Ctx& x, std::vector<uint8_t>& out, const Duplex& d, int re
     if (!consensus_umis(x.c->h_umi_tables.t, umis, cu)) { x.err = "consensus_umis: UMIs of unequal length or mixed DNA/non-DNA characters"; return false; }
     tag_z(rec, "RX", cu.data(), cu.size());
   }
+  if (d.meth.some) {   // am/au/at, bm/bu/bt, MM/ML/cu/ct (duplex_caller.rs:1338-1398)
+    const bool top = !d.is_ba_only;
+    const int mode = x.o.methylation_mode;
+    std::string mm;
+    std::vector<uint8_t> ml;
+    auto counts = [&](const Annot& a, const char* tu, const char* tt) { tag_count_array(rec, tu, a.u.data(), (uint32_t)a.u.size()); tag_count_array(rec, tt, a.t.data(), (uint32_t)a.t.size()); };
+    if (d.ab_meth.some) {
+      if (meth_build_mm_ml(d.ab_b.data(), (uint32_t)d.ab_b.size(), d.ab_meth.flag.data(), d.ab_meth.u.data(), d.ab_meth.t.data(), top, mode, mm, ml)) tag_z(rec, top ? "am" : "bm", mm.data(), mm.size());
+      counts(d.ab_meth, top ? "au" : "bu", top ? "at" : "bt");
+    }
+    if (d.has_ba && d.ba_meth.some) {
+      if (meth_build_mm_ml(d.ba_b.data(), (uint32_t)d.ba_b.size(), d.ba_meth.flag.data(), d.ba_meth.u.data(), d.ba_meth.t.data(), false, mode, mm, ml)) tag_z(rec, "bm", mm.data(), mm.size());
+      counts(d.ba_meth, "bu", "bt");
+    }
+    if (meth_build_mm_ml(d.bases.data(), (uint32_t)d.bases.size(), d.meth.flag.data(), d.meth.u.data(), d.meth.t.data(), top, mode, mm, ml)) {
+      tag_z(rec, "MM", mm.data(), mm.size());
+      tag_u8_array(rec, "ML", ml.data(), (uint32_t)ml.size());
+    }
+    counts(d.meth, "cu", "ct");
+  }
   append_with_block_size(out, rec.data(), (uint32_t)rec.size());
   return true;
 }
@@ -224,7 +286,9 @@ int duplex_process_general(fgx_caller* c, const uint8_t* blob, const uint64_t* r
   c->grp_out_end.assign(n_grp, 0);
   const bool track = o.track_rejects;
   const bool single_strand_allowed = x.min_yx == 0;
-  const SrcParams sp{o.min_input_base_quality, o.trim != 0, o.duplex_max_reads_per_strand >= 0};
+  const bool meth_on = o.methylation_mode != FGX_METHYLATION_DISABLED && c->genome;
+  const SrcParams sp{o.min_input_base_quality, o.trim != 0, o.duplex_max_reads_per_strand >= 0, meth_on};
+  B.want_stage_back = meth_on;   // the duplex error recount reads the normalised source reads (consensus_call keeps them, vanilla_caller.rs:771)
   std::vector<std::vector<uint8_t>> scratch;
   std::vector<Molecule> mols(n_grp);
   uint64_t ov[4] = {0, 0, 0, 0};
@@ -351,7 +415,7 @@ int duplex_process_general(fgx_caller* c, const uint8_t* blob, const uint64_t* r
     split(ys, f_ba_r1, f_ab_r2);
     auto call = [&](SsCall& sc, const std::vector<SrcRead>& srs, const std::vector<RawRef>& raws) {
       for (auto& s : srs) { sc.src_rd.push_back(s.rd); sc.raws.push_back(raws[s.orig_idx]); }
-      sc.job = stage_consensus_call(B, srs, o.duplex_max_reads_per_strand);
+      sc.job = stage_consensus_call(B, srs, o.duplex_max_reads_per_strand, meth_on ? c->genome.get() : nullptr, &sc.meth);
     };
     call(m.ab_r1, f_ab_r1, x_raws); call(m.ab_r2, f_ab_r2, y_raws); call(m.ba_r1, f_ba_r1, y_raws); call(m.ba_r2, f_ba_r2, x_raws);
   }
@@ -369,7 +433,16 @@ int duplex_process_general(fgx_caller* c, const uint8_t* blob, const uint64_t* r
     bool kept = true;
     if (m.early) kept = m.early_kept;
     else {
-      auto view = [&](const SsCall& sc, View& v) { if (sc.job < 0) return false; const ColJob& j = B.jobs[(size_t)sc.job]; v = View{B.ob.data() + j.out_off, B.oq.data() + j.out_off, B.od.data() + j.out_off, B.oe.data() + j.out_off, j.cons_len}; return true; };
+      auto view = [&](const SsCall& sc, View& v) {
+        if (sc.job < 0) return false;
+        const ColJob& j = B.jobs[(size_t)sc.job];
+        v = View{B.ob.data() + j.out_off, B.oq.data() + j.out_off, B.od.data() + j.out_off, B.oe.data() + j.out_off, j.cons_len};
+        if (sc.meth >= 0 && !B.mflag.empty()) {   // (the anchor is the longest read of the uncapped set: its annotation covers the consensus)
+          const MethJob& mj = B.mjobs[(size_t)sc.meth];
+          if (mj.n_pos >= j.cons_len) { v.mflag = B.mflag.data() + mj.out_off; v.mu = B.mu.data() + mj.out_off; v.mt = B.mt.data() + mj.out_off; }
+        }
+        return true;
+      };
       View v_ab_r1, v_ab_r2, v_ba_r1, v_ba_r2;
       bool h1 = view(m.ab_r1, v_ab_r1), h2 = view(m.ab_r2, v_ab_r2), h3 = view(m.ba_r1, v_ba_r1), h4 = view(m.ba_r2, v_ba_r2);
       auto cons_ok = [&](const Duplex& d) { return x.min_reads_ok(d.ab_max(), d.has_ba ? d.ba_max() : 0); };

@@ -6,6 +6,8 @@
 #include <vector>
 #include "../../include/fgumi_amd.h"
 #include "consensus_math.h"
+#include "methylation_core.h"
+#include <memory>
 
 namespace fgx {
 
@@ -55,6 +57,8 @@ void hip_check(hipError_t e, const char* what);
 void launch_column_jobs(hipStream_t s, const uint8_t* d_stage, const ReadDesc* d_reads, const ColJob* d_jobs, const Tile* d_tiles,
                         uint32_t n_tiles, const DeviceTables* d_tables, ColParams prm, uint8_t* d_ob, uint8_t* d_oq, uint16_t* d_od,
                         uint16_t* d_oe);
+void launch_meth_annotate(hipStream_t s, uint8_t* d_stage, const ReadDesc* d_reads, const MethJob* d_jobs, const MethRun* d_runs, const MethTile* d_tiles,
+                          uint32_t n_tiles, const uint8_t* d_genome, uint8_t* d_flag, uint32_t* d_unconverted, uint32_t* d_converted);
 void launch_libm_test(hipStream_t s, int op, const double* d_x, double* d_y, uint64_t n);
 void launch_sim_generate(hipStream_t s, fgx_sim_params p, const uint64_t* d_fam_byte_off, const uint32_t* d_fam_rec_first,
                          uint8_t* d_blob, uint64_t* d_rec_off, uint32_t* d_rec_len, uint32_t* d_grp_first);
@@ -68,7 +72,23 @@ struct ColumnBatch {
   // results (host copies)
   std::vector<uint8_t> ob, oq;
   std::vector<uint16_t> od, oe;
-  void clear() { stage.clear(); reads.clear(); jobs.clear(); n_cols = 0; }
+  // methylation-aware mode: annotation jobs run before the column jobs (they normalise the staged bases in place)
+  std::vector<MethJob> mjobs;
+  std::vector<MethRun> mruns;
+  uint32_t n_mpos = 0;
+  bool want_stage_back = false;          // duplex: the error recount reads the NORMALISED source reads on the host
+  std::vector<uint8_t> mflag;            // results: is_ref_c, unconverted, converted per annotated position
+  std::vector<uint32_t> mu, mt;
+  void clear() { stage.clear(); reads.clear(); jobs.clear(); n_cols = 0; mjobs.clear(); mruns.clear(); n_mpos = 0; want_stage_back = false; }
+  // One annotate_and_normalize call over the contiguous ReadDescs [rd0, rd0 + n_reads); returns the job id.
+  uint32_t add_meth_job(uint32_t rd0, uint32_t n_reads, uint32_t n_pos, const std::vector<MethRun>& runs, bool top, uint64_t contig_off, uint64_t contig_len) {
+    MethJob j; j.rd0 = rd0; j.n_reads = n_reads; j.n_pos = n_pos; j.out_off = n_mpos; j.run0 = (uint32_t)mruns.size(); j.n_runs = (uint32_t)runs.size();
+    j.top = top ? 1u : 0u; j._pad = 0; j.contig_off = contig_off; j.contig_len = contig_len;
+    mruns.insert(mruns.end(), runs.begin(), runs.end());
+    n_mpos += n_pos;
+    mjobs.push_back(j);
+    return (uint32_t)mjobs.size() - 1;
+  }
   // Appends a source read; returns its ReadDesc index.
   uint32_t add_read(const uint8_t* bases, const uint8_t* quals, uint32_t len) {
     ReadDesc d; d.off = stage.size(); d.len = len; d._pad = 0;
@@ -100,6 +120,17 @@ struct FilterBuffers {
 
 }  // namespace fgx
 
+namespace fgx {
+// The reference genome of the methylation-aware mode, resident in HBM (fgx_set_reference): contig i of the BAM header at
+// [off[i], off[i] + len[i]) of `d_genome`.  Shared (read-only) with the helper callers of the multi-threaded general path.
+struct GenomeRef {
+  int device = 0;
+  DevBuf d_genome;
+  std::vector<uint64_t> off, len;
+  ~GenomeRef() { (void)hipSetDevice(device); d_genome.free_(); }
+};
+}  // namespace fgx
+
 // The caller object behind the C ABI.
 struct FastState;
 struct fgx_caller {
@@ -113,6 +144,8 @@ struct fgx_caller {
   fgx::DeviceTables h_umi_tables;   // consensus_umis tables (90, 90), simple_umi.rs:12-18
   fgx::DevBuf d_tables, d_umi_tables;
   fgx::DevBuf d_stage, d_reads, d_jobs, d_tiles, d_ob, d_oq, d_od, d_oe, d_scratch_a, d_scratch_b;
+  fgx::DevBuf d_mjobs, d_mruns, d_mtiles, d_mflag, d_mu, d_mt;    // methylation annotation jobs and their results
+  std::shared_ptr<fgx::GenomeRef> genome;                          // fgx_set_reference (null: no reference)
   fgx::ColumnBatch batch;
   // outputs of the last call
   std::vector<uint8_t> out_data, out_rejects;

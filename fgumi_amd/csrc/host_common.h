@@ -330,6 +330,16 @@ inline void tag_i16_array(std::vector<uint8_t>& r, const char* tag, const uint16
   put_le32(r, n);
   for (uint32_t i = 0; i < n; i++) put_le16(r, v[i] < 32767 ? v[i] : 32767);
 }
+inline void tag_u8_array(std::vector<uint8_t>& r, const char* tag, const uint8_t* v, uint32_t n) {   // B:C (raw-bam/tags.rs:733-743)
+  r.push_back(tag[0]); r.push_back(tag[1]); r.push_back('B'); r.push_back('C');
+  put_le32(r, n);
+  r.insert(r.end(), v, v + n);
+}
+inline void tag_count_array(std::vector<uint8_t>& r, const char* tag, const uint32_t* v, uint32_t n) {   // B:s of u32 counts clamped to i16::MAX (methylation.rs:50-62)
+  r.push_back(tag[0]); r.push_back(tag[1]); r.push_back('B'); r.push_back('s');
+  put_le32(r, n);
+  for (uint32_t i = 0; i < n; i++) put_le16(r, (uint16_t)(v[i] < 32767u ? v[i] : 32767u));
+}
 inline void tag_phred33(std::vector<uint8_t>& r, const char* tag, const uint8_t* q, uint32_t n) {
   r.push_back(tag[0]); r.push_back(tag[1]); r.push_back('Z');
   for (uint32_t i = 0; i < n; i++) { unsigned v = (unsigned)q[i] + 33; r.push_back((uint8_t)(v > 255 ? 255 : v)); }

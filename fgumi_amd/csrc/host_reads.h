@@ -14,12 +14,16 @@ struct SrcRead {
   uint16_t flags;
   int32_t name_hash;
   SimpCigar cigar;
+  int32_t ref_id = -1;       // methylation-aware mode: reference id, 0-based start, simplified CIGAR before reversal / truncation
+  int64_t aln_start = -1;
+  SimpCigar orig_cigar;
 };
 
 struct SrcParams {
   uint8_t min_bq;
   bool trim;
   bool want_rank;   // max_reads set → Murmur3 name rank, else 0
+  bool meth = false;   // methylation-aware mode: keep the alignment of each source read
 };
 
 // create_source_read: orient, (trim), mask, mate-clip, strip trailing N; stages the read.  0 dropped / 1 ok / -1 fatal.
@@ -47,6 +51,7 @@ inline int make_source_read(ColumnBatch& B, const SrcParams& sp, const uint8_t* 
   out.orig_idx = idx; out.len = final_len; out.flags = flg;
   out.rd = B.add_read(tb.data(), tq.data(), final_len);
   SimpCigar sc = simplify_cigar(v);
+  if (sp.meth) { out.ref_id = v.ref_id(); out.aln_start = (int64_t)v.pos(); out.orig_cigar = sc; }
   if (neg) std::reverse(sc.begin(), sc.end());
   out.cigar = truncate_cigar(sc, final_len);
   out.name_hash = sp.want_rank ? read_name_rank(v.name(), v.name_len()) : 0;
@@ -88,8 +93,23 @@ inline void filter_by_alignment(std::vector<SrcRead>& srs, HostStats& st, std::v
 // consensus_call (vanilla_caller.rs:706-779) with the single-strand settings the duplex / CODEC callers use
 // (min_reads = 1): optional per-strand cap by name rank, then one column job over the (capped) reads with
 // consensus length = the longest read.  Returns the job id or -1 for None.
-inline int64_t stage_consensus_call(ColumnBatch& B, const std::vector<SrcRead>& srs, int64_t max_reads) {
+// With a genome (methylation-aware mode) the call is annotated first, over ALL its reads (the cap shapes the consensus only,
+// vanilla_caller.rs:715-724): *meth_job = the annotation job, or -1 (annotate_and_normalize returned None).
+inline int64_t stage_consensus_call(ColumnBatch& B, const std::vector<SrcRead>& srs, int64_t max_reads, const GenomeRef* genome = nullptr, int64_t* meth_job = nullptr) {
+  if (meth_job) *meth_job = -1;
   if (srs.empty()) return -1;
+  if (genome && meth_job) {
+    size_t a = 0;   // max_by_key: the LAST longest read
+    for (size_t i = 1; i < srs.size(); i++) if (srs[i].len >= srs[a].len) a = i;
+    const SrcRead& an = srs[a];
+    if (an.ref_id >= 0 && an.aln_start >= 0 && (size_t)an.ref_id < genome->len.size()) {
+      std::vector<MethRun> runs;
+      meth_runs(an.cigar, an.aln_start, (an.flags & bam::F_REVERSE) != 0, an.orig_cigar, runs);
+      uint32_t rd0 = (uint32_t)B.reads.size();
+      for (auto& s : srs) B.reads.push_back(B.reads[s.rd]);   // descriptors only
+      *meth_job = (int64_t)B.add_meth_job(rd0, (uint32_t)srs.size(), an.len, runs, meth_is_top_strand(an.flags), genome->off[(size_t)an.ref_id], genome->len[(size_t)an.ref_id]);
+    }
+  }
   std::vector<const SrcRead*> use;
   if (max_reads >= 0 && srs.size() > (size_t)max_reads) {
     std::vector<uint32_t> idx(srs.size());

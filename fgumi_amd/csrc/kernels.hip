@@ -78,6 +78,35 @@ void launch_column_jobs(hipStream_t s, const uint8_t* d_stage, const ReadDesc* d
 }
 
 // -----------------------------------------------------------------------------------------
+// Methylation-aware mode (general path): one wavefront = 64 consecutive positions of one annotation job (one
+// annotate_and_normalize call, vanilla_caller.rs:781-860); a lane looks its position's reference base up in the genome (resident
+// in HBM) through the anchor's aligned runs, counts unconverted / converted bases down the call's source reads (coalesced along
+// the read, like the column kernel) and rewrites converted bases in the staged bytes.  Runs BEFORE k_column_jobs on the stream.
+// Bound: HBM / L2 streaming of 1 B per source base; the genome reads are 64 consecutive bytes per wavefront.
+// -----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_meth_annotate(uint8_t* __restrict__ stage, const ReadDesc* __restrict__ reads, const MethJob* __restrict__ jobs,
+                                                       const MethRun* __restrict__ runs, const MethTile* __restrict__ tiles, uint32_t n_tiles,
+                                                       const uint8_t* __restrict__ genome, uint8_t* __restrict__ flag, uint32_t* __restrict__ unconverted,
+                                                       uint32_t* __restrict__ converted) {
+  uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  uint32_t lane = threadIdx.x & 63;
+  if (wave >= n_tiles) return;
+  MethTile t = tiles[wave];
+  MethJob j = jobs[t.job];
+  uint32_t p = t.p0 + lane;
+  if (p >= j.n_pos) return;
+  uint32_t o = j.out_off + p;
+  meth_annotate_position(stage, reads + j.rd0, j.n_reads, runs + j.run0, j.n_runs, genome + j.contig_off, j.contig_len, j.top != 0, p, &flag[o], &unconverted[o],
+                         &converted[o]);
+}
+void launch_meth_annotate(hipStream_t s, uint8_t* d_stage, const ReadDesc* d_reads, const MethJob* d_jobs, const MethRun* d_runs, const MethTile* d_tiles,
+                          uint32_t n_tiles, const uint8_t* d_genome, uint8_t* d_flag, uint32_t* d_unconverted, uint32_t* d_converted) {
+  if (n_tiles == 0) return;
+  uint32_t blocks = (n_tiles + 3) / 4;
+  hipLaunchKernelGGL(k_meth_annotate, dim3(blocks), dim3(256), 0, s, d_stage, d_reads, d_jobs, d_runs, d_tiles, n_tiles, d_genome, d_flag, d_unconverted, d_converted);
+}
+
+// -----------------------------------------------------------------------------------------
 // Device self-test of the glibc-compatible libm.
 // -----------------------------------------------------------------------------------------
 __global__ void k_libm(int op, const double* __restrict__ x, double* __restrict__ y, uint64_t n) {

@@ -32,6 +32,9 @@ struct SrcRead {
   uint16_t flags;
   int32_t name_hash;
   SimpCigar cigar;
+  int32_t ref_id = -1;         // methylation-aware mode: reference id, 0-based start and the simplified CIGAR before reversal /
+  int64_t aln_start = -1;      // truncation (vanilla_caller.rs:1176-1190)
+  SimpCigar orig_cigar;
 };
 
 enum ReadType { RT_FRAGMENT = 0, RT_R1 = 1, RT_R2 = 2 };
@@ -42,6 +45,8 @@ struct PendingRecord {   // one consensus record to assemble once the device ret
   std::string umi;
   const uint8_t* first_raw; uint32_t first_len;    // for the cell-barcode tag
   std::vector<std::string> rx;                      // RX of every retained read
+  int64_t meth_job = -1;                            // annotation job of the methylation-aware mode (-1: no annotation)
+  bool meth_top = true;                             // is_top_strand of the FIRST retained read (vanilla_caller.rs:1855-1858)
 };
 
 struct Positioned { uint32_t pos; const uint8_t* p; uint32_t n; };
@@ -101,6 +106,7 @@ int create_source_read(Ctx& x, const Positioned& pr, uint32_t idx, uint64_t mate
   out.flags = flg;
   out.rd = x.c->batch.add_read(tb.data(), tq.data(), final_len);
   SimpCigar sc = simplify_cigar(v);
+  if (x.o.methylation_mode != FGX_METHYLATION_DISABLED) { out.ref_id = v.ref_id(); out.aln_start = (int64_t)v.pos(); out.orig_cigar = sc; }
   if (neg) std::reverse(sc.begin(), sc.end());
   out.cigar = truncate_cigar(sc, final_len);
   out.name_hash = x.o.max_reads >= 0 ? read_name_rank(v.name(), v.name_len()) : 0;
@@ -205,6 +211,21 @@ int process_subgroup(Ctx& x, const std::string& umi, ReadType rt, const std::vec
     for (auto& s : srs) B.reads.push_back(B.reads[s.rd]);   // descriptors only; staged bytes are shared
   }
   PendingRecord pr;
+  // annotate_and_normalize (vanilla_caller.rs:781-860) of the retained reads: the anchor is the LAST longest read (max_by_key); no
+  // annotation without a reference, for an unplaced anchor or a reference id outside the header.  The job runs on the device before
+  // the column job and rewrites the staged bases (methylation_core.h).
+  if (x.o.methylation_mode != FGX_METHYLATION_DISABLED && x.c->genome) {
+    size_t a = 0;
+    for (size_t i = 1; i < srs.size(); i++) if (srs[i].len >= srs[a].len) a = i;
+    const SrcRead& an = srs[a];
+    const GenomeRef& G = *x.c->genome;
+    if (an.ref_id >= 0 && an.aln_start >= 0 && (size_t)an.ref_id < G.len.size()) {
+      std::vector<MethRun> runs;
+      meth_runs(an.cigar, an.aln_start, (an.flags & bam::F_REVERSE) != 0, an.orig_cigar, runs);
+      pr.meth_job = (int64_t)B.add_meth_job(rd0, (uint32_t)srs.size(), an.len, runs, meth_is_top_strand(an.flags), G.off[(size_t)an.ref_id], G.len[(size_t)an.ref_id]);
+      pr.meth_top = meth_is_top_strand(srs[0].flags);
+    }
+  }
   pr.job = B.add_job(rd0, (uint32_t)srs.size(), cons_len);
   pr.read_type = (uint8_t)rt;
   pr.umi = umi;
@@ -363,6 +384,18 @@ int simplex_process_general(fgx_caller* c, const uint8_t* blob, const uint64_t* 
       std::string cu;
       if (!consensus_umis(c->h_umi_tables.t, pr.rx, cu)) { c->err = "consensus_umis: UMIs of unequal length or mixed DNA/non-DNA characters"; return 2; }
       tag_z(rec, "RX", cu.data(), cu.size());
+    }
+    if (pr.meth_job >= 0 && !B.mflag.empty()) {   // MM, ML, cu, ct (vanilla_caller.rs:1853-1876); the annotation is cut to the consensus length
+      const MethJob& mj = B.mjobs[(size_t)pr.meth_job];
+      const uint32_t n = std::min(mj.n_pos, j.cons_len);
+      std::string mm;
+      std::vector<uint8_t> ml;
+      if (n == j.cons_len && meth_build_mm_ml(bases, n, B.mflag.data() + mj.out_off, B.mu.data() + mj.out_off, B.mt.data() + mj.out_off, pr.meth_top, o.methylation_mode, mm, ml)) {
+        tag_z(rec, "MM", mm.data(), mm.size());
+        tag_u8_array(rec, "ML", ml.data(), (uint32_t)ml.size());
+      }
+      tag_count_array(rec, "cu", B.mu.data() + mj.out_off, n);
+      tag_count_array(rec, "ct", B.mt.data() + mj.out_off, n);
     }
     append_with_block_size(c->out_data, rec.data(), (uint32_t)rec.size());
   }

@@ -1,0 +1,202 @@
+"""GPU parity: the methylation-aware mode (EM-Seq / TAPs) of the simplex and duplex callers through the C ABI — genome resident in
+HBM (`fgx_set_reference`), annotation + normalisation kernel (`k_meth_annotate`) ahead of the column kernel, MM / ML / cu / ct (and the
+duplex per-strand am/au/at, bm/bu/bt) assembled with the records — against the oracle, byte for byte: the inputs of the reference's own
+unit tests (tests/test_oracle_methylation_pins.py) and seeded EM-Seq-like batches (tests/methsim.py) large enough for the sharded
+general path."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import bamutil
+import fgx_opts
+import methsim
+import orc
+from fgumi_amd import DuplexConsensusCaller, GroupedReads, MethylationMode, VanillaUmiConsensusCaller, VanillaUmiConsensusOptions, split_records
+from fgumi_amd._lib import Options, Output, lib
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle(o, contigs, g, batch_groups=50):
+    orc.set_reference(contigs)
+    try:
+        return orc.process(o, g.blob, g.rec_off, g.rec_len, g.grp_first, batch_groups=batch_groups)
+    finally:
+        orc.set_reference(None)
+
+
+def set_reference(h, contigs):
+    if not contigs:
+        assert lib.fgx_set_reference(h, 0, None, None) == 0
+        return
+    bufs = [C.create_string_buffer(bytes(s), max(1, len(s))) for s in contigs]
+    ptrs = (C.c_void_p * len(bufs))(*[C.cast(b, C.c_void_p).value for b in bufs])
+    lens = (C.c_uint64 * len(bufs))(*[len(s) for s in contigs])
+    rc = lib.fgx_set_reference(h, len(bufs), ptrs, lens)
+    assert rc == 0, lib.fgx_last_error(h).decode()
+
+
+def product(o, contigs, g, general_only=False):
+    po = Options.from_buffer_copy(bytes(o))
+    h = lib.fgx_create(C.byref(po))
+    assert h, lib.fgx_global_error().decode()
+    try:
+        set_reference(h, contigs)
+        if general_only:
+            lib.fgx_set_general_only(h, 1)
+        out = Output()
+        rc = lib.fgx_process_batch(h, g.blob.ctypes.data, g.blob.size, g.rec_off.ctypes.data, g.rec_len.ctypes.data, g.n_rec, g.grp_first.ctypes.data, g.n_grp, C.byref(out))
+        assert rc == 0, lib.fgx_last_error(h).decode()
+        return dict(data=C.string_at(out.data, out.data_len) if out.data_len else b"", count=int(out.count), stats=np.array(list(out.stats), dtype=np.uint64),
+                    rejects=C.string_at(out.rejects, out.rejects_len) if out.rejects_len else b"", n_rejects=int(out.n_rejects))
+    finally:
+        lib.fgx_destroy(h)
+
+
+def same(o, contigs, groups, batch_groups=50, **kw):
+    g = groups if isinstance(groups, GroupedReads) else GroupedReads.from_groups(groups)
+    want = oracle(o, contigs, g, batch_groups)
+    got = product(o, contigs, g, **kw)
+    assert got["count"] == want["count"]
+    if got["data"] != want["data"]:
+        for i, (a, b) in enumerate(zip(split_records(got["data"]), split_records(want["data"]))):
+            if a != b:
+                raise AssertionError(f"record {i} differs:\n got {bamutil.parse(a)}\nwant {bamutil.parse(b)}")
+        raise AssertionError("record count / length differs")
+    assert np.array_equal(got["stats"], want["stats"]), (got["stats"].tolist(), want["stats"].tolist())
+    if o.track_rejects:
+        assert got["rejects"] == want["rejects"] and got["n_rejects"] == want["n_rejects"]
+    return want
+
+
+def opts_from(kw):
+    kw = dict(kw)
+    mr = kw.pop("duplex_min_reads", None)
+    o = fgx_opts.defaults(**kw)
+    if mr:
+        o.duplex_min_reads[0], o.duplex_min_reads[1], o.duplex_min_reads[2] = mr
+    return o
+
+
+def test_reference_unit_test_inputs():
+    """Every caller-level case of the reference's methylation tests (simplex EM-Seq / TAPs, longest-read anchor, non-C reference,
+    mode off, BA-only duplex molecules) and of this repo's crafted additions (reverse fragments, pairs, indel anchors, no reference,
+    contig outside the header) through the HIP path."""
+    import test_oracle_methylation_pins as pins
+    cases = pins.replay_cases()
+    assert len(cases) >= 18
+    n_tagged = 0
+    for kw, contigs, groups in cases:
+        o = opts_from(kw)
+        want = same(o, contigs, groups, batch_groups=100 if kw.get("kind") == 1 else 50)
+        n_tagged += sum("cu" in bamutil.parse(r)["tags"] for r in split_records(want["data"]))
+    assert n_tagged >= 15
+
+
+@pytest.mark.parametrize("mode,kw", [
+    (1, dict(min_reads=1)), (2, dict(min_reads=1)), (1, dict(min_reads=2, track_rejects=1)), (1, dict(min_reads=1, max_reads=3)),
+    (2, dict(min_reads=2, overlapping_consensus=0, produce_per_base_tags=0)), (1, dict(min_reads=1, min_input_base_quality=25, trim=1)),
+])
+def test_simplex_em_seq_like_batches(mode, kw):
+    """1 500 families (fragments of both orientations, pairs, overlapping mates, indel and soft-clipped anchors, reads off the end of a
+    contig, a contig outside the header): enough groups for the general path's shards to run on several helper callers, which share
+    the one genome in HBM."""
+    rng = methsim.seeded(40 + mode)
+    contigs = methsim.genome(rng)
+    groups = methsim.simplex_groups(rng, contigs, 1500)
+    want = same(fgx_opts.defaults(methylation_mode=mode, **kw), contigs, groups)
+    recs = [bamutil.parse(r) for r in split_records(want["data"])]
+    assert sum("MM" in r["tags"] for r in recs) > 200 and sum("cu" in r["tags"] for r in recs) > 800
+
+
+@pytest.mark.parametrize("mode,min_reads,kw", [
+    (1, (1, 1, 0), {}), (2, (1, 1, 0), {}), (1, (2, 1, 1), dict(track_rejects=1)), (1, (1, 1, 0), dict(duplex_max_reads_per_strand=2)),
+    (1, (3, 2, 1), dict(produce_per_base_tags=0, overlapping_consensus=0)),
+])
+def test_duplex_em_seq_like_batches(mode, min_reads, kw):
+    """1 200 duplex molecules: A-only, B-only and two-strand molecules, conversion on the A strand's C's and the B strand's G's (the
+    conversion-artifact rule of duplex_consensus), deletions and soft clips in the anchors, a per-strand cap that bites (annotation over
+    all reads, consensus over the capped ones)."""
+    rng = methsim.seeded(70 + mode)
+    contigs = methsim.genome(rng)
+    groups = methsim.duplex_groups(rng, contigs, 1200)
+    o = fgx_opts.defaults(kind=1, methylation_mode=mode, **kw)
+    o.duplex_min_reads[0], o.duplex_min_reads[1], o.duplex_min_reads[2] = min_reads
+    want = same(o, contigs, groups, batch_groups=100)
+    recs = [bamutil.parse(r) for r in split_records(want["data"])]
+    assert sum("au" in r["tags"] and "bu" in r["tags"] for r in recs) > 100 and sum("MM" in r["tags"] for r in recs) > 200
+
+
+def test_small_batch_runs_inline_and_general_only_agrees():
+    rng = methsim.seeded(9)
+    contigs = methsim.genome(rng, n_contigs=2, length=1500)
+    groups = methsim.simplex_groups(rng, contigs, 60)
+    o = fgx_opts.defaults(min_reads=1, methylation_mode=1)
+    same(o, contigs, groups)
+    same(o, contigs, groups, general_only=True)
+
+
+def test_mode_without_a_reference_and_dropping_the_reference():
+    rng = methsim.seeded(21)
+    contigs = methsim.genome(rng, n_contigs=1, length=1200)
+    groups = methsim.simplex_groups(rng, contigs, 80)
+    o = fgx_opts.defaults(min_reads=1, methylation_mode=1)
+    want = same(o, None, groups)                 # annotate_and_normalize returns None without a reference: the plain consensus
+    assert not any("cu" in bamutil.parse(r)["tags"] for r in split_records(want["data"]))
+    g = GroupedReads.from_groups(groups)
+    po = Options.from_buffer_copy(bytes(o))
+    h = lib.fgx_create(C.byref(po))
+    try:
+        out = Output()
+        args = (g.blob.ctypes.data, g.blob.size, g.rec_off.ctypes.data, g.rec_len.ctypes.data, g.n_rec, g.grp_first.ctypes.data, g.n_grp)
+        set_reference(h, contigs)
+        assert lib.fgx_process_batch(h, *args, C.byref(out)) == 0
+        with_ref = C.string_at(out.data, out.data_len)
+        set_reference(h, None)
+        assert lib.fgx_process_batch(h, *args, C.byref(out)) == 0
+        assert C.string_at(out.data, out.data_len) == want["data"] and with_ref == oracle(o, contigs, g)["data"] != want["data"]
+    finally:
+        lib.fgx_destroy(h)
+
+
+def test_device_entry_and_codec_refuse_the_mode():
+    o = fgx_opts.defaults(min_reads=1, methylation_mode=1)
+    po = Options.from_buffer_copy(bytes(o))
+    h = lib.fgx_create(C.byref(po))
+    assert h
+    try:
+        out, nd, dp = Output(), C.c_uint32(), C.c_void_p()
+        rc = lib.fgx_process_batch_device(h, None, 0, None, None, 0, None, 0, C.byref(out), C.byref(nd), C.byref(dp))
+        assert rc != 0 and b"methylation" in lib.fgx_last_error(h)
+    finally:
+        lib.fgx_destroy(h)
+    bad = Options.from_buffer_copy(bytes(fgx_opts.defaults(kind=2, methylation_mode=1)))
+    assert not lib.fgx_create(C.byref(bad)) and b"CODEC" in lib.fgx_global_error()
+    bad = Options.from_buffer_copy(bytes(fgx_opts.defaults(methylation_mode=7)))
+    assert not lib.fgx_create(C.byref(bad))
+
+
+def test_python_mirror_of_set_reference():
+    """`VanillaUmiConsensusCaller::set_reference(reference, ref_names)` and `DuplexConsensusCaller::set_reference(reference,
+    ref_names, methylation_mode)` as the host mirror spells them."""
+    ref = {"chr1": b"N" * 99 + b"CCCCCCCCCC"}
+    reads = [bamutil.make_record(f"r{i}", s, [30] * 10, flag=0, ref_id=0, pos=99, tags=[("MI", "Z", "UMI1")]) for i, s in enumerate(["C" * 10, "C" * 10, "T" * 10])]
+    c = VanillaUmiConsensusCaller("consensus", "A", VanillaUmiConsensusOptions(min_reads=1, min_consensus_base_quality=0, methylation_mode=MethylationMode.EmSeq))
+    c.set_reference(ref, ["chr1"])
+    rec = bamutil.parse(split_records(c.process_batch(GroupedReads.from_groups([reads])).data)[0])
+    c.close()
+    assert rec["seq"] == "C" * 10 and rec["tags"]["ML"][1] == [170] * 10 and rec["tags"]["cu"][1] == [2] * 10 and rec["tags"]["ct"][1] == [1] * 10
+    ref = {"chr1": b"N" * 99 + b"GGGGGGGGGG"}
+    F_PAIRED, F_REVERSE, F_MATE_REVERSE, F_FIRST, F_LAST = 0x1, 0x10, 0x20, 0x40, 0x80
+    mol = []
+    for i in (1, 2, 3):
+        for seq, flag in (("G" * 10, F_PAIRED | F_FIRST | F_REVERSE), ("C" * 10, F_PAIRED | F_LAST | F_MATE_REVERSE)):
+            mol.append(bamutil.make_record(f"q{i}", seq, [30] * 10, flag=flag, ref_id=0, pos=99, mapq=0, cigar="10M", mate_ref=0, mate_pos=99, tags=[("MI", "Z", "foo/B"), ("RG", "Z", "A")]))
+    d = DuplexConsensusCaller("consensus", "RG1", [1, 1, 0], min_input_base_quality=0, produce_per_base_tags=False)
+    d.set_reference(ref, ["chr1"], MethylationMode.EmSeq)
+    out = d.process_batch(GroupedReads.from_groups([mol]))
+    d.close()
+    assert out.count == 2
+    for r in map(bamutil.parse, split_records(out.data)):
+        assert "bu" in r["tags"] and "bt" in r["tags"] and "au" not in r["tags"]
