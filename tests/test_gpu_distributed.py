@@ -29,13 +29,13 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, shape):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     from fgumi_amd import VanillaUmiConsensusCaller, VanillaUmiConsensusOptions, simulate_grouped_reads
     from fgumi_amd.distributed import gather_payload_to_root, gather_sizes, sum_over_ranks
-    g = simulate_grouped_reads(F_PER_RANK, family_size=3, first_family=rank * F_PER_RANK)      # this rank's shard of the stream
+    g = simulate_grouped_reads(F_PER_RANK, first_family=rank * F_PER_RANK, **shape)              # this rank's shard of the stream
     c = VanillaUmiConsensusCaller("", "A", VanillaUmiConsensusOptions(min_reads=1, min_consensus_base_quality=2, cell_tag="CB"), overlapping_consensus=True)
     out = c.process_batch(g)                                                                     # the HIP engine; it has no CPU fallback
     local = torch.frombuffer(bytearray(out.data), dtype=torch.uint8)
@@ -54,13 +54,16 @@ def _worker(rank, world, port, outdir):
 
 
 @pytest.mark.timeout(600)
-def test_two_ranks_on_one_gpu_concatenate_to_the_oracle_output_of_the_whole_stream(tmp_path):
+@pytest.mark.parametrize("shape", [dict(family_size=3), dict(family_size=2, family_size_max=50)], ids=["depth3", "long_tail_2_to_50"])
+def test_two_ranks_on_one_gpu_concatenate_to_the_oracle_output_of_the_whole_stream(tmp_path, shape):
+    """depth3: the smallest BASELINE shape; long_tail_2_to_50: the family-size distribution of configs[3] (the 8-GPU long-tail run), where
+    the ranks' shards differ in bytes and the wave2 / workgroup kernels decide most families."""
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), shape), nprocs=world, join=True)
     import fgx_opts
     import orc
     from fgumi_amd import simulate_grouped_reads
-    g = simulate_grouped_reads(world * F_PER_RANK, family_size=3)
+    g = simulate_grouped_reads(world * F_PER_RANK, **shape)
     want = orc.process(fgx_opts.defaults(min_reads=1), g.blob, g.rec_off, g.rec_len, g.grp_first)
     payload = np.load(tmp_path / "payload.npy").tobytes()
     sizes = np.load(tmp_path / "sizes.npy")
