@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tests", "hostemu", "hostemu.cpp")
 OUT = os.path.join(ROOT, "tests", "hostemu", "_build", "libhostemu.so")
 CSRC = os.path.join(ROOT, "fgumi_amd", "csrc")
-PARTS = [SRC, os.path.join(CSRC, "simplex_host.cpp"), os.path.join(CSRC, "duplex_host.cpp")]
+PARTS = [SRC, os.path.join(CSRC, "simplex_host.cpp"), os.path.join(CSRC, "duplex_host.cpp"), os.path.join(CSRC, "codec_host.cpp")]
 
 
 def _stale():

@@ -1,6 +1,6 @@
 // hostemu.cpp — TEST INFRASTRUCTURE ONLY.  Not part of the product, never loaded by it.
 //
-// The general path's host orchestration (fgumi_amd/csrc/simplex_host.cpp, duplex_host.cpp: source-read preparation, annotation jobs,
+// The general path's host orchestration (fgumi_amd/csrc/simplex_host.cpp, duplex_host.cpp, codec_host.cpp: source-read preparation, annotation jobs,
 // the duplex strand combine, record assembly) linked against a stand-in for `fgx_caller::run_columns` that walks the staged jobs on
 // the host, lane by lane: the annotation job through the product's own host + device source (methylation_core.h), the column job
 // through consensus_math.h's ColumnAcc / column_call — the functions the kernels call.  There is no GPU where the CPU suite runs; this
@@ -120,6 +120,7 @@ int hemu_process_batch(fgx_caller* c, const uint8_t* records, const uint64_t* re
   try {
     if (c->opt.caller_kind == FGX_CALLER_SIMPLEX) return simplex_process_general(c, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
     if (c->opt.caller_kind == FGX_CALLER_DUPLEX) return duplex_process_general(c, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
+    if (c->opt.caller_kind == FGX_CALLER_CODEC) return codec_process_general(c, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
     c->err = "hostemu: caller kind not covered";
     return 1;
   } catch (const std::exception& ex) { c->err = ex.what(); return 3; }
