@@ -12,6 +12,7 @@
 #include "fastpath.h"
 #include "host_common.h"
 #include "simgen.h"
+#include "canon_core.h"
 
 using namespace fgx;
 
@@ -297,6 +298,27 @@ int fgx_methylation_mm_ml_host(const uint8_t* bases, uint32_t n, const uint8_t* 
   memcpy(mm, s.c_str(), s.size() + 1);
   if (!m.empty()) memcpy(ml, m.data(), m.size());
   return (int)m.size();
+}
+
+// canon_core.h on the host: the canonical form of ONE duplex molecule (the records at rec_off / rec_len), written to `out` at the same
+// offsets; out_len[i] = the canonical record's length, 0 = dropped by the alignment filter.  delta5 = {reads dropped
+// (MinorityAlignment), the four CorrectionStats of the overlap pre-step}.  Returns 0, or 1 when the molecule is out of scope.
+static canon::Params canon_params(const fgx_options* o) {
+  canon::Params P;
+  P.min_bq = o->min_input_base_quality; P.overlapping = o->overlapping_consensus; P.trim = o->trim; P._pad = 0;
+  P.min_total = o->duplex_min_reads[0]; P.min_xy = o->duplex_min_reads[1]; P.min_yx = o->duplex_min_reads[2];
+  P.max_reads_per_strand = o->duplex_max_reads_per_strand;
+  P.cell_tag[0] = o->cell_tag[0]; P.cell_tag[1] = o->cell_tag[1]; P._pad2[0] = P._pad2[1] = 0;
+  return P;
+}
+int fgx_canon_duplex_host(const fgx_options* o, const uint8_t* blob, const uint64_t* rec_off, const uint32_t* rec_len, uint32_t n, uint8_t* out, uint32_t* out_len,
+                          uint64_t* delta5) {
+  if (!o || o->struct_size != sizeof(fgx_options) || !blob || !out || !out_len || !delta5) return 2;
+  static thread_local canon::Scratch S;
+  canon::Delta D;
+  const int rc = canon::canon_duplex_molecule(canon_params(o), blob, rec_off, rec_len, n, out, rec_off, out_len, S, D);
+  delta5[0] = D.minority; for (int i = 0; i < 4; i++) delta5[1 + i] = D.ov[i];
+  return rc;
 }
 
 // Host-input entry: upload once, run the device-resident pipeline, bring the records back, and send

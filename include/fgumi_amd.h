@@ -199,6 +199,18 @@ uint32_t fgx_methylation_runs_host(const uint32_t* simplified, uint32_t n_s, int
 int fgx_methylation_mm_ml_host(const uint8_t* bases, uint32_t n, const uint8_t* is_ref_c, const uint32_t* unconverted, const uint32_t* converted, int top_strand,
                                int mode, char* mm, uint32_t mm_cap, uint8_t* ml, uint32_t ml_cap);
 
+/* ---- canonical form of a duplex molecule with indel / skip / pad CIGARs (fgumi_amd/csrc/canon_core.h), host-side test hook ------
+ * Rewrites ONE duplex molecule so that the device pipeline's one-aligned-block duplex kernels decide it exactly as the reference
+ * decides the original: the R1/R2 overlap pre-correction (overlapping.rs:236-336; duplex.rs:786-795) is written into the bases and
+ * qualities, the mate clip (raw-bam/overlap.rs:181-268) is applied by cutting the read, reads the alignment filter rejects
+ * (vanilla_caller.rs:48-120, 1242-1296) are dropped and counted, the survivors get the CIGAR `<len>M` and lose their MC tag.
+ * `out` receives the canonical records at the records' own offsets (out_len[i] bytes each; 0 = dropped); delta5 = {dropped reads
+ * (MinorityAlignment), overlapping_bases, bases_agreeing, bases_disagreeing, bases_corrected} to add to the statistics of the
+ * canonical molecule.  Returns 0; 1 = out of scope (the molecule stays on the general path); 2 = bad arguments.  The same
+ * source compiles for the device (one lane per molecule). */
+int fgx_canon_duplex_host(const fgx_options* o, const uint8_t* blob, const uint64_t* rec_off, const uint32_t* rec_len, uint32_t n, uint8_t* out, uint32_t* out_len,
+                          uint64_t* delta5);
+
 /* Device self-test of the glibc-compatible libm: op 0 exp, 1 log, 2 log1p, 3 expm1. */
 int fgx_device_libm(fgx_caller* c, int op, const double* x, double* y, uint64_t n);
 
