@@ -181,6 +181,8 @@ def load():
     L.fgx_build_tables_host.restype = I
     L.fgx_host_libm_array.argtypes = [I, VP, VP, U64]
     L.fgx_host_libm_array.restype = None
+    L.fgx_debug_last_deferral.argtypes = [VP, VP]
+    L.fgx_debug_last_deferral.restype = None
     L.fgx_set_general_only.argtypes = [VP, I]
     L.fgx_set_general_only.restype = None
     L.fgx_set_fast_lds_bytes.argtypes = [VP, U32]

@@ -232,7 +232,7 @@ void fgx_destroy(fgx_caller* c) {
   (void)hipSetDevice(c->device);
   for (DevBuf* b : {&c->d_tables, &c->d_umi_tables, &c->d_stage, &c->d_reads, &c->d_jobs, &c->d_tiles, &c->d_ob, &c->d_oq, &c->d_od,
                     &c->d_oe, &c->d_scratch_a, &c->d_scratch_b, &c->d_in_blob, &c->d_in_off, &c->d_in_len, &c->d_in_grp, &c->d_mjobs, &c->d_mruns,
-                    &c->d_mtiles, &c->d_mflag, &c->d_mu, &c->d_mt})
+                    &c->d_mtiles, &c->d_mflag, &c->d_mu, &c->d_mt, &c->d_canon_blob, &c->d_canon_off, &c->d_canon_len, &c->d_canon_grp})
     b->free_();
   c->genome.reset();
   if (c->fast) { c->fast->fp.release(); c->fast->pin_out.free_(); delete c->fast; }
@@ -444,6 +444,97 @@ static int process_hybrid(fgx_caller* c, general_fn general, const uint8_t* reco
 
 // Kernels, download and the splice with the general path's output for the deferred families.  `dst` (pinned, dst_cap bytes):
 // when the records fit they are downloaded straight there and out->data == dst; otherwise they land in the caller's own buffers.
+// Opt-in (FGX_DUPLEX_CANON=1): duplex molecules the device pipeline deferred because of indel / skip / pad CIGARs are rewritten into
+// their canonical form (canon_core.h: overlap correction, mate clip and alignment filter applied; every read `<len>M`) on the host's
+// cores and decided by the device pipeline in a SECOND pass; only what the canonical form cannot express (and what the second pass
+// still defers) takes the general path.  tests/test_canon_core.py shows through the oracle that the canonical molecule plus the
+// counted delta gives the original's result.  Off by default until the whole GPU suite has run with it.
+static bool duplex_canon_enabled() { const char* e = getenv("FGX_DUPLEX_CANON"); return e && e[0] == '1'; }
+
+struct CanonPass {
+  std::vector<uint8_t> used;            // per deferred group: 1 = its records come from the second device pass
+  std::vector<uint64_t> beg, end;       // ... their byte range in `out`
+  std::vector<uint8_t> out;             // the second pass's records (host copy)
+  uint64_t count = 0, stats[FGX_STATS_LEN] = {0};
+  double ms_kernels = 0, ms_host = 0;
+};
+
+static void canon_second_pass(fgx_caller* c, const uint8_t* records, const uint64_t* rec_off, const uint32_t* rec_len, const uint32_t* grp_first,
+                              const std::vector<uint32_t>& def, CanonPass& cp) {
+  const size_t nd = def.size();
+  cp.used.assign(nd, 0); cp.beg.assign(nd, 0); cp.end.assign(nd, 0);
+  auto t0 = clk::now();
+  // slots of the deferred molecules' records in one compact buffer: 4-byte length prefix + room for the original body
+  std::vector<uint64_t> first(nd + 1, 0);
+  for (size_t k = 0; k < nd; k++) first[k + 1] = first[k] + (grp_first[def[k] + 1] - grp_first[def[k]]);
+  const uint64_t n_slots = first[nd];
+  std::vector<uint64_t> out_off(n_slots);
+  std::vector<uint32_t> out_len(n_slots, 0);
+  uint64_t bytes = 0;
+  for (size_t k = 0; k < nd; k++)
+    for (uint32_t r = grp_first[def[k]], i = 0; r < grp_first[def[k] + 1]; r++, i++) { out_off[first[k] + i] = bytes + 4; bytes += 4ull + rec_len[r]; }
+  std::vector<uint8_t> blob(bytes + 16, 0);
+  std::vector<int> status(nd, canon::CANON_OUT_OF_SCOPE);
+  std::vector<canon::Delta> delta(nd);
+  const canon::Params P = canon_params(&c->opt);
+  unsigned T = host_threads();
+  if (T > nd / 64 + 1) T = (unsigned)(nd / 64 + 1);
+  auto work = [&](unsigned t) {
+    std::unique_ptr<canon::Scratch> S(new canon::Scratch());
+    for (size_t k = t; k < nd; k += T) {
+      const uint32_t r0 = grp_first[def[k]], n = grp_first[def[k] + 1] - r0;
+      status[k] = canon::canon_duplex_molecule(P, records, rec_off + r0, rec_len + r0, n, blob.data(), out_off.data() + first[k], out_len.data() + first[k], *S, delta[k]);
+    }
+  };
+  if (T <= 1) work(0);
+  else { std::vector<std::thread> th; for (unsigned t = 0; t < T; t++) th.emplace_back(work, t); for (auto& x : th) x.join(); }
+  // the canonical molecules as one batch
+  std::vector<uint64_t> c_off;
+  std::vector<uint32_t> c_len, c_grp(1, 0), c_def;
+  for (size_t k = 0; k < nd; k++) {
+    if (status[k] != canon::CANON_OK) continue;
+    for (uint64_t i = first[k]; i < first[k + 1]; i++)
+      if (out_len[i]) { c_off.push_back(out_off[i]); c_len.push_back(out_len[i]); const uint32_t L = out_len[i]; memcpy(blob.data() + out_off[i] - 4, &L, 4); }
+    c_grp.push_back((uint32_t)c_off.size());
+    c_def.push_back((uint32_t)k);
+  }
+  cp.ms_host = ms_between(t0, clk::now());
+  const uint32_t n_cg = (uint32_t)c_def.size(), n_cr = (uint32_t)c_off.size();
+  if (n_cg == 0) return;
+  c->d_canon_blob.reserve(blob.size());
+  c->d_canon_off.reserve((size_t)n_cr * 8 + 8); c->d_canon_len.reserve((size_t)n_cr * 4 + 4); c->d_canon_grp.reserve((size_t)(n_cg + 1) * 4);
+  hip_check(hipMemcpyAsync(c->d_canon_blob.p, blob.data(), blob.size(), hipMemcpyHostToDevice, c->stream), "H2D canonical blob");
+  if (n_cr) {
+    hip_check(hipMemcpyAsync(c->d_canon_off.p, c_off.data(), (size_t)n_cr * 8, hipMemcpyHostToDevice, c->stream), "H2D canonical rec_off");
+    hip_check(hipMemcpyAsync(c->d_canon_len.p, c_len.data(), (size_t)n_cr * 4, hipMemcpyHostToDevice, c->stream), "H2D canonical rec_len");
+  }
+  hip_check(hipMemcpyAsync(c->d_canon_grp.p, c_grp.data(), (size_t)(n_cg + 1) * 4, hipMemcpyHostToDevice, c->stream), "H2D canonical grp_first");
+  hip_check(hipStreamSynchronize(c->stream), "sync");
+  FastResult fr2;
+  c->fast->fp.run(c, c->d_canon_blob.as<uint8_t>(), bytes, c->d_canon_off.as<uint64_t>(), c->d_canon_len.as<uint32_t>(), n_cr, c->d_canon_grp.as<uint32_t>(), n_cg, &fr2);
+  cp.out.resize(fr2.out_len);
+  if (fr2.out_len) hip_check(hipMemcpy(cp.out.data(), fr2.d_out, fr2.out_len, hipMemcpyDeviceToHost), "D2H canonical out");
+  std::vector<uint64_t> slot2((size_t)3 * n_cg);
+  hip_check(hipMemcpy(slot2.data(), fr2.d_out_off, slot2.size() * 8, hipMemcpyDeviceToHost), "D2H canonical offsets");
+  std::vector<uint32_t> def2(fr2.n_deferred);
+  if (fr2.n_deferred) hip_check(hipMemcpy(def2.data(), fr2.d_deferred, (size_t)fr2.n_deferred * 4, hipMemcpyDeviceToHost), "D2H canonical deferred");
+  std::vector<uint8_t> again(n_cg, 0);
+  for (uint32_t g : def2) if (g < n_cg) again[g] = 1;
+  for (uint32_t ci = 0; ci < n_cg; ci++) {
+    if (again[ci]) continue;                                   // (still deferred: the general path takes the ORIGINAL molecule)
+    const size_t k = c_def[ci];
+    cp.used[k] = 1;
+    cp.beg[k] = slot2[(size_t)3 * ci];
+    cp.end[k] = ci + 1 < n_cg ? slot2[(size_t)3 * (ci + 1)] : fr2.out_len;
+    cp.stats[0] += delta[k].minority; cp.stats[2] += delta[k].minority; cp.stats[3 + FGX_REJ_MINORITY_ALIGNMENT] += delta[k].minority;
+    for (int i = 0; i < 4; i++) cp.stats[24 + i] += delta[k].ov[i];
+  }
+  for (int i = 0; i < FGX_STATS_LEN; i++) cp.stats[i] += fr2.stats[i];
+  cp.count = fr2.count;
+  cp.ms_kernels = fr2.ms_kernels;
+  for (size_t k = 0; k < nd; k++) c->last_canon_molecules += cp.used[k];
+}
+
 static int hybrid_after_upload(fgx_caller* c, general_fn general, const uint8_t* records, uint64_t records_len, const uint64_t* rec_off,
                                const uint32_t* rec_len, uint32_t n_rec, const uint32_t* grp_first, uint32_t n_grp, fgx_output* out,
                                uint8_t* dst, uint64_t dst_cap) {
@@ -476,36 +567,50 @@ static int hybrid_after_upload(fgx_caller* c, general_fn general, const uint8_t*
   std::sort(def.begin(), def.end());
   std::vector<uint64_t> slot_off((size_t)3 * n_grp);
   hip_check(hipMemcpy(slot_off.data(), fr.d_out_off, slot_off.size() * 8, hipMemcpyDeviceToHost), "D2H offsets");
+  CanonPass cp;
+  cp.used.assign(def.size(), 0);
+  c->last_canon_molecules = 0;
+  c->last_deferred_groups = (uint64_t)def.size();
+  if (c->opt.caller_kind == FGX_CALLER_DUPLEX && duplex_canon_enabled()) canon_second_pass(c, records, rec_off, rec_len, grp_first, def, cp);
   std::vector<uint64_t> d_off;
   std::vector<uint32_t> d_len, d_grp(1, 0);
-  for (uint32_t g : def) {
+  for (size_t k = 0; k < def.size(); k++) {
+    if (cp.used[k]) continue;
+    const uint32_t g = def[k];
     for (uint32_t r = grp_first[g]; r < grp_first[g + 1]; r++) { d_off.push_back(rec_off[r]); d_len.push_back(rec_len[r]); }
     d_grp.push_back((uint32_t)d_off.size());
   }
   fgx_output gen;
-  int rc = run_general(c, general, records, d_off.data(), d_len.data(), (uint32_t)d_off.size(), d_grp.data(), (uint32_t)def.size(), &gen);
+  memset(&gen, 0, sizeof(gen));
+  c->out_data.clear(); c->grp_out_end.clear();
+  int rc = d_grp.size() > 1 ? run_general(c, general, records, d_off.data(), d_len.data(), (uint32_t)d_off.size(), d_grp.data(), (uint32_t)d_grp.size() - 1, &gen) : 0;
   if (rc != 0) return rc;
   // CODEC molecules without an MI are named by a counter that advances on EVERY emitted record (codec_caller.rs:1568-1577):
   // the deferred subset alone would restart it at 0, so the whole batch goes through the general path in one piece
   if (c->opt.caller_kind == FGX_CALLER_CODEC && c->counter_names_used)
     return run_general(c, general, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
   std::vector<uint8_t> merged;
-  merged.reserve(fr.out_len + c->out_data.size());
+  merged.reserve(fr.out_len + c->out_data.size() + cp.out.size());
   uint64_t fpos = 0;   // fast output is contiguous in group order; deferred groups contributed nothing to it
   uint64_t gprev = 0;
+  size_t gk = 0;       // index among the groups the general path took
   for (size_t k = 0; k < def.size(); k++) {
     uint64_t upto = slot_off[(size_t)3 * def[k]];          // fast bytes of all groups before def[k]
     merged.insert(merged.end(), fast_out + fpos, fast_out + upto);
     fpos = upto;
-    merged.insert(merged.end(), c->out_data.begin() + gprev, c->out_data.begin() + c->grp_out_end[k]);
-    gprev = c->grp_out_end[k];
+    if (cp.used[k]) merged.insert(merged.end(), cp.out.begin() + cp.beg[k], cp.out.begin() + cp.end[k]);
+    else {
+      merged.insert(merged.end(), c->out_data.begin() + gprev, c->out_data.begin() + c->grp_out_end[gk]);
+      gprev = c->grp_out_end[gk];
+      gk++;
+    }
   }
   merged.insert(merged.end(), fast_out + fpos, fast_out + fr.out_len);
   c->out_data.swap(merged);
-  out->data = c->out_data.data(); out->data_len = c->out_data.size(); out->count = fr.count + gen.count;
-  for (int i = 0; i < FGX_STATS_LEN; i++) out->stats[i] = fr.stats[i] + gen.stats[i];
-  out->ms_h2d = ms(t0, t1); out->ms_kernels = fr.ms_kernels + gen.ms_kernels; out->ms_d2h = ms(t2, t3);
-  out->ms_host_prep = gen.ms_host_prep; out->ms_emit = gen.ms_emit;
+  out->data = c->out_data.data(); out->data_len = c->out_data.size(); out->count = fr.count + gen.count + cp.count;
+  for (int i = 0; i < FGX_STATS_LEN; i++) out->stats[i] = fr.stats[i] + gen.stats[i] + cp.stats[i];
+  out->ms_h2d = ms(t0, t1); out->ms_kernels = fr.ms_kernels + gen.ms_kernels + cp.ms_kernels; out->ms_d2h = ms(t2, t3);
+  out->ms_host_prep = gen.ms_host_prep + cp.ms_host; out->ms_emit = gen.ms_emit;
   return 0;
 }
 
@@ -715,6 +820,9 @@ int fgx_filter_records(fgx_caller* c, const fgx_filter_options* f, const uint8_t
   } catch (const std::exception& ex) { c->err = ex.what(); return 3; }
 }
 
+// diagnostics of the last fgx_process_batch call that deferred groups: out2 = {groups the first device pass deferred, of those the
+// molecules the canonical second pass decided (FGX_DUPLEX_CANON=1)}
+void fgx_debug_last_deferral(const fgx_caller* c, uint64_t* out2) { if (c && out2) { out2[0] = c->last_deferred_groups; out2[1] = c->last_canon_molecules; } }
 // 1: route everything through the general host path (parity tests of that path); 0: hybrid (default)
 void fgx_set_general_only(fgx_caller* c, int on) { if (c) c->general_only = on != 0; }
 // dynamic LDS bytes of the large-family launch of the family kernel (default 48 KiB)

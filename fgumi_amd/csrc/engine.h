@@ -155,8 +155,10 @@ struct fgx_caller {
   std::vector<fgx_caller*> workers;         // helper callers (own stream and buffers) of the multi-threaded general path
   struct FastState* fast = nullptr;        // device-resident pipeline state (fastpath.hip)
   fgx::DevBuf d_in_blob, d_in_off, d_in_len, d_in_grp;   // host-input staging for fgx_process_batch
+  fgx::DevBuf d_canon_blob, d_canon_off, d_canon_len, d_canon_grp;   // canonical duplex molecules of the second device pass (canon_core.h)
   fgx::FilterBuffers* filt = nullptr;      // fgx_filter_records[_device] state (filter.hip)
   void* pipe_state = nullptr;              // buffers of fgx_run_bam, kept from run to run (pipeline.cpp: fgx_pipeline_release)
+  uint64_t last_deferred_groups = 0, last_canon_molecules = 0;   // host entry: groups the first device pass deferred / molecules the canonical second pass decided
   uint32_t last_boundary_rounds = 0;       // repair rounds of the last fgx_record_boundaries_device call (boundaries.hip; 0 = every guess was right)
 
   // Runs the staged column jobs of `b` on the device and fills b.ob/oq/od/oe. Returns kernel ms.
