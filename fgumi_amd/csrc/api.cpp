@@ -321,6 +321,19 @@ int fgx_canon_duplex_host(const fgx_options* o, const uint8_t* blob, const uint6
   return rc;
 }
 
+static canon::CodecParams canon_codec_params(const fgx_options* o) {
+  canon::CodecParams P;
+  P.min_reads_per_strand = o->codec_min_reads_per_strand; P.min_duplex_length = o->codec_min_duplex_length; P.max_reads_per_strand = o->codec_max_reads_per_strand;
+  return P;
+}
+// canon_core.h on the host: the canonical form of ONE CODEC molecule (same contract; every record is kept).  0, 1 = out of scope, 2 = bad arguments.
+int fgx_canon_codec_host(const fgx_options* o, const uint8_t* blob, const uint64_t* rec_off, const uint32_t* rec_len, uint32_t n, uint8_t* out, uint32_t* out_len) {
+  if (!o || o->struct_size != sizeof(fgx_options) || !blob || !out || !out_len) return 2;
+  static thread_local std::unique_ptr<canon::CodecScratch> S;
+  if (!S) S.reset(new canon::CodecScratch());
+  return canon::canon_codec_molecule(canon_codec_params(o), blob, rec_off, rec_len, n, out, rec_off, out_len, *S);
+}
+
 // Host-input entry: upload once, run the device-resident pipeline, bring the records back, and send
 // only the families the fast path deferred through the general path, splicing both in group order.
 typedef int (*general_fn)(fgx_caller*, const uint8_t*, const uint64_t*, const uint32_t*, uint32_t, const uint32_t*, uint32_t, fgx_output*);

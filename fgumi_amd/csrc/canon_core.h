@@ -441,5 +441,317 @@ CANON_HD int canon_duplex_molecule(const Params& P, const uint8_t* blob, const u
   return CANON_OK;
 }
 
+
+// =====================================================================================================================================
+// CODEC molecules (codec_caller.rs:625-1262).  The CODEC caller reads a CIGAR in four places: the virtual hard clip against the mate in
+// hand (`clip_cigar_ops_raw`, raw-bam/cigar.rs:404-446, by `num_bases_extending_past_mate_vs_mate_raw`), the per-strand alignment
+// filter, and the overlap GEOMETRY of the longest alignment of each strand — the shared reference window, the phase check
+// (`read_pos_at_ref_pos`, cigar.rs:461-500) and the consensus length = query position of the window's end in the forward read + length
+// of the reverse read - query position of that end in the reverse read.  The source reads themselves are the clipped, oriented bases.
+// A canonical molecule keeps every record (the consensus UMI is called over ALL records of the group, so nothing may be dropped: a
+// molecule whose filter rejects a read is out of scope), cuts each read by its clip, gives it `<len>M`, and PLACES the reads so that the
+// pass recomputes the same geometry: each template's reverse read starts d >= max(0, len_fwd - len_rev) after its forward read (an FR
+// pair with nothing extending past the mate: clip 0), and the two reads the pass will pick as longest sit `cons_len - len_rev` apart, so
+// that the consensus length comes out the same; the phase check holds trivially for single-block reads.  Every decision the original
+// takes before the per-position work is taken here first; anything but "emit" leaves the molecule where it is (the general path decides
+// rejected molecules cheaply).
+struct CodecParams {
+  uint32_t min_reads_per_strand;
+  uint32_t min_duplex_length;
+  int64_t max_reads_per_strand;   // -1 = none
+};
+struct CodecInfo {                // ClippedRecordInfo (codec_caller.rs:323-336)
+  uint32_t rec, mate;             // record index, its mate's
+  uint32_t clip, keep;            // clipped bases, bases left
+  uint32_t n_ops;
+  uint32_t ops[MAX_OPS + 2];      // clipped CIGAR
+  uint64_t adj_pos;               // 1-based start after the clip
+  uint8_t reverse, first;
+  uint32_t canon_pos;             // 1-based start of the canonical record
+};
+struct CodecScratch {
+  CodecInfo r[MAX_READS];
+  uint32_t r1[MAX_READS / 2], r2[MAX_READS / 2];   // per template: index into r of its R1 / R2
+  Scratch filt;                   // the alignment filter's lists
+};
+
+CANON_HD bool cq_consumes_read(uint32_t t) { return t == 0 || t == 1 || t == 7 || t == 8; }   // (clip walk: S / H are handled apart)
+CANON_HD uint32_t cq_enc(uint32_t t, uint64_t len) { return ((uint32_t)len << 4) | t; }
+
+// clip_cigar_ops_raw (cigar.rs:404-446 with its helpers :669-922): hard-clip `clip` query bases off one end.  Returns the op count, or
+// -1 when the result does not fit.
+CANON_HD int clip_cigar(const uint32_t* ops, uint32_t n, uint64_t clip, bool from_start, uint32_t* out, uint32_t cap, uint64_t* ref_consumed) {
+  *ref_consumed = 0;
+  if (clip == 0 || n == 0) { if (n > cap) return -1; for (uint32_t i = 0; i < n; i++) out[i] = ops[i]; return (int)n; }
+  auto at = [&](uint32_t k) { return from_start ? ops[k] : ops[n - 1 - k]; };
+  uint64_t existing = 0;
+  for (uint32_t k = 0; k < n; k++) { const uint32_t t = at(k) & 0xF; if (t != 4 && t != 5) break; existing += at(k) >> 4; }
+  uint64_t hard = 0, soft = 0;
+  uint32_t skip = 0;
+  while (skip < n && (at(skip) & 0xF) == 5) { hard += at(skip) >> 4; skip++; }
+  while (skip < n && (at(skip) & 0xF) == 4) { soft += at(skip) >> 4; skip++; }
+  uint32_t m = 0;
+  auto push = [&](uint32_t v) { if (m < cap) out[m] = v; m++; };
+  if (clip <= existing) {   // upgrade_clipping_raw: soft -> hard, alignment untouched
+    const uint64_t room = clip > hard ? clip - hard : 0, up = soft < room ? soft : room;
+    if (from_start) {
+      push(cq_enc(5, hard + up));
+      if (soft - up) push(cq_enc(4, soft - up));
+      for (uint32_t k = skip; k < n; k++) push(ops[k]);
+    } else {
+      for (uint32_t k = 0; k < n - skip; k++) push(ops[k]);
+      if (soft - up) push(cq_enc(4, soft - up));
+      push(cq_enc(5, hard + up));
+    }
+    return m <= cap ? (int)m : -1;
+  }
+  const uint64_t want = clip - existing;
+  uint64_t got = 0;
+  uint32_t kept[MAX_OPS + 2], nk = 0;                     // ops that survive next to the clip, in walking order
+  const uint32_t lo = from_start ? skip : 0, hi = from_start ? n : n - skip;   // the unclipped middle [lo, hi)
+  uint32_t taken = 0;
+  while (lo + taken < hi) {
+    const uint32_t op = from_start ? ops[lo + taken] : ops[hi - 1 - taken];
+    const uint32_t t = op & 0xF;
+    const uint64_t len = op >> 4;
+    if (got == want && nk == 0 && t == 2) { if (from_start) *ref_consumed += len; taken++; continue; }   // a deletion at the boundary
+    if (got >= want) break;
+    const bool is_read = cq_consumes_read(t), is_ref = bam::op_consumes_ref(t);
+    if (is_read && len > want - got) {
+      if (t == 1) got += len;                               // an insertion at the boundary goes whole
+      else {
+        const uint64_t part = want - got;
+        got += part;
+        if (is_ref && from_start) *ref_consumed += part;
+        if (nk < MAX_OPS + 2) kept[nk] = cq_enc(t, len - part);
+        nk++;
+      }
+    } else {
+      if (is_read) got += len;
+      if (is_ref && from_start) *ref_consumed += len;
+    }
+    taken++;
+  }
+  if (nk > MAX_OPS + 2) return -1;
+  const uint64_t total_hard = hard + soft + got;
+  if (from_start) {
+    push(cq_enc(5, total_hard));
+    for (uint32_t k = 0; k < nk; k++) push(kept[k]);
+    for (uint32_t k = lo + taken; k < n; k++) push(ops[k]);
+  } else {
+    for (uint32_t k = 0; k < hi - taken; k++) push(ops[k]);
+    for (uint32_t k = nk; k-- > 0;) push(kept[k]);
+    push(cq_enc(5, total_hard));
+  }
+  return m <= cap ? (int)m : -1;
+}
+
+CANON_HD int32_t ref_len_wrapping(const uint32_t* ops, uint32_t n) {   // reference_length_from_cigar cigar.rs:137-150
+  uint32_t r = 0;
+  for (uint32_t i = 0; i < n; i++) if (bam::op_consumes_ref(ops[i] & 0xF)) r += ops[i] >> 4;
+  return (int32_t)r;
+}
+
+// read_pos_at_ref_pos_raw (cigar.rs:461-500): 1-based query position at a 1-based reference position
+CANON_HD bool read_pos_at(const uint32_t* ops, uint32_t n, uint64_t aln_start, uint64_t ref_pos, bool last_if_deleted, uint64_t* out) {
+  if (ref_pos < aln_start) return false;
+  uint64_t ref_off = 0, q_off = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    const uint32_t t = ops[i] & 0xF;
+    const uint64_t len = ops[i] >> 4;
+    if (bam::op_consumes_ref(t)) {
+      const uint64_t s = aln_start + ref_off, e = s + len - 1;
+      if (ref_pos >= s && ref_pos <= e) {
+        if (bam::op_consumes_query(t)) { *out = q_off + (ref_pos - s) + 1; return true; }
+        if (last_if_deleted) { *out = q_off > 0 ? q_off : 1; return true; }
+        return false;
+      }
+      ref_off += len;
+    }
+    if (bam::op_consumes_query(t)) q_off += len;
+  }
+  return false;
+}
+
+// is_primary_fr_pair_raw (raw-bam/overlap.rs:83-108) and num_bases_extending_past_mate_vs_mate_raw (:223-230)
+CANON_HD bool primary_fr_pair(const bam::Rec& a, const uint32_t* a_ops, const bam::Rec& b, const uint32_t* b_ops) {
+  const uint16_t fa = a.flags(), fb = b.flags();
+  if ((fa | fb) & bam::F_UNMAPPED) return false;
+  if ((fa | fb) & bam::F_MATE_UNMAPPED) return false;
+  if (a.ref_id() != b.ref_id()) return false;
+  const bool ar = (fa & bam::F_REVERSE) != 0, br = (fb & bam::F_REVERSE) != 0;
+  if (ar == br) return false;
+  return ar ? bam::is_fr_pair(a, a_ops, a.n_cigar()) : bam::is_fr_pair(b, b_ops, b.n_cigar());
+}
+
+// One CODEC molecule; same contract as canon_duplex_molecule (every record is kept: out_len[i] > 0 on CANON_OK).
+CANON_HD int canon_codec_molecule(const CodecParams& P, const uint8_t* blob, const uint64_t* rec_off, const uint32_t* rec_len, uint32_t n, uint8_t* out,
+                                  const uint64_t* out_off, uint32_t* out_len, CodecScratch& S) {
+  if (n < 2 || n > MAX_READS || (n & 1)) return CANON_OUT_OF_SCOPE;
+  // every record: paired, primary, mapped with a mapped mate, a CIGAR that fits and spans the read, qualities present; MI on the first
+  for (uint32_t i = 0; i < n; i++) {
+    const uint32_t len = rec_len[i];
+    if (len < 32) return CANON_OUT_OF_SCOPE;
+    bam::Rec v{blob + rec_off[i], len};
+    const uint16_t f = v.flags();
+    const uint32_t nc = v.n_cigar(), l = v.l_seq();
+    if (v.l_read_name() == 0 || (uint64_t)v.aux_off() > len) return CANON_OUT_OF_SCOPE;
+    if (!(f & bam::F_PAIRED) || (f & (bam::F_UNMAPPED | bam::F_MATE_UNMAPPED | bam::F_SECONDARY | bam::F_SUPPLEMENTARY))) return CANON_OUT_OF_SCOPE;
+    if (((f & bam::F_FIRST) != 0) == ((f & bam::F_LAST) != 0)) return CANON_OUT_OF_SCOPE;
+    if (nc == 0 || nc > MAX_OPS || l == 0 || v.pos() < 0) return CANON_OUT_OF_SCOPE;
+    uint64_t ql = 0;
+    for (uint32_t k = 0; k < nc; k++) { const uint32_t op = v.cigar_op(k); if ((op & 0xF) > 8) return CANON_OUT_OF_SCOPE; if (bam::op_consumes_query(op & 0xF)) ql += op >> 4; }
+    if (ql != l) return CANON_OUT_OF_SCOPE;
+    S.r[i].rec = i; S.r[i].mate = 0xFFFFFFFFu;
+  }
+  {
+    bam::Rec v0{blob + rec_off[0], rec_len[0]};
+    uint32_t vl = 0;
+    if (bam::find_z_tag(v0.b + v0.aux_off(), v0.len - v0.aux_off(), 'M', 'I', &vl) < 0) return CANON_OUT_OF_SCOPE;   // (named by a running counter otherwise)
+  }
+  // templates in first-appearance order: exactly one R1 and one R2 of a name, a primary FR pair
+  uint32_t nt = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    if (S.r[i].mate != 0xFFFFFFFFu) continue;
+    bam::Rec vi{blob + rec_off[i], rec_len[i]};
+    uint32_t j_found = 0xFFFFFFFFu;
+    for (uint32_t j = i + 1; j < n; j++) {
+      if (!names_equal(vi, bam::Rec{blob + rec_off[j], rec_len[j]})) continue;
+      if (j_found != 0xFFFFFFFFu || S.r[j].mate != 0xFFFFFFFFu) return CANON_OUT_OF_SCOPE;      // three records of a name
+      j_found = j;
+    }
+    if (j_found == 0xFFFFFFFFu) return CANON_OUT_OF_SCOPE;
+    S.r[i].mate = j_found; S.r[j_found].mate = i;
+    const bool i_first = (vi.flags() & bam::F_FIRST) != 0;
+    const bool j_first = (bam::Rec{blob + rec_off[j_found], rec_len[j_found]}.flags() & bam::F_FIRST) != 0;
+    if (i_first == j_first) return CANON_OUT_OF_SCOPE;
+    S.r1[nt] = i_first ? i : j_found; S.r2[nt] = i_first ? j_found : i;
+    nt++;
+  }
+  if (nt < P.min_reads_per_strand) return CANON_OUT_OF_SCOPE;
+  if (P.max_reads_per_strand >= 0 && (uint64_t)nt > (uint64_t)P.max_reads_per_strand) return CANON_OUT_OF_SCOPE;
+  // the virtual clip of every read against its mate, and its ClippedRecordInfo
+  uint32_t opsa[MAX_OPS], opsb[MAX_OPS];
+  for (uint32_t t = 0; t < nt; t++) {
+    const uint32_t i1 = S.r1[t], i2 = S.r2[t];
+    bam::Rec a{blob + rec_off[i1], rec_len[i1]}, b{blob + rec_off[i2], rec_len[i2]};
+    for (uint32_t k = 0; k < a.n_cigar(); k++) opsa[k] = a.cigar_op(k);
+    for (uint32_t k = 0; k < b.n_cigar(); k++) opsb[k] = b.cigar_op(k);
+    if (!primary_fr_pair(a, opsa, b, opsb)) return CANON_OUT_OF_SCOPE;
+    for (int side = 0; side < 2; side++) {
+      const bam::Rec& v = side ? b : a;
+      const bam::Rec& mt = side ? a : b;
+      const uint32_t* vo = side ? opsb : opsa;
+      const uint32_t* mo = side ? opsa : opsb;
+      CodecInfo& I = S.r[side ? i2 : i1];
+      const bool rev = (v.flags() & bam::F_REVERSE) != 0;
+      const uint64_t clip = bam::past_mate_ops(rev, (int32_t)((uint32_t)v.pos() + 1u), vo, v.n_cigar(), (int32_t)((uint32_t)mt.pos() + 1u), mo, mt.n_cigar());
+      const uint32_t l = v.l_seq();
+      I.clip = clip > l ? l : (uint32_t)clip;
+      I.keep = l - I.clip;
+      I.reverse = rev; I.first = (v.flags() & bam::F_FIRST) != 0;
+      uint64_t ref_consumed = 0;
+      const int no = clip_cigar(vo, v.n_cigar(), clip, rev, I.ops, MAX_OPS + 2, &ref_consumed);
+      if (no < 0) return CANON_OUT_OF_SCOPE;
+      I.n_ops = (uint32_t)no;
+      const uint64_t p1 = (uint64_t)(int64_t)(v.pos() + 1);
+      I.adj_pos = rev ? p1 + ref_consumed : p1;
+      if (I.keep < 2) return CANON_OUT_OF_SCOPE;
+    }
+  }
+  // one orientation per strand
+  const bool r1_neg = S.r[S.r1[0]].reverse != 0;
+  for (uint32_t t = 0; t < nt; t++) if ((S.r[S.r1[t]].reverse != 0) != r1_neg || (S.r[S.r2[t]].reverse != 0) == r1_neg) return CANON_OUT_OF_SCOPE;
+  // the alignment filter of each strand must keep every read (codec_caller.rs:1130-1174): simplified CLIPPED CIGARs, reversed for
+  // reverse reads, untruncated, ordered by the clipped length
+  for (int strand = 0; strand < 2; strand++) {
+    if (nt < 2) break;
+    for (uint32_t t = 0; t < nt; t++) {
+      const CodecInfo& I = S.r[strand ? S.r2[t] : S.r1[t]];
+      ReadInfo& R = S.filt.r[t];
+      R.final_len = I.keep; R.keep = 1; R.n_simp = 0;
+      SimpOp tmp[MAX_OPS + 2];
+      uint32_t m = 0;
+      for (uint32_t k = 0; k < I.n_ops; k++) {
+        const uint32_t ty = I.ops[k] & 0xF;
+        const uint8_t kk = (ty == 4 || ty == 5 || ty == 7 || ty == 8) ? (uint8_t)0 : (uint8_t)ty;
+        if (m && tmp[m - 1].k == kk) tmp[m - 1].len += I.ops[k] >> 4;
+        else { tmp[m].k = kk; tmp[m].len = I.ops[k] >> 4; m++; }
+      }
+      if (m > MAX_OPS) return CANON_OUT_OF_SCOPE;
+      for (uint32_t k = 0; k < m; k++) R.simp[k] = tmp[I.reverse ? m - 1 - k : k];
+      R.n_simp = (uint8_t)m;
+      S.filt.list[t] = t;
+    }
+    const int rej = alignment_filter(S.filt, nt);
+    if (rej != 0) return CANON_OUT_OF_SCOPE;
+  }
+  // overlap geometry of the original (codec_caller.rs:1200-1262): longest alignment of each strand = first maximum of the reference length
+  auto longest = [&](const uint32_t* idx, bool by_keep) -> uint32_t {
+    uint32_t best = 0;
+    int64_t bl = by_keep ? (int64_t)S.r[idx[0]].keep : (int64_t)ref_len_wrapping(S.r[idx[0]].ops, S.r[idx[0]].n_ops);
+    for (uint32_t t = 1; t < nt; t++) {
+      const int64_t l = by_keep ? (int64_t)S.r[idx[t]].keep : (int64_t)ref_len_wrapping(S.r[idx[t]].ops, S.r[idx[t]].n_ops);
+      if (l > bl) { bl = l; best = t; }
+    }
+    return best;
+  };
+  const CodecInfo& l1 = S.r[S.r1[longest(S.r1, false)]];
+  const CodecInfo& l2 = S.r[S.r2[longest(S.r2, false)]];
+  const CodecInfo& lpos = r1_neg ? l2 : l1;
+  const CodecInfo& lneg = r1_neg ? l1 : l2;
+  const uint64_t pos_ref = (uint64_t)(int64_t)ref_len_wrapping(lpos.ops, lpos.n_ops), neg_ref = (uint64_t)(int64_t)ref_len_wrapping(lneg.ops, lneg.n_ops);
+  const uint64_t pos_end = lpos.adj_pos + (pos_ref ? pos_ref - 1 : 0), neg_end = lneg.adj_pos + (neg_ref ? neg_ref - 1 : 0);
+  const uint64_t ov_s = lneg.adj_pos > lpos.adj_pos ? lneg.adj_pos : lpos.adj_pos, ov_e = pos_end < neg_end ? pos_end : neg_end;
+  const int64_t duplex_len = (int64_t)ov_e - (int64_t)ov_s + 1;
+  if (duplex_len < (int64_t)P.min_duplex_length || duplex_len < 1) return CANON_OUT_OF_SCOPE;
+  auto at0 = [&](const CodecInfo& r, uint64_t p) -> int64_t { uint64_t q; return read_pos_at(r.ops, r.n_ops, r.adj_pos, p, true, &q) ? (int64_t)q : 0; };
+  if ((at0(l1, ov_s) - at0(l2, ov_s)) != (at0(l1, ov_e) - at0(l2, ov_e))) return CANON_OUT_OF_SCOPE;
+  uint64_t prp = 0, nrp = 0;
+  if (!read_pos_at(lpos.ops, lpos.n_ops, lpos.adj_pos, ov_e, false, &prp) || !read_pos_at(lneg.ops, lneg.n_ops, lneg.adj_pos, ov_e, false, &nrp)) return CANON_OUT_OF_SCOPE;
+  if (prp + lneg.keep < nrp) return CANON_OUT_OF_SCOPE;
+  const int64_t cons_len = (int64_t)(prp + lneg.keep - nrp);
+  // the canonical placement: what the pass will pick as longest (first maximum of the kept length), `cons_len - len_rev` apart
+  const uint32_t t1c = longest(S.r1, true), t2c = longest(S.r2, true);
+  const uint32_t tA = r1_neg ? t2c : t1c;      // template of the forward read the pass picks
+  const uint32_t tB = r1_neg ? t1c : t2c;      // template of the reverse read it picks
+  auto fwd_of = [&](uint32_t t) -> CodecInfo& { return S.r[r1_neg ? S.r2[t] : S.r1[t]]; };
+  auto rev_of = [&](uint32_t t) -> CodecInfo& { return S.r[r1_neg ? S.r1[t] : S.r2[t]]; };
+  const int64_t a_c = fwd_of(tA).keep, b_c = rev_of(tB).keep;
+  const int64_t D = cons_len - b_c;              // reverse start - forward start of the picked reads
+  const int64_t BASE = 1000000;
+  for (uint32_t t = 0; t < nt; t++) {
+    const int64_t a = fwd_of(t).keep, b = rev_of(t).keep;
+    int64_t d = a > b ? a - b : 0;
+    int64_t Pf = BASE + (int64_t)t * 4096, Qr;
+    if (tA == tB && t == tA) { if (D < d) return CANON_OUT_OF_SCOPE; d = D; Qr = Pf + d; }
+    else if (t == tA) { Pf = BASE; Qr = Pf + d; }
+    else if (t == tB) { Qr = BASE + D; Pf = Qr - d; }
+    else Qr = Pf + d;
+    if (Pf < 1 || Qr < 1) return CANON_OUT_OF_SCOPE;
+    fwd_of(t).canon_pos = (uint32_t)Pf; rev_of(t).canon_pos = (uint32_t)Qr;
+  }
+  {
+    // the pass's own view of the geometry: the window must stay non-empty and long enough
+    const int64_t Pa = fwd_of(tA).canon_pos, Qb = rev_of(tB).canon_pos;
+    const int64_t s2 = Qb > Pa ? Qb : Pa, e2 = (Pa + a_c - 1) < (Qb + b_c - 1) ? (Pa + a_c - 1) : (Qb + b_c - 1);
+    const int64_t dl = e2 - s2 + 1;
+    if (dl < 1 || dl < (int64_t)P.min_duplex_length) return CANON_OUT_OF_SCOPE;
+    if ((e2 - Pa + 1) + b_c - (e2 - Qb + 1) != cons_len) return CANON_OUT_OF_SCOPE;
+  }
+  // the canonical records: cut, `<keep>M`, placed; the mate fields follow
+  for (uint32_t i = 0; i < n; i++) {
+    uint8_t* w = out + out_off[i];
+    const uint32_t len = rec_len[i];
+    const uint8_t* src = blob + rec_off[i];
+    for (uint32_t k = 0; k < len; k++) w[k] = src[k];
+    const CodecInfo& I = S.r[i];
+    wr32(w + 4, I.canon_pos - 1);
+    wr32(w + 24, S.r[I.mate].canon_pos - 1);
+    out_len[i] = rewrite_record(w, len, I.clip, false);
+  }
+  return CANON_OK;
+}
+
 }  // namespace canon
 }  // namespace fgx

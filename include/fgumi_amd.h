@@ -210,6 +210,11 @@ int fgx_methylation_mm_ml_host(const uint8_t* bases, uint32_t n, const uint8_t* 
  * source compiles for the device (one lane per molecule). */
 int fgx_canon_duplex_host(const fgx_options* o, const uint8_t* blob, const uint64_t* rec_off, const uint32_t* rec_len, uint32_t n, uint8_t* out, uint32_t* out_len,
                           uint64_t* delta5);
+/* The same for ONE CODEC molecule (codec_caller.rs:625-1262): every read cut by its virtual clip against the mate in hand
+ * (raw-bam/cigar.rs:404-446), `<len>M`, and PLACED so that the one-M-op CODEC kernels recompute the original's overlap geometry — the
+ * consensus length above all (query positions at the end of the shared window, cigar.rs:461-500).  Every record is kept (the consensus
+ * UMI is called over all of them); a molecule the original would reject, or whose filter / cap would drop a read, is out of scope. */
+int fgx_canon_codec_host(const fgx_options* o, const uint8_t* blob, const uint64_t* rec_off, const uint32_t* rec_len, uint32_t n, uint8_t* out, uint32_t* out_len);
 
 /* Device self-test of the glibc-compatible libm: op 0 exp, 1 log, 2 log1p, 3 expm1. */
 int fgx_device_libm(fgx_caller* c, int op, const double* x, double* y, uint64_t n);
