@@ -463,6 +463,10 @@ static int process_hybrid(fgx_caller* c, general_fn general, const uint8_t* reco
 // still defers) takes the general path.  tests/test_canon_core.py shows through the oracle that the canonical molecule plus the
 // counted delta gives the original's result.  Off by default until the whole GPU suite has run with it.
 static bool duplex_canon_enabled() { const char* e = getenv("FGX_DUPLEX_CANON"); return e && e[0] == '1'; }
+// The same for CODEC molecules (FGX_CODEC_CANON=1; canon_core.h `canon_codec_molecule`, proof tests/test_canon_codec.py): virtual clip
+// applied, `<len>M`, reads placed so that the overlap geometry and the consensus length come out the same; every record is kept and
+// no counter moves, so there is no delta.  Only molecules the original would EMIT are in scope; rejected ones stay on the general path.
+static bool codec_canon_enabled() { const char* e = getenv("FGX_CODEC_CANON"); return e && e[0] == '1'; }
 
 struct CanonPass {
   std::vector<uint8_t> used;            // per deferred group: 1 = its records come from the second device pass
@@ -489,14 +493,19 @@ static void canon_second_pass(fgx_caller* c, const uint8_t* records, const uint6
   std::vector<uint8_t> blob(bytes + 16, 0);
   std::vector<int> status(nd, canon::CANON_OUT_OF_SCOPE);
   std::vector<canon::Delta> delta(nd);
+  memset(delta.data(), 0, nd * sizeof(canon::Delta));
+  const bool codec = c->opt.caller_kind == FGX_CALLER_CODEC;
   const canon::Params P = canon_params(&c->opt);
+  const canon::CodecParams PC = canon_codec_params(&c->opt);
   unsigned T = host_threads();
   if (T > nd / 64 + 1) T = (unsigned)(nd / 64 + 1);
   auto work = [&](unsigned t) {
-    std::unique_ptr<canon::Scratch> S(new canon::Scratch());
+    std::unique_ptr<canon::Scratch> S(codec ? nullptr : new canon::Scratch());
+    std::unique_ptr<canon::CodecScratch> SC(codec ? new canon::CodecScratch() : nullptr);
     for (size_t k = t; k < nd; k += T) {
       const uint32_t r0 = grp_first[def[k]], n = grp_first[def[k] + 1] - r0;
-      status[k] = canon::canon_duplex_molecule(P, records, rec_off + r0, rec_len + r0, n, blob.data(), out_off.data() + first[k], out_len.data() + first[k], *S, delta[k]);
+      status[k] = codec ? canon::canon_codec_molecule(PC, records, rec_off + r0, rec_len + r0, n, blob.data(), out_off.data() + first[k], out_len.data() + first[k], *SC)
+                        : canon::canon_duplex_molecule(P, records, rec_off + r0, rec_len + r0, n, blob.data(), out_off.data() + first[k], out_len.data() + first[k], *S, delta[k]);
     }
   };
   if (T <= 1) work(0);
@@ -584,7 +593,8 @@ static int hybrid_after_upload(fgx_caller* c, general_fn general, const uint8_t*
   cp.used.assign(def.size(), 0);
   c->last_canon_molecules = 0;
   c->last_deferred_groups = (uint64_t)def.size();
-  if (c->opt.caller_kind == FGX_CALLER_DUPLEX && duplex_canon_enabled()) canon_second_pass(c, records, rec_off, rec_len, grp_first, def, cp);
+  if ((c->opt.caller_kind == FGX_CALLER_DUPLEX && duplex_canon_enabled()) || (c->opt.caller_kind == FGX_CALLER_CODEC && codec_canon_enabled()))
+    canon_second_pass(c, records, rec_off, rec_len, grp_first, def, cp);
   std::vector<uint64_t> d_off;
   std::vector<uint32_t> d_len, d_grp(1, 0);
   for (size_t k = 0; k < def.size(); k++) {
@@ -596,6 +606,7 @@ static int hybrid_after_upload(fgx_caller* c, general_fn general, const uint8_t*
   fgx_output gen;
   memset(&gen, 0, sizeof(gen));
   c->out_data.clear(); c->grp_out_end.clear();
+  c->counter_names_used = false;   // (run_general resets it too; it is not called when the second pass took every deferred group)
   int rc = d_grp.size() > 1 ? run_general(c, general, records, d_off.data(), d_len.data(), (uint32_t)d_off.size(), d_grp.data(), (uint32_t)d_grp.size() - 1, &gen) : 0;
   if (rc != 0) return rc;
   // CODEC molecules without an MI are named by a counter that advances on EVERY emitted record (codec_caller.rs:1568-1577):

@@ -1,0 +1,67 @@
+"""GPU parity of the opt-in canonical second pass for CODEC molecules (FGX_CODEC_CANON=1, fgumi_amd/csrc/canon_core.h
+`canon_codec_molecule` + api.cpp `canon_second_pass`): molecules with soft clips, indels, skips or pads in their CIGARs, which the
+device pipeline defers, are rewritten into their canonical form (proved equivalent through the oracle in tests/test_canon_codec.py)
+and decided by the device pipeline in a second pass — byte-identical to the oracle, counters included.
+
+NOT RUN ON HARDWARE YET: this file was written after the round's GPU budget was spent (the duplex twin, tests/test_gpu_duplex_canon.py,
+ran green: profiles/r03am_duplex_canon_gpu_test.txt).  The tests are therefore marked xfail(strict=False): an XPASS in the driver's
+round-end run is the first hardware evidence, a failure does not stop the suite.  The flag is off by default either way."""
+import ctypes as C
+import os
+import random
+
+import numpy as np
+import pytest
+
+import bamutil
+import fgx_opts
+import orc
+import test_canon_codec as tcc
+from fgumi_amd import GroupedReads, simulate_grouped_reads, split_records
+from test_gpu_duplex_canon import product
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.xfail(strict=False, reason="written after the round's GPU budget was spent; never run on hardware (flag is opt-in)")]
+
+
+@pytest.fixture
+def codec_canon_on():
+    old = os.environ.get("FGX_CODEC_CANON")
+    os.environ["FGX_CODEC_CANON"] = "1"
+    yield
+    if old is None:
+        os.environ.pop("FGX_CODEC_CANON", None)
+    else:
+        os.environ["FGX_CODEC_CANON"] = old
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(min_input_base_quality=20, produce_per_base_tags=1), dict(codec_min_reads_per_strand=2, cell_tag=b"\0\0"),
+                                dict(codec_outer_bases_length=5, codec_has_outer_bases_qual=1, codec_outer_bases_qual=7, codec_min_duplex_length=10)])
+def test_codec_indel_molecules_take_the_canonical_second_pass(codec_canon_on, kw):
+    rng = random.Random(41)
+    groups = []
+    sim = simulate_grouped_reads(120, family_size=3, read_length=150, insert_mean=200, insert_sd=30, codec=1)     # regular molecules in between
+    for g in range(360):
+        groups.append(sim.records(g // 3) if g % 3 == 0 else tcc.codec_molecule(rng, 1000 + g))
+    gr = GroupedReads.from_groups(groups)
+    o = fgx_opts.defaults(kind=2, overlapping_consensus=0, **kw)
+    want = orc.process(o, gr.blob, gr.rec_off, gr.rec_len, gr.grp_first, batch_groups=1000)
+    got = product(o, gr)
+    assert got["deferred"] > 50 and got["canon"] > 0.2 * got["deferred"], (got["deferred"], got["canon"])
+    if got["data"] != want["data"]:
+        for i, (a, b) in enumerate(zip(split_records(got["data"]), split_records(want["data"]))):
+            if a != b:
+                raise AssertionError(f"record {i} differs:\n got {bamutil.parse(a)}\nwant {bamutil.parse(b)}")
+        raise AssertionError("record count / length differs")
+    assert got["count"] == want["count"] and np.array_equal(got["stats"], want["stats"]), (got["stats"].tolist(), want["stats"].tolist())
+
+
+def test_codec_second_pass_is_off_by_default():
+    rng = random.Random(42)
+    groups = [tcc.codec_molecule(rng, g) for g in range(80)]
+    gr = GroupedReads.from_groups(groups)
+    o = fgx_opts.defaults(kind=2, overlapping_consensus=0)
+    os.environ.pop("FGX_CODEC_CANON", None)
+    want = orc.process(o, gr.blob, gr.rec_off, gr.rec_len, gr.grp_first, batch_groups=1000)
+    got = product(o, gr)
+    assert got["canon"] == 0 and got["data"] == want["data"] and np.array_equal(got["stats"], want["stats"])
