@@ -14,6 +14,14 @@
 #include "simgen.h"
 #include "canon_core.h"
 
+namespace fgx {
+// canon_device.hip
+uint32_t launch_canon_molecules(hipStream_t s, bool codec, const canon::Params& P, const canon::CodecParams& PC, const uint8_t* d_blob,
+                                const uint64_t* d_rec_off, const uint32_t* d_rec_len, const uint32_t* d_grp_first, const uint32_t* d_def, uint32_t nd,
+                                const uint64_t* d_first, uint8_t* d_out, const uint64_t* d_out_off, uint32_t* d_out_len, int* d_status,
+                                canon::Delta* d_delta, DevBuf& slabs);
+}
+
 using namespace fgx;
 
 static thread_local std::string g_global_err;
@@ -232,7 +240,7 @@ void fgx_destroy(fgx_caller* c) {
   (void)hipSetDevice(c->device);
   for (DevBuf* b : {&c->d_tables, &c->d_umi_tables, &c->d_stage, &c->d_reads, &c->d_jobs, &c->d_tiles, &c->d_ob, &c->d_oq, &c->d_od,
                     &c->d_oe, &c->d_scratch_a, &c->d_scratch_b, &c->d_in_blob, &c->d_in_off, &c->d_in_len, &c->d_in_grp, &c->d_mjobs, &c->d_mruns,
-                    &c->d_mtiles, &c->d_mflag, &c->d_mu, &c->d_mt, &c->d_canon_blob, &c->d_canon_off, &c->d_canon_len, &c->d_canon_grp})
+                    &c->d_mtiles, &c->d_mflag, &c->d_mu, &c->d_mt, &c->d_canon_blob, &c->d_canon_off, &c->d_canon_len, &c->d_canon_grp, &c->d_canon_aux, &c->d_canon_slabs})
     b->free_();
   c->genome.reset();
   if (c->fast) { c->fast->fp.release(); c->fast->pin_out.free_(); delete c->fast; }
@@ -466,6 +474,9 @@ static bool duplex_canon_enabled() { const char* e = getenv("FGX_DUPLEX_CANON");
 // The same for CODEC molecules (FGX_CODEC_CANON=1; canon_core.h `canon_codec_molecule`, proof tests/test_canon_codec.py): virtual clip
 // applied, `<len>M`, reads placed so that the overlap geometry and the consensus length come out the same; every record is kept and
 // no counter moves, so there is no delta.  Only molecules the original would EMIT are in scope; rejected ones stay on the general path.
+// FGX_CANON_DEVICE=1 (with either flag above): the canonical form is computed by a device kernel (canon_device.hip, the same scalar source,
+// a lane per molecule) from the records already uploaded, instead of on the host's cores; the records do not come back.
+static bool canon_device_enabled() { const char* e = getenv("FGX_CANON_DEVICE"); return e && e[0] == '1'; }
 static bool codec_canon_enabled() { const char* e = getenv("FGX_CODEC_CANON"); return e && e[0] == '1'; }
 
 struct CanonPass {
@@ -490,42 +501,69 @@ static void canon_second_pass(fgx_caller* c, const uint8_t* records, const uint6
   uint64_t bytes = 0;
   for (size_t k = 0; k < nd; k++)
     for (uint32_t r = grp_first[def[k]], i = 0; r < grp_first[def[k] + 1]; r++, i++) { out_off[first[k] + i] = bytes + 4; bytes += 4ull + rec_len[r]; }
-  std::vector<uint8_t> blob(bytes + 16, 0);
+  const bool on_device = canon_device_enabled();
+  std::vector<uint8_t> blob(on_device ? 0 : bytes + 16, 0);
   std::vector<int> status(nd, canon::CANON_OUT_OF_SCOPE);
   std::vector<canon::Delta> delta(nd);
   memset(delta.data(), 0, nd * sizeof(canon::Delta));
   const bool codec = c->opt.caller_kind == FGX_CALLER_CODEC;
   const canon::Params P = canon_params(&c->opt);
   const canon::CodecParams PC = canon_codec_params(&c->opt);
-  unsigned T = host_threads();
-  if (T > nd / 64 + 1) T = (unsigned)(nd / 64 + 1);
-  auto work = [&](unsigned t) {
-    std::unique_ptr<canon::Scratch> S(codec ? nullptr : new canon::Scratch());
-    std::unique_ptr<canon::CodecScratch> SC(codec ? new canon::CodecScratch() : nullptr);
-    for (size_t k = t; k < nd; k += T) {
-      const uint32_t r0 = grp_first[def[k]], n = grp_first[def[k] + 1] - r0;
-      status[k] = codec ? canon::canon_codec_molecule(PC, records, rec_off + r0, rec_len + r0, n, blob.data(), out_off.data() + first[k], out_len.data() + first[k], *SC)
-                        : canon::canon_duplex_molecule(P, records, rec_off + r0, rec_len + r0, n, blob.data(), out_off.data() + first[k], out_len.data() + first[k], *S, delta[k]);
-    }
-  };
-  if (T <= 1) work(0);
-  else { std::vector<std::thread> th; for (unsigned t = 0; t < T; t++) th.emplace_back(work, t); for (auto& x : th) x.join(); }
+  c->d_canon_blob.reserve(bytes + 16);
+  if (on_device) {
+    // FGX_CANON_DEVICE=1: a lane per molecule over the records hybrid_upload already put on the device (canon_device.hip); the
+    // canonical records are written into d_canon_blob there, and only status / lengths / delta come back
+    DevBuf& aux = c->d_canon_aux;      // first[nd+1] u64 | out_off[n_slots] u64 | delta[nd] | def[nd] u32 | status[nd] i32 | out_len[n_slots] u32
+    const size_t o_first = 0, o_off = o_first + (nd + 1) * 8, o_delta = o_off + n_slots * 8, o_def = o_delta + nd * sizeof(canon::Delta),
+                 o_status = o_def + nd * 4, o_len = o_status + nd * 4, total = o_len + n_slots * 4;
+    aux.reserve(total + 16);
+    uint8_t* a = aux.as<uint8_t>();
+    hipStream_t s = c->stream;
+    hip_check(hipMemsetAsync(c->d_canon_blob.p, 0, bytes + 16, s), "memset canonical blob");
+    hip_check(hipMemsetAsync(a + o_len, 0, n_slots * 4, s), "memset canonical lengths");
+    hip_check(hipMemcpyAsync(a + o_first, first.data(), (nd + 1) * 8, hipMemcpyHostToDevice, s), "H2D canonical slots");
+    hip_check(hipMemcpyAsync(a + o_off, out_off.data(), n_slots * 8, hipMemcpyHostToDevice, s), "H2D canonical slot offsets");
+    hip_check(hipMemcpyAsync(a + o_def, def.data(), nd * 4, hipMemcpyHostToDevice, s), "H2D deferred groups");
+    launch_canon_molecules(s, codec, P, PC, c->d_in_blob.as<uint8_t>(), c->d_in_off.as<uint64_t>(), c->d_in_len.as<uint32_t>(), c->d_in_grp.as<uint32_t>(),
+                           (const uint32_t*)(a + o_def), (uint32_t)nd, (const uint64_t*)(a + o_first), c->d_canon_blob.as<uint8_t>(), (const uint64_t*)(a + o_off),
+                           (uint32_t*)(a + o_len), (int*)(a + o_status), (canon::Delta*)(a + o_delta), c->d_canon_slabs);
+    hip_check(hipMemcpyAsync(status.data(), a + o_status, nd * 4, hipMemcpyDeviceToHost, s), "D2H canonical status");
+    hip_check(hipMemcpyAsync(out_len.data(), a + o_len, n_slots * 4, hipMemcpyDeviceToHost, s), "D2H canonical lengths");
+    if (!codec) hip_check(hipMemcpyAsync(delta.data(), a + o_delta, nd * sizeof(canon::Delta), hipMemcpyDeviceToHost, s), "D2H canonical delta");
+    hip_check(hipStreamSynchronize(s), "canonicalisation kernel");
+  } else {
+    unsigned T = host_threads();
+    if (T > nd / 64 + 1) T = (unsigned)(nd / 64 + 1);
+    auto work = [&](unsigned t) {
+      std::unique_ptr<canon::Scratch> S(codec ? nullptr : new canon::Scratch());
+      std::unique_ptr<canon::CodecScratch> SC(codec ? new canon::CodecScratch() : nullptr);
+      for (size_t k = t; k < nd; k += T) {
+        const uint32_t r0 = grp_first[def[k]], n = grp_first[def[k] + 1] - r0;
+        status[k] = codec ? canon::canon_codec_molecule(PC, records, rec_off + r0, rec_len + r0, n, blob.data(), out_off.data() + first[k], out_len.data() + first[k], *SC)
+                          : canon::canon_duplex_molecule(P, records, rec_off + r0, rec_len + r0, n, blob.data(), out_off.data() + first[k], out_len.data() + first[k], *S, delta[k]);
+      }
+    };
+    if (T <= 1) work(0);
+    else { std::vector<std::thread> th; for (unsigned t = 0; t < T; t++) th.emplace_back(work, t); for (auto& x : th) x.join(); }
+  }
   // the canonical molecules as one batch
   std::vector<uint64_t> c_off;
   std::vector<uint32_t> c_len, c_grp(1, 0), c_def;
   for (size_t k = 0; k < nd; k++) {
     if (status[k] != canon::CANON_OK) continue;
     for (uint64_t i = first[k]; i < first[k + 1]; i++)
-      if (out_len[i]) { c_off.push_back(out_off[i]); c_len.push_back(out_len[i]); const uint32_t L = out_len[i]; memcpy(blob.data() + out_off[i] - 4, &L, 4); }
+      if (out_len[i]) {
+        c_off.push_back(out_off[i]); c_len.push_back(out_len[i]);
+        if (!on_device) { const uint32_t L = out_len[i]; memcpy(blob.data() + out_off[i] - 4, &L, 4); }   // (the kernel wrote its own prefixes)
+      }
     c_grp.push_back((uint32_t)c_off.size());
     c_def.push_back((uint32_t)k);
   }
   cp.ms_host = ms_between(t0, clk::now());
   const uint32_t n_cg = (uint32_t)c_def.size(), n_cr = (uint32_t)c_off.size();
   if (n_cg == 0) return;
-  c->d_canon_blob.reserve(blob.size());
   c->d_canon_off.reserve((size_t)n_cr * 8 + 8); c->d_canon_len.reserve((size_t)n_cr * 4 + 4); c->d_canon_grp.reserve((size_t)(n_cg + 1) * 4);
-  hip_check(hipMemcpyAsync(c->d_canon_blob.p, blob.data(), blob.size(), hipMemcpyHostToDevice, c->stream), "H2D canonical blob");
+  if (!on_device) hip_check(hipMemcpyAsync(c->d_canon_blob.p, blob.data(), blob.size(), hipMemcpyHostToDevice, c->stream), "H2D canonical blob");
   if (n_cr) {
     hip_check(hipMemcpyAsync(c->d_canon_off.p, c_off.data(), (size_t)n_cr * 8, hipMemcpyHostToDevice, c->stream), "H2D canonical rec_off");
     hip_check(hipMemcpyAsync(c->d_canon_len.p, c_len.data(), (size_t)n_cr * 4, hipMemcpyHostToDevice, c->stream), "H2D canonical rec_len");
