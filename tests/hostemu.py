@@ -8,7 +8,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tests", "hostemu", "hostemu.cpp")
-OUT = os.path.join(ROOT, "tests", "hostemu", "_build", "libhostemu.so")
+SANITIZE = os.environ.get("HOSTEMU_SANITIZE") == "1"     # tools/sanitize_host.sh: clang -fsanitize=address,undefined build, loaded under LD_PRELOAD of the ASan runtime
+OUT = os.path.join(ROOT, "tests", "hostemu", "_build", "libhostemu_san.so" if SANITIZE else "libhostemu.so")
 CSRC = os.path.join(ROOT, "fgumi_amd", "csrc")
 PARTS = [SRC, os.path.join(CSRC, "simplex_host.cpp"), os.path.join(CSRC, "duplex_host.cpp"), os.path.join(CSRC, "codec_host.cpp")]
 
@@ -24,7 +25,8 @@ def _stale():
 def build():
     if _stale():
         os.makedirs(os.path.dirname(OUT), exist_ok=True)
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+        cc = ["/opt/rocm/lib/llvm/bin/clang++", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-shared-libasan", "-fno-omit-frame-pointer"] if SANITIZE else ["g++"]
+        subprocess.check_call(cc + ["-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
                                "-Wno-unused-function", "-Wno-attributes", "-w"] + PARTS + ["-o", OUT, "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"])
     return OUT
 
