@@ -3,38 +3,25 @@ FGX_CODEC_CANON; fgumi_amd/csrc/canon_device.hip: a lane per deferred molecule r
 already uploaded).  Same inputs and assertions as the host-canonicalised twins (tests/test_gpu_duplex_canon.py, test_gpu_codec_canon.py):
 byte-identical to the oracle, counters included.
 
-NOT RUN ON HARDWARE YET: written after the round's GPU budget was spent.  xfail(strict=False): an XPASS in the driver's round-end run is
-the first hardware evidence; a failure does not stop the suite.  The flags are off by default."""
-import os
-
+NOT RUN ON HARDWARE YET: written after the round's GPU budget was spent.  xfail(strict=False), each test in a child interpreter
+(tests/isolated.py): an XPASS in the driver's round-end run is the first hardware evidence; a failure — or a device fault in the new
+kernel — does not stop the suite.  The flags are off by default."""
 import pytest
 
-import test_gpu_codec_canon as tg_codec
-import test_gpu_duplex_canon as tg_duplex
+from isolated import run_isolated
 
 pytestmark = [pytest.mark.gpu,
               pytest.mark.xfail(strict=False, reason="written after the round's GPU budget was spent; never run on hardware (flags are opt-in)")]
 
 
-@pytest.fixture
-def flags():
-    names = ("FGX_CANON_DEVICE", "FGX_DUPLEX_CANON", "FGX_CODEC_CANON")
-    old = {k: os.environ.get(k) for k in names}
-    for k in names:
-        os.environ[k] = "1"
-    yield
-    for k, v in old.items():
-        if v is None:
-            os.environ.pop(k, None)
-        else:
-            os.environ[k] = v
+FLAGS = {"FGX_CANON_DEVICE": "1", "FGX_DUPLEX_CANON": "1", "FGX_CODEC_CANON": "1"}
 
 
 @pytest.mark.parametrize("kw,mr", [(dict(overlapping_consensus=1), (1, 1, 0)), (dict(overlapping_consensus=0, min_input_base_quality=20), (2, 1, 1))])
-def test_duplex_indel_molecules_canonicalised_on_the_device(flags, kw, mr):
-    tg_duplex.test_indel_molecules_take_the_canonical_second_pass(None, kw, mr)     # (its fixture only sets the flag `flags` already set)
+def test_duplex_indel_molecules_canonicalised_on_the_device(kw, mr):
+    run_isolated("test_gpu_duplex_canon", "test_indel_molecules_take_the_canonical_second_pass", None, kw, mr, env=FLAGS)
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(min_input_base_quality=20, produce_per_base_tags=1)])
-def test_codec_molecules_canonicalised_on_the_device(flags, kw):
-    tg_codec.test_codec_indel_molecules_take_the_canonical_second_pass(None, kw)
+def test_codec_molecules_canonicalised_on_the_device(kw):
+    run_isolated("test_gpu_codec_canon", "check_codec_indel_molecules", kw, env=FLAGS)

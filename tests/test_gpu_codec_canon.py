@@ -4,8 +4,9 @@ device pipeline defers, are rewritten into their canonical form (proved equivale
 and decided by the device pipeline in a second pass — byte-identical to the oracle, counters included.
 
 NOT RUN ON HARDWARE YET: this file was written after the round's GPU budget was spent (the duplex twin, tests/test_gpu_duplex_canon.py,
-ran green: profiles/r03am_duplex_canon_gpu_test.txt).  The tests are therefore marked xfail(strict=False): an XPASS in the driver's
-round-end run is the first hardware evidence, a failure does not stop the suite.  The flag is off by default either way."""
+ran green: profiles/r03am_duplex_canon_gpu_test.txt).  The tests are therefore marked xfail(strict=False) and each runs in a child
+interpreter (tests/isolated.py): an XPASS in the driver's round-end run is the first hardware evidence, a failure — or a device fault —
+does not stop the suite.  The flag is off by default either way."""
 import ctypes as C
 import os
 import random
@@ -18,26 +19,20 @@ import fgx_opts
 import orc
 import test_canon_codec as tcc
 from fgumi_amd import GroupedReads, simulate_grouped_reads, split_records
+from isolated import run_isolated
 from test_gpu_duplex_canon import product
 
 pytestmark = [pytest.mark.gpu,
               pytest.mark.xfail(strict=False, reason="written after the round's GPU budget was spent; never run on hardware (flag is opt-in)")]
 
 
-@pytest.fixture
-def codec_canon_on():
-    old = os.environ.get("FGX_CODEC_CANON")
-    os.environ["FGX_CODEC_CANON"] = "1"
-    yield
-    if old is None:
-        os.environ.pop("FGX_CODEC_CANON", None)
-    else:
-        os.environ["FGX_CODEC_CANON"] = old
-
-
 @pytest.mark.parametrize("kw", [dict(), dict(min_input_base_quality=20, produce_per_base_tags=1), dict(codec_min_reads_per_strand=2, cell_tag=b"\0\0"),
                                 dict(codec_outer_bases_length=5, codec_has_outer_bases_qual=1, codec_outer_bases_qual=7, codec_min_duplex_length=10)])
-def test_codec_indel_molecules_take_the_canonical_second_pass(codec_canon_on, kw):
+def test_codec_indel_molecules_take_the_canonical_second_pass(kw):
+    run_isolated("test_gpu_codec_canon", "check_codec_indel_molecules", kw, env={"FGX_CODEC_CANON": "1"})
+
+
+def check_codec_indel_molecules(kw):
     rng = random.Random(41)
     groups = []
     sim = simulate_grouped_reads(120, family_size=3, read_length=150, insert_mean=200, insert_sd=30, codec=1)     # regular molecules in between
@@ -57,6 +52,10 @@ def test_codec_indel_molecules_take_the_canonical_second_pass(codec_canon_on, kw
 
 
 def test_codec_second_pass_is_off_by_default():
+    run_isolated("test_gpu_codec_canon", "check_off_by_default")
+
+
+def check_off_by_default():
     rng = random.Random(42)
     groups = [tcc.codec_molecule(rng, g) for g in range(80)]
     gr = GroupedReads.from_groups(groups)
