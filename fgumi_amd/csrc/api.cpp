@@ -13,6 +13,7 @@
 #include "host_common.h"
 #include "simgen.h"
 #include "canon_core.h"
+#include "reject_core.h"
 
 namespace fgx {
 // canon_device.hip
@@ -340,6 +341,42 @@ int fgx_canon_codec_host(const fgx_options* o, const uint8_t* blob, const uint64
   static thread_local std::unique_ptr<canon::CodecScratch> S;
   if (!S) S.reset(new canon::CodecScratch());
   return canon::canon_codec_molecule(canon_codec_params(o), blob, rec_off, rec_len, n, out, rec_off, out_len, *S);
+}
+
+static rej::Params reject_params(const fgx_options* o) {
+  rej::Params P;
+  P.min_bq = o->min_input_base_quality; P.overlapping = o->overlapping_consensus; P.trim = o->trim; P.has_max_reads = o->max_reads >= 0;
+  P.min_reads = o->min_reads; P.max_reads = o->max_reads < 0 ? 0u : o->max_reads > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)o->max_reads;
+  return P;
+}
+// reject_core.h on the host: the `--rejects` stream of the simplex caller for a whole batch, computed from the records alone (mask pass
+// per group, then the rejected records — overlap-corrected copies, or the original bytes for a group below --min-reads — each with its
+// block_size, in input order).  This is what the device side kernels of reject_device.hip run, lane per group.  `out` may be NULL to size:
+// *out_len receives the bytes needed.  Returns 0; 1 = some group is out of scope (nothing written); 2 = bad arguments / `cap` too small.
+int fgx_simplex_rejects_host(const fgx_options* o, const uint8_t* blob, const uint64_t* rec_off, const uint32_t* rec_len, const uint32_t* grp_first, uint32_t n_grp,
+                             uint8_t* out, uint64_t cap, uint64_t* out_len, uint64_t* n_rejects) {
+  if (!o || o->struct_size != sizeof(fgx_options) || !out_len || !n_rejects || (n_grp && (!blob || !rec_off || !rec_len || !grp_first))) return 2;
+  const rej::Params P = reject_params(o);
+  std::unique_ptr<rej::Scratch> S(new rej::Scratch());
+  std::vector<uint8_t> work, mask;
+  uint64_t pos = 0, cnt = 0;
+  for (uint32_t g = 0; g < n_grp; g++) {
+    const uint32_t r0 = grp_first[g], n = grp_first[g + 1] - r0;
+    uint64_t bytes = 0;
+    for (uint32_t i = 0; i < n; i++) bytes += rec_len[r0 + i];
+    work.resize(bytes + 16); mask.assign(n + 1, 0);
+    uint8_t whole = 0;
+    if (rej::simplex_reject_mask(P, blob, rec_off + r0, rec_len + r0, n, work.data(), mask.data(), *S, &whole) != rej::REJ_OK) return 1;
+    uint32_t c = 0;
+    const uint64_t b = rej::reject_bytes(rec_len + r0, n, mask.data(), &c);
+    if (out && b) {
+      if (pos + b > cap) return 2;
+      rej::emit_rejects(blob, rec_off + r0, rec_len + r0, n, mask.data(), P.overlapping && !whole, work.data(), S->c.ops, out + pos);
+    }
+    pos += b; cnt += c;
+  }
+  *out_len = pos; *n_rejects = cnt;
+  return 0;
 }
 
 // Host-input entry: upload once, run the device-resident pipeline, bring the records back, and send

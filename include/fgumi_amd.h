@@ -216,6 +216,17 @@ int fgx_canon_duplex_host(const fgx_options* o, const uint8_t* blob, const uint6
  * UMI is called over all of them); a molecule the original would reject, or whose filter / cap would drop a read, is out of scope. */
 int fgx_canon_codec_host(const fgx_options* o, const uint8_t* blob, const uint64_t* rec_off, const uint32_t* rec_len, uint32_t n, uint8_t* out, uint32_t* out_len);
 
+/* The `--rejects` stream of the simplex caller for a batch of MI groups, from the records alone (fgumi_amd/csrc/reject_core.h): every
+ * rejection the vanilla caller makes is taken before the per-position arithmetic (vanilla_caller.rs:1329-1646: secondary / supplementary,
+ * --min-reads at the group and subgroup level, zero length after trimming, unmapped among mapped, minority alignments, --max-reads
+ * downsampling, the orphan R1 / R2 rule), and the rejected records are the group's records after the R1 / R2 overlap pre-correction
+ * (simplex.rs:685-700), block_size-prefixed, in input order (:1430-1436).  This host entry runs the scalar source the device kernels of
+ * reject_device.hip run lane per group; tests compare it with the reference restatement byte for byte.  out == NULL sizes (*out_len).
+ * Returns 0; 1 = a group is out of scope (> 128 records, > 16 CIGAR ops, malformed records: the general path decides the batch);
+ * 2 = bad arguments or `cap` too small. */
+int fgx_simplex_rejects_host(const fgx_options* o, const uint8_t* blob, const uint64_t* rec_off, const uint32_t* rec_len, const uint32_t* grp_first, uint32_t n_grp,
+                             uint8_t* out, uint64_t cap, uint64_t* out_len, uint64_t* n_rejects);
+
 /* Device self-test of the glibc-compatible libm: op 0 exp, 1 log, 2 log1p, 3 expm1. */
 int fgx_device_libm(fgx_caller* c, int op, const double* x, double* y, uint64_t n);
 
