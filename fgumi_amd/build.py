@@ -16,7 +16,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
 
 
 def sources():
-    extra = [f for f in ("fastpath.hip", "grouping.hip", "boundaries.hip", "bgzf_device.hip", "filter.hip", "canon_device.hip", "duplex_host.cpp", "codec_host.cpp", "bgzf_host.cpp", "pipeline.cpp") if os.path.exists(os.path.join(CSRC, f))]
+    extra = [f for f in ("fastpath.hip", "grouping.hip", "boundaries.hip", "bgzf_device.hip", "filter.hip", "canon_device.hip", "reject_device.hip", "duplex_host.cpp", "codec_host.cpp", "bgzf_host.cpp", "pipeline.cpp") if os.path.exists(os.path.join(CSRC, f))]
     return [os.path.join(CSRC, f) for f in SOURCES + extra]
 
 

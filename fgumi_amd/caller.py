@@ -169,6 +169,14 @@ class DeviceOutput:
     count: int
     n_deferred: int
     deferred_ptr: Optional[int]
+    rejects_ptr: Optional[int] = None      # track_rejects with FGX_REJECTS_DEVICE=1: the rejected input records, block_size-prefixed, in HBM
+    rejects_len: int = 0
+    n_rejects: int = 0
+
+    def rejects_to_host(self) -> bytes:
+        import torch  # noqa: F401
+        from ._lib import hip_memcpy_d2h
+        return hip_memcpy_d2h(self.rejects_ptr, self.rejects_len) if self.rejects_len else b""
 
     def to_host(self) -> bytes:
         import torch  # noqa: F401  (ensures the HIP runtime is initialised in this process)
@@ -384,7 +392,7 @@ class _HandleCaller(ConsensusCaller):
         self._stats.merge(self._last_stats)
         self.last_stats_array = [int(v) for v in out.stats]          # the raw counters of this batch (fgx_output.stats order)
         self.last_timing = dict(kernels=out.ms_kernels, k_family=out.ms_k_family, k_emit=out.ms_k_emit, full_columns=int(out.ms_emit))
-        return DeviceOutput(out.data, int(out.data_len), int(out.count), int(n_def.value), d_def.value)
+        return DeviceOutput(out.data, int(out.data_len), int(out.count), int(n_def.value), d_def.value, out.rejects, int(out.rejects_len), int(out.n_rejects))
 
     def simulate_on_device(self, n_families, family_size=3, read_length=150, seed=42, **kw) -> "DeviceGroupedReads":
         import torch

@@ -244,6 +244,7 @@ void fgx_destroy(fgx_caller* c) {
                     &c->d_mtiles, &c->d_mflag, &c->d_mu, &c->d_mt, &c->d_canon_blob, &c->d_canon_off, &c->d_canon_len, &c->d_canon_grp, &c->d_canon_aux, &c->d_canon_slabs})
     b->free_();
   c->genome.reset();
+  reject_release(c);
   if (c->fast) { c->fast->fp.release(); c->fast->pin_out.free_(); delete c->fast; }
   if (c->filt) { c->filt->release(); delete c->filt; }
   pipeline_release(c);
@@ -343,6 +344,8 @@ int fgx_canon_codec_host(const fgx_options* o, const uint8_t* blob, const uint64
   return canon::canon_codec_molecule(canon_codec_params(o), blob, rec_off, rec_len, n, out, rec_off, out_len, *S);
 }
 
+// FGX_REJECTS_DEVICE=1: `--rejects` of the simplex caller without the general path (reject_device.hip).  Off by default: not yet run on hardware.
+static bool rejects_device_enabled() { const char* e = getenv("FGX_REJECTS_DEVICE"); return e && e[0] == '1'; }
 static rej::Params reject_params(const fgx_options* o) {
   rej::Params P;
   P.min_bq = o->min_input_base_quality; P.overlapping = o->overlapping_consensus; P.trim = o->trim; P.has_max_reads = o->max_reads >= 0;
@@ -490,12 +493,29 @@ static int process_hybrid(fgx_caller* c, general_fn general, const uint8_t* reco
                           const uint32_t* rec_len, uint32_t n_rec, const uint32_t* grp_first, uint32_t n_grp, fgx_output* out) {
   // --rejects (record copies in input order) and the methylation-aware mode (reference lookups per source read) are decided by the
   // general path: host orchestration, device kernels for the per-base work
-  if (c->opt.track_rejects || c->opt.methylation_mode != FGX_METHYLATION_DISABLED || n_grp == 0) return run_general(c, general, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
+  // Opt-in (FGX_REJECTS_DEVICE=1), simplex caller: the rejects come from side kernels that evaluate the caller's rejection decisions on the
+  // uploaded records, a lane per group (reject_device.hip / reject_core.h), and the records from the device pipeline as without --rejects.
+  const bool dev_rejects = c->opt.track_rejects && c->opt.caller_kind == FGX_CALLER_SIMPLEX && c->opt.methylation_mode == FGX_METHYLATION_DISABLED && n_grp != 0 &&
+                           rejects_device_enabled();
+  if ((c->opt.track_rejects && !dev_rejects) || c->opt.methylation_mode != FGX_METHYLATION_DISABLED || n_grp == 0) return run_general(c, general, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
   if (!c->fast) c->fast = new FastState();
   auto t0 = clk::now();
   hybrid_upload(c, records, records_len, rec_off, rec_len, n_rec, grp_first, n_grp);
   auto t1 = clk::now();
+  RejectResult rr = {nullptr, 0, 0, 0, 0.0};
+  if (dev_rejects) {
+    simplex_rejects_device(c, reject_params(&c->opt), c->d_in_blob.as<uint8_t>(), c->d_in_off.as<uint64_t>(), c->d_in_len.as<uint32_t>(), n_rec, c->d_in_grp.as<uint32_t>(), n_grp, &rr);
+    c->last_reject_oos = rr.n_out_of_scope;
+    if (rr.n_out_of_scope) return run_general(c, general, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);   // (> 128 records, > 16 CIGAR ops, malformed records)
+    c->rejects_host.resize(rr.bytes);
+    if (rr.bytes) hip_check(hipMemcpy(c->rejects_host.data(), rr.d_out, rr.bytes, hipMemcpyDeviceToHost), "D2H rejects");
+  }
+  // (the rejects of EVERY group are in hand, also of the groups the device pipeline defers: the general path need not track them again)
+  struct Untrack { fgx_caller* c; uint8_t saved; Untrack(fgx_caller* cc, bool on) : c(cc), saved(cc->opt.track_rejects) { if (on) set(0); }
+                   void set(uint8_t v) { c->opt.track_rejects = v; for (fgx_caller* w : c->workers) w->opt.track_rejects = v; }
+                   ~Untrack() { set(saved); } } untrack(c, dev_rejects);
   int rc = hybrid_after_upload(c, general, records, records_len, rec_off, rec_len, n_rec, grp_first, n_grp, out, nullptr, 0);
+  if (rc == 0 && dev_rejects) { out->rejects = c->rejects_host.data(); out->rejects_len = rr.bytes; out->n_rejects = rr.count; out->ms_kernels += rr.ms; }
   if (rc == 0) out->ms_h2d = ms_between(t0, t1);
   return rc;
 }
@@ -758,7 +778,8 @@ int fgx_process_batch_device(fgx_caller* c, const void* d_records, uint64_t reco
     if (c->opt.caller_kind == FGX_CALLER_CODEC && (c->opt.codec_max_duplex_disagreements != 0xFFFFFFFFu || c->opt.codec_max_duplex_disagreement_rate < 1.0)) {
       c->err = "fgx_process_batch_device: CODEC duplex-disagreement thresholds need the host path (fgx_process_batch)"; return 1;
     }
-    if (c->opt.track_rejects) { c->err = "fgx_process_batch_device: --rejects needs the host path (fgx_process_batch)"; return 1; }
+    const bool dev_rejects = c->opt.track_rejects && c->opt.caller_kind == FGX_CALLER_SIMPLEX && rejects_device_enabled();
+    if (c->opt.track_rejects && !dev_rejects) { c->err = "fgx_process_batch_device: --rejects needs the host path (fgx_process_batch)"; return 1; }
     if (c->opt.methylation_mode != FGX_METHYLATION_DISABLED) { c->err = "fgx_process_batch_device: the methylation-aware mode needs the host entry (fgx_process_batch)"; return 1; }
     if (!c->fast) c->fast = new FastState();
     c->fast->has_last = false;   // set again only when this batch succeeds
@@ -774,6 +795,13 @@ int fgx_process_batch_device(fgx_caller* c, const void* d_records, uint64_t reco
     out->ms_emit = (double)fr.full_items;   /* device path: number of columns that needed call_full (diagnostic) */
     if (n_deferred) *n_deferred = fr.n_deferred;
     if (d_deferred_groups) *d_deferred_groups = fr.d_deferred;
+    if (dev_rejects) {   // out->rejects is a DEVICE pointer here, like out->data; it covers every group, the deferred ones included
+      RejectResult rr;
+      simplex_rejects_device(c, reject_params(&c->opt), (const uint8_t*)d_records, (const uint64_t*)d_rec_off, (const uint32_t*)d_rec_len, n_rec, (const uint32_t*)d_grp_first, n_grp, &rr);
+      c->last_reject_oos = rr.n_out_of_scope;
+      if (rr.n_out_of_scope) { c->err = "fgx_process_batch_device: --rejects: a group is out of the side kernels' scope (more than 128 records or 16 CIGAR ops, malformed records); use the host entry (fgx_process_batch)"; return 1; }
+      out->rejects = rr.d_out; out->rejects_len = rr.bytes; out->n_rejects = rr.count; out->ms_kernels += rr.ms;
+    }
     return 0;
   } catch (const std::exception& ex) { c->err = ex.what(); return 3; }
 }

@@ -158,6 +158,9 @@ struct fgx_caller {
   fgx::DevBuf d_canon_aux, d_canon_slabs;   // device canonicalisation (canon_device.hip): slot tables / status / lengths, per-lane lists
   fgx::DevBuf d_canon_blob, d_canon_off, d_canon_len, d_canon_grp;   // canonical duplex molecules of the second device pass (canon_core.h)
   fgx::FilterBuffers* filt = nullptr;      // fgx_filter_records[_device] state (filter.hip)
+  std::vector<uint8_t> rejects_host;       // host entry: the device-made rejects of the last batch (FGX_REJECTS_DEVICE=1)
+  uint32_t last_reject_oos = 0;            // ... groups its side kernels could not decide (the batch then took the general path)
+  void* rej_state = nullptr;               // buffers of the device `--rejects` side kernels (reject_device.hip: reject_release)
   void* pipe_state = nullptr;              // buffers of fgx_run_bam, kept from run to run (pipeline.cpp: fgx_pipeline_release)
   uint64_t last_deferred_groups = 0, last_canon_molecules = 0;   // host entry: groups the first device pass deferred / molecules the canonical second pass decided
   uint32_t last_boundary_rounds = 0;       // repair rounds of the last fgx_record_boundaries_device call (boundaries.hip; 0 = every guess was right)
@@ -174,6 +177,12 @@ int simplex_process_general(fgx_caller* c, const uint8_t* blob, const uint64_t* 
 int duplex_process_general(fgx_caller* c, const uint8_t* blob, const uint64_t* rec_off, const uint32_t* rec_len, uint32_t n_rec,
                            const uint32_t* grp_first, uint32_t n_grp, fgx_output* out);
 // grouping.hip — MI grouping on the device
+// reject_device.hip: the simplex caller's `--rejects` stream from side kernels (reject_core.h, a lane per MI group)
+namespace rej { struct Params; }
+struct RejectResult { const uint8_t* d_out; uint64_t bytes, count; uint32_t n_out_of_scope; double ms; };
+void simplex_rejects_device(fgx_caller* c, const rej::Params& P, const uint8_t* d_blob, const uint64_t* d_rec_off, const uint32_t* d_rec_len, uint32_t n_rec,
+                            const uint32_t* d_grp_first, uint32_t n_grp, RejectResult* r);
+void reject_release(fgx_caller* c);
 int group_records_device(fgx_caller* c, const fgx_group_options* o, const uint8_t* d_blob, uint64_t blob_len, const uint64_t* d_rec_off,
                          const uint32_t* d_rec_len, uint32_t n, uint64_t* d_out_off, uint32_t* d_out_len, uint32_t* d_grp_first, uint32_t* n_kept,
                          uint32_t* n_grp);
