@@ -369,7 +369,7 @@ int fgx_simplex_rejects_host(const fgx_options* o, const uint8_t* blob, const ui
     for (uint32_t i = 0; i < n; i++) bytes += rec_len[r0 + i];
     work.resize(bytes + 16); mask.assign(n + 1, 0);
     uint8_t whole = 0;
-    if (rej::simplex_reject_mask(P, blob, rec_off + r0, rec_len + r0, n, work.data(), mask.data(), *S, &whole) != rej::REJ_OK) return 1;
+    if (rej::simplex_reject_mask(P, blob, ~0ull, rec_off + r0, rec_len + r0, n, work.data(), mask.data(), *S, &whole) != rej::REJ_OK) return 1;
     uint32_t c = 0;
     const uint64_t b = rej::reject_bytes(rec_len + r0, n, mask.data(), &c);
     if (out && b) {
@@ -504,7 +504,7 @@ static int process_hybrid(fgx_caller* c, general_fn general, const uint8_t* reco
   auto t1 = clk::now();
   RejectResult rr = {nullptr, 0, 0, 0, 0.0};
   if (dev_rejects) {
-    simplex_rejects_device(c, reject_params(&c->opt), c->d_in_blob.as<uint8_t>(), c->d_in_off.as<uint64_t>(), c->d_in_len.as<uint32_t>(), n_rec, c->d_in_grp.as<uint32_t>(), n_grp, &rr);
+    simplex_rejects_device(c, reject_params(&c->opt), c->d_in_blob.as<uint8_t>(), records_len, c->d_in_off.as<uint64_t>(), c->d_in_len.as<uint32_t>(), n_rec, c->d_in_grp.as<uint32_t>(), n_grp, &rr);
     c->last_reject_oos = rr.n_out_of_scope;
     if (rr.n_out_of_scope) return run_general(c, general, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);   // (> 128 records, > 16 CIGAR ops, malformed records)
     c->rejects_host.resize(rr.bytes);
@@ -797,7 +797,7 @@ int fgx_process_batch_device(fgx_caller* c, const void* d_records, uint64_t reco
     if (d_deferred_groups) *d_deferred_groups = fr.d_deferred;
     if (dev_rejects) {   // out->rejects is a DEVICE pointer here, like out->data; it covers every group, the deferred ones included
       RejectResult rr;
-      simplex_rejects_device(c, reject_params(&c->opt), (const uint8_t*)d_records, (const uint64_t*)d_rec_off, (const uint32_t*)d_rec_len, n_rec, (const uint32_t*)d_grp_first, n_grp, &rr);
+      simplex_rejects_device(c, reject_params(&c->opt), (const uint8_t*)d_records, records_len, (const uint64_t*)d_rec_off, (const uint32_t*)d_rec_len, n_rec, (const uint32_t*)d_grp_first, n_grp, &rr);
       c->last_reject_oos = rr.n_out_of_scope;
       if (rr.n_out_of_scope) { c->err = "fgx_process_batch_device: --rejects: a group is out of the side kernels' scope (more than 128 records or 16 CIGAR ops, malformed records); use the host entry (fgx_process_batch)"; return 1; }
       out->rejects = rr.d_out; out->rejects_len = rr.bytes; out->n_rejects = rr.count; out->ms_kernels += rr.ms;

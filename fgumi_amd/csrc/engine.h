@@ -180,7 +180,7 @@ int duplex_process_general(fgx_caller* c, const uint8_t* blob, const uint64_t* r
 // reject_device.hip: the simplex caller's `--rejects` stream from side kernels (reject_core.h, a lane per MI group)
 namespace rej { struct Params; }
 struct RejectResult { const uint8_t* d_out; uint64_t bytes, count; uint32_t n_out_of_scope; double ms; };
-void simplex_rejects_device(fgx_caller* c, const rej::Params& P, const uint8_t* d_blob, const uint64_t* d_rec_off, const uint32_t* d_rec_len, uint32_t n_rec,
+void simplex_rejects_device(fgx_caller* c, const rej::Params& P, const uint8_t* d_blob, uint64_t blob_len, const uint64_t* d_rec_off, const uint32_t* d_rec_len, uint32_t n_rec,
                             const uint32_t* d_grp_first, uint32_t n_grp, RejectResult* r);
 void reject_release(fgx_caller* c);
 int group_records_device(fgx_caller* c, const fgx_group_options* o, const uint8_t* d_blob, uint64_t blob_len, const uint64_t* d_rec_off,

@@ -61,11 +61,11 @@ CANON_HD int32_t name_rank(const uint8_t* name, uint32_t len) {
 CANON_HD bool eligible(const bam::Rec& v) { return (v.flags() & (bam::F_SECONDARY | bam::F_SUPPLEMENTARY)) == 0; }
 
 // Basic shape of every record of the group; false = out of scope.
-CANON_HD bool records_in_scope(const uint8_t* blob, const uint64_t* rec_off, const uint32_t* rec_len, uint32_t n) {
+CANON_HD bool records_in_scope(const uint8_t* blob, uint64_t blob_len, const uint64_t* rec_off, const uint32_t* rec_len, uint32_t n) {
   if (n > canon::MAX_READS) return false;
   for (uint32_t i = 0; i < n; i++) {
     const uint32_t len = rec_len[i];
-    if (len < 32) return false;
+    if (len < 32 || len > blob_len || rec_off[i] > blob_len - len) return false;      // (a record outside the blob: the general path raises the error)
     bam::Rec v{blob + rec_off[i], len};
     if (v.l_read_name() == 0 || (uint64_t)v.aux_off() > len) return false;
     const uint32_t nc = v.n_cigar();
@@ -214,10 +214,10 @@ CANON_HD bool subgroup(const Params& P, const uint8_t* base, const uint64_t* off
 // The reject mask of one MI group: mask[i] = 1 when record i is written to the rejects.  `work` (sum of rec_len bytes) receives the
 // overlap-corrected working copies when the option is on and the group reaches the pre-correction.  *whole = 1 when the group was
 // rejected before the pre-correction (its rejects are the ORIGINAL bytes).  Returns REJ_OK or REJ_OUT_OF_SCOPE.
-CANON_HD int simplex_reject_mask(const Params& P, const uint8_t* blob, const uint64_t* rec_off, const uint32_t* rec_len, uint32_t n, uint8_t* work, uint8_t* mask,
-                                 Scratch& S, uint8_t* whole) {
+CANON_HD int simplex_reject_mask(const Params& P, const uint8_t* blob, uint64_t blob_len, const uint64_t* rec_off, const uint32_t* rec_len, uint32_t n, uint8_t* work,
+                                 uint8_t* mask, Scratch& S, uint8_t* whole) {
   *whole = 0;
-  if (!records_in_scope(blob, rec_off, rec_len, n)) return REJ_OUT_OF_SCOPE;
+  if (!records_in_scope(blob, blob_len, rec_off, rec_len, n)) return REJ_OUT_OF_SCOPE;
   for (uint32_t i = 0; i < n; i++) mask[i] = 0;
   if (n == 0) return REJ_OK;
   if (n < P.min_reads) { for (uint32_t i = 0; i < n; i++) mask[i] = 1; *whole = 1; return REJ_OK; }      // simplex.rs:673-683

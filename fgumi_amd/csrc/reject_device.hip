@@ -42,7 +42,7 @@ __global__ void k_group_bytes_max(const uint32_t* __restrict__ rec_len, const ui
 }
 
 __global__ void __launch_bounds__(REJ_BLOCK)
-k_reject_mask(rej::Params P, const uint8_t* __restrict__ blob, const uint64_t* __restrict__ rec_off, const uint32_t* __restrict__ rec_len,
+k_reject_mask(rej::Params P, const uint8_t* __restrict__ blob, uint64_t blob_len, const uint64_t* __restrict__ rec_off, const uint32_t* __restrict__ rec_len,
               const uint32_t* __restrict__ grp_first, uint32_t n_grp, uint8_t* mask, unsigned long long* grp_bytes, uint8_t* grp_flag,
               unsigned long long* totals, uint8_t* work, uint64_t slab_bytes, rej::Scratch* slabs) {
   const uint32_t lane = blockIdx.x * REJ_BLOCK + threadIdx.x, stride = gridDim.x * REJ_BLOCK;
@@ -51,7 +51,7 @@ k_reject_mask(rej::Params P, const uint8_t* __restrict__ blob, const uint64_t* _
   for (uint32_t g = lane; g < n_grp; g += stride) {
     const uint32_t r0 = grp_first[g], n = grp_first[g + 1] - r0;
     uint8_t whole = 0;
-    const int st = rej::simplex_reject_mask(P, blob, rec_off + r0, rec_len + r0, n, w, mask + r0, S, &whole);
+    const int st = rej::simplex_reject_mask(P, blob, blob_len, rec_off + r0, rec_len + r0, n, w, mask + r0, S, &whole);
     if (st != rej::REJ_OK) { grp_bytes[g] = 0; grp_flag[g] = 2; atomicAdd(&totals[1], 1ull); continue; }
     uint32_t cnt = 0;
     grp_bytes[g] = rej::reject_bytes(rec_len + r0, n, mask + r0, &cnt);
@@ -85,7 +85,7 @@ void reject_release(fgx_caller* c) {
 
 // The rejects of the batch at d_blob / d_rec_off / d_rec_len / d_grp_first, left in device memory (r->d_out, r->bytes; r->count records).
 // r->n_out_of_scope > 0: some group could not be decided here — nothing is to be used, the general path decides the batch.
-void simplex_rejects_device(fgx_caller* c, const rej::Params& P, const uint8_t* d_blob, const uint64_t* d_rec_off, const uint32_t* d_rec_len, uint32_t n_rec,
+void simplex_rejects_device(fgx_caller* c, const rej::Params& P, const uint8_t* d_blob, uint64_t blob_len, const uint64_t* d_rec_off, const uint32_t* d_rec_len, uint32_t n_rec,
                             const uint32_t* d_grp_first, uint32_t n_grp, RejectResult* r) {
   r->d_out = nullptr; r->bytes = 0; r->count = 0; r->n_out_of_scope = 0; r->ms = 0;
   if (n_grp == 0) return;
@@ -117,7 +117,7 @@ void simplex_rejects_device(fgx_caller* c, const rej::Params& P, const uint8_t* 
   uint8_t* grp_flag = (uint8_t*)(grp_off + n_grp);
   B.work.reserve((size_t)lanes * slab_bytes + 16);
   B.slabs.reserve((size_t)lanes * sizeof(rej::Scratch));
-  hipLaunchKernelGGL(k_reject_mask, dim3(blocks), dim3(REJ_BLOCK), 0, s, P, d_blob, d_rec_off, d_rec_len, d_grp_first, n_grp, B.mask.as<uint8_t>(), grp_bytes, grp_flag, misc,
+  hipLaunchKernelGGL(k_reject_mask, dim3(blocks), dim3(REJ_BLOCK), 0, s, P, d_blob, blob_len, d_rec_off, d_rec_len, d_grp_first, n_grp, B.mask.as<uint8_t>(), grp_bytes, grp_flag, misc,
                      B.work.as<uint8_t>(), slab_bytes, B.slabs.as<rej::Scratch>());
   hip_check(hipGetLastError(), "k_reject_mask launch");
   size_t tb = 0;
