@@ -160,7 +160,9 @@ int fgx_process_batch(fgx_caller* c, const uint8_t* records, uint64_t records_le
  * pipelines do not decide (reads with more than 6 CIGAR ops, unmapped reads, malformed records; for
  * duplex / CODEC also molecules with indels or a biting per-strand read cap) are reported in
  * *n_deferred / d_deferred_groups and must be re-submitted through fgx_process_batch; 0 for
- * `simulate`-shaped input.  The kernels stage a family's bytes in whole 16-byte pieces: `d_records` must be
+ * `simulate`-shaped input.  `track_rejects` is refused here, except for the simplex caller when FGX_REJECTS_DEVICE=1 is set in the
+ * environment (side kernels, fgumi_amd/csrc/reject_device.hip; not yet run on hardware): `out->rejects` is then a DEVICE pointer too and
+ * covers every group, the deferred ones included.  The kernels stage a family's bytes in whole 16-byte pieces: `d_records` must be
  * READABLE for 16 bytes past `records_len` (any allocation larger than the stream by 16 bytes will do; the
  * bytes are never interpreted).  The host entry above pads its own device copy. */
 int fgx_process_batch_device(fgx_caller* c, const void* d_records, uint64_t records_len, const void* d_rec_off,
