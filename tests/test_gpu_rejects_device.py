@@ -56,7 +56,6 @@ def check_host_entry(kw, seed):
         assert int(out.count) == want["count"] and np.array_equal(np.array(list(out.stats), dtype=np.uint64), want["stats"])
         assert int(out.n_rejects) == want["n_rejects"]
         assert (C.string_at(out.rejects, out.rejects_len) if out.rejects_len else b"") == want["rejects"]
-        assert out.ms_host_prep == 0.0 or out.ms_emit >= 0.0          # (the general path only saw the deferred groups, if any)
     finally:
         lib.fgx_destroy(h)
 
