@@ -17,7 +17,9 @@
 // general path (7 M reads/s) for the whole batch.
 #include "engine.h"
 #include "reject_core.h"
+#ifndef FGX_DEVEMU            // (tests/devemu compiles this file for the host with a serial scan)
 #include <hipcub/hipcub.hpp>
+#endif
 #include <chrono>
 
 namespace fgx {

@@ -1,0 +1,90 @@
+"""Builds and binds tests/devemu/devemu.cpp (TEST INFRASTRUCTURE): the lane-per-item kernels of reject_device.hip / canon_device.hip and
+their launch code compiled for the host (a launch = a serial loop over blocks and threads).  Never used by the product or the GPU tests."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "devemu", "devemu.cpp")
+SANITIZE = os.environ.get("HOSTEMU_SANITIZE") == "1"     # tools/sanitize_host.sh: ASan + UBSan build (the "device" buffers are malloc'd: a slab or offset overrun is reported)
+OUT = os.path.join(ROOT, "tests", "hostemu", "_build", "libdevemu_san.so" if SANITIZE else "libdevemu.so")
+CSRC = os.path.join(ROOT, "fgumi_amd", "csrc")
+
+
+def _stale():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [SRC, os.path.join(ROOT, "include", "fgumi_amd.h")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h") or f in ("reject_device.hip", "canon_device.hip")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build():
+    if _stale():
+        os.makedirs(os.path.dirname(OUT), exist_ok=True)
+        cc = ["/opt/rocm/lib/llvm/bin/clang++", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-shared-libasan", "-fno-omit-frame-pointer"] if SANITIZE else ["g++"]
+        subprocess.check_call(cc + ["-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-w",
+                               SRC, "-o", OUT, "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"])
+    return OUT
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build())
+        VP, U32, U64 = C.c_void_p, C.c_uint32, C.c_uint64
+        L.demu_simplex_rejects.argtypes = [VP, VP, U64, VP, VP, U32, VP, U32, VP, U64, VP, VP, VP]
+        L.demu_canon.argtypes = [VP, C.c_int, VP, VP, VP, VP, VP, U32, VP, VP, VP, VP, VP, VP]
+        _lib = L
+    return _lib
+
+
+def simplex_rejects(o, g):
+    """The rejects of batch `g` (GroupedReads) as the emulated device path produces them: (n_out_of_scope, bytes, count)."""
+    L = lib()
+    n, cnt, oos = C.c_uint64(0), C.c_uint64(0), C.c_uint32(0)
+    cap = int(g.blob.size) + 4 * int(g.n_rec) + 64
+    out = np.zeros(cap, dtype=np.uint8)
+    rc = L.demu_simplex_rejects(C.addressof(o), g.blob.ctypes.data, g.blob.size, g.rec_off.ctypes.data, g.rec_len.ctypes.data, g.n_rec, g.grp_first.ctypes.data, g.n_grp,
+                                out.ctypes.data, cap, C.addressof(n), C.addressof(cnt), C.addressof(oos))
+    assert rc == 0, rc
+    return oos.value, bytes(out[:n.value]) if oos.value == 0 else b"", cnt.value
+
+
+def canon(o, codec, g, deferred):
+    """Canonicalises the groups `deferred` (sorted indices) of batch `g` through the emulated kernel with api.cpp's slot layout.
+    Returns per deferred group: (status, [canonical record bytes or None], [block_size prefix or None], delta5)."""
+    L = lib()
+    nd = len(deferred)
+    d = np.array(deferred, dtype=np.uint32)
+    first = np.zeros(nd + 1, dtype=np.uint64)
+    for k, gi in enumerate(deferred):
+        first[k + 1] = first[k] + (int(g.grp_first[gi + 1]) - int(g.grp_first[gi]))
+    n_slots = int(first[nd])
+    out_off = np.zeros(max(1, n_slots), dtype=np.uint64)
+    b = 0
+    for k, gi in enumerate(deferred):
+        for i, r in enumerate(range(int(g.grp_first[gi]), int(g.grp_first[gi + 1]))):
+            out_off[int(first[k]) + i] = b + 4
+            b += 4 + int(g.rec_len[r])
+    out = np.zeros(b + 16, dtype=np.uint8)
+    out_len = np.zeros(max(1, n_slots), dtype=np.uint32)
+    status = np.full(max(1, nd), -7, dtype=np.int32)
+    delta = np.zeros(5 * max(1, nd), dtype=np.uint64)
+    rc = L.demu_canon(C.addressof(o), int(codec), g.blob.ctypes.data, g.rec_off.ctypes.data, g.rec_len.ctypes.data, g.grp_first.ctypes.data, d.ctypes.data, nd,
+                      first.ctypes.data, out.ctypes.data, out_off.ctypes.data, out_len.ctypes.data, status.ctypes.data, delta.ctypes.data)
+    assert rc == 0, rc
+    res = []
+    for k in range(nd):
+        recs, pre = [], []
+        for i in range(int(first[k]), int(first[k + 1])):
+            o0, ln = int(out_off[i]), int(out_len[i])
+            recs.append(bytes(out[o0:o0 + ln]) if ln else None)
+            pre.append(int.from_bytes(bytes(out[o0 - 4:o0]), "little"))
+        res.append((int(status[k]), recs, pre, [int(x) for x in delta[5 * k:5 * k + 5]]))
+    return res

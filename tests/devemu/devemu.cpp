@@ -1,0 +1,116 @@
+// devemu.cpp — TEST INFRASTRUCTURE ONLY.  Not part of the product, never loaded by it.
+//
+// The lane-per-item kernels of fgumi_amd/csrc/reject_device.hip and canon_device.hip, and the host code that launches them (slab sizing,
+// grid-stride loops, the scan of the groups' bytes, offsets, totals), compiled for the HOST: a kernel launch becomes a serial loop over
+// blocks and threads, device memory is host memory, the hipcub scan a serial sum.  These kernels use no wavefront intrinsics and no
+// LDS, so the emulation runs exactly the source the GPU runs, index for index — what it cannot show is the hardware executing it (that is
+// what the `-m gpu` tests are for).  There is no GPU where the CPU suite runs; this lets `-m "not gpu"` tests drive the new device
+// paths end to end against the oracle and against the per-molecule host entries.
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include "../../fgumi_amd/csrc/engine.h"
+
+// ---- the shim: what the two sources need from the HIP language and runtime ---------------------------------------------------------
+#define FGX_DEVEMU 1
+#undef __global__
+#undef __device__
+#undef __host__
+#undef __launch_bounds__
+#undef hipLaunchKernelGGL
+#define __global__
+#define __device__
+#define __host__
+#define __launch_bounds__(...)
+namespace devemu {
+struct Idx { uint32_t x = 0, y = 0, z = 0; };
+static thread_local Idx g_block, g_thread, g_grid, g_bdim;
+template <class F> void launch(dim3 grid, dim3 block, F&& body) {
+  g_grid.x = grid.x; g_bdim.x = block.x;
+  for (uint32_t b = 0; b < grid.x; b++)
+    for (uint32_t t = 0; t < block.x; t++) { g_block.x = b; g_thread.x = t; body(); }
+}
+}  // namespace devemu
+#define blockIdx devemu::g_block
+#define threadIdx devemu::g_thread
+#define gridDim devemu::g_grid
+#define blockDim devemu::g_bdim
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) devemu::launch((grid), (block), [&] { kernel(__VA_ARGS__); })
+static inline unsigned long long emu_atomic_add(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; *p = o + v; return o; }
+static inline unsigned long long emu_atomic_max(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; if (v > o) *p = v; return o; }
+#define atomicAdd emu_atomic_add
+#define atomicMax emu_atomic_max
+#define hipMemsetAsync(p, v, n, s) (memset((p), (v), (n)), hipSuccess)
+#define hipMemcpyAsync(d, s, n, k, st) (memcpy((d), (s), (n)), hipSuccess)
+#define hipStreamSynchronize(s) (hipSuccess)
+#define hipGetLastError() (hipSuccess)
+namespace hipcub {
+struct DeviceScan {
+  template <class In, class Out> static hipError_t ExclusiveSum(void* tmp, size_t& bytes, In in, Out out, int n, hipStream_t) {
+    if (!tmp) { bytes = 16; return hipSuccess; }
+    unsigned long long run = 0;
+    for (int i = 0; i < n; i++) { const unsigned long long v = in[i]; out[i] = run; run += v; }
+    return hipSuccess;
+  }
+};
+}  // namespace hipcub
+
+namespace fgx {
+void hip_check(hipError_t e, const char* what) { if (e != hipSuccess) throw std::runtime_error(what); }
+void DevBuf::reserve(size_t n) { if (n > cap) { free(p); p = malloc(n); if (!p) throw std::bad_alloc(); cap = n; } }
+void DevBuf::free_() { free(p); p = nullptr; cap = 0; }
+void PinnedBuf::reserve(size_t) {}
+void PinnedBuf::free_() {}
+}  // namespace fgx
+double fgx_caller::run_columns(fgx::ColumnBatch&, fgx::ColParams) { return 0.0; }
+
+#include "../../fgumi_amd/csrc/reject_device.hip"
+#include "../../fgumi_amd/csrc/canon_device.hip"
+
+using namespace fgx;
+
+extern "C" {
+
+// simplex_rejects_device over a batch held in host memory.  Returns 0; *n_oos > 0 = nothing written.
+int demu_simplex_rejects(const fgx_options* o, const uint8_t* blob, uint64_t blob_len, const uint64_t* rec_off, const uint32_t* rec_len, uint32_t n_rec,
+                         const uint32_t* grp_first, uint32_t n_grp, uint8_t* out, uint64_t cap, uint64_t* out_len, uint64_t* count, uint32_t* n_oos) {
+  rej::Params P;   // (as api.cpp's reject_params)
+  P.min_bq = o->min_input_base_quality; P.overlapping = o->overlapping_consensus; P.trim = o->trim; P.has_max_reads = o->max_reads >= 0;
+  P.min_reads = o->min_reads; P.max_reads = o->max_reads < 0 ? 0u : o->max_reads > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)o->max_reads;
+  fgx_caller* c = new fgx_caller();
+  int rc = 0;
+  try {
+    RejectResult r;
+    simplex_rejects_device(c, P, blob, blob_len, rec_off, rec_len, n_rec, grp_first, n_grp, &r);
+    *out_len = r.bytes; *count = r.count; *n_oos = r.n_out_of_scope;
+    if (r.n_out_of_scope == 0 && r.bytes) { if (r.bytes > cap) rc = 2; else memcpy(out, r.d_out, r.bytes); }
+  } catch (const std::exception&) { rc = 3; }
+  reject_release(c);
+  delete c;
+  return rc;
+}
+
+// launch_canon_molecules over the deferred molecules def[0..nd) of a batch held in host memory; the slot layout (first, out_off) is the
+// caller's, as in api.cpp's canon_second_pass.  delta5 per molecule as fgx_canon_duplex_host reports it.
+int demu_canon(const fgx_options* o, int codec, const uint8_t* blob, const uint64_t* rec_off, const uint32_t* rec_len, const uint32_t* grp_first, const uint32_t* def,
+               uint32_t nd, const uint64_t* first, uint8_t* out, const uint64_t* out_off, uint32_t* out_len, int* status, uint64_t* delta5) {
+  canon::Params P;   // (as api.cpp's canon_params / canon_codec_params)
+  P.min_bq = o->min_input_base_quality; P.overlapping = o->overlapping_consensus; P.trim = o->trim; P._pad = 0;
+  P.min_total = o->duplex_min_reads[0]; P.min_xy = o->duplex_min_reads[1]; P.min_yx = o->duplex_min_reads[2];
+  P.max_reads_per_strand = o->duplex_max_reads_per_strand;
+  P.cell_tag[0] = o->cell_tag[0]; P.cell_tag[1] = o->cell_tag[1]; P._pad2[0] = P._pad2[1] = 0;
+  canon::CodecParams PC;
+  PC.min_reads_per_strand = o->codec_min_reads_per_strand; PC.min_duplex_length = o->codec_min_duplex_length; PC.max_reads_per_strand = o->codec_max_reads_per_strand;
+  DevBuf slabs;
+  std::vector<canon::Delta> delta(nd ? nd : 1);
+  memset(delta.data(), 0, delta.size() * sizeof(canon::Delta));
+  int rc = 0;
+  try {
+    launch_canon_molecules(nullptr, codec != 0, P, PC, blob, rec_off, rec_len, grp_first, def, nd, first, out, out_off, out_len, status, delta.data(), slabs);
+  } catch (const std::exception&) { rc = 3; }
+  for (uint32_t k = 0; k < nd; k++) { delta5[5 * k] = delta[k].minority; for (int i = 0; i < 4; i++) delta5[5 * k + 1 + i] = delta[k].ov[i]; }
+  slabs.free_();
+  return rc;
+}
+
+}  // extern "C"
