@@ -24,9 +24,11 @@ def _stale():
 def build():
     if _stale():
         os.makedirs(os.path.dirname(OUT), exist_ok=True)
+        tmp = f"{OUT}.{os.getpid()}.tmp"          # (xdist workers may build at the same time: each writes its own file, the rename is atomic)
         cc = ["/opt/rocm/lib/llvm/bin/clang++", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-shared-libasan", "-fno-omit-frame-pointer"] if SANITIZE else ["g++"]
         subprocess.check_call(cc + ["-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-w",
-                               SRC, "-o", OUT, "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"])
+                               SRC, "-o", tmp, "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"])
+        os.replace(tmp, OUT)
     return OUT
 
 
