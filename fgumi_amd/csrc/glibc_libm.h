@@ -367,7 +367,7 @@ FGX_HD double g_expm1(double x) {
   if (k <= -2 || k > 56) {
     y = one - (e - x);
     uint64_t yb = fgx_asuint64(y);
-    yb += (uint64_t)(uint32_t)(k << 20) << 32;
+    yb += (uint64_t)((uint32_t)k << 20) << 32;
     y = fgx_asdouble(yb);
     return y - one;
   }
@@ -375,14 +375,14 @@ FGX_HD double g_expm1(double x) {
     t = fgx_asdouble((uint64_t)(uint32_t)(0x3ff00000 - (0x200000 >> k)) << 32);
     y = t - (e - x);
     uint64_t yb = fgx_asuint64(y);
-    yb += (uint64_t)(uint32_t)(k << 20) << 32;
+    yb += (uint64_t)((uint32_t)k << 20) << 32;
     y = fgx_asdouble(yb);
   } else {
-    t = fgx_asdouble((uint64_t)(uint32_t)((0x3ff - k) << 20) << 32);
+    t = fgx_asdouble((uint64_t)((uint32_t)(0x3ff - k) << 20) << 32);
     y = x - (e + t);
     y += one;
     uint64_t yb = fgx_asuint64(y);
-    yb += (uint64_t)(uint32_t)(k << 20) << 32;
+    yb += (uint64_t)((uint32_t)k << 20) << 32;
     y = fgx_asdouble(yb);
   }
   return y;

@@ -1,0 +1,154 @@
+// apiemu.cpp — TEST INFRASTRUCTURE ONLY.  Not part of the product, never loaded by it.
+//
+// The product's WHOLE host side — api.cpp (fgx_create, fgx_process_batch with its hybrid splice, the canonical second pass, the
+// `--rejects` side path, fgx_process_batch_device), the general path's orchestration, the BGZF / pipeline host code — built unmodified
+// and linked, instead of against libamdhip64 and the device kernels, against
+//   * a fake HIP runtime: device memory is host memory, copies are memcpy, streams and events do nothing;
+//   * the lane-per-item kernels compiled for the host (reject_device.hip, canon_device.hip: tests/devemu's shim, a launch = a serial loop);
+//   * host stand-ins for the column and annotation kernels' launchers, built from the functions those kernels call (column_emu.h,
+//     methylation_core.h);
+//   * a stand-in for the device-resident pipeline (`FastPath::run`): it DEFERS groups by a rule (a read that is not one aligned block,
+//     like the real duplex / CODEC kernels; APIEMU_DEFER=mod3 defers every third group as well, =none nothing) and decides the others
+//     through the product's general path on a helper caller, handing back records, per-group offsets, counters and the deferred list
+//     in the layout fastpath.hip produces.
+// `FGX_LIB=libapiemu.so` then lets the `-m "not gpu"` suite run the very bodies of the GPU tests of the opt-in paths (canonical second
+// pass on the host and on the "device", `--rejects` side kernels through both entries) against the oracle: every line of host plumbing
+// around the kernels executes on the CPU.  What it cannot show is the real kernels producing those inputs and outputs on hardware.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../fgumi_amd/csrc/engine.h"
+#include "../../fgumi_amd/csrc/fastpath.h"
+#include "../../fgumi_amd/csrc/methylation_core.h"
+#include "../hostemu/column_emu.h"
+
+// ---- fake HIP runtime ---------------------------------------------------------------------------------------------------------------
+extern "C" {
+hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+hipError_t hipHostMalloc(void** p, size_t n, unsigned int) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) memmove(d, s, n); return hipSuccess; }
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { if (n) memmove(d, s, n); return hipSuccess; }
+hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { if (n) memset(d, v, n); return hipSuccess; }
+hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+const char* hipGetErrorString(hipError_t) { return "apiemu"; }
+hipError_t hipGetLastError(void) { return hipSuccess; }
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned int) { *s = nullptr; return hipSuccess; }
+hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
+hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
+}
+
+namespace fgx {
+
+// ---- the general path's kernels: their launchers walk the tiles on the host -----------------------------------------------------
+void launch_column_jobs(hipStream_t, const uint8_t* d_stage, const ReadDesc* d_reads, const ColJob* d_jobs, const Tile* d_tiles, uint32_t n_tiles,
+                        const DeviceTables* d_tables, ColParams prm, uint8_t* d_ob, uint8_t* d_oq, uint16_t* d_od, uint16_t* d_oe) {
+  for (uint32_t t = 0; t < n_tiles; t++) {
+    const ColJob& j = d_jobs[d_tiles[t].job];
+    for (uint32_t p = d_tiles[t].p0; p < d_tiles[t].p0 + 64 && p < j.cons_len; p++) emu::column_position(d_stage, d_reads, *d_tables, prm, j, p, d_ob, d_oq, d_od, d_oe);
+  }
+}
+void launch_meth_annotate(hipStream_t, uint8_t* d_stage, const ReadDesc* d_reads, const MethJob* d_jobs, const MethRun* d_runs, const MethTile* d_tiles, uint32_t n_tiles,
+                          const uint8_t* d_genome, uint8_t* d_flag, uint32_t* d_unconverted, uint32_t* d_converted) {
+  for (uint32_t t = 0; t < n_tiles; t++) {
+    const MethJob& j = d_jobs[d_tiles[t].job];
+    for (uint32_t p = d_tiles[t].p0; p < d_tiles[t].p0 + 64 && p < j.n_pos; p++)
+      meth_annotate_position(d_stage, d_reads + j.rd0, j.n_reads, d_runs + j.run0, j.n_runs, d_genome + j.contig_off, j.contig_len, j.top != 0, p, &d_flag[j.out_off + p],
+                             &d_unconverted[j.out_off + p], &d_converted[j.out_off + p]);
+  }
+}
+
+int simplex_process_general(fgx_caller*, const uint8_t*, const uint64_t*, const uint32_t*, uint32_t, const uint32_t*, uint32_t, fgx_output*);
+int duplex_process_general(fgx_caller*, const uint8_t*, const uint64_t*, const uint32_t*, uint32_t, const uint32_t*, uint32_t, fgx_output*);
+int codec_process_general(fgx_caller*, const uint8_t*, const uint64_t*, const uint32_t*, uint32_t, const uint32_t*, uint32_t, fgx_output*);
+
+// ---- the device-resident pipeline's stand-in ----------------------------------------------------------------------------------------
+static std::map<FastPath*, fgx_caller*> g_helpers;
+
+static bool one_aligned_block(const bam::Rec& v) {
+  if (v.flags() & bam::F_UNMAPPED) return false;
+  return v.n_cigar() == 1 && (v.cigar_op(0) & 0xF) == 0 && (v.cigar_op(0) >> 4) == v.l_seq();
+}
+
+int FastPath::run(fgx_caller* c, const uint8_t* blob, uint64_t blob_len, const uint64_t* rec_off, const uint32_t* rec_len, uint32_t n_rec, const uint32_t* grp_first, uint32_t n_grp,
+                  FastResult* res) {
+  fgx_caller*& h = g_helpers[this];
+  if (!h) {
+    fgx_options o = c->opt;
+    o.read_name_prefix = c->prefix.c_str(); o.read_group_id = c->rg.c_str(); o.device = c->device; o.track_rejects = 0;
+    h = fgx_create(&o);
+    if (!h) throw std::runtime_error(std::string("apiemu helper caller: ") + fgx_global_error());
+  }
+  h->opt.track_rejects = 0;
+  const char* mode_s = getenv("APIEMU_DEFER");
+  const std::string mode = mode_s ? mode_s : "indel";
+  std::vector<uint32_t> def;
+  std::vector<uint64_t> k_off;
+  std::vector<uint32_t> k_len, k_grp(1, 0), kept;
+  for (uint32_t g = 0; g < n_grp; g++) {
+    const uint32_t r0 = grp_first[g], r1 = grp_first[g + 1];
+    bool d = r1 == r0 || r1 - r0 > 128;
+    if (mode != "none")
+      for (uint32_t r = r0; r < r1 && !d; r++) {
+        if (rec_len[r] < 32 || rec_off[r] + rec_len[r] > blob_len) { d = true; break; }
+        d = !one_aligned_block(bam::Rec{blob + rec_off[r], rec_len[r]});
+      }
+    if (mode == "mod3" && g % 3 == 1) d = true;
+    if (d) { def.push_back(g); continue; }
+    for (uint32_t r = r0; r < r1; r++) { k_off.push_back(rec_off[r]); k_len.push_back(rec_len[r]); }
+    k_grp.push_back((uint32_t)k_off.size());
+    kept.push_back(g);
+  }
+  fgx_output o;
+  memset(&o, 0, sizeof(o));
+  h->out_data.clear(); h->grp_out_end.clear();
+  if (!kept.empty()) {
+    auto fn = c->opt.caller_kind == FGX_CALLER_SIMPLEX ? simplex_process_general : c->opt.caller_kind == FGX_CALLER_DUPLEX ? duplex_process_general : codec_process_general;
+    const int rc = fn(h, blob, k_off.data(), k_len.data(), (uint32_t)k_off.size(), k_grp.data(), (uint32_t)kept.size(), &o);
+    if (rc != 0) throw std::runtime_error("apiemu device pipeline stand-in: " + h->err);
+  }
+  d_out.reserve(h->out_data.size() + 16);
+  if (!h->out_data.empty()) memcpy(d_out.p, h->out_data.data(), h->out_data.size());
+  d_offsets.reserve((size_t)3 * n_grp * 8 + 8);
+  uint64_t* off = d_offsets.as<uint64_t>();
+  uint64_t pos = 0;
+  size_t k = 0;
+  for (uint32_t g = 0; g < n_grp; g++) {
+    uint64_t end = pos;
+    if (k < kept.size() && kept[k] == g) { end = h->grp_out_end[k]; k++; }
+    off[3 * g] = pos; off[3 * g + 1] = end; off[3 * g + 2] = end;
+    pos = end;
+  }
+  d_deferred.reserve(def.size() * 4 + 4);
+  if (!def.empty()) memcpy(d_deferred.p, def.data(), def.size() * 4);
+  memset(res, 0, sizeof(*res));
+  res->d_out = d_out.as<uint8_t>(); res->out_len = h->out_data.size(); res->count = o.count;
+  for (int i = 0; i < FGX_STATS_LEN; i++) res->stats[i] = o.stats[i];
+  res->n_deferred = (uint32_t)def.size(); res->d_deferred = d_deferred.as<uint32_t>();
+  res->d_out_off = off; res->d_slot_size = nullptr; res->n_slots = 3 * n_grp;
+  return 0;
+}
+
+void FastPath::release() {
+  auto it = g_helpers.find(this);
+  if (it != g_helpers.end()) { fgx_destroy(it->second); g_helpers.erase(it); }
+  for (DevBuf* b : {&d_out, &d_offsets, &d_deferred}) b->free_();
+}
+
+}  // namespace fgx
+
+// ---- the lane-per-item kernels, compiled for the host (tests/devemu's shim; this file's runtime definitions stay as they are) -------
+#define DEVEMU_EMBEDDED 1
+#include "../devemu/devemu.cpp"

@@ -55,6 +55,7 @@ struct DeviceScan {
 };
 }  // namespace hipcub
 
+#ifndef DEVEMU_EMBEDDED      // (tests/apiemu includes this file into a build that has api.cpp's own definitions on a fake HIP runtime)
 namespace fgx {
 void hip_check(hipError_t e, const char* what) { if (e != hipSuccess) throw std::runtime_error(what); }
 void DevBuf::reserve(size_t n) { if (n > cap) { free(p); p = malloc(n); if (!p) throw std::bad_alloc(); cap = n; } }
@@ -63,6 +64,7 @@ void PinnedBuf::reserve(size_t) {}
 void PinnedBuf::free_() {}
 }  // namespace fgx
 double fgx_caller::run_columns(fgx::ColumnBatch&, fgx::ColParams) { return 0.0; }
+#endif
 
 #include "../../fgumi_amd/csrc/reject_device.hip"
 #include "../../fgumi_amd/csrc/canon_device.hip"

@@ -1,0 +1,140 @@
+"""The host plumbing of the opt-in device paths, executed on the CPU: tests/apiemu links the product's whole host side (api.cpp and the
+general path, unmodified) against a fake HIP runtime, the host-compiled lane-per-item kernels and a stand-in for the device-resident
+pipeline, and `FGX_LIB` makes the ordinary ctypes binding load that library — so the BODIES of the GPU tests of the canonical second
+pass (host- and "device"-canonicalised, duplex and CODEC) and of the `--rejects` side kernels (host entry and device entry) run here,
+in child interpreters, against the oracle.  APIEMU_DEFER=mod3 makes the stand-in defer every third group as well, which puts first-pass,
+second-pass and general-path records next to each other in every order the splice has to handle."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import apiemu
+import fgx_opts
+import orc
+from isolated import run_isolated
+
+
+def env(**flags):
+    e = {"FGX_LIB": apiemu.build(), "FGX_ALLOW_LIBM_MISMATCH": "1"}
+    e.update({k: str(v) for k, v in flags.items()})
+    return e
+
+
+def check_plain_hybrid(kind, defer):
+    """No opt-in flag: the splice of device-pipeline records with general-path records, as it has always run on the GPU."""
+    import random
+    import test_canon_codec as tcc
+    import test_canon_core as tc
+    import test_gpu_duplex_canon as tg
+    from fgumi_amd import GroupedReads, simulate_grouped_reads
+    rng = random.Random(5)
+    if kind == 2:
+        sim = simulate_grouped_reads(60, family_size=3, read_length=150, insert_mean=200, insert_sd=30, codec=1)
+        groups = [sim.records(g // 2) if g % 2 == 0 else tcc.codec_molecule(rng, 100 + g) for g in range(120)]
+        o = fgx_opts.defaults(kind=2, overlapping_consensus=0)
+    else:
+        sim = simulate_grouped_reads(60, family_size=4, duplex=int(kind == 1))
+        groups = []
+        for g in range(120):
+            m = tc.duplex_indel_molecule(rng, 100 + g) if g % 2 else None
+            groups.append(m if m else sim.records(g // 2))
+        o = fgx_opts.defaults(kind=kind, min_reads=1)
+    gr = GroupedReads.from_groups(groups)
+    want = orc.process(o, gr.blob, gr.rec_off, gr.rec_len, gr.grp_first, batch_groups={0: 50, 1: 100, 2: 1000}[kind])
+    got = tg.product(o, gr)
+    assert got["data"] == want["data"] and got["count"] == want["count"] and np.array_equal(got["stats"], want["stats"]), (got["stats"].tolist(), want["stats"].tolist())
+    if defer != "none":
+        assert got["deferred"] > 20
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+@pytest.mark.parametrize("defer", ["indel", "mod3", "none"])
+def test_plain_hybrid_splice(kind, defer):
+    if defer == "none" and kind != 0:
+        pytest.skip("the stand-in decides through the general path, which takes everything: nothing to splice")
+    run_isolated("test_apiemu", "check_plain_hybrid", kind, defer, env=env(APIEMU_DEFER=defer))
+
+
+DUPLEX = [(dict(overlapping_consensus=1), (1, 1, 0)), (dict(overlapping_consensus=0, min_input_base_quality=20), (2, 1, 1)),
+          (dict(overlapping_consensus=1, cell_tag=b"\0\0", produce_per_base_tags=0), (1, 1, 1))]
+
+
+@pytest.mark.parametrize("on_device", [0, 1])
+@pytest.mark.parametrize("defer", ["indel", "mod3"])
+@pytest.mark.parametrize("kw,mr", DUPLEX)
+def test_duplex_canonical_second_pass(kw, mr, defer, on_device):
+    run_isolated("test_gpu_duplex_canon", "test_indel_molecules_take_the_canonical_second_pass", None, kw, mr,
+                 env=env(FGX_DUPLEX_CANON=1, FGX_CANON_DEVICE=on_device, APIEMU_DEFER=defer))
+
+
+@pytest.mark.parametrize("on_device", [0, 1])
+@pytest.mark.parametrize("defer", ["indel", "mod3"])
+@pytest.mark.parametrize("kw", [dict(), dict(min_input_base_quality=20, produce_per_base_tags=1), dict(codec_min_reads_per_strand=2, cell_tag=b"\0\0"),
+                                dict(codec_outer_bases_length=5, codec_has_outer_bases_qual=1, codec_outer_bases_qual=7, codec_min_duplex_length=10)])
+def test_codec_canonical_second_pass(kw, defer, on_device):
+    run_isolated("test_gpu_codec_canon", "check_codec_indel_molecules", kw, env=env(FGX_CODEC_CANON=1, FGX_CANON_DEVICE=on_device, APIEMU_DEFER=defer))
+
+
+def test_canonical_pass_off_by_default():
+    run_isolated("test_gpu_duplex_canon", "test_second_pass_is_off_by_default", env=env())
+    run_isolated("test_gpu_codec_canon", "check_off_by_default", env=env())
+
+
+def check_device_entry_emu(kw, seed):
+    """tests/test_gpu_rejects_device.check_device_entry with host arrays standing in for the tensors in HBM."""
+    import test_gpu_rejects_device as tgr
+    from fgumi_amd._lib import Options, Output, lib
+    g = tgr.batch(seed)
+    o = fgx_opts.defaults(kind=0, track_rejects=1, **kw)
+    want = orc.process(o, g.blob, g.rec_off, g.rec_len, g.grp_first, batch_groups=50)
+    po = Options.from_buffer_copy(bytes(o))
+    h = lib.fgx_create(C.byref(po))
+    assert h, lib.fgx_global_error().decode()
+    try:
+        blob = np.concatenate([g.blob, np.zeros(16, dtype=np.uint8)])
+        out, nd, dp = Output(), C.c_uint32(), C.c_void_p()
+        rc = lib.fgx_process_batch_device(h, blob.ctypes.data, g.blob.size, g.rec_off.ctypes.data, g.rec_len.ctypes.data, g.n_rec, g.grp_first.ctypes.data, g.n_grp,
+                                          C.byref(out), C.byref(nd), C.byref(dp))
+        assert rc == 0, lib.fgx_last_error(h).decode()
+        assert int(out.n_rejects) == want["n_rejects"] > 0
+        assert (C.string_at(out.rejects, out.rejects_len) if out.rejects_len else b"") == want["rejects"]
+        if nd.value == 0:
+            assert (C.string_at(out.data, out.data_len) if out.data_len else b"") == want["data"] and int(out.count) == want["count"]
+    finally:
+        lib.fgx_destroy(h)
+
+
+def check_device_entry_refuses_without_the_flag():
+    import test_gpu_rejects_device as tgr
+    from fgumi_amd._lib import Options, Output, lib
+    g = tgr.batch(3)
+    o = fgx_opts.defaults(kind=0, track_rejects=1, min_reads=1)
+    po = Options.from_buffer_copy(bytes(o))
+    h = lib.fgx_create(C.byref(po))
+    try:
+        out, nd, dp = Output(), C.c_uint32(), C.c_void_p()
+        rc = lib.fgx_process_batch_device(h, g.blob.ctypes.data, g.blob.size, g.rec_off.ctypes.data, g.rec_len.ctypes.data, g.n_rec, g.grp_first.ctypes.data, g.n_grp,
+                                          C.byref(out), C.byref(nd), C.byref(dp))
+        assert rc != 0 and b"--rejects" in lib.fgx_last_error(h)
+    finally:
+        lib.fgx_destroy(h)
+
+
+@pytest.mark.parametrize("defer", ["indel", "mod3", "none"])
+@pytest.mark.parametrize("kw", [dict(min_reads=1), dict(min_reads=2, max_reads=3), dict(min_reads=3, overlapping_consensus=0, min_input_base_quality=30),
+                                dict(min_reads=2, trim=1, min_input_base_quality=25)])
+def test_rejects_side_kernels_host_entry(kw, defer):
+    run_isolated("test_gpu_rejects_device", "check_host_entry", kw, 11, env=env(FGX_REJECTS_DEVICE=1, APIEMU_DEFER=defer))
+
+
+@pytest.mark.parametrize("kw", [dict(min_reads=1), dict(min_reads=2, max_reads=3)])
+def test_rejects_side_kernels_device_entry(kw):
+    run_isolated("test_apiemu", "check_device_entry_emu", kw, 12, env=env(FGX_REJECTS_DEVICE=1, APIEMU_DEFER="none"))
+    run_isolated("test_apiemu", "check_device_entry_emu", kw, 12, env=env(FGX_REJECTS_DEVICE=1, APIEMU_DEFER="mod3"))
+
+
+def test_rejects_without_the_flag_take_the_general_path():
+    run_isolated("test_gpu_rejects_device", "check_host_entry", dict(min_reads=2), 11, env=env())          # (whole batch on the general path: same answer)
+    run_isolated("test_apiemu", "check_device_entry_refuses_without_the_flag", env=env())

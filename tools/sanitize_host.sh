@@ -30,6 +30,6 @@ RT="$($CL -print-file-name=libclang_rt.asan-x86_64.so)"
 export FGX_LIB="$OUT/libfgumi_host_san.so" HOSTEMU_SANITIZE=1
 export ASAN_OPTIONS="detect_leaks=0:abort_on_error=1" UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1"
 cd "$ROOT"
-TESTS="tests/test_canon_core.py tests/test_canon_codec.py tests/test_reject_core.py tests/test_devemu.py tests/test_inflate_core.py tests/test_deflate_core.py tests/test_methylation_core.py tests/test_bgzf.py tests/test_general_path_hostemu.py tests/test_general_path_fuzz.py"
+TESTS="tests/test_canon_core.py tests/test_canon_codec.py tests/test_reject_core.py tests/test_devemu.py tests/test_apiemu.py tests/test_inflate_core.py tests/test_deflate_core.py tests/test_methylation_core.py tests/test_bgzf.py tests/test_general_path_hostemu.py tests/test_general_path_fuzz.py"
 LD_PRELOAD="$RT" python -m pytest $TESTS -x -q -m "not gpu" -p no:cacheprovider "$@"
-rm -f "$OUT/libfgumi_host_san.so" "$OUT/libhostemu_san.so" "$OUT/libdevemu_san.so"     # (large; they would travel to the GPU box with the snapshot)
+rm -f "$OUT/libfgumi_host_san.so" "$OUT/libhostemu_san.so" "$OUT/libdevemu_san.so" "$OUT/libapiemu_san.so"     # (large; they would travel to the GPU box with the snapshot)
