@@ -21,6 +21,13 @@ uint32_t launch_canon_molecules(hipStream_t s, bool codec, const canon::Params& 
                                 const uint64_t* d_rec_off, const uint32_t* d_rec_len, const uint32_t* d_grp_first, const uint32_t* d_def, uint32_t nd,
                                 const uint64_t* d_first, uint8_t* d_out, const uint64_t* d_out_off, uint32_t* d_out_len, int* d_status,
                                 canon::Delta* d_delta, DevBuf& slabs);
+void canon_layout_device(hipStream_t s, const uint32_t* d_rec_len, const uint32_t* d_grp_first, const uint32_t* d_def, uint32_t nd, unsigned long long* work,
+                         unsigned long long* d_first, DevBuf& out_off, DevBuf& scan_tmp, uint64_t* n_slots, uint64_t* bytes);
+void canon_compact_device(hipStream_t s, const int* d_status, const unsigned long long* d_first, const uint64_t* d_out_off, const uint32_t* d_out_len, uint32_t nd,
+                          unsigned long long* work, DevBuf& c_off, DevBuf& c_len, DevBuf& c_grp, DevBuf& c_def, DevBuf& scan_tmp, uint32_t* n_cg, uint32_t* n_cr);
+void resident_merge_device(hipStream_t s, uint32_t n_grp, const uint64_t* off1, const uint8_t* out1, uint64_t len1, const uint32_t* d_def, uint32_t nd, const uint32_t* c_def,
+                           uint32_t n_cg, const uint64_t* off2, const uint8_t* out2, uint64_t len2, const uint32_t* again_list, uint32_t n_again, DevBuf& aux, DevBuf& scan_tmp,
+                           uint8_t* d_used, DevBuf& final_out, uint64_t* final_len);
 }
 
 using namespace fgx;
@@ -241,7 +248,8 @@ void fgx_destroy(fgx_caller* c) {
   (void)hipSetDevice(c->device);
   for (DevBuf* b : {&c->d_tables, &c->d_umi_tables, &c->d_stage, &c->d_reads, &c->d_jobs, &c->d_tiles, &c->d_ob, &c->d_oq, &c->d_od,
                     &c->d_oe, &c->d_scratch_a, &c->d_scratch_b, &c->d_in_blob, &c->d_in_off, &c->d_in_len, &c->d_in_grp, &c->d_mjobs, &c->d_mruns,
-                    &c->d_mtiles, &c->d_mflag, &c->d_mu, &c->d_mt, &c->d_canon_blob, &c->d_canon_off, &c->d_canon_len, &c->d_canon_grp, &c->d_canon_aux, &c->d_canon_slabs})
+                    &c->d_mtiles, &c->d_mflag, &c->d_mu, &c->d_mt, &c->d_canon_blob, &c->d_canon_off, &c->d_canon_len, &c->d_canon_grp, &c->d_canon_aux, &c->d_canon_slabs,
+                    &c->d_res_out1, &c->d_res_off1, &c->d_res_final, &c->d_res_aux, &c->d_res_aux2, &c->d_res_deferred, &c->d_res_scan, &c->d_res_cdef, &c->d_res_outoff})
     b->free_();
   c->genome.reset();
   reject_release(c);
@@ -769,6 +777,89 @@ int fgx_process_batch(fgx_caller* c, const uint8_t* records, uint64_t records_le
   }
 }
 
+// FGX_CANON_RESIDENT=1 (with FGX_DUPLEX_CANON / FGX_CODEC_CANON): the canonical second pass INSIDE the device-resident entry.  The molecules
+// the first pass deferred are canonicalised by the kernel of canon_device.hip where they lie, decided by the device pipeline in a second
+// pass, and the two passes' records are merged in group order on the device; what the canonical form cannot express, or the second pass
+// defers again, stays in the deferred list the caller re-submits.  The host sees the deferred indices, per-molecule status and counted
+// deltas — never a record.  Off by default: not yet run on hardware (tests/test_apiemu.py runs it on the CPU).
+static bool canon_resident_enabled(int kind) {
+  const char* e = getenv("FGX_CANON_RESIDENT");
+  if (!(e && e[0] == '1')) return false;
+  return (kind == FGX_CALLER_DUPLEX && duplex_canon_enabled()) || (kind == FGX_CALLER_CODEC && codec_canon_enabled());
+}
+
+struct ResidentOut { const uint8_t* d_out; uint64_t out_len, count, stats[FGX_STATS_LEN]; uint32_t n_deferred; const uint32_t* d_deferred; uint64_t n_canon; double ms_kernels; };
+
+static bool canon_resident_pass(fgx_caller* c, const uint8_t* d_blob, const uint64_t* d_rec_off, const uint32_t* d_rec_len, const uint32_t* d_grp_first, uint32_t n_grp,
+                                const FastResult& fr, ResidentOut* ro) {
+  hipStream_t s = c->stream;
+  const uint32_t nd = fr.n_deferred;
+  const bool codec = c->opt.caller_kind == FGX_CALLER_CODEC;
+  std::vector<uint32_t> def(nd);
+  hip_check(hipMemcpy(def.data(), fr.d_deferred, (size_t)nd * 4, hipMemcpyDeviceToHost), "D2H deferred");
+  std::sort(def.begin(), def.end());
+  // the first pass's records and slot offsets are stashed: the second run reuses the pipeline's buffers
+  const uint64_t len1 = fr.out_len, count1 = fr.count;
+  uint64_t stats1[FGX_STATS_LEN];
+  for (int i = 0; i < FGX_STATS_LEN; i++) stats1[i] = fr.stats[i];
+  c->d_res_out1.reserve(len1 + 16);
+  c->d_res_off1.reserve((size_t)3 * n_grp * 8 + 8);
+  if (len1) hip_check(hipMemcpyAsync(c->d_res_out1.p, fr.d_out, len1, hipMemcpyDeviceToDevice, s), "stash first-pass records");
+  hip_check(hipMemcpyAsync(c->d_res_off1.p, fr.d_out_off, (size_t)3 * n_grp * 8, hipMemcpyDeviceToDevice, s), "stash first-pass offsets");
+  // aux: work 4(nd+1) u64 | first (nd+1) u64 | delta nd x 40 B | def nd u32 | status nd i32 | used nd u8
+  const size_t o_work = 0, o_first = o_work + 4ull * (nd + 1) * 8, o_delta = o_first + (nd + 1) * 8ull, o_def = o_delta + (size_t)nd * sizeof(canon::Delta),
+               o_status = o_def + (size_t)nd * 4, o_used = o_status + (size_t)nd * 4, total = o_used + nd;
+  c->d_res_aux.reserve(total + 64);
+  uint8_t* a = c->d_res_aux.as<uint8_t>();
+  unsigned long long* work = (unsigned long long*)(a + o_work);
+  unsigned long long* d_first = (unsigned long long*)(a + o_first);
+  canon::Delta* d_delta = (canon::Delta*)(a + o_delta);
+  uint32_t* d_def = (uint32_t*)(a + o_def);
+  int* d_status = (int*)(a + o_status);
+  uint8_t* d_used = a + o_used;
+  hip_check(hipMemcpyAsync(d_def, def.data(), (size_t)nd * 4, hipMemcpyHostToDevice, s), "H2D deferred groups");
+  hip_check(hipMemsetAsync(d_delta, 0, (size_t)nd * sizeof(canon::Delta), s), "memset delta");
+  uint64_t n_slots = 0, bytes = 0;
+  canon_layout_device(s, d_rec_len, d_grp_first, d_def, nd, work, d_first, c->d_res_outoff, c->d_res_scan, &n_slots, &bytes);
+  c->d_canon_blob.reserve(bytes + 16);
+  c->d_canon_aux.reserve(n_slots * 4 + 16);                     // (here: the canonical lengths alone)
+  uint32_t* d_out_len = c->d_canon_aux.as<uint32_t>();
+  hip_check(hipMemsetAsync(c->d_canon_blob.p, 0, bytes + 16, s), "memset canonical blob");
+  hip_check(hipMemsetAsync(d_out_len, 0, n_slots * 4 + 4, s), "memset canonical lengths");
+  launch_canon_molecules(s, codec, canon_params(&c->opt), canon_codec_params(&c->opt), d_blob, d_rec_off, d_rec_len, d_grp_first, d_def, nd, (const uint64_t*)d_first,
+                         c->d_canon_blob.as<uint8_t>(), c->d_res_outoff.as<uint64_t>(), d_out_len, d_status, d_delta, c->d_canon_slabs);
+  uint32_t n_cg = 0, n_cr = 0;
+  canon_compact_device(s, d_status, d_first, c->d_res_outoff.as<uint64_t>(), d_out_len, nd, work, c->d_canon_off, c->d_canon_len, c->d_canon_grp, c->d_res_cdef, c->d_res_scan,
+                       &n_cg, &n_cr);
+  hip_check(hipStreamSynchronize(s), "canonical lists");
+  if (n_cg == 0) return false;                                   // nothing in scope: the first pass's buffers are untouched
+  FastResult fr2;
+  c->fast->fp.run(c, c->d_canon_blob.as<uint8_t>(), bytes, c->d_canon_off.as<uint64_t>(), c->d_canon_len.as<uint32_t>(), n_cr, c->d_canon_grp.as<uint32_t>(), n_cg, &fr2);
+  uint64_t final_len = 0;
+  resident_merge_device(s, n_grp, c->d_res_off1.as<uint64_t>(), c->d_res_out1.as<uint8_t>(), len1, d_def, nd, c->d_res_cdef.as<uint32_t>(), n_cg, fr2.d_out_off, fr2.d_out,
+                        fr2.out_len, fr2.d_deferred, fr2.n_deferred, c->d_res_aux2, c->d_res_scan, d_used, c->d_res_final, &final_len);
+  std::vector<uint8_t> used(nd);
+  std::vector<canon::Delta> delta(nd);
+  hip_check(hipMemcpy(used.data(), d_used, nd, hipMemcpyDeviceToHost), "D2H used");
+  hip_check(hipMemcpy(delta.data(), d_delta, (size_t)nd * sizeof(canon::Delta), hipMemcpyDeviceToHost), "D2H delta");
+  for (int i = 0; i < FGX_STATS_LEN; i++) ro->stats[i] = stats1[i] + fr2.stats[i];
+  std::vector<uint32_t> left;
+  uint64_t n_canon = 0;
+  for (uint32_t k = 0; k < nd; k++) {
+    if (!used[k]) { left.push_back(def[k]); continue; }
+    n_canon++;
+    if (!codec) {
+      ro->stats[0] += delta[k].minority; ro->stats[2] += delta[k].minority; ro->stats[3 + FGX_REJ_MINORITY_ALIGNMENT] += delta[k].minority;
+      for (int i = 0; i < 4; i++) ro->stats[24 + i] += delta[k].ov[i];
+    }
+  }
+  c->d_res_deferred.reserve(left.size() * 4 + 4);
+  if (!left.empty()) hip_check(hipMemcpy(c->d_res_deferred.p, left.data(), left.size() * 4, hipMemcpyHostToDevice), "H2D remaining deferred");
+  ro->d_out = c->d_res_final.as<uint8_t>(); ro->out_len = final_len; ro->count = count1 + fr2.count;
+  ro->n_deferred = (uint32_t)left.size(); ro->d_deferred = c->d_res_deferred.as<uint32_t>(); ro->n_canon = n_canon; ro->ms_kernels = fr2.ms_kernels;
+  return true;
+}
+
 int fgx_process_batch_device(fgx_caller* c, const void* d_records, uint64_t records_len, const void* d_rec_off, const void* d_rec_len,
                              uint32_t n_rec, const void* d_grp_first, uint32_t n_grp, fgx_output* out, uint32_t* n_deferred,
                              const void** d_deferred_groups) {
@@ -795,6 +886,19 @@ int fgx_process_batch_device(fgx_caller* c, const void* d_records, uint64_t reco
     out->ms_emit = (double)fr.full_items;   /* device path: number of columns that needed call_full (diagnostic) */
     if (n_deferred) *n_deferred = fr.n_deferred;
     if (d_deferred_groups) *d_deferred_groups = fr.d_deferred;
+    c->last_deferred_groups = fr.n_deferred; c->last_canon_molecules = 0;
+    if (fr.n_deferred > 0 && canon_resident_enabled(c->opt.caller_kind)) {
+      ResidentOut ro;
+      if (canon_resident_pass(c, (const uint8_t*)d_records, (const uint64_t*)d_rec_off, (const uint32_t*)d_rec_len, (const uint32_t*)d_grp_first, n_grp, fr, &ro)) {
+        c->fast->has_last = false;                  // (the slot tables of `last` describe one pass only: fgx_filter_last_output_device has to be given the records)
+        out->data = ro.d_out; out->data_len = ro.out_len; out->count = ro.count;
+        for (int i = 0; i < FGX_STATS_LEN; i++) out->stats[i] = ro.stats[i];
+        out->ms_kernels += ro.ms_kernels;
+        if (n_deferred) *n_deferred = ro.n_deferred;
+        if (d_deferred_groups) *d_deferred_groups = ro.d_deferred;
+        c->last_canon_molecules = ro.n_canon;
+      }
+    }
     if (dev_rejects) {   // out->rejects is a DEVICE pointer here, like out->data; it covers every group, the deferred ones included
       RejectResult rr;
       simplex_rejects_device(c, reject_params(&c->opt), (const uint8_t*)d_records, records_len, (const uint64_t*)d_rec_off, (const uint32_t*)d_rec_len, n_rec, (const uint32_t*)d_grp_first, n_grp, &rr);

@@ -14,6 +14,9 @@
 // in flight against 16 threads.  A grid-stride loop bounds the slabs (at most MAX_LANES of them).
 #include "engine.h"
 #include "canon_core.h"
+#ifndef FGX_DEVEMU            // (tests/devemu compiles this file for the host with a serial scan)
+#include <hipcub/hipcub.hpp>
+#endif
 
 namespace fgx {
 
@@ -75,6 +78,168 @@ uint32_t launch_canon_molecules(hipStream_t s, bool codec, const canon::Params& 
                        d_out_len, d_status, d_delta, slabs.as<canon::Scratch>());
   hip_check(hipGetLastError(), "k_canon launch");
   return lanes;
+}
+
+// =====================================================================================================================================
+// The canonical second pass INSIDE the device-resident entry (fgx_process_batch_device with FGX_DUPLEX_CANON / FGX_CODEC_CANON): the
+// records never leave HBM and the host never sees a record length, so the slot layout, the list of canonical records and the merge of the
+// two passes' outputs are made here, by small lane-per-item kernels around hipcub scans.  api.cpp (canon_resident_pass) orders the calls.
+// =====================================================================================================================================
+namespace {
+
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+
+// slots and bytes (4-byte block_size + record) each deferred group needs in the canonical blob; element nd of both arrays stays 0
+__global__ void k_canon_count(const uint32_t* __restrict__ rec_len, const uint32_t* __restrict__ grp_first, const uint32_t* __restrict__ def, uint32_t nd,
+                              unsigned long long* cnt, unsigned long long* bytes) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nd) return;
+  const uint32_t r0 = grp_first[def[k]], r1 = grp_first[def[k] + 1];
+  unsigned long long b = 0;
+  for (uint32_t r = r0; r < r1; r++) b += 4ull + rec_len[r];
+  cnt[k] = r1 - r0; bytes[k] = b;
+}
+// out_off of every slot: the record body starts 4 bytes into its room (first = exclusive scan of cnt, base = exclusive scan of bytes)
+__global__ void k_canon_fill(const uint32_t* __restrict__ rec_len, const uint32_t* __restrict__ grp_first, const uint32_t* __restrict__ def, uint32_t nd,
+                             const unsigned long long* __restrict__ first, const unsigned long long* __restrict__ base, uint64_t* out_off) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nd) return;
+  const uint32_t r0 = grp_first[def[k]], n = grp_first[def[k] + 1] - r0;
+  unsigned long long o = base[k];
+  for (uint32_t i = 0; i < n; i++) { out_off[first[k] + i] = o + 4; o += 4ull + rec_len[r0 + i]; }
+}
+// canonical molecules: kept records and a 0 / 1 flag per deferred group (element nd of both stays 0)
+__global__ void k_canon_kept(const int* __restrict__ status, const unsigned long long* __restrict__ first, const uint32_t* __restrict__ out_len, uint32_t nd,
+                             unsigned long long* kept, unsigned long long* ok) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nd) return;
+  unsigned long long c = 0;
+  const bool good = status[k] == canon::CANON_OK;
+  if (good) for (unsigned long long i = first[k]; i < first[k + 1]; i++) c += out_len[i] != 0;
+  kept[k] = c; ok[k] = good ? 1 : 0;
+}
+// the canonical batch: rec_off / rec_len of the kept records, grp_first, and the deferred index of each canonical group
+__global__ void k_canon_lists(const int* __restrict__ status, const unsigned long long* __restrict__ first, const uint64_t* __restrict__ out_off,
+                              const uint32_t* __restrict__ out_len, uint32_t nd, const unsigned long long* __restrict__ rbase, const unsigned long long* __restrict__ gidx,
+                              uint64_t* c_off, uint32_t* c_len, uint32_t* c_grp, uint32_t* c_def) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nd) return;
+  if (k == nd - 1) c_grp[gidx[nd]] = (uint32_t)rbase[nd];                  // the closing boundary
+  if (status[k] != canon::CANON_OK) return;
+  const unsigned long long g = gidx[k];
+  c_grp[g] = (uint32_t)rbase[k]; c_def[g] = k;
+  unsigned long long w = rbase[k];
+  for (unsigned long long i = first[k]; i < first[k + 1]; i++) if (out_len[i]) { c_off[w] = out_off[i]; c_len[w] = out_len[i]; w++; }
+}
+__global__ void k_res_again(const uint32_t* __restrict__ again_list, uint32_t n_again, uint8_t* again) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_again) again[again_list[i]] = 1;
+}
+// canonical group ci was decided by the second pass: its original group takes the second pass's records
+__global__ void k_res_map(const uint32_t* __restrict__ def, const uint32_t* __restrict__ c_def, const uint8_t* __restrict__ again, uint32_t n_cg, uint32_t* g2ci, uint8_t* used) {
+  const uint32_t ci = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ci >= n_cg || again[ci]) return;
+  const uint32_t k = c_def[ci];
+  g2ci[def[k]] = ci; used[k] = 1;
+}
+// bytes of every group in the merged stream (a group has first-pass records or second-pass records, never both); element n_grp stays 0
+__global__ void k_res_sizes(uint32_t n_grp, const uint64_t* __restrict__ off1, uint64_t len1, const uint32_t* __restrict__ g2ci, const uint64_t* __restrict__ off2, uint64_t len2,
+                            uint32_t n_cg, unsigned long long* size) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_grp) return;
+  const uint64_t s1 = (g + 1 < n_grp ? off1[3ull * (g + 1)] : len1) - off1[3ull * g];
+  const uint32_t ci = g2ci[g];
+  const uint64_t s2 = ci != NONE ? (ci + 1 < n_cg ? off2[3ull * (ci + 1)] : len2) - off2[3ull * ci] : 0;
+  size[g] = s1 + s2;
+}
+// the merged stream: a workgroup per group copies its records (lanes take bytes 64 apart: coalesced whatever the alignment of the record)
+__global__ void __launch_bounds__(64)
+k_res_copy(uint32_t n_grp, const uint64_t* __restrict__ off1, const uint8_t* __restrict__ out1, const uint32_t* __restrict__ g2ci, const uint64_t* __restrict__ off2,
+           const uint8_t* __restrict__ out2, const unsigned long long* __restrict__ foff, uint8_t* dst) {
+  for (uint32_t g = blockIdx.x; g < n_grp; g += gridDim.x) {
+    const uint64_t len = foff[g + 1] - foff[g];
+    if (len == 0) continue;
+    const uint32_t ci = g2ci[g];
+    const uint8_t* src = ci != NONE ? out2 + off2[3ull * ci] : out1 + off1[3ull * g];
+    uint8_t* d = dst + foff[g];
+    for (uint64_t i = threadIdx.x; i < len; i += 64) d[i] = src[i];
+  }
+}
+
+inline dim3 grid_for(uint32_t n) { return dim3((n + 255) / 256); }
+void scan_u64(hipStream_t s, DevBuf& tmp, const unsigned long long* in, unsigned long long* out, uint32_t n) {
+  size_t tb = 0;
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, in, out, (int)n, s);
+  tmp.reserve(tb + 64);
+  hip_check(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, in, out, (int)n, s), "canonical pass scan");
+}
+
+}  // namespace
+
+// Slot layout for the deferred groups d_def[0..nd) (sorted): d_first[nd+1] (slot index of each group's first record), d_out_off[n_slots].
+// `work` holds 4 x (nd+1) u64 of scratch.  Returns the totals.
+void canon_layout_device(hipStream_t s, const uint32_t* d_rec_len, const uint32_t* d_grp_first, const uint32_t* d_def, uint32_t nd, unsigned long long* work,
+                         unsigned long long* d_first, DevBuf& out_off, DevBuf& scan_tmp, uint64_t* n_slots, uint64_t* bytes) {
+  unsigned long long* cnt = work; unsigned long long* byt = work + (nd + 1); unsigned long long* base = work + 2ull * (nd + 1);
+  hip_check(hipMemsetAsync(work, 0, 4ull * (nd + 1) * 8, s), "memset layout");
+  hipLaunchKernelGGL(k_canon_count, grid_for(nd), dim3(256), 0, s, d_rec_len, d_grp_first, d_def, nd, cnt, byt);
+  scan_u64(s, scan_tmp, cnt, d_first, nd + 1);
+  scan_u64(s, scan_tmp, byt, base, nd + 1);
+  unsigned long long tot[2] = {0, 0};
+  hip_check(hipMemcpyAsync(&tot[0], d_first + nd, 8, hipMemcpyDeviceToHost, s), "D2H slots");
+  hip_check(hipMemcpyAsync(&tot[1], base + nd, 8, hipMemcpyDeviceToHost, s), "D2H bytes");
+  hip_check(hipStreamSynchronize(s), "canonical layout");
+  *n_slots = tot[0]; *bytes = tot[1];
+  out_off.reserve((size_t)tot[0] * 8 + 8);
+  hipLaunchKernelGGL(k_canon_fill, grid_for(nd), dim3(256), 0, s, d_rec_len, d_grp_first, d_def, nd, d_first, base, out_off.as<uint64_t>());
+  hip_check(hipGetLastError(), "k_canon_fill launch");
+}
+
+// The canonical batch out of the kernel's results: c_off / c_len / c_grp / c_def (grown as needed).  `work` as above.
+void canon_compact_device(hipStream_t s, const int* d_status, const unsigned long long* d_first, const uint64_t* d_out_off, const uint32_t* d_out_len, uint32_t nd,
+                          unsigned long long* work, DevBuf& c_off, DevBuf& c_len, DevBuf& c_grp, DevBuf& c_def, DevBuf& scan_tmp, uint32_t* n_cg, uint32_t* n_cr) {
+  unsigned long long* kept = work; unsigned long long* ok = work + (nd + 1); unsigned long long* rbase = work + 2ull * (nd + 1); unsigned long long* gidx = work + 3ull * (nd + 1);
+  hip_check(hipMemsetAsync(work, 0, 4ull * (nd + 1) * 8, s), "memset compaction");
+  hipLaunchKernelGGL(k_canon_kept, grid_for(nd), dim3(256), 0, s, d_status, d_first, d_out_len, nd, kept, ok);
+  scan_u64(s, scan_tmp, kept, rbase, nd + 1);
+  scan_u64(s, scan_tmp, ok, gidx, nd + 1);
+  unsigned long long tot[2] = {0, 0};
+  hip_check(hipMemcpyAsync(&tot[0], rbase + nd, 8, hipMemcpyDeviceToHost, s), "D2H kept records");
+  hip_check(hipMemcpyAsync(&tot[1], gidx + nd, 8, hipMemcpyDeviceToHost, s), "D2H canonical groups");
+  hip_check(hipStreamSynchronize(s), "canonical compaction");
+  *n_cr = (uint32_t)tot[0]; *n_cg = (uint32_t)tot[1];
+  c_off.reserve((size_t)tot[0] * 8 + 8); c_len.reserve((size_t)tot[0] * 4 + 4); c_grp.reserve((size_t)(tot[1] + 1) * 4); c_def.reserve((size_t)tot[1] * 4 + 4);
+  hipLaunchKernelGGL(k_canon_lists, grid_for(nd), dim3(256), 0, s, d_status, d_first, d_out_off, d_out_len, nd, rbase, gidx, c_off.as<uint64_t>(), c_len.as<uint32_t>(),
+                     c_grp.as<uint32_t>(), c_def.as<uint32_t>());
+  hip_check(hipGetLastError(), "k_canon_lists launch");
+}
+
+// Merge of the two passes' record streams in group order.  off1 / out1 / len1: the first pass (3 slots per group, a deferred group holds
+// nothing); off2 / out2 / len2: the second pass over the n_cg canonical groups; again_list: the canonical groups the second pass deferred.
+// d_used[nd] = 1 for the deferred groups the second pass decided; `aux` holds (n_grp + 1) x 2 u64 + n_grp u32 + n_cg bytes.
+void resident_merge_device(hipStream_t s, uint32_t n_grp, const uint64_t* off1, const uint8_t* out1, uint64_t len1, const uint32_t* d_def, uint32_t nd, const uint32_t* c_def,
+                           uint32_t n_cg, const uint64_t* off2, const uint8_t* out2, uint64_t len2, const uint32_t* again_list, uint32_t n_again, DevBuf& aux, DevBuf& scan_tmp,
+                           uint8_t* d_used, DevBuf& final_out, uint64_t* final_len) {
+  aux.reserve(2ull * (n_grp + 1) * 8 + (size_t)n_grp * 4 + n_cg + 64);
+  unsigned long long* size = aux.as<unsigned long long>(); unsigned long long* foff = size + (n_grp + 1);
+  uint32_t* g2ci = (uint32_t*)(foff + (n_grp + 1)); uint8_t* again = (uint8_t*)(g2ci + n_grp);
+  hip_check(hipMemsetAsync(size, 0, 2ull * (n_grp + 1) * 8, s), "memset sizes");
+  hip_check(hipMemsetAsync(g2ci, 0xFF, (size_t)n_grp * 4, s), "memset map");
+  hip_check(hipMemsetAsync(again, 0, n_cg + 1, s), "memset again");
+  hip_check(hipMemsetAsync(d_used, 0, nd, s), "memset used");
+  if (n_again) hipLaunchKernelGGL(k_res_again, grid_for(n_again), dim3(256), 0, s, again_list, n_again, again);
+  if (n_cg) hipLaunchKernelGGL(k_res_map, grid_for(n_cg), dim3(256), 0, s, d_def, c_def, again, n_cg, g2ci, d_used);
+  hipLaunchKernelGGL(k_res_sizes, grid_for(n_grp), dim3(256), 0, s, n_grp, off1, len1, g2ci, off2, len2, n_cg, size);
+  scan_u64(s, scan_tmp, size, foff, n_grp + 1);
+  unsigned long long tot = 0;
+  hip_check(hipMemcpyAsync(&tot, foff + n_grp, 8, hipMemcpyDeviceToHost, s), "D2H merged length");
+  hip_check(hipStreamSynchronize(s), "merge sizes");
+  *final_len = tot;
+  final_out.reserve((size_t)tot + 16);
+  const uint32_t blocks = n_grp < (1u << 20) ? n_grp : (1u << 20);
+  hipLaunchKernelGGL(k_res_copy, dim3(blocks), dim3(64), 0, s, n_grp, off1, out1, g2ci, off2, out2, foff, final_out.as<uint8_t>());
+  hip_check(hipGetLastError(), "k_res_copy launch");
+  hip_check(hipStreamSynchronize(s), "k_res_copy");
 }
 
 }  // namespace fgx

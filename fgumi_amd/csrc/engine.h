@@ -155,6 +155,7 @@ struct fgx_caller {
   std::vector<fgx_caller*> workers;         // helper callers (own stream and buffers) of the multi-threaded general path
   struct FastState* fast = nullptr;        // device-resident pipeline state (fastpath.hip)
   fgx::DevBuf d_in_blob, d_in_off, d_in_len, d_in_grp;   // host-input staging for fgx_process_batch
+  fgx::DevBuf d_res_out1, d_res_off1, d_res_final, d_res_aux, d_res_aux2, d_res_deferred, d_res_scan, d_res_cdef, d_res_outoff;   // canonical second pass inside the device-resident entry
   fgx::DevBuf d_canon_aux, d_canon_slabs;   // device canonicalisation (canon_device.hip): slot tables / status / lengths, per-lane lists
   fgx::DevBuf d_canon_blob, d_canon_off, d_canon_len, d_canon_grp;   // canonical duplex molecules of the second device pass (canon_core.h)
   fgx::FilterBuffers* filt = nullptr;      // fgx_filter_records[_device] state (filter.hip)

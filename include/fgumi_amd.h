@@ -160,7 +160,8 @@ int fgx_process_batch(fgx_caller* c, const uint8_t* records, uint64_t records_le
  * pipelines do not decide (reads with more than 6 CIGAR ops, unmapped reads, malformed records; for
  * duplex / CODEC also molecules with indels or a biting per-strand read cap) are reported in
  * *n_deferred / d_deferred_groups and must be re-submitted through fgx_process_batch; 0 for
- * `simulate`-shaped input.  `track_rejects` is refused here, except for the simplex caller when FGX_REJECTS_DEVICE=1 is set in the
+ * `simulate`-shaped input (with FGX_DUPLEX_CANON / FGX_CODEC_CANON and FGX_CANON_RESIDENT set, opt-in and not yet run on hardware, the
+ * entry decides the indel molecules its canonical form covers in a second device pass and only the rest is reported).  `track_rejects` is refused here, except for the simplex caller when FGX_REJECTS_DEVICE=1 is set in the
  * environment (side kernels, fgumi_amd/csrc/reject_device.hip; not yet run on hardware): `out->rejects` is then a DEVICE pointer too and
  * covers every group, the deferred ones included.  The kernels stage a family's bytes in whole 16-byte pieces: `d_records` must be
  * READABLE for 16 bytes past `records_len` (any allocation larger than the stream by 16 bytes will do; the

@@ -138,3 +138,70 @@ def test_rejects_side_kernels_device_entry(kw):
 def test_rejects_without_the_flag_take_the_general_path():
     run_isolated("test_gpu_rejects_device", "check_host_entry", dict(min_reads=2), 11, env=env())          # (whole batch on the general path: same answer)
     run_isolated("test_apiemu", "check_device_entry_refuses_without_the_flag", env=env())
+
+
+def check_resident_pass(kind, kw, mr, on_gpu=False):
+    """fgx_process_batch_device with the canonical second pass inside it (FGX_CANON_RESIDENT=1): the records it returns are those of every
+    group it did not leave in the deferred list, in group order, counters included; the deferred list shrinks to what the canonical form
+    cannot express (or the second pass deferred again)."""
+    import random
+    import test_canon_codec as tcc
+    import test_canon_core as tc
+    from fgumi_amd import GroupedReads, simulate_grouped_reads
+    from fgumi_amd._lib import Options, Output, lib
+    rng = random.Random(77)
+    if kind == 2:
+        sim = simulate_grouped_reads(60, family_size=3, read_length=150, insert_mean=200, insert_sd=30, codec=1)
+        groups = [sim.records(g // 3) if g % 3 == 0 else tcc.codec_molecule(rng, 500 + g) for g in range(180)]
+        o = fgx_opts.defaults(kind=2, overlapping_consensus=0, **kw)
+    else:
+        sim = simulate_grouped_reads(60, family_size=4, duplex=1)
+        groups = []
+        for g in range(180):
+            m = tc.duplex_indel_molecule(rng, 500 + g) if g % 3 else None
+            groups.append(m if m else sim.records(g // 3))
+        o = fgx_opts.defaults(kind=1, **kw)
+        o.duplex_min_reads[0], o.duplex_min_reads[1], o.duplex_min_reads[2] = mr
+    per_group = []
+    for x in groups:
+        g1 = GroupedReads.from_groups([x])
+        per_group.append(orc.process(o, g1.blob, g1.rec_off, g1.rec_len, g1.grp_first, batch_groups=1000))
+    g = GroupedReads.from_groups(groups)
+    po = Options.from_buffer_copy(bytes(o))
+    h = lib.fgx_create(C.byref(po))
+    assert h, lib.fgx_global_error().decode()
+    try:
+        out, nd, dp = Output(), C.c_uint32(), C.c_void_p()
+        if on_gpu:                                                  # tests/test_gpu_canon_device.py: the same check on an MI355X
+            import torch
+            from fgumi_amd._lib import hip_memcpy_d2h as fetch
+            dg = g.to_device(0)
+            torch.cuda.synchronize()
+            ptrs = (dg.blob.data_ptr(), dg.blob_len, dg.rec_off.data_ptr(), dg.rec_len.data_ptr(), dg.n_rec, dg.grp_first.data_ptr(), dg.n_grp)
+        else:                                                       # tests/apiemu: device memory is host memory
+            def fetch(p, n):
+                return C.string_at(p, n) if n else b""
+            blob = np.concatenate([g.blob, np.zeros(16, dtype=np.uint8)])
+            ptrs = (blob.ctypes.data, g.blob.size, g.rec_off.ctypes.data, g.rec_len.ctypes.data, g.n_rec, g.grp_first.ctypes.data, g.n_grp)
+        rc = lib.fgx_process_batch_device(h, *ptrs, C.byref(out), C.byref(nd), C.byref(dp))
+        assert rc == 0, lib.fgx_last_error(h).decode()
+        left = set(np.frombuffer(fetch(dp.value, 4 * nd.value), dtype=np.uint32).tolist()) if nd.value else set()
+        d = (C.c_uint64 * 2)()
+        lib.fgx_debug_last_deferral(h, d)
+        first_pass_deferred, canon = int(d[0]), int(d[1])
+        assert first_pass_deferred > 60 and canon > 0.2 * first_pass_deferred and first_pass_deferred - canon == len(left), (first_pass_deferred, canon, len(left))
+        want = b"".join(per_group[i]["data"] for i in range(len(groups)) if i not in left)
+        stats = sum((per_group[i]["stats"] for i in range(len(groups)) if i not in left), np.zeros(28, dtype=np.uint64))
+        got = fetch(out.data, int(out.data_len))
+        assert got == want
+        assert int(out.count) == sum(per_group[i]["count"] for i in range(len(groups)) if i not in left)
+        assert np.array_equal(np.array(list(out.stats), dtype=np.uint64), stats), (list(out.stats), stats.tolist())
+    finally:
+        lib.fgx_destroy(h)
+
+
+@pytest.mark.parametrize("defer", ["indel", "mod3"])
+@pytest.mark.parametrize("kind,kw,mr", [(1, dict(overlapping_consensus=1), (1, 1, 0)), (1, dict(overlapping_consensus=0, min_input_base_quality=20), (2, 1, 1)),
+                                        (2, dict(), None), (2, dict(codec_min_reads_per_strand=2, cell_tag=b"\0\0"), None)])
+def test_canonical_pass_inside_the_device_entry(kind, kw, mr, defer):
+    run_isolated("test_apiemu", "check_resident_pass", kind, kw, mr, env=env(FGX_DUPLEX_CANON=1, FGX_CODEC_CANON=1, FGX_CANON_RESIDENT=1, APIEMU_DEFER=defer))

@@ -25,3 +25,10 @@ def test_duplex_indel_molecules_canonicalised_on_the_device(kw, mr):
 @pytest.mark.parametrize("kw", [dict(), dict(min_input_base_quality=20, produce_per_base_tags=1)])
 def test_codec_molecules_canonicalised_on_the_device(kw):
     run_isolated("test_gpu_codec_canon", "check_codec_indel_molecules", kw, env=FLAGS)
+
+
+@pytest.mark.parametrize("kind,kw,mr", [(1, dict(overlapping_consensus=1), (1, 1, 0)), (2, dict(), None)])
+def test_canonical_pass_inside_the_device_entry(kind, kw, mr):
+    """FGX_CANON_RESIDENT=1: fgx_process_batch_device canonicalises, re-runs and merges on the device; its deferred list shrinks to the
+    out-of-scope remainder (the CPU twin: tests/test_apiemu.py, same check function)."""
+    run_isolated("test_apiemu", "check_resident_pass", kind, kw, mr, True, env=dict(FLAGS, FGX_CANON_RESIDENT="1"))
