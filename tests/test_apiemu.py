@@ -205,3 +205,23 @@ def check_resident_pass(kind, kw, mr, on_gpu=False):
                                         (2, dict(), None), (2, dict(codec_min_reads_per_strand=2, cell_tag=b"\0\0"), None)])
 def test_canonical_pass_inside_the_device_entry(kind, kw, mr, defer):
     run_isolated("test_apiemu", "check_resident_pass", kind, kw, mr, env=env(FGX_DUPLEX_CANON=1, FGX_CODEC_CANON=1, FGX_CANON_RESIDENT=1, APIEMU_DEFER=defer))
+
+
+def test_host_entry_gpu_tests_run_against_the_emulation():
+    """The GPU tests that go through the HOST entry (simplex / duplex / CODEC parity batches, the reference's unit-test inputs, the
+    methylation-aware mode, the duplex canonical pass) run as they are against tests/apiemu: the host side they exercise — validation,
+    hybrid splice, general path, record assembly — is then covered on the CPU as well, by the very assertions the hardware run makes.
+    Tests that need a real device (the device-resident entry with torch tensors, the device libm, kernels with no stand-in) are left out."""
+    import subprocess
+    import sys
+    files = ["tests/test_gpu_parity.py", "tests/test_gpu_duplex.py", "tests/test_gpu_codec.py", "tests/test_gpu_methylation.py", "tests/test_gpu_duplex_canon.py"]
+    skip = "not device_libm and not device_resident and not full_size and not stay_on_the_device and not noisy_batch"
+    e = dict(os.environ)
+    e.update(env())
+    p = subprocess.run([sys.executable, "-m", "pytest"] + files + ["-m", "gpu", "-q", "-x", "-k", skip, "-p", "no:cacheprovider", "-n", "4"],
+                       env=e, cwd=apiemu.ROOT, capture_output=True, text=True, timeout=1800)
+    tail = p.stdout[-3000:]
+    assert p.returncode == 0, tail + p.stderr[-3000:]
+    import re
+    m = re.search(r"(\d+) passed", tail)
+    assert m and int(m.group(1)) >= 170, tail
