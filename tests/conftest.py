@@ -15,4 +15,9 @@ def _build_oracle():
     so = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
     if not os.path.exists(so):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    # the product library: prebuilt on the GPU box (it travels with the snapshot); in a fresh checkout with hipcc at hand it is built once
+    # (cross-compilation needs no GPU) — without hipcc the tests that need it fail loudly through fgumi_amd._lib.LibraryMissing
+    lib = os.path.join(ROOT, "fgumi_amd", "libfgumi_amd.so")
+    if not os.path.exists(lib) and not os.environ.get("FGX_LIB") and os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+        subprocess.check_call([sys.executable, "-m", "fgumi_amd.build"], cwd=ROOT)
     yield
