@@ -225,3 +225,57 @@ def test_host_entry_gpu_tests_run_against_the_emulation():
     import re
     m = re.search(r"(\d+) passed", tail)
     assert m and int(m.group(1)) >= 170, tail
+
+
+def check_hybrid_fuzz(kind, seed0, n_seeds):
+    """The hostile groups of the general-path fuzz through the HOST ENTRY (validation, device-pipeline stand-in, splice, opt-in paths as the
+    environment says): records, counters and rejects as the oracle gives them, or an error where the reference refuses the batch."""
+    import random
+    import test_general_path_fuzz as fuzz
+    from fgumi_amd import GroupedReads
+    from fgumi_amd._lib import Options, Output, lib
+    name = ["simplex", "duplex", "codec"][kind]
+    done = errors = 0
+    for seed in range(seed0, seed0 + n_seeds):
+        rng = random.Random(seed)
+        exotic = rng.random() < 0.6
+        groups = [x for x in (fuzz.random_group(rng, g, name, exotic) for g in range(60)) if x]
+        if not groups:
+            continue
+        o = fuzz.random_options(rng, name)
+        g = GroupedReads.from_groups(groups)
+        try:
+            want = orc.process(o, g.blob, g.rec_off, g.rec_len, g.grp_first, batch_groups=max({0: 50, 1: 100, 2: 1000}[kind], len(groups)))
+        except RuntimeError:
+            want = None
+        po = Options.from_buffer_copy(bytes(o))
+        h = lib.fgx_create(C.byref(po))
+        assert h, lib.fgx_global_error().decode()
+        try:
+            out = Output()
+            rc = lib.fgx_process_batch(h, g.blob.ctypes.data, g.blob.size, g.rec_off.ctypes.data, g.rec_len.ctypes.data, g.n_rec, g.grp_first.ctypes.data, g.n_grp, C.byref(out))
+            if want is None:
+                assert rc != 0, (name, seed)
+                errors += 1
+                continue
+            assert rc == 0, (name, seed, lib.fgx_last_error(h).decode())
+            assert (C.string_at(out.data, out.data_len) if out.data_len else b"") == want["data"], (name, seed)
+            assert int(out.count) == want["count"] and np.array_equal(np.array(list(out.stats), dtype=np.uint64), want["stats"]), (name, seed)
+            if o.track_rejects:
+                assert int(out.n_rejects) == want["n_rejects"] and (C.string_at(out.rejects, out.rejects_len) if out.rejects_len else b"") == want["rejects"], (name, seed)
+            done += 1
+        finally:
+            lib.fgx_destroy(h)
+    assert done >= n_seeds // 2, (done, errors)
+
+
+@pytest.mark.parametrize("defer", ["indel", "mod3"])
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_hostile_groups_through_the_host_entry(kind, defer):
+    run_isolated("test_apiemu", "check_hybrid_fuzz", kind, 40000 + 100 * kind, 12,
+                 env=env(APIEMU_DEFER=defer, FGX_REJECTS_DEVICE=1, FGX_DUPLEX_CANON=1, FGX_CODEC_CANON=1, FGX_CANON_DEVICE=1))
+
+
+def test_hostile_groups_through_the_host_entry_default_switches():
+    for kind in (0, 1, 2):
+        run_isolated("test_apiemu", "check_hybrid_fuzz", kind, 41000 + 100 * kind, 8, env=env(APIEMU_DEFER="mod3"))
