@@ -74,17 +74,17 @@ def test_duplex_canonical_second_pass(kw, mr, defer, on_device):
 @pytest.mark.parametrize("kw", [dict(), dict(min_input_base_quality=20, produce_per_base_tags=1), dict(codec_min_reads_per_strand=2, cell_tag=b"\0\0"),
                                 dict(codec_outer_bases_length=5, codec_has_outer_bases_qual=1, codec_outer_bases_qual=7, codec_min_duplex_length=10)])
 def test_codec_canonical_second_pass(kw, defer, on_device):
-    run_isolated("test_gpu_codec_canon", "check_codec_indel_molecules", kw, env=env(FGX_CODEC_CANON=1, FGX_CANON_DEVICE=on_device, APIEMU_DEFER=defer))
+    run_isolated("test_gpu_zz_codec_canon", "check_codec_indel_molecules", kw, env=env(FGX_CODEC_CANON=1, FGX_CANON_DEVICE=on_device, APIEMU_DEFER=defer))
 
 
 def test_canonical_pass_off_by_default():
     run_isolated("test_gpu_duplex_canon", "test_second_pass_is_off_by_default", env=env())
-    run_isolated("test_gpu_codec_canon", "check_off_by_default", env=env())
+    run_isolated("test_gpu_zz_codec_canon", "check_off_by_default", env=env())
 
 
 def check_device_entry_emu(kw, seed):
-    """tests/test_gpu_rejects_device.check_device_entry with host arrays standing in for the tensors in HBM."""
-    import test_gpu_rejects_device as tgr
+    """tests/test_gpu_zz_rejects_device.check_device_entry with host arrays standing in for the tensors in HBM."""
+    import test_gpu_zz_rejects_device as tgr
     from fgumi_amd._lib import Options, Output, lib
     g = tgr.batch(seed)
     o = fgx_opts.defaults(kind=0, track_rejects=1, **kw)
@@ -107,7 +107,7 @@ def check_device_entry_emu(kw, seed):
 
 
 def check_device_entry_refuses_without_the_flag():
-    import test_gpu_rejects_device as tgr
+    import test_gpu_zz_rejects_device as tgr
     from fgumi_amd._lib import Options, Output, lib
     g = tgr.batch(3)
     o = fgx_opts.defaults(kind=0, track_rejects=1, min_reads=1)
@@ -126,7 +126,7 @@ def check_device_entry_refuses_without_the_flag():
 @pytest.mark.parametrize("kw", [dict(min_reads=1), dict(min_reads=2, max_reads=3), dict(min_reads=3, overlapping_consensus=0, min_input_base_quality=30),
                                 dict(min_reads=2, trim=1, min_input_base_quality=25)])
 def test_rejects_side_kernels_host_entry(kw, defer):
-    run_isolated("test_gpu_rejects_device", "check_host_entry", kw, 11, env=env(FGX_REJECTS_DEVICE=1, APIEMU_DEFER=defer))
+    run_isolated("test_gpu_zz_rejects_device", "check_host_entry", kw, 11, env=env(FGX_REJECTS_DEVICE=1, APIEMU_DEFER=defer))
 
 
 @pytest.mark.parametrize("kw", [dict(min_reads=1), dict(min_reads=2, max_reads=3)])
@@ -136,7 +136,7 @@ def test_rejects_side_kernels_device_entry(kw):
 
 
 def test_rejects_without_the_flag_take_the_general_path():
-    run_isolated("test_gpu_rejects_device", "check_host_entry", dict(min_reads=2), 11, env=env())          # (whole batch on the general path: same answer)
+    run_isolated("test_gpu_zz_rejects_device", "check_host_entry", dict(min_reads=2), 11, env=env())          # (whole batch on the general path: same answer)
     run_isolated("test_apiemu", "check_device_entry_refuses_without_the_flag", env=env())
 
 
@@ -172,7 +172,7 @@ def check_resident_pass(kind, kw, mr, on_gpu=False):
     assert h, lib.fgx_global_error().decode()
     try:
         out, nd, dp = Output(), C.c_uint32(), C.c_void_p()
-        if on_gpu:                                                  # tests/test_gpu_canon_device.py: the same check on an MI355X
+        if on_gpu:                                                  # tests/test_gpu_zz_canon_device.py: the same check on an MI355X
             import torch
             from fgumi_amd._lib import hip_memcpy_d2h as fetch
             dg = g.to_device(0)

@@ -1,7 +1,7 @@
 """The new lane-per-item device paths driven END TO END on the CPU (tests/devemu: reject_device.hip and canon_device.hip compiled for the
 host, a launch = a serial loop): slab sizing, grid-stride loops, the scan of the groups' bytes, offsets and totals of the `--rejects` side
 kernels against the oracle's rejects; the canonicalisation kernel with api.cpp's slot layout against the per-molecule host entries.  What
-this cannot show is the hardware running them — tests/test_gpu_rejects_device.py and tests/test_gpu_canon_device.py do."""
+this cannot show is the hardware running them — tests/test_gpu_zz_rejects_device.py and tests/test_gpu_zz_canon_device.py do."""
 import random
 
 import numpy as np
@@ -13,7 +13,7 @@ import orc
 import test_canon_codec as tcc
 import test_canon_core as tc
 import test_general_path_fuzz as fuzz
-import test_gpu_rejects_device as tgr
+import test_gpu_zz_rejects_device as tgr
 from fgumi_amd import GroupedReads, simulate_grouped_reads
 
 

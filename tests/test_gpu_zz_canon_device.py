@@ -1,6 +1,6 @@
 """GPU parity of the canonical second pass with the canonical form computed ON THE DEVICE (FGX_CANON_DEVICE=1 on top of FGX_DUPLEX_CANON /
 FGX_CODEC_CANON; fgumi_amd/csrc/canon_device.hip: a lane per deferred molecule runs the scalar source of canon_core.h over the records
-already uploaded).  Same inputs and assertions as the host-canonicalised twins (tests/test_gpu_duplex_canon.py, test_gpu_codec_canon.py):
+already uploaded).  Same inputs and assertions as the host-canonicalised twins (tests/test_gpu_duplex_canon.py, test_gpu_zz_codec_canon.py):
 byte-identical to the oracle, counters included.
 
 NOT RUN ON HARDWARE YET: written after the round's GPU budget was spent.  xfail(strict=False), each test in a child interpreter
@@ -24,7 +24,7 @@ def test_duplex_indel_molecules_canonicalised_on_the_device(kw, mr):
 
 @pytest.mark.parametrize("kw", [dict(), dict(min_input_base_quality=20, produce_per_base_tags=1)])
 def test_codec_molecules_canonicalised_on_the_device(kw):
-    run_isolated("test_gpu_codec_canon", "check_codec_indel_molecules", kw, env=FLAGS)
+    run_isolated("test_gpu_zz_codec_canon", "check_codec_indel_molecules", kw, env=FLAGS)
 
 
 @pytest.mark.parametrize("kind,kw,mr", [(1, dict(overlapping_consensus=1), (1, 1, 0)), (2, dict(), None)])

@@ -29,7 +29,7 @@ pytestmark = [pytest.mark.gpu,
 @pytest.mark.parametrize("kw", [dict(), dict(min_input_base_quality=20, produce_per_base_tags=1), dict(codec_min_reads_per_strand=2, cell_tag=b"\0\0"),
                                 dict(codec_outer_bases_length=5, codec_has_outer_bases_qual=1, codec_outer_bases_qual=7, codec_min_duplex_length=10)])
 def test_codec_indel_molecules_take_the_canonical_second_pass(kw):
-    run_isolated("test_gpu_codec_canon", "check_codec_indel_molecules", kw, env={"FGX_CODEC_CANON": "1"})
+    run_isolated("test_gpu_zz_codec_canon", "check_codec_indel_molecules", kw, env={"FGX_CODEC_CANON": "1"})
 
 
 def check_codec_indel_molecules(kw):
@@ -52,7 +52,7 @@ def check_codec_indel_molecules(kw):
 
 
 def test_codec_second_pass_is_off_by_default():
-    run_isolated("test_gpu_codec_canon", "check_off_by_default")
+    run_isolated("test_gpu_zz_codec_canon", "check_off_by_default")
 
 
 def check_off_by_default():

@@ -89,9 +89,9 @@ def check_device_entry(kw, seed):
 
 @pytest.mark.parametrize("kw", KWS)
 def test_host_entry_rejects_come_from_the_side_kernels(kw):
-    run_isolated("test_gpu_rejects_device", "check_host_entry", kw, 11, env=FLAG)
+    run_isolated("test_gpu_zz_rejects_device", "check_host_entry", kw, 11, env=FLAG)
 
 
 @pytest.mark.parametrize("kw", KWS[:2])
 def test_device_entry_accepts_track_rejects(kw):
-    run_isolated("test_gpu_rejects_device", "check_device_entry", kw, 12, env=FLAG)
+    run_isolated("test_gpu_zz_rejects_device", "check_device_entry", kw, 12, env=FLAG)
