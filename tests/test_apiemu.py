@@ -279,3 +279,33 @@ def test_hostile_groups_through_the_host_entry(kind, defer):
 def test_hostile_groups_through_the_host_entry_default_switches():
     for kind in (0, 1, 2):
         run_isolated("test_apiemu", "check_hybrid_fuzz", kind, 41000 + 100 * kind, 8, env=env(APIEMU_DEFER="mod3"))
+
+
+def check_sharded_general_path_with_side_rejects():
+    """Enough deferred groups (> 1024) for the general path to shard them over helper callers on threads while the rejects come from the
+    side kernels: the helpers must not track rejects during that call and must track them again afterwards."""
+    from fgumi_amd import GroupedReads, simulate_grouped_reads
+    from fgumi_amd._lib import Options, Output, lib
+    sim = simulate_grouped_reads(3300, family_size=1, family_size_max=5, seed=21)
+    g = GroupedReads.from_groups([sim.records(i) for i in range(sim.n_grp)])
+    o = fgx_opts.defaults(kind=0, track_rejects=1, min_reads=2, max_reads=3)
+    want = orc.process(o, g.blob, g.rec_off, g.rec_len, g.grp_first, batch_groups=50)
+    assert want["n_rejects"] > 100
+    po = Options.from_buffer_copy(bytes(o))
+    h = lib.fgx_create(C.byref(po))
+    assert h, lib.fgx_global_error().decode()
+    try:
+        for flag in ("1", "0", "1"):              # side kernels, then the whole batch on the (sharded) general path with tracking, then side kernels again
+            os.environ["FGX_REJECTS_DEVICE"] = flag
+            out = Output()
+            rc = lib.fgx_process_batch(h, g.blob.ctypes.data, g.blob.size, g.rec_off.ctypes.data, g.rec_len.ctypes.data, g.n_rec, g.grp_first.ctypes.data, g.n_grp, C.byref(out))
+            assert rc == 0, lib.fgx_last_error(h).decode()
+            assert (C.string_at(out.data, out.data_len) if out.data_len else b"") == want["data"], flag
+            assert np.array_equal(np.array(list(out.stats), dtype=np.uint64), want["stats"]), flag
+            assert int(out.n_rejects) == want["n_rejects"] and (C.string_at(out.rejects, out.rejects_len) if out.rejects_len else b"") == want["rejects"], flag
+    finally:
+        lib.fgx_destroy(h)
+
+
+def test_sharded_general_path_with_side_rejects():
+    run_isolated("test_apiemu", "check_sharded_general_path_with_side_rejects", env=env(APIEMU_DEFER="mod3"))
