@@ -8,8 +8,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "fgumi_amd", "csrc")
 SRC = os.path.join(ROOT, "tests", "apiemu", "apiemu.cpp")
 BUILD = os.path.join(ROOT, "tests", "hostemu", "_build")
+TSAN = os.environ.get("HOSTEMU_SANITIZE") == "thread"    # ThreadSanitizer build (the sharded general path, the host threads of the canonical pass)
 SANITIZE = os.environ.get("HOSTEMU_SANITIZE") == "1"     # tools/sanitize_host.sh: ASan + UBSan build, loaded under LD_PRELOAD of the ASan runtime (children inherit it)
-OUT = os.path.join(BUILD, "libapiemu_san.so" if SANITIZE else "libapiemu.so")
+OUT = os.path.join(BUILD, "libapiemu_tsan.so" if TSAN else "libapiemu_san.so" if SANITIZE else "libapiemu.so")
 HOST = ["api.cpp", "simplex_host.cpp", "duplex_host.cpp", "codec_host.cpp", "bgzf_host.cpp", "pipeline.cpp"]
 CL = "/opt/rocm/lib/llvm/bin/clang++"        # (inflate_core.h uses clang builtins)
 
@@ -29,6 +30,8 @@ def build():
     os.makedirs(BUILD, exist_ok=True)
     tag = f"{os.getpid()}"
     flags = ["-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-D__HIP_PLATFORM_AMD__", "-DFGX_HAVE_CODEC", "-I/opt/rocm/include", "-w", "-pthread"]
+    if TSAN:
+        flags += ["-g", "-fsanitize=thread", "-shared-libsan", "-fno-omit-frame-pointer"]
     if SANITIZE:
         flags += ["-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-shared-libasan", "-fno-omit-frame-pointer"]
     srcs = [os.path.join(CSRC, f) for f in HOST] + [SRC]
@@ -46,7 +49,7 @@ def build():
     tmp = f"{OUT}.{tag}.tmp"
     subprocess.check_call([CL] + flags + srcs + [stubs, "-o", tmp, "-lz"])
     left = subprocess.run(["ldd", "-r", tmp], capture_output=True, text=True)
-    missing = [ln for ln in (left.stdout + left.stderr).splitlines() if ln.startswith("undefined symbol") and "asan" not in ln and "ubsan" not in ln]
+    missing = [ln for ln in (left.stdout + left.stderr).splitlines() if ln.startswith("undefined symbol") and "asan" not in ln and "ubsan" not in ln and "tsan" not in ln]
     assert not missing, missing
     os.replace(tmp, OUT)
     for p in (first, stubs):

@@ -33,3 +33,6 @@ cd "$ROOT"
 TESTS="tests/test_canon_core.py tests/test_canon_codec.py tests/test_reject_core.py tests/test_devemu.py tests/test_apiemu.py tests/test_inflate_core.py tests/test_deflate_core.py tests/test_methylation_core.py tests/test_bgzf.py tests/test_general_path_hostemu.py tests/test_general_path_fuzz.py"
 LD_PRELOAD="$RT" python -m pytest $TESTS -x -q -m "not gpu" -p no:cacheprovider "$@"
 rm -f "$OUT/libfgumi_host_san.so" "$OUT/libhostemu_san.so" "$OUT/libdevemu_san.so" "$OUT/libapiemu_san.so"     # (large; they would travel to the GPU box with the snapshot)
+# ThreadSanitizer over the threaded host paths (the general path sharded over helper callers, the host threads of the canonical pass) — opt-in, slow:
+#   HOSTEMU_SANITIZE=thread LD_PRELOAD="$($CL -print-file-name=libclang_rt.tsan-x86_64.so)" TSAN_OPTIONS=report_signal_unsafe=0 \
+#     python -m pytest tests/test_apiemu.py -q -k "canonical_second_pass or sharded or hostile or rejects_side" -p no:cacheprovider
