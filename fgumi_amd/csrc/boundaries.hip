@@ -17,7 +17,9 @@
 //                   written and the walk repeated; every round makes at least the first wrong segment right.
 //   scan + k_bound_write   record indices from the per-segment counts; offsets and lengths written by a second walk.
 // Nothing in the result depends on the heuristic: it only decides how many repair rounds there are (none, in practice).
+#ifndef FGX_DEVEMU            // (tests/apiemu compiles this file for the host with a serial scan)
 #include <hipcub/hipcub.hpp>
+#endif
 #include "engine.h"
 #include <cstdio>
 #include <cstdlib>

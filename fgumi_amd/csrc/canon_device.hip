@@ -87,7 +87,7 @@ uint32_t launch_canon_molecules(hipStream_t s, bool codec, const canon::Params& 
 // =====================================================================================================================================
 namespace {
 
-constexpr uint32_t NONE = 0xFFFFFFFFu;
+constexpr uint32_t NO_CANON = 0xFFFFFFFFu;
 
 // slots and bytes (4-byte block_size + record) each deferred group needs in the canonical blob; element nd of both arrays stays 0
 __global__ void k_canon_count(const uint32_t* __restrict__ rec_len, const uint32_t* __restrict__ grp_first, const uint32_t* __restrict__ def, uint32_t nd,
@@ -149,7 +149,7 @@ __global__ void k_res_sizes(uint32_t n_grp, const uint64_t* __restrict__ off1, u
   if (g >= n_grp) return;
   const uint64_t s1 = (g + 1 < n_grp ? off1[3ull * (g + 1)] : len1) - off1[3ull * g];
   const uint32_t ci = g2ci[g];
-  const uint64_t s2 = ci != NONE ? (ci + 1 < n_cg ? off2[3ull * (ci + 1)] : len2) - off2[3ull * ci] : 0;
+  const uint64_t s2 = ci != NO_CANON ? (ci + 1 < n_cg ? off2[3ull * (ci + 1)] : len2) - off2[3ull * ci] : 0;
   size[g] = s1 + s2;
 }
 // the merged stream: a workgroup per group copies its records (lanes take bytes 64 apart: coalesced whatever the alignment of the record)
@@ -160,7 +160,7 @@ k_res_copy(uint32_t n_grp, const uint64_t* __restrict__ off1, const uint8_t* __r
     const uint64_t len = foff[g + 1] - foff[g];
     if (len == 0) continue;
     const uint32_t ci = g2ci[g];
-    const uint8_t* src = ci != NONE ? out2 + off2[3ull * ci] : out1 + off1[3ull * g];
+    const uint8_t* src = ci != NO_CANON ? out2 + off2[3ull * ci] : out1 + off1[3ull * g];
     uint8_t* d = dst + foff[g];
     for (uint64_t i = threadIdx.x; i < len; i += 64) d[i] = src[i];
   }

@@ -8,7 +8,9 @@
 //                                                 unmapped dropped unless --allow-unmapped)
 //           crates/fgumi-umi/src/lib.rs:370-375  extract_mi_base (duplex: cut the value at its last '/', if not leading)
 // Keys are compared as bytes (the reference compares `from_utf8_lossy` strings: identical for valid UTF-8 tag values).
+#ifndef FGX_DEVEMU            // (tests/apiemu compiles this file for the host with a serial scan)
 #include <hipcub/hipcub.hpp>
+#endif
 #include "bamrec.h"
 #include "engine.h"
 

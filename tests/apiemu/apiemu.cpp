@@ -4,7 +4,10 @@
 // `--rejects` side path, fgx_process_batch_device), the general path's orchestration, the BGZF / pipeline host code — built unmodified
 // and linked, instead of against libamdhip64 and the device kernels, against
 //   * a fake HIP runtime: device memory is host memory, copies are memcpy, streams and events do nothing;
-//   * the lane-per-item kernels compiled for the host (reject_device.hip, canon_device.hip: tests/devemu's shim, a launch = a serial loop);
+//   * the lane-per-item kernels compiled for the host — reject_device.hip, canon_device.hip and, REAL sources as well, boundaries.hip
+//     (FindBoundaries: segment guesses, walks, mutual check) and grouping.hip (the MI grouper) — through tests/devemu's shim (a launch = a
+//     serial loop over the grid, hipcub scans = serial sums);
+//   * zlib for the BGZF inflate / CRC kernels (LDS tables, 64-lane folds: no host form), so that fgx_run_bam runs end to end;
 //   * host stand-ins for the column and annotation kernels' launchers, built from the functions those kernels call (column_emu.h,
 //     methylation_core.h);
 //   * a stand-in for the device-resident pipeline (`FastPath::run`): it DEFERS groups by a rule (a read that is not one aligned block,
@@ -152,3 +155,38 @@ void FastPath::release() {
 // ---- the lane-per-item kernels, compiled for the host (tests/devemu's shim; this file's runtime definitions stay as they are) -------
 #define DEVEMU_EMBEDDED 1
 #include "../devemu/devemu.cpp"
+// FindBoundaries and the MI grouper are lane-per-item kernels around scans as well: the real sources, on the host
+#include "../../fgumi_amd/csrc/boundaries.hip"
+#include "../../fgumi_amd/csrc/grouping.hip"
+
+// ---- BGZF on the "device": zlib stands in for k_bgzf_inflate / k_bgzf_crc / k_bgzf_crc_blocks (LDS tables, 64-lane CRC folds) -----------
+#include <zlib.h>
+namespace fgx {
+void bgzf_inflate_launch(hipStream_t, const uint8_t* d_raw, const BgzfDevBlock* d_blk, uint32_t n, uint8_t* d_out, uint32_t* d_status, uint32_t* h_status) {
+  uint32_t st = 0;
+  for (uint32_t i = 0; i < n && !st; i++) {
+    const BgzfDevBlock& b = d_blk[i];
+    z_stream z;
+    memset(&z, 0, sizeof(z));
+    if (inflateInit2(&z, -15) != Z_OK) { st = ((i + 1) << 4) | 1; break; }
+    z.next_in = (Bytef*)(d_raw + b.in_off); z.avail_in = b.in_len;
+    z.next_out = d_out + b.out_off; z.avail_out = b.isize;
+    const int rc = inflate(&z, Z_FINISH);
+    const bool ok = (rc == Z_STREAM_END) && z.total_out == b.isize;
+    inflateEnd(&z);
+    if (!ok) { st = ((i + 1) << 4) | 4; break; }
+    if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), d_out + b.out_off, b.isize) != b.crc) st = ((i + 1) << 4) | 9;
+  }
+  if (n) *d_status = st;
+  *h_status = st;
+}
+int bgzf_inflate_status(fgx_caller* c, uint32_t st) {
+  if (!st) return 0;
+  c->err = "BGZF block " + std::to_string((st >> 4) - 1) + " of the chunk failed to inflate on the device (apiemu stand-in), code " + std::to_string(st & 15u);
+  return 1;
+}
+void bgzf_crc_blocks_device(fgx_caller*, const uint8_t* d_in, uint64_t len, uint32_t* d_crcs) {
+  const uint64_t P = 0xff00;
+  for (uint64_t b = 0, o = 0; o < len; b++, o += P) d_crcs[b] = (uint32_t)crc32(crc32(0L, Z_NULL, 0), d_in + o, (uInt)(len - o < P ? len - o : P));
+}
+}  // namespace fgx

@@ -36,8 +36,8 @@ template <class F> void launch(dim3 grid, dim3 block, F&& body) {
 #define gridDim devemu::g_grid
 #define blockDim devemu::g_bdim
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) devemu::launch((grid), (block), [&] { kernel(__VA_ARGS__); })
-static inline unsigned long long emu_atomic_add(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; *p = o + v; return o; }
-static inline unsigned long long emu_atomic_max(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; if (v > o) *p = v; return o; }
+template <class T, class U> static inline T emu_atomic_add(T* p, U v) { const T o = *p; *p = (T)(o + (T)v); return o; }
+template <class T, class U> static inline T emu_atomic_max(T* p, U v) { const T o = *p; if ((T)v > o) *p = (T)v; return o; }
 #define atomicAdd emu_atomic_add
 #define atomicMax emu_atomic_max
 #define hipMemsetAsync(p, v, n, s) (memset((p), (v), (n)), hipSuccess)
@@ -50,6 +50,12 @@ struct DeviceScan {
     if (!tmp) { bytes = 16; return hipSuccess; }
     unsigned long long run = 0;
     for (int i = 0; i < n; i++) { const unsigned long long v = in[i]; out[i] = run; run += v; }
+    return hipSuccess;
+  }
+  template <class In, class Out> static hipError_t InclusiveSum(void* tmp, size_t& bytes, In in, Out out, int n, hipStream_t) {
+    if (!tmp) { bytes = 16; return hipSuccess; }
+    unsigned long long run = 0;
+    for (int i = 0; i < n; i++) { run += in[i]; out[i] = run; }
     return hipSuccess;
   }
 };

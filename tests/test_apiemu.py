@@ -214,8 +214,9 @@ def test_host_entry_gpu_tests_run_against_the_emulation():
     Tests that need a real device (the device-resident entry with torch tensors, the device libm, kernels with no stand-in) are left out."""
     import subprocess
     import sys
-    files = ["tests/test_gpu_parity.py", "tests/test_gpu_duplex.py", "tests/test_gpu_codec.py", "tests/test_gpu_methylation.py", "tests/test_gpu_duplex_canon.py"]
-    skip = "not device_libm and not device_resident and not full_size and not stay_on_the_device and not noisy_batch"
+    files = ["tests/test_gpu_parity.py", "tests/test_gpu_duplex.py", "tests/test_gpu_codec.py", "tests/test_gpu_methylation.py", "tests/test_gpu_duplex_canon.py",
+             "tests/test_gpu_pipeline.py"]            # (fgx_run_bam: BAM file -> consensus BAM file == the oracle; boundaries.hip / grouping.hip are the real sources)
+    skip = "not device_libm and not device_resident and not full_size and not stay_on_the_device and not noisy_batch and not device_deflate and not device_boundaries"
     e = dict(os.environ)
     e.update(env())
     p = subprocess.run([sys.executable, "-m", "pytest"] + files + ["-m", "gpu", "-q", "-x", "-k", skip, "-p", "no:cacheprovider", "-n", "4"],
@@ -224,7 +225,7 @@ def test_host_entry_gpu_tests_run_against_the_emulation():
     assert p.returncode == 0, tail + p.stderr[-3000:]
     import re
     m = re.search(r"(\d+) passed", tail)
-    assert m and int(m.group(1)) >= 170, tail
+    assert m and int(m.group(1)) >= 178, tail
 
 
 def check_hybrid_fuzz(kind, seed0, n_seeds):
@@ -309,3 +310,41 @@ def check_sharded_general_path_with_side_rejects():
 
 def test_sharded_general_path_with_side_rejects():
     run_isolated("test_apiemu", "check_sharded_general_path_with_side_rejects", env=env(APIEMU_DEFER="mod3"))
+
+
+def check_boundaries_and_grouping_kernels():
+    """boundaries.hip (segment guesses, walks, mutual check, repair rounds) and grouping.hip (keys, compaction, group bounds) are
+    lane-per-item kernels around scans: tests/apiemu compiles the REAL sources for the host.  The GPU tests' own bodies run here with
+    host arrays standing in for the tensors in HBM."""
+    import test_gpu_pipeline as tp
+    import test_grouping as tg
+    from fgumi_amd import VanillaUmiConsensusCaller
+    from fgumi_amd._lib import lib
+
+    def boundaries(c, stream, start):
+        buf = np.frombuffer(bytes(stream) + bytes(64), dtype=np.uint8).copy()
+        n, used = C.c_uint64(), C.c_uint64()
+        rc = lib.fgx_record_boundaries_device(c._h, buf.ctypes.data, len(stream), start, None, None, 0, C.byref(n), C.byref(used))
+        assert rc == 0, lib.fgx_last_error(c._h)
+        off = np.zeros(max(1, n.value), dtype=np.uint64)
+        ln = np.zeros(max(1, n.value), dtype=np.uint32)
+        n2 = C.c_uint64()
+        rc = lib.fgx_record_boundaries_device(c._h, buf.ctypes.data, len(stream), start, off.ctypes.data, ln.ctypes.data, n.value, C.byref(n2), C.byref(used))
+        assert rc == 0 and n2.value == n.value
+        return off[:n.value], ln[:n.value], used.value
+    tp._device_boundaries = boundaries
+    tp.test_device_boundaries_equal_the_sequential_chain()
+    tp.test_device_boundaries_with_records_longer_than_a_segment_and_record_like_payloads()
+    c = VanillaUmiConsensusCaller("", "A")
+    for kw in (dict(cell_tag="CB"), dict(cell_tag=None), dict(cell_tag="CB", strip_strand_suffix=True), dict(cell_tag=None, strip_strand_suffix=True, allow_unmapped=True)):
+        okw = dict(kw)
+        okw["cell_tag"] = kw["cell_tag"].encode() if kw["cell_tag"] else None
+        for blob, off, ln in (tg._mixed_stream(), tg._stream([]), tg._stream([tg._rec()]), tg._stream([tg._rec("7", "X")])):
+            want = orc.group_records(blob, off, ln, **okw)
+            got = c.group_records(blob, off, ln, **kw)
+            assert np.array_equal(got.rec_off, want[0]) and np.array_equal(got.rec_len, want[1]) and np.array_equal(got.grp_first, want[2])
+    c.close()
+
+
+def test_boundaries_and_grouping_kernels_on_the_host():
+    run_isolated("test_apiemu", "check_boundaries_and_grouping_kernels", env=env())
