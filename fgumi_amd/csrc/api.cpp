@@ -910,6 +910,81 @@ int fgx_process_batch_device(fgx_caller* c, const void* d_records, uint64_t reco
   } catch (const std::exception& ex) { c->err = ex.what(); return 3; }
 }
 
+// pipeline.cpp (opt-in FGX_PIPE_SUBSET=1): the groups the device-resident entry has JUST deferred are decided by the general path from copies
+// of their records alone (one small device-to-host copy per group, instead of the whole batch coming back and going through the host
+// entry a second time), and the merged stream — the device's records with the general path's records inserted at the deferred groups'
+// places, group order kept — is assembled in the caller object's host buffer.  `dev` is the output of that fgx_process_batch_device call.
+// Returns 0 (merged filled: data on the host), or -1 when this cannot be done here (no slot table of the last device batch; CODEC
+// molecules named by the running counter) and the caller must take the whole-batch way.
+extern "C++" {
+namespace fgx {
+int resubmit_deferred(fgx_caller* c, const uint8_t* d_blob, const uint64_t* d_rec_off, const uint32_t* d_rec_len, uint32_t n_rec, const uint32_t* d_grp_first, uint32_t n_grp,
+                      const fgx_output* dev, uint32_t n_def, const uint32_t* d_def, fgx_output* merged) {
+  if (!c->fast || !c->fast->has_last || n_def == 0) return -1;
+  const FastResult& fr = c->fast->last;
+  general_fn general = c->opt.caller_kind == FGX_CALLER_SIMPLEX ? simplex_process_general : c->opt.caller_kind == FGX_CALLER_DUPLEX ? duplex_process_general : codec_process_general;
+  std::vector<uint32_t> def(n_def);
+  hip_check(hipMemcpy(def.data(), d_def, (size_t)n_def * 4, hipMemcpyDeviceToHost), "D2H deferred");
+  std::sort(def.begin(), def.end());
+  std::vector<uint32_t> grp((size_t)n_grp + 1);
+  hip_check(hipMemcpy(grp.data(), d_grp_first, ((size_t)n_grp + 1) * 4, hipMemcpyDeviceToHost), "D2H group boundaries");
+  // the deferred groups' record tables and bytes (a group's records lie in stream order: one span per group)
+  std::vector<uint8_t> blob;
+  std::vector<uint64_t> s_off, g_off;
+  std::vector<uint32_t> s_len, s_grp(1, 0), g_len;
+  for (uint32_t g : def) {
+    if (g >= n_grp) return -1;
+    const uint32_t r0 = grp[g], r1 = grp[g + 1];
+    if (r1 > n_rec || r0 > r1) return -1;
+    const uint32_t n = r1 - r0;
+    if (n) {
+      g_off.resize(n); g_len.resize(n);
+      hip_check(hipMemcpy(g_off.data(), d_rec_off + r0, (size_t)n * 8, hipMemcpyDeviceToHost), "D2H rec_off of a deferred group");
+      hip_check(hipMemcpy(g_len.data(), d_rec_len + r0, (size_t)n * 4, hipMemcpyDeviceToHost), "D2H rec_len of a deferred group");
+      uint64_t lo = ~0ull, hi = 0;
+      for (uint32_t i = 0; i < n; i++) { if (g_off[i] < lo) lo = g_off[i]; if (g_off[i] + g_len[i] > hi) hi = g_off[i] + g_len[i]; }
+      const size_t at = blob.size();
+      blob.resize(at + (size_t)(hi - lo));
+      hip_check(hipMemcpy(blob.data() + at, d_blob + lo, (size_t)(hi - lo), hipMemcpyDeviceToHost), "D2H records of a deferred group");
+      for (uint32_t i = 0; i < n; i++) { s_off.push_back(at + (g_off[i] - lo)); s_len.push_back(g_len[i]); }
+    }
+    s_grp.push_back((uint32_t)s_off.size());
+  }
+  blob.resize(blob.size() + 16);
+  fgx_output gen;
+  memset(&gen, 0, sizeof(gen));
+  c->out_data.clear(); c->grp_out_end.clear();
+  const int rc = run_general(c, general, blob.data(), s_off.data(), s_len.data(), (uint32_t)s_off.size(), s_grp.data(), n_def, &gen);
+  if (rc != 0) return rc;
+  if (c->opt.caller_kind == FGX_CALLER_CODEC && c->counter_names_used) return -1;
+  // slot offsets of the deferred groups in the device's record stream (they hold nothing there), then the merge
+  std::vector<uint64_t> at_dev(n_def);
+  for (uint32_t k = 0; k < n_def; k++) hip_check(hipMemcpy(&at_dev[k], fr.d_out_off + (size_t)3 * def[k], 8, hipMemcpyDeviceToHost), "D2H slot offset");
+  std::vector<uint8_t> m;
+  m.resize(dev->data_len + c->out_data.size() + 16);
+  uint64_t w = 0, dpos = 0, gprev = 0;
+  for (uint32_t k = 0; k < n_def; k++) {
+    const uint64_t upto = at_dev[k];
+    if (upto < dpos || upto > dev->data_len) return -1;
+    if (upto > dpos) hip_check(hipMemcpy(m.data() + w, dev->data + dpos, (size_t)(upto - dpos), hipMemcpyDeviceToHost), "D2H device records");
+    w += upto - dpos; dpos = upto;
+    const uint64_t gend = c->grp_out_end[k];
+    if (gend > gprev) memcpy(m.data() + w, c->out_data.data() + gprev, (size_t)(gend - gprev));
+    w += gend - gprev; gprev = gend;
+  }
+  if (dev->data_len > dpos) hip_check(hipMemcpy(m.data() + w, dev->data + dpos, (size_t)(dev->data_len - dpos), hipMemcpyDeviceToHost), "D2H device records");
+  w += dev->data_len - dpos;
+  m.resize(w);
+  c->out_data.swap(m);
+  memset(merged, 0, sizeof(*merged));
+  merged->data = c->out_data.data(); merged->data_len = c->out_data.size(); merged->count = dev->count + gen.count;
+  for (int i = 0; i < FGX_STATS_LEN; i++) merged->stats[i] = dev->stats[i] + gen.stats[i];
+  merged->ms_kernels = dev->ms_kernels + gen.ms_kernels; merged->ms_host_prep = gen.ms_host_prep; merged->ms_emit = gen.ms_emit;
+  return 0;
+}
+}  // namespace fgx
+}  // extern "C++"
+
 int fgx_group_records_device(fgx_caller* c, const fgx_group_options* g, const void* d_records, uint64_t records_len, const void* d_rec_off,
                              const void* d_rec_len, uint32_t n_rec, void* d_out_rec_off, void* d_out_rec_len, void* d_grp_first,
                              uint32_t* n_kept, uint32_t* n_grp) {

@@ -196,6 +196,10 @@ void bgzf_inflate_launch(hipStream_t s, const uint8_t* d_raw, const BgzfDevBlock
 int bgzf_inflate_status(fgx_caller* c, uint32_t status_word);
 void bgzf_crc_blocks_device(fgx_caller* c, const uint8_t* d_in, uint64_t len, uint32_t* d_crcs);
 int bgzf_deflate_device(fgx_caller* c, const uint8_t* d_in, uint64_t len, DevBuf& slots, DevBuf& scratch, DevBuf& meta, DevBuf& packed, uint64_t* packed_len);
+// api.cpp — fgx_run_bam's way of deciding ONLY the groups the device entry just deferred (general path on copies of their records) and
+// merging them into the device's record stream on the host; -1 = not possible here, take the whole-batch way
+int resubmit_deferred(fgx_caller* c, const uint8_t* d_blob, const uint64_t* d_rec_off, const uint32_t* d_rec_len, uint32_t n_rec, const uint32_t* d_grp_first, uint32_t n_grp,
+                      const fgx_output* dev, uint32_t n_def, const uint32_t* d_def, fgx_output* merged);
 // pipeline.cpp — frees what fgx_run_bam keeps in c->pipe_state
 void pipeline_release(fgx_caller* c);
 // filter.hip — `fgumi filter` on the device

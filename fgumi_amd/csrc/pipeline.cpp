@@ -39,6 +39,8 @@
 #include "../../include/fgumi_amd.h"
 
 namespace {
+bool subset_enabled() { const char* e = getenv("FGX_PIPE_SUBSET"); return e && e[0] == '1'; }
+bool pipe_debug() { static const bool on = [] { const char* e = getenv("FGX_PIPE_DEBUG"); return e && e[0] == '1'; }(); return on; }
 
 using Clock = std::chrono::steady_clock;
 double since(Clock::time_point t) { return std::chrono::duration<double>(Clock::now() - t).count(); }
@@ -755,9 +757,27 @@ int fgx_run_bam(fgx_caller* c, const char* in_path, const char* out_path, const 
           }
           ch.out_len = out.data_len; ch.have_crcs = true;
           sec_d2h += since(t0);
+        } else if (subset_enabled() && [&] {
+                     // Opt-in (FGX_PIPE_SUBSET=1): only the deferred groups come back (their records, a span per group), the general path
+                     // decides them, and the merged stream is assembled on the host — the batch is not uploaded and run a second time.
+                     fgx_output merged;
+                     const int mrc = fgx::resubmit_deferred(c, base, d_koff.as<uint64_t>(), d_klen.as<uint32_t>(), batch_rec, d_grp.as<uint32_t>(), batch_grp, &out, n_def,
+                                                            (const uint32_t*)d_def, &merged);
+                     if (mrc > 0) throw std::runtime_error(c->err);
+                     if (mrc < 0) return false;                          // (not possible here: the whole-batch way below)
+                     st->deferred_groups += n_def;
+                     if (pipe_debug()) fprintf(stderr, "fgx_run_bam: %u of %u groups deferred: decided alone (general path on their records), merged on the host\n", n_def, batch_grp);
+                     ch.out.reserve(merged.data_len + 64, true);
+                     if (merged.data_len) memcpy(ch.out.p, merged.data, merged.data_len);
+                     ch.out_len = merged.data_len;
+                     out = merged;
+                     sec_cons += since(t0);
+                     return true;
+                   }()) {
         } else {
           // families the device pipelines do not decide: the whole batch through the host entry (it splices both paths in group order)
           st->deferred_groups += n_def;
+          if (pipe_debug()) fprintf(stderr, "fgx_run_bam: %u of %u groups deferred: the whole batch through the host entry\n", n_def, batch_grp);
           h_blob.resize(batch_end + 16); h_off.resize(batch_rec); h_len.resize(batch_rec); h_grp.resize((size_t)batch_grp + 1);
           fgx::hip_check(hipMemcpy(h_blob.data(), base, batch_end, hipMemcpyDeviceToHost), "D2H");
           fgx::hip_check(hipMemcpy(h_off.data(), d_koff.p, (size_t)batch_rec * 8, hipMemcpyDeviceToHost), "D2H");

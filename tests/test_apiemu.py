@@ -348,3 +348,20 @@ def check_boundaries_and_grouping_kernels():
 
 def test_boundaries_and_grouping_kernels_on_the_host():
     run_isolated("test_apiemu", "check_boundaries_and_grouping_kernels", env=env())
+
+
+@pytest.mark.parametrize("defer", ["mod3", "indel"])
+def test_pipeline_resubmits_only_the_deferred_groups(defer):
+    """FGX_PIPE_SUBSET=1: fgx_run_bam sends only the groups the device entry deferred (copies of their records) through the general path and
+    merges on the host, instead of the whole batch through the host entry.  The file-to-file tests, with the stand-in deferring groups in
+    every batch: the consensus BAM equals the oracle's either way."""
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    e.update(env(FGX_PIPE_SUBSET=1, APIEMU_DEFER=defer, FGX_PIPE_DEBUG=1))
+    p = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_pipeline.py", "-m", "gpu", "-q", "-x", "-s", "-k", "not device_deflate and not device_boundaries",
+                        "-p", "no:cacheprovider"], env=e, cwd=apiemu.ROOT, capture_output=True, text=True, timeout=1800)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    trace = p.stdout + p.stderr
+    assert "8 passed" in trace
+    assert trace.count("decided alone") > (20 if defer == "mod3" else 0) and "the whole batch through the host entry" not in trace
