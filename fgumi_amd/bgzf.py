@@ -105,6 +105,9 @@ def recompress_file(in_path: str, out_path: str, level: int = 1, threads: Option
     return int(n.value)
 
 
+WRITE_PIECE_BLOCKS = 4096      # write_bam deflates 4096 blocks (≈ 267 MB of records) per native call
+
+
 def native_deflate(stream, level: int = 1, threads: Optional[int] = None, with_eof: bool = False):
     L = _native()
     if L is None:
@@ -162,13 +165,20 @@ def write_bam(path: str, header_text: str, refs: Sequence[Tuple[str, int]], reco
     """Writes header + `records` (a record stream with block_size prefixes) as a BGZF BAM.  The header gets its own blocks,
     the record stream is cut every 0xff00 bytes (records may straddle blocks, as in any BAM).  Returns the file size."""
     hdr_blocks = bgzf_compress(bam_header_bytes(header_text, refs), level, threads)
-    nat = native_deflate(records, level, threads, with_eof=True)
-    if nat is not None:                       # the library's block-parallel deflate (same framing, checked by tests/test_bgzf.py)
+    if _native() is not None:                 # the library's block-parallel deflate (same framing, checked by tests/test_bgzf.py)
+        # in bounded pieces of whole blocks (a piece and its compressed form are all that is held at a time: a 25 GB stream in one call
+        # would need twice that in host memory); cutting at multiples of the payload size gives the same blocks as one call
+        mv = memoryview(records).cast("B") if not isinstance(records, (bytes, bytearray)) else memoryview(records)
+        n, piece = len(mv), WRITE_PIECE_BLOCKS * BGZF_MAX_PAYLOAD
         size = 0
         with open(path, "wb") as f:
             for b in hdr_blocks:
                 f.write(b); size += len(b)
-            f.write(memoryview(nat[0])); size += int(nat[0].size)
+            for at in range(0, max(n, 1), piece):
+                last = at + piece >= n
+                arr, own = native_deflate(mv[at:at + piece], level, threads, with_eof=last)
+                f.write(memoryview(arr)); size += int(arr.size)
+                del arr, own
         return size
     rec_blocks = bgzf_compress(records, level, threads)
     size = 0

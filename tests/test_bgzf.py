@@ -159,3 +159,23 @@ def test_streaming_host_stages_reblock_a_bam_file(tmp_path):
     open(src, "wb").write(cut)
     with pytest.raises(ValueError):
         bgzf.recompress_file(src, dst)
+
+
+def test_write_bam_deflates_in_bounded_pieces(tmp_path):
+    """write_bam hands the native deflate whole-block pieces (so that a 25 GB stream never sits twice in host memory): the file does not
+    depend on the piece size."""
+    import gzip
+    rng = np.random.default_rng(3)
+    recs = (rng.integers(0, 4, size=700_000, dtype=np.uint8) + 65).tobytes()
+    old = bgzf.WRITE_PIECE_BLOCKS
+    try:
+        files = []
+        for blocks in (4096, 3, 1):
+            bgzf.WRITE_PIECE_BLOCKS = blocks
+            p = str(tmp_path / f"p{blocks}.bam")
+            bgzf.write_bam(p, "@HD\tVN:1.6\n", [], recs)
+            files.append(open(p, "rb").read())
+        assert files[0] == files[1] == files[2]
+        assert gzip.decompress(files[0]).endswith(recs) and files[0].endswith(bgzf.BGZF_EOF)
+    finally:
+        bgzf.WRITE_PIECE_BLOCKS = old
