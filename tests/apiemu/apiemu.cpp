@@ -8,8 +8,8 @@
 //     (FindBoundaries: segment guesses, walks, mutual check) and grouping.hip (the MI grouper) — through tests/devemu's shim (a launch = a
 //     serial loop over the grid, hipcub scans = serial sums);
 //   * zlib for the BGZF inflate / CRC kernels (LDS tables, 64-lane folds: no host form), so that fgx_run_bam runs end to end;
-//   * host stand-ins for the column and annotation kernels' launchers, built from the functions those kernels call (column_emu.h,
-//     methylation_core.h);
+//   * kernels.hip itself (k_column_jobs, k_meth_annotate, the device libm self-test, the simulator: plain lane-per-item kernels), so the
+//     general path's per-base work is done by the real kernel sources;
 //   * a stand-in for the device-resident pipeline (`FastPath::run`): it DEFERS groups by a rule (a read that is not one aligned block,
 //     like the real duplex / CODEC kernels; APIEMU_DEFER=mod3 defers every third group as well, =none nothing) and decides the others
 //     through the product's general path on a helper caller, handing back records, per-group offsets, counters and the deferred list
@@ -24,10 +24,9 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+#include "../../fgumi_amd/csrc/bamrec.h"
 #include "../../fgumi_amd/csrc/engine.h"
 #include "../../fgumi_amd/csrc/fastpath.h"
-#include "../../fgumi_amd/csrc/methylation_core.h"
-#include "../hostemu/column_emu.h"
 
 // ---- fake HIP runtime ---------------------------------------------------------------------------------------------------------------
 extern "C" {
@@ -54,24 +53,6 @@ hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; 
 }
 
 namespace fgx {
-
-// ---- the general path's kernels: their launchers walk the tiles on the host -----------------------------------------------------
-void launch_column_jobs(hipStream_t, const uint8_t* d_stage, const ReadDesc* d_reads, const ColJob* d_jobs, const Tile* d_tiles, uint32_t n_tiles,
-                        const DeviceTables* d_tables, ColParams prm, uint8_t* d_ob, uint8_t* d_oq, uint16_t* d_od, uint16_t* d_oe) {
-  for (uint32_t t = 0; t < n_tiles; t++) {
-    const ColJob& j = d_jobs[d_tiles[t].job];
-    for (uint32_t p = d_tiles[t].p0; p < d_tiles[t].p0 + 64 && p < j.cons_len; p++) emu::column_position(d_stage, d_reads, *d_tables, prm, j, p, d_ob, d_oq, d_od, d_oe);
-  }
-}
-void launch_meth_annotate(hipStream_t, uint8_t* d_stage, const ReadDesc* d_reads, const MethJob* d_jobs, const MethRun* d_runs, const MethTile* d_tiles, uint32_t n_tiles,
-                          const uint8_t* d_genome, uint8_t* d_flag, uint32_t* d_unconverted, uint32_t* d_converted) {
-  for (uint32_t t = 0; t < n_tiles; t++) {
-    const MethJob& j = d_jobs[d_tiles[t].job];
-    for (uint32_t p = d_tiles[t].p0; p < d_tiles[t].p0 + 64 && p < j.n_pos; p++)
-      meth_annotate_position(d_stage, d_reads + j.rd0, j.n_reads, d_runs + j.run0, j.n_runs, d_genome + j.contig_off, j.contig_len, j.top != 0, p, &d_flag[j.out_off + p],
-                             &d_unconverted[j.out_off + p], &d_converted[j.out_off + p]);
-  }
-}
 
 int simplex_process_general(fgx_caller*, const uint8_t*, const uint64_t*, const uint32_t*, uint32_t, const uint32_t*, uint32_t, fgx_output*);
 int duplex_process_general(fgx_caller*, const uint8_t*, const uint64_t*, const uint32_t*, uint32_t, const uint32_t*, uint32_t, fgx_output*);
@@ -155,7 +136,8 @@ void FastPath::release() {
 // ---- the lane-per-item kernels, compiled for the host (tests/devemu's shim; this file's runtime definitions stay as they are) -------
 #define DEVEMU_EMBEDDED 1
 #include "../devemu/devemu.cpp"
-// FindBoundaries and the MI grouper are lane-per-item kernels around scans as well: the real sources, on the host
+// the general path's kernels, FindBoundaries and the MI grouper are lane-per-item kernels (around scans) as well: the real sources, on the host
+#include "../../fgumi_amd/csrc/kernels.hip"
 #include "../../fgumi_amd/csrc/boundaries.hip"
 #include "../../fgumi_amd/csrc/grouping.hip"
 

@@ -211,12 +211,14 @@ def test_host_entry_gpu_tests_run_against_the_emulation():
     """The GPU tests that go through the HOST entry (simplex / duplex / CODEC parity batches, the reference's unit-test inputs, the
     methylation-aware mode, the duplex canonical pass) run as they are against tests/apiemu: the host side they exercise — validation,
     hybrid splice, general path, record assembly — is then covered on the CPU as well, by the very assertions the hardware run makes.
-    Tests that need a real device (the device-resident entry with torch tensors, the device libm, kernels with no stand-in) are left out."""
+    The per-base work of the general path is done by the REAL kernels.hip sources compiled for the host (k_column_jobs, k_meth_annotate,
+    the device libm self-test).  Tests that need a real device (the device-resident entry with torch tensors, kernels with wavefront
+    intrinsics and no host form) are left out."""
     import subprocess
     import sys
     files = ["tests/test_gpu_parity.py", "tests/test_gpu_duplex.py", "tests/test_gpu_codec.py", "tests/test_gpu_methylation.py", "tests/test_gpu_duplex_canon.py",
              "tests/test_gpu_pipeline.py"]            # (fgx_run_bam: BAM file -> consensus BAM file == the oracle; boundaries.hip / grouping.hip are the real sources)
-    skip = "not device_libm and not device_resident and not full_size and not stay_on_the_device and not noisy_batch and not device_deflate and not device_boundaries"
+    skip = "not device_resident and not full_size and not stay_on_the_device and not noisy_batch and not device_deflate and not device_boundaries"
     e = dict(os.environ)
     e.update(env())
     p = subprocess.run([sys.executable, "-m", "pytest"] + files + ["-m", "gpu", "-q", "-x", "-k", skip, "-p", "no:cacheprovider", "-n", "4"],
@@ -225,7 +227,7 @@ def test_host_entry_gpu_tests_run_against_the_emulation():
     assert p.returncode == 0, tail + p.stderr[-3000:]
     import re
     m = re.search(r"(\d+) passed", tail)
-    assert m and int(m.group(1)) >= 178, tail
+    assert m and int(m.group(1)) >= 186, tail
 
 
 def check_hybrid_fuzz(kind, seed0, n_seeds):
