@@ -666,6 +666,7 @@ static int hybrid_after_upload(fgx_caller* c, general_fn general, const uint8_t*
   auto ms = ms_between;
   if (!c->fast) c->fast = new FastState();
   c->fast->has_last = false;   // this run overwrites (and may reallocate) the device buffers a device-resident batch left behind
+  c->last_group_off = nullptr;
   hip_check(hipSetDevice(c->device), "hipSetDevice");
   auto t0 = clk::now();
   auto t1 = t0;
@@ -788,7 +789,8 @@ static bool canon_resident_enabled(int kind) {
   return (kind == FGX_CALLER_DUPLEX && duplex_canon_enabled()) || (kind == FGX_CALLER_CODEC && codec_canon_enabled());
 }
 
-struct ResidentOut { const uint8_t* d_out; uint64_t out_len, count, stats[FGX_STATS_LEN]; uint32_t n_deferred; const uint32_t* d_deferred; uint64_t n_canon; double ms_kernels; };
+struct ResidentOut { const uint8_t* d_out; uint64_t out_len, count, stats[FGX_STATS_LEN]; uint32_t n_deferred; const uint32_t* d_deferred; uint64_t n_canon; double ms_kernels;
+                     const uint64_t* d_group_off; };   // byte offset of every group in the merged stream (n_grp + 1 entries, device)
 
 static bool canon_resident_pass(fgx_caller* c, const uint8_t* d_blob, const uint64_t* d_rec_off, const uint32_t* d_rec_len, const uint32_t* d_grp_first, uint32_t n_grp,
                                 const FastResult& fr, ResidentOut* ro) {
@@ -857,6 +859,7 @@ static bool canon_resident_pass(fgx_caller* c, const uint8_t* d_blob, const uint
   if (!left.empty()) hip_check(hipMemcpy(c->d_res_deferred.p, left.data(), left.size() * 4, hipMemcpyHostToDevice), "H2D remaining deferred");
   ro->d_out = c->d_res_final.as<uint8_t>(); ro->out_len = final_len; ro->count = count1 + fr2.count;
   ro->n_deferred = (uint32_t)left.size(); ro->d_deferred = c->d_res_deferred.as<uint32_t>(); ro->n_canon = n_canon; ro->ms_kernels = fr2.ms_kernels;
+  ro->d_group_off = (const uint64_t*)(c->d_res_aux2.as<unsigned long long>() + (n_grp + 1));     // resident_merge_device: sizes | offsets | ...
   return true;
 }
 
@@ -874,6 +877,7 @@ int fgx_process_batch_device(fgx_caller* c, const void* d_records, uint64_t reco
     if (c->opt.methylation_mode != FGX_METHYLATION_DISABLED) { c->err = "fgx_process_batch_device: the methylation-aware mode needs the host entry (fgx_process_batch)"; return 1; }
     if (!c->fast) c->fast = new FastState();
     c->fast->has_last = false;   // set again only when this batch succeeds
+    c->last_group_off = nullptr;
     hip_check(hipSetDevice(c->device), "hipSetDevice");
     FastResult fr;
     c->fast->fp.run(c, (const uint8_t*)d_records, records_len, (const uint64_t*)d_rec_off, (const uint32_t*)d_rec_len, n_rec,
@@ -887,6 +891,7 @@ int fgx_process_batch_device(fgx_caller* c, const void* d_records, uint64_t reco
     if (n_deferred) *n_deferred = fr.n_deferred;
     if (d_deferred_groups) *d_deferred_groups = fr.d_deferred;
     c->last_deferred_groups = fr.n_deferred; c->last_canon_molecules = 0;
+    c->last_group_off = fr.d_out_off; c->last_group_stride = 3;
     if (fr.n_deferred > 0 && canon_resident_enabled(c->opt.caller_kind)) {
       ResidentOut ro;
       if (canon_resident_pass(c, (const uint8_t*)d_records, (const uint64_t*)d_rec_off, (const uint32_t*)d_rec_len, (const uint32_t*)d_grp_first, n_grp, fr, &ro)) {
@@ -897,6 +902,7 @@ int fgx_process_batch_device(fgx_caller* c, const void* d_records, uint64_t reco
         if (n_deferred) *n_deferred = ro.n_deferred;
         if (d_deferred_groups) *d_deferred_groups = ro.d_deferred;
         c->last_canon_molecules = ro.n_canon;
+        c->last_group_off = ro.d_group_off; c->last_group_stride = 1;
       }
     }
     if (dev_rejects) {   // out->rejects is a DEVICE pointer here, like out->data; it covers every group, the deferred ones included
@@ -914,14 +920,13 @@ int fgx_process_batch_device(fgx_caller* c, const void* d_records, uint64_t reco
 // of their records alone (one small device-to-host copy per group, instead of the whole batch coming back and going through the host
 // entry a second time), and the merged stream — the device's records with the general path's records inserted at the deferred groups'
 // places, group order kept — is assembled in the caller object's host buffer.  `dev` is the output of that fgx_process_batch_device call.
-// Returns 0 (merged filled: data on the host), or -1 when this cannot be done here (no slot table of the last device batch; CODEC
+// Returns 0 (merged filled: data on the host), or -1 when this cannot be done here (no group offsets of the last device batch; CODEC
 // molecules named by the running counter) and the caller must take the whole-batch way.
 extern "C++" {
 namespace fgx {
 int resubmit_deferred(fgx_caller* c, const uint8_t* d_blob, const uint64_t* d_rec_off, const uint32_t* d_rec_len, uint32_t n_rec, const uint32_t* d_grp_first, uint32_t n_grp,
                       const fgx_output* dev, uint32_t n_def, const uint32_t* d_def, fgx_output* merged) {
-  if (!c->fast || !c->fast->has_last || n_def == 0) return -1;
-  const FastResult& fr = c->fast->last;
+  if (!c->fast || !c->last_group_off || n_def == 0) return -1;
   general_fn general = c->opt.caller_kind == FGX_CALLER_SIMPLEX ? simplex_process_general : c->opt.caller_kind == FGX_CALLER_DUPLEX ? duplex_process_general : codec_process_general;
   std::vector<uint32_t> def(n_def);
   hip_check(hipMemcpy(def.data(), d_def, (size_t)n_def * 4, hipMemcpyDeviceToHost), "D2H deferred");
@@ -959,7 +964,7 @@ int resubmit_deferred(fgx_caller* c, const uint8_t* d_blob, const uint64_t* d_re
   if (c->opt.caller_kind == FGX_CALLER_CODEC && c->counter_names_used) return -1;
   // slot offsets of the deferred groups in the device's record stream (they hold nothing there), then the merge
   std::vector<uint64_t> at_dev(n_def);
-  for (uint32_t k = 0; k < n_def; k++) hip_check(hipMemcpy(&at_dev[k], fr.d_out_off + (size_t)3 * def[k], 8, hipMemcpyDeviceToHost), "D2H slot offset");
+  for (uint32_t k = 0; k < n_def; k++) hip_check(hipMemcpy(&at_dev[k], c->last_group_off + (size_t)c->last_group_stride * def[k], 8, hipMemcpyDeviceToHost), "D2H slot offset");
   std::vector<uint8_t> m;
   m.resize(dev->data_len + c->out_data.size() + 16);
   uint64_t w = 0, dpos = 0, gprev = 0;

@@ -160,6 +160,7 @@ struct fgx_caller {
   fgx::DevBuf d_canon_blob, d_canon_off, d_canon_len, d_canon_grp;   // canonical duplex molecules of the second device pass (canon_core.h)
   fgx::FilterBuffers* filt = nullptr;      // fgx_filter_records[_device] state (filter.hip)
   std::vector<uint8_t> rejects_host;       // host entry: the device-made rejects of the last batch (FGX_REJECTS_DEVICE=1)
+  const uint64_t* last_group_off = nullptr; uint32_t last_group_stride = 0;   // device-resident entry: byte offset of group g in its record stream = last_group_off[g * stride] (device memory; nullptr: none)
   uint32_t last_reject_oos = 0;            // ... groups its side kernels could not decide (the batch then took the general path)
   void* rej_state = nullptr;               // buffers of the device `--rejects` side kernels (reject_device.hip: reject_release)
   void* pipe_state = nullptr;              // buffers of fgx_run_bam, kept from run to run (pipeline.cpp: fgx_pipeline_release)

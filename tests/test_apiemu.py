@@ -352,8 +352,9 @@ def test_boundaries_and_grouping_kernels_on_the_host():
     run_isolated("test_apiemu", "check_boundaries_and_grouping_kernels", env=env())
 
 
+@pytest.mark.parametrize("resident", [0, 1])
 @pytest.mark.parametrize("defer", ["mod3", "indel"])
-def test_pipeline_resubmits_only_the_deferred_groups(defer):
+def test_pipeline_resubmits_only_the_deferred_groups(defer, resident):
     """FGX_PIPE_SUBSET=1: fgx_run_bam sends only the groups the device entry deferred (copies of their records) through the general path and
     merges on the host, instead of the whole batch through the host entry.  The file-to-file tests, with the stand-in deferring groups in
     every batch: the consensus BAM equals the oracle's either way."""
@@ -361,6 +362,8 @@ def test_pipeline_resubmits_only_the_deferred_groups(defer):
     import sys
     e = dict(os.environ)
     e.update(env(FGX_PIPE_SUBSET=1, APIEMU_DEFER=defer, FGX_PIPE_DEBUG=1))
+    if resident:            # with the canonical second pass inside the device entry: the merged stream's group offsets serve the resubmission
+        e.update(FGX_DUPLEX_CANON="1", FGX_CODEC_CANON="1", FGX_CANON_RESIDENT="1")
     p = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_pipeline.py", "-m", "gpu", "-q", "-x", "-s", "-k", "not device_deflate and not device_boundaries",
                         "-p", "no:cacheprovider"], env=e, cwd=apiemu.ROOT, capture_output=True, text=True, timeout=1800)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
