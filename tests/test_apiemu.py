@@ -370,3 +370,36 @@ def test_pipeline_resubmits_only_the_deferred_groups(defer, resident):
     trace = p.stdout + p.stderr
     assert "8 passed" in trace
     assert trace.count("decided alone") > (20 if defer == "mod3" else 0) and "the whole batch through the host entry" not in trace
+
+
+def check_pipeline_with_indel_duplex_molecules():
+    """fgx_run_bam over a duplex BAM in which two molecules in three carry indels, every combination of the opt-in switches the environment
+    holds: the consensus BAM equals the oracle's."""
+    import random
+    import tempfile
+    import pathlib
+    import test_canon_core as tc
+    import test_gpu_pipeline as tp
+    from fgumi_amd import DuplexConsensusCaller, GroupedReads, simulate_grouped_reads
+    rng = random.Random(91)
+    sim = simulate_grouped_reads(450, family_size=4, duplex=1)
+    groups, used = [], 0
+    for g in range(450):
+        m = tc.duplex_indel_molecule(rng, 7000 + g) if g % 3 else None
+        if not m:                                   # (every group its own MI: the pipeline regroups the stream by MI)
+            m, used = sim.records(used), used + 1
+        groups.append(m)
+    gr = GroupedReads.from_groups(groups)
+    o = fgx_opts.defaults(kind=1)
+    o.duplex_min_reads[0], o.duplex_min_reads[1], o.duplex_min_reads[2] = 1, 1, 0
+    c = DuplexConsensusCaller("", "A", [1, 1, 0], cell_tag="CB", overlapping_consensus=True)
+    with tempfile.TemporaryDirectory() as d:
+        st = tp._run_and_compare(pathlib.Path(d), c, o, gr, 100, 1 << 17, strip_strand_suffix=True, cell_tag=None)     # (the generator varies CB inside a molecule: group by MI alone)
+    c.close()
+    assert st["deferred_groups"] > 0
+
+
+@pytest.mark.parametrize("flags", [dict(), dict(FGX_PIPE_SUBSET=1), dict(FGX_DUPLEX_CANON=1, FGX_CANON_RESIDENT=1), dict(FGX_PIPE_SUBSET=1, FGX_DUPLEX_CANON=1, FGX_CANON_RESIDENT=1),
+                                   dict(FGX_PIPE_SUBSET=1, FGX_DUPLEX_CANON=1, FGX_CANON_DEVICE=1)])
+def test_pipeline_with_indel_duplex_molecules(flags):
+    run_isolated("test_apiemu", "check_pipeline_with_indel_duplex_molecules", env=env(**flags))
