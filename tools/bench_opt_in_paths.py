@@ -7,12 +7,16 @@
                    (+ FGX_CANON_DEVICE=1); every variant's bytes are compared with the first's.
   rejects        : a simplex batch with `track_rejects`, through fgx_process_batch with the side kernels off (whole batch on the general
                    path) and on (FGX_REJECTS_DEVICE=1).
+  pipeline       : a duplex BAM file with the same share of indel molecules through fgx_run_bam: the whole chunk through the host entry
+                   whenever its device batch defers groups (default), only the deferred groups (FGX_PIPE_SUBSET=1), and with the
+                   canonical second pass inside the device entry as well (+ FGX_DUPLEX_CANON=1 FGX_CANON_RESIDENT=1); the output files'
+                   records are compared.
 
 The indel molecules come from the test generators (tests/test_canon_core.py, tests/test_canon_codec.py: Python, a few thousand per
 second), so the batches are small — this measures per-molecule cost, not a roofline.  The environment switches are read per call, so one
 process times all variants.  Needs a GPU; `FGX_LIB=tests/hostemu/_build/libapiemu.so` dry-runs it on the CPU (times meaningless).
 
-usage: python tools/bench_opt_in_paths.py [--molecules 3000] [--indel-fraction 0.3] [--steps 3] [--cases duplex,codec,rejects]"""
+usage: python tools/bench_opt_in_paths.py [--molecules 3000] [--indel-fraction 0.3] [--steps 3] [--cases duplex,codec,rejects,pipeline]"""
 import argparse
 import ctypes as C
 import json
@@ -25,7 +29,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-FLAGS = ("FGX_DUPLEX_CANON", "FGX_CODEC_CANON", "FGX_CANON_DEVICE", "FGX_REJECTS_DEVICE")
+FLAGS = ("FGX_DUPLEX_CANON", "FGX_CODEC_CANON", "FGX_CANON_DEVICE", "FGX_REJECTS_DEVICE", "FGX_CANON_RESIDENT", "FGX_PIPE_SUBSET")
 
 
 def run(o, g, steps, **env):
@@ -59,12 +63,54 @@ def run(o, g, steps, **env):
         lib.fgx_destroy(h)
 
 
+def pipeline_case(a, rng):
+    import tempfile
+    import test_canon_core as tc
+    from fgumi_amd import DuplexConsensusCaller, GroupedReads, bgzf, simulate_grouped_reads
+    sim = simulate_grouped_reads(a.molecules, family_size=4, duplex=1)
+    groups, used = [], 0
+    for i in range(a.molecules):
+        m = tc.duplex_indel_molecule(rng, 10 ** 6 + i) if rng.random() < a.indel_fraction else None
+        if not m:
+            m, used = sim.records(used), used + 1
+        groups.append(m)
+    g = GroupedReads.from_groups(groups)
+    refs = [("chr%d" % (i + 1), 2147483647) for i in range(24)]
+    variants = [("whole chunk through the host entry", {}), ("only the deferred groups", dict(FGX_PIPE_SUBSET=1)),
+                ("only the deferred groups, canonical second pass inside the device entry", dict(FGX_PIPE_SUBSET=1, FGX_DUPLEX_CANON=1, FGX_CANON_RESIDENT=1))]
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "grouped.bam")
+        bgzf.write_bam(src, bgzf.grouped_input_header(refs), refs, g.blob)
+        ref = None
+        for name, env in variants:
+            for k in FLAGS:
+                os.environ.pop(k, None)
+            os.environ.update({k: "1" for k in env})
+            c = DuplexConsensusCaller("", "A", [1, 1, 0], cell_tag="CB", overlapping_consensus=True)
+            dst = os.path.join(d, "out.bam")
+            best = None
+            for i in range(a.steps + 1):
+                t0 = time.perf_counter()
+                st = c.run_bam(src, dst, strip_strand_suffix=True, cell_tag=None)
+                dt = time.perf_counter() - t0
+                if i and (best is None or dt < best):
+                    best = dt
+            c.close()
+            _, _, stream, off, ln = bgzf.read_bam(dst)
+            recs = b"".join(bytes(stream[int(o) - 4:int(o) + int(l)]) for o, l in zip(off, ln))
+            if ref is None:
+                ref = recs
+            print(json.dumps({"case": "pipeline", "variant": name, "workload": f"{g.n_grp} duplex molecules in a BAM file, {a.indel_fraction:.0%} with indel CIGARs",
+                              "raw_reads": int(g.n_rec), "unit": "file to file, best of steps", "ms": best * 1e3, "raw_reads_per_s": g.n_rec / best,
+                              "deferred_groups": st["deferred_groups"], "consensus_records": st["consensus_records"], "same_records_as_first_variant": recs == ref}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--molecules", type=int, default=3000)
     ap.add_argument("--indel-fraction", type=float, default=0.3)
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--cases", default="duplex,codec,rejects")
+    ap.add_argument("--cases", default="duplex,codec,rejects,pipeline")
     a = ap.parse_args()
     import fgx_opts
     import test_canon_codec as tcc
@@ -72,6 +118,9 @@ def main():
     from fgumi_amd import GroupedReads, simulate_grouped_reads
     rng = random.Random(1)
     for case in a.cases.split(","):
+        if case == "pipeline":
+            pipeline_case(a, rng)
+            continue
         if case == "rejects":
             sim = simulate_grouped_reads(a.molecules, family_size=1, family_size_max=9, seed=2)
             g = GroupedReads.from_groups([sim.records(i) for i in range(sim.n_grp)])
