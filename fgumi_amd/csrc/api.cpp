@@ -353,7 +353,7 @@ int fgx_canon_codec_host(const fgx_options* o, const uint8_t* blob, const uint64
 }
 
 // FGX_REJECTS_DEVICE=1: `--rejects` of the simplex caller without the general path (reject_device.hip).  Off by default: not yet run on hardware.
-static bool rejects_device_enabled() { const char* e = getenv("FGX_REJECTS_DEVICE"); return e && e[0] == '1'; }
+static bool rejects_device_enabled() { return opt_in("FGX_REJECTS_DEVICE"); }
 static rej::Params reject_params(const fgx_options* o) {
   rej::Params P;
   P.min_bq = o->min_input_base_quality; P.overlapping = o->overlapping_consensus; P.trim = o->trim; P.has_max_reads = o->max_reads >= 0;
@@ -535,14 +535,14 @@ static int process_hybrid(fgx_caller* c, general_fn general, const uint8_t* reco
 // cores and decided by the device pipeline in a SECOND pass; only what the canonical form cannot express (and what the second pass
 // still defers) takes the general path.  tests/test_canon_core.py shows through the oracle that the canonical molecule plus the
 // counted delta gives the original's result.  Off by default until the whole GPU suite has run with it.
-static bool duplex_canon_enabled() { const char* e = getenv("FGX_DUPLEX_CANON"); return e && e[0] == '1'; }
+static bool duplex_canon_enabled() { return opt_in("FGX_DUPLEX_CANON"); }
 // The same for CODEC molecules (FGX_CODEC_CANON=1; canon_core.h `canon_codec_molecule`, proof tests/test_canon_codec.py): virtual clip
 // applied, `<len>M`, reads placed so that the overlap geometry and the consensus length come out the same; every record is kept and
 // no counter moves, so there is no delta.  Only molecules the original would EMIT are in scope; rejected ones stay on the general path.
 // FGX_CANON_DEVICE=1 (with either flag above): the canonical form is computed by a device kernel (canon_device.hip, the same scalar source,
 // a lane per molecule) from the records already uploaded, instead of on the host's cores; the records do not come back.
-static bool canon_device_enabled() { const char* e = getenv("FGX_CANON_DEVICE"); return e && e[0] == '1'; }
-static bool codec_canon_enabled() { const char* e = getenv("FGX_CODEC_CANON"); return e && e[0] == '1'; }
+static bool canon_device_enabled() { return opt_in("FGX_CANON_DEVICE"); }
+static bool codec_canon_enabled() { return opt_in("FGX_CODEC_CANON"); }
 
 struct CanonPass {
   std::vector<uint8_t> used;            // per deferred group: 1 = its records come from the second device pass
@@ -784,8 +784,7 @@ int fgx_process_batch(fgx_caller* c, const uint8_t* records, uint64_t records_le
 // defers again, stays in the deferred list the caller re-submits.  The host sees the deferred indices, per-molecule status and counted
 // deltas — never a record.  Off by default: not yet run on hardware (tests/test_apiemu.py runs it on the CPU).
 static bool canon_resident_enabled(int kind) {
-  const char* e = getenv("FGX_CANON_RESIDENT");
-  if (!(e && e[0] == '1')) return false;
+  if (!opt_in("FGX_CANON_RESIDENT")) return false;
   return (kind == FGX_CALLER_DUPLEX && duplex_canon_enabled()) || (kind == FGX_CALLER_CODEC && codec_canon_enabled());
 }
 

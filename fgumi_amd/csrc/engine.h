@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 #include "../../include/fgumi_amd.h"
@@ -52,6 +53,15 @@ struct PinnedBuf {  // grow-only pinned host allocation
 };
 
 void hip_check(hipError_t e, const char* what);
+
+// The opt-in paths of round 3: a path is on when its own switch is "1" — "0" keeps it off — or, without one, when
+// FGX_OPT_IN_ALL=1 turns every one of them on (how the whole GPU suite is run with them before they become defaults).
+inline bool opt_in(const char* name) {
+  const char* e = getenv(name);
+  if (e && e[0]) return e[0] == '1';
+  const char* a = getenv("FGX_OPT_IN_ALL");
+  return a && a[0] == '1';
+}
 
 // kernels.hip
 void launch_column_jobs(hipStream_t s, const uint8_t* d_stage, const ReadDesc* d_reads, const ColJob* d_jobs, const Tile* d_tiles,

@@ -39,7 +39,7 @@
 #include "../../include/fgumi_amd.h"
 
 namespace {
-bool subset_enabled() { const char* e = getenv("FGX_PIPE_SUBSET"); return e && e[0] == '1'; }
+bool subset_enabled() { return fgx::opt_in("FGX_PIPE_SUBSET"); }
 bool pipe_debug() { static const bool on = [] { const char* e = getenv("FGX_PIPE_DEBUG"); return e && e[0] == '1'; }(); return on; }
 
 using Clock = std::chrono::steady_clock;

@@ -207,7 +207,8 @@ def test_canonical_pass_inside_the_device_entry(kind, kw, mr, defer):
     run_isolated("test_apiemu", "check_resident_pass", kind, kw, mr, env=env(FGX_DUPLEX_CANON=1, FGX_CODEC_CANON=1, FGX_CANON_RESIDENT=1, APIEMU_DEFER=defer))
 
 
-def test_host_entry_gpu_tests_run_against_the_emulation():
+@pytest.mark.parametrize("all_on", [0, 1])
+def test_host_entry_gpu_tests_run_against_the_emulation(all_on):
     """The GPU tests that go through the HOST entry (simplex / duplex / CODEC parity batches, the reference's unit-test inputs, the
     methylation-aware mode, the duplex canonical pass) run as they are against tests/apiemu: the host side they exercise — validation,
     hybrid splice, general path, record assembly — is then covered on the CPU as well, by the very assertions the hardware run makes.
@@ -220,7 +221,7 @@ def test_host_entry_gpu_tests_run_against_the_emulation():
              "tests/test_gpu_pipeline.py"]            # (fgx_run_bam: BAM file -> consensus BAM file == the oracle; boundaries.hip / grouping.hip are the real sources)
     skip = "not device_resident and not full_size and not stay_on_the_device and not noisy_batch and not device_deflate and not device_boundaries"
     e = dict(os.environ)
-    e.update(env())
+    e.update(env(FGX_OPT_IN_ALL=all_on))      # all_on: the rehearsal of "the whole suite with every opt-in path switched on" 
     p = subprocess.run([sys.executable, "-m", "pytest"] + files + ["-m", "gpu", "-q", "-x", "-k", skip, "-p", "no:cacheprovider", "-n", "4"],
                        env=e, cwd=apiemu.ROOT, capture_output=True, text=True, timeout=1800)
     tail = p.stdout[-3000:]
