@@ -404,3 +404,37 @@ def check_pipeline_with_indel_duplex_molecules():
                                    dict(FGX_PIPE_SUBSET=1, FGX_DUPLEX_CANON=1, FGX_CANON_DEVICE=1)])
 def test_pipeline_with_indel_duplex_molecules(flags):
     run_isolated("test_apiemu", "check_pipeline_with_indel_duplex_molecules", env=env(**flags))
+
+
+def check_device_simulator_equals_the_host_one():
+    """k_sim_generate (kernels.hip: the synthetic input of bench.py, written straight into HBM) against the host generator of the same
+    source (simgen.h): the same bytes, offsets and group boundaries — simplex, duplex and CODEC shapes, a family-size range."""
+    from fgumi_amd import VanillaUmiConsensusCaller, simulate_grouped_reads
+    from fgumi_amd._lib import SimParams, lib
+    c = VanillaUmiConsensusCaller("", "A")
+    try:
+        for kw in (dict(family_size=3), dict(family_size=2, family_size_max=9), dict(family_size=6, duplex=1), dict(family_size=3, read_length=300, insert_mean=350, insert_sd=60, codec=1)):
+            want = simulate_grouped_reads(400, seed=7, **kw)
+            p = SimParams()
+            p.seed, p.n_families, p.read_length, p.family_size = 7, 400, kw.get("read_length", 150), kw["family_size"]
+            p.insert_mean, p.insert_sd, p.error_rate_ppm = 300, 50, 1000
+            for k, v in kw.items():
+                if k not in ("family_size", "read_length"):
+                    setattr(p, k, v)
+            bl, nr = C.c_uint64(), C.c_uint64()
+            assert lib.fgx_sim_sizes(C.byref(p), C.byref(bl), C.byref(nr)) == 0
+            assert bl.value == want.blob.size and nr.value == want.n_rec
+            blob = np.zeros(bl.value + 16, dtype=np.uint8)
+            off = np.zeros(max(1, nr.value), dtype=np.uint64)
+            ln = np.zeros(max(1, nr.value), dtype=np.uint32)
+            grp = np.zeros(401, dtype=np.uint32)
+            rc = lib.fgx_sim_generate_device(c._h, C.byref(p), blob.ctypes.data, off.ctypes.data, ln.ctypes.data, grp.ctypes.data)
+            assert rc == 0, lib.fgx_last_error(c._h)
+            assert np.array_equal(blob[:bl.value], want.blob) and np.array_equal(off[:nr.value], want.rec_off) and np.array_equal(ln[:nr.value], want.rec_len)
+            assert np.array_equal(grp, want.grp_first)
+    finally:
+        c.close()
+
+
+def test_device_simulator_equals_the_host_one():
+    run_isolated("test_apiemu", "check_device_simulator_equals_the_host_one", env=env())
