@@ -21,6 +21,6 @@ def test_pipeline_file_tests_with_subset_resubmission():
     e = dict(os.environ)
     e.update(FGX_PIPE_SUBSET="1", FGX_PIPE_DEBUG="1")
     p = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_pipeline.py", "-m", "gpu", "-q", "-x", "-s", "-p", "no:cacheprovider"],
-                       env=e, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+                       env=e, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     assert "decided alone" in p.stdout + p.stderr          # (the 300-record family and the indel molecules are deferred on hardware)
