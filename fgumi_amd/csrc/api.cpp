@@ -932,27 +932,55 @@ int resubmit_deferred(fgx_caller* c, const uint8_t* d_blob, const uint64_t* d_re
   std::sort(def.begin(), def.end());
   std::vector<uint32_t> grp((size_t)n_grp + 1);
   hip_check(hipMemcpy(grp.data(), d_grp_first, ((size_t)n_grp + 1) * 4, hipMemcpyDeviceToHost), "D2H group boundaries");
-  // the deferred groups' record tables and bytes (a group's records lie in stream order: one span per group)
-  std::vector<uint8_t> blob;
-  std::vector<uint64_t> s_off, g_off;
+  // the deferred groups' record tables and bytes.  Few deferred groups: their table rows alone; many: the whole tables in one copy each
+  // (12 B per record).  A group's records lie in stream order, so its bytes are one span; spans that touch or nearly touch (runs of
+  // deferred groups) come back as one copy.
+  constexpr uint32_t BULK_TABLES = 64;
+  constexpr uint64_t JOIN_GAP = 4096;
+  std::vector<uint64_t> all_off;
+  std::vector<uint32_t> all_len;
+  if (n_def > BULK_TABLES) {
+    all_off.resize(n_rec); all_len.resize(n_rec);
+    if (n_rec) {
+      hip_check(hipMemcpy(all_off.data(), d_rec_off, (size_t)n_rec * 8, hipMemcpyDeviceToHost), "D2H rec_off");
+      hip_check(hipMemcpy(all_len.data(), d_rec_len, (size_t)n_rec * 4, hipMemcpyDeviceToHost), "D2H rec_len");
+    }
+  }
+  struct Span { uint64_t lo, hi; uint32_t first_rec, n; };          // per deferred group: its byte span, its rows in s_off / s_len
+  std::vector<Span> spans;
+  std::vector<uint64_t> s_off, g_off;            // s_off: first the offsets in the DEVICE blob, rebased below
   std::vector<uint32_t> s_len, s_grp(1, 0), g_len;
   for (uint32_t g : def) {
     if (g >= n_grp) return -1;
     const uint32_t r0 = grp[g], r1 = grp[g + 1];
     if (r1 > n_rec || r0 > r1) return -1;
     const uint32_t n = r1 - r0;
+    Span sp = {~0ull, 0, (uint32_t)s_off.size(), n};
     if (n) {
-      g_off.resize(n); g_len.resize(n);
-      hip_check(hipMemcpy(g_off.data(), d_rec_off + r0, (size_t)n * 8, hipMemcpyDeviceToHost), "D2H rec_off of a deferred group");
-      hip_check(hipMemcpy(g_len.data(), d_rec_len + r0, (size_t)n * 4, hipMemcpyDeviceToHost), "D2H rec_len of a deferred group");
-      uint64_t lo = ~0ull, hi = 0;
-      for (uint32_t i = 0; i < n; i++) { if (g_off[i] < lo) lo = g_off[i]; if (g_off[i] + g_len[i] > hi) hi = g_off[i] + g_len[i]; }
-      const size_t at = blob.size();
-      blob.resize(at + (size_t)(hi - lo));
-      hip_check(hipMemcpy(blob.data() + at, d_blob + lo, (size_t)(hi - lo), hipMemcpyDeviceToHost), "D2H records of a deferred group");
-      for (uint32_t i = 0; i < n; i++) { s_off.push_back(at + (g_off[i] - lo)); s_len.push_back(g_len[i]); }
+      const uint64_t* po; const uint32_t* pl;
+      if (!all_off.empty()) { po = all_off.data() + r0; pl = all_len.data() + r0; }
+      else {
+        g_off.resize(n); g_len.resize(n);
+        hip_check(hipMemcpy(g_off.data(), d_rec_off + r0, (size_t)n * 8, hipMemcpyDeviceToHost), "D2H rec_off of a deferred group");
+        hip_check(hipMemcpy(g_len.data(), d_rec_len + r0, (size_t)n * 4, hipMemcpyDeviceToHost), "D2H rec_len of a deferred group");
+        po = g_off.data(); pl = g_len.data();
+      }
+      for (uint32_t i = 0; i < n; i++) { if (po[i] < sp.lo) sp.lo = po[i]; if (po[i] + pl[i] > sp.hi) sp.hi = po[i] + pl[i]; s_off.push_back(po[i]); s_len.push_back(pl[i]); }
     }
+    spans.push_back(sp);
     s_grp.push_back((uint32_t)s_off.size());
+  }
+  std::vector<uint8_t> blob;
+  for (size_t a = 0; a < spans.size();) {
+    if (!spans[a].n) { a++; continue; }
+    uint64_t lo = spans[a].lo, hi = spans[a].hi;
+    size_t b = a + 1;
+    while (b < spans.size() && (!spans[b].n || (spans[b].lo >= lo && spans[b].lo <= hi + JOIN_GAP))) { if (spans[b].n && spans[b].hi > hi) hi = spans[b].hi; b++; }
+    const size_t at = blob.size();
+    blob.resize(at + (size_t)(hi - lo));
+    hip_check(hipMemcpy(blob.data() + at, d_blob + lo, (size_t)(hi - lo), hipMemcpyDeviceToHost), "D2H records of deferred groups");
+    for (size_t k = a; k < b; k++) for (uint32_t i = 0; i < spans[k].n; i++) s_off[spans[k].first_rec + i] = at + (s_off[spans[k].first_rec + i] - lo);
+    a = b;
   }
   blob.resize(blob.size() + 16);
   fgx_output gen;
@@ -963,7 +991,12 @@ int resubmit_deferred(fgx_caller* c, const uint8_t* d_blob, const uint64_t* d_re
   if (c->opt.caller_kind == FGX_CALLER_CODEC && c->counter_names_used) return -1;
   // slot offsets of the deferred groups in the device's record stream (they hold nothing there), then the merge
   std::vector<uint64_t> at_dev(n_def);
-  for (uint32_t k = 0; k < n_def; k++) hip_check(hipMemcpy(&at_dev[k], c->last_group_off + (size_t)c->last_group_stride * def[k], 8, hipMemcpyDeviceToHost), "D2H slot offset");
+  if (n_def > BULK_TABLES) {
+    std::vector<uint64_t> tab((size_t)n_grp * c->last_group_stride);
+    hip_check(hipMemcpy(tab.data(), c->last_group_off, tab.size() * 8, hipMemcpyDeviceToHost), "D2H group offsets");
+    for (uint32_t k = 0; k < n_def; k++) at_dev[k] = tab[(size_t)c->last_group_stride * def[k]];
+  } else
+    for (uint32_t k = 0; k < n_def; k++) hip_check(hipMemcpy(&at_dev[k], c->last_group_off + (size_t)c->last_group_stride * def[k], 8, hipMemcpyDeviceToHost), "D2H slot offset");
   std::vector<uint8_t> m;
   m.resize(dev->data_len + c->out_data.size() + 16);
   uint64_t w = 0, dpos = 0, gprev = 0;

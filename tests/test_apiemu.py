@@ -373,7 +373,7 @@ def test_pipeline_resubmits_only_the_deferred_groups(defer, resident):
     assert trace.count("decided alone") > (20 if defer == "mod3" else 0) and "the whole batch through the host entry" not in trace
 
 
-def check_pipeline_with_indel_duplex_molecules():
+def check_pipeline_with_indel_duplex_molecules(chunk=1 << 17):
     """fgx_run_bam over a duplex BAM in which two molecules in three carry indels, every combination of the opt-in switches the environment
     holds: the consensus BAM equals the oracle's."""
     import random
@@ -395,7 +395,7 @@ def check_pipeline_with_indel_duplex_molecules():
     o.duplex_min_reads[0], o.duplex_min_reads[1], o.duplex_min_reads[2] = 1, 1, 0
     c = DuplexConsensusCaller("", "A", [1, 1, 0], cell_tag="CB", overlapping_consensus=True)
     with tempfile.TemporaryDirectory() as d:
-        st = tp._run_and_compare(pathlib.Path(d), c, o, gr, 100, 1 << 17, strip_strand_suffix=True, cell_tag=None)     # (the generator varies CB inside a molecule: group by MI alone)
+        st = tp._run_and_compare(pathlib.Path(d), c, o, gr, 100, chunk, strip_strand_suffix=True, cell_tag=None)     # (the generator varies CB inside a molecule: group by MI alone)
     c.close()
     assert st["deferred_groups"] > 0
 
@@ -404,6 +404,8 @@ def check_pipeline_with_indel_duplex_molecules():
                                    dict(FGX_PIPE_SUBSET=1, FGX_DUPLEX_CANON=1, FGX_CANON_DEVICE=1)])
 def test_pipeline_with_indel_duplex_molecules(flags):
     run_isolated("test_apiemu", "check_pipeline_with_indel_duplex_molecules", env=env(**flags))
+    if flags.get("FGX_PIPE_SUBSET"):           # one chunk: hundreds of deferred groups in one batch (whole tables in one copy, joined spans)
+        run_isolated("test_apiemu", "check_pipeline_with_indel_duplex_molecules", 0, env=env(FGX_PIPE_DEBUG=1, **flags))
 
 
 def check_device_simulator_equals_the_host_one():
