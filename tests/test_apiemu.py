@@ -440,3 +440,24 @@ def check_device_simulator_equals_the_host_one():
 
 def test_device_simulator_equals_the_host_one():
     run_isolated("test_apiemu", "check_device_simulator_equals_the_host_one", env=env())
+
+
+def check_switch_semantics():
+    """FGX_OPT_IN_ALL=1 turns a path on, its own switch set to 0 keeps it off, set to 1 turns it on without ALL."""
+    import random
+    import test_canon_core as tc
+    import test_gpu_duplex_canon as tg
+    from fgumi_amd import GroupedReads
+    rng = random.Random(8)
+    gr = GroupedReads.from_groups([m for m in (tc.duplex_indel_molecule(rng, g) for g in range(60)) if m])
+    o = fgx_opts.defaults(kind=1)
+    for all_on, own, expect in ((None, None, False), ("1", None, True), ("1", "0", False), (None, "1", True), ("0", "1", True)):
+        for k, v in (("FGX_OPT_IN_ALL", all_on), ("FGX_DUPLEX_CANON", own)):
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+        assert (tg.product(o, gr)["canon"] > 0) == expect, (all_on, own)
+
+
+def test_switch_semantics():
+    run_isolated("test_apiemu", "check_switch_semantics", env=env())
