@@ -461,3 +461,27 @@ def check_switch_semantics():
 
 def test_switch_semantics():
     run_isolated("test_apiemu", "check_switch_semantics", env=env())
+
+
+def check_pipeline_with_indel_codec_molecules():
+    import random
+    import tempfile
+    import pathlib
+    import test_canon_codec as tcc
+    import test_gpu_pipeline as tp
+    from fgumi_amd import CodecConsensusCaller, CodecConsensusOptions, GroupedReads, simulate_grouped_reads
+    rng = random.Random(92)
+    sim = simulate_grouped_reads(300, family_size=3, read_length=150, insert_mean=200, insert_sd=30, codec=1)
+    groups = [tcc.codec_molecule(rng, 9000 + g) if g % 3 else sim.records(g // 3) for g in range(300)]
+    gr = GroupedReads.from_groups(groups)
+    o = fgx_opts.defaults(kind=2, overlapping_consensus=0, cell_tag=b"\0\0", produce_per_base_tags=1)
+    c = CodecConsensusCaller("", "A", CodecConsensusOptions(produce_per_base_tags=True))
+    with tempfile.TemporaryDirectory() as d:
+        st = tp._run_and_compare(pathlib.Path(d), c, o, gr, 1000, 1 << 17, cell_tag=None)
+    c.close()
+    assert st["deferred_groups"] > 0
+
+
+@pytest.mark.parametrize("flags", [dict(), dict(FGX_OPT_IN_ALL=1)])
+def test_pipeline_with_indel_codec_molecules(flags):
+    run_isolated("test_apiemu", "check_pipeline_with_indel_codec_molecules", env=env(**flags))
