@@ -485,3 +485,36 @@ def check_pipeline_with_indel_codec_molecules():
 @pytest.mark.parametrize("flags", [dict(), dict(FGX_OPT_IN_ALL=1)])
 def test_pipeline_with_indel_codec_molecules(flags):
     run_isolated("test_apiemu", "check_pipeline_with_indel_codec_molecules", env=env(**flags))
+
+
+def _rank_worker(rank, world, port, outdir, shape):
+    import torch
+    torch.cuda.set_device = lambda *a, **k: None          # (the emulation has no device to select)
+    import test_gpu_distributed as tgd
+    tgd._worker(rank, world, port, outdir, shape)
+
+
+def check_two_ranks_run_the_product():
+    """tests/test_gpu_distributed.py's body with the emulation on every rank: two processes over gloo, each runs its contiguous shard of the
+    family stream through the product's host entry, the payloads gathered in rank order and the summed counters equal the oracle's output
+    of the whole stream."""
+    import tempfile
+    import pathlib
+    import torch.multiprocessing as mp
+    import test_gpu_distributed as tgd
+    from fgumi_amd import simulate_grouped_reads
+    for shape in (dict(family_size=3), dict(family_size=2, family_size_max=50)):
+        with tempfile.TemporaryDirectory() as d:
+            world = 2
+            mp.spawn(_rank_worker, args=(world, tgd._free_port(), d, shape), nprocs=world, join=True)
+            g = simulate_grouped_reads(world * tgd.F_PER_RANK, **shape)
+            want = orc.process(fgx_opts.defaults(min_reads=1), g.blob, g.rec_off, g.rec_len, g.grp_first)
+            tmp = pathlib.Path(d)
+            assert np.load(tmp / "payload.npy").tobytes() == want["data"]
+            sizes, stats = np.load(tmp / "sizes.npy"), np.load(tmp / "stats.npy")
+            assert sizes[:, 1].sum() == want["count"] and sizes[:, 2].sum() == g.n_rec
+            assert np.array_equal(stats[:len(want["stats"])], want["stats"].astype(np.int64))
+
+
+def test_two_ranks_run_the_product_over_gloo():
+    run_isolated("test_apiemu", "check_two_ranks_run_the_product", env=env(APIEMU_DEFER="mod3"), timeout=600)
