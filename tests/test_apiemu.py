@@ -1,9 +1,15 @@
-"""The host plumbing of the opt-in device paths, executed on the CPU: tests/apiemu links the product's whole host side (api.cpp and the
-general path, unmodified) against a fake HIP runtime, the host-compiled lane-per-item kernels and a stand-in for the device-resident
-pipeline, and `FGX_LIB` makes the ordinary ctypes binding load that library — so the BODIES of the GPU tests of the canonical second
-pass (host- and "device"-canonicalised, duplex and CODEC) and of the `--rejects` side kernels (host entry and device entry) run here,
-in child interpreters, against the oracle.  APIEMU_DEFER=mod3 makes the stand-in defer every third group as well, which puts first-pass,
-second-pass and general-path records next to each other in every order the splice has to handle."""
+"""The product's host side, executed on the CPU: tests/apiemu links api.cpp, the general path, bgzf_host.cpp and pipeline.cpp — unmodified —
+against a fake HIP runtime, the lane-per-item kernel sources compiled for the host (kernels.hip, boundaries.hip, grouping.hip,
+reject_device.hip, canon_device.hip), zlib for the BGZF kernels and a stand-in for the device-resident pipeline (groups deferred by rule,
+the rest decided through the general path); `FGX_LIB` makes the ordinary ctypes binding load that library.  What runs here, in child
+interpreters, against the oracle:
+  * the BODIES of the GPU tests of every opt-in path: canonical second pass (form made on the host / by the kernel / inside the device
+    entry), `--rejects` side kernels through both entries, fgx_run_bam resubmitting only the deferred groups — and their combinations;
+  * the EXISTING host-entry GPU tests as they are (parity, duplex, CODEC, methylation, streaming pipeline), with the opt-in paths off and on;
+  * the hostile fuzz groups through the host entry; the sharded general path; two ranks over gloo; FindBoundaries / grouper / simulator
+    kernels against their host twins.
+APIEMU_DEFER=mod3 makes the stand-in defer every third group as well, which puts first-pass, second-pass and general-path records next to
+each other in every order the splices have to handle.  What this cannot show is the real kernels running on an MI355X."""
 import ctypes as C
 import os
 
