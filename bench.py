@@ -158,6 +158,7 @@ def main():
     ap.add_argument("--cpu-sample-families", type=int, default=320000, help="families of the multi-thread CPU leg (320000 x 16 = 5.12 M reads at depth 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--no-strong-block", action="store_true", help="weak runs also time the strong-scaling reading (`strong_scaling` in the line); this skips it")
     ap.add_argument("--reassemble", choices=["auto", "none", "root"], default="auto",
                     help="root: a second timed loop also gathers the shard payloads to rank 0 in rank (= input) order over RCCL, reported beside `value`; "
                          "auto = none")
@@ -196,73 +197,90 @@ def main():
     else:
         caller = VanillaUmiConsensusCaller("", "A", VanillaUmiConsensusOptions(min_reads=1, min_consensus_base_quality=2, cell_tag="CB"),
                                            overlapping_consensus=True, device=local_rank)
-    # synthetic families generated straight into HBM
-    if args.scaling == "strong" and world > 1:
-        # one stream of `families` molecules, cut where the running record bytes reach k/world of the total
-        w = simulated_family_bytes(args.families, family_size=args.depth, read_length=args.read_length, duplex=int(duplex), **sim_extra)
-        lo, hi = balanced_shards(w, world)[rank]
-        shard_bytes = int(w[lo:hi].sum())
-    else:
-        lo, hi = (rank * args.families, (rank + 1) * args.families) if args.scaling == "weak" else (0, args.families)
-        shard_bytes = None
-    fam = hi - lo
-    dg = caller.simulate_on_device(fam, family_size=args.depth, read_length=args.read_length, first_family=lo, duplex=int(duplex), **sim_extra)
-    if shard_bytes is None:
-        shard_bytes = int(dg.blob_len)
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_loop(steps, with_gather):
-        k_family_ms = k_emit_ms = k_total_ms = 0.0
-        gathered = 0
-        out = None
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            out = caller.process_batch_device(dg)
-            k_family_ms += caller.last_timing["k_family"]
-            k_emit_ms += caller.last_timing["k_emit"]
-            k_total_ms += caller.last_timing["kernels"]
-            if with_gather:
-                whole = gather_payload_to_root(out.as_tensor(local_rank), root=0)
-                if whole is not None:
-                    gathered = int(whole.numel())
-                del whole
-        barrier()
-        dt = max_over_ranks(time.perf_counter() - t0, "cuda")                            # MAX over ranks
-        return dt, out, k_family_ms, k_emit_ms, k_total_ms, gathered
+    def measure(scaling, steps, warmup, with_gather):
+        """One workload (weak: `families` per GPU; strong: `families` in total, cut into contiguous shards of equal record bytes),
+        generated straight into HBM, `warmup` untimed + `steps` timed passes (barrier + synchronize on both sides, MAX over ranks)."""
+        if scaling == "strong" and world > 1:
+            # one stream of `families` molecules, cut where the running record bytes reach k/world of the total
+            w = simulated_family_bytes(args.families, family_size=args.depth, read_length=args.read_length, duplex=int(duplex), **sim_extra)
+            lo, hi = balanced_shards(w, world)[rank]
+            shard_bytes = int(w[lo:hi].sum())
+        else:
+            lo, hi = (rank * args.families, (rank + 1) * args.families) if scaling == "weak" else (0, args.families)
+            shard_bytes = None
+        fam = hi - lo
+        dg = caller.simulate_on_device(fam, family_size=args.depth, read_length=args.read_length, first_family=lo, duplex=int(duplex), **sim_extra)
+        if shard_bytes is None:
+            shard_bytes = int(dg.blob_len)
 
-    out = None
-    for _ in range(args.warmup):
-        out = caller.process_batch_device(dg)
-    dt, out, k_family_ms, k_emit_ms, k_total_ms, _ = timed_loop(args.steps, False)       # the K timed steps: `value`
-    dt_gather, gathered_bytes = None, 0
-    if reassemble == "root":                                                              # the same K steps with the gather to rank 0
-        r = timed_loop(args.steps, True)
-        dt_gather, gathered_bytes = r[0], r[5]
-    per_rank = gather_sizes([out.data_len, out.count, dg.n_rec, out.n_deferred, fam, shard_bytes,
-                             int(round(k_family_ms / args.steps * 1e3)), int(round(k_emit_ms / args.steps * 1e3))], "cuda")   # rank (= input) order
+        def timed_loop(n_steps, gather):
+            k_family_ms = k_emit_ms = k_total_ms = 0.0
+            gathered = 0
+            out = None
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(n_steps):
+                out = caller.process_batch_device(dg)
+                k_family_ms += caller.last_timing["k_family"]
+                k_emit_ms += caller.last_timing["k_emit"]
+                k_total_ms += caller.last_timing["kernels"]
+                if gather:
+                    whole = gather_payload_to_root(out.as_tensor(local_rank), root=0)
+                    if whole is not None:
+                        gathered = int(whole.numel())
+                    del whole
+            barrier()
+            dt = max_over_ranks(time.perf_counter() - t0, "cuda")                            # MAX over ranks
+            return dt, out, k_family_ms, k_emit_ms, k_total_ms, gathered
+
+        out = None
+        for _ in range(warmup):
+            out = caller.process_batch_device(dg)
+        dt, out, k_family_ms, k_emit_ms, k_total_ms, _ = timed_loop(steps, False)           # the K timed steps: `value`
+        dt_gather, gathered_bytes = None, 0
+        if with_gather:                                                                      # the same K steps with the gather to rank 0
+            r = timed_loop(steps, True)
+            dt_gather, gathered_bytes = r[0], r[5]
+        per_rank = gather_sizes([out.data_len, out.count, dg.n_rec, out.n_deferred, fam, shard_bytes,
+                                 int(round(k_family_ms / steps * 1e3)), int(round(k_emit_ms / steps * 1e3))], "cuda")   # rank (= input) order
+        # the batch counters (ConsensusCallingStats / RejectionReason order, then the overlap CorrectionStats) summed over the ranks
+        counters = sum_over_ranks(caller.last_stats_array, "cuda")
+        res = dict(dt=dt, out_count=int(out.count), n_rec=int(dg.n_rec), fam=fam, k_family_ms=k_family_ms, k_emit_ms=k_emit_ms, k_total_ms=k_total_ms,
+                   dt_gather=dt_gather, gathered_bytes=gathered_bytes, per_rank=per_rank, counters=counters, full_columns=caller.last_timing.get("full_columns"))
+        del dg, out
+        torch.cuda.empty_cache()
+        return res
+
+    M = measure(args.scaling, args.steps, args.warmup, reassemble == "root")
+    dt, k_family_ms, k_emit_ms, k_total_ms = M["dt"], M["k_family_ms"], M["k_emit_ms"], M["k_total_ms"]
+    dt_gather, gathered_bytes, per_rank, counters, fam = M["dt_gather"], M["gathered_bytes"], M["per_rank"], M["counters"], M["fam"]
     total_bytes, total_cons, total_raw, total_def = [int(v) for v in per_rank[:, :4].sum(0).tolist()]
-    # the batch counters (ConsensusCallingStats / RejectionReason order, then the overlap CorrectionStats) summed over the ranks
-    counters = sum_over_ranks(caller.last_stats_array, "cuda")
+    # The other reading of the metric, in the SAME invocation (the driver runs `bench.py --gpus N` once per N): north_star's target is
+    # strong scaling — ONE stream of `families` molecules cut over the ranks.  The weak line's step IS the N=1 workload on every GPU
+    # (`families` per GPU), so its step time is this run's own N=1 reference: speedup_vs_n1 = weak ms_per_step / strong ms_per_step.
+    S = None
+    if args.scaling == "weak" and not args.no_strong_block:
+        S = measure("strong", max(1, min(args.steps, 10)), 1, reassemble == "root" and world > 1)
 
     if rank == 0:
         L = args.read_length
         steps = args.steps
         # algorithmic bytes of ONE k_family launch on ONE GPU (SURVEY.md §8d): per raw read ceil(L/2)+L read,
         # per consensus read 6*Lc written (bases, quals, depth i16, errors i16)
-        alg_read = dg.n_rec * ((L + 1) // 2 + L)
-        alg_write = out.count * 6 * L          # (per consensus read, once — also for duplex / CODEC records)
+        alg_read = M["n_rec"] * ((L + 1) // 2 + L)
+        alg_write = M["out_count"] * 6 * L          # (SURVEY 8d: per consensus read, once — also for duplex / CODEC records)
         k_avg_s = k_family_ms / steps / 1e3
         achieved = (alg_read + alg_write) / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
         plain = not (duplex or codec or args.depth_max)
         pmc, pmc_file = pmc_profile(fam, args.depth, L) if plain else (None, None)
         # the arithmetic floor of the dominant kernel: every observation (read x position) costs two Kahan chains = 8 dependent
         # f64 add/sub on the vector ALUs (full rate: one per lane per 4 cycles)
-        valu_floor_ms = dg.n_rec * L * F64_OPS_PER_OBSERVATION / F64_LANE_OPS_PER_S * 1e3
+        valu_floor_ms = M["n_rec"] * L * F64_OPS_PER_OBSERVATION / F64_LANE_OPS_PER_S * 1e3
         shape = (f"CODEC consensus, {args.depth} pairs of 2x{L}bp, insert N(350,60) (BASELINE configs[4] shape)" if codec else
                  f"duplex consensus, {args.depth} pairs split over /A and /B, {L}bp paired (BASELINE configs[2] shape)" if duplex else
                  f"simplex consensus, depth {args.depth}..{args.depth_max} pairs (long tail), {L}bp paired (BASELINE configs[3] shape)" if args.depth_max else
@@ -293,7 +311,7 @@ def main():
                        "k_family_ms_per_rank": [v / 1e3 for v in per_rank[:, 6].tolist()], "k_emit_ms_per_rank": [v / 1e3 for v in per_rank[:, 7].tolist()],
                        "counters_all_ranks": {"total_reads": counters[0], "consensus_reads": counters[1], "filtered_reads": counters[2],
                                               "rejected_by_reason": counters[3:24], "overlap_correction": counters[24:28]},
-                       "columns_needing_call_full_per_step": caller.last_timing.get("full_columns")},
+                       "columns_needing_call_full_per_step": M["full_columns"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          # HBM bytes of one launch: 2 x FETCH_SIZE (gfx950 correction for wide coalesced reads) + WRITE_SIZE, KiB → bytes,
                          # from the committed PMC passes (`traffic_source`), NOT measured in this run
@@ -317,6 +335,25 @@ def main():
                                             if (pmc and "SQ_ACTIVE_INST_VALU" in pmc and k_avg_s > 0) else None),
                          "pmc_kernel": pmc["kernel"] if pmc else None, "pmc_source": pmc_file},
         }
+        if S is not None:
+            s_raw = int(S["per_rank"][:, 2].sum())
+            s_steps = max(1, min(args.steps, 10))
+            s_ms = S["dt"] / s_steps * 1e3
+            line["strong_scaling"] = {
+                "workload": f"{args.families} families in TOTAL, cut into {world} contiguous shards of equal record bytes (distributed.balanced_shards)",
+                "value": s_raw * s_steps / S["dt"], "unit": "raw reads/s", "steps": s_steps, "warmup": 1, "ms_per_step": s_ms,
+                # this run's weak step is the N=1 workload on every GPU at once: the N=1 reference measured in the same process, same box
+                "speedup_vs_n1": (dt / steps * 1e3) / s_ms if s_ms > 0 else None,
+                "n1_reference": "ms_per_step of this line (weak: the same `families` per GPU = the N=1 workload)",
+                "families_per_rank": [int(v) for v in S["per_rank"][:, 4].tolist()], "raw_reads_per_rank": [int(v) for v in S["per_rank"][:, 2].tolist()],
+                "input_bytes_per_rank": [int(v) for v in S["per_rank"][:, 5].tolist()],
+                "k_family_ms_per_rank": [v / 1e3 for v in S["per_rank"][:, 6].tolist()], "k_emit_ms_per_rank": [v / 1e3 for v in S["per_rank"][:, 7].tolist()],
+                "deferred_families": int(S["per_rank"][:, 3].sum()),
+                # N=1 self-check: the strong reading IS the weak workload there — same counters, value within 2 %
+                "n1_self_check": None if world > 1 else {"counters_equal_the_weak_line": S["counters"] == counters,
+                                                         "value_within_2pct_of_the_weak_line": abs((s_raw * s_steps / S["dt"]) / (total_raw * steps / dt) - 1.0) < 0.02},
+                "value_with_reassembly_on_root": (s_raw * s_steps / S["dt_gather"]) if S["dt_gather"] else None,
+            }
         if not args.no_cpu_baseline and world == 1 and not args.depth_max:
             # threads = the CPUs the container may really use (cgroup quota): oversubscribing a throttled cgroup only adds queueing
             line["cpu_baseline"] = cpu_baseline(min(fam, args.cpu_sample_families), args.depth, L, min(os.cpu_count() or 1, cgroup_cpu_quota() or 1 << 30), duplex, codec)

@@ -269,15 +269,16 @@ int fgx_set_reference(fgx_caller* c, uint32_t n_ref, const uint8_t* const* seqs,
   try {
     if (n_ref == 0) { c->genome.reset(); for (fgx_caller* w : c->workers) w->genome.reset(); return 0; }
     if (!seqs || !lens) { c->err = "fgx_set_reference: null sequence table"; return 1; }
-    for (uint32_t i = 0; i < n_ref; i++) if (!seqs[i] && lens[i]) { c->err = "fgx_set_reference: contig " + std::to_string(i) + " of the header has no sequence (every header contig must be in the FASTA)"; return 1; }
     hip_check(hipSetDevice(c->device), "hipSetDevice");
     auto g = std::make_shared<GenomeRef>();
     g->device = c->device;
     uint64_t total = 0;
-    for (uint32_t i = 0; i < n_ref; i++) { g->off.push_back(total); g->len.push_back(lens[i]); total += lens[i]; }
+    // a header contig that the FASTA does not hold (seqs[i] == NULL) is an EMPTY contig: every base of it is unknown and the annotation is
+    // emitted with zero counts, as the reference does for a contig missing from its reference map (methylation.rs: `reference.get(..)` -> None)
+    for (uint32_t i = 0; i < n_ref; i++) { const uint64_t L = seqs[i] ? lens[i] : 0; g->off.push_back(total); g->len.push_back(L); total += L; }
     g->d_genome.reserve(total + 64);
     for (uint32_t i = 0; i < n_ref; i++)
-      if (lens[i]) hip_check(hipMemcpy((uint8_t*)g->d_genome.p + g->off[i], seqs[i], lens[i], hipMemcpyHostToDevice), "genome H2D");
+      if (g->len[i]) hip_check(hipMemcpy((uint8_t*)g->d_genome.p + g->off[i], seqs[i], lens[i], hipMemcpyHostToDevice), "genome H2D");
     c->genome = g;
     for (fgx_caller* w : c->workers) w->genome = g;
     return 0;
@@ -352,7 +353,7 @@ int fgx_canon_codec_host(const fgx_options* o, const uint8_t* blob, const uint64
   return canon::canon_codec_molecule(canon_codec_params(o), blob, rec_off, rec_len, n, out, rec_off, out_len, *S);
 }
 
-// FGX_REJECTS_DEVICE=1: `--rejects` of the simplex caller without the general path (reject_device.hip).  Off by default: not yet run on hardware.
+// `--rejects` of the simplex caller without the general path (reject_device.hip): the default since round 4, FGX_REJECTS_DEVICE=0 opts out.
 static bool rejects_device_enabled() { return opt_in("FGX_REJECTS_DEVICE"); }
 static rej::Params reject_params(const fgx_options* o) {
   rej::Params P;
@@ -501,10 +502,12 @@ static int process_hybrid(fgx_caller* c, general_fn general, const uint8_t* reco
                           const uint32_t* rec_len, uint32_t n_rec, const uint32_t* grp_first, uint32_t n_grp, fgx_output* out) {
   // --rejects (record copies in input order) and the methylation-aware mode (reference lookups per source read) are decided by the
   // general path: host orchestration, device kernels for the per-base work
-  // Opt-in (FGX_REJECTS_DEVICE=1), simplex caller: the rejects come from side kernels that evaluate the caller's rejection decisions on the
+  // Simplex caller (default; FGX_REJECTS_DEVICE=0 opts out): the rejects come from side kernels that evaluate the caller's rejection decisions on the
   // uploaded records, a lane per group (reject_device.hip / reject_core.h), and the records from the device pipeline as without --rejects.
   const bool dev_rejects = c->opt.track_rejects && c->opt.caller_kind == FGX_CALLER_SIMPLEX && c->opt.methylation_mode == FGX_METHYLATION_DISABLED && n_grp != 0 &&
                            rejects_device_enabled();
+  c->last_canon_molecules = 0;
+  c->last_deferred_groups = n_grp;          // (diagnostics, fgx_debug_last_deferral: the whole batch on the general path counts as every group deferred)
   if ((c->opt.track_rejects && !dev_rejects) || c->opt.methylation_mode != FGX_METHYLATION_DISABLED || n_grp == 0) return run_general(c, general, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
   if (!c->fast) c->fast = new FastState();
   auto t0 = clk::now();
@@ -530,11 +533,11 @@ static int process_hybrid(fgx_caller* c, general_fn general, const uint8_t* reco
 
 // Kernels, download and the splice with the general path's output for the deferred families.  `dst` (pinned, dst_cap bytes):
 // when the records fit they are downloaded straight there and out->data == dst; otherwise they land in the caller's own buffers.
-// Opt-in (FGX_DUPLEX_CANON=1): duplex molecules the device pipeline deferred because of indel / skip / pad CIGARs are rewritten into
+// Default since round 4 (FGX_DUPLEX_CANON=0 / FGX_CODEC_CANON=0 opt out): duplex molecules the device pipeline deferred because of indel / skip / pad CIGARs are rewritten into
 // their canonical form (canon_core.h: overlap correction, mate clip and alignment filter applied; every read `<len>M`) on the host's
 // cores and decided by the device pipeline in a SECOND pass; only what the canonical form cannot express (and what the second pass
 // still defers) takes the general path.  tests/test_canon_core.py shows through the oracle that the canonical molecule plus the
-// counted delta gives the original's result.  Off by default until the whole GPU suite has run with it.
+// counted delta gives the original's result.  On by default since the whole GPU suite ran with it (round 4).
 static bool duplex_canon_enabled() { return opt_in("FGX_DUPLEX_CANON"); }
 // The same for CODEC molecules (FGX_CODEC_CANON=1; canon_core.h `canon_codec_molecule`, proof tests/test_canon_codec.py): virtual clip
 // applied, `<len>M`, reads placed so that the overlap geometry and the consensus length come out the same; every record is kept and
@@ -681,6 +684,7 @@ static int hybrid_after_upload(fgx_caller* c, general_fn general, const uint8_t*
   if (fr.out_len) hip_check(hipMemcpy((void*)fast_out, fr.d_out, fr.out_len, hipMemcpyDeviceToHost), "D2H out");
   auto t3 = clk::now();
   memset(out, 0, sizeof(*out));
+  c->last_deferred_groups = fr.n_deferred;
   if (fr.n_deferred == 0) {
     out->data = fast_out; out->data_len = fr.out_len; out->count = fr.count;
     for (int i = 0; i < FGX_STATS_LEN; i++) out->stats[i] = fr.stats[i];
@@ -782,7 +786,7 @@ int fgx_process_batch(fgx_caller* c, const uint8_t* records, uint64_t records_le
 // the first pass deferred are canonicalised by the kernel of canon_device.hip where they lie, decided by the device pipeline in a second
 // pass, and the two passes' records are merged in group order on the device; what the canonical form cannot express, or the second pass
 // defers again, stays in the deferred list the caller re-submits.  The host sees the deferred indices, per-molecule status and counted
-// deltas — never a record.  Off by default: not yet run on hardware (tests/test_apiemu.py runs it on the CPU).
+// deltas — never a record.  Default since round 4 (FGX_CANON_RESIDENT=0 opts out); tests/test_apiemu.py also runs it on the CPU.
 static bool canon_resident_enabled(int kind) {
   if (!opt_in("FGX_CANON_RESIDENT")) return false;
   return (kind == FGX_CALLER_DUPLEX && duplex_canon_enabled()) || (kind == FGX_CALLER_CODEC && codec_canon_enabled());
@@ -915,7 +919,7 @@ int fgx_process_batch_device(fgx_caller* c, const void* d_records, uint64_t reco
   } catch (const std::exception& ex) { c->err = ex.what(); return 3; }
 }
 
-// pipeline.cpp (opt-in FGX_PIPE_SUBSET=1): the groups the device-resident entry has JUST deferred are decided by the general path from copies
+// pipeline.cpp (default; FGX_PIPE_SUBSET=0 opts out): the groups the device-resident entry has JUST deferred are decided by the general path from copies
 // of their records alone (one small device-to-host copy per group, instead of the whole batch coming back and going through the host
 // entry a second time), and the merged stream — the device's records with the general path's records inserted at the deferred groups'
 // places, group order kept — is assembled in the caller object's host buffer.  `dev` is the output of that fgx_process_batch_device call.
@@ -1166,6 +1170,8 @@ int fgx_filter_records(fgx_caller* c, const fgx_filter_options* f, const uint8_t
 // diagnostics of the last fgx_process_batch call that deferred groups: out2 = {groups the first device pass deferred, of those the
 // molecules the canonical second pass decided (FGX_DUPLEX_CANON=1)}
 void fgx_debug_last_deferral(const fgx_caller* c, uint64_t* out2) { if (c && out2) { out2[0] = c->last_deferred_groups; out2[1] = c->last_canon_molecules; } }
+// chunks of the record / column split pipeline in the last device batch (FGX_SPLIT_CHUNKS, or 8 / 4 / 1 by batch size); 0 = it did not run
+uint32_t fgx_debug_last_split_chunks(const fgx_caller* c) { return (c && c->fast) ? c->fast->fp.last_split_chunks : 0u; }
 // 1: route everything through the general host path (parity tests of that path); 0: hybrid (default)
 void fgx_set_general_only(fgx_caller* c, int on) { if (c) c->general_only = on != 0; }
 // dynamic LDS bytes of the large-family launch of the family kernel (default 48 KiB)

@@ -1,4 +1,4 @@
-// canon_device.hip — the canonical form of deferred duplex / CODEC molecules computed ON THE DEVICE (opt-in, FGX_CANON_DEVICE=1 on top of
+// canon_device.hip — the canonical form of deferred duplex / CODEC molecules computed ON THE DEVICE (default since round 4, FGX_CANON_DEVICE=0 opts out; on top of
 // FGX_DUPLEX_CANON / FGX_CODEC_CANON): one lane per molecule runs the scalar source of canon_core.h — the very functions
 // tests/test_canon_core.py and tests/test_canon_codec.py prove through the oracle on the host — over the records that the host entry
 // already uploaded, and writes the canonical records into a second device blob.  The records never come back to the host: only the

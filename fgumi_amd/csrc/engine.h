@@ -54,13 +54,15 @@ struct PinnedBuf {  // grow-only pinned host allocation
 
 void hip_check(hipError_t e, const char* what);
 
-// The opt-in paths of round 3: a path is on when its own switch is "1" — "0" keeps it off — or, without one, when
-// FGX_OPT_IN_ALL=1 turns every one of them on (how the whole GPU suite is run with them before they become defaults).
+// The device paths that were opt-in in round 3 (canonical second pass for indel duplex / CODEC molecules, its device kernel, the pass
+// inside the device-resident entry, the --rejects side kernels, subset resubmission in the streaming pipeline) are the DEFAULT since
+// round 4; the environment only opts OUT: a path is off when its own switch is "0", or, without one, when FGX_OPT_IN_ALL=0 turns every
+// one of them off (the round-3 behaviour, kept for A/B measurements and the opt-out tests).
 inline bool opt_in(const char* name) {
   const char* e = getenv(name);
-  if (e && e[0]) return e[0] == '1';
+  if (e && e[0]) return e[0] != '0';
   const char* a = getenv("FGX_OPT_IN_ALL");
-  return a && a[0] == '1';
+  return !(a && a[0] == '0');
 }
 
 // kernels.hip

@@ -188,6 +188,7 @@ struct FastPath {
   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: one flag per FastPath (= per caller = per device), not per process
   bool lds_attr_set = false, s2_attr_set = false, v2_attr_set = false;
   static constexpr int MAX_CHUNKS = 16;
+  uint32_t last_split_chunks = 0;         // chunks the record / column pipeline ran the last batch in (0: another head of the chain); diagnostics
   hipStream_t s2 = nullptr;
   hipEvent_t ev_chunk[MAX_CHUNKS] = {}, ev_cols[MAX_CHUNKS] = {}, ev_fin = nullptr, ev_sample = nullptr;
   int run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const uint64_t* d_rec_off, const uint32_t* d_rec_len, uint32_t n_rec,

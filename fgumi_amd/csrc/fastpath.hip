@@ -3455,10 +3455,9 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
   {
     const uint32_t stages[3] = {wave_bytes, 12288u, 22016u};
     if (!lds_attr_set) {
-      (void)hipFuncSetAttribute((const void*)k_family_wave<0>, hipFuncAttributeMaxDynamicSharedMemorySize, WAVES_PER_BLOCK * 22016);
-      (void)hipFuncSetAttribute((const void*)k_family_wave<1>, hipFuncAttributeMaxDynamicSharedMemorySize, WAVES_PER_BLOCK * 22016);
-      (void)hipFuncSetAttribute((const void*)k_family_wave<2>, hipFuncAttributeMaxDynamicSharedMemorySize, WAVES_PER_BLOCK * 22016);
-      (void)hipGetLastError();
+      hip_check(hipFuncSetAttribute((const void*)k_family_wave<0>, hipFuncAttributeMaxDynamicSharedMemorySize, WAVES_PER_BLOCK * 22016), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_family_wave<0>: the device refused the dynamic LDS size");
+      hip_check(hipFuncSetAttribute((const void*)k_family_wave<1>, hipFuncAttributeMaxDynamicSharedMemorySize, WAVES_PER_BLOCK * 22016), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_family_wave<1>: the device refused the dynamic LDS size");
+      hip_check(hipFuncSetAttribute((const void*)k_family_wave<2>, hipFuncAttributeMaxDynamicSharedMemorySize, WAVES_PER_BLOCK * 22016), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_family_wave<2>: the device refused the dynamic LDS size");
       lds_attr_set = true;
     }
     d_retry2.reserve((size_t)n_grp * 4);
@@ -3471,13 +3470,13 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
     // growing LDS slices; what is outside its shape is collected in `retry_old` and goes through the k_family_wave<0> launches below.
     uint32_t n_v2 = n_grp;
     const uint32_t* v2_list = nullptr;
+    last_split_chunks = 0;
     if (use_split) {
       // k_split_cols over growing LDS slices (4 / 2 / 1 / 1 wavefronts per workgroup); what it does not take is collected in
       // `route` and starts the k_simplex_wave2 chain below
         if (!s2_attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_split_cols<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        (void)hipFuncSetAttribute((const void*)k_split_cols<160, 80>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        (void)hipGetLastError();
+        hip_check(hipFuncSetAttribute((const void*)k_split_cols<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_split_cols<0, 0>: the device refused the dynamic LDS size");
+        hip_check(hipFuncSetAttribute((const void*)k_split_cols<160, 80>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_split_cols<160, 80>: the device refused the dynamic LDS size");
         s2_attr_set = true;
       }
       if (!d_s2img.p) {   // the tables of a caller never change: one image per FastPath
@@ -3517,6 +3516,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       uint32_t n_chunks = chunks_env >= 1 ? (uint32_t)chunks_env : (n_grp >= 400000u ? 8u : n_grp >= 100000u ? 4u : 1u);
       if (n_chunks > (uint32_t)MAX_CHUNKS - 1) n_chunks = MAX_CHUNKS - 1;   // (the last event marks where the second stream starts)
       uint32_t chunk_fam = (n_grp + n_chunks - 1) / n_chunks;
+      last_split_chunks = n_chunks;
       chunk_fam = ((chunk_fam + 4 * fpw - 1) / (4 * fpw)) * (4 * fpw);      // whole workgroups of both kernels per chunk
       hip_check(hipEventRecord(ev_chunk[MAX_CHUNKS - 1], s), "event");      // (the second stream starts where this one is: buffers, memsets)
       hip_check(hipStreamWaitEvent(s2, ev_chunk[MAX_CHUNKS - 1], 0), "wait");
@@ -3570,7 +3570,8 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
         FastParams PS = P;
         PS.group_list = s2_list; PS.lds_wave_bytes = st2[ci].bytes;
         PS.retry = last ? nullptr : lists[s2_out]; PS.n_retry = d_cnt;
-        const uint32_t wpb = st2[ci].wpb;
+        if (st2[ci].bytes > 65536u) continue;                 // (more than the attribute limit set above: the family goes down the chain)
+        const uint32_t wpb = std::min<uint32_t>(st2[ci].wpb, 65536u / st2[ci].bytes);   // wpb x slice within the 64 KiB requested for k_split_cols
         const size_t lds = (size_t)wpb * st2[ci].bytes;
         auto launch_cols = [&](uint32_t g_first, uint32_t count) {
           PS.g0 = g_first;
@@ -3617,10 +3618,9 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       // Launch chain: k_simplex_seg<4> / <2> (4 / 2 families per wavefront, while the mean family fits a quarter / half of the
       // wave's LDS) → k_simplex_wave2 over the growing slices.  A family that does not fit a launch moves to the next one.
         if (!v2_attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_simplex_wave2, hipFuncAttributeMaxDynamicSharedMemorySize, WAVES_PER_BLOCK * 22016);
-        (void)hipFuncSetAttribute((const void*)k_simplex_seg<2>, hipFuncAttributeMaxDynamicSharedMemorySize, WAVES_PER_BLOCK * 32768);
-        (void)hipFuncSetAttribute((const void*)k_simplex_seg<4>, hipFuncAttributeMaxDynamicSharedMemorySize, WAVES_PER_BLOCK * 32768);
-        (void)hipGetLastError();
+        hip_check(hipFuncSetAttribute((const void*)k_simplex_wave2, hipFuncAttributeMaxDynamicSharedMemorySize, WAVES_PER_BLOCK * 22016), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_simplex_wave2: the device refused the dynamic LDS size");
+        hip_check(hipFuncSetAttribute((const void*)k_simplex_seg<2>, hipFuncAttributeMaxDynamicSharedMemorySize, WAVES_PER_BLOCK * 32768), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_simplex_seg<2>: the device refused the dynamic LDS size");
+        hip_check(hipFuncSetAttribute((const void*)k_simplex_seg<4>, hipFuncAttributeMaxDynamicSharedMemorySize, WAVES_PER_BLOCK * 32768), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_simplex_seg<4>: the device refused the dynamic LDS size");
         v2_attr_set = true;
       }
       if (!d_w2img.p) {   // the tables of a caller never change: one image per FastPath
@@ -3704,8 +3704,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       FastParams P2 = P;
       P2.group_list = cur_list; P2.retry = nullptr; P2.n_retry = nullptr;
       if (const char* e = getenv("FGX_LDS_TILE_LARGE")) { uint32_t v = (uint32_t)atoi(e); if (v >= 16384 && v <= 163840) lds_tile_bytes_large = v & ~15u; P2.lds_tile_bytes = lds_tile_bytes_large; }   // tuning knob
-      (void)hipFuncSetAttribute((const void*)k_family, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile_bytes_large);
-      (void)hipGetLastError();
+      hip_check(hipFuncSetAttribute((const void*)k_family, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile_bytes_large), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_family: the device refused the dynamic LDS size");
       hipLaunchKernelGGL(k_family, dim3(n_cur), dim3(NT), lds_tile_bytes_large, s, P2);
       hip_check(hipGetLastError(), "k_family (large) launch");
     }

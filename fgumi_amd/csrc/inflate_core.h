@@ -52,14 +52,18 @@ struct BitReader {
 FGX_HD inline uint64_t infl_load64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
 // at least 56 valid bits afterwards.  The bytes come from `nxt`, which was asked for at the PREVIOUS refill: on the device a refill is a
 // global-memory round trip, and this way it runs under the five or so symbols decoded in between instead of in front of them.
-// (Reads up to 16 bytes past the payload.)
+// Reads at most 8 bytes past the payload, whatever the stream claims: once `pos` has passed the end (a corrupt or truncated payload
+// that keeps decoding zero bits) the load address stays at base + len — for a valid stream the same bytes as before, since nothing
+// beyond the payload is ever consumed — and the decoding loops give up as soon as `pos` proves the overrun (infl_overrun).
 FGX_HD inline void infl_refill(BitReader& r) {
   r.bb |= r.nxt << r.bc;
   r.pos += (63u - r.bc) >> 3;
   r.bc |= 56u;
-  r.nxt = infl_load64(r.base + r.pos);
+  r.nxt = infl_load64(r.base + (r.pos < r.len ? r.pos : r.len));
 }
-FGX_HD inline void infl_seek(BitReader& r, uint32_t pos) { r.pos = pos; r.bb = 0; r.bc = 0; r.nxt = infl_load64(r.base + pos); }
+// after a refill (bc >= 56): more than 8 bytes past the end means bits beyond the payload HAVE been consumed (pos - bc / 8 > len)
+FGX_HD inline bool infl_overrun(const BitReader& r) { return r.pos > r.len + 8u; }
+FGX_HD inline void infl_seek(BitReader& r, uint32_t pos) { r.pos = pos; r.bb = 0; r.bc = 0; r.nxt = infl_load64(r.base + (pos < r.len ? pos : r.len)); }
 FGX_HD inline uint32_t infl_bits(BitReader& r, uint32_t n) {   // n <= 16, bc >= n
   const uint32_t v = (uint32_t)(r.bb & ((1ull << n) - 1ull));
   r.bb >>= n; r.bc -= n;
@@ -208,7 +212,7 @@ FGX_HD inline void infl_store_pending(uint8_t* dst, uint32_t n, uint64_t v0, uin
 }
 
 // inflates `in[0 .. in_len)` into `out[0 .. out_len)`; the stream must produce exactly out_len bytes (the block's ISIZE).
-// `in` must be readable for 16 bytes past in_len.  F / W: this lane's tables (LDS / private memory on the device).
+// `in` must be readable for 8 bytes past in_len (no load goes further, also for corrupt input).  F / W: this lane's tables (LDS / private memory on the device).
 template <class FastPtr>
 FGX_HD inline int inflate_block_t(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, FastPtr f_lit, FastPtr f_dist, InflateSlow& W) {
   constexpr uint32_t LB = FGX_INFL_LIT_BITS, DB = FGX_INFL_DIST_BITS;
@@ -259,7 +263,7 @@ FGX_HD inline int inflate_block_t(const uint8_t* in, uint32_t in_len, uint8_t* o
         infl_walk_setup(W.dist_count, DB, wc);
         uint32_t n = 0;
         while (n < hlit + hdist) {
-          if (r.bc < 32) infl_refill(r);
+          if (r.bc < 32) { infl_refill(r); if (infl_overrun(r)) return INFL_INPUT_OVERRUN; }
           const int32_t s = infl_decode<DB>(r, f_dist, wc, W.dist_sym);
           if (s < 0) return INFL_BAD_CODE_LENGTHS;
           if (s < 16) lens[n++] = (uint8_t)s;
@@ -280,7 +284,7 @@ FGX_HD inline int inflate_block_t(const uint8_t* in, uint32_t in_len, uint8_t* o
       infl_walk_setup(W.lit_count, LB, wl);
       infl_walk_setup(W.dist_count, DB, wd);
       for (;;) {
-        if (r.bc < 48) infl_refill(r);                 // a length + distance pair takes at most 15 + 5 + 15 + 13 = 48 bits
+        if (r.bc < 48) { infl_refill(r); if (infl_overrun(r)) return INFL_INPUT_OVERRUN; }   // a length + distance pair takes at most 15 + 5 + 15 + 13 = 48 bits
         int32_t s = infl_decode<LB>(r, f_lit, wl, W.lit_sym);
         if (s < 0) return INFL_BAD_SYMBOL;
         if (s < 256) {

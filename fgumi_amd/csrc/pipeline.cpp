@@ -79,16 +79,24 @@ class Pool {
     for (auto& t : ts_) t.join();
   }
   unsigned size() const { return (unsigned)ts_.size(); }
-  // fn(index, worker id); worker ids are 0 .. size() (the calling thread helps as worker `size()`)
+  static constexpr unsigned MAX_HELPERS = 8;   // stage threads that may be inside parallel_for at the same time
+  // fn(index, worker id); worker ids are 0 .. size() + MAX_HELPERS - 1: the pool's threads, then one id PER CALLING THREAD that is
+  // helping right now (two stage threads inside parallel_for at once used to share the id size(), and with it any per-worker scratch)
   void parallel_for(size_t n, size_t grain, const std::function<void(size_t, unsigned)>& fn) {
     if (n == 0) return;
     auto job = std::make_shared<Job>();
     job->n = n; job->grain = grain ? grain : 1; job->fn = &fn;
-    { std::lock_guard<std::mutex> l(m_); jobs_.push_back(job); }
+    int helper = -1;
+    {
+      std::lock_guard<std::mutex> l(m_);
+      jobs_.push_back(job);
+      for (unsigned k = 0; k < MAX_HELPERS; k++) if (!(helpers_busy_ & (1u << k))) { helpers_busy_ |= 1u << k; helper = (int)k; break; }
+    }
     cv_.notify_all();
-    work(*job, size());
+    if (helper >= 0) work(*job, size() + (unsigned)helper);   // (every helper id taken: this caller only waits)
     std::unique_lock<std::mutex> l(m_);
     job->cv.wait(l, [&] { return job->done.load() >= job->n; });
+    if (helper >= 0) helpers_busy_ &= ~(1u << helper);
     for (size_t i = 0; i < jobs_.size(); i++) if (jobs_[i] == job) { jobs_.erase(jobs_.begin() + (long)i); break; }
   }
 
@@ -127,6 +135,7 @@ class Pool {
   std::vector<std::thread> ts_;
   std::vector<std::shared_ptr<Job>> jobs_;
   std::mutex m_;
+  unsigned helpers_busy_ = 0;   // bit k: helper id size() + k is in use (under m_)
   std::condition_variable cv_;
   bool stop_ = false;
 };
@@ -276,7 +285,7 @@ struct Pipeline {
     if (!fout) { if (file) munmap((void*)file, file_len); close(fd); err = std::string("cannot create ") + out_path; return 1; }
     if (raw_chunk < (1u << 16)) raw_chunk = 1u << 16;             // (a BGZF block is at most 64 KiB: every chunk holds at least one)
     Pool pool(threads ? threads : usable_cpus());
-    const unsigned n_workers = pool.size() + 8;                 // (+ the stage threads that help)
+    const unsigned n_workers = pool.size() + Pool::MAX_HELPERS;   // (+ the stage threads that help, each under its own id)
 
     std::thread t_read([&] {
       try {
@@ -717,7 +726,7 @@ int fgx_run_bam(fgx_caller* c, const char* in_path, const char* out_path, const 
           uint64_t o = 0;
           fgx::hip_check(hipMemcpy(&o, d_koff.as<uint64_t>() + first_of_last, 8, hipMemcpyDeviceToHost), "D2H");
           batch_grp = n_grp - 1; batch_rec = first_of_last; batch_end = o - 4;
-        } else { batch_grp = 0; batch_rec = 0; batch_end = 0; }
+        } else { batch_grp = 0; batch_rec = 0; batch_end = consumed; }   // (nothing kept: only the partial record behind `consumed` is pending — not the header, not the alignment bytes in front)
       }
       // ---- consensus ----
       t0 = Clock::now();
@@ -758,7 +767,7 @@ int fgx_run_bam(fgx_caller* c, const char* in_path, const char* out_path, const 
           ch.out_len = out.data_len; ch.have_crcs = true;
           sec_d2h += since(t0);
         } else if (subset_enabled() && [&] {
-                     // Opt-in (FGX_PIPE_SUBSET=1): only the deferred groups come back (their records, a span per group), the general path
+                     // Default (FGX_PIPE_SUBSET=0 opts out): only the deferred groups come back (their records, a span per group), the general path
                      // decides them, and the merged stream is assembled on the host — the batch is not uploaded and run a second time.
                      fgx_output merged;
                      const int mrc = fgx::resubmit_deferred(c, base, d_koff.as<uint64_t>(), d_klen.as<uint32_t>(), batch_rec, d_grp.as<uint32_t>(), batch_grp, &out, n_def,

@@ -1,4 +1,4 @@
-// reject_device.hip — the simplex caller's `--rejects` stream on the device (opt-in, FGX_REJECTS_DEVICE=1), beside the unchanged consensus
+// reject_device.hip — the simplex caller's `--rejects` stream on the device (default since round 4, FGX_REJECTS_DEVICE=0 opts out), beside the unchanged consensus
 // pipeline: every rejection of the vanilla caller is decided before the per-position arithmetic (reject_core.h has the list and the
 // reference lines), so a side kernel evaluates that decision, one lane per MI group, only when rejects are asked for, and the hot kernels
 // carry no per-record flags.  tests/test_reject_core.py proves the lane body against the reference restatement on the host.

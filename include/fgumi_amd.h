@@ -129,7 +129,8 @@ int fgx_libm_self_check(char* msg, uint64_t msg_cap);
 /* Replaces `VanillaUmiConsensusCaller::set_reference(reference, ref_names)` (vanilla_caller.rs:512-522) and
  * `DuplexConsensusCaller::set_reference` (duplex_caller.rs:524-536) after `load_methylation_reference` (src/lib/commands/common.rs:108-144):
  * the reference genome of the methylation-aware mode.  Contig i of the BAM header (= a record's ref_id) is seqs[i], lens[i] bases as the
- * FASTA holds them (any case; every header contig must be present, as the reference's loader requires).  The sequences are copied into
+ * FASTA holds them (any case).  seqs[i] == NULL stands for a contig the FASTA does not hold: an empty contig, every base unknown — the
+ * caller-level `set_reference` accepts any provider; failing fast on missing contigs is the CLI loader's job (common.rs:131-141).  The sequences are copied into
  * HBM once (one byte per base; a human genome is 3.1 GB of the 288) and every batch's annotation kernel reads them there.  n_ref = 0
  * drops the reference.  With a methylation mode set and no reference, reads are called without annotation or tags, as the reference
  * does (annotate_and_normalize, vanilla_caller.rs:792-797).  Returns 0, or non-zero with fgx_last_error(c). */
@@ -158,11 +159,12 @@ int fgx_process_batch(fgx_caller* c, const uint8_t* records, uint64_t records_le
  * consensus records left in HBM: the measured configuration of bench.py and the multi-GPU path.
  * `out->data` is a DEVICE pointer; `out->stats` is copied back (224 bytes).  Families the device
  * pipelines do not decide (reads with more than 6 CIGAR ops, unmapped reads, malformed records; for
- * duplex / CODEC also molecules with indels or a biting per-strand read cap) are reported in
+ * duplex / CODEC also what the canonical form does not cover) are reported in
  * *n_deferred / d_deferred_groups and must be re-submitted through fgx_process_batch; 0 for
- * `simulate`-shaped input (with FGX_DUPLEX_CANON / FGX_CODEC_CANON and FGX_CANON_RESIDENT set, opt-in and not yet run on hardware, the
- * entry decides the indel molecules its canonical form covers in a second device pass and only the rest is reported).  `track_rejects` is refused here, except for the simplex caller when FGX_REJECTS_DEVICE=1 is set in the
- * environment (side kernels, fgumi_amd/csrc/reject_device.hip; not yet run on hardware): `out->rejects` is then a DEVICE pointer too and
+ * `simulate`-shaped input.  Duplex / CODEC molecules with indels or clips are canonicalised and decided in a second device pass
+ * inside this entry (default since round 4; FGX_DUPLEX_CANON / FGX_CODEC_CANON / FGX_CANON_RESIDENT = 0 opt out).  `track_rejects`
+ * is accepted for the simplex caller (side kernels, fgumi_amd/csrc/reject_device.hip; FGX_REJECTS_DEVICE=0 opts out and the entry then
+ * refuses `track_rejects`): `out->rejects` is then a DEVICE pointer too and
  * covers every group, the deferred ones included.  The kernels stage a family's bytes in whole 16-byte pieces: `d_records` must be
  * READABLE for 16 bytes past `records_len` (any allocation larger than the stream by 16 bytes will do; the
  * bytes are never interpreted).  The host entry above pads its own device copy. */

@@ -83,9 +83,9 @@ def test_codec_canonical_second_pass(kw, defer, on_device):
     run_isolated("test_gpu_zz_codec_canon", "check_codec_indel_molecules", kw, env=env(FGX_CODEC_CANON=1, FGX_CANON_DEVICE=on_device, APIEMU_DEFER=defer))
 
 
-def test_canonical_pass_off_by_default():
-    run_isolated("test_gpu_duplex_canon", "test_second_pass_is_off_by_default", env=env())
-    run_isolated("test_gpu_zz_codec_canon", "check_off_by_default", env=env())
+def test_canonical_pass_can_be_switched_off():
+    run_isolated("test_gpu_duplex_canon", "check_second_pass_can_be_switched_off", env=env())
+    run_isolated("test_gpu_zz_codec_canon", "check_switched_off", env=env(FGX_CODEC_CANON=0))
 
 
 def check_device_entry_emu(kw, seed):
@@ -142,8 +142,8 @@ def test_rejects_side_kernels_device_entry(kw):
 
 
 def test_rejects_without_the_flag_take_the_general_path():
-    run_isolated("test_gpu_zz_rejects_device", "check_host_entry", dict(min_reads=2), 11, env=env())          # (whole batch on the general path: same answer)
-    run_isolated("test_apiemu", "check_device_entry_refuses_without_the_flag", env=env())
+    run_isolated("test_gpu_zz_rejects_device", "check_host_entry", dict(min_reads=2), 11, env=env(FGX_REJECTS_DEVICE=0))          # (whole batch on the general path: same answer)
+    run_isolated("test_apiemu", "check_device_entry_refuses_without_the_flag", env=env(FGX_REJECTS_DEVICE=0))
 
 
 def check_resident_pass(kind, kw, mr, on_gpu=False):
@@ -375,7 +375,7 @@ def test_pipeline_resubmits_only_the_deferred_groups(defer, resident):
                         "-p", "no:cacheprovider"], env=e, cwd=apiemu.ROOT, capture_output=True, text=True, timeout=1800)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     trace = p.stdout + p.stderr
-    assert "8 passed" in trace
+    assert "9 passed" in trace
     assert trace.count("decided alone") > (20 if defer == "mod3" else 0) and "the whole batch through the host entry" not in trace
 
 
@@ -449,7 +449,7 @@ def test_device_simulator_equals_the_host_one():
 
 
 def check_switch_semantics():
-    """FGX_OPT_IN_ALL=1 turns a path on, its own switch set to 0 keeps it off, set to 1 turns it on without ALL."""
+    """A path is on by default; its own switch set to 0 turns it off; FGX_OPT_IN_ALL=0 turns every one off unless its own switch says 1."""
     import random
     import test_canon_core as tc
     import test_gpu_duplex_canon as tg
@@ -457,7 +457,7 @@ def check_switch_semantics():
     rng = random.Random(8)
     gr = GroupedReads.from_groups([m for m in (tc.duplex_indel_molecule(rng, g) for g in range(60)) if m])
     o = fgx_opts.defaults(kind=1)
-    for all_on, own, expect in ((None, None, False), ("1", None, True), ("1", "0", False), (None, "1", True), ("0", "1", True)):
+    for all_on, own, expect in ((None, None, True), ("0", None, False), ("1", "0", False), (None, "0", False), ("0", "1", True), ("1", None, True)):
         for k, v in (("FGX_OPT_IN_ALL", all_on), ("FGX_DUPLEX_CANON", own)):
             os.environ.pop(k, None)
             if v is not None:

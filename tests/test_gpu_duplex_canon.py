@@ -1,4 +1,4 @@
-"""GPU parity of the opt-in canonical second pass (FGX_DUPLEX_CANON=1, fgumi_amd/csrc/canon_core.h + api.cpp): duplex molecules with
+"""GPU parity of the canonical second pass (default since round 4; FGX_DUPLEX_CANON=0 opts out; fgumi_amd/csrc/canon_core.h + api.cpp): duplex molecules with
 indel / skip / pad CIGARs, which the device pipeline defers, are rewritten into their canonical form and decided by the device pipeline
 in a second pass instead of by the general path — byte-identical to the oracle, and the diagnostics show the second pass took them."""
 import ctypes as C
@@ -72,14 +72,26 @@ def test_indel_molecules_take_the_canonical_second_pass(canon_on, kw, mr):
     assert got["count"] == want["count"] and np.array_equal(got["stats"], want["stats"]), (got["stats"].tolist(), want["stats"].tolist())
 
 
-def test_second_pass_is_off_by_default():
-    if os.environ.get("FGX_OPT_IN_ALL") == "1":
-        pytest.skip("every opt-in path is switched on for this run")
+def check_second_pass_can_be_switched_off():
+    """FGX_DUPLEX_CANON=0: the round-3 behaviour — every deferred molecule takes the general path — and the same bytes."""
+    os.environ["FGX_DUPLEX_CANON"] = "0"
     rng = random.Random(32)
     groups = [m for m in (tc.duplex_indel_molecule(rng, g) for g in range(80)) if m]
     gr = GroupedReads.from_groups(groups)
     o = fgx_opts.defaults(kind=1)
-    os.environ.pop("FGX_DUPLEX_CANON", None)
     want = orc.process(o, gr.blob, gr.rec_off, gr.rec_len, gr.grp_first, batch_groups=100)
-    got = product(o, gr)
-    assert got["canon"] == 0 and got["data"] == want["data"] and np.array_equal(got["stats"], want["stats"])
+    try:
+        got = product(o, gr)
+        if os.environ.get("FGX_OPT_IN_ALL") == "0":
+            os.environ["FGX_DUPLEX_CANON"] = "1"     # (a run with every path switched off: its own switch wins)
+        else:
+            del os.environ["FGX_DUPLEX_CANON"]       # the default: the second pass takes them
+        again = product(o, gr)
+    finally:
+        os.environ.pop("FGX_DUPLEX_CANON", None)
+    assert got["deferred"] > 0 and got["canon"] == 0 and got["data"] == want["data"] and np.array_equal(got["stats"], want["stats"])
+    assert again["canon"] > 0.6 * again["deferred"] and again["data"] == want["data"] and np.array_equal(again["stats"], want["stats"])
+
+
+def test_second_pass_can_be_switched_off():
+    check_second_pass_can_be_switched_off()

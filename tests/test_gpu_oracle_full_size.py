@@ -1,0 +1,136 @@
+"""ORACLE parity at BASELINE.json's own sizes, on the code path bench.py times.
+
+The whole batch (configs[1]: 5 M simplex families x 8 pairs x 150 bp = 80 M reads; configs[2]: 2 M duplex molecules of 6+6 pairs;
+configs[4]: 1 M CODEC molecules of 4 pairs of 2x300 bp; the configs[3] long-tail shape at 1 M families of 2..50 pairs) is generated in HBM
+and run ONCE through the device-resident entry — for 5 M simplex families that is the 8-chunk, two-stream split pipeline the bench
+measures (fastpath.hip: n_grp >= 400 000 -> 8 chunks).  Then, shard by shard (`first_family = k * shard`), the same molecules are
+generated again, brought to the host, and decided by the oracle (the C++ restatement of the reference CPU caller,
+vanilla_caller.rs:1652-1755 / duplex_caller.rs:931-1108 / codec_caller.rs:625-1004) on the box's cores; the oracle's bytes of shard k
+must equal the whole-batch output's slice for that shard, and the oracle's counters must add up to the batch's.  Nothing is compared
+against the product itself here.
+
+The chunk boundaries of the split pipeline are also forced at small sizes (FGX_SPLIT_CHUNKS = 4 and 8 over 3 000 families, child
+interpreters because the knob is read once per process)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import fgx_opts
+import orc
+from fgumi_amd import (CodecConsensusCaller, CodecConsensusOptions, DuplexConsensusCaller, VanillaUmiConsensusCaller,
+                       VanillaUmiConsensusOptions)
+from isolated import run_isolated
+
+pytestmark = pytest.mark.gpu
+
+
+def _threads():
+    n = os.cpu_count() or 1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(p))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
+def _host_arrays(dg):
+    """The device-resident grouped reads as the numpy arrays the oracle takes."""
+    blob = dg.blob[:dg.blob_len + 16].cpu().numpy()
+    rec_off = dg.rec_off[:dg.n_rec].cpu().numpy().view(np.uint64)
+    rec_len = dg.rec_len[:dg.n_rec].cpu().numpy().view(np.uint32)
+    grp_first = dg.grp_first[:dg.n_grp + 1].cpu().numpy().view(np.uint32)
+    return blob, rec_off, rec_len, grp_first
+
+
+CASES = {
+    # name: (make caller, oracle options, molecules, shard, simulator arguments, oracle batch size, reads per molecule or None)
+    "simplex_config1": (lambda: VanillaUmiConsensusCaller("", "A", VanillaUmiConsensusOptions(min_reads=1, min_consensus_base_quality=2, cell_tag="CB"), overlapping_consensus=True),
+                        lambda: fgx_opts.defaults(min_reads=1), 5_000_000, 1_000_000, dict(family_size=8), 50, 16),
+    "duplex_config2": (lambda: DuplexConsensusCaller("", "A", [1], cell_tag="CB", overlapping_consensus=True),
+                       lambda: _duplex_opts(), 2_000_000, 1_000_000, dict(family_size=12, duplex=1), 100, 24),
+    "codec_config4": (lambda: CodecConsensusCaller("", "A", CodecConsensusOptions(produce_per_base_tags=True, cell_tag="CB")),
+                      lambda: fgx_opts.defaults(kind=2, overlapping_consensus=0, produce_per_base_tags=1), 1_000_000, 1_000_000,
+                      dict(family_size=4, read_length=300, insert_mean=350, insert_sd=60, codec=1), 1000, 8),
+    "simplex_long_tail_config3_shape": (lambda: VanillaUmiConsensusCaller("", "A", VanillaUmiConsensusOptions(min_reads=1, min_consensus_base_quality=2, cell_tag="CB"), overlapping_consensus=True),
+                                        lambda: fgx_opts.defaults(min_reads=1), 1_000_000, 500_000, dict(family_size=2, family_size_max=50), 50, None),
+}
+
+
+def _duplex_opts():
+    o = fgx_opts.defaults(kind=1)
+    o.duplex_min_reads[0], o.duplex_min_reads[1], o.duplex_min_reads[2] = 1, 1, 1
+    return o
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_whole_batch_equals_the_oracle_shard_by_shard(name):
+    if os.environ.get("FGX_SKIP_FULL_SIZE"):
+        pytest.skip("FGX_SKIP_FULL_SIZE set")
+    import torch
+    if torch.cuda.mem_get_info()[1] < 120 * 2**30:
+        pytest.skip("needs a 288 GB-class GPU")
+    make, make_opts, n, shard, sim, bg, reads_per = CASES[name]
+    c = make()
+    o = make_opts()
+    T = _threads()
+    dg = c.simulate_on_device(n, **sim)
+    out = c.process_batch_device(dg)                     # ONE batch: the launch chain bench.py times
+    assert out.n_deferred == 0 and out.count > 0
+    st = np.array(c.last_stats_array, dtype=np.uint64)
+    if reads_per:
+        assert int(st[0]) == reads_per * n
+    full = out.to_host()
+    del dg, out
+    torch.cuda.empty_cache()
+    off = count = 0
+    stats = np.zeros(28, dtype=np.uint64)
+    for k in range(n // shard):
+        dk = c.simulate_on_device(shard, first_family=k * shard, **sim)
+        blob, rec_off, rec_len, grp_first = _host_arrays(dk)
+        del dk
+        want = orc.process(o, blob, rec_off, rec_len, grp_first, batch_groups=bg, threads=T)
+        part = want["data"]
+        got = full[off:off + len(part)]
+        if got != part:
+            a, b = hashlib.sha256(got).hexdigest()[:16], hashlib.sha256(part).hexdigest()[:16]
+            first = next((i for i in range(min(len(got), len(part))) if got[i] != part[i]), min(len(got), len(part)))
+            raise AssertionError(f"{name}: shard {k} ({shard} molecules from {k * shard}): device sha256 {a} != oracle {b}; first differing byte at {first} of {len(part)}")
+        off += len(part)
+        count += want["count"]
+        stats += want["stats"]
+        del want, part, got, blob
+    assert off == len(full), (off, len(full))
+    assert np.array_equal(stats, st), (stats.tolist(), st.tolist())
+    c.close()
+
+
+def check_forced_chunks(n_families, sim):
+    import torch  # noqa: F401
+    from fgumi_amd import simulate_grouped_reads
+    g = simulate_grouped_reads(n_families, **sim)
+    want = orc.process(fgx_opts.defaults(min_reads=1), g.blob, g.rec_off, g.rec_len, g.grp_first)
+    c = VanillaUmiConsensusCaller("", "A", VanillaUmiConsensusOptions(min_reads=1, min_consensus_base_quality=2, cell_tag="CB"), overlapping_consensus=True)
+    out = c.process_batch_device(g.to_device())
+    assert out.n_deferred == 0
+    assert out.count == want["count"] and out.to_host() == want["data"]
+    assert np.array_equal(np.array(c.last_stats_array, dtype=np.uint64), want["stats"])
+    # the knob must have taken effect: the split pipeline ran in `chunks` pieces
+    import ctypes as C
+    from fgumi_amd import lib
+    if hasattr(lib, "fgx_debug_last_split_chunks"):
+        lib.fgx_debug_last_split_chunks.restype = C.c_uint32
+        lib.fgx_debug_last_split_chunks.argtypes = [C.c_void_p]
+        assert lib.fgx_debug_last_split_chunks(c._h) == int(os.environ["FGX_SPLIT_CHUNKS"]), lib.fgx_debug_last_split_chunks(c._h)
+    c.close()
+
+
+@pytest.mark.parametrize("chunks", [4, 8])
+@pytest.mark.parametrize("sim", [dict(family_size=8), dict(family_size=5, family_size_max=12, error_rate_ppm=20000)])
+def test_forced_split_chunks_equal_the_oracle(chunks, sim):
+    """3 000 families cut into 4 / 8 chunks of the record / column pipeline (the boundaries the 5 M-family batch has at 625 000-family
+    distance): chunk-local prefix offsets, the second stream's hand-over and the per-chunk finish kernels, against the oracle."""
+    run_isolated("test_gpu_oracle_full_size", "check_forced_chunks", 3000, sim, env={"FGX_SPLIT_CHUNKS": str(chunks)})

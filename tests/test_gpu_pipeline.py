@@ -209,3 +209,31 @@ def test_run_bam_edge_files(tmp_path):
     got = b"".join(bytes(stream[int(o) - 4:int(o) + int(l)]) for o, l in zip(off, ln))
     assert got == want["data"] and st["kept_records"] == g.n_rec
     c.close()
+
+
+def test_chunks_that_keep_no_record_at_all(tmp_path):
+    """Whole chunks of records the grouper drops (unmapped, untagged): the first chunk holds the BAM header and nothing kept, later chunks
+    hold dropped records only.  Nothing but the partial record behind the last whole one may be carried into the next chunk — not the
+    header, not the alignment bytes in front of the leftover (`batch_end = 0` carried the whole chunk)."""
+    refs = [("chr1", 1000000)]
+    src, dst = str(tmp_path / "in.bam"), str(tmp_path / "out.bam")
+    g = simulate_grouped_reads(300, family_size=3)
+    recs = [bytes(g.blob[int(o) - 4:int(o) + int(l)]) for o, l in zip(g.rec_off, g.rec_len)]
+    rng = random.Random(5)
+
+    def dropped(i):
+        seq = "".join(rng.choice("ACGT") for _ in range(150))
+        r = bamutil.make_record(f"drop{i:06d}", seq, [rng.randrange(2, 41) for _ in range(150)], flag=4 if i % 2 else 0, ref_id=-1 if i % 2 else 0, pos=-1 if i % 2 else 7,
+                                tags=() if i % 3 else (("RX", "Z", "ACGT"),))
+        return len(r).to_bytes(4, "little") + r
+    run = b"".join(dropped(i) for i in range(2500))                   # ~ 600 KB of records that all go away: several 32 KiB chunks (random bases: they do not compress away)
+    mixed = run + b"".join(recs[:len(recs) // 2]) + run + b"".join(recs[len(recs) // 2:]) + run
+    bgzf.write_bam(src, bgzf.grouped_input_header(refs), refs, mixed)
+    c = _caller()
+    st = c.run_bam(src, dst, chunk_raw_bytes=1 << 15)
+    want = orc.process(fgx_opts.defaults(min_reads=1), g.blob, g.rec_off, g.rec_len, g.grp_first)
+    text, orefs, stream, off, ln = bgzf.read_bam(dst)
+    got = b"".join(bytes(stream[int(o) - 4:int(o) + int(l)]) for o, l in zip(off, ln))
+    assert st["chunks"] > 12
+    assert got == want["data"] and st["kept_records"] == g.n_rec and st["groups"] == g.n_grp
+    c.close()

@@ -1,17 +1,12 @@
-"""GPU parity of the canonical second pass with the canonical form computed ON THE DEVICE (FGX_CANON_DEVICE=1 on top of FGX_DUPLEX_CANON /
-FGX_CODEC_CANON; fgumi_amd/csrc/canon_device.hip: a lane per deferred molecule runs the scalar source of canon_core.h over the records
+"""GPU parity of the canonical second pass with the canonical form computed ON THE DEVICE (the default since round 4; FGX_CANON_DEVICE=0 computes
+it on the host's cores; fgumi_amd/csrc/canon_device.hip: a lane per deferred molecule runs the scalar source of canon_core.h over the records
 already uploaded).  Same inputs and assertions as the host-canonicalised twins (tests/test_gpu_duplex_canon.py, test_gpu_zz_codec_canon.py):
-byte-identical to the oracle, counters included.
-
-NOT RUN ON HARDWARE YET: written after the round's GPU budget was spent.  xfail(strict=False), each test in a child interpreter
-(tests/isolated.py): an XPASS in the driver's round-end run is the first hardware evidence; a failure — or a device fault in the new
-kernel — does not stop the suite.  The flags are off by default."""
+byte-identical to the oracle, counters included; the resident test asserts that the device entry's deferred list IS the out-of-scope remainder."""
 import pytest
 
 from isolated import run_isolated
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.xfail(strict=False, reason="written after the round's GPU budget was spent; never run on hardware (flags are opt-in)")]
+pytestmark = pytest.mark.gpu
 
 
 FLAGS = {"FGX_CANON_DEVICE": "1", "FGX_DUPLEX_CANON": "1", "FGX_CODEC_CANON": "1"}

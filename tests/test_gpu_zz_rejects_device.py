@@ -1,10 +1,7 @@
-"""GPU parity of `--rejects` for the simplex caller WITHOUT the general path (FGX_REJECTS_DEVICE=1; fgumi_amd/csrc/reject_device.hip runs
-reject_core.h's decision function a lane per MI group beside the unchanged device pipeline): consensus records, counters AND the rejects
-stream byte-identical to the oracle, through the host entry and through the device-resident entry.
-
-NOT RUN ON HARDWARE YET: written after the round's GPU budget was spent (the lane body is proved on the CPU: tests/test_reject_core.py).
-xfail(strict=False), each test in a child interpreter (tests/isolated.py): an XPASS in the driver's round-end run is the first hardware
-evidence; a failure — or a device fault in the new kernels — does not stop the suite.  The flag is off by default."""
+"""GPU parity of `--rejects` for the simplex caller WITHOUT the general path (default since round 4, FGX_REJECTS_DEVICE=0 opts out;
+fgumi_amd/csrc/reject_device.hip runs reject_core.h's decision function a lane per MI group beside the unchanged device pipeline): consensus
+records, counters AND the rejects stream byte-identical to the oracle, through the host entry and through the device-resident entry, and the
+deferral diagnostics show that the batch did NOT go to the general path."""
 import ctypes as C
 import random
 
@@ -15,10 +12,8 @@ import fgx_opts
 import orc
 from isolated import run_isolated
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.xfail(strict=False, reason="written after the round's GPU budget was spent; never run on hardware (flag is opt-in)")]
+pytestmark = pytest.mark.gpu
 
-FLAG = {"FGX_REJECTS_DEVICE": "1"}
 KWS = [dict(min_reads=1), dict(min_reads=2, max_reads=3), dict(min_reads=3, overlapping_consensus=0, min_input_base_quality=30), dict(min_reads=2, trim=1, min_input_base_quality=25)]
 
 
@@ -56,6 +51,17 @@ def check_host_entry(kw, seed):
         assert int(out.count) == want["count"] and np.array_equal(np.array(list(out.stats), dtype=np.uint64), want["stats"])
         assert int(out.n_rejects) == want["n_rejects"]
         assert (C.string_at(out.rejects, out.rejects_len) if out.rejects_len else b"") == want["rejects"]
+        # the path taken: with the side kernels the device pipeline decides the batch (before round 4 `--rejects` sent EVERY group to the
+        # general path); FGX_REJECTS_DEVICE=0 restores that
+        d = (C.c_uint64 * 2)()
+        lib.fgx_debug_last_deferral(h, d)
+        import os
+        if os.environ.get("FGX_REJECTS_DEVICE") == "0":
+            assert int(d[0]) == g.n_grp, (int(d[0]), g.n_grp)
+        elif os.environ.get("APIEMU_DEFER"):          # (tests/apiemu: the stand-in for the device pipeline defers groups by rule)
+            assert int(d[0]) < g.n_grp
+        else:
+            assert int(d[0]) == 0, f"{int(d[0])} of {g.n_grp} groups were deferred to the general path"
     finally:
         lib.fgx_destroy(h)
 
@@ -80,6 +86,7 @@ def check_device_entry(kw, seed):
         assert rc == 0, lib.fgx_last_error(h).decode()
         assert int(out.n_rejects) == want["n_rejects"]
         assert hip_memcpy_d2h(out.rejects, int(out.rejects_len)) == want["rejects"]     # (covers every group, the deferred ones included)
+        assert nd.value == 0, f"{nd.value} groups deferred by the device entry"
         if nd.value == 0:
             assert hip_memcpy_d2h(out.data, int(out.data_len)) == want["data"] and int(out.count) == want["count"]
             assert np.array_equal(np.array(list(out.stats), dtype=np.uint64), want["stats"])
@@ -89,9 +96,13 @@ def check_device_entry(kw, seed):
 
 @pytest.mark.parametrize("kw", KWS)
 def test_host_entry_rejects_come_from_the_side_kernels(kw):
-    run_isolated("test_gpu_zz_rejects_device", "check_host_entry", kw, 11, env=FLAG)
+    run_isolated("test_gpu_zz_rejects_device", "check_host_entry", kw, 11)
+
+
+def test_host_entry_rejects_opt_out_takes_the_general_path():
+    run_isolated("test_gpu_zz_rejects_device", "check_host_entry", KWS[1], 11, env={"FGX_REJECTS_DEVICE": "0"})
 
 
 @pytest.mark.parametrize("kw", KWS[:2])
 def test_device_entry_accepts_track_rejects(kw):
-    run_isolated("test_gpu_zz_rejects_device", "check_device_entry", kw, 12, env=FLAG)
+    run_isolated("test_gpu_zz_rejects_device", "check_device_entry", kw, 12)

@@ -54,3 +54,45 @@ def test_inflate_core_refuses_corrupted_streams():
     assert st != 0
     st, _, _ = _inflate(comp, len(data) + 1)   # ... or larger
     assert st != 0
+
+
+def check_truncated_payloads_never_read_past_the_slack():
+    """a truncated / corrupt payload kept decoding garbage until the output overflowed and could read ~120 KB past the input.
+    The payload sits at the END of a mapping whose next page is PROT_NONE, 8 bytes of slack behind it (what the host entry documents): a
+    load past `in_len + 8` is a segmentation fault of this child process."""
+    import mmap
+    libc = C.CDLL(None, use_errno=True)
+    libc.mprotect.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    PAGE = mmap.PAGESIZE
+    rng = random.Random(17)
+    data = bytes(simulate_grouped_reads(200, family_size=4).blob)[:65000]
+    lib.fgx_inflate_block_host.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    out = C.create_string_buffer(65536 + 64)
+    n_pages = 24
+    m = mmap.mmap(-1, (n_pages + 1) * PAGE)
+    base = C.addressof(C.c_char.from_buffer(m))
+    assert libc.mprotect(base + n_pages * PAGE, PAGE, 0) == 0, C.get_errno()
+    refused = 0
+    for level, strategy in ((1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_FIXED), (1, zlib.Z_HUFFMAN_ONLY), (0, zlib.Z_DEFAULT_STRATEGY)):
+        co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+        comp = co.compress(data) + co.flush()
+        for trial in range(60):
+            cut = rng.randrange(1, len(comp)) if trial else len(comp)          # trial 0: the whole payload, which must decode
+            piece = bytearray(comp[:cut])
+            if trial % 3 == 2:                                                   # ... and bit flips on top
+                piece[rng.randrange(len(piece))] ^= 1 << rng.randrange(8)
+            assert len(piece) + 8 <= n_pages * PAGE
+            at = n_pages * PAGE - 8 - len(piece)
+            m[at:at + len(piece)] = bytes(piece)
+            m[at + len(piece):n_pages * PAGE] = b"\0" * 8
+            st = lib.fgx_inflate_block_host(base + at, len(piece), out, len(data), None)
+            if trial == 0:
+                assert st == 0 and out.raw[:len(data)] == data
+            else:
+                refused += st != 0
+    assert refused > 200
+
+
+def test_truncated_payloads_never_read_past_the_slack():
+    from isolated import run_isolated
+    run_isolated("test_inflate_core", "check_truncated_payloads_never_read_past_the_slack")
