@@ -96,6 +96,19 @@ struct SplitOut {           // 32 bytes: what k_split_cols decided for a family;
 };
 static_assert(sizeof(SplitRec) == 32 && sizeof(SplitFam) == 32 && sizeof(SplitOut) == 32, "split descriptors are moved as two 16-byte pieces");
 
+// ---- direct records (round 4): k_split_cols writes the consensus records of its families itself ------------------------------------
+// k_split_parse predicts the exact bytes of every family's records (final lengths at the reads' 3' ends, consensus lengths, tag
+// lengths); a per-chunk exclusive scan turns them into output offsets before the chunk's column kernel starts; the column lanes store
+// nibbles / qualities / cd / ce straight into the records and the family's wavefront writes header, name and tags.  The columns that
+// wait for k_call_full are patched in the records by that kernel (nibble OR, quality byte, cd / ce entries, the record's error count),
+// and k_fix_ce rewrites the cE value of the records that had errors.  No column scratch, no EndDesc, no k_emit for these families.
+struct SlotDesc {           // one directly written record (slot 3g + type): what k_call_full / k_fix_ce need to patch it
+  uint64_t out_off;         // offset of the record (its block_size prefix) in the output buffer
+  uint32_t lc_seq;          // consensus length | offset of SEQ inside the record (from the prefix) << 16
+  uint32_t sum_depth;       // sum of the per-base depths: the denominator of cE
+};
+constexpr uint64_t FULL_DEST_DIRECT = 1ull << 62;   // FullItem.dest: DIRECT | slot << 16 | column
+
 struct FastParams {
   const uint8_t* blob; const uint64_t* rec_off; const uint32_t* rec_len; const uint32_t* grp_first;
   uint32_t g0;
@@ -119,6 +132,14 @@ struct FastParams {
   const void* s2_image;            // k_split_cols: image of its LDS tables (S2Lds, simplex_split.inc)
   const uint4* fam_desc;           // per family {first record offset lo, hi, bytes to the end of the last record (~0: none), records} (k_col_bound)
   uint64_t blob_len;               // records must end inside the blob (checked before the family's bytes are staged)
+  // direct records (k_split_parse predicts, k_split_cols<.., .., 1> writes)
+  uint32_t* dir_size;              // per family: bytes of its consensus records (block_size prefixes included); 0: none / not this pipeline's
+  const uint64_t* dir_off;         // per family: offset of its first record in `out` (exclusive scan of dir_size)
+  uint8_t* out; uint64_t out_cap;  // the output buffer
+  uint64_t* out_off;               // per slot (3g + type): offset of the record in `out` (what the scan of rec_sizes gives the scratch path)
+  SlotDesc* slot_desc; uint32_t* slot_err;   // per slot: patch descriptor; errors counted by k_call_full
+  const char* strings;             // read-name prefix | read group id
+  uint32_t* dir_flags;             // [0] families whose records differ in size from the prediction, [1] records past out_cap
   uint32_t lds_tile_bytes;
   uint32_t lds_wave_bytes;
   FullItem* full_items; uint32_t* full_count; uint32_t full_cap;   // N_LISTS append lists of `full_cap` items each

@@ -118,6 +118,13 @@ class Builder:
         return a, cap.value
 
 
+def _bytes_at(address, n):
+    """`n` bytes at `address` (ctypes.string_at takes its size as a C int: lengths of 2 GiB and more come out truncated)."""
+    if not n:
+        return b""
+    return C.string_at(address, n) if n < (1 << 31) else bytes((C.c_char * n).from_address(address))
+
+
 def process(opts, blob, rec_off, rec_len, grp_first, batch_groups=50, threads=1):
     """Run the oracle over a whole input. Returns dict(data=bytes, count, stats=np.uint64[28], rejects, n_rejects)."""
     n_rec = len(rec_off)
@@ -127,11 +134,11 @@ def process(opts, blob, rec_off, rec_len, grp_first, batch_groups=50, threads=1)
         raise RuntimeError("oracle error: " + lib.orc_last_error().decode())
     try:
         n = lib.orc_result_len(h)
-        data = C.string_at(lib.orc_result_data(h), n) if n else b""
+        data = _bytes_at(lib.orc_result_data(h), n)
         stats = np.zeros(28, dtype=np.uint64)
         lib.orc_result_stats(h, ptr(stats))
         rn = lib.orc_result_rejects_len(h)
-        rej = C.string_at(lib.orc_result_rejects(h), rn) if rn else b""
+        rej = _bytes_at(lib.orc_result_rejects(h), rn)
         return dict(data=data, count=lib.orc_result_count(h), stats=stats, rejects=rej, n_rejects=lib.orc_result_n_rejects(h),
                     seconds_workers=lib.orc_result_seconds(h))
     finally:
