@@ -1172,6 +1172,9 @@ int fgx_filter_records(fgx_caller* c, const fgx_filter_options* f, const uint8_t
 void fgx_debug_last_deferral(const fgx_caller* c, uint64_t* out2) { if (c && out2) { out2[0] = c->last_deferred_groups; out2[1] = c->last_canon_molecules; } }
 // chunks of the record / column split pipeline in the last device batch (FGX_SPLIT_CHUNKS, or 8 / 4 / 1 by batch size); 0 = it did not run
 uint32_t fgx_debug_last_split_chunks(const fgx_caller* c) { return (c && c->fast) ? c->fast->fp.last_split_chunks : 0u; }
+// how the last device batch produced its records: 0 column scratch + k_emit, 1 written directly by the split pipeline, 2 directly + merge with the
+// records of the families that left it
+int fgx_debug_last_direct(const fgx_caller* c) { return (c && c->fast) ? c->fast->fp.last_direct : 0; }
 // 1: route everything through the general host path (parity tests of that path); 0: hybrid (default)
 void fgx_set_general_only(fgx_caller* c, int on) { if (c) c->general_only = on != 0; }
 // dynamic LDS bytes of the large-family launch of the family kernel (default 48 KiB)

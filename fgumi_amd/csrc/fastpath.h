@@ -157,6 +157,7 @@ struct EmitParams {
   const uint8_t* col_code; const uint8_t* col_qual; const uint16_t* col_depth; const uint16_t* col_err;
   const char* prefix; uint32_t prefix_len; const char* rg; uint32_t rg_len;
   uint8_t per_base_tags; char tag0, tag1, cell0, cell1;
+  const uint32_t* fam_list; uint32_t n_fam;   // non-null: a wavefront per LISTED family (direct records: the families that left the split pipeline)
 };
 
 struct DuplexEmitParams {
@@ -196,6 +197,10 @@ struct FastPath {
   DevBuf d_famdesc;                       // k_col_bound's family descriptors
   DevBuf d_fwimg;                         // FwLds image (k_family_wave)
   DevBuf d_split_rec, d_split_fam, d_split_out, d_route, d_s2img;   // split simplex pipeline
+  DevBuf d_dir_size, d_dir_off, d_dir_base, d_slot_desc, d_slot_err, d_out2, d_scan_tmp2;   // direct records (simplex_split.inc, fastpath.h)
+  bool direct_off = false;                // a batch whose predicted record sizes did not hold: this caller stays on the scratch path (diagnostics: last_direct)
+  uint64_t dir_cap_min = 0;               // output room a batch asked for beyond the first estimate
+  int last_direct = 0;                    // 0: the last batch went through the column scratch + k_emit; 1: records written directly; 2: directly + merge
   uint32_t lds_wave_bytes = 6144;         // wave-per-family kernel: LDS copy of one family's raw records
   uint32_t lds_wave_bytes_duplex = 8704;  // duplex molecules carry both strands (config 3: 24 records x ~330 B)
   uint32_t lds_wave_bytes_codec = 5120;   // CODEC (config 5: 8 records x ~570 B): its kernel needs 71 VGPRs, so the smaller slice buys a sixth wave per SIMD (+3 %)
@@ -203,7 +208,7 @@ struct FastPath {
   // split simplex pipeline: the record kernel runs chunk by chunk on a second stream, under the column kernel of the chunk before
   uint32_t pool_slack = 256; bool pool_init = false;
   uint32_t pool_div = 8;                  // k_call_full's append lists hold 1 / pool_div of the column bound (halved when a batch exhausts them)
-  static constexpr int RUN_AGAIN_LARGER_POOL = -77;
+  static constexpr int RUN_AGAIN_LARGER_POOL = -77;   // (also: the batch again without / with more room for the direct records)
   int run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const uint64_t* d_rec_off, const uint32_t* d_rec_len, uint32_t n_rec,
                const uint32_t* d_grp_first, uint32_t n_grp, FastResult* res);
   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: one flag per FastPath (= per caller = per device), not per process

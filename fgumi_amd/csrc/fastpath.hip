@@ -2296,7 +2296,70 @@ struct FullParams {
   uint8_t* col_code; uint8_t* col_qual; uint16_t* col_err;
   char* rx_base; uint32_t rx_stride;   // consensus-UMI characters: rx_base + slot * rx_stride + index
   uint16_t* col_depth; uint32_t min_input_bq;   // observation items (k_split_cols): the column's depth is counted here
+  // direct records (FullItem.dest & FULL_DEST_DIRECT): the column is patched in the record k_split_cols wrote
+  uint8_t* out; const SlotDesc* slot_desc; uint32_t* slot_err; uint32_t rg_len, per_base_tags;
 };
+
+// A column of a directly written record (fastpath.h: SlotDesc): the sequence nibble is OR-ed into the word that holds its byte (k_split_cols
+// left it 0; the other nibble of the byte may be patched by another lane), quality, cd (observation items: the depth is counted here) and
+// ce entries are stored, and the column's errors are added to the record's count for k_fix_ce.
+__device__ __forceinline__ void full_patch_direct(const FullParams& P, uint64_t dest, uint32_t ob, uint32_t oq, uint32_t err, uint32_t depth, bool with_depth) {
+  const uint32_t slot = (uint32_t)(dest >> 16), p = (uint32_t)dest & 0xFFFFu;
+  const SlotDesc sd = P.slot_desc[slot];
+  uint8_t* const rec = P.out + sd.out_off;
+  const uint32_t Lc = sd.lc_seq & 0xFFFFu, o_seq = sd.lc_seq >> 16;
+  const uint32_t o_qual = o_seq + ((Lc + 1u) >> 1), o_cd = o_qual + Lc + 3u + P.rg_len + 1u + 15u + 8u, o_ce = o_cd + 2u * Lc + 8u;
+  const uintptr_t a = (uintptr_t)(rec + o_seq + (p >> 1));
+  atomicOr((unsigned int*)(a & ~(uintptr_t)3), ob << (8u * (uint32_t)(a & 3) + ((p & 1u) ? 0u : 4u)));
+  rec[o_qual + p] = (uint8_t)oq;
+  const uint32_t e16 = err < 32767u ? err : 32767u;
+  if (P.per_base_tags) {
+    if (with_depth) { const uint16_t d16 = (uint16_t)depth; __builtin_memcpy(rec + o_cd + 2u * p, &d16, 2); }
+    const uint16_t w = (uint16_t)e16; __builtin_memcpy(rec + o_ce + 2u * p, &w, 2);
+  }
+  if (e16) atomicAdd(&P.slot_err[slot], e16);
+}
+struct DirCast { __host__ __device__ __forceinline__ uint64_t operator()(const uint32_t& v) const { return (uint64_t)v; } };
+typedef hipcub::TransformInputIterator<uint64_t, DirCast, const uint32_t*> DirSizeIn;
+// a chunk's record offsets: its exclusive scan + the bytes of the chunks before; the last family leaves the next chunk's base
+__global__ void k_dir_carry(uint64_t* __restrict__ off, const uint32_t* __restrict__ size, uint32_t n, uint64_t* __restrict__ base) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t b = base[0], local = off[i];
+  off[i] = local + b;
+  if (i == n - 1) base[1] = b + local + size[i];
+}
+// cE of the directly written records whose columns had errors: f32(total errors) / f32(total depth) (vanilla_caller.rs:1805-1808); the
+// value sits 11 bytes into the cD cM cE block that follows the RG tag
+__global__ void k_fix_ce(const SlotDesc* __restrict__ slot_desc, const uint32_t* __restrict__ slot_err, uint32_t n_slots, uint8_t* __restrict__ out, uint32_t rg_len) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_slots) return;
+  const uint32_t e = slot_err[i];
+  if (!e) return;
+  const SlotDesc sd = slot_desc[i];
+  const uint32_t Lc = sd.lc_seq & 0xFFFFu, o_seq = sd.lc_seq >> 16;
+  const uint32_t o_t3 = o_seq + ((Lc + 1u) >> 1) + Lc + 3u + rg_len + 1u;
+  const float rate = sd.sum_depth > 0 ? (float)e / (float)sd.sum_depth : 0.0f;
+  const uint32_t u = __float_as_uint(rate);
+  uint8_t* const q = out + sd.out_off + o_t3 + 11u;
+  q[0] = (uint8_t)u; q[1] = (uint8_t)(u >> 8); q[2] = (uint8_t)(u >> 16); q[3] = (uint8_t)(u >> 24);
+}
+// The merge of a batch in which some families left the split pipeline (or were deferred): the directly written records of family g lie at
+// dir_off[g] in `dir`; they move to their place in the final stream (the scan of ALL record sizes), a wavefront per family.
+__global__ __launch_bounds__(256) void k_dir_copy(const SplitOut* __restrict__ split_out, const uint64_t* __restrict__ dir_off, const uint64_t* __restrict__ out_off,
+                                                  const uint64_t* __restrict__ sizes, const uint8_t* __restrict__ dir, uint8_t* __restrict__ out, uint32_t n_grp) {
+  const uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6)), lane = threadIdx.x & 63;
+  if (g >= n_grp) return;
+  if (split_out[g].status != 1) return;
+  const uint64_t bytes = sizes[3 * (size_t)g] + sizes[3 * (size_t)g + 1] + sizes[3 * (size_t)g + 2];
+  const uint8_t* const src = dir + dir_off[g];
+  uint8_t* const dst = out + out_off[3 * (size_t)g];
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  uint64_t i = 16ull * lane;
+  for (; i + 16 <= bytes; i += 1024) { u32x4 v; __builtin_memcpy(&v, src + i, 16); __builtin_memcpy(dst + i, &v, 16); }
+  const uint64_t whole = bytes & ~15ull;
+  if (lane < (uint32_t)(bytes - whole)) dst[whole + lane] = src[whole + lane];
+}
 
 __global__ __launch_bounds__(256) void k_call_full(FullParams P) {
   const uint32_t list = blockIdx.y;
@@ -2332,6 +2395,7 @@ __global__ __launch_bounds__(256) void k_call_full(FullParams P) {
     if (depth < P.min_reads) { ob = 15; oq = 0; }
     else if (q < P.min_cons_bq) { ob = 15; oq = FGX_MIN_PHRED; }
     else { ob = code; oq = q; }
+    if (it.dest & FULL_DEST_DIRECT) { full_patch_direct(P, it.dest, ob, oq, err, depth, true); return; }
     P.col_code[it.dest] = ob; P.col_qual[it.dest] = oq; P.col_err[it.dest] = (uint16_t)(err < 32767u ? err : 32767u);
     P.col_depth[it.dest] = (uint16_t)depth;
     return;
@@ -2366,6 +2430,7 @@ __global__ __launch_bounds__(256) void k_call_full(FullParams P) {
   if (depth < P.min_reads) { ob = 15; oq = 0; }
   else if (q < P.min_cons_bq) { ob = 15; oq = FGX_MIN_PHRED; }
   else { ob = code; oq = q; }
+  if (it.dest & FULL_DEST_DIRECT) { full_patch_direct(P, it.dest, ob, oq, err, depth, false); return; }
   P.col_code[it.dest] = ob; P.col_qual[it.dest] = oq; P.col_err[it.dest] = (uint16_t)(err < 32767u ? err : 32767u);
 }
 
@@ -2617,8 +2682,12 @@ __global__ __launch_bounds__(256, FGX_EMIT_OCC) void k_emit(EmitParams P) {
   // loads, the valid flags and then each record's fields were dependent memory round trips of their own
   __shared__ __align__(16) EndDesc sD[4][3];
   static_assert(sizeof(EndDesc) == 96, "EndDesc is copied as six 16-byte pieces");
-  const uint32_t fam = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+  uint32_t fam = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
   const uint32_t lane = threadIdx.x & 63, wv = (threadIdx.x >> 6) & 3;
+  if (P.fam_list) {   // the merge of a direct-records batch: only the families that left the split pipeline have descriptors
+    if (fam >= P.n_fam) return;
+    fam = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.fam_list[fam]);
+  }
   const uint32_t s0 = P.slot0 + 3 * fam;
   if (s0 >= P.slot_end) return;
   // (every kernel argument the records need is asked for here, in one batch: fetched where first used they were five separate
@@ -3306,7 +3375,7 @@ __global__ void k_reduce_stats(const unsigned long long* __restrict__ slots, uns
 void FastPath::release() {
   for (DevBuf* b : {&d_ends, &d_sizes, &d_offsets, &d_code, &d_qual, &d_depth, &d_err, &d_misc, &d_deferred, &d_out, &d_scan_tmp, &d_strings, &d_obs, &d_retry2,
                     &d_retry, &d_bound, &d_colbase, &d_statslots, &d_full_items, &d_full_count, &d_retry_old, &d_w2img, &d_famdesc, &d_fwimg,
-                    &d_split_rec, &d_split_fam, &d_split_out, &d_route, &d_s2img})
+                    &d_split_rec, &d_split_fam, &d_split_out, &d_route, &d_s2img, &d_dir_size, &d_dir_off, &d_dir_base, &d_slot_desc, &d_slot_err, &d_out2, &d_scan_tmp2})
     b->free_();
   for (int i = 0; i < 4; i++) if (ev[i]) { (void)hipEventDestroy(ev[i]); ev[i] = nullptr; }
   if (s2) {
@@ -3394,7 +3463,25 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
   // most 32 records (FGX_SPLIT=0 / 2: never / always).
   static const int split_mode = [] { const char* e = getenv("FGX_SPLIT"); return e ? atoi(e) : 1; }();
   const bool use_split = simplex_v2 && use_split_env && !seg4 && (split_mode == 2 || (double)small_recs >= 0.9 * (double)n_rec);
+  // Direct records (fastpath.h): the split pipeline's column kernel writes the consensus records itself.  FGX_DIRECT=0 keeps the column
+  // scratch + k_emit for every family (the round-3 chain; also what a batch falls back to when a predicted record size does not hold).
+  const bool direct_env = [] { const char* e = getenv("FGX_DIRECT"); return !(e && e[0] == '0'); }();   // (read per batch: tools/direct_check.py switches it between two runs of one process)
+  const bool direct = use_split && direct_env && !direct_off;
+  last_direct = 0;
   uint64_t col_cap = lastb[0] + lastb[1] + 64;
+  uint64_t dir_cap = 0;
+  if (direct) {
+    // room for the records: 6 bytes per column of the (generous) column bound covers sequence + qualities + cd + ce twice over for
+    // simulate-shaped reads; names and tags come on top.  A batch that needs more says so (dir_flags[1]) and runs again with what it asked for.
+    dir_cap = std::max<uint64_t>(col_cap * 6 + (uint64_t)n_slots * 64 + 4096, dir_cap_min);
+    d_out.reserve(dir_cap + 64);
+    d_dir_size.reserve((size_t)n_grp * 4 + 64); d_dir_off.reserve((size_t)n_grp * 8 + 64); d_dir_base.reserve((MAX_CHUNKS + 2) * 8);
+    d_slot_desc.reserve((size_t)n_slots * sizeof(SlotDesc)); d_slot_err.reserve((size_t)n_slots * 4);
+    hip_check(hipMemsetAsync(d_dir_size.p, 0, (size_t)n_grp * 4, s), "memset");
+    hip_check(hipMemsetAsync(d_dir_base.p, 0, (MAX_CHUNKS + 2) * 8, s), "memset");
+    hip_check(hipMemsetAsync(d_slot_err.p, 0, (size_t)n_slots * 4, s), "memset");
+    hip_check(hipMemsetAsync(d_sizes.p, 0, (size_t)n_slots * 8, s), "memset");
+  }
   d_code.reserve(col_cap + 64); d_qual.reserve(col_cap + 64); d_err.reserve(col_cap * 2 + 64);   // (+ slack: k_emit reads whole dwords)
   if (duplex) d_obs.reserve(col_cap * 4); else d_depth.reserve(col_cap * 2 + 64);
 
@@ -3433,6 +3520,11 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
   P.ends = d_ends.as<EndDesc>(); P.rec_sizes = d_sizes.as<uint64_t>();
   P.col_code = d_code.as<uint8_t>(); P.col_qual = d_qual.as<uint8_t>(); P.col_depth = d_depth.as<uint16_t>(); P.col_err = d_err.as<uint16_t>();
   P.col_base = d_colbase.as<uint64_t>();
+  if (direct) {
+    P.dir_size = d_dir_size.as<uint32_t>(); P.dir_off = d_dir_off.as<uint64_t>(); P.out = d_out.as<uint8_t>(); P.out_cap = dir_cap;
+    P.out_off = d_offsets.as<uint64_t>(); P.slot_desc = d_slot_desc.as<SlotDesc>(); P.slot_err = d_slot_err.as<uint32_t>();
+    P.strings = d_strings.as<char>(); P.dir_flags = (uint32_t*)(misc + 36);
+  }
   P.stats = d_statslots.as<unsigned long long>(); P.n_deferred = (uint32_t*)(misc + 29);
   P.deferred = d_deferred.as<uint32_t>();
   d_retry.reserve((size_t)n_grp * 4);
@@ -3475,8 +3567,10 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       // k_split_cols over growing LDS slices (4 / 2 / 1 / 1 wavefronts per workgroup); what it does not take is collected in
       // `route` and starts the k_simplex_wave2 chain below
         if (!s2_attr_set) {
-        hip_check(hipFuncSetAttribute((const void*)k_split_cols<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_split_cols<0, 0>: the device refused the dynamic LDS size");
-        hip_check(hipFuncSetAttribute((const void*)k_split_cols<160, 80>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_split_cols<160, 80>: the device refused the dynamic LDS size");
+        hip_check(hipFuncSetAttribute((const void*)k_split_cols<0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_split_cols<0, 0, 0>: the device refused the dynamic LDS size");
+        hip_check(hipFuncSetAttribute((const void*)k_split_cols<160, 80, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_split_cols<160, 80, 0>: the device refused the dynamic LDS size");
+        hip_check(hipFuncSetAttribute((const void*)k_split_cols<0, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_split_cols<0, 0, 1>: the device refused the dynamic LDS size");
+        hip_check(hipFuncSetAttribute((const void*)k_split_cols<160, 80, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_split_cols<160, 80, 1>: the device refused the dynamic LDS size");
         s2_attr_set = true;
       }
       if (!d_s2img.p) {   // the tables of a caller never change: one image per FastPath
@@ -3507,6 +3601,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       PK.tag0 = o.tag[0]; PK.tag1 = o.tag[1]; PK.cell0 = o.cell_tag[0]; PK.cell1 = o.cell_tag[1];
       PK.prefix_len = (uint32_t)c->prefix.size();
       PK.split_rec = P.split_rec; PK.split_fam = P.split_fam;
+      if (direct) { PK.dir_size = P.dir_size; PK.min_input_bq = o.min_input_base_quality; PK.per_base_tags = o.produce_per_base_tags; PK.rg_len = (uint32_t)c->rg.size(); }
       // families per wavefront of the record kernel: as many as fill its 64 lanes on average
       const double mean_recs = (double)n_rec / (double)n_grp;
       uint32_t fpw = mean_recs >= 1.0 ? (uint32_t)(64.0 / mean_recs) : 16u;
@@ -3520,12 +3615,25 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       chunk_fam = ((chunk_fam + 4 * fpw - 1) / (4 * fpw)) * (4 * fpw);      // whole workgroups of both kernels per chunk
       hip_check(hipEventRecord(ev_chunk[MAX_CHUNKS - 1], s), "event");      // (the second stream starts where this one is: buffers, memsets)
       hip_check(hipStreamWaitEvent(s2, ev_chunk[MAX_CHUNKS - 1], 0), "wait");
+      size_t dir_scan_bytes = 0;
+      if (direct) {
+        const DirSizeIn in(d_dir_size.as<uint32_t>(), DirCast());
+        (void)hipcub::DeviceScan::ExclusiveSum(nullptr, dir_scan_bytes, in, d_dir_off.as<uint64_t>(), (int)std::min<uint64_t>(chunk_fam, n_grp), s2);
+        d_scan_tmp2.reserve(dir_scan_bytes + 64);
+      }
       auto launch_parse = [&](uint32_t ci) {
         const uint32_t ga = ci * chunk_fam, gb = std::min<uint64_t>((uint64_t)ga + chunk_fam, n_grp);
         if (ga >= gb) return;
         const uint64_t waves = ((uint64_t)(gb - ga) + fpw - 1) / fpw;
         hipLaunchKernelGGL(k_split_parse, dim3((uint32_t)((waves + 1) / 2)), dim3(128), 0, s2, PK, ga, gb, fpw, (uint64_t*)nullptr, 3u, (uint4*)nullptr);
         hip_check(hipGetLastError(), "k_split_parse launch");
+        if (direct) {   // the chunk's record offsets: exclusive scan of the predicted family sizes, carried on from the chunk before
+          const DirSizeIn in(d_dir_size.as<uint32_t>() + ga, DirCast());
+          hip_check(hipcub::DeviceScan::ExclusiveSum(d_scan_tmp2.p, dir_scan_bytes, in, d_dir_off.as<uint64_t>() + ga, (int)(gb - ga), s2), "scan of the record sizes");
+          hipLaunchKernelGGL(k_dir_carry, dim3((gb - ga + 255) / 256), dim3(256), 0, s2, d_dir_off.as<uint64_t>() + ga, d_dir_size.as<uint32_t>() + ga, gb - ga,
+                             d_dir_base.as<uint64_t>() + ci);
+          hip_check(hipGetLastError(), "k_dir_carry launch");
+        }
         hip_check(hipEventRecord(ev_chunk[ci], s2), "event");
       };
       launch_parse(0);
@@ -3576,8 +3684,11 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
         auto launch_cols = [&](uint32_t g_first, uint32_t count) {
           PS.g0 = g_first;
           const dim3 grid((count + wpb - 1) / wpb), block(64 * wpb);
-          if (st2[ci].fixed) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<160, 80>), grid, block, lds, s, PS, count);
-          else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<0, 0>), grid, block, lds, s, PS, count);
+          if (direct) {
+            if (st2[ci].fixed) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<160, 80, 1>), grid, block, lds, s, PS, count);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<0, 0, 1>), grid, block, lds, s, PS, count);
+          } else if (st2[ci].fixed) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<160, 80, 0>), grid, block, lds, s, PS, count);
+          else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<0, 0, 0>), grid, block, lds, s, PS, count);
         };
         if (ci == 0) {   // the first stage takes the families in file order, chunk by chunk behind the record kernel
           for (uint32_t k = 0; k < n_chunks; k++) {
@@ -3735,6 +3846,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       F.T = P.T; F.TU = P.TU; F.min_reads = P.min_reads; F.min_cons_bq = P.min_cons_bq;
       F.col_code = P.col_code; F.col_qual = P.col_qual; F.col_err = P.col_err;
       F.col_depth = P.col_depth; F.min_input_bq = P.min_input_bq;
+      F.out = P.out; F.slot_desc = P.slot_desc; F.slot_err = P.slot_err; F.rg_len = P.rg_len; F.per_base_tags = P.per_base_tags;
       if (duplex) { F.rx_base = (char*)P.dends + offsetof(DuplexDesc, rx); F.rx_stride = sizeof(DuplexDesc); }
       else if (codec) { F.rx_base = (char*)P.cends + offsetof(CodecDesc, rx); F.rx_stride = sizeof(CodecDesc); }
       else { F.rx_base = (char*)P.ends + offsetof(EndDesc, rx); F.rx_stride = sizeof(EndDesc); }
@@ -3742,24 +3854,58 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       hip_check(hipGetLastError(), "k_call_full launch");
     }
   }
+  // ---- direct records: cE of the records whose columns had errors; did every prediction hold; is there anything to merge? ----------
+  bool dir_pure = false;
+  uint32_t dir_routed = 0;
+  uint64_t dir_total = 0;
+  if (direct) {
+    hipLaunchKernelGGL(k_fix_ce, dim3((n_slots + 255) / 256), dim3(256), 0, s, d_slot_desc.as<SlotDesc>(), d_slot_err.as<uint32_t>(), n_slots, d_out.as<uint8_t>(), P.rg_len);
+    hip_check(hipGetLastError(), "k_fix_ce launch");
+    unsigned long long h_flags = 0, h_def = 0, h_route = 0;
+    hip_check(hipMemcpyAsync(&h_flags, misc + 36, 8, hipMemcpyDeviceToHost, s), "D2H");
+    hip_check(hipMemcpyAsync(&h_def, misc + 29, 8, hipMemcpyDeviceToHost, s), "D2H");
+    hip_check(hipMemcpyAsync(&h_route, misc + 33, 8, hipMemcpyDeviceToHost, s), "D2H");
+    hip_check(hipMemcpyAsync(&dir_total, d_dir_base.as<uint64_t>() + last_split_chunks, 8, hipMemcpyDeviceToHost, s), "D2H");
+    hip_check(hipStreamSynchronize(s), "sync");
+    static const bool dir_verbose = [] { const char* e = getenv("FGX_S2_VERBOSE"); return e && e[0] == '1'; }();
+    if ((uint32_t)h_flags != 0) {          // a family's records are not what k_split_parse predicted: nothing of the batch can be trusted to be in place
+      fprintf(stderr, "[fgx] direct records: %u families differ in size from the prediction; this caller goes back to the column scratch (please report)\n", (uint32_t)h_flags);
+      direct_off = true;
+      return RUN_AGAIN_LARGER_POOL;
+    }
+    if ((uint32_t)(h_flags >> 32) != 0) {  // more record bytes than the first estimate of the room: the exact amount is known now
+      dir_cap_min = dir_total + dir_total / 16 + 4096;
+      if (dir_verbose) fprintf(stderr, "[fgx] direct records: the batch needs %llu bytes of output, %llu were at hand: again\n", (unsigned long long)dir_total, (unsigned long long)dir_cap);
+      return RUN_AGAIN_LARGER_POOL;
+    }
+    dir_routed = (uint32_t)h_route;
+    dir_pure = dir_routed == 0 && (uint32_t)h_def == 0;
+    last_direct = dir_pure ? 1 : 2;
+    if (dir_verbose) fprintf(stderr, "[fgx] direct records: %llu bytes in place, %u families left the split pipeline, %u deferred\n", (unsigned long long)dir_total, dir_routed, (uint32_t)h_def);
+  }
   hip_check(hipEventRecord(ev[1], s), "event");
 
-  size_t tmp_bytes = 0;
-  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_sizes.as<uint64_t>(), d_offsets.as<uint64_t>(), (int)n_slots, s);
-  d_scan_tmp.reserve(tmp_bytes);
-  hip_check(hipcub::DeviceScan::ExclusiveSum(d_scan_tmp.p, tmp_bytes, d_sizes.as<uint64_t>(), d_offsets.as<uint64_t>(), (int)n_slots, s), "scan");
+  uint64_t out_len = dir_total;
+  uint8_t* out_ptr = d_out.as<uint8_t>();
+  if (!dir_pure) {
+    size_t tmp_bytes = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_sizes.as<uint64_t>(), d_offsets.as<uint64_t>(), (int)n_slots, s);
+    d_scan_tmp.reserve(tmp_bytes);
+    hip_check(hipcub::DeviceScan::ExclusiveSum(d_scan_tmp.p, tmp_bytes, d_sizes.as<uint64_t>(), d_offsets.as<uint64_t>(), (int)n_slots, s), "scan");
 
-  // total output size = last offset + last size
-  uint64_t last[2];
-  hip_check(hipMemcpyAsync(&last[0], d_offsets.as<uint64_t>() + (n_slots - 1), 8, hipMemcpyDeviceToHost, s), "D2H");
-  hip_check(hipMemcpyAsync(&last[1], d_sizes.as<uint64_t>() + (n_slots - 1), 8, hipMemcpyDeviceToHost, s), "D2H");
-  hip_check(hipStreamSynchronize(s), "sync");
-  uint64_t out_len = last[0] + last[1];
-  d_out.reserve(out_len + 16);
+    // total output size = last offset + last size
+    uint64_t last[2];
+    hip_check(hipMemcpyAsync(&last[0], d_offsets.as<uint64_t>() + (n_slots - 1), 8, hipMemcpyDeviceToHost, s), "D2H");
+    hip_check(hipMemcpyAsync(&last[1], d_sizes.as<uint64_t>() + (n_slots - 1), 8, hipMemcpyDeviceToHost, s), "D2H");
+    hip_check(hipStreamSynchronize(s), "sync");
+    out_len = last[0] + last[1];
+    if (direct) { d_out2.reserve(out_len + 16); out_ptr = d_out2.as<uint8_t>(); }   // the merged stream: d_out holds the directly written records
+    else { d_out.reserve(out_len + 16); out_ptr = d_out.as<uint8_t>(); }
+  }
 
   EmitParams E;
   memset(&E, 0, sizeof(E));
-  E.blob = d_blob; E.rec_off = d_rec_off; E.ends = d_ends.as<EndDesc>(); E.out_off = d_offsets.as<uint64_t>(); E.out = d_out.as<uint8_t>();
+  E.blob = d_blob; E.rec_off = d_rec_off; E.ends = d_ends.as<EndDesc>(); E.out_off = d_offsets.as<uint64_t>(); E.out = out_ptr;
   E.out_base = 0; E.slot0 = 0; E.slot_end = n_slots;
   E.col_code = P.col_code; E.col_qual = P.col_qual; E.col_depth = P.col_depth; E.col_err = P.col_err;
   E.prefix = d_strings.as<char>(); E.prefix_len = P.prefix_len; E.rg = d_strings.as<char>() + P.prefix_len; E.rg_len = P.rg_len;
@@ -3788,6 +3934,17 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
     DE.per_base_tags = P.per_base_tags; DE.cell0 = P.cell0; DE.cell1 = P.cell1;
     hipLaunchKernelGGL(k_emit_duplex_fast, dim3((n_slots + 3) / 4), dim3(256), 0, s, DE);
     hipLaunchKernelGGL(k_emit_duplex, dim3((n_slots + 3) / 4), dim3(256), 0, s, DE);
+  } else if (direct) {
+    if (!dir_pure) {
+      // the merge: the families that left the split pipeline are written by k_emit from their descriptors, the directly written ones move
+      // to their place in the final stream
+      if (dir_routed) {
+        E.fam_list = d_route.as<uint32_t>(); E.n_fam = dir_routed;
+        hipLaunchKernelGGL(k_emit, dim3((dir_routed + 3) / 4), dim3(256), 0, s, E);
+      }
+      hipLaunchKernelGGL(k_dir_copy, dim3((n_grp + 3) / 4), dim3(256), 0, s, d_split_out.as<SplitOut>(), d_dir_off.as<uint64_t>(), d_offsets.as<uint64_t>(),
+                         d_sizes.as<uint64_t>(), d_out.as<uint8_t>(), out_ptr, n_grp);
+    }
   } else hipLaunchKernelGGL(k_emit, dim3((n_grp + 3) / 4), dim3(256), 0, s, E);   // one wavefront per family (slots 3g .. 3g + 2)
   hip_check(hipGetLastError(), "k_emit launch");
   hip_check(hipEventRecord(ev[3], s), "event");
@@ -3799,7 +3956,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
   float ms = 0;
   hip_check(hipEventElapsedTime(&ms, c->ev0, c->ev1), "elapsed");
 
-  res->d_out = d_out.as<uint8_t>();
+  res->d_out = out_ptr;
   res->out_len = out_len;
   res->count = h_misc[1];   // every consensus read of a fast-path family is one record
   for (int i = 0; i < FGX_STATS_LEN; i++) res->stats[i] = h_misc[i];
