@@ -92,7 +92,7 @@ struct SplitOut {           // 32 bytes: what k_split_cols decided for a family;
   uint16_t lc_a, lc_b;      // consensus lengths
   uint32_t rej;             // rejected reads: insufficient | zero length << 8 | orphan << 16
   uint32_t ov_agree, ov_dis, ov_corr;   // overlapping-bases counters
-  uint32_t _pad;
+  uint32_t depth_stats;     // direct records: max | min << 8 of the per-base depths of end A, the same of end B << 16 (the cD / cM tags; at most 16 reads per end)
 };
 static_assert(sizeof(SplitRec) == 32 && sizeof(SplitFam) == 32 && sizeof(SplitOut) == 32, "split descriptors are moved as two 16-byte pieces");
 
@@ -200,6 +200,7 @@ struct FastPath {
   DevBuf d_dir_size, d_dir_off, d_dir_base, d_slot_desc, d_slot_err, d_out2, d_scan_tmp2;   // direct records (simplex_split.inc, fastpath.h)
   bool direct_off = false;                // a batch whose predicted record sizes did not hold: this caller stays on the scratch path (diagnostics: last_direct)
   uint64_t dir_cap_min = 0;               // output room a batch asked for beyond the first estimate
+  uint32_t dir_chunks_run = 0;            // chunks of the last direct batch that held families: d_dir_base[dir_chunks_run] = bytes of all directly written records
   int last_direct = 0;                    // 0: the last batch went through the column scratch + k_emit; 1: records written directly; 2: directly + merge
   uint32_t lds_wave_bytes = 6144;         // wave-per-family kernel: LDS copy of one family's raw records
   uint32_t lds_wave_bytes_duplex = 8704;  // duplex molecules carry both strands (config 3: 24 records x ~330 B)

@@ -3463,9 +3463,12 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
   // most 32 records (FGX_SPLIT=0 / 2: never / always).
   static const int split_mode = [] { const char* e = getenv("FGX_SPLIT"); return e ? atoi(e) : 1; }();
   const bool use_split = simplex_v2 && use_split_env && !seg4 && (split_mode == 2 || (double)small_recs >= 0.9 * (double)n_rec);
-  // Direct records (fastpath.h): the split pipeline's column kernel writes the consensus records itself.  FGX_DIRECT=0 keeps the column
-  // scratch + k_emit for every family (the round-3 chain; also what a batch falls back to when a predicted record size does not hold).
-  const bool direct_env = [] { const char* e = getenv("FGX_DIRECT"); return !(e && e[0] == '0'); }();   // (read per batch: tools/direct_check.py switches it between two runs of one process)
+  // Direct records (fastpath.h): the split pipeline's column kernel writes the consensus records itself (FGX_DIRECT=1).  Byte-identical on
+  // the GPU (tools/direct_check.py, tests/test_gpu_direct_records.py), but NOT the default: measured on 5 M depth-8 families the column kernel
+  // pays for the emission what k_emit cost as a kernel of its own (k_split_cols 2.82 -> 3.82 ms per chunk, k_split_parse 0.94 -> 1.41 ms with the
+  // size prediction; step 33.7 -> 40.2 ms with the merge, ~34 ms without: profiles/r04_experiments.md) — vector-instruction issue is what the
+  // stage is short of, and the record's constant bytes cost as many instructions written from here as from there.
+  const bool direct_env = [] { const char* e = getenv("FGX_DIRECT"); return e && e[0] == '1'; }();   // (read per batch: tools/direct_check.py switches it between two runs of one process)
   const bool direct = use_split && direct_env && !direct_off;
   last_direct = 0;
   uint64_t col_cap = lastb[0] + lastb[1] + 64;
@@ -3612,6 +3615,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       if (n_chunks > (uint32_t)MAX_CHUNKS - 1) n_chunks = MAX_CHUNKS - 1;   // (the last event marks where the second stream starts)
       uint32_t chunk_fam = (n_grp + n_chunks - 1) / n_chunks;
       last_split_chunks = n_chunks;
+      dir_chunks_run = (n_grp + chunk_fam - 1) / chunk_fam;     // chunks that hold families (the rounding of chunk_fam can leave the last ones empty)
       chunk_fam = ((chunk_fam + 4 * fpw - 1) / (4 * fpw)) * (4 * fpw);      // whole workgroups of both kernels per chunk
       hip_check(hipEventRecord(ev_chunk[MAX_CHUNKS - 1], s), "event");      // (the second stream starts where this one is: buffers, memsets)
       hip_check(hipStreamWaitEvent(s2, ev_chunk[MAX_CHUNKS - 1], 0), "wait");
@@ -3865,7 +3869,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
     hip_check(hipMemcpyAsync(&h_flags, misc + 36, 8, hipMemcpyDeviceToHost, s), "D2H");
     hip_check(hipMemcpyAsync(&h_def, misc + 29, 8, hipMemcpyDeviceToHost, s), "D2H");
     hip_check(hipMemcpyAsync(&h_route, misc + 33, 8, hipMemcpyDeviceToHost, s), "D2H");
-    hip_check(hipMemcpyAsync(&dir_total, d_dir_base.as<uint64_t>() + last_split_chunks, 8, hipMemcpyDeviceToHost, s), "D2H");
+    hip_check(hipMemcpyAsync(&dir_total, d_dir_base.as<uint64_t>() + dir_chunks_run, 8, hipMemcpyDeviceToHost, s), "D2H");
     hip_check(hipStreamSynchronize(s), "sync");
     static const bool dir_verbose = [] { const char* e = getenv("FGX_S2_VERBOSE"); return e && e[0] == '1'; }();
     if ((uint32_t)h_flags != 0) {          // a family's records are not what k_split_parse predicted: nothing of the batch can be trusted to be in place

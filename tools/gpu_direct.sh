@@ -8,7 +8,7 @@ if [ "$2" != "quick" ]; then
   timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider -rfEs --timeout 600 > $OUT/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest.log
   grep -E "passed|failed|^FAILED|^ERROR" $OUT/pytest.log | tail -25
 fi
-timeout 400 python bench.py --no-strong-block > $OUT/bench_line.json 2> $OUT/bench.err; echo "bench rc=$?"; tail -3 $OUT/bench.err
+timeout 400 python bench.py --no-strong-block --no-cpu-baseline > $OUT/bench_line.json 2> $OUT/bench.err; echo "bench rc=$?"; tail -3 $OUT/bench.err
 python - $OUT/bench_line.json <<'PY'
 import json, sys
 try:
@@ -18,9 +18,10 @@ try:
 except Exception as e:
     print("no bench line:", e)
 PY
-FGX_DIRECT=0 timeout 400 python bench.py --no-strong-block --no-cpu-baseline --steps 5 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('FGX_DIRECT=0: value %.4g ms/step %.2f k_family %.2f k_emit %.2f'%(d['value'], d['ms_per_step'], r['kernel_ms'], r['k_emit_ms']))"
+FGX_S2_VERBOSE=1 FGX_DIRECT=1 timeout 400 python bench.py --no-strong-block --no-cpu-baseline --steps 5 2> $OUT/bench_direct.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('FGX_DIRECT=1: value %.4g ms/step %.2f k_family %.2f k_emit %.2f'%(d['value'], d['ms_per_step'], r['kernel_ms'], r['k_emit_ms']))"
+grep "direct records" $OUT/bench_direct.err | tail -2
 cd /tmp; export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o simplex -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-strong-block > $OUT/stats.log 2>&1
+FGX_DIRECT=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o simplex_direct -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-strong-block > $OUT/stats.log 2>&1
 rm -rf $OUT/*_agent_info.csv $OUT/*kernel_trace.csv
 python - $OUT <<'PY'
 import csv, glob, sys
