@@ -418,7 +418,7 @@ class _HandleCaller(ConsensusCaller):
     # ---- a BAM file in, a consensus BAM file out (the streaming pipeline of csrc/pipeline.cpp) ---------
     def run_bam(self, in_path: str, out_path: str, header_text: Optional[str] = None, level: int = 1, threads: Optional[int] = None,
                 chunk_raw_bytes: int = 0, tag: str = "MI", cell_tag: Optional[str] = "CB", strip_strand_suffix: bool = False,
-                allow_unmapped: bool = False, host_inflate: bool = False, device_deflate: bool = False) -> dict:
+                allow_unmapped: bool = False, host_inflate: bool = False, device_deflate: bool = False, rejects_path: Optional[str] = None) -> dict:
         """Reads the grouped BAM `in_path` chunk by chunk (BGZF inflate on the host cores, record boundaries + MI grouping + the
         consensus batch on the device — and the BGZF inflate itself, unless `host_inflate` — BGZF deflate on the host cores) and writes the consensus BAM `out_path`; the stages of
         successive chunks overlap.  Returns the pipeline's counters and stage times."""
@@ -430,14 +430,18 @@ class _HandleCaller(ConsensusCaller):
         hb = np.frombuffer(hdr, dtype=np.uint8)
         o = GroupOptions(tag.encode(), cell_tag.encode() if cell_tag else b"\0\0", int(strip_strand_suffix), int(allow_unmapped))
         st = BamRunStats()
-        rc = lib.fgx_run_bam(self._h, in_path.encode(), out_path.encode(), hb.ctypes.data, hb.size, C.byref(o), threads or 0, level,
-                             chunk_raw_bytes, (1 if host_inflate else 0) | (2 if device_deflate else 0), C.byref(st))
+        n_rej = C.c_uint64(0)
+        # `rejects_path` = the reference's `--rejects <file>` (simplex.rs:260-285): the input header + the rejected input records, batch-input order
+        rc = lib.fgx_run_bam_rejects(self._h, in_path.encode(), out_path.encode(), rejects_path.encode() if rejects_path else None, hb.ctypes.data, hb.size,
+                                     C.byref(o), threads or 0, level, chunk_raw_bytes, (1 if host_inflate else 0) | (2 if device_deflate else 0), C.byref(st),
+                                     C.byref(n_rej))
         if rc != 0:
             raise RuntimeError(lib.fgx_last_error(self._h).decode())
         self._last_stats = ConsensusCallingStats.from_array(st.stats)
         self._stats.merge(self._last_stats)
         out = {k: getattr(st, k) for k, _ in BamRunStats._fields_ if k not in ("stats", "_pad")}
         out["stats"] = [int(v) for v in st.stats]
+        out["rejected_records"] = int(n_rej.value)
         return out
 
     # ---- the trait -----------------------------------------------------------------------------

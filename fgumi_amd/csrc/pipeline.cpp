@@ -185,6 +185,10 @@ struct Chunk {
   bool have_crcs = false;
   bool precompressed = false;               // `packed` already holds the chunk's BGZF blocks (device deflate): the deflate stage passes it on
   uint64_t header_size = 0;                 // first chunk: bytes of the BAM header at the start of the inflated stream (0 = not found)
+  // --rejects: the chunk's rejected input records (block_size prefixes included, batch-input order), then their BGZF blocks
+  HostBuf rej, rej_comp, rej_packed;
+  std::vector<uint32_t> rej_sizes;
+  uint64_t rej_len = 0, rej_packed_len = 0;
 };
 
 // parses the BSIZE chain of raw[0 .. len): whole blocks into `blocks`; returns the bytes they cover
@@ -232,11 +236,17 @@ struct Pipeline {
   std::string err;
   double busy[N_STAGES] = {0, 0, 0, 0, 0};
   uint64_t in_bytes = 0, inflated_bytes = 0, out_bytes = 0, out_file_bytes = 0;
+  // --rejects (simplex.rs:7-12, 260-285): a second BGZF file that advertises the INPUT header and holds the rejected input records in
+  // batch-input order.  `rej_header` is filled by the middle stage of the first chunk (that is where the header is first seen whole).
+  std::string rej_path;
+  std::vector<uint8_t> rej_header;
+  uint64_t rej_bytes = 0, rej_file_bytes = 0;
 
   void reset() {                                     // before a run (the chunks keep their buffers)
     for (int k = 0; k < N_STAGES; k++) { progress[k] = 0; busy[k] = 0; }
     n_chunks_total = ~0ull; failed = false; err.clear();
     in_bytes = inflated_bytes = out_bytes = out_file_bytes = 0;
+    rej_path.clear(); rej_header.clear(); rej_bytes = rej_file_bytes = 0;
   }
   void fail(const std::string& e) {
     std::lock_guard<std::mutex> l(m);
@@ -283,6 +293,11 @@ struct Pipeline {
     }
     FILE* fout = fopen(out_path, "wb");
     if (!fout) { if (file) munmap((void*)file, file_len); close(fd); err = std::string("cannot create ") + out_path; return 1; }
+    FILE* frej = nullptr;
+    if (!rej_path.empty()) {
+      frej = fopen(rej_path.c_str(), "wb");
+      if (!frej) { fclose(fout); if (file) munmap((void*)file, file_len); close(fd); err = std::string("cannot create ") + rej_path; return 1; }
+    }
     if (raw_chunk < (1u << 16)) raw_chunk = 1u << 16;             // (a BGZF block is at most 64 KiB: every chunk holds at least one)
     Pool pool(threads ? threads : usable_cpus());
     const unsigned n_workers = pool.size() + Pool::MAX_HELPERS;   // (+ the stage threads that help, each under its own id)
@@ -471,6 +486,8 @@ struct Pipeline {
           const auto t0 = Clock::now();
           Chunk& c = chunks[s % N_CHUNKS];
           if (!c.precompressed && !deflate_stream(c.out.p, c.out_len, c.comp, c.comp_size, c.packed, &c.packed_len, c.out.pinned, c.have_crcs ? c.crcs.data() : nullptr)) { fail("deflate failed"); return; }
+          c.rej_packed_len = 0;
+          if (frej && c.rej_len && !deflate_stream(c.rej.p, c.rej_len, c.rej_comp, c.rej_sizes, c.rej_packed, &c.rej_packed_len, c.rej.pinned, nullptr)) { fail("deflate failed"); return; }
           busy[3] += since(t0);
           leave(3);
         }
@@ -488,16 +505,30 @@ struct Pipeline {
             put(hp.p, hl);
           }
         }
+        auto put_rej = [&](const uint8_t* p, size_t n) { if (n && fwrite(p, 1, n, frej) != n) throw std::runtime_error("write of the rejects file failed"); rej_file_bytes += n; };
+        bool rej_header_written = false;
+        auto rej_head = [&] {                          // the input's own header, as its own BGZF block(s) (known once the first chunk has passed the middle stage)
+          if (!frej || rej_header_written) return;
+          rej_header_written = true;
+          HostBuf hc, hp; std::vector<uint32_t> hs;
+          uint64_t hl = 0;
+          if (!rej_header.empty()) {
+            if (!deflate_stream(rej_header.data(), rej_header.size(), hc, hs, hp, &hl, false, nullptr)) throw std::runtime_error("deflate failed");
+            put_rej(hp.p, hl);
+          }
+        };
         for (uint64_t s = 0;; s++) {
           if (!enter(4, s)) break;
           const auto t0 = Clock::now();
           Chunk& c = chunks[s % N_CHUNKS];
           put(c.packed.p, c.packed_len);
+          if (frej) { rej_head(); put_rej(c.rej_packed.p, c.rej_packed_len); rej_bytes += c.rej_len; }
           busy[4] += since(t0);
           leave(4);
         }
         static const uint8_t EOF_BLOCK[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (!failed) put(EOF_BLOCK, 28);
+        if (!failed && frej) { rej_head(); put_rej(EOF_BLOCK, 28); }
       } catch (const std::exception& ex) { fail(ex.what()); }
     });
 
@@ -505,6 +536,7 @@ struct Pipeline {
     if (file) munmap((void*)file, file_len);
     close(fd);
     if (fclose(fout) != 0 && !failed) { failed = true; err = "closing the output file failed"; }
+    if (frej && fclose(frej) != 0 && !failed) { failed = true; err = "closing the rejects file failed"; }
     return failed ? 1 : 0;
   }
 };
@@ -576,7 +608,18 @@ const char* fgx_pipeline_last_error(void) { return t_perr.c_str(); }
 
 int fgx_run_bam(fgx_caller* c, const char* in_path, const char* out_path, const uint8_t* out_header, uint64_t out_header_len,
                 const fgx_group_options* g, uint32_t threads, int level, uint64_t chunk_raw_bytes, uint32_t flags, fgx_bam_run_stats* st) {
+  return fgx_run_bam_rejects(c, in_path, out_path, nullptr, out_header, out_header_len, g, threads, level, chunk_raw_bytes, flags, st, nullptr);
+}
+
+// fgx_run_bam with the reference's `--rejects <file>` (src/lib/commands/simplex.rs:7-12, 260-285, 613-720): a second BAM that advertises the
+// INPUT header and holds the rejected input records — the records of MI groups below --min-reads as they stand, the caller's rejects
+// (overlap-corrected copies) — in batch-input order.  The caller must have been created with track_rejects.
+int fgx_run_bam_rejects(fgx_caller* c, const char* in_path, const char* out_path, const char* rejects_path, const uint8_t* out_header, uint64_t out_header_len,
+                        const fgx_group_options* g, uint32_t threads, int level, uint64_t chunk_raw_bytes, uint32_t flags, fgx_bam_run_stats* st,
+                        uint64_t* rejected_records) {
   if (!c || !in_path || !out_path || !g || !st) return 1;
+  if (rejects_path && !c->opt.track_rejects) { c->err = "fgx_run_bam_rejects: the caller was not created with track_rejects"; return 1; }
+  if (rejected_records) *rejected_records = 0;
   c->err.clear();
   memset(st, 0, sizeof(*st));
   const auto t_begin = Clock::now();
@@ -607,6 +650,9 @@ int fgx_run_bam(fgx_caller* c, const char* in_path, const char* out_path, const 
     std::vector<uint8_t> h_blob; std::vector<uint64_t> h_off; std::vector<uint32_t> h_len, h_grp;   // (only for chunks with deferred families)
     Pipeline* P = &S->P;
     P->reset();
+    const bool want_rej = rejects_path != nullptr;
+    if (want_rej) P->rej_path = rejects_path;
+    uint64_t n_rejected = 0;
     bool ahead = false;                    // the chunk after the one in the device stage is already on its way into D[cur ^ 1]
     uint64_t ahead_seq = 0, ahead_inf_len = 0;
     // room for a stream of inf_len bytes behind the pad of D[buf]; `preserve` bytes at the end of the pad survive a regrowth
@@ -682,6 +728,11 @@ int fgx_run_bam(fgx_caller* c, const char* in_path, const char* out_path, const 
       uint8_t* const base = (uint8_t*)D[cur].p + base_off;
       const uint64_t start = (lead - base_off) + h;
       const uint64_t total = (lead - base_off) + left_len + ch.inf_len;
+      ch.rej_len = 0;
+      if (want_rej && h) {                                     // the rejects file advertises the input's own header: its bytes as the stream holds them
+        P->rej_header.resize(h);
+        fgx::hip_check(hipMemcpy(P->rej_header.data(), base + (lead - base_off), h, hipMemcpyDeviceToHost), "D2H header");
+      }
       // ---- the next chunk, if the host stages have it ready: upload + inflate under everything below ----
       auto try_ahead = [&] {
         if (ahead || ch.last || !P->staged(seq + 1)) return;
@@ -736,8 +787,14 @@ int fgx_run_bam(fgx_caller* c, const char* in_path, const char* out_path, const 
         uint32_t n_def = 0;
         const void* d_def = nullptr;
         int prc = fgx_process_batch_device(c, base, batch_end, d_koff.p, d_klen.p, batch_rec, d_grp.p, batch_grp, &out, &n_def, &d_def);
-        if (prc != 0) throw std::runtime_error(c->err);
-        if (n_def == 0 && device_deflate) {
+        // --rejects: the device entry serves the simplex caller through its side kernels; what it refuses (a group outside their scope: more
+        // than 128 records, malformed records; the duplex / CODEC callers; FGX_REJECTS_DEVICE=0) goes through the host entry in one piece
+        const bool host_whole = prc == 1 && c->opt.track_rejects;
+        if (prc != 0 && !host_whole) throw std::runtime_error(c->err);
+        const void* const rej_dev = host_whole ? nullptr : out.rejects;
+        const uint64_t rej_dev_len = host_whole ? 0 : out.rejects_len, rej_dev_n = host_whole ? 0 : out.n_rejects;
+        if (host_whole) n_def = batch_grp;
+        if (!host_whole && n_def == 0 && device_deflate) {
           // the records are cut into BGZF blocks and compressed where they lie; an eighth of the bytes comes back
           sec_cons += since(t0);
           t0 = Clock::now();
@@ -749,7 +806,7 @@ int fgx_run_bam(fgx_caller* c, const char* in_path, const char* out_path, const 
           if (plen) fgx::hip_check(hipMemcpy(ch.packed.p, S->d_packed.p, plen, hipMemcpyDeviceToHost), "D2H blocks");
           ch.packed_len = plen; ch.out_len = out.data_len; ch.precompressed = true;
           sec_d2h += since(t0);
-        } else if (n_def == 0) {
+        } else if (!host_whole && n_def == 0) {
           sec_cons += since(t0);
           t0 = Clock::now();
           // the records come back into pinned memory, and with them the CRC-32 of every BGZF payload they will be cut into (a
@@ -766,7 +823,7 @@ int fgx_run_bam(fgx_caller* c, const char* in_path, const char* out_path, const 
           }
           ch.out_len = out.data_len; ch.have_crcs = true;
           sec_d2h += since(t0);
-        } else if (subset_enabled() && [&] {
+        } else if (!host_whole && subset_enabled() && [&] {
                      // Default (FGX_PIPE_SUBSET=0 opts out): only the deferred groups come back (their records, a span per group), the general path
                      // decides them, and the merged stream is assembled on the host — the batch is not uploaded and run a second time.
                      fgx_output merged;
@@ -785,8 +842,9 @@ int fgx_run_bam(fgx_caller* c, const char* in_path, const char* out_path, const 
                    }()) {
         } else {
           // families the device pipelines do not decide: the whole batch through the host entry (it splices both paths in group order)
-          st->deferred_groups += n_def;
-          if (pipe_debug()) fprintf(stderr, "fgx_run_bam: %u of %u groups deferred: the whole batch through the host entry\n", n_def, batch_grp);
+          st->deferred_groups += host_whole ? 0 : n_def;
+          if (pipe_debug()) fprintf(stderr, host_whole ? "fgx_run_bam: --rejects of this batch need the host entry: the whole batch (%u of %u groups)\n"
+                                                       : "fgx_run_bam: %u of %u groups deferred: the whole batch through the host entry\n", n_def, batch_grp);
           h_blob.resize(batch_end + 16); h_off.resize(batch_rec); h_len.resize(batch_rec); h_grp.resize((size_t)batch_grp + 1);
           fgx::hip_check(hipMemcpy(h_blob.data(), base, batch_end, hipMemcpyDeviceToHost), "D2H");
           fgx::hip_check(hipMemcpy(h_off.data(), d_koff.p, (size_t)batch_rec * 8, hipMemcpyDeviceToHost), "D2H");
@@ -799,6 +857,16 @@ int fgx_run_bam(fgx_caller* c, const char* in_path, const char* out_path, const 
           if (out.data_len) memcpy(ch.out.p, out.data, out.data_len);
           ch.out_len = out.data_len;
           sec_cons += since(t0);
+        }
+        if (want_rej) {   // the batch's rejected input records: the side kernels' stream (HBM) or the host entry's
+          const uint64_t rl = host_whole ? out.rejects_len : rej_dev_len;
+          ch.rej.reserve(rl + 64, true);
+          if (rl) {
+            if (host_whole) memcpy(ch.rej.p, out.rejects, rl);
+            else fgx::hip_check(hipMemcpy(ch.rej.p, rej_dev, rl, hipMemcpyDeviceToHost), "D2H rejects");
+          }
+          ch.rej_len = rl;
+          n_rejected += host_whole ? out.n_rejects : rej_dev_n;
         }
         for (int i = 0; i < FGX_STATS_LEN; i++) st->stats[i] += out.stats[i];
         st->consensus_records += out.count;
@@ -833,6 +901,7 @@ int fgx_run_bam(fgx_caller* c, const char* in_path, const char* out_path, const 
     st->seconds_device_deflate = sec_defl; st->device_deflate = device_deflate ? 1u : 0u;
     st->seconds_h2d = sec_h2d; st->seconds_boundaries = sec_bound; st->seconds_grouping = sec_group; st->seconds_consensus = sec_cons; st->seconds_d2h = sec_d2h;
     st->seconds_total = since(t_begin);
+    if (rejected_records) *rejected_records = n_rejected;
     if (rc != 0) { c->err = P->err; return 1; }
     return 0;
   } catch (const std::exception& ex) { c->err = ex.what(); return 3; }

@@ -377,6 +377,15 @@ typedef struct fgx_bam_run_stats {
                                        the same compressor on the host's cores the device stage is the one that bounds the pipeline */
 int fgx_run_bam(fgx_caller* c, const char* in_path, const char* out_path, const uint8_t* out_header, uint64_t out_header_len,
                 const fgx_group_options* g, uint32_t threads, int level, uint64_t chunk_raw_bytes, uint32_t flags, fgx_bam_run_stats* st);
+/* fgx_run_bam with the reference's `--rejects <file>` (src/lib/commands/simplex.rs:7-12, 260-285, 613-720; duplex.rs / codec.rs alike): a second
+ * BGZF BAM that advertises the INPUT header (its bytes as the input holds them: @RG / @PG / contigs preserved) and holds the rejected input
+ * records in batch-input order — the records of MI groups below --min-reads as they stand, and the caller's rejects (overlap-corrected copies
+ * where the pre-correction ran).  `c` must have been created with track_rejects; rejects_path = NULL is fgx_run_bam.  The simplex caller's
+ * rejects come from the side kernels of the device entry (fgumi_amd/csrc/reject_device.hip); a batch they refuse, and the duplex / CODEC
+ * callers, go through the host entry in one piece.  *rejected_records (may be NULL) = records written to the rejects file. */
+int fgx_run_bam_rejects(fgx_caller* c, const char* in_path, const char* out_path, const char* rejects_path, const uint8_t* out_header,
+                        uint64_t out_header_len, const fgx_group_options* g, uint32_t threads, int level, uint64_t chunk_raw_bytes, uint32_t flags,
+                        fgx_bam_run_stats* st, uint64_t* rejected_records);
 /* The device's DEFLATE decoder (fgumi_amd/csrc/inflate_core.h, one GPU lane per BGZF block) run on the host — the same source, for
  * tests without a device.  `in` must be readable for 8 bytes past in_len; `out_len` = the block's ISIZE.  Returns the decoder's
  * status (0 = ok) and, in *crc_out, the CRC-32 of the output computed with the device's 64-slice fold. */

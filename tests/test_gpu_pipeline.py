@@ -237,3 +237,55 @@ def test_chunks_that_keep_no_record_at_all(tmp_path):
     assert st["chunks"] > 12
     assert got == want["data"] and st["kept_records"] == g.n_rec and st["groups"] == g.n_grp
     c.close()
+
+
+def _rejects_case(tmp_path, caller, opts, g, batch_groups, chunk, **run_kw):
+    """fgx_run_bam_rejects: consensus BAM == the oracle's records, rejects BAM == the oracle's rejects (batch-input order) under the INPUT header."""
+    refs = [("chr%d" % (i + 1), 2147483647) for i in range(24)]
+    src, dst, rej = str(tmp_path / "grouped.bam"), str(tmp_path / "consensus.bam"), str(tmp_path / "rejects.bam")
+    in_text = bgzf.grouped_input_header(refs)
+    bgzf.write_bam(src, in_text, refs, g.blob)
+    st = caller.run_bam(src, dst, chunk_raw_bytes=chunk, threads=8, rejects_path=rej, **run_kw)
+    want = orc.process(opts, g.blob, g.rec_off, g.rec_len, g.grp_first, batch_groups=batch_groups)
+    text, orefs, stream, off, ln = bgzf.read_bam(dst)
+    got = b"".join(bytes(stream[int(o) - 4:int(o) + int(l)]) for o, l in zip(off, ln))
+    assert got == want["data"], "the consensus BAM's records differ from the oracle's"
+    rtext, rrefs, rstream, roff, rln = bgzf.read_bam(rej)
+    rgot = b"".join(bytes(rstream[int(o) - 4:int(o) + int(l)]) for o, l in zip(roff, rln))
+    assert rtext == in_text and [n for n, _ in rrefs] == [n for n, _ in refs], "the rejects BAM must advertise the input header"
+    assert want["n_rejects"] > 0 and len(roff) == want["n_rejects"] == st["rejected_records"]
+    assert rgot == want["rejects"], "the rejects BAM's records differ from the oracle's rejects"
+    assert st["stats"][:len(want["stats"])] == [int(v) for v in want["stats"]]
+    return st
+
+
+def test_run_bam_with_rejects_simplex(tmp_path):
+    """`--rejects` through the streaming pipeline (simplex.rs:7-12, 260-285): groups below --min-reads leave their input records, the caller's
+    rejects are the overlap-corrected copies; one chunk and many (groups cross chunks, rejects of successive batches keep input order)."""
+    g = simulate_grouped_reads(3000, family_size=1, family_size_max=9)
+    for kw in (dict(min_reads=2), dict(min_reads=3, max_reads=4)):
+        c = VanillaUmiConsensusCaller("", "A", VanillaUmiConsensusOptions(min_consensus_base_quality=2, cell_tag="CB", **kw), track_rejects=True, overlapping_consensus=True)
+        o = fgx_opts.defaults(track_rejects=1, **kw)
+        one = _rejects_case(tmp_path, c, o, g, 50, 0)
+        many = _rejects_case(tmp_path, c, o, g, 50, 1 << 16)
+        assert one["chunks"] == 1 and many["chunks"] > 10
+        c.close()
+
+
+def test_run_bam_with_rejects_takes_the_host_entry_when_the_side_kernels_refuse(tmp_path):
+    """A family of 300 records is outside the reject side kernels' scope (and the device pipeline's): that batch goes through the host entry
+    in one piece, rejects included; and the duplex caller, whose `--rejects` the device entry does not serve, does so for every batch."""
+    big = simulate_grouped_reads(1, family_size=150)
+    small = simulate_grouped_reads(300, family_size=1, family_size_max=5, seed=7)
+    recs = [small.records(i) for i in range(150)] + [big.records(0)] + [small.records(i) for i in range(150, 300)]
+    from fgumi_amd import GroupedReads
+    g = GroupedReads.from_groups(recs)
+    c = VanillaUmiConsensusCaller("", "A", VanillaUmiConsensusOptions(min_reads=2, min_consensus_base_quality=2, cell_tag="CB"), track_rejects=True, overlapping_consensus=True)
+    _rejects_case(tmp_path, c, fgx_opts.defaults(track_rejects=1, min_reads=2), g, 50, 1 << 16)
+    c.close()
+    gd = simulate_grouped_reads(400, family_size=1, family_size_max=6, duplex=1)
+    od = fgx_opts.defaults(kind=1, track_rejects=1)
+    od.duplex_min_reads[0], od.duplex_min_reads[1], od.duplex_min_reads[2] = 3, 2, 1
+    cd = DuplexConsensusCaller("", "A", [3, 2, 1], cell_tag="CB", overlapping_consensus=True, track_rejects=True)
+    _rejects_case(tmp_path, cd, od, gd, 100, 1 << 16, strip_strand_suffix=True)
+    cd.close()
