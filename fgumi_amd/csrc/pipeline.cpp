@@ -606,6 +606,63 @@ int fgx_bgzf_recompress_file(const char* in_path, const char* out_path, uint32_t
 }
 const char* fgx_pipeline_last_error(void) { return t_perr.c_str(); }
 
+// The device's BGZF inflate (+ CRC-32 check) alone, for measurements and tests: the whole blocks of raw[0 .. raw_len) are uploaded once and
+// inflated `reps` times; *ms = average device time of one pass (HIP events), *inflated_len = bytes produced.  When `out` is given
+// (inflated_cap bytes) the stream of the last pass is copied there.  Returns 0, or non-zero with fgx_last_error(c).
+int fgx_bgzf_inflate_device_bench(fgx_caller* c, const uint8_t* raw, uint64_t raw_len, uint32_t reps, double* ms, uint64_t* inflated_len, uint8_t* out,
+                                  uint64_t inflated_cap) {
+  if (!c || !raw || !ms || !inflated_len) return 1;
+  c->err.clear();
+  try {
+    fgx::hip_check(hipSetDevice(c->device), "hipSetDevice");
+    std::vector<Block> blocks;
+    uint64_t infl = 0;
+    std::string e;
+    const size_t used = block_table(raw, raw_len, blocks, &infl, &e);
+    if (used == (size_t)-1) { c->err = e; return 1; }
+    std::vector<fgx::BgzfDevBlock> dev(blocks.size());
+    for (size_t i = 0; i < blocks.size(); i++) {
+      const Block& b = blocks[i];
+      const uint32_t xlen = raw[b.in_off + 10] | (raw[b.in_off + 11] << 8);
+      fgx::BgzfDevBlock d;
+      d.in_off = b.in_off + 12 + xlen; d.out_off = b.out_off; d.in_len = b.in_size - 12 - xlen - 8; d.isize = b.isize;
+      memcpy(&d.crc, raw + b.in_off + b.in_size - 8, 4);
+      d._pad = 0;
+      dev[i] = d;
+    }
+    fgx::DevBuf d_raw, d_blk, d_out;
+    d_raw.reserve(used + 64); d_blk.reserve(dev.size() * sizeof(fgx::BgzfDevBlock) + 64); d_out.reserve(infl + 256);
+    uint32_t* h_status = nullptr;
+    fgx::hip_check(hipHostMalloc((void**)&h_status, 64, hipHostMallocDefault), "hipHostMalloc");
+    hipStream_t s = c->stream;
+    fgx::hip_check(hipMemcpyAsync(d_raw.p, raw, used, hipMemcpyHostToDevice, s), "H2D");
+    fgx::hip_check(hipMemsetAsync((uint8_t*)d_raw.p + used, 0, 64, s), "memset");
+    const size_t blk_bytes = dev.size() * sizeof(fgx::BgzfDevBlock);
+    if (blk_bytes) fgx::hip_check(hipMemcpyAsync(d_blk.p, dev.data(), blk_bytes, hipMemcpyHostToDevice, s), "H2D");
+    uint32_t* d_status = (uint32_t*)((uint8_t*)d_blk.p + ((blk_bytes + 15) & ~(size_t)15));
+    hipEvent_t e0, e1;
+    fgx::hip_check(hipEventCreate(&e0), "event"); fgx::hip_check(hipEventCreate(&e1), "event");
+    int rc = 0;
+    fgx::bgzf_inflate_launch(s, d_raw.as<uint8_t>(), d_blk.as<fgx::BgzfDevBlock>(), (uint32_t)dev.size(), d_out.as<uint8_t>(), d_status, h_status);   // warm-up
+    fgx::hip_check(hipStreamSynchronize(s), "sync");
+    if (fgx::bgzf_inflate_status(c, *h_status) != 0) rc = 1;
+    fgx::hip_check(hipEventRecord(e0, s), "event");
+    for (uint32_t r = 0; r < (reps ? reps : 1u) && rc == 0; r++)
+      fgx::bgzf_inflate_launch(s, d_raw.as<uint8_t>(), d_blk.as<fgx::BgzfDevBlock>(), (uint32_t)dev.size(), d_out.as<uint8_t>(), d_status, h_status);
+    fgx::hip_check(hipEventRecord(e1, s), "event");
+    fgx::hip_check(hipStreamSynchronize(s), "sync");
+    if (rc == 0 && fgx::bgzf_inflate_status(c, *h_status) != 0) rc = 1;
+    float t = 0;
+    fgx::hip_check(hipEventElapsedTime(&t, e0, e1), "elapsed");
+    *ms = (double)t / (double)(reps ? reps : 1u);
+    *inflated_len = infl;
+    if (rc == 0 && out && inflated_cap >= infl && infl) fgx::hip_check(hipMemcpy(out, d_out.p, infl, hipMemcpyDeviceToHost), "D2H");
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipHostFree(h_status);
+    d_raw.free_(); d_blk.free_(); d_out.free_();
+    return rc;
+  } catch (const std::exception& ex) { c->err = ex.what(); return 3; }
+}
+
 int fgx_run_bam(fgx_caller* c, const char* in_path, const char* out_path, const uint8_t* out_header, uint64_t out_header_len,
                 const fgx_group_options* g, uint32_t threads, int level, uint64_t chunk_raw_bytes, uint32_t flags, fgx_bam_run_stats* st) {
   return fgx_run_bam_rejects(c, in_path, out_path, nullptr, out_header, out_header_len, g, threads, level, chunk_raw_bytes, flags, st, nullptr);
@@ -789,7 +846,8 @@ int fgx_run_bam_rejects(fgx_caller* c, const char* in_path, const char* out_path
         int prc = fgx_process_batch_device(c, base, batch_end, d_koff.p, d_klen.p, batch_rec, d_grp.p, batch_grp, &out, &n_def, &d_def);
         // --rejects: the device entry serves the simplex caller through its side kernels; what it refuses (a group outside their scope: more
         // than 128 records, malformed records; the duplex / CODEC callers; FGX_REJECTS_DEVICE=0) goes through the host entry in one piece
-        const bool host_whole = prc == 1 && c->opt.track_rejects;
+        // (and the methylation-aware mode, whose annotation runs on the general path: every batch of such a caller)
+        const bool host_whole = prc == 1 && (c->opt.track_rejects || c->opt.methylation_mode != FGX_METHYLATION_DISABLED);
         if (prc != 0 && !host_whole) throw std::runtime_error(c->err);
         const void* const rej_dev = host_whole ? nullptr : out.rejects;
         const uint64_t rej_dev_len = host_whole ? 0 : out.rejects_len, rej_dev_n = host_whole ? 0 : out.n_rejects;
@@ -843,7 +901,7 @@ int fgx_run_bam_rejects(fgx_caller* c, const char* in_path, const char* out_path
         } else {
           // families the device pipelines do not decide: the whole batch through the host entry (it splices both paths in group order)
           st->deferred_groups += host_whole ? 0 : n_def;
-          if (pipe_debug()) fprintf(stderr, host_whole ? "fgx_run_bam: --rejects of this batch need the host entry: the whole batch (%u of %u groups)\n"
+          if (pipe_debug()) fprintf(stderr, host_whole ? "fgx_run_bam: --rejects / the methylation-aware mode of this batch need the host entry: the whole batch (%u of %u groups)\n"
                                                        : "fgx_run_bam: %u of %u groups deferred: the whole batch through the host entry\n", n_def, batch_grp);
           h_blob.resize(batch_end + 16); h_off.resize(batch_rec); h_len.resize(batch_rec); h_grp.resize((size_t)batch_grp + 1);
           fgx::hip_check(hipMemcpy(h_blob.data(), base, batch_end, hipMemcpyDeviceToHost), "D2H");

@@ -390,10 +390,18 @@ int fgx_run_bam_rejects(fgx_caller* c, const char* in_path, const char* out_path
  * tests without a device.  `in` must be readable for 8 bytes past in_len; `out_len` = the block's ISIZE.  Returns the decoder's
  * status (0 = ok) and, in *crc_out, the CRC-32 of the output computed with the device's 64-slice fold. */
 int fgx_inflate_block_host(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, uint32_t* crc_out);
+/* ... in the form the device kernel instantiates (every byte through a ring of `win` = 512 / 1024 / 4096 bytes that serves the near matches and
+ * leaves for the output in 16-byte pieces; work area behind pointers) */
+int fgx_inflate_block_host_staged(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, uint32_t win);
 /* The device's DEFLATE compressor (fgumi_amd/csrc/deflate_core.h, one GPU lane per BGZF block: greedy LZ77 + one dynamic Huffman
  * code per block) run on the host, for tests without a device.  `in` readable for 8 bytes past n (n <= 65535).  Returns the bytes
  * written to `out`, or 0 when they do not fit `cap` (the caller stores the block). */
 uint32_t fgx_deflate_block_host(const uint8_t* in, uint32_t n, uint8_t* out, uint32_t cap);
+/* The device's BGZF inflate (+ CRC-32 check) alone (fgumi_amd/csrc/bgzf_device.hip), for measurements and tests: the whole blocks of
+ * raw[0 .. raw_len) go to the device once and are inflated `reps` times; *ms = device time of one pass, *inflated_len = bytes produced; with
+ * `out` (inflated_cap bytes) the inflated stream comes back.  Returns 0, or non-zero with fgx_last_error(c) (a failing block is named). */
+int fgx_bgzf_inflate_device_bench(fgx_caller* c, const uint8_t* raw, uint64_t raw_len, uint32_t reps, double* ms, uint64_t* inflated_len, uint8_t* out,
+                                  uint64_t inflated_cap);
 /* The host stages alone (read, inflate, deflate, write) around a copy: re-blocks a BGZF file; needs no device. */
 int fgx_bgzf_recompress_file(const char* in_path, const char* out_path, uint32_t threads, int level, uint64_t chunk_raw_bytes,
                              uint64_t* inflated_bytes);

@@ -200,3 +200,30 @@ def test_python_mirror_of_set_reference():
     assert out.count == 2
     for r in map(bamutil.parse, split_records(out.data)):
         assert "bu" in r["tags"] and "bt" in r["tags"] and "au" not in r["tags"]
+
+
+def test_run_bam_with_the_methylation_aware_mode(tmp_path):
+    """BAM file in, consensus BAM file out with `--methylation-mode em-seq` (simplex.rs:240-245): the streaming pipeline sends every batch of
+    such a caller through the host entry (the annotation runs on the general path) — same records as the oracle's, MM / ML / cu / ct included,
+    over one chunk and over many."""
+    from fgumi_amd import bgzf
+    rng = methsim.seeded(77)
+    contigs = methsim.genome(rng, n_contigs=3, length=4000)
+    names = [f"chr{i + 1}" for i in range(len(contigs))]
+    g = GroupedReads.from_groups(methsim.simplex_groups(rng, contigs, 600))
+    o = fgx_opts.defaults(min_reads=1, methylation_mode=int(MethylationMode.EmSeq))
+    want = oracle(o, contigs, g, 50)
+    assert b"MM" in want["data"] and b"cu" in want["data"]
+    refs = [(n, len(s)) for n, s in zip(names, contigs)]
+    src, dst = str(tmp_path / "grouped.bam"), str(tmp_path / "consensus.bam")
+    bgzf.write_bam(src, bgzf.grouped_input_header(refs), refs, g.blob)
+    c = VanillaUmiConsensusCaller("", "A", VanillaUmiConsensusOptions(min_reads=1, min_consensus_base_quality=2, cell_tag="CB", methylation_mode=MethylationMode.EmSeq),
+                                  overlapping_consensus=True)
+    c.set_reference({n: bytes(s) for n, s in zip(names, contigs)}, names)
+    for chunk in (0, 1 << 16):
+        st = c.run_bam(src, dst, chunk_raw_bytes=chunk, threads=8)
+        text, orefs, stream, off, ln = bgzf.read_bam(dst)
+        got = b"".join(bytes(stream[int(o_) - 4:int(o_) + int(l)]) for o_, l in zip(off, ln))
+        assert got == want["data"] and st["consensus_records"] == want["count"]
+        assert st["stats"][:len(want["stats"])] == [int(v) for v in want["stats"]]
+    c.close()
