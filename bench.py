@@ -116,6 +116,47 @@ def cpu_baseline(n_families, family_size, read_length, threads, duplex=False, co
                        f"compute-only (records in RAM -> per-batch ConsensusOutput bytes), batches of {bg} MI groups pulled by the worker threads")
 
 
+def end_to_end(caller, families, depth, read_length, directory):
+    """BAM file in -> consensus BAM file out through the streaming pipeline (fgx_run_bam: BGZF inflate + boundaries + MI grouping + consensus + block
+    CRCs on the device, level-1 deflate on the host cores, five overlapping stages) on a bounded file of the same workload: what a user of the
+    command sees, next to the device-resident `value`.  Best of two runs, input file in the page cache."""
+    from fgumi_amd import bgzf, simulate_grouped_reads
+    os.makedirs(directory, exist_ok=True)
+    refs = [(f"chr{i + 1}", 2147483647) for i in range(24)]
+    gin, gout = os.path.join(directory, "grouped.bam"), os.path.join(directory, "consensus.bam")
+    n_rec, slab = 0, 125000
+    with open(gin, "wb") as f:
+        for b in bgzf.bgzf_compress(bgzf.bam_header_bytes(bgzf.grouped_input_header(refs), refs), 1, None):
+            f.write(b)
+        for lo in range(0, families, slab):
+            g = simulate_grouped_reads(min(slab, families - lo), family_size=depth, read_length=read_length, first_family=lo)
+            n_rec += int(g.n_rec)
+            nat = bgzf.native_deflate(g.blob, 1, 32, with_eof=False)
+            f.write(memoryview(nat[0]))
+            del g, nat
+        f.write(bgzf.BGZF_EOF)
+    best = None
+    for _ in range(2):
+        t = time.perf_counter()
+        st = caller.run_bam(gin, gout, header_text=bgzf.consensus_header("A", "Read group", 0, "fgumi simplex"), chunk_raw_bytes=512 << 20)
+        wall = time.perf_counter() - t
+        if best is None or wall < best[0]:
+            best = (wall, st)
+    wall, st = best
+    for pth in (gin, gout):
+        try:
+            os.remove(pth)
+        except OSError:
+            pass
+    stages = {k: st["seconds_" + k] for k in ("read", "inflate", "device", "deflate", "write")}
+    return dict(metric="BAM file in -> consensus BAM file out (fgx_run_bam), raw reads/s", value=n_rec / wall, unit="raw reads/s", families=families, raw_reads=n_rec,
+                total_s=wall, chunks=int(st["chunks"]), stage_busy_s=stages, bottleneck=max(stages, key=stages.get),
+                device_stage_s={k: st["seconds_" + k] for k in ("h2d", "device_inflate", "boundaries", "grouping", "consensus", "d2h")},
+                input_bam_bytes=int(st["in_bytes"]), input_uncompressed_bytes=int(st["inflated_bytes"]), output_bam_bytes=int(st["out_file_bytes"]),
+                consensus_records=int(st["consensus_records"]), deferred_groups=int(st["deferred_groups"]),
+                note="bounded sample of the same workload; stages of successive chunks overlap (total_s is below the sum of the busy times); host side = the cores the cgroup grants")
+
+
 def pmc_profile(families, depth, read_length):
     """Counters of ONE launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS workload (separate --pmc
     runs by tools/profile_round.sh, summarised by tools/pmc_parse.py into profiles/*pmc_<N>M_families.json).  Returns
@@ -157,6 +198,7 @@ def main():
                     help="simplex only: long-tail family sizes in [depth, depth-max] pairs, count ~ size^-1.5 (BASELINE configs[3] shape: --depth 2 --depth-max 50)")
     ap.add_argument("--cpu-sample-families", type=int, default=320000, help="families of the multi-thread CPU leg (320000 x 16 = 5.12 M reads at depth 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--end-to-end-families", type=int, default=250000, help="N=1, simplex: families of the file -> file leg (`end_to_end` in the line); 0 skips it")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-strong-block", action="store_true", help="weak runs also time the strong-scaling reading (`strong_scaling` in the line); this skips it")
     ap.add_argument("--reassemble", choices=["auto", "none", "root"], default="auto",
@@ -354,6 +396,11 @@ def main():
                                                          "value_within_2pct_of_the_weak_line": abs((s_raw * s_steps / S["dt"]) / (total_raw * steps / dt) - 1.0) < 0.02},
                 "value_with_reassembly_on_root": (s_raw * s_steps / S["dt_gather"]) if S["dt_gather"] else None,
             }
+        if world == 1 and plain and args.end_to_end_families > 0 and not args.no_cpu_baseline:     # (the two extra legs go together: profiling runs switch both off)
+            try:
+                line["end_to_end"] = end_to_end(caller, min(args.end_to_end_families, fam), args.depth, L, os.environ.get("FGX_BENCH_TMP", "/tmp/fgx_bench_e2e"))
+            except Exception as ex:                      # (a full /tmp or a read-only file system must not cost the line)
+                line["end_to_end"] = {"error": str(ex)[:300]}
         if not args.no_cpu_baseline and world == 1 and not args.depth_max:
             # threads = the CPUs the container may really use (cgroup quota): oversubscribing a throttled cgroup only adds queueing
             line["cpu_baseline"] = cpu_baseline(min(fam, args.cpu_sample_families), args.depth, L, min(os.cpu_count() or 1, cgroup_cpu_quota() or 1 << 30), duplex, codec)

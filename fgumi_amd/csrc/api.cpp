@@ -1170,6 +1170,30 @@ int fgx_filter_records(fgx_caller* c, const fgx_filter_options* f, const uint8_t
 // diagnostics of the last fgx_process_batch call that deferred groups: out2 = {groups the first device pass deferred, of those the
 // molecules the canonical second pass decided (FGX_DUPLEX_CANON=1)}
 void fgx_debug_last_deferral(const fgx_caller* c, uint64_t* out2) { if (c && out2) { out2[0] = c->last_deferred_groups; out2[1] = c->last_canon_molecules; } }
+// Multi-GPU, for a host that is not Python: contiguous shards of a weighted family stream with roughly equal total weight
+// (weight = record bytes of the family; long-tail family sizes make equal-count shards unbalanced).  Shard k = families
+// [cuts[k], cuts[k + 1]); it ends after the first family at which the running weight reaches k / world of the total — the same cuts as
+// fgumi_amd/distributed.py balanced_shards (bench.py --scaling strong).  `cuts` holds world + 1 entries.  Returns 0, or 1 on bad arguments.
+int fgx_balanced_shards(const uint64_t* weights, uint32_t n, uint32_t world, uint32_t* cuts) {
+  if (!cuts || world == 0 || (n && !weights)) return 1;
+  cuts[0] = 0;
+  if (n == 0) { for (uint32_t k = 1; k <= world; k++) cuts[k] = 0; return 0; }
+  // (float64 running sums, as numpy's cumsum over float64 weights: the cut positions are compared, not the sums)
+  std::vector<double> acc(n);
+  double run = 0.0;
+  for (uint32_t i = 0; i < n; i++) { run += (double)weights[i]; acc[i] = run; }
+  const double total = acc[n - 1];
+  for (uint32_t k = 1; k < world; k++) {
+    const double want = total * (double)k / (double)world;
+    const uint32_t idx = (uint32_t)(std::lower_bound(acc.begin(), acc.end(), want) - acc.begin());   // first family whose running weight reaches `want`
+    uint32_t c = idx + 1 > n ? n : idx + 1;
+    if (c < cuts[k - 1]) c = cuts[k - 1];
+    cuts[k] = c;
+  }
+  cuts[world] = n;
+  for (uint32_t k = 1; k <= world; k++) if (cuts[k] < cuts[k - 1]) cuts[k] = cuts[k - 1];
+  return 0;
+}
 // chunks of the record / column split pipeline in the last device batch (FGX_SPLIT_CHUNKS, or 8 / 4 / 1 by batch size); 0 = it did not run
 uint32_t fgx_debug_last_split_chunks(const fgx_caller* c) { return (c && c->fast) ? c->fast->fp.last_split_chunks : 0u; }
 // how the last device batch produced its records: 0 column scratch + k_emit, 1 written directly by the split pipeline, 2 directly + merge with the

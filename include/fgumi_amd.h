@@ -232,6 +232,13 @@ int fgx_canon_codec_host(const fgx_options* o, const uint8_t* blob, const uint64
 int fgx_simplex_rejects_host(const fgx_options* o, const uint8_t* blob, const uint64_t* rec_off, const uint32_t* rec_len, const uint32_t* grp_first, uint32_t n_grp,
                              uint8_t* out, uint64_t cap, uint64_t* out_len, uint64_t* n_rejects);
 
+/* Multi-GPU from a host that is not Python (one process / one fgx_caller per GPU): contiguous shards of a weighted family
+ * stream — weights[i] = record bytes of family i (fgx_sim_family_bytes for simulated input; Σ rec_len per group otherwise) — with roughly
+ * equal total weight: shard k = families [cuts[k], cuts[k + 1]), cuts has world + 1 entries.  The same cuts as the Python mirror
+ * (fgumi_amd/distributed.py balanced_shards) that bench.py --scaling strong uses.  Families are independent: no collective on the data path;
+ * output is SO:unsorted in input order, so the shard payloads concatenated in rank order ARE the whole output. */
+int fgx_balanced_shards(const uint64_t* weights, uint32_t n, uint32_t world, uint32_t* cuts);
+
 /* Device self-test of the glibc-compatible libm: op 0 exp, 1 log, 2 log1p, 3 expm1. */
 int fgx_device_libm(fgx_caller* c, int op, const double* x, double* y, uint64_t n);
 

@@ -119,3 +119,23 @@ def test_strong_scaling_weighted_shards_reassemble_to_the_whole_stream(tmp_path)
     # equal work, not equal family counts: the byte split is within one (largest) family of even
     assert abs(int(sizes[0, 4]) - int(sizes[1, 4])) <= 2 * 40 * 340
     assert sizes[0, 3] != sizes[1, 3]
+
+
+def test_c_abi_balanced_shards_equal_the_python_mirror():
+    """fgx_balanced_shards (the helper a non-Python host binds) cuts a weighted family stream exactly where
+    fgumi_amd.distributed.balanced_shards does — constant weights, long-tail weights, fewer families than ranks, empty streams."""
+    import ctypes as C
+    import numpy as np
+    from fgumi_amd import lib, simulated_family_bytes
+    from fgumi_amd.distributed import balanced_shards
+    lib.fgx_balanced_shards.restype = C.c_int
+    lib.fgx_balanced_shards.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    rng = np.random.default_rng(3)
+    cases = [np.full(1000, 5280, dtype=np.uint64), simulated_family_bytes(5000, family_size=2, family_size_max=50), rng.integers(1, 10**6, size=37).astype(np.uint64),
+             np.array([7], dtype=np.uint64), np.zeros(0, dtype=np.uint64), np.array([1, 1, 1000000, 1, 1], dtype=np.uint64)]
+    for w in cases:
+        for world in (1, 2, 3, 4, 8):
+            cuts = np.zeros(world + 1, dtype=np.uint32)
+            assert lib.fgx_balanced_shards(w.ctypes.data if w.size else None, w.size, world, cuts.ctypes.data) == 0
+            want = balanced_shards(w, world)
+            assert [(int(cuts[k]), int(cuts[k + 1])) for k in range(world)] == [(int(a), int(b)) for a, b in want], (w.size, world)
