@@ -47,7 +47,7 @@ class FilterOptions(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("min_reads", C.c_uint32 * 3), ("max_read_error_rate", C.c_double * 3), ("max_base_error_rate", C.c_double * 3),
                 ("min_mean_base_quality", C.c_double), ("max_no_call_fraction", C.c_double), ("has_min_base_quality", C.c_uint8), ("min_base_quality", C.c_uint8),
                 ("has_min_mean_base_quality", C.c_uint8), ("require_single_strand_agreement", C.c_uint8), ("reverse_per_base_tags", C.c_uint8),
-                ("filter_by_template", C.c_uint8), ("track_rejects", C.c_uint8), ("_pad", C.c_uint8)]
+                ("filter_by_template", C.c_uint8), ("track_rejects", C.c_uint8), ("regenerate_alignment_tags", C.c_uint8)]
 
 
 class FilterOutput(C.Structure):
@@ -83,7 +83,7 @@ EXPORTS = ["fgx_options_default", "fgx_create", "fgx_destroy", "fgx_last_error",
            "fgx_sim_generate_host", "fgx_sim_generate_device", "fgx_group_records", "fgx_group_records_device", "fgx_filter_options_default",
            "fgx_filter_records", "fgx_filter_records_device", "fgx_filter_last_output_device",
            "fgx_record_boundaries_device", "fgx_inflate_block_host", "fgx_inflate_block_host_staged", "fgx_deflate_block_host", "fgx_run_bam", "fgx_run_bam_rejects", "fgx_bgzf_inflate_device_bench", "fgx_bgzf_recompress_file", "fgx_pipeline_last_error",
-           "fgx_set_reference", "fgx_methylation_annotate_host", "fgx_methylation_runs_host", "fgx_methylation_mm_ml_host", "fgx_canon_duplex_host", "fgx_canon_codec_host", "fgx_simplex_rejects_host", "fgx_balanced_shards"]
+           "fgx_set_reference", "fgx_methylation_annotate_host", "fgx_methylation_runs_host", "fgx_methylation_mm_ml_host", "fgx_canon_duplex_host", "fgx_canon_codec_host", "fgx_simplex_rejects_host", "fgx_balanced_shards", "fgx_regenerate_alignment_tags_host"]
 
 _lib = None
 

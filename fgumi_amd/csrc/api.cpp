@@ -14,6 +14,7 @@
 #include "simgen.h"
 #include "canon_core.h"
 #include "reject_core.h"
+#include "aln_tags_core.h"
 
 namespace fgx {
 // canon_device.hip
@@ -283,6 +284,25 @@ int fgx_set_reference(fgx_caller* c, uint32_t n_ref, const uint8_t* const* seqs,
     for (fgx_caller* w : c->workers) w->genome = g;
     return 0;
   } catch (const std::exception& ex) { c->err = ex.what(); return 3; }
+}
+
+// aln_tags_core.h on the host: NM / UQ / MD of ONE record regenerated against the given contigs (contig i of the BAM header = seqs[i]; NULL = the
+// FASTA lacks it) — what the lanes of filter.hip's k_aln_plan / k_aln_write run.  The edited record goes to out (cap bytes), *out_len = its
+// length.  Returns the aln::Status (0 regenerated, 1 tags removed, >= 2 the reference's fatal errors), or -1 when `cap` is too small.
+int fgx_regenerate_alignment_tags_host(const uint8_t* rec, uint32_t len, uint32_t n_ref, const uint8_t* const* seqs, const uint64_t* lens, uint8_t* out, uint32_t cap,
+                                       uint32_t* out_len) {
+  if (!rec || !out_len) return -1;
+  std::vector<uint8_t> genome;
+  std::vector<uint64_t> off(n_ref + 1, 0), ln(n_ref + 1, 0);
+  for (uint32_t i = 0; i < n_ref; i++) { off[i] = genome.size(); ln[i] = (seqs && seqs[i]) ? lens[i] : 0; if (ln[i]) genome.insert(genome.end(), seqs[i], seqs[i] + ln[i]); }
+  genome.push_back(0);
+  aln::Plan P; aln::Geometry G{};
+  aln::plan(rec, len, genome.data(), off.data(), ln.data(), n_ref, P, G);
+  *out_len = P.new_len;
+  if (P.status > aln::ALN_REMOVED) return P.status;
+  if (P.new_len > cap || !out) return -1;
+  aln::write(rec, len, genome.data(), off.data(), P, G, out);
+  return P.status;
 }
 
 // ---- methylation-aware mode: the device code's per-position body and the host-side pieces, callable without a device ----------

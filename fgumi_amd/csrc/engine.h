@@ -120,11 +120,12 @@ struct ColumnBatch {
 // filter.hip — device buffers of the consensus-read filter (grow-only, owned by the caller object)
 struct FilterBuffers {
   DevBuf pass, masked, newt, incl, first, ord_src, keep_size, rej_size, keep_off, rej_off, misc, scan_tmp, out_keep, out_rej, in_blob, in_off, in_len, slot_flag, slot_pos;
+  DevBuf aln_len, aln_contigs;      // --ref: lengths of the records with regenerated NM / UQ / MD; contig offsets | lengths of the caller's genome
   PinnedBuf pin_keep, pin_rej;
   uint32_t lds_slice = 0;           // LDS bytes per wavefront for the staged record; 0 = sized from the mean record length
   void release() {
     for (DevBuf* b : {&pass, &masked, &newt, &incl, &first, &ord_src, &keep_size, &rej_size, &keep_off, &rej_off, &misc, &scan_tmp, &out_keep, &out_rej,
-                      &in_blob, &in_off, &in_len, &slot_flag, &slot_pos})
+                      &in_blob, &in_off, &in_len, &slot_flag, &slot_pos, &aln_len, &aln_contigs})
       b->free_();
     pin_keep.free_(); pin_rej.free_();
   }

@@ -21,6 +21,7 @@
 #include <hipcub/hipcub.hpp>
 #include "bamrec.h"
 #include "engine.h"
+#include "aln_tags_core.h"
 
 namespace fgx {
 
@@ -33,7 +34,7 @@ __device__ const uint16_t FILTER_TAGS[N_TAGS] = {TG('c', 'D'), TG('c', 'E'), TG(
                                                  TG('a', 'E'), TG('b', 'E'), TG('a', 'd'), TG('a', 'e'), TG('b', 'd'), TG('b', 'e'), TG('a', 'c'), TG('b', 'c'),
                                                  TG('a', 'q'), TG('b', 'q'), TG('c', 'u'), TG('c', 't'), TG('a', 'u'), TG('a', 't'), TG('b', 'u'), TG('b', 't')};
 
-enum : uint32_t { ERR_SHORT = 1, ERR_MAPPED = 2, ERR_NO_TAGS = 3, ERR_MULTI_R1 = 4, ERR_MULTI_R2 = 5 };
+enum : uint32_t { ERR_SHORT = 1, ERR_MAPPED = 2, ERR_NO_TAGS = 3, ERR_MULTI_R1 = 4, ERR_MULTI_R2 = 5, ERR_ALN = 16 /* + aln::Status (2 .. 7) */ };
 // per-position value sources: K_NONE reads 0 everywhere
 enum : uint32_t { K_NONE = 0, K_U8 = 1, K_U16 = 2, K_I16 = 3, K_I8 = 4, K_ZERO = 5, K_BYTES = 6 };
 
@@ -108,7 +109,7 @@ __device__ __forceinline__ void filter_body(const FilterParams& P, const uint32_
   const uint32_t l_name = R[8], n_cig = bam::rd16(R + 12), flags = bam::rd16(R + 14), l_seq = bam::rd32(R + 16);
   const uint64_t seq_off64 = 32ull + l_name + 4ull * n_cig, aux_off64 = seq_off64 + ((uint64_t)l_seq + 1) / 2 + l_seq;
   if (aux_off64 > len) { if (lane == 0) { report(P.error, r, ERR_SHORT); P.pass[r] = 0; P.masked[r] = 0; } return; }
-  if (!(flags & bam::F_UNMAPPED)) { if (lane == 0) { report(P.error, r, ERR_MAPPED); P.pass[r] = 0; P.masked[r] = 0; } return; }
+  if (!(flags & bam::F_UNMAPPED) && !P.o.regenerate_alignment_tags) { if (lane == 0) { report(P.error, r, ERR_MAPPED); P.pass[r] = 0; P.masked[r] = 0; } return; }   // (filter.rs:782-792: only without --ref)
   const uint32_t seq_off = (uint32_t)seq_off64, qual_off = seq_off + (l_seq + 1) / 2, aux_off = (uint32_t)aux_off64, an = len - aux_off;
   const uint8_t* A = R + aux_off;
 
@@ -531,6 +532,46 @@ __global__ __launch_bounds__(256) void k_copy_records(const CopyParams P) {
   }
 }
 
+// ---- --ref: NM / UQ / MD regenerated after the masking (filter.rs:888-890; aln_tags_core.h) ---------------------------------------------------
+// A lane per record runs the scalar source the CPU tests prove against the oracle: k_aln_plan measures the edited record (the sizes the
+// template kernel and the scans work with), k_aln_write produces it at its scanned place — every record, kept or rejected, as the reference
+// edits a record before it decides about it.  The stores scatter and the walks diverge: this is the simple form (a consensus BAM has an
+// eighth of the raw reads), not the fast one.
+struct AlnParams {
+  const uint8_t* blob; uint64_t blob_len; const uint64_t* rec_off; const uint32_t* rec_len; uint32_t n_rec;
+  const uint8_t* genome; const uint64_t* contig_off; const uint64_t* contig_len; uint32_t n_ref;
+  uint32_t* new_len; unsigned long long* error;
+  // k_aln_write
+  const uint32_t* ord_src; const uint64_t* keep_size; const uint64_t* rej_size; const uint64_t* keep_off; const uint64_t* rej_off; uint8_t* out_keep; uint8_t* out_rej;
+};
+__global__ void k_aln_plan(const AlnParams P) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= P.n_rec) return;
+  const uint32_t len = P.rec_len[r];
+  const uint64_t off = P.rec_off[r];
+  if (len < 32 || off + len > P.blob_len) { P.new_len[r] = len; return; }     // (k_filter_records has reported it)
+  aln::Plan pl; aln::Geometry G{};
+  aln::plan(P.blob + off, len, P.genome, P.contig_off, P.contig_len, P.n_ref, pl, G);
+  if (pl.status > aln::ALN_REMOVED) { report(P.error, r, ERR_ALN + (uint32_t)pl.status); P.new_len[r] = len; return; }
+  P.new_len[r] = pl.new_len;
+}
+__global__ void k_aln_write(const AlnParams P) {
+  const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= P.n_rec) return;
+  uint8_t* D;
+  if (P.keep_size[o]) D = P.out_keep + P.keep_off[o];
+  else if (P.rej_size[o]) D = P.out_rej + P.rej_off[o];
+  else return;
+  const uint32_t src = P.ord_src[o];
+  const uint32_t len = P.rec_len[src];
+  const uint8_t* rec = P.blob + P.rec_off[src];
+  aln::Plan pl; aln::Geometry G{};
+  aln::plan(rec, len, P.genome, P.contig_off, P.contig_len, P.n_ref, pl, G);
+  const uint32_t nl = pl.new_len;
+  D[0] = (uint8_t)nl; D[1] = (uint8_t)(nl >> 8); D[2] = (uint8_t)(nl >> 16); D[3] = (uint8_t)(nl >> 24);
+  aln::write(rec, len, P.genome, P.contig_off, pl, G, D + 4);
+}
+
 }  // namespace
 
 // Device buffers in (masked in place), device buffers out; fills the counters and the device pointers of `out`.
@@ -584,8 +625,25 @@ int filter_records_device(fgx_caller* c, FilterBuffers& B, const fgx_filter_opti
     hip_check(hipStreamSynchronize(s), "sync");
     d_first = B.first.as<uint32_t>();
   }
+  // --ref: the edited records' lengths (every record: the reference edits before it decides)
+  const bool regen = o->regenerate_alignment_tags != 0;
+  AlnParams A{};
+  if (regen) {
+    B.aln_len.reserve((size_t)n * 4 + 64);
+    const GenomeRef* gr = c->genome.get();
+    const uint32_t n_ref = gr ? (uint32_t)gr->off.size() : 0u;
+    B.aln_contigs.reserve((size_t)(n_ref + 1) * 16 + 64);
+    if (n_ref) {
+      hip_check(hipMemcpyAsync(B.aln_contigs.p, gr->off.data(), (size_t)n_ref * 8, hipMemcpyHostToDevice, s), "H2D contig offsets");
+      hip_check(hipMemcpyAsync(B.aln_contigs.as<uint64_t>() + n_ref, gr->len.data(), (size_t)n_ref * 8, hipMemcpyHostToDevice, s), "H2D contig lengths");
+    }
+    A.blob = d_blob; A.blob_len = blob_len; A.rec_off = d_rec_off; A.rec_len = d_rec_len; A.n_rec = n;
+    A.genome = gr ? (const uint8_t*)gr->d_genome.p : nullptr; A.contig_off = B.aln_contigs.as<uint64_t>(); A.contig_len = B.aln_contigs.as<uint64_t>() + n_ref; A.n_ref = n_ref;
+    A.new_len = B.aln_len.as<uint32_t>(); A.error = d_err;
+    hipLaunchKernelGGL(k_aln_plan, grid_t, block, 0, s, A);
+  }
   DecideParams Q{};
-  Q.blob = d_blob; Q.rec_off = d_rec_off; Q.rec_len = d_rec_len; Q.n_rec = n; Q.tmpl_first = d_first; Q.n_tmpl = n_tmpl;
+  Q.blob = d_blob; Q.rec_off = d_rec_off; Q.rec_len = regen ? (const uint32_t*)A.new_len : d_rec_len; Q.n_rec = n; Q.tmpl_first = d_first; Q.n_tmpl = n_tmpl;
   Q.pass = P.pass; Q.masked = P.masked; Q.track_rejects = o->track_rejects;
   Q.ord_src = B.ord_src.as<uint32_t>(); Q.keep_size = B.keep_size.as<uint64_t>(); Q.rej_size = B.rej_size.as<uint64_t>();
   Q.counters = d_cnt; Q.error = d_err;
@@ -615,7 +673,14 @@ int filter_records_device(fgx_caller* c, FilterBuffers& B, const fgx_filter_opti
                       : code == ERR_NO_TAGS
                           ? "read does not appear to have consensus calling tags (cD/cE) present; FilterConsensusReads requires reads produced by consensus calling"
                       : code == ERR_MULTI_R1 ? "Multiple non-secondary, non-supplemental R1 records for a read name"
-                                             : "Multiple non-secondary, non-supplemental R2 records for a read name";
+                      : code == ERR_MULTI_R2 ? "Multiple non-secondary, non-supplemental R2 records for a read name"
+                      // --ref (regenerate_alignment_tags_raw, crates/fgumi-sam/src/alignment_tags.rs:259-433)
+                      : code == ERR_ALN + aln::ALN_TOO_SHORT ? "BAM record too short"
+                      : code == ERR_ALN + aln::ALN_REF_ID ? "Reference sequence ID not found in header"
+                      : code == ERR_ALN + aln::ALN_BAD_START ? "Invalid alignment start position"
+                      : code == ERR_ALN + aln::ALN_REGION ? "the alignment leaves its reference sequence (region out of bounds, or the FASTA lacks the contig)"
+                      : code == ERR_ALN + aln::ALN_TRUNCATED ? "Truncated BAM record: seq/qual extends past record end"
+                                                             : "CIGAR consumes more bases than sequence length";
     c->err = std::string(msg) + " (record " + std::to_string(rec) + ")";
     return 2;
   }
@@ -625,7 +690,10 @@ int filter_records_device(fgx_caller* c, FilterBuffers& B, const fgx_filter_opti
   CopyParams C{};
   C.blob = d_blob; C.blob_len = blob_len; C.rec_off = d_rec_off; C.rec_len = d_rec_len; C.n_rec = n; C.ord_src = Q.ord_src; C.keep_size = Q.keep_size; C.rej_size = Q.rej_size;
   C.keep_off = B.keep_off.as<uint64_t>(); C.rej_off = B.rej_off.as<uint64_t>(); C.out_keep = B.out_keep.as<uint8_t>(); C.out_rej = B.out_rej.as<uint8_t>();
-  hipLaunchKernelGGL(k_copy_records, grid_w, block, 0, s, C);
+  if (regen) {
+    A.ord_src = Q.ord_src; A.keep_size = Q.keep_size; A.rej_size = Q.rej_size; A.keep_off = C.keep_off; A.rej_off = C.rej_off; A.out_keep = C.out_keep; A.out_rej = C.out_rej;
+    hipLaunchKernelGGL(k_aln_write, grid_t, block, 0, s, A);
+  } else hipLaunchKernelGGL(k_copy_records, grid_w, block, 0, s, C);
   hip_check(hipStreamSynchronize(s), "sync");
   hip_check(hipGetLastError(), "k_copy_records");
   out->data = B.out_keep.as<uint8_t>(); out->data_len = keep_total;

@@ -1,4 +1,5 @@
-"""Python host mirror of `fgumi filter` for unmapped consensus records, over the C ABI (fgx_filter_*).
+"""Python host mirror of `fgumi filter` over the C ABI (fgx_filter_*): unmapped consensus records, and — with a reference (`--ref`,
+`ConsensusFilter.set_reference`) — mapped ones, whose NM / UQ / MD tags are regenerated after the masking.
 
 Mirrors (names, argument meaning, error behaviour):
   * `FilterThresholds`, `FilterConfig::{new, for_single_strand, for_duplex, for_duplex_asymmetric}`
@@ -131,7 +132,10 @@ def record_offsets(data: bytes):
 
 
 class ConsensusFilter:
-    """`fgumi filter` without --ref: consensus records in, kept (and optionally rejected) records out, masked like the reference."""
+    """`fgumi filter`: consensus records in, kept (and optionally rejected) records out, masked like the reference.  Without a reference a mapped
+    record is the reference's fatal error ("--ref is required ..."); after `set_reference` (the command's `--ref`, filter.rs:115-118) mapped
+    records are accepted and NM / UQ / MD are regenerated after the masking (unmapped records lose the three tags), as
+    `regenerate_alignment_tags_raw` does (crates/fgumi-sam/src/alignment_tags.rs:259-433)."""
 
     def __init__(self, config: FilterConfig, filter_by_template: bool = True, require_single_strand_agreement: bool = False,
                  reverse_per_base_tags: bool = False, track_rejects: bool = False, device: int = -1, handle=None):
@@ -168,6 +172,22 @@ class ConsensusFilter:
     def _check(self, rc):
         if rc != 0:
             raise RuntimeError(lib.fgx_last_error(self._h).decode())
+
+    def set_reference(self, reference, ref_names: Sequence[str]):
+        """`--ref <fasta>`: `reference` maps a contig name to its bases, `ref_names[i]` = the name of contig i of the BAM header (a record's
+        reference id).  Like the command's loader this fails when a header contig is missing from the FASTA (`ReferenceReader` would hand back an
+        error at the first record that needs it; filter.rs opens the FASTA up front).  `set_reference(None, [])` drops the reference again."""
+        names = list(ref_names or [])
+        if reference is None or not names:
+            self._check(lib.fgx_set_reference(self._h, 0, None, None))
+            self._o.regenerate_alignment_tags = 0
+            return
+        seqs = [bytes(reference.get(n, b"")) for n in names]
+        bufs = [C.create_string_buffer(s, max(1, len(s))) for s in seqs]
+        ptrs = (C.c_void_p * len(seqs))(*[C.cast(b, C.c_void_p).value for b in bufs])
+        lens = (C.c_uint64 * len(seqs))(*[len(s) for s in seqs])
+        self._check(lib.fgx_set_reference(self._h, len(seqs), ptrs, lens))
+        self._o.regenerate_alignment_tags = 1
 
     def filter_stream(self, blob: np.ndarray, rec_off: np.ndarray, rec_len: np.ndarray) -> FilterResult:
         blob = np.ascontiguousarray(blob, dtype=np.uint8)

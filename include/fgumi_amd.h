@@ -246,6 +246,13 @@ int fgx_device_libm(fgx_caller* c, int op, const double* x, double* y, uint64_t 
  * which: 0 correct[q], 1 error_per_alt[q], 2 gap thresholds, 3 cerr_min; *cap = pre-UMI cap. */
 int fgx_get_table(const fgx_caller* c, int which, double* out94, uint32_t* cap);
 
+/* fgumi_amd/csrc/aln_tags_core.h on the host (the scalar source a GPU lane per record runs for `fgumi filter --ref`): NM / UQ / MD of one record
+ * regenerated against the given contigs as regenerate_alignment_tags_raw does (crates/fgumi-sam/src/alignment_tags.rs:259-433): 0 = regenerated,
+ * 1 = tags removed (unmapped / no reference id), >= 2 = the reference's fatal errors (too short, reference id not in the header, invalid start,
+ * alignment leaves the contig, truncated record, CIGAR longer than the sequence), -1 = `cap` too small (*out_len = bytes needed). */
+int fgx_regenerate_alignment_tags_host(const uint8_t* rec, uint32_t len, uint32_t n_ref, const uint8_t* const* seqs, const uint64_t* lens, uint8_t* out, uint32_t cap,
+                                       uint32_t* out_len);
+
 /* ---- synthetic grouped reads (`fgumi simulate grouped-reads` model) ------------------------
  * Restates the record SHAPE of src/lib/commands/simulate/grouped_reads.rs:666-1011 and the
  * quality model of src/lib/simulate/quality.rs:60-135 with a counter-based integer RNG so the
@@ -312,7 +319,10 @@ typedef struct fgx_filter_options {
   uint8_t  reverse_per_base_tags;                     /* -R */
   uint8_t  filter_by_template;                        /* --filter-by-template (default true) */
   uint8_t  track_rejects;                             /* --rejects given */
-  uint8_t  _pad;
+  uint8_t  regenerate_alignment_tags;                 /* --ref given (filter.rs:115-118, 888-890): mapped records are accepted and their NM / UQ / MD tags are
+                                                         recomputed after the masking against the reference handed over with fgx_set_reference (contig i of the
+                                                         BAM header = seqs[i]); on unmapped records the three tags are removed (regenerate_alignment_tags_raw,
+                                                         crates/fgumi-sam/src/alignment_tags.rs:259-433).  0: a mapped record is the reference's fatal error */
 } fgx_filter_options;
 void fgx_filter_options_default(fgx_filter_options* o);   /* min_reads {1,1,1}; everything else the CLI defaults */
 

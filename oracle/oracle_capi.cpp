@@ -288,7 +288,10 @@ struct OrcFilterResult { orc_filter::BatchResult r; Bytes blob; };
 void* orc_filter_records(const fgx_filter_options* o, const uint8_t* blob, uint64_t blob_len, const uint64_t* rec_off, const uint32_t* rec_len, uint32_t n_rec) {
   OrcFilterResult* res = new OrcFilterResult();
   res->blob.assign(blob, blob + blob_len);
-  try { orc_filter::filter_stream(o, res->blob.data(), rec_off, rec_len, n_rec, res->r); }
+  // --ref (fgx_filter_options.regenerate_alignment_tags): the reference set with orc_set_reference; a missing one = no contigs at all
+  static const Reference no_contigs;
+  const Reference* ref = o->regenerate_alignment_tags ? (g_reference ? g_reference.get() : &no_contigs) : nullptr;
+  try { orc_filter::filter_stream(o, res->blob.data(), rec_off, rec_len, n_rec, res->r, ref); }
   catch (const OracleError& e) { g_err = e.what; delete res; return nullptr; }
   return res;
 }
@@ -317,6 +320,18 @@ int orc_filter_duplex_read(const uint8_t* rec, uint32_t len, const double* cc, c
   catch (const OracleError& e) { g_err = e.what; return -1; }
 }
 void orc_filter_reverse_tags(uint8_t* rec, uint32_t len) { orc_filter::reverse_per_base_tags(rec, len); }   // tag_reversal.rs:27-67 alone
+// regenerate_alignment_tags_raw alone (alignment_tags.rs:259-433) against the reference of orc_set_reference: the new record into out
+// (cap bytes), *out_len its length.  Returns 1 regenerated, 0 tags removed, -1 error (orc_last_error), -2 cap too small.
+int orc_regenerate_alignment_tags(const uint8_t* rec, uint32_t len, uint8_t* out, uint32_t cap, uint32_t* out_len) {
+  static const Reference no_contigs;
+  Bytes v(rec, rec + len);
+  bool r;
+  try { r = orc_filter::regenerate_alignment_tags_raw(v, g_reference ? *g_reference : no_contigs); } catch (const OracleError& e) { g_err = e.what; return -1; }
+  *out_len = (uint32_t)v.size();
+  if (v.size() > cap) return -2;
+  memcpy(out, v.data(), v.size());
+  return r ? 1 : 0;
+}
 int orc_filter_is_duplex(const uint8_t* rec, uint32_t len) { return orc_filter::is_duplex_consensus(RecView(rec, len).aux()); }
 int orc_filter_process_record(const fgx_filter_options* o, uint8_t* rec, uint32_t len, uint64_t* masked, int* pass) {
   bool p = false;

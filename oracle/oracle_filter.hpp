@@ -28,6 +28,7 @@
 
 #include "../include/fgumi_amd.h"
 #include "oracle_bam.hpp"
+#include "oracle_methylation.hpp"   // struct Reference: the genome by header index
 #include "oracle_phred.hpp"
 
 namespace orc_filter {
@@ -269,11 +270,125 @@ inline bool check_no_call_and_quality(const uint8_t* rec, size_t rec_len, double
   return frac <= max_frac;
 }
 
-// filter.rs (command) :762-940 with reference == None and the methylation filters off
-inline void process_record_raw(uint8_t* rec, size_t rec_len, const fgx_filter_options* o, uint64_t& masked, bool& pass) {
+// ---- raw tag editing (crates/fgumi-raw-bam/src/tags.rs) --------------------------------------------------------------------------
+// find_tag_bounds :104-109 (first entry with the key; None when that entry's size cannot be told); returns false for None
+inline bool find_tag_bounds(const uint8_t* aux, size_t n, const char tag[2], size_t& start, size_t& end) {
+  uint8_t vt = 0;
+  long p = find_tag_position(aux, n, tag, vt);
+  if (p < 0) return false;
+  long size = tag_value_size(vt, aux + p + 3, n - ((size_t)p + 3));
+  if (size < 0) return false;
+  start = (size_t)p; end = (size_t)p + 3 + (size_t)size;
+  return true;
+}
+inline size_t aux_offset_or_len(const Bytes& rec) {   // aux_data_offset_from_record(..).unwrap_or(record.len())
+  if (rec.size() < 32) return rec.size();
+  RecView v(rec.data(), rec.size());
+  size_t off = 32 + (size_t)v.l_read_name() + 4 * (size_t)v.n_cigar_op() + ((size_t)v.l_seq() + 1) / 2 + (size_t)v.l_seq();
+  return off <= rec.size() ? off : rec.size();
+}
+inline void remove_tag(Bytes& rec, const char tag[2]) {   // :808-821
+  size_t a = aux_offset_or_len(rec);
+  if (a >= rec.size()) return;
+  size_t st, en;
+  if (find_tag_bounds(rec.data() + a, rec.size() - a, tag, st, en)) rec.erase(rec.begin() + (long)(a + st), rec.begin() + (long)(a + en));
+}
+inline void update_string_tag(Bytes& rec, const char tag[2], const uint8_t* v, size_t n) {   // :832-859
+  size_t a = aux_offset_or_len(rec), st, en;
+  if (a < rec.size() && find_tag_bounds(rec.data() + a, rec.size() - a, tag, st, en)) {
+    size_t abs_start = a + st, abs_end = a + en;
+    size_t old_value_len = en - st - 4;          // tag(2) + type(1) + NUL(1)
+    if (old_value_len == n) { if (n) memcpy(rec.data() + abs_start + 3, v, n); }
+    else {
+      Bytes repl;
+      repl.push_back((uint8_t)tag[0]); repl.push_back((uint8_t)tag[1]); repl.push_back('Z');
+      repl.insert(repl.end(), v, v + n); repl.push_back(0);
+      rec.erase(rec.begin() + (long)abs_start, rec.begin() + (long)abs_end);
+      rec.insert(rec.begin() + (long)abs_start, repl.begin(), repl.end());
+    }
+    return;
+  }
+  append_string_tag(rec, tag, v, n);
+}
+inline void update_int_tag(Bytes& rec, const char tag[2], int32_t value) {   // :867-888
+  size_t a = aux_offset_or_len(rec), st, en;
+  if (a < rec.size() && find_tag_bounds(rec.data() + a, rec.size() - a, tag, st, en)) {
+    size_t abs_start = a + st, abs_end = a + en;
+    uint8_t vt = rec[abs_start + 2];
+    if ((vt == 'i' || vt == 'I') && abs_end - abs_start == 7) { uint32_t u = (uint32_t)value; for (int i = 0; i < 4; i++) rec[abs_start + 3 + i] = (uint8_t)(u >> (8 * i)); return; }
+    rec.erase(rec.begin() + (long)abs_start, rec.begin() + (long)abs_end);
+    append_int_tag(rec, tag, value);
+    return;
+  }
+  append_int_tag(rec, tag, value);
+}
+
+// regenerate_alignment_tags_raw (crates/fgumi-sam/src/alignment_tags.rs:259-433).  `ref` = the reference by header index (contig i of the BAM
+// header = seqs[i], as fgx_set_reference / orc_set_reference hand it over; a contig the FASTA lacks is empty).  Returns true when the tags
+// were recomputed, false when they were removed.
+inline bool regenerate_alignment_tags_raw(Bytes& rec, const Reference& ref) {
+  if (rec.size() < 36) throw OracleError{"BAM record too short (minimum 36 bytes)"};
+  RecView v0(rec.data(), rec.size());
+  if (v0.flags() & flags::UNMAPPED) { remove_tag(rec, "NM"); remove_tag(rec, "UQ"); remove_tag(rec, "MD"); return false; }
+  int32_t ref_id = v0.ref_id();
+  if (ref_id < 0) { remove_tag(rec, "NM"); remove_tag(rec, "UQ"); remove_tag(rec, "MD"); return false; }
+  if ((size_t)ref_id >= ref.seqs.size()) throw OracleError{"Reference sequence ID not found in header"};
+  int32_t pos0 = v0.pos();
+  if (pos0 < 0) throw OracleError{"Invalid alignment start position"};
+  size_t ref_span = (size_t)reference_length_from_raw_bam(v0);
+  if (ref_span == 0) { update_int_tag(rec, "NM", 0); update_int_tag(rec, "UQ", 0); update_string_tag(rec, "MD", (const uint8_t*)"0", 1); return true; }
+  const Bytes& contig = ref.seqs[(size_t)ref_id];
+  size_t start_idx = (size_t)pos0, end_idx = (size_t)pos0 + ref_span;          // reference.rs:291-310 (1-based inclusive -> [start, end))
+  if (end_idx > contig.size() || start_idx >= end_idx) throw OracleError{"Invalid parameter 'region': reference span outside the contig"};
+  const uint8_t* all = contig.data() + start_idx;
+  size_t seq_off = v0.seq_offset(), qual_off = v0.qual_offset(), l_seq = v0.l_seq();
+  if (seq_off + (l_seq + 1) / 2 > rec.size() || qual_off + l_seq > rec.size()) throw OracleError{"Truncated BAM record: seq/qual extends past record end"};
+  int32_t nm = 0; uint32_t uq = 0;
+  std::string md;
+  size_t ref_offset = 0, seq_pos = 0, match_count = 0;
+  size_t n_ops = v0.n_cigar_op(), cig = 32 + (size_t)v0.l_read_name();
+  for (size_t k = 0; k < n_ops; k++) {
+    uint32_t op = rd32(rec.data() + cig + 4 * k), t = op & 0xF; size_t len = op >> 4;
+    if (t == 0 || t == 7 || t == 8) {
+      if (ref_offset + len > ref_span) throw OracleError{"CIGAR references beyond fetched reference span"};
+      if (seq_pos + len > l_seq) throw OracleError{"CIGAR consumes more bases than sequence length"};
+      for (size_t i = 0; i < len; i++) {
+        uint8_t rb = all[ref_offset + i];
+        uint8_t code = (rec[seq_off + seq_pos / 2] >> ((seq_pos & 1) ? 0 : 4)) & 15, sb = BAM_BASE_TO_ASCII[code], q = rec[qual_off + seq_pos];
+        auto lower = [](uint8_t c) { return (uint8_t)((c >= 'A' && c <= 'Z') ? c + 32 : c); };
+        if (sb == 'N' || lower(sb) != lower(rb)) { nm += 1; uq += q; md += std::to_string(match_count); match_count = 0; md.push_back((char)rb); }
+        else match_count++;
+        seq_pos++;
+      }
+      ref_offset += len;
+    } else if (t == 1) {
+      if (seq_pos + len > l_seq) throw OracleError{"CIGAR insertion consumes more bases than sequence length"};
+      nm += (int32_t)len; seq_pos += len;
+    } else if (t == 2) {
+      if (ref_offset + len > ref_span) throw OracleError{"CIGAR deletion references beyond fetched reference span"};
+      nm += (int32_t)len; md += std::to_string(match_count); match_count = 0; md.push_back('^');
+      for (size_t i = 0; i < len; i++) md.push_back((char)all[ref_offset + i]);
+      ref_offset += len;
+    } else if (t == 4) {
+      if (seq_pos + len > l_seq) throw OracleError{"CIGAR soft clip consumes more bases than sequence length"};
+      seq_pos += len;
+    } else if (t == 3) ref_offset += len;
+  }
+  md += std::to_string(match_count);
+  update_int_tag(rec, "NM", nm);
+  update_int_tag(rec, "UQ", (int32_t)std::min<uint32_t>(uq, (uint32_t)INT32_MAX));
+  update_string_tag(rec, "MD", (const uint8_t*)md.data(), md.size());
+  return true;
+}
+
+// filter.rs (command) :762-940; the methylation filters off.  `ref` (may be null) = --ref: mapped reads are accepted and NM / UQ / MD are
+// regenerated after the masking (the record may change its length: `rec` is a vector of its own).
+inline void process_record_raw(Bytes& recv, const fgx_filter_options* o, const Reference* ref, uint64_t& masked, bool& pass) {
+  uint8_t* rec = recv.data();
+  size_t rec_len = recv.size();
   if (rec_len < 32) throw OracleError{"BAM record too short"};
   RecView v(rec, rec_len);
-  if (!(v.flags() & flags::UNMAPPED)) throw OracleError{"--ref is required when filtering mapped reads to keep NM/UQ/MD tags consistent"};
+  if (!ref && !(v.flags() & flags::UNMAPPED)) throw OracleError{"--ref is required when filtering mapped reads to keep NM/UQ/MD tags consistent"};
   if (o->reverse_per_base_tags) reverse_per_base_tags(rec, rec_len);
   double pre_mask_mean = 0.0;
   if (o->has_min_mean_base_quality) {   // filter.rs:688-705
@@ -287,8 +402,16 @@ inline void process_record_raw(uint8_t* rec, size_t rec_len, const fgx_filter_op
   bool duplex = is_duplex_consensus(v.aux());
   masked = duplex ? mask_duplex_bases(rec, rec_len, cc, ab, ba, o->has_min_base_quality, o->min_base_quality, o->require_single_strand_agreement)
                   : mask_bases(rec, rec_len, cc, o->has_min_base_quality, o->min_base_quality);
-  Result r = duplex ? filter_duplex_read(v.aux(), cc, ab, ba) : filter_read(v.aux(), cc);
-  pass = r == PASS && check_no_call_and_quality(rec, rec_len, pre_mask_mean, o->has_min_mean_base_quality, o->min_mean_base_quality, o->max_no_call_fraction);
+  if (ref) regenerate_alignment_tags_raw(recv, *ref);       // :888-890 (the vector may have been reallocated / resized)
+  RecView v2(recv.data(), recv.size());
+  Result r = duplex ? filter_duplex_read(v2.aux(), cc, ab, ba) : filter_read(v2.aux(), cc);
+  pass = r == PASS && check_no_call_and_quality(recv.data(), recv.size(), pre_mask_mean, o->has_min_mean_base_quality, o->min_mean_base_quality, o->max_no_call_fraction);
+}
+// (the in-place form of the round-3 tests: no reference)
+inline void process_record_raw(uint8_t* rec, size_t rec_len, const fgx_filter_options* o, uint64_t& masked, bool& pass) {
+  Bytes v(rec, rec + rec_len);
+  process_record_raw(v, o, nullptr, masked, pass);
+  memcpy(rec, v.data(), rec_len);
 }
 
 struct BatchResult {
@@ -304,16 +427,17 @@ inline void put_record(Bytes& out, const uint8_t* rec, uint32_t len) {
 inline bool is_primary(const uint8_t* rec) { uint16_t f = rd16(rec + 14); return !(f & flags::SECONDARY) && !(f & flags::SUPPLEMENTARY); }
 
 // The whole stream: TemplateGrouper + the Process closure of either mode.  `blob` is mutated (masking is in place).
-inline void filter_stream(const fgx_filter_options* o, uint8_t* blob, const uint64_t* rec_off, const uint32_t* rec_len, uint32_t n_rec, BatchResult& res) {
+inline void filter_stream(const fgx_filter_options* o, uint8_t* blob, const uint64_t* rec_off, const uint32_t* rec_len, uint32_t n_rec, BatchResult& res,
+                          const Reference* ref = nullptr) {
   if (!o->filter_by_template) {   // filter.rs:581-625
     for (uint32_t r = 0; r < n_rec; r++) {
-      uint8_t* rec = blob + rec_off[r];
+      Bytes rec(blob + rec_off[r], blob + rec_off[r] + rec_len[r]);
       uint64_t masked = 0; bool pass = false;
-      process_record_raw(rec, rec_len[r], o, masked, pass);
+      process_record_raw(rec, o, ref, masked, pass);
       res.records_count++;
-      if (pass && is_primary(rec)) res.bases_masked += masked;
-      if (pass) { res.passed_count++; put_record(res.data, rec, rec_len[r]); }
-      else if (o->track_rejects) { res.rejected_count++; put_record(res.rejects, rec, rec_len[r]); }
+      if (pass && is_primary(rec.data())) res.bases_masked += masked;
+      if (pass) { res.passed_count++; put_record(res.data, rec.data(), (uint32_t)rec.size()); }
+      else if (o->track_rejects) { res.rejected_count++; put_record(res.rejects, rec.data(), (uint32_t)rec.size()); }
     }
     return;
   }
@@ -350,25 +474,26 @@ inline void filter_stream(const fgx_filter_options* o, uint8_t* blob, const uint
     // filter.rs:660-721
     std::vector<uint64_t> masked(order.size());
     std::vector<uint8_t> pass(order.size());
+    std::vector<Bytes> recs(order.size());
     bool has_primary = false, all_pass = true;
     for (size_t k = 0; k < order.size(); k++) {
       uint32_t i = order[k];
       bool p = false;
       res.records_count++;
-      process_record_raw(blob + rec_off[i], rec_len[i], o, masked[k], p);
+      recs[k].assign(blob + rec_off[i], blob + rec_off[i] + rec_len[i]);
+      process_record_raw(recs[k], o, ref, masked[k], p);
       pass[k] = p;
     }
     for (size_t k = 0; k < order.size(); k++)   // template_passes: first failing primary breaks, result identical
       if (is_primary(blob + rec_off[order[k]])) { has_primary = true; if (!pass[k]) all_pass = false; }
     bool tpass = has_primary && all_pass;
     for (size_t k = 0; k < order.size(); k++) {
-      uint32_t i = order[k];
-      const uint8_t* rec = blob + rec_off[i];
+      const uint8_t* rec = recs[k].data();
       bool prim = is_primary(rec);
       if (tpass && prim) res.bases_masked += masked[k];
       bool keep = prim ? tpass : (tpass && pass[k]);
-      if (keep) { res.passed_count++; put_record(res.data, rec, rec_len[i]); }
-      else if (o->track_rejects) { res.rejected_count++; put_record(res.rejects, rec, rec_len[i]); }
+      if (keep) { res.passed_count++; put_record(res.data, rec, (uint32_t)recs[k].size()); }
+      else if (o->track_rejects) { res.rejected_count++; put_record(res.rejects, rec, (uint32_t)recs[k].size()); }
     }
     r = e;
   }

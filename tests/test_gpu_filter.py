@@ -262,3 +262,78 @@ def test_filter_odd_records_and_tag_encodings():
     with pytest.raises(RuntimeError, match="cD/cE"):
         f.filter_stream(*tof.stream([wrong_type]))
     f.close()
+
+
+# ---- `fgumi filter --ref`: mapped consensus records, NM / UQ / MD regenerated after the masking (filter.rs:115-118, 888-890) ---------------------
+def _mapped_consensus_records(rng, contigs, n_templates):
+    """Consensus-shaped records as they look after alignment: mapped pairs (FR, reverse mates with reversed per-base tags left to the filter),
+    CIGARs with clips / indels, stale NM / UQ / MD of several encodings among the consensus tags, a few unmapped mates and a few fragments."""
+    recs = []
+    for t in range(n_templates):
+        L = rng.choice([20, 45, 80, 151])
+        rid = rng.randrange(len(contigs))
+        contig = contigs[rid]
+        paired = rng.random() < 0.85
+        for mate in ((1, 2) if paired else (0,)):
+            lead, trail = rng.choice([0, 0, 3]), rng.choice([0, 0, 5])
+            core = L - lead - trail
+            a = max(1, core // 2 - 1)
+            if rng.random() < 0.25 and core > 12:
+                ops, span = f"{lead}S" * (lead > 0) + f"{a}M2I{core - a - 2}M" + f"{trail}S" * (trail > 0), core - 2
+            elif rng.random() < 0.25 and core > 12:
+                ops, span = f"{lead}S" * (lead > 0) + f"{a}M3D{core - a}M" + f"{trail}S" * (trail > 0), core + 3
+            else:
+                ops, span = f"{lead}S" * (lead > 0) + f"{core}M" + f"{trail}S" * (trail > 0), core
+            start = rng.randrange(0, len(contig) - span - 1)
+            seq = "".join((chr(contig[(start + i) % len(contig)]).upper() if rng.random() < 0.95 else rng.choice("ACGT")) for i in range(L))
+            q = [rng.choice([5, 12, 25]) if rng.random() < 0.1 else 40 for _ in range(L)]
+            cd = [rng.choice([1, 2]) if rng.random() < 0.1 else 8 for _ in range(L)]
+            ce = [1 if rng.random() < 0.03 else 0 for _ in range(L)]
+            unmapped = rng.random() < 0.06
+            flag = (0x1 | (0x40 if mate == 1 else 0x80) if mate else 0) | (0x10 if (mate == 2 and not unmapped) else 0) | (0x4 if unmapped else 0)
+            tags = [("RG", "Z", "A"), ("cD", "i", max(cd)), ("cM", "i", min(cd)), ("cE", "f", sum(ce) / max(1, sum(cd))),
+                    ("cd", "raw", b"Bs" + struct.pack("<I", L) + struct.pack(f"<{L}h", *cd)), ("ce", "raw", b"Bs" + struct.pack("<I", L) + struct.pack(f"<{L}h", *ce)),
+                    ("MI", "Z", str(t))]
+            if rng.random() < 0.7:
+                tags.insert(rng.randrange(len(tags) + 1), ("NM", "raw", rng.choice([b"c\x02", b"i\x02\x00\x00\x00", b"S\x10\x27"])))
+            if rng.random() < 0.7:
+                tags.insert(rng.randrange(len(tags) + 1), ("MD", "Z", rng.choice([str(L), "10A5^AC20", "0"])))
+            if rng.random() < 0.5:
+                tags.insert(rng.randrange(len(tags) + 1), ("UQ", "raw", rng.choice([b"C\x2d", b"I\x2d\x00\x00\x00"])))
+            recs.append(bamutil.make_record(f"tmpl{t:05d}", seq, q, flag=flag, ref_id=-1 if unmapped else rid, pos=-1 if unmapped else start, cigar=None if unmapped else ops, tags=tags))
+    return recs
+
+
+@pytest.mark.parametrize("kw", [dict(min_reads=[3], min_base_quality=20, track_rejects=True), dict(min_reads=[1], filter_by_template=False, reverse_per_base_tags=True, track_rejects=True),
+                                dict(min_reads=[8], max_no_call_fraction=0.3, track_rejects=True)])
+def test_filter_with_a_reference_regenerates_alignment_tags(kw):
+    rng = random.Random(99)
+    contigs = [bytes(rng.choice(b"ACGTacgtN") for _ in range(L)) for L in (3000, 800)]
+    recs = _mapped_consensus_records(rng, contigs, 700)
+    blob, off, ln = tof.stream(recs)
+    orc.set_reference(contigs)
+    try:
+        want = orc.filter_records(orc.filter_options(regenerate_alignment_tags=True, **kw), blob, off, ln)
+    finally:
+        orc.set_reference(None)
+    f = ConsensusFilter(_cfg(kw), **_flags(kw))
+    f.set_reference({f"chr{i}": s for i, s in enumerate(contigs)}, [f"chr{i}" for i in range(len(contigs))])
+    got = f.filter_stream(blob, off, ln)
+    if got.data != want["data"]:
+        a, b = tof.bamutil_split(got.data), tof.bamutil_split(want["data"])
+        for i, (x, y) in enumerate(zip(a, b)):
+            if x != y:
+                raise AssertionError(f"kept record {i} differs:\n got {bamutil.parse(x)}\nwant {bamutil.parse(y)}")
+        raise AssertionError(f"kept count differs: {len(a)} vs {len(b)}")
+    assert got.rejects == want["rejects"] and got.rejected_count == want["rejected"] > 0
+    assert (got.records_count, got.passed_count, got.bases_masked) == (want["records"], want["passed"], want["masked"]) and got.passed_count > 50, got.passed_count
+    assert b"MD" in got.data
+    # without the reference the first mapped record is the reference's fatal error
+    f.set_reference(None, [])
+    with pytest.raises(RuntimeError, match="--ref is required"):
+        f.filter_stream(blob, off, ln)
+    # and an alignment that leaves its contig is fatal with it
+    f.set_reference({"chr0": contigs[0][:50], "chr1": contigs[1]}, ["chr0", "chr1"])
+    with pytest.raises(RuntimeError, match="leaves its reference"):
+        f.filter_stream(blob, off, ln)
+    f.close()
