@@ -25,33 +25,10 @@ namespace {
 #define FGX_INFL_LANES 8
 #endif
 constexpr uint32_t INFL_LANES = FGX_INFL_LANES;
-#ifndef FGX_INFL_RING
-#define FGX_INFL_RING 0   /* > 0: bytes of a lane's output ring in LDS (a power of two >= 512) — the round-4 experiment, see k_bgzf_inflate */
-#endif
 
 template <uint32_t INFL_LANES>
 __global__ __launch_bounds__(INFL_LANES) void k_bgzf_inflate(const uint8_t* __restrict__ raw, const BgzfDevBlock* __restrict__ blk, uint32_t n,
                                                              uint8_t* __restrict__ out, uint32_t* __restrict__ status) {
-#if FGX_INFL_RING
-  // Experiment of round 4 (profiles/r04_experiments.md; build with -DFGX_INFL_RING=1024): per lane, all in LDS, the first-level tables (1152 B),
-  // the canonical counts / symbols of both codes and the build scratch (736 B), the code lengths of a dynamic header (320 B) and an output
-  // ring through which every decoded byte passes and from which near matches are served.  Measured SLOWER than the form below (44 vs 31 ms per
-  // 766 MB): BAM records compress into ~9 700 matches of 6 bytes per block with only 37 % of the distances inside 1 KiB, and a lane's
-  // byte-wise LDS copies cost more than the global round trips they replace, at half the blocks in flight.
-  struct alignas(16) LaneLds { InflateFast f; uint16_t lit_count[16], dist_count[16], lit_sym[288], dist_sym[32], offs[16]; uint8_t lens[320]; uint32_t ring[FGX_INFL_RING / 4]; };
-  __shared__ LaneLds sL[INFL_LANES];
-  const uint32_t b = blockIdx.x * INFL_LANES + threadIdx.x;
-  if (b >= n) return;
-  const BgzfDevBlock B = blk[b];
-  if (B.isize == 0) return;
-  typedef __attribute__((address_space(3))) uint16_t* LdsPtr;     // (typed LDS pointers: table lookups are ds_read, not flat loads)
-  typedef __attribute__((address_space(3))) uint8_t* LdsByte;
-  typedef __attribute__((address_space(3))) uint32_t* LdsWord;
-  LaneLds& L = sL[threadIdx.x];
-  const InflateWork<LdsPtr, LdsByte> Wk{(LdsPtr)L.lit_count, (LdsPtr)L.dist_count, (LdsPtr)L.lit_sym, (LdsPtr)L.dist_sym, (LdsPtr)L.offs, (LdsByte)L.lens};
-  OutRing<FGX_INFL_RING, LdsByte, LdsWord> O(out + B.out_off, B.isize, (LdsByte)L.ring, (LdsWord)L.ring);
-  const int st = inflate_block_w(raw + B.in_off, B.in_len, (LdsPtr)L.f.lit, (LdsPtr)L.f.dist, Wk, O);
-#else
   __shared__ InflateFast sF[INFL_LANES];
   InflateSlow W;                                                // (private: touched by the rare codes longer than the first-level tables)
   const uint32_t b = blockIdx.x * INFL_LANES + threadIdx.x;
@@ -60,7 +37,6 @@ __global__ __launch_bounds__(INFL_LANES) void k_bgzf_inflate(const uint8_t* __re
   if (B.isize == 0) return;
   typedef __attribute__((address_space(3))) uint16_t* LdsPtr;     // (typed LDS pointers: table lookups are ds_read, not flat loads)
   const int st = inflate_block_t<LdsPtr>(raw + B.in_off, B.in_len, out + B.out_off, B.isize, (LdsPtr)sF[threadIdx.x].lit, (LdsPtr)sF[threadIdx.x].dist, W);
-#endif
   if (st != INFL_OK) atomicMax(status, ((b + 1u) << 4) | (uint32_t)st);      // (which block, why: the highest failing block wins)
 }
 
@@ -189,10 +165,11 @@ void bgzf_inflate_launch(hipStream_t s, const uint8_t* d_raw, const BgzfDevBlock
   *h_status = 0;
   if (n == 0) return;
   hip_check(hipMemsetAsync(d_status, 0, 4, s), "memset");
-  static const uint32_t lanes = [] { const char* e = getenv("FGX_INFL_LANES"); const int v = e ? atoi(e) : 0; return (v == 4 || v == 16 || v == 32) ? (uint32_t)v : INFL_LANES; }();   // (a measuring knob: profiles/r03_experiments.md)
+  static const uint32_t lanes = [] { const char* e = getenv("FGX_INFL_LANES"); const int v = e ? atoi(e) : 0; return (v == 4 || v == 16 || v == 32 || v == 64) ? (uint32_t)v : INFL_LANES; }();   // (a measuring knob: profiles/r03_experiments.md)
   if (lanes == 4) hipLaunchKernelGGL(k_bgzf_inflate<4>, dim3((n + 3) / 4), dim3(4), 0, s, d_raw, d_blk, n, d_out, d_status);
   else if (lanes == 16) hipLaunchKernelGGL(k_bgzf_inflate<16>, dim3((n + 15) / 16), dim3(16), 0, s, d_raw, d_blk, n, d_out, d_status);
   else if (lanes == 32) hipLaunchKernelGGL(k_bgzf_inflate<32>, dim3((n + 31) / 32), dim3(32), 0, s, d_raw, d_blk, n, d_out, d_status);
+  else if (lanes == 64) hipLaunchKernelGGL(k_bgzf_inflate<64>, dim3((n + 63) / 64), dim3(64), 0, s, d_raw, d_blk, n, d_out, d_status);
   else hipLaunchKernelGGL(k_bgzf_inflate<INFL_LANES>, dim3((n + INFL_LANES - 1) / INFL_LANES), dim3(INFL_LANES), 0, s, d_raw, d_blk, n, d_out, d_status);
   hipLaunchKernelGGL(k_bgzf_crc, dim3((n + 3) / 4), dim3(256), 0, s, (const uint8_t*)d_out, d_blk, n, d_status);
   hip_check(hipMemcpyAsync(h_status, d_status, 4, hipMemcpyDeviceToHost, s), "D2H");

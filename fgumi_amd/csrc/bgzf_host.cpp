@@ -115,21 +115,6 @@ int fgx_inflate_block_host(const uint8_t* in, uint32_t in_len, uint8_t* out, uin
   return st;
 }
 
-// the decoder in the form the DEVICE runs (work area behind pointers; every byte through a ring of `win` bytes — 512 / 1024 / 4096 — that serves
-// the near matches and leaves for the output in 16-byte pieces), with plain host memory behind the pointers: the CPU tests drive both forms
-// over the same streams
-int fgx_inflate_block_host_staged(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, uint32_t win) {
-  static thread_local fgx::InflateTables T;
-  static thread_local uint16_t offs[16];
-  static thread_local uint8_t lens[320];
-  alignas(16) static thread_local uint32_t ring[4096 / 4];
-  const fgx::InflateWork<uint16_t*, uint8_t*> Wk{T.w.lit_count, T.w.dist_count, T.w.lit_sym, T.w.dist_sym, offs, lens};
-  if (win == 512) { fgx::OutRing<512, uint8_t*, uint32_t*> O(out, out_len, (uint8_t*)ring, ring); return fgx::inflate_block_w(in, in_len, (uint16_t*)T.f.lit, (uint16_t*)T.f.dist, Wk, O); }
-  if (win == 4096) { fgx::OutRing<4096, uint8_t*, uint32_t*> O(out, out_len, (uint8_t*)ring, ring); return fgx::inflate_block_w(in, in_len, (uint16_t*)T.f.lit, (uint16_t*)T.f.dist, Wk, O); }
-  fgx::OutRing<1024, uint8_t*, uint32_t*> O(out, out_len, (uint8_t*)ring, ring);
-  return fgx::inflate_block_w(in, in_len, (uint16_t*)T.f.lit, (uint16_t*)T.f.dist, Wk, O);
-}
-
 // the device's DEFLATE compressor (deflate_core.h) run on the host: the same source, for the CPU tests.  `in` must be readable for
 // 8 bytes past n.  Returns the compressed size, 0 when the stream does not fit `cap` (a block to be stored).
 uint32_t fgx_deflate_block_host(const uint8_t* in, uint32_t n, uint8_t* out, uint32_t cap) {

@@ -77,9 +77,8 @@ FGX_HD inline uint32_t infl_rev(uint32_t code, uint32_t len) {
 
 // canonical Huffman tables from code lengths (RFC 1951 3.2.2).  Returns false for an over-subscribed set; an incomplete set is
 // allowed only for a single code (the one-distance-code case) — what zlib accepts.
-template <class LensPtr, class SlowPtr, class FastPtr>   // plain pointers on the host; LDS (address space 3) pointers on the device: ds_read / ds_write
-                                                         // instead of flat or private (scratch = global memory) accesses.  `offs`: 16 entries of scratch
-FGX_HD inline bool infl_build(LensPtr lens, uint32_t n, SlowPtr count, SlowPtr sym, SlowPtr offs, FastPtr fast, uint32_t fast_bits) {
+template <class FastPtr>   // uint16_t* on the host; an LDS (address space 3) pointer on the device: ds_read instead of a flat load
+FGX_HD inline bool infl_build(const uint8_t* lens, uint32_t n, uint16_t* count, uint16_t* sym, FastPtr fast, uint32_t fast_bits) {
   for (uint32_t l = 0; l < 16; l++) count[l] = 0;
   for (uint32_t s = 0; s < n; s++) count[lens[s]]++;
   for (uint32_t i = 0; i < (1u << fast_bits); i++) fast[i] = 0;
@@ -87,6 +86,7 @@ FGX_HD inline bool infl_build(LensPtr lens, uint32_t n, SlowPtr count, SlowPtr s
   int32_t left = 1;
   for (uint32_t l = 1; l < 16; l++) { left <<= 1; left -= (int32_t)count[l]; if (left < 0) return false; }
   if (left > 0 && !(n - count[0] == 1 && count[1] == 1)) return false;
+  uint16_t offs[16];
   offs[1] = 0;
   for (uint32_t l = 1; l < 15; l++) offs[l + 1] = (uint16_t)(offs[l] + count[l]);
   for (uint32_t s = 0; s < n; s++) if (lens[s]) sym[offs[lens[s]]++] = (uint16_t)s;
@@ -108,8 +108,7 @@ FGX_HD inline bool infl_build(LensPtr lens, uint32_t n, SlowPtr count, SlowPtr s
 // (The walk used to start at bit 1 and read count[] from private memory — a global-memory round trip per bit, and with sixteen lanes
 // decoding in step nearly every step had a lane on it.)
 struct InflWalk { uint32_t first, index; uint32_t cnt[5]; };
-template <class SlowPtr>
-FGX_HD inline void infl_walk_setup(SlowPtr count, uint32_t K, InflWalk& w) {
+FGX_HD inline void infl_walk_setup(const uint16_t* count, uint32_t K, InflWalk& w) {
   uint32_t first = 0, index = 0;
   for (uint32_t l = 1; l <= K; l++) { index += count[l]; first = (first + count[l]) << 1; }
   w.first = first; w.index = index;
@@ -119,8 +118,8 @@ FGX_HD inline void infl_walk_setup(SlowPtr count, uint32_t K, InflWalk& w) {
   }
 }
 // one symbol: the first-level table (K peeked bits), else the walk from bit K + 1 on.  Returns the symbol or -1.
-template <uint32_t K, class FastPtr, class SlowPtr>
-FGX_HD inline int32_t infl_decode(BitReader& r, FastPtr fast, const InflWalk& w, SlowPtr sym) {
+template <uint32_t K, class FastPtr>
+FGX_HD inline int32_t infl_decode(BitReader& r, FastPtr fast, const InflWalk& w, const uint16_t* sym) {
   static_assert(K >= 5 && K <= 14, "InflWalk holds the counts of at most ten lengths");
   const uint32_t e = fast[(uint32_t)r.bb & ((1u << K) - 1u)];
   if (e & 15u) { const uint32_t l = e & 15u; r.bb >>= l; r.bc -= l; return (int32_t)(e >> 4); }
@@ -212,102 +211,17 @@ FGX_HD inline void infl_store_pending(uint8_t* dst, uint32_t n, uint64_t v0, uin
   if (n >= 32) memcpy(dst + 24, &v3, 8); else infl_store_bytes(dst + 24, v3, n - 24);
 }
 
-// The per-block work area beside the first-level tables: canonical counts / symbols of both codes, 16 entries of build scratch and the code
-// lengths of a dynamic header.  On the host it points into plain structs; on the device its fields are LDS pointers — as private arrays
-// they lived in scratch memory (= global memory: every dynamic index a round trip).
-template <class SlowPtr, class LensPtr>
-struct InflateWork { SlowPtr lit_count, dist_count, lit_sym, dist_sym, offs; LensPtr lens; };
-
-// ---- where the decoded bytes go -----------------------------------------------------------------------------------------------------
-// OutDirect: every byte straight to its place; a match copies from there (the window IS the output).  The host's form, and the device's
-// until round 4.
-struct OutDirect {
-  uint8_t* out; uint32_t out_len;
-  uint32_t pos = 0;
-  uint64_t pv0 = 0, pv1 = 0, pv2 = 0, pv3 = 0;                                  // a match whose bytes are loaded and not stored yet (p_len of them at p_pos)
-  uint32_t p_pos = 0, p_len = 0;
-  FGX_HD OutDirect(uint8_t* o, uint32_t n) : out(o), out_len(n) {}
-  FGX_HD inline bool room(uint32_t n) const { return pos + n <= out_len; }
-  FGX_HD inline void lit(uint32_t b) { out[pos++] = (uint8_t)b; }
-  FGX_HD inline void match(uint32_t dist, uint32_t len) {
-    if (dist >= len && len <= 32) {
-      // a short match whose source lies wholly before it (most matches): its bytes are LOADED now and STORED when the next match
-      // arrives (or the block ends).  The stores of the match before go out first, so a source that overlaps that match's destination
-      // reads what was just stored (a wavefront's memory operations keep their order).
-      if (p_len) infl_store_pending(out + p_pos, p_len, pv0, pv1, pv2, pv3);
-      const uint8_t* src = out + pos - dist;
-      pv0 = infl_load64(src);
-      pv1 = len > 8 ? infl_load64(src + 8) : 0ull;
-      pv2 = len > 16 ? infl_load64(src + 16) : 0ull;
-      pv3 = len > 24 ? infl_load64(src + 24) : 0ull;
-      p_pos = pos; p_len = len;
-    } else {
-      if (p_len) { infl_store_pending(out + p_pos, p_len, pv0, pv1, pv2, pv3); p_len = 0; }
-      infl_copy_match(out + pos, dist, len);
-    }
-    pos += len;
-  }
-  FGX_HD inline void end_of_block() { if (p_len) { infl_store_pending(out + p_pos, p_len, pv0, pv1, pv2, pv3); p_len = 0; } }
-  FGX_HD inline void finish() {}
-};
-// OutRing (the device's form): every decoded byte goes into a ring of WIN bytes (LDS), which is also where a match finds its source as
-// long as the distance fits the ring — a match used to cost a global-memory round trip (the source bytes had just been stored), and a
-// 64 KiB block of BAM records holds thousands of them; the ring leaves for the output in 16-byte pieces, and only a match that reaches
-// further back than the ring reads global memory.  RingPtr / RingWordPtr: the same ring as bytes / as 32-bit words (WIN a power of two).
-template <uint32_t WIN, class RingPtr, class RingWordPtr>
-struct OutRing {
-  // a source this close is inside the ring: byte i of the match overwrites position pos + i - WIN, and every byte still to be read lies behind it
-  // (pos - dist + i' > pos + i - WIN for i' >= i and dist <= WIN - 2); what has not left for `out` yet (< 64 + 16 + 258 bytes) fits as well
-  static constexpr uint32_t M = WIN - 1, NEAR = WIN - 2;
-  static_assert((WIN & (WIN - 1)) == 0 && WIN >= 512, "ring size");
-  uint8_t* out; uint32_t out_len;
-  RingPtr ring; RingWordPtr ring32;
-  uint32_t pos = 0, fl = 0;                                                     // bytes decoded / bytes that have left for `out` (a multiple of 16)
-  FGX_HD OutRing(uint8_t* o, uint32_t n, RingPtr r, RingWordPtr r32) : out(o), out_len(n), ring(r), ring32(r32) {}
-  FGX_HD inline bool room(uint32_t n) const { return pos + n <= out_len; }
-  FGX_HD inline void flush_upto(uint32_t limit) {
-    while (fl + 16 <= limit) {
-      const uint32_t w0 = (fl & M) >> 2;
-      const uint32_t w[4] = {ring32[w0], ring32[w0 + 1], ring32[w0 + 2], ring32[w0 + 3]};
-      memcpy(out + fl, w, 16);
-      fl += 16;
-    }
-  }
-  FGX_HD inline void lit(uint32_t b) {
-    ring[pos & M] = (uint8_t)b;
-    pos++;
-    if (pos - fl >= 64) flush_upto(pos);
-  }
-  FGX_HD inline void match(uint32_t dist, uint32_t len) {
-    if (dist <= NEAR) {
-      for (uint32_t i = 0; i < len; i++) ring[(pos + i) & M] = ring[(pos + i - dist) & M];     // (in order: a match may repeat its own beginning)
-    } else {
-      // further back than the ring (dist > WIN - 2 >= 510 > len: no overlap): those bytes left for `out` long ago (what had not left before this
-      // match is less than 80 bytes)
-      const uint8_t* src = out + pos - dist;
-      for (uint32_t i = 0; i < len; i += 8) {
-        const uint64_t v = infl_load64(src + i);                                // (dist > len: the source lies wholly before the match; may read 7 bytes past it, inside `out`)
-        const uint32_t n = len - i < 8u ? len - i : 8u;
-        for (uint32_t k = 0; k < n; k++) ring[(pos + i + k) & M] = (uint8_t)(v >> (8 * k));
-      }
-    }
-    pos += len;
-    flush_upto(pos);
-  }
-  FGX_HD inline void end_of_block() {}
-  FGX_HD inline void finish() { flush_upto(pos); for (; fl < pos; fl++) out[fl] = ring[fl & M]; }
-};
-
-// inflates `in[0 .. in_len)`; the stream must produce exactly O.out_len bytes (the block's ISIZE).
-// `in` must be readable for 8 bytes past in_len (no load goes further, also for corrupt input).  f_lit / f_dist / Wk: this lane's tables and
-// work area; O: where the bytes go (OutDirect / OutRing).
-template <class FastPtr, class Work, class Out>
-FGX_HD inline int inflate_block_w(const uint8_t* in, uint32_t in_len, FastPtr f_lit, FastPtr f_dist, const Work& Wk, Out& O) {
+// inflates `in[0 .. in_len)` into `out[0 .. out_len)`; the stream must produce exactly out_len bytes (the block's ISIZE).
+// `in` must be readable for 8 bytes past in_len (no load goes further, also for corrupt input).  F / W: this lane's tables (LDS / private memory on the device).
+template <class FastPtr>
+FGX_HD inline int inflate_block_t(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, FastPtr f_lit, FastPtr f_dist, InflateSlow& W) {
   constexpr uint32_t LB = FGX_INFL_LIT_BITS, DB = FGX_INFL_DIST_BITS;
   static constexpr uint8_t CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
   BitReader r{in, in_len, 0u, 0ull, 0u, 0ull};
   infl_seek(r, 0);
-  auto lens = Wk.lens;
+  uint64_t pv0 = 0, pv1 = 0, pv2 = 0, pv3 = 0;                                  // a match whose bytes are loaded and not stored yet (p_len of them at p_pos)
+  uint32_t p_pos = 0, p_len = 0;
+  uint32_t pos = 0;
   for (;;) {
     infl_refill(r);
     const uint32_t bfinal = infl_bits(r, 1), btype = infl_bits(r, 2);
@@ -321,10 +235,12 @@ FGX_HD inline int inflate_block_w(const uint8_t* in, uint32_t in_len, FastPtr f_
       // the bytes still in the bit buffer belong to the payload: step the byte position back over them
       const uint32_t src = r.pos - (r.bc >> 3);
       if (src + len > in_len) return INFL_INPUT_OVERRUN;
-      if (!O.room(len)) return INFL_OUTPUT_OVERFLOW;
-      for (uint32_t i = 0; i < len; i++) O.lit(in[src + i]);
+      if (pos + len > out_len) return INFL_OUTPUT_OVERFLOW;
+      for (uint32_t i = 0; i < len; i++) out[pos + i] = in[src + i];
+      pos += len;
       infl_seek(r, src + len);
     } else if (btype == 1 || btype == 2) {
+      uint8_t lens[320];
       uint32_t hlit, hdist;
       if (btype == 1) {
         hlit = 288; hdist = 32;                        // (the fixed distance code is 32 five-bit codes; 30 and 31 never appear in valid data)
@@ -337,18 +253,18 @@ FGX_HD inline int inflate_block_w(const uint8_t* in, uint32_t in_len, FastPtr f_
         hlit = infl_bits(r, 5) + 257; hdist = infl_bits(r, 5) + 1;
         const uint32_t hclen = infl_bits(r, 4) + 4;
         if (hlit > 286 || hdist > 30) return INFL_BAD_CODE_LENGTHS;
-        // the code-length code: its 19 lengths sit at the END of `lens` while the header is read (entries 301 .. 319: a header holds at most
-        // 286 + 30 = 316 lengths, and those slots are written last), its tables in the distance slots for the moment (19 symbols, up to 7 bits)
-        for (uint32_t i = 0; i < 19; i++) lens[301 + i] = 0;
+        uint8_t cl[19];
+        for (uint32_t i = 0; i < 19; i++) cl[i] = 0;
         infl_refill(r);
-        for (uint32_t i = 0; i < hclen; i++) { if (r.bc < 3) infl_refill(r); lens[301 + CL_ORDER[i]] = (uint8_t)infl_bits(r, 3); }
-        if (!infl_build(lens + 301, 19, Wk.dist_count, Wk.dist_sym, Wk.offs, f_dist, DB)) return INFL_BAD_CODE_LENGTHS;
+        for (uint32_t i = 0; i < hclen; i++) { if (r.bc < 3) infl_refill(r); cl[CL_ORDER[i]] = (uint8_t)infl_bits(r, 3); }
+        // the code-length code: its tables live in the distance slots for the moment (19 symbols, up to 7 bits)
+        if (!infl_build(cl, 19, W.dist_count, W.dist_sym, f_dist, DB)) return INFL_BAD_CODE_LENGTHS;
         InflWalk wc;
-        infl_walk_setup(Wk.dist_count, DB, wc);
+        infl_walk_setup(W.dist_count, DB, wc);
         uint32_t n = 0;
         while (n < hlit + hdist) {
           if (r.bc < 32) { infl_refill(r); if (infl_overrun(r)) return INFL_INPUT_OVERRUN; }
-          const int32_t s = infl_decode<DB>(r, f_dist, wc, Wk.dist_sym);
+          const int32_t s = infl_decode<DB>(r, f_dist, wc, W.dist_sym);
           if (s < 0) return INFL_BAD_CODE_LENGTHS;
           if (s < 16) lens[n++] = (uint8_t)s;
           else {
@@ -362,47 +278,53 @@ FGX_HD inline int inflate_block_w(const uint8_t* in, uint32_t in_len, FastPtr f_
         }
         if (lens[256] == 0) return INFL_BAD_CODE_LENGTHS;        // no end-of-block code
       }
-      if (!infl_build(lens, hlit, Wk.lit_count, Wk.lit_sym, Wk.offs, f_lit, LB)) return INFL_BAD_CODE_LENGTHS;
-      if (!infl_build(lens + hlit, hdist, Wk.dist_count, Wk.dist_sym, Wk.offs, f_dist, DB)) return INFL_BAD_CODE_LENGTHS;
+      if (!infl_build(lens, hlit, W.lit_count, W.lit_sym, f_lit, LB)) return INFL_BAD_CODE_LENGTHS;
+      if (!infl_build(lens + hlit, hdist, W.dist_count, W.dist_sym, f_dist, DB)) return INFL_BAD_CODE_LENGTHS;
       InflWalk wl, wd;
-      infl_walk_setup(Wk.lit_count, LB, wl);
-      infl_walk_setup(Wk.dist_count, DB, wd);
+      infl_walk_setup(W.lit_count, LB, wl);
+      infl_walk_setup(W.dist_count, DB, wd);
       for (;;) {
         if (r.bc < 48) { infl_refill(r); if (infl_overrun(r)) return INFL_INPUT_OVERRUN; }   // a length + distance pair takes at most 15 + 5 + 15 + 13 = 48 bits
-        int32_t s = infl_decode<LB>(r, f_lit, wl, Wk.lit_sym);
+        int32_t s = infl_decode<LB>(r, f_lit, wl, W.lit_sym);
         if (s < 0) return INFL_BAD_SYMBOL;
         if (s < 256) {
-          if (!O.room(1)) return INFL_OUTPUT_OVERFLOW;
-          O.lit((uint32_t)s);
+          if (pos >= out_len) return INFL_OUTPUT_OVERFLOW;
+          out[pos++] = (uint8_t)s;
           continue;
         }
-        if (s == 256) { O.end_of_block(); break; }
+        if (s == 256) { if (p_len) { infl_store_pending(out + p_pos, p_len, pv0, pv1, pv2, pv3); p_len = 0; } break; }
         s -= 257;
         if (s >= 29) return INFL_BAD_SYMBOL;
         const uint32_t len = infl_len_base((uint32_t)s) + infl_bits(r, infl_len_extra((uint32_t)s));
-        const int32_t d = infl_decode<DB>(r, f_dist, wd, Wk.dist_sym);
+        const int32_t d = infl_decode<DB>(r, f_dist, wd, W.dist_sym);
         if (d < 0 || d >= 30) return INFL_BAD_DISTANCE;
         const uint32_t dist = infl_dist_base((uint32_t)d) + infl_bits(r, infl_dist_extra((uint32_t)d));
-        if (dist > O.pos) return INFL_BAD_DISTANCE;
-        if (!O.room(len)) return INFL_OUTPUT_OVERFLOW;
-        O.match(dist, len);
+        if (dist > pos) return INFL_BAD_DISTANCE;
+        if (pos + len > out_len) return INFL_OUTPUT_OVERFLOW;
+        if (dist >= len && len <= 32) {
+          // a short match whose source lies wholly before it (most matches): its bytes are LOADED now and STORED when the next match
+          // arrives (or the block ends) — a wavefront's lanes run the loop in step, nearly every step has a lane with a match, and
+          // waiting for the match's source inside the step made every step a global-memory round trip.  The stores of the match
+          // before go out first, so a source that overlaps that match's destination reads what was just stored (a wavefront's memory
+          // operations keep their order).
+          if (p_len) infl_store_pending(out + p_pos, p_len, pv0, pv1, pv2, pv3);
+          const uint8_t* src = out + pos - dist;
+          pv0 = infl_load64(src);
+          pv1 = len > 8 ? infl_load64(src + 8) : 0ull;
+          pv2 = len > 16 ? infl_load64(src + 16) : 0ull;
+          pv3 = len > 24 ? infl_load64(src + 24) : 0ull;
+          p_pos = pos; p_len = len;
+        } else {
+          if (p_len) { infl_store_pending(out + p_pos, p_len, pv0, pv1, pv2, pv3); p_len = 0; }
+          infl_copy_match(out + pos, dist, len);
+        }
+        pos += len;
       }
     } else return INFL_BAD_BLOCK_TYPE;
     if (r.pos - (r.bc >> 3) > in_len) return INFL_INPUT_OVERRUN;   // bits were taken from beyond the payload
     if (bfinal) break;
   }
-  O.finish();
-  return O.pos == O.out_len ? INFL_OK : INFL_SIZE_MISMATCH;
-}
-
-// the host form: tables in a plain struct, 320 code lengths and the build scratch on the stack, every byte stored where it belongs
-template <class FastPtr>
-FGX_HD inline int inflate_block_t(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, FastPtr f_lit, FastPtr f_dist, InflateSlow& W) {
-  uint8_t lens[320];
-  uint16_t offs[16];
-  const InflateWork<uint16_t*, uint8_t*> Wk{W.lit_count, W.dist_count, W.lit_sym, W.dist_sym, offs, lens};
-  OutDirect O(out, out_len);
-  return inflate_block_w(in, in_len, f_lit, f_dist, Wk, O);
+  return pos == out_len ? INFL_OK : INFL_SIZE_MISMATCH;
 }
 
 FGX_HD inline int inflate_block(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, InflateFast& F, InflateSlow& W) {

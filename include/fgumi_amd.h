@@ -407,9 +407,6 @@ int fgx_run_bam_rejects(fgx_caller* c, const char* in_path, const char* out_path
  * tests without a device.  `in` must be readable for 8 bytes past in_len; `out_len` = the block's ISIZE.  Returns the decoder's
  * status (0 = ok) and, in *crc_out, the CRC-32 of the output computed with the device's 64-slice fold. */
 int fgx_inflate_block_host(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, uint32_t* crc_out);
-/* ... in the form the device kernel instantiates (every byte through a ring of `win` = 512 / 1024 / 4096 bytes that serves the near matches and
- * leaves for the output in 16-byte pieces; work area behind pointers) */
-int fgx_inflate_block_host_staged(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, uint32_t win);
 /* The device's DEFLATE compressor (fgumi_amd/csrc/deflate_core.h, one GPU lane per BGZF block: greedy LZ77 + one dynamic Huffman
  * code per block) run on the host, for tests without a device.  `in` readable for 8 bytes past n (n <= 65535).  Returns the bytes
  * written to `out`, or 0 when they do not fit `cap` (the caller stores the block). */
