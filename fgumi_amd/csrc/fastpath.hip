@@ -3759,7 +3759,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       // families on ONE wavefront while the other three wait at a barrier, 11.9 ms, and the same as a producer / consumer pipeline
       // in persistent workgroups, 19.3 ms, against 10.2 ms per 1 M depth-8 families here: they execute 20 % fewer vector and 43 %
       // fewer scalar instructions, but a lone wavefront retires an instruction every ~30 cycles, and the CU is fed by the number of
-      // independent wavefronts, not by lane utilisation.  profiles/r02c_pmc_1M_blk.json, r02d_pmc_1M_pipe.json)
+      // independent wavefronts, not by lane utilisation.  profiles/r02c_pmc_1M_blk.json, r02d_pmc_1M_pipe.json; HISTORY.md §4.)
       // wavefronts per workgroup of k_simplex_wave2's first launch: the LDS of a workgroup is freed when its SLOWEST wavefront is
       // done, so small workgroups keep more wavefronts running (FGX_W2_WPB: measurement knob)
       static const uint32_t w2_wpb = [] { const char* e = getenv("FGX_W2_WPB"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= WAVES_PER_BLOCK ? v : FGX_W2_WPB_DEFAULT); }();

@@ -227,7 +227,7 @@ def test_host_entry_gpu_tests_run_against_the_emulation(all_on):
              "tests/test_gpu_pipeline.py"]            # (fgx_run_bam: BAM file -> consensus BAM file == the oracle; boundaries.hip / grouping.hip are the real sources)
     skip = "not device_resident and not full_size and not stay_on_the_device and not noisy_batch and not device_deflate and not device_boundaries"
     e = dict(os.environ)
-    e.update(env(FGX_OPT_IN_ALL=all_on))      # all_on: the rehearsal of "the whole suite with every opt-in path switched on" 
+    e.update(env(FGX_OPT_IN_ALL=all_on))      # all_on: the rehearsal of "the whole suite with every opt-in path switched on" (HISTORY.md §15, step 2: done in round 4, the paths are defaults now)
     p = subprocess.run([sys.executable, "-m", "pytest"] + files + ["-m", "gpu", "-q", "-x", "-k", skip, "-p", "no:cacheprovider", "-n", "4"],
                        env=e, cwd=apiemu.ROOT, capture_output=True, text=True, timeout=1800)
     tail = p.stdout[-3000:]

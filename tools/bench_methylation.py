@@ -1,6 +1,6 @@
 """Stage times of the methylation-aware mode on one GPU: a seeded EM-Seq-like batch (tests/methsim.py) through `fgx_process_batch` with
 and without the mode; prints one JSON line (host preparation / kernels / record assembly in ms as fgx_output reports them, reads per
-second of the whole call).  The mode runs on the general path: this is its cost, not a headline."""
+second of the whole call).  The mode runs on the general path (HISTORY.md §13): this is its cost, not a headline."""
 import ctypes as C
 import json
 import os
