@@ -47,7 +47,9 @@ class FilterOptions(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("min_reads", C.c_uint32 * 3), ("max_read_error_rate", C.c_double * 3), ("max_base_error_rate", C.c_double * 3),
                 ("min_mean_base_quality", C.c_double), ("max_no_call_fraction", C.c_double), ("has_min_base_quality", C.c_uint8), ("min_base_quality", C.c_uint8),
                 ("has_min_mean_base_quality", C.c_uint8), ("require_single_strand_agreement", C.c_uint8), ("reverse_per_base_tags", C.c_uint8),
-                ("filter_by_template", C.c_uint8), ("track_rejects", C.c_uint8), ("regenerate_alignment_tags", C.c_uint8)]
+                ("filter_by_template", C.c_uint8), ("track_rejects", C.c_uint8), ("regenerate_alignment_tags", C.c_uint8),
+                ("has_min_methylation_depth", C.c_uint8), ("require_strand_methylation_agreement", C.c_uint8), ("has_min_conversion_fraction", C.c_uint8),
+                ("methylation_mode", C.c_uint8), ("min_methylation_depth", C.c_uint32 * 3), ("min_conversion_fraction", C.c_double)]
 
 
 class FilterOutput(C.Structure):

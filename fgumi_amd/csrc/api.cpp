@@ -1124,6 +1124,18 @@ static bool filter_options_valid(const fgx_filter_options* f, std::string& err) 
   if (f->min_reads[1] > f->min_reads[0] || f->min_reads[2] > f->min_reads[1]) { err = "min-reads values must be specified high to low (duplex >= AB >= BA)"; return false; }
   if (f->max_read_error_rate[1] > f->max_read_error_rate[2]) { err = "max-read-error-rate for AB must be <= BA (more stringent)"; return false; }
   if (f->max_base_error_rate[1] > f->max_base_error_rate[2]) { err = "max-base-error-rate for AB must be <= BA (more stringent)"; return false; }
+  // the methylation filters (filter.rs:1110-1154)
+  if (f->has_min_methylation_depth) {
+    if (f->min_methylation_depth[0] < f->min_methylation_depth[1]) { err = "min-methylation-depth values must be specified high to low (duplex >= AB)"; return false; }
+    if (f->min_methylation_depth[1] < f->min_methylation_depth[2]) { err = "min-methylation-depth values must be specified high to low (AB >= BA)"; return false; }
+  }
+  if (f->require_strand_methylation_agreement && !f->regenerate_alignment_tags) { err = "--require-strand-methylation-agreement requires --ref to identify CpG sites"; return false; }
+  if (f->has_min_conversion_fraction) {
+    if (!(f->min_conversion_fraction >= 0.0 && f->min_conversion_fraction <= 1.0)) { err = "--min-conversion-fraction must be between 0.0 and 1.0"; return false; }
+    if (!f->regenerate_alignment_tags) { err = "--min-conversion-fraction requires --ref to identify non-CpG cytosines"; return false; }
+    if (f->methylation_mode != FGX_METHYLATION_EM_SEQ && f->methylation_mode != FGX_METHYLATION_TAPS) { err = "--min-conversion-fraction requires --methylation-mode to be set"; return false; }
+  }
+  if (f->methylation_mode > FGX_METHYLATION_TAPS) { err = "fgx_filter_options.methylation_mode: not a FGX_METHYLATION_* value"; return false; }
   return true;
 }
 

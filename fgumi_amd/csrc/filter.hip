@@ -43,6 +43,8 @@ struct FilterParams {
   fgx_filter_options o;
   uint8_t* pass; uint32_t* masked; unsigned long long* error;
   uint32_t lds_slice;
+  // the reference-dependent methylation filters (k_filter_records<1>): the genome of fgx_set_reference, contig i of the header = [off, off + len)
+  const uint8_t* genome; const uint64_t* contig_off; const uint64_t* contig_len; uint32_t n_ref;
 };
 
 __device__ inline uint32_t rl(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
@@ -104,6 +106,7 @@ __device__ unsigned long long g_fphase[64 * 8];
 
 // Everything after staging; R points at the record in LDS (or in HBM for a record larger than the slice) — called once per
 // address space so that the LDS path compiles to ds_read / ds_write instead of flat accesses.
+template <int METH>
 __device__ __forceinline__ void filter_body(const FilterParams& P, const uint32_t r, const uint32_t lane, uint8_t* g, uint8_t* R, const bool staged,
                                             const uint32_t len FPH_ARG) {
   const uint32_t l_name = R[8], n_cig = bam::rd16(R + 12), flags = bam::rd16(R + 14), l_seq = bam::rd32(R + 16);
@@ -313,6 +316,107 @@ __device__ __forceinline__ void filter_body(const FilterParams& P, const uint32_
     }
   }
   FPH(3)
+  // ---- the methylation (EM-Seq / TAPs) filters (src/lib/commands/filter.rs:833-886, 924-937; crates/fgumi-consensus/src/filter.rs:925-1340).
+  // Only in the <1> instantiation (the host picks it when one of the three options is set).  They run after the masking above like the
+  // reference's: a lane re-reads ITS OWN pair bytes from HBM (`g`: the masks above went there, not into the LDS copy), the count arrays
+  // come from the (already reversed) LDS copy.  A base that is N by now is skipped, so every newly masked base is counted once.
+  bool conv_ok = true;
+  if constexpr (METH != 0) {
+    const Src cu = src_of(T_cu), ct = src_of(T_ct), au = src_of(T_au), at = src_of(T_at), bu = src_of(T_bu), bt = src_of(T_bt);
+    auto ev = [&](const Src& sc, uint32_t i) { return elem(A, sc.kind, sc.off, sc.count, i); };
+    const bool has_cuct = rl(arr_ok, T_cu) || rl(arr_ok, T_ct);             // MethylationTags: a B array that parses (filter.rs:462-484)
+    // mask_methylation_depth_{simplex,duplex}_raw_with_tags :973-1066
+    if (P.o.has_min_methylation_depth && has_cuct) {
+      const uint64_t t_cc = P.o.min_methylation_depth[0], t_ab = P.o.min_methylation_depth[1], t_ba = P.o.min_methylation_depth[2];
+      for (uint32_t j = lane; j < n_pairs; j += 64) {
+        const uint8_t b = g[seq_off + j];
+        uint8_t nb = b;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const uint32_t i = 2 * j + h;
+          if (i >= l_seq) break;
+          if ((h == 0 ? (b >> 4) : (b & 0xF)) == 0xF) continue;
+          bool m = (uint64_t)(ev(cu, i) + ev(ct, i)) < t_cc;
+          if (duplex) m = m || (uint64_t)(ev(au, i) + ev(at, i)) < t_ab || (uint64_t)(ev(bu, i) + ev(bt, i)) < t_ba;
+          if (m) { n_masked++; n_nocall++; nb |= h == 0 ? 0xF0 : 0x0F; g[qual_off + i] = 2; }
+        }
+        if (nb != b) g[seq_off + j] = nb;
+      }
+    }
+    // resolve_ref_bases_for_record :1072-1133 as a cursor over the CIGAR that every lane advances for its own (increasing) positions: 0 = None.
+    // (A ref_id beyond the contigs or a negative pos: regenerate_alignment_tags refuses the record right after, nothing of it is kept.)
+    const int32_t ref_id = (int32_t)bam::rd32(R), pos = (int32_t)bam::rd32(R + 4);
+    const bool has_map = P.o.regenerate_alignment_tags && !(flags & bam::F_UNMAPPED) && ref_id >= 0 && (uint32_t)ref_id < P.n_ref;
+    const bool strand = P.o.require_strand_methylation_agreement && duplex && (rl(arr_ok, T_au) || rl(arr_ok, T_bu));   // :1166-1190
+    const bool conv = P.o.has_min_conversion_fraction && P.o.methylation_mode != FGX_METHYLATION_DISABLED && has_cuct;  // :1279-1301
+    if (has_map && (strand || conv)) {
+      const uint64_t coff = P.contig_off[ref_id], clen = P.contig_len[ref_id];
+      const uint8_t* CG = R + 32 + l_name;
+      uint32_t ck = 0, cq = 0;
+      uint64_t crp = (uint64_t)(int64_t)pos;
+      auto ref_at = [&](uint32_t i) -> uint32_t {
+        while (ck < n_cig) {
+          const uint32_t op = bam::rd32(CG + 4 * ck), t = op & 15, n = op >> 4;
+          const bool mm = t == 0 || t == 7 || t == 8;
+          if (mm || t == 1 || t == 4) {
+            if (i - cq < n) {
+              if (!mm) return 0;
+              const uint64_t p = crp + (i - cq);
+              if (p >= clen) return 0;
+              const uint32_t c = P.genome[coff + p];
+              return (c >= 'a' && c <= 'z') ? c - 32 : c;
+            }
+            cq += n;
+            if (mm) crp += n;
+          } else if (t == 2 || t == 3) crp += n;
+          ck++;
+        }
+        return 0;
+      };
+      // the pair (k, k+1) is a reference CpG whose strands call the methylation differently (:1197-1224)
+      auto discordant = [&](uint32_t k, uint32_t rk, uint32_t rk1) {
+        if (rk != 'C' || rk1 != 'G') return false;
+        const uint32_t tu = ev(au, k), tc = ev(at, k), qu = ev(bu, k + 1), qc = ev(bt, k + 1);
+        if (tu + tc == 0 || qu + qc == 0) return false;
+        return (tu > tc) != (qu > qc);
+      };
+      const bool taps = P.o.methylation_mode == FGX_METHYLATION_TAPS;
+      uint64_t num = 0, evi = 0;
+      for (uint32_t j = lane; j < n_pairs; j += 64) {
+        const uint32_t i0 = 2 * j;
+        const uint32_t rm = i0 > 0 ? ref_at(i0 - 1) : 0u, r0 = ref_at(i0), r1 = i0 + 1 < l_seq ? ref_at(i0 + 1) : 0u, r2 = i0 + 2 < l_seq ? ref_at(i0 + 2) : 0u;
+        if (strand) {
+          const bool dm = i0 > 0 && discordant(i0 - 1, rm, r0), d0 = i0 + 1 < l_seq && discordant(i0, r0, r1), d1 = i0 + 2 < l_seq && discordant(i0 + 1, r1, r2);
+          const bool mk[2] = {dm || d0, i0 + 1 < l_seq && (d0 || d1)};
+          if (mk[0] || mk[1]) {
+            const uint8_t b = g[seq_off + j];
+            uint8_t nb = b;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+              if (!mk[h] || (h == 0 ? (b >> 4) : (b & 0xF)) == 0xF) continue;
+              n_masked++; n_nocall++; nb |= h == 0 ? 0xF0 : 0x0F; g[qual_off + i0 + h] = 2;
+            }
+            if (nb != b) g[seq_off + j] = nb;
+          }
+        }
+        if (conv) {
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            const uint32_t i = i0 + h;
+            if (i >= l_seq) break;
+            const uint32_t ri = h == 0 ? r0 : r1, rn = h == 0 ? r1 : r2;           // (rn is None past the read: `i + 1 < len` of :1313)
+            if (ri != 'C' || rn == 'G') continue;
+            const uint32_t u = ev(cu, i), t = ev(ct, i);
+            if (u + t > 0) { num += taps ? u : t; evi += u + t; }
+          }
+        }
+      }
+      if (conv) {
+        const uint64_t num_t = wave_sum(num), evi_t = wave_sum(evi);
+        if (evi_t > 0 && !((double)num_t / (double)evi_t >= P.o.min_conversion_fraction)) conv_ok = false;
+      }
+    }
+  }
   const uint64_t masked_total = wave_sum(n_masked), nocall_total = wave_sum(n_nocall), qsum_total = wave_sum(qsum);
 
   // ---- read-level filters (filter_read / filter_duplex_read, check_no_call_and_quality) ----
@@ -352,6 +456,7 @@ __device__ __forceinline__ void filter_body(const FilterParams& P, const uint32_
     if (P.o.max_no_call_fraction >= 1.0) ok = (double)nocall_total <= P.o.max_no_call_fraction;
     else ok = (l_seq > 0 ? (double)nocall_total / (double)l_seq : 0.0) <= P.o.max_no_call_fraction;
   }
+  if (!conv_ok) ok = false;
   if (lane == 0) { P.pass[r] = ok ? 1 : 0; P.masked[r] = (uint32_t)masked_total; }
   FPH(4)
 }
@@ -359,6 +464,7 @@ __device__ __forceinline__ void filter_body(const FilterParams& P, const uint32_
 #ifndef FGX_FILTER_OCC
 #define FGX_FILTER_OCC 8
 #endif
+template <int METH>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FGX_FILTER_OCC, FGX_FILTER_OCC))) void k_filter_records(const FilterParams P) {
   extern __shared__ __align__(16) uint8_t lds_raw[];
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -388,9 +494,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FGX_FILTER_
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    filter_body(P, r, lane, g, slice + shift, true, len FPH_PASS);
+    filter_body<METH>(P, r, lane, g, slice + shift, true, len FPH_PASS);
   } else {
-    filter_body(P, r, lane, g, g, false, len FPH_PASS);      // beyond the slice: read from HBM
+    filter_body<METH>(P, r, lane, g, g, false, len FPH_PASS);      // beyond the slice: read from HBM
   }
 }
 
@@ -608,7 +714,22 @@ int filter_records_device(fgx_caller* c, FilterBuffers& B, const fgx_filter_opti
   }
   P.pass = B.pass.as<uint8_t>(); P.masked = B.masked.as<uint32_t>(); P.error = d_err; P.lds_slice = slice;
   const dim3 block(256), grid_w((n + 3) / 4), grid_t((n + 255) / 256);
-  hipLaunchKernelGGL(k_filter_records, grid_w, block, (size_t)slice * 4, s, P);
+  // --ref: the contig table next to the genome of fgx_set_reference (the reference-dependent methylation filters and the NM / UQ / MD kernels)
+  const bool regen = o->regenerate_alignment_tags != 0;
+  const GenomeRef* gr = regen ? c->genome.get() : nullptr;
+  const uint32_t n_ref = gr ? (uint32_t)gr->off.size() : 0u;
+  if (regen) {
+    B.aln_contigs.reserve((size_t)(n_ref + 1) * 16 + 64);
+    if (n_ref) {
+      hip_check(hipMemcpyAsync(B.aln_contigs.p, gr->off.data(), (size_t)n_ref * 8, hipMemcpyHostToDevice, s), "H2D contig offsets");
+      hip_check(hipMemcpyAsync(B.aln_contigs.as<uint64_t>() + n_ref, gr->len.data(), (size_t)n_ref * 8, hipMemcpyHostToDevice, s), "H2D contig lengths");
+    }
+    P.genome = gr ? (const uint8_t*)gr->d_genome.p : nullptr; P.contig_off = B.aln_contigs.as<uint64_t>(); P.contig_len = B.aln_contigs.as<uint64_t>() + n_ref; P.n_ref = n_ref;
+  }
+  if (o->has_min_methylation_depth || o->require_strand_methylation_agreement || o->has_min_conversion_fraction)
+    hipLaunchKernelGGL(k_filter_records<1>, grid_w, block, (size_t)slice * 4, s, P);
+  else
+    hipLaunchKernelGGL(k_filter_records<0>, grid_w, block, (size_t)slice * 4, s, P);
 
   uint32_t n_tmpl = n;
   const uint32_t* d_first = nullptr;
@@ -626,17 +747,9 @@ int filter_records_device(fgx_caller* c, FilterBuffers& B, const fgx_filter_opti
     d_first = B.first.as<uint32_t>();
   }
   // --ref: the edited records' lengths (every record: the reference edits before it decides)
-  const bool regen = o->regenerate_alignment_tags != 0;
   AlnParams A{};
   if (regen) {
     B.aln_len.reserve((size_t)n * 4 + 64);
-    const GenomeRef* gr = c->genome.get();
-    const uint32_t n_ref = gr ? (uint32_t)gr->off.size() : 0u;
-    B.aln_contigs.reserve((size_t)(n_ref + 1) * 16 + 64);
-    if (n_ref) {
-      hip_check(hipMemcpyAsync(B.aln_contigs.p, gr->off.data(), (size_t)n_ref * 8, hipMemcpyHostToDevice, s), "H2D contig offsets");
-      hip_check(hipMemcpyAsync(B.aln_contigs.as<uint64_t>() + n_ref, gr->len.data(), (size_t)n_ref * 8, hipMemcpyHostToDevice, s), "H2D contig lengths");
-    }
     A.blob = d_blob; A.blob_len = blob_len; A.rec_off = d_rec_off; A.rec_len = d_rec_len; A.n_rec = n;
     A.genome = gr ? (const uint8_t*)gr->d_genome.p : nullptr; A.contig_off = B.aln_contigs.as<uint64_t>(); A.contig_len = B.aln_contigs.as<uint64_t>() + n_ref; A.n_ref = n_ref;
     A.new_len = B.aln_len.as<uint32_t>(); A.error = d_err;

@@ -138,7 +138,9 @@ class ConsensusFilter:
     `regenerate_alignment_tags_raw` does (crates/fgumi-sam/src/alignment_tags.rs:259-433)."""
 
     def __init__(self, config: FilterConfig, filter_by_template: bool = True, require_single_strand_agreement: bool = False,
-                 reverse_per_base_tags: bool = False, track_rejects: bool = False, device: int = -1, handle=None):
+                 reverse_per_base_tags: bool = False, track_rejects: bool = False, device: int = -1, handle=None,
+                 min_methylation_depth: Optional[Sequence[int]] = None, require_strand_methylation_agreement: bool = False,
+                 min_conversion_fraction: Optional[float] = None, methylation_mode: Optional[str] = None):
         self.config = config
         o = FilterOptions()
         lib.fgx_filter_options_default(C.byref(o))
@@ -149,6 +151,23 @@ class ConsensusFilter:
         o.max_no_call_fraction = config.max_no_call_fraction
         o.require_single_strand_agreement, o.reverse_per_base_tags = int(require_single_strand_agreement), int(reverse_per_base_tags)
         o.filter_by_template, o.track_rejects = int(filter_by_template), int(track_rejects)
+        # the methylation filters (--min-methylation-depth 1-3 values, --require-strand-methylation-agreement, --min-conversion-fraction with
+        # --methylation-mode em-seq|taps: src/lib/commands/filter.rs:181-206; the last two need set_reference, checked by the library at the call)
+        if min_methylation_depth is not None:
+            d = list(min_methylation_depth) if isinstance(min_methylation_depth, (list, tuple)) else [int(min_methylation_depth)]
+            if not 1 <= len(d) <= 3:
+                raise ValueError(f"--min-methylation-depth must have 1-3 values, got {len(d)}")
+            d = (d + [d[-1]] * 3)[:3]
+            o.has_min_methylation_depth = 1
+            o.min_methylation_depth[:] = d
+        o.require_strand_methylation_agreement = int(require_strand_methylation_agreement)
+        if min_conversion_fraction is not None:
+            o.has_min_conversion_fraction, o.min_conversion_fraction = 1, float(min_conversion_fraction)
+        if methylation_mode is not None:
+            modes = {"disabled": 0, "em-seq": 1, "emseq": 1, "taps": 2}
+            if str(methylation_mode).lower() not in modes:
+                raise ValueError(f"methylation_mode must be 'em-seq' or 'taps', got {methylation_mode!r}")
+            o.methylation_mode = modes[str(methylation_mode).lower()]
         self._o = o
         self._own = handle is None
         if handle is None:

@@ -323,6 +323,14 @@ typedef struct fgx_filter_options {
                                                          recomputed after the masking against the reference handed over with fgx_set_reference (contig i of the
                                                          BAM header = seqs[i]); on unmapped records the three tags are removed (regenerate_alignment_tags_raw,
                                                          crates/fgumi-sam/src/alignment_tags.rs:259-433).  0: a mapped record is the reference's fatal error */
+  /* the methylation (EM-Seq / TAPs) filters (src/lib/commands/filter.rs:181-206, 833-937; crates/fgumi-consensus/src/filter.rs:925-1340) */
+  uint8_t  has_min_methylation_depth;                 /* --min-methylation-depth given: a base whose cu+ct (duplex: also au+at, bu+bt) is below its threshold is masked */
+  uint8_t  require_strand_methylation_agreement;      /* duplex records: both bases of a reference CpG are masked when the AB strand (au/at at the C) and the BA strand
+                                                         (bu/bt at the G) call the methylation differently; needs the reference (regenerate_alignment_tags) */
+  uint8_t  has_min_conversion_fraction;               /* --min-conversion-fraction given (needs the reference and methylation_mode) */
+  uint8_t  methylation_mode;                          /* FGX_METHYLATION_*: EM-Seq counts ct, TAPs cu at non-CpG reference Cs; DISABLED = the check passes */
+  uint32_t min_methylation_depth[3];                  /* [duplex, AB, BA], expanded like min_reads */
+  double   min_conversion_fraction;
 } fgx_filter_options;
 void fgx_filter_options_default(fgx_filter_options* o);   /* min_reads {1,1,1}; everything else the CLI defaults */
 

@@ -332,6 +332,38 @@ int orc_regenerate_alignment_tags(const uint8_t* rec, uint32_t len, uint8_t* out
   memcpy(out, v.data(), v.size());
   return r ? 1 : 0;
 }
+// the methylation filters alone (filter.rs:925-1340), for replaying the reference's unit tests; the reference of orc_set_reference
+int64_t orc_filter_mask_methylation_depth(uint8_t* rec, uint32_t len, int duplex, const uint32_t* thr3) {
+  try {
+    auto t = orc_filter::methylation_tags_from_record(rec, len);
+    return (int64_t)(duplex ? orc_filter::mask_methylation_depth_duplex(rec, len, thr3, t) : orc_filter::mask_methylation_depth_simplex(rec, len, thr3[0], t));
+  } catch (const OracleError& e) { g_err = e.what; return -1; }
+}
+// out[i] = upper-cased reference base of query position i or -1; returns 1 (a map; *n = l_seq) or 0 (None)
+int orc_filter_resolve_ref_bases(const uint8_t* rec, uint32_t len, int16_t* out, uint32_t cap, uint32_t* n) {
+  static const Reference no_contigs;
+  std::vector<int16_t> m;
+  if (!orc_filter::resolve_ref_bases(rec, len, g_reference ? *g_reference : no_contigs, m)) { *n = 0; return 0; }
+  *n = (uint32_t)m.size();
+  for (size_t i = 0; i < m.size() && i < cap; i++) out[i] = m[i];
+  return 1;
+}
+int64_t orc_filter_mask_strand_methylation_agreement(uint8_t* rec, uint32_t len) {
+  static const Reference no_contigs;
+  try {
+    auto t = orc_filter::methylation_tags_from_record(rec, len);
+    std::vector<int16_t> m;
+    bool has = orc_filter::resolve_ref_bases(rec, len, g_reference ? *g_reference : no_contigs, m);
+    return (int64_t)orc_filter::mask_strand_methylation_agreement(rec, len, has ? &m : nullptr, t);
+  } catch (const OracleError& e) { g_err = e.what; return -1; }
+}
+int orc_filter_check_conversion_fraction(const uint8_t* rec, uint32_t len, double min_fraction, int mode) {
+  static const Reference no_contigs;
+  auto t = orc_filter::methylation_tags_from_record(rec, len);
+  std::vector<int16_t> m;
+  bool has = orc_filter::resolve_ref_bases(rec, len, g_reference ? *g_reference : no_contigs, m);
+  return orc_filter::check_conversion_fraction(rec, len, min_fraction, has ? &m : nullptr, t, mode) ? 1 : 0;
+}
 int orc_filter_is_duplex(const uint8_t* rec, uint32_t len) { return orc_filter::is_duplex_consensus(RecView(rec, len).aux()); }
 int orc_filter_process_record(const fgx_filter_options* o, uint8_t* rec, uint32_t len, uint64_t* masked, int* pass) {
   bool p = false;

@@ -381,7 +381,117 @@ inline bool regenerate_alignment_tags_raw(Bytes& rec, const Reference& ref) {
   return true;
 }
 
-// filter.rs (command) :762-940; the methylation filters off.  `ref` (may be null) = --ref: mapped reads are accepted and NM / UQ / MD are
+// ---- methylation (EM-Seq / TAPs) filters (crates/fgumi-consensus/src/filter.rs:925-1340) ------------------------------------------
+// MethylationTags::from_record :447-484: the six per-base count arrays copied out of the record (the record is edited afterwards)
+struct MethTag { std::vector<uint16_t> v; bool some = false; uint16_t at(size_t i) const { return (some && i < v.size()) ? v[i] : (uint16_t)0; } };
+struct MethTags { MethTag cu, ct, au, at, bu, bt; };
+inline MethTags methylation_tags_from_record(const uint8_t* rec, size_t rec_len) {
+  size_t a = rec_len;
+  if (rec_len >= 32) {
+    RecView v(rec, rec_len);
+    size_t off = 32 + (size_t)v.l_read_name() + 4 * (size_t)v.n_cigar_op() + ((size_t)v.l_seq() + 1) / 2 + (size_t)v.l_seq();
+    if (off <= rec_len) a = off;
+  }
+  Slice aux{rec + a, rec_len - a, true};
+  auto get = [&](const char* tag) {
+    MethTag t;
+    ArrayRef r = find_array_tag(aux, tag);
+    if (r.some) { t.some = true; t.v.resize(r.count); for (size_t i = 0; i < r.count; i++) t.v[i] = elem_u16(r, i); }
+    return t;
+  };
+  MethTags m;
+  m.cu = get("cu"); m.ct = get("ct"); m.au = get("au"); m.at = get("at"); m.bu = get("bu"); m.bt = get("bt");
+  return m;
+}
+// mask_methylation_depth_simplex_raw_with_tags :973-1004
+inline uint64_t mask_methylation_depth_simplex(uint8_t* rec, size_t rec_len, uint64_t min_depth, const MethTags& t) {
+  if (rec_len < 32) throw OracleError{"BAM record too short"};
+  RecView v(rec, rec_len);
+  size_t seq_off = v.seq_offset(), qual_off = v.qual_offset(), len = v.l_seq();
+  if (!t.cu.some && !t.ct.some) return 0;
+  uint64_t masked = 0;
+  for (size_t i = 0; i < len; i++) {
+    if (is_n(rec, seq_off, i)) continue;
+    uint64_t total = (uint64_t)t.cu.at(i) + t.ct.at(i);
+    if (total < min_depth) { masked++; mask_base(rec, seq_off, i); rec[qual_off + i] = 2; }
+  }
+  return masked;
+}
+// mask_methylation_depth_duplex_raw_with_tags :1026-1066 (thr = [duplex, AB, BA])
+inline uint64_t mask_methylation_depth_duplex(uint8_t* rec, size_t rec_len, const uint32_t thr[3], const MethTags& t) {
+  if (rec_len < 32) throw OracleError{"BAM record too short"};
+  RecView v(rec, rec_len);
+  size_t seq_off = v.seq_offset(), qual_off = v.qual_offset(), len = v.l_seq();
+  if (!t.cu.some && !t.ct.some) return 0;
+  uint64_t masked = 0;
+  for (size_t i = 0; i < len; i++) {
+    if (is_n(rec, seq_off, i)) continue;
+    uint64_t cc = (uint64_t)t.cu.at(i) + t.ct.at(i), ab = (uint64_t)t.au.at(i) + t.at.at(i), ba = (uint64_t)t.bu.at(i) + t.bt.at(i);
+    if (cc < thr[0] || ab < thr[1] || ba < thr[2]) { masked++; mask_base(rec, seq_off, i); rec[qual_off + i] = 2; }
+  }
+  return masked;
+}
+// resolve_ref_bases_for_record :1072-1133: per query position the upper-cased reference base, -1 for None; false = the whole map is None.
+// (`ref_names.get(tid)` of a tid beyond the header and the u64 arithmetic of a negative pos are not restated: with a reference present
+// regenerate_alignment_tags_raw refuses both records right after — callers of the filters never see their output.)
+inline bool resolve_ref_bases(const uint8_t* rec, size_t rec_len, const Reference& ref, std::vector<int16_t>& out) {
+  RecView v(rec, rec_len);
+  out.clear();
+  if (v.flags() & flags::UNMAPPED) return false;
+  int32_t tid = v.ref_id();
+  if (tid < 0 || (size_t)tid >= ref.seqs.size()) return false;
+  const Bytes& contig = ref.seqs[(size_t)tid];
+  uint64_t ref_pos = (uint64_t)(int64_t)v.pos();
+  size_t len = v.l_seq(), n_ops = v.n_cigar_op(), cig = 32 + (size_t)v.l_read_name();
+  for (size_t k = 0; k < n_ops && out.size() < len; k++) {
+    uint32_t op = rd32(rec + cig + 4 * k), t = op & 0xF; size_t n = op >> 4;
+    if (t == 0 || t == 7 || t == 8) {
+      for (size_t i = 0; i < n && out.size() < len; i++) out.push_back(ref_pos + i < contig.size() ? (int16_t)orc::upper(contig[(size_t)(ref_pos + i)]) : (int16_t)-1);
+      ref_pos += n;
+    } else if (t == 1 || t == 4) {
+      for (size_t i = 0; i < n && out.size() < len; i++) out.push_back(-1);
+    } else if (t == 2 || t == 3) ref_pos += n;
+  }
+  out.resize(len, -1);
+  return true;
+}
+// mask_strand_methylation_agreement_raw_with_ref_bases_and_tags :1166-1236 (`map` null = None)
+inline uint64_t mask_strand_methylation_agreement(uint8_t* rec, size_t rec_len, const std::vector<int16_t>* map, const MethTags& t) {
+  if (rec_len < 32) throw OracleError{"BAM record too short"};
+  if (!map) return 0;
+  RecView v(rec, rec_len);
+  size_t seq_off = v.seq_offset(), qual_off = v.qual_offset(), len = v.l_seq();
+  if (!t.au.some && !t.bu.some) return 0;
+  std::vector<uint8_t> should(len, 0);
+  for (size_t i = 0; i + 1 < len; i++) {
+    if (!(i + 1 < map->size() && (*map)[i] == 'C' && (*map)[i + 1] == 'G')) continue;
+    uint32_t top_u = t.au.at(i), top_c = t.at.at(i), bot_u = t.bu.at(i + 1), bot_c = t.bt.at(i + 1);
+    if (top_u + top_c == 0 || bot_u + bot_c == 0) continue;
+    if ((top_u > top_c) != (bot_u > bot_c)) should[i] = should[i + 1] = 1;
+  }
+  uint64_t masked = 0;
+  for (size_t i = 0; i < len; i++)
+    if (should[i] && !is_n(rec, seq_off, i)) { masked++; mask_base(rec, seq_off, i); rec[qual_off + i] = 2; }
+  return masked;
+}
+// check_conversion_fraction_raw_with_ref_bases_and_tags :1279-1340 (mode: FGX_METHYLATION_*)
+inline bool check_conversion_fraction(const uint8_t* rec, size_t rec_len, double min_fraction, const std::vector<int16_t>* map, const MethTags& t, int mode) {
+  if (mode == FGX_METHYLATION_DISABLED) return true;
+  if (!map) return true;
+  size_t len = RecView(rec, rec_len).l_seq();
+  if (!t.cu.some && !t.ct.some) return true;
+  uint64_t num = 0, evi = 0;
+  for (size_t i = 0; i < len; i++) {
+    if (!(i < map->size() && (*map)[i] == 'C')) continue;
+    if (i + 1 < len && i + 1 < map->size() && (*map)[i + 1] == 'G') continue;
+    uint64_t cu = t.cu.at(i), ct = t.ct.at(i), e = cu + ct;
+    if (e > 0) { num += mode == FGX_METHYLATION_TAPS ? cu : ct; evi += e; }
+  }
+  if (evi == 0) return true;
+  return (double)num / (double)evi >= min_fraction;
+}
+
+// filter.rs (command) :762-940.  `ref` (may be null) = --ref: mapped reads are accepted and NM / UQ / MD are
 // regenerated after the masking (the record may change its length: `rec` is a vector of its own).
 inline void process_record_raw(Bytes& recv, const fgx_filter_options* o, const Reference* ref, uint64_t& masked, bool& pass) {
   uint8_t* rec = recv.data();
@@ -402,10 +512,21 @@ inline void process_record_raw(Bytes& recv, const fgx_filter_options* o, const R
   bool duplex = is_duplex_consensus(v.aux());
   masked = duplex ? mask_duplex_bases(rec, rec_len, cc, ab, ba, o->has_min_base_quality, o->min_base_quality, o->require_single_strand_agreement)
                   : mask_bases(rec, rec_len, cc, o->has_min_base_quality, o->min_base_quality);
+  // the methylation filters :833-886
+  const bool strand = o->require_strand_methylation_agreement && duplex, conv = o->has_min_conversion_fraction != 0;
+  MethTags mt;
+  if (o->has_min_methylation_depth || strand || conv) mt = methylation_tags_from_record(rec, rec_len);
+  if (o->has_min_methylation_depth)
+    masked += duplex ? mask_methylation_depth_duplex(rec, rec_len, o->min_methylation_depth, mt) : mask_methylation_depth_simplex(rec, rec_len, o->min_methylation_depth[0], mt);
+  std::vector<int16_t> map;
+  bool has_map = false;
+  if ((strand || conv) && ref) has_map = resolve_ref_bases(rec, rec_len, *ref, map);
+  if (strand) masked += mask_strand_methylation_agreement(rec, rec_len, has_map ? &map : nullptr, mt);
   if (ref) regenerate_alignment_tags_raw(recv, *ref);       // :888-890 (the vector may have been reallocated / resized)
   RecView v2(recv.data(), recv.size());
   Result r = duplex ? filter_duplex_read(v2.aux(), cc, ab, ba) : filter_read(v2.aux(), cc);
   pass = r == PASS && check_no_call_and_quality(recv.data(), recv.size(), pre_mask_mean, o->has_min_mean_base_quality, o->min_mean_base_quality, o->max_no_call_fraction);
+  if (pass && conv && !check_conversion_fraction(recv.data(), recv.size(), o->min_conversion_fraction, has_map ? &map : nullptr, mt, o->methylation_mode)) pass = false;   // :924-937
 }
 // (the in-place form of the round-3 tests: no reference)
 inline void process_record_raw(uint8_t* rec, size_t rec_len, const fgx_filter_options* o, uint64_t& masked, bool& pass) {

@@ -166,7 +166,9 @@ class FilterOptions(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("min_reads", C.c_uint32 * 3), ("max_read_error_rate", C.c_double * 3), ("max_base_error_rate", C.c_double * 3),
                 ("min_mean_base_quality", C.c_double), ("max_no_call_fraction", C.c_double), ("has_min_base_quality", C.c_uint8), ("min_base_quality", C.c_uint8),
                 ("has_min_mean_base_quality", C.c_uint8), ("require_single_strand_agreement", C.c_uint8), ("reverse_per_base_tags", C.c_uint8),
-                ("filter_by_template", C.c_uint8), ("track_rejects", C.c_uint8), ("regenerate_alignment_tags", C.c_uint8)]
+                ("filter_by_template", C.c_uint8), ("track_rejects", C.c_uint8), ("regenerate_alignment_tags", C.c_uint8),
+                ("has_min_methylation_depth", C.c_uint8), ("require_strand_methylation_agreement", C.c_uint8), ("has_min_conversion_fraction", C.c_uint8),
+                ("methylation_mode", C.c_uint8), ("min_methylation_depth", C.c_uint32 * 3), ("min_conversion_fraction", C.c_double)]
 
 
 def _three(v):
@@ -176,7 +178,8 @@ def _three(v):
 
 def filter_options(min_reads=1, max_read_error_rate=0.025, max_base_error_rate=0.1, min_base_quality=None, min_mean_base_quality=None,
                    max_no_call_fraction=0.2, require_single_strand_agreement=False, reverse_per_base_tags=False, filter_by_template=True,
-                   track_rejects=False, regenerate_alignment_tags=False):
+                   track_rejects=False, regenerate_alignment_tags=False, min_methylation_depth=None, require_strand_methylation_agreement=False,
+                   min_conversion_fraction=None, methylation_mode=0):
     o = FilterOptions()
     o.struct_size = C.sizeof(FilterOptions)
     o.min_reads[:] = _three(min_reads)
@@ -188,6 +191,12 @@ def filter_options(min_reads=1, max_read_error_rate=0.025, max_base_error_rate=0
     o.require_single_strand_agreement, o.reverse_per_base_tags = int(require_single_strand_agreement), int(reverse_per_base_tags)
     o.filter_by_template, o.track_rejects = int(filter_by_template), int(track_rejects)
     o.regenerate_alignment_tags = int(regenerate_alignment_tags)
+    o.has_min_methylation_depth = int(min_methylation_depth is not None)
+    if min_methylation_depth is not None:
+        o.min_methylation_depth[:] = _three(min_methylation_depth)      # MethylationDepthThresholds::from_values (filter.rs:944-954)
+    o.require_strand_methylation_agreement = int(require_strand_methylation_agreement)
+    o.has_min_conversion_fraction, o.min_conversion_fraction = int(min_conversion_fraction is not None), float(min_conversion_fraction or 0.0)
+    o.methylation_mode = int(methylation_mode)                           # FGX_METHYLATION_*: 0 disabled, 1 em-seq, 2 taps
     return o
 
 

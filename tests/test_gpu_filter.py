@@ -337,3 +337,131 @@ def test_filter_with_a_reference_regenerates_alignment_tags(kw):
     with pytest.raises(RuntimeError, match="leaves its reference"):
         f.filter_stream(blob, off, ln)
     f.close()
+
+
+# ---- the methylation (EM-Seq / TAPs) filters (src/lib/commands/filter.rs:181-206, 833-937; crates/fgumi-consensus/src/filter.rs:925-1340) -----------
+def _methylation_records(rng, contigs, n_templates):
+    """Mapped simplex and duplex consensus records with the methylation count arrays of the methylation-aware callers (cu ct, duplex: au at bu bt)
+    in several encodings and with gaps (a tag missing, an array shorter than the read), CpG-rich contigs, strands that disagree at some CpGs."""
+    def arr(tag, v):
+        ty = rng.choice("sSC")
+        v = [min(x, 255) for x in v] if ty == "C" else v
+        return (tag, "raw", b"B" + ty.encode() + struct.pack("<I", len(v)) + struct.pack(f"<{len(v)}{'h' if ty == 's' else 'H' if ty == 'S' else 'B'}", *v))
+    recs = []
+    for t in range(n_templates):
+        L = rng.choice([9, 20, 45, 80, 151])
+        rid = rng.randrange(len(contigs))
+        contig = contigs[rid]
+        duplex = rng.random() < 0.5
+        for mate in (1, 2):
+            lead, trail = rng.choice([0, 0, 3]), rng.choice([0, 0, 4])
+            core = L - lead - trail
+            a = max(1, core // 2 - 1)
+            pick = rng.random()
+            if pick < 0.2 and core > 12:
+                ops, span = f"{lead}S" * (lead > 0) + f"{a}M2I{core - a - 2}M" + f"{trail}S" * (trail > 0), core - 2
+            elif pick < 0.4 and core > 12:
+                ops, span = f"{lead}S" * (lead > 0) + f"{a}M3D{core - a}M" + f"{trail}S" * (trail > 0), core + 3
+            elif pick < 0.5 and core > 12:
+                ops, span = f"{lead}S" * (lead > 0) + f"{a}M7N{core - a}M" + f"{trail}S" * (trail > 0), core + 7
+            else:
+                ops, span = f"{lead}S" * (lead > 0) + f"{core}M" + f"{trail}S" * (trail > 0), core
+            start = rng.randrange(0, len(contig) - span - 1)
+            seq = "".join((chr(contig[(start + i) % len(contig)]).upper() if rng.random() < 0.93 else rng.choice("ACGTN")) for i in range(L))
+            q = [rng.choice([5, 25]) if rng.random() < 0.05 else 40 for _ in range(L)]
+            unmapped = rng.random() < 0.05
+            flag = 0x1 | (0x40 if mate == 1 else 0x80) | (0x10 if (mate == 2 and not unmapped) else 0) | (0x4 if unmapped else 0)
+            cd = [rng.choice([1, 2]) if rng.random() < 0.04 else 8 for _ in range(L)]
+            ce = [0] * L
+            tags = [("RG", "Z", "A"), ("cD", "i", max(cd)), ("cM", "i", min(cd)), ("cE", "f", 0.0), arr("cd", cd), arr("ce", ce), ("MI", "Z", str(t))]
+            if duplex:
+                tags += [("aD", "i", 4), ("bD", "i", 4), ("aE", "f", 0.0), ("bE", "f", 0.0), arr("ad", [4] * L), arr("bd", [4] * L), arr("ae", ce), arr("be", ce)]
+            # counts: a converted (methylation-insensitive) library converts most non-CpG Cs; one template in five is badly converted
+            bad = rng.random() < 0.2
+            def counts(total):
+                u = [0] * L
+                c = [0] * L
+                for i in range(L):
+                    n = rng.choice([0, 1, 2]) if rng.random() < 0.08 else total
+                    k = sum(rng.random() < (0.6 if bad else 0.05) for _ in range(n)) if rng.random() < 0.8 else rng.choice([0, n])
+                    u[i], c[i] = k, n - k
+                return u, c
+            au, at = counts(4)
+            bu, bt = counts(4)
+            cu, ct = [x + y for x, y in zip(au, bu)], [x + y for x, y in zip(at, bt)]
+            short = rng.random() < 0.1
+            meth = [arr("cu", cu[:L - 2] if short else cu), arr("ct", ct)]
+            if duplex:
+                meth += [arr("au", au), arr("at", at), arr("bu", bu), arr("bt", bt[:max(0, L - 3)] if short else bt)]
+            for k in range(len(meth) - 1, -1, -1):
+                if rng.random() < 0.06:
+                    del meth[k]
+            if rng.random() < 0.05:
+                meth = []
+            for m in meth:
+                tags.insert(rng.randrange(len(tags) + 1), m)
+            if rng.random() < 0.5:
+                tags.insert(rng.randrange(len(tags) + 1), ("NM", "raw", b"c\x02"))
+            recs.append(bamutil.make_record(f"tmpl{t:05d}", seq, q, flag=flag, ref_id=-1 if unmapped else rid, pos=-1 if unmapped else start, cigar=None if unmapped else ops, tags=tags))
+    return recs
+
+
+METHYLATION_OPTION_SETS = [
+    dict(min_reads=[1], min_methylation_depth=[6], track_rejects=True),
+    dict(min_reads=[1], min_methylation_depth=[7, 4, 3], max_no_call_fraction=0.5, filter_by_template=False, track_rejects=True),
+    dict(min_reads=[1], require_strand_methylation_agreement=True, track_rejects=True, max_no_call_fraction=0.4),
+    dict(min_reads=[1], min_conversion_fraction=0.8, methylation_mode="em-seq", track_rejects=True, max_no_call_fraction=1000.0),
+    dict(min_reads=[1], min_conversion_fraction=0.3, methylation_mode="taps", track_rejects=True, filter_by_template=False, max_no_call_fraction=1000.0),
+    dict(min_reads=[3], min_base_quality=20, min_methylation_depth=[5, 2], require_strand_methylation_agreement=True, min_conversion_fraction=0.75,
+         methylation_mode="em-seq", reverse_per_base_tags=True, track_rejects=True, max_no_call_fraction=0.6),
+]
+
+
+@pytest.mark.parametrize("kw", METHYLATION_OPTION_SETS)
+def test_filter_methylation_filters(kw):
+    rng = random.Random(2024)
+    contigs = [bytes(rng.choice(b"ACGCGTacgN" if rng.random() < 0.9 else b"CG") for _ in range(n)) for n in (4000, 900)]
+    recs = _methylation_records(rng, contigs, 600)
+    blob, off, ln = tof.stream(recs)
+    okw = dict(kw)
+    okw["methylation_mode"] = {"em-seq": 1, "taps": 2, None: 0}[kw.get("methylation_mode")]
+    orc.set_reference(contigs)
+    try:
+        want = orc.filter_records(orc.filter_options(regenerate_alignment_tags=True, **okw), blob, off, ln)
+        plain = orc.filter_records(orc.filter_options(regenerate_alignment_tags=True, **{k: v for k, v in okw.items() if "methylation" not in k and "conversion" not in k}), blob, off, ln)
+    finally:
+        orc.set_reference(None)
+    assert (want["data"], want["masked"], want["passed"]) != (plain["data"], plain["masked"], plain["passed"])       # the filters under test do something here
+    f = ConsensusFilter(_cfg(kw), **_flags(kw), **{k: kw[k] for k in ("min_methylation_depth", "require_strand_methylation_agreement", "min_conversion_fraction", "methylation_mode") if k in kw})
+    f.set_reference({f"chr{i}": s for i, s in enumerate(contigs)}, [f"chr{i}" for i in range(len(contigs))])
+    got = f.filter_stream(blob, off, ln)
+    if got.data != want["data"]:
+        a, b = tof.bamutil_split(got.data), tof.bamutil_split(want["data"])
+        for i, (x, y) in enumerate(zip(a, b)):
+            if x != y:
+                raise AssertionError(f"kept record {i} differs:\n got {bamutil.parse(x)}\nwant {bamutil.parse(y)}")
+        raise AssertionError(f"kept count differs: {len(a)} vs {len(b)}")
+    assert got.rejects == want["rejects"]
+    assert (got.records_count, got.passed_count, got.bases_masked, got.rejected_count) == (want["records"], want["passed"], want["masked"], want["rejected"])
+    assert 0 < got.passed_count < got.records_count
+    f.close()
+
+
+def test_filter_methylation_option_checks():
+    """Filter::validate (src/lib/commands/filter.rs:1110-1154): the value order of --min-methylation-depth, the reference both reference-dependent
+    filters need, the mode the conversion fraction needs."""
+    blob, off, ln = tof.stream([tof.rec("ACGT", [30] * 4, cD=10, cE=0.0, cd=[10] * 4, ce=[0] * 4)])
+    for kw, msg in ((dict(min_methylation_depth=[2, 5]), "high to low"), (dict(min_methylation_depth=[5, 2, 3]), "high to low"),
+                    (dict(require_strand_methylation_agreement=True), "requires --ref"), (dict(min_conversion_fraction=0.5, methylation_mode="taps"), "requires --ref"),
+                    (dict(min_conversion_fraction=1.5, methylation_mode="taps"), "between 0.0 and 1.0")):
+        f = ConsensusFilter(FilterConfig.new([1]), **kw)
+        with pytest.raises(RuntimeError, match=msg):
+            f.filter_stream(blob, off, ln)
+        f.close()
+    f = ConsensusFilter(FilterConfig.new([1]), min_conversion_fraction=0.5)
+    f.set_reference({"chr0": b"ACGT"}, ["chr0"])
+    with pytest.raises(RuntimeError, match="--methylation-mode"):
+        f.filter_stream(blob, off, ln)
+    f.close()
+    with pytest.raises(ValueError, match="1-3 values"):
+        ConsensusFilter(FilterConfig.new([1]), min_methylation_depth=[4, 3, 2, 1])
