@@ -1230,6 +1230,11 @@ int fgx_balanced_shards(const uint64_t* weights, uint32_t n, uint32_t world, uin
 uint32_t fgx_debug_last_split_chunks(const fgx_caller* c) { return (c && c->fast) ? c->fast->fp.last_split_chunks : 0u; }
 // how the last device batch produced its records: 0 column scratch + k_emit, 1 written directly by the split pipeline, 2 directly + merge with the
 // records of the families that left it
+// families of the last device batch that went to the workgroup-per-family kernel because they have more than 64 records / that the split
+// pipeline handed down the k_simplex_wave2 chain
+uint32_t fgx_debug_last_big_families(const fgx_caller* c) { return (c && c->fast) ? c->fast->fp.last_big_families : 0u; }
+uint32_t fgx_debug_last_deep_families(const fgx_caller* c) { return (c && c->fast) ? c->fast->fp.last_deep_families : 0u; }
+uint32_t fgx_debug_last_routed(const fgx_caller* c) { return (c && c->fast) ? c->fast->fp.last_routed : 0u; }
 int fgx_debug_last_direct(const fgx_caller* c) { return (c && c->fast) ? c->fast->fp.last_direct : 0; }
 // 1: route everything through the general host path (parity tests of that path); 0: hybrid (default)
 void fgx_set_general_only(fgx_caller* c, int on) { if (c) c->general_only = on != 0; }

@@ -53,6 +53,10 @@ constexpr int N_LISTS = 1024;
 // 16-bit each (4-bit code in consensus orientation << 8 | quality), chains & 0xFF of them in file order (at most 16);
 // k_call_full accumulates them with the four-lane Kahan loop (base_builder.rs:836-868) and calls the column
 constexpr uint32_t FULL_ITEM_OBS = 0x80000000u;
+// A column of more than 16 observations (an end of up to 64 reads) takes ceil(m / 16) CONSECUTIVE items of one list: the head item as above
+// with m = chains & 0xFF, then continuation items — chains == FULL_ITEM_CONT, observations 16 .. in `ll` again — which k_call_full's own
+// threads skip.  (A family's items stay in one list when it holds such a column: k_split_cols pads a list's tail with continuation items.)
+constexpr uint32_t FULL_ITEM_CONT = 0x40000000u;
 
 // ---- split simplex pipeline (simplex_split.inc): k_split_parse leaves one SplitRec per record and one SplitFam per family;
 // k_split_cols (one wavefront per family) reads them instead of parsing, pairing and walking tags itself --------------------------
@@ -129,6 +133,7 @@ struct FastParams {
   const void* fw_image;            // k_family_wave: image of its LDS tables (FwLds, fastpath.hip)
   SplitRec* split_rec; SplitFam* split_fam; SplitOut* split_out;   // split simplex pipeline: k_split_parse → k_split_cols → k_split_finish
   uint32_t* route; uint32_t* n_route;         // k_split_cols: families it does not take → k_simplex_wave2
+  uint32_t* big; uint32_t* n_big;             // families of more than 64 records (no wavefront-per-family kernel takes them): straight to k_family's list (may be null)
   const void* s2_image;            // k_split_cols: image of its LDS tables (S2Lds, simplex_split.inc)
   const uint4* fam_desc;           // per family {first record offset lo, hi, bytes to the end of the last record (~0: none), records} (k_col_bound)
   uint64_t blob_len;               // records must end inside the blob (checked before the family's bytes are staged)
@@ -197,6 +202,11 @@ struct FastPath {
   DevBuf d_famdesc;                       // k_col_bound's family descriptors
   DevBuf d_fwimg;                         // FwLds image (k_family_wave)
   DevBuf d_split_rec, d_split_fam, d_split_out, d_route, d_s2img;   // split simplex pipeline
+  DevBuf d_big;                            // simplex families of more than 64 records: k_family's list, filled by the first kernel that sees them
+  uint32_t last_big_families = 0;          // ... in the last batch
+  uint32_t last_deep_families = 0;         // ... of which k_deep_parse + k_deep_cols (simplex_deep.inc) took
+  DevBuf d_deep_sizes, d_deep_row0, d_deep_rows, d_deep_fams, d_deep_out;
+  uint32_t last_routed = 0;                // families the split pipeline handed to the k_simplex_wave2 chain in the last batch
   DevBuf d_dir_size, d_dir_off, d_dir_base, d_slot_desc, d_slot_err, d_out2, d_scan_tmp2;   // direct records (simplex_split.inc, fastpath.h)
   bool direct_off = false;                // a batch whose predicted record sizes did not hold: this caller stays on the scratch path (diagnostics: last_direct)
   uint64_t dir_cap_min = 0;               // output room a batch asked for beyond the first estimate

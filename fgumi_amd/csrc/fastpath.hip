@@ -1105,7 +1105,12 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
   // does not fit this launch's LDS slice: the next launch (bigger slices, fewer waves per CU) picks it up; after the last one
   // simplex families go to the workgroup-per-family kernel, duplex / CODEC molecules to the general path
   auto to_retry = [&]() { if (!P.retry) { to_defer(); return; } if (lane == 0) { uint32_t k = atomicAdd(P.n_retry, 1u); P.retry[k] = g; } };
-  if (!bail && n > 64) { if (MODE == 0) to_retry(); else to_defer(); bail = true; }
+  if (!bail && n > 64) {
+    if (MODE == 0 && P.big) { if (lane == 0) { uint32_t k = atomicAdd(P.n_big, 1u); P.big[k] = g; } }   // k_family's, directly
+    else if (MODE == 0) to_retry();
+    else to_defer();
+    bail = true;
+  }
   // an empty group has no byte span (the minimum below would be ~0 and the staging loop would read the 16 bytes BEFORE the blob —
   // a fault when the blob starts an allocation): the general path emits its nothing
   if (!bail && n == 0) { to_defer(); bail = true; }
@@ -2368,21 +2373,25 @@ __global__ __launch_bounds__(256) void k_call_full(FullParams P) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= cnt) return;
   FullItem it = P.items[(size_t)list * P.cap + i];
+  if (it.chains == FULL_ITEM_CONT) return;                  // observations 16 .. of the column whose head item sits before it (or padding)
   if (it.chains & FULL_ITEM_OBS) {
     // a column that showed a second base (k_split_cols): its observations in file order, 16 bits each — the four-lane Kahan sum of
-    // ConsensusBaseBuilder::add (base_builder.rs:836-868), then the call
+    // ConsensusBaseBuilder::add (base_builder.rs:836-868), then the call.  More than 16 of them: the following items hold the rest.
     const uint32_t m = it.chains & 0xFF;
-    uint16_t ob16[16];
-    __builtin_memcpy(ob16, it.ll, 32);
     ColumnAcc acc;
     acc.reset();
     const ConsensusTables& TT = P.T->t;
+    for (uint32_t k0 = 0; k0 < m; k0 += 16) {
+      uint16_t ob16[16];
+      if (k0 == 0) __builtin_memcpy(ob16, it.ll, 32);
+      else __builtin_memcpy(ob16, P.items[(size_t)list * P.cap + i + (k0 >> 4)].ll, 32);
 #pragma unroll
-    for (uint32_t j = 0; j < 16; j++) {
-      if (j < m) {
-        const uint32_t o = ob16[j], q = o & 0xFF, code = (o >> 8) & 15;
-        const int bl = bam::code_to_lane((uint8_t)code);
-        if (bl != 255 && q >= P.min_input_bq) { const uint32_t qq = q < 93 ? q : 93; acc.add(bl, TT.correct[qq], TT.error_per_alt[qq]); }
+      for (uint32_t j = 0; j < 16; j++) {
+        if (k0 + j < m) {
+          const uint32_t o = ob16[j], q = o & 0xFF, code = (o >> 8) & 15;
+          const int bl = bam::code_to_lane((uint8_t)code);
+          if (bl != 255 && q >= P.min_input_bq) { const uint32_t qq = q < 93 ? q : 93; acc.add(bl, TT.correct[qq], TT.error_per_alt[qq]); }
+        }
       }
     }
     int bi;
@@ -3327,6 +3336,7 @@ __global__ __launch_bounds__(256) void k_emit_codec_fast(CodecEmitParams P) {
 #include "simplex_wave2.inc"
 #include "simplex_seg.inc"
 #include "simplex_split.inc"
+#include "simplex_deep.inc"
 
 // Upper bound on the consensus columns a batch can produce: a family yields at most three ends, each no
 // longer than its longest read, and l_seq <= (block_size - 33) * 2 / 3.
@@ -3339,7 +3349,7 @@ __global__ void k_col_bound(const uint32_t* __restrict__ grp_first, const uint32
   uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   {
     uint32_t mine = 0;
-    if (g < n_grp) { const uint32_t n = grp_first[g + 1] - grp_first[g]; mine = (grp_first[g + 1] >= grp_first[g] && n <= 32u) ? n : 0u; }
+    if (g < n_grp) { const uint32_t n = grp_first[g + 1] - grp_first[g]; mine = (grp_first[g + 1] >= grp_first[g] && n <= 64u) ? n : 0u; }
     const uint32_t tot = wave_sum(mine);
     if ((threadIdx.x & 63) == 0 && tot) atomicAdd(small_recs, (unsigned long long)tot);
   }
@@ -3375,7 +3385,7 @@ __global__ void k_reduce_stats(const unsigned long long* __restrict__ slots, uns
 void FastPath::release() {
   for (DevBuf* b : {&d_ends, &d_sizes, &d_offsets, &d_code, &d_qual, &d_depth, &d_err, &d_misc, &d_deferred, &d_out, &d_scan_tmp, &d_strings, &d_obs, &d_retry2,
                     &d_retry, &d_bound, &d_colbase, &d_statslots, &d_full_items, &d_full_count, &d_retry_old, &d_w2img, &d_famdesc, &d_fwimg,
-                    &d_split_rec, &d_split_fam, &d_split_out, &d_route, &d_s2img, &d_dir_size, &d_dir_off, &d_dir_base, &d_slot_desc, &d_slot_err, &d_out2, &d_scan_tmp2})
+                    &d_split_rec, &d_split_fam, &d_split_out, &d_route, &d_s2img, &d_dir_size, &d_dir_off, &d_dir_base, &d_slot_desc, &d_slot_err, &d_out2, &d_scan_tmp2, &d_big, &d_deep_sizes, &d_deep_row0, &d_deep_rows, &d_deep_fams, &d_deep_out})
     b->free_();
   for (int i = 0; i < 4; i++) if (ev[i]) { (void)hipEventDestroy(ev[i]); ev[i] = nullptr; }
   if (s2) {
@@ -3437,7 +3447,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
   // whose record kernel also leaves what k_col_bound would (column bound, byte-span descriptor).
   static const bool use_v2 = [] { const char* e = getenv("FGX_V2"); return !(e && e[0] == '0'); }();
   static const bool use_seg = [] { const char* e = getenv("FGX_SEG"); return !(e && e[0] == '0'); }();
-  static const bool use_split_env = [] { const char* e = getenv("FGX_SPLIT"); return !(e && e[0] == '0'); }();
+  const bool use_split_env = [] { const char* e = getenv("FGX_SPLIT"); return !(e && e[0] == '0'); }();   // (read per batch: tests switch it inside one process)
   uint32_t seg_bytes = 11776;   // 4 wavefronts x 11776 B + the static tables = 3 workgroups per CU
   if (const char* e = getenv("FGX_SEG_BYTES")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 4096 && v <= 32768) seg_bytes = v & ~63u; }
   const double mean_span = (double)blob_len / (double)n_grp + 48.0;   // mean bytes of a family + alignment / read-ahead slack
@@ -3457,12 +3467,12 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
   unsigned long long small_recs = 0;
   hip_check(hipMemcpyAsync(&small_recs, misc + 35, 8, hipMemcpyDeviceToHost, s), "D2H");
   hip_check(hipStreamSynchronize(s), "sync");
-  // The split pipeline is the faster head for families of moderate size (depth 8: 25.7 against 37 ms per 5 M families); on long-tail
-  // sizes — most reads in families of dozens of records, which the split pipeline only parses and hands on — the k_simplex_wave2 chain
-  // alone is (27.3 against 30.6 ms per 1 M families of 2 .. 50 pairs).  Split when at least 90 % of the reads sit in families of at
-  // most 32 records (FGX_SPLIT=0 / 2: never / always).
-  static const int split_mode = [] { const char* e = getenv("FGX_SPLIT"); return e ? atoi(e) : 1; }();
-  const bool use_split = simplex_v2 && use_split_env && !seg4 && (split_mode == 2 || (double)small_recs >= 0.9 * (double)n_rec);
+  // The split pipeline is the faster head for every family it keeps (depth 8: 25.7 against 37 ms per 5 M families) — since round 4 that is
+  // every family of up to 64 records in the common shape (an end of more than 16 reads sends its disagreeing columns to k_call_full as
+  // several items); larger families it only measures and hands to k_family.  Split when at least half of the reads sit in families of
+  // at most 64 records (FGX_SPLIT=0 / 2: never / always).
+  const int split_mode = [] { const char* e = getenv("FGX_SPLIT"); return e ? atoi(e) : 1; }();
+  const bool use_split = simplex_v2 && use_split_env && !seg4 && (split_mode == 2 || (double)small_recs >= 0.5 * (double)n_rec);
   // Direct records (fastpath.h): the split pipeline's column kernel writes the consensus records itself (FGX_DIRECT=1).  Byte-identical on
   // the GPU (tools/direct_check.py, tests/test_gpu_direct_records.py), but NOT the default: measured on 5 M depth-8 families the column kernel
   // pays for the emission what k_emit cost as a kernel of its own (k_split_cols 2.82 -> 3.82 ms per chunk, k_split_parse 0.94 -> 1.41 ms with the
@@ -3471,6 +3481,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
   const bool direct_env = [] { const char* e = getenv("FGX_DIRECT"); return e && e[0] == '1'; }();   // (read per batch: tools/direct_check.py switches it between two runs of one process)
   const bool direct = use_split && direct_env && !direct_off;
   last_direct = 0;
+  last_routed = 0; last_big_families = 0; last_deep_families = 0;
   uint64_t col_cap = lastb[0] + lastb[1] + 64;
   uint64_t dir_cap = 0;
   if (direct) {
@@ -3557,6 +3568,10 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
     }
     d_retry2.reserve((size_t)n_grp * 4);
     uint32_t* lists[2] = {d_retry.as<uint32_t>(), d_retry2.as<uint32_t>()};
+    // simplex families of more than 64 records: no wavefront-per-family kernel takes them — the first kernel that sees one puts it on
+    // k_family's list (round 3 walked them through k_simplex_wave2 and three k_family_wave<0> launches first: 2 ms per 1 M long-tail families)
+    uint32_t* d_cnt_big = (uint32_t*)(misc + 37);
+    if (!duplex && !codec) { d_big.reserve((size_t)n_grp * 4); P.big = d_big.as<uint32_t>(); P.n_big = d_cnt_big; }
     uint32_t* d_cnt = (uint32_t*)(misc + 31);
     uint32_t n_cur = n_grp;
     const uint32_t* cur_list = nullptr;
@@ -3726,6 +3741,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       hip_check(hipMemcpyAsync(&n_route, d_cnt_route, 4, hipMemcpyDeviceToHost, s), "D2H");
       hip_check(hipStreamSynchronize(s), "sync");
       n_v2 = n_route; v2_list = d_route.as<uint32_t>();
+      last_routed = n_route;
       static const bool s2_verbose = [] { const char* e = getenv("FGX_S2_VERBOSE"); return e && e[0] == '1'; }();
       if (s2_verbose) fprintf(stderr, "[fgx] split pipeline: %u families, %u routed to k_simplex_wave2\n", n_grp, n_route);
     }
@@ -3815,12 +3831,63 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       hip_check(hipStreamSynchronize(s), "sync");
       cur_list = lists[out_list]; n_cur = PS.retry ? n_next : 0; out_list ^= 1;
     }
-    if (n_cur && !duplex && !codec) {   // more than 64 records, or more bytes than the largest slice: one workgroup per family
+    uint32_t n_big = 0;
+    if (!duplex && !codec) {
+      hip_check(hipMemcpyAsync(&n_big, d_cnt_big, 4, hipMemcpyDeviceToHost, s), "D2H");
+      hip_check(hipStreamSynchronize(s), "sync");
+    }
+    last_big_families = n_big;
+    last_deep_families = 0;
+    // ---- deep families: k_deep_parse + k_deep_cols (simplex_deep.inc) take the big list; what is outside their shape goes on to k_family ----
+    const bool use_deep = [] { const char* e = getenv("FGX_DEEP"); return !(e && e[0] == '0'); }();   // (read per batch)
+    const uint32_t* big_list = d_big.as<uint32_t>();
+    if (n_big && use_deep && !o.trim) {
+      if (!d_s2img.p) {   // (the column kernel's LDS tables: the split pipeline's image)
+        S2Lds* img = new S2Lds;
+        build_s2_image(*img, c->h_tables.t);
+        d_s2img.reserve(sizeof(S2Lds));
+        hip_check(hipMemcpyAsync(d_s2img.p, img, sizeof(S2Lds), hipMemcpyHostToDevice, s), "H2D s2 image");
+        hip_check(hipStreamSynchronize(s), "sync");
+        delete img;
+      }
+      P.s2_image = d_s2img.p;
+      d_deep_sizes.reserve((size_t)n_big * 8 + 64); d_deep_row0.reserve((size_t)n_big * 8 + 64);
+      hipLaunchKernelGGL(k_deep_sizes, dim3((n_big + 255) / 256), dim3(256), 0, s, d_big.as<uint32_t>(), n_big, d_grp_first, d_deep_sizes.as<uint64_t>());
+      size_t tb = 0;
+      (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_deep_sizes.as<uint64_t>(), d_deep_row0.as<uint64_t>(), (int)n_big, s);
+      d_scan_tmp.reserve(tb);
+      hip_check(hipcub::DeviceScan::ExclusiveSum(d_scan_tmp.p, tb, d_deep_sizes.as<uint64_t>(), d_deep_row0.as<uint64_t>(), (int)n_big, s), "scan of the deep families' records");
+      uint64_t lastr[2] = {0, 0};
+      hip_check(hipMemcpyAsync(&lastr[0], d_deep_row0.as<uint64_t>() + (n_big - 1), 8, hipMemcpyDeviceToHost, s), "D2H");
+      hip_check(hipMemcpyAsync(&lastr[1], d_deep_sizes.as<uint64_t>() + (n_big - 1), 8, hipMemcpyDeviceToHost, s), "D2H");
+      hip_check(hipStreamSynchronize(s), "sync");
+      const uint64_t n_rows = lastr[0] + lastr[1];
+      d_deep_rows.reserve((size_t)n_rows * sizeof(DeepRow) + 64); d_deep_fams.reserve((size_t)n_big * sizeof(DeepFam) + 64); d_deep_out.reserve((size_t)n_big * 4 + 64);
+      uint32_t* d_cnt_deep = (uint32_t*)(misc + 38);
+      DeepParams DP;
+      DP.list = d_big.as<uint32_t>(); DP.n_list = n_big; DP.row0 = d_deep_row0.as<uint64_t>();
+      DP.rows = d_deep_rows.as<DeepRow>(); DP.fams = d_deep_fams.as<DeepFam>(); DP.out_list = d_deep_out.as<uint32_t>(); DP.n_out = d_cnt_deep;
+      FastParams PD = P;
+      PD.group_list = nullptr;
+      hipLaunchKernelGGL(k_deep_parse, dim3(n_big), dim3(DEEP_NT), 0, s, PD, DP);
+      hip_check(hipGetLastError(), "k_deep_parse launch");
+      hipLaunchKernelGGL(k_deep_cols, dim3((n_big + 3) / 4), dim3(256), 0, s, PD, DP);
+      hip_check(hipGetLastError(), "k_deep_cols launch");
+      uint32_t n_left = 0;
+      hip_check(hipMemcpyAsync(&n_left, d_cnt_deep, 4, hipMemcpyDeviceToHost, s), "D2H");
+      hip_check(hipStreamSynchronize(s), "sync");
+      last_deep_families = n_big - n_left;
+      big_list = d_deep_out.as<uint32_t>(); n_big = n_left;
+    }
+    // more than 64 records (the list the first kernels filled), or more bytes than the largest slice (what the chain left): one workgroup per family
+    for (int pass = 0; pass < 2 && !duplex && !codec; pass++) {
+      const uint32_t cnt = pass == 0 ? n_cur : n_big;
+      if (!cnt) continue;
       FastParams P2 = P;
-      P2.group_list = cur_list; P2.retry = nullptr; P2.n_retry = nullptr;
+      P2.group_list = pass == 0 ? cur_list : big_list; P2.retry = nullptr; P2.n_retry = nullptr;
       if (const char* e = getenv("FGX_LDS_TILE_LARGE")) { uint32_t v = (uint32_t)atoi(e); if (v >= 16384 && v <= 163840) lds_tile_bytes_large = v & ~15u; P2.lds_tile_bytes = lds_tile_bytes_large; }   // tuning knob
       hip_check(hipFuncSetAttribute((const void*)k_family, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile_bytes_large), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_family: the device refused the dynamic LDS size");
-      hipLaunchKernelGGL(k_family, dim3(n_cur), dim3(NT), lds_tile_bytes_large, s, P2);
+      hipLaunchKernelGGL(k_family, dim3(cnt), dim3(NT), lds_tile_bytes_large, s, P2);
       hip_check(hipGetLastError(), "k_family (large) launch");
     }
   }

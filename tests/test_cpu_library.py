@@ -44,7 +44,10 @@ def test_filter_options_layout_defaults_and_host_mirror():
     from fgumi_amd import FilterConfig, FilterThresholds, record_offsets
     o = _lib.FilterOptions()
     lib.fgx_filter_options_default(C.byref(o))
-    assert o.struct_size == C.sizeof(_lib.FilterOptions) == C.sizeof(orc.FilterOptions) == 88
+    assert o.struct_size == C.sizeof(_lib.FilterOptions) == C.sizeof(orc.FilterOptions) == 112
+    assert [f[0] for f in _lib.FilterOptions._fields_] == [f[0] for f in orc.FilterOptions._fields_]
+    assert _lib.FilterOptions.min_methylation_depth.offset == 92 and _lib.FilterOptions.min_conversion_fraction.offset == 104
+    assert not (o.has_min_methylation_depth or o.require_strand_methylation_agreement or o.has_min_conversion_fraction or o.methylation_mode)   # filter.rs:181-206
     assert list(o.min_reads) == [1, 1, 1] and list(o.max_read_error_rate) == [0.025] * 3 and list(o.max_base_error_rate) == [0.1] * 3
     assert o.max_no_call_fraction == 0.2 and o.filter_by_template == 1 and not o.has_min_base_quality and not o.track_rejects
     c = FilterConfig.new([5, 3], [0.05], [0.2, 0.1, 0.3], min_base_quality=20)
