@@ -3682,16 +3682,26 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       const bool s2_fixed = s2_fixed_env >= 0 ? s2_fixed_env != 0 : 2 * n160 > n_sample;
       struct S2Stage { uint32_t bytes, wpb; bool fixed; };
       std::vector<S2Stage> st2;
-      if (s2_fixed) st2.push_back({s2_bytes0, s2_wpb, true});
-      st2.push_back({s2_bytes0, s2_wpb, false});
-      st2.push_back({2 * s2_bytes0 > 8704u ? 2 * s2_bytes0 : 8704u, 2u, false});
-      st2.push_back({17408u, 1u, false});
-      st2.push_back({34816u, 1u, false});
+      // (reads of up to 160 bases: every slice size in the build with the strides as immediates, then ONE launch of the generic build for
+      // the families with other strides; round 3 ran the generic build from the second slice on — a long-tail batch spends most of its
+      // column time there)
+      if (s2_fixed) {
+        st2.push_back({s2_bytes0, s2_wpb, true});
+        st2.push_back({2 * s2_bytes0 > 8704u ? 2 * s2_bytes0 : 8704u, 2u, true});
+        st2.push_back({17408u, 1u, true});
+        st2.push_back({34816u, 1u, true});
+        st2.push_back({34816u, 1u, false});
+      } else {
+        st2.push_back({s2_bytes0, s2_wpb, false});
+        st2.push_back({2 * s2_bytes0 > 8704u ? 2 * s2_bytes0 : 8704u, 2u, false});
+        st2.push_back({17408u, 1u, false});
+        st2.push_back({34816u, 1u, false});
+      }
       uint32_t n_s2 = n_grp;
       const uint32_t* s2_list = nullptr;
       int s2_out = 0;
       for (size_t ci = 0; ci < st2.size() && n_s2; ci++) {
-        if (ci > 0 && !st2[ci - 1].fixed && st2[ci].bytes <= st2[ci - 1].bytes) continue;
+        if (ci > 0 && st2[ci - 1].fixed == st2[ci].fixed && st2[ci].bytes <= st2[ci - 1].bytes) continue;
         const bool last = ci + 1 == st2.size();
         hip_check(hipMemsetAsync(d_cnt, 0, 4, s), "memset");
         FastParams PS = P;

@@ -114,7 +114,7 @@ def test_families_of_more_than_64_records_on_the_streaming_kernels(kw):
 def test_deep_families_without_the_streaming_kernels(monkeypatch):
     """FGX_DEEP=0: the workgroup-per-family kernel takes the big list as in round 3 (up to 128 records; the rest is the host's)."""
     monkeypatch.setenv("FGX_DEEP", "0")
-    g = simulate_grouped_reads(300, family_size=33, family_size_max=60, error_rate_ppm=10000)
+    g = simulate_grouped_reads(300, family_size=33, family_size_max=45, error_rate_ppm=10000)   # (up to 90 records: what fits that kernel's 64 KB of LDS)
     path = _run(g)
     assert path["deep"] == 0 and path["big"] == 300 and path["deferred"] == 0, path
 

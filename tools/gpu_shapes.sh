@@ -22,4 +22,5 @@ for f in glob.glob(sys.argv[1] + '/**/' + sys.argv[2] + '_kernel_stats.csv', rec
 PY
   grep '^{' $OUT/$S.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('   value %.3f G  ms/step %.2f k_family %.2f k_emit %.2f frac %.4f deferred %s'%(d['value']/1e9, d['ms_per_step'], r['kernel_ms'], r['k_emit_ms'], r['frac'], d['config'].get('deferred_families')))" || tail -5 $OUT/$S.log
 done
+for S in $SHAPES; do python $R/tools/launch_times.py $OUT $S k_split_cols 12; done
 rm -rf $OUT/*_agent_info.csv $OUT/*kernel_trace.csv
