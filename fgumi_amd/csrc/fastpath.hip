@@ -224,6 +224,16 @@ __device__ inline void alignment_filter(Shared& S, uint32_t e, uint32_t n) {
 }
 
 
+#include "chain_observe.inc"
+// mask of the lanes l with p0 + l < limit (both scalar), on the scalar unit (k_simplex_wave2's lanes_below, which is defined after this kernel)
+__device__ __forceinline__ unsigned long long fw_lanes_below(uint32_t limit, uint32_t p0) {
+  unsigned long long m;
+  uint32_t span;
+  asm("s_max_u32 %1, %2, %3\n\ts_sub_u32 %1, %1, %3\n\ts_bfm_b64 %0, %1, 0\n\ts_cmp_ge_u32 %1, 64\n\ts_cselect_b64 %0, -1, %0"
+      : "=&s"(m), "=&s"(span) : "s"(limit), "s"(p0) : "scc");
+  return m;
+}
+
 // ---- wavefront helpers, unaligned LDS words, the aux walk (shared by every family kernel) ----------------------------
 constexpr int WAVES_PER_BLOCK = 4;
 #ifndef FGX_W2_WPB_DEFAULT
@@ -1047,7 +1057,11 @@ inline void build_fw_image(FwLds& L, const ConsensusTables& t) {
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P, uint32_t n_grp_total) {
+#ifndef FGX_WAVE_OCC_DUPLEX
+#define FGX_WAVE_OCC_DUPLEX 4   /* the duplex branch holds four column sets' worth of state beside the record lanes: at 5 waves per SIMD (96 VGPRs) its
+                                   member loop spilled */
+#endif
+__global__ __launch_bounds__(256, MODE == 1 ? FGX_WAVE_OCC_DUPLEX : FGX_WAVE_OCC) void k_family_wave(FastParams P, uint32_t n_grp_total) {
   extern __shared__ __align__(16) uint8_t dyn[];
   __shared__ __align__(16) FwLds sL;
   ConsensusTables& sT = sL.t;
@@ -1811,6 +1825,76 @@ __global__ __launch_bounds__(256, FGX_WAVE_OCC) void k_family_wave(FastParams P,
     if (!members) continue;
     const uint32_t mc = (uint32_t)__popcll(members);
     const uint32_t plen = (k == 0 || k == 3) ? plen1 : plen2;
+    // A REGULAR set — every member on one strand (reverse: one read length), untrimmed: the usual set — takes k_simplex_wave2's column
+    // step (chain_observe.inc: ~20 vector instructions per observation instead of ~50; the lane's index into a member is the same for
+    // every member, a member's final length is a scalar lane mask, the codes stay as stored and the chains' bases are complemented once
+    // at the end).  Anything else: the general loop below.  (Final lengths DO differ inside a set: a read that ends in a base below
+    // --min-input-base-quality loses it — 44 % of the benchmark's molecules have such a set.)
+    bool regular = false;
+    uint32_t Lrev = 0;
+    bool set_rev = false;
+    if (mc > 1) {
+      const bool mine = (members >> lane) & 1;
+      const unsigned long long rm = members & __ballot(rev);
+      set_rev = rm != 0;
+      if (rm) Lrev = rlane(l_seq, (uint32_t)__builtin_ctzll(rm));
+      const bool oddm = mine && (trim_to != l_seq || (rm != 0 && l_seq != Lrev));
+      regular = !__any(oddm) && (rm == 0 || rm == members);
+    }
+#ifdef FGX_DUPLEX_REQUIRE_REGULAR   /* measurement builds: a molecule with a set that is not regular is deferred — the bench line's deferred count says how many */
+    if (mc > 1 && !regular) { to_defer(); return; }
+#endif
+    if (regular) {
+      const uint8_t* const pairs = (const uint8_t*)&sPair[0][0];
+      for (uint32_t p0 = 0; p0 < elen[k]; p0 += 64) {
+        const uint32_t p = (uint32_t)__builtin_amdgcn_readfirstlane((int)p0) + lane;
+        const bool incol = p < elen[k];
+        const uint32_t ix = incol ? (set_rev ? Lrev - 1 - p : p) : 0u;
+        const uint32_t iq = ix, is = ix >> 1, ish = (~ix & 1) << 2;
+        double s1 = 0.0, c1 = 0.0, sR = 0.0, cR = 0.0, s2, c2, s3, c3;
+        asm volatile("" : "=v"(s2), "=v"(c2), "=v"(s3), "=v"(c3));   // (chains 2 / 3: written when opened)
+        uint32_t allow = incol ? 0x116u : 0u, b1 = 0, b2 = 0, b3 = 0, n1 = 0, n2 = 0, n3 = 0, nR = 0;
+        for (unsigned long long m = members; m;) {
+          const uint32_t r = (uint32_t)__builtin_ctzll(m);
+          m &= m - 1;
+          const uint32_t x0 = rlane(d0, r), x1 = rlane(d1, r);
+          const bool in = __builtin_amdgcn_inverse_ballot_w64(fw_lanes_below(x1 >> 16, (uint32_t)__builtin_amdgcn_readfirstlane((int)p0)));   // inside this member's final length
+          const uint32_t q = W[iq + (x0 >> 16)];
+          const uint32_t c = __builtin_amdgcn_ubfe((uint32_t)W[is + (x0 & 0xFFFF)], ish, 4u);
+          W2_OBSERVE(0, in, q, c, *(const double2*)(pairs + (((q) < 93u ? (q) : 93u) << 4)));
+        }
+        if (allow != 0) b1 = (uint32_t)__builtin_ctz(allow);
+        if (set_rev) { b1 = __builtin_bitreverse32(b1) >> 28; b2 = __builtin_bitreverse32(b2) >> 28; b3 = __builtin_bitreverse32(b3) >> 28; }
+        double ll[4];
+        uint32_t obs[4];
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) {
+          const uint32_t code = 1u << i;
+          ll[i] = code == b1 ? s1 : code == b2 ? s2 : code == b3 ? s3 : sR;
+          obs[i] = code == b1 ? n1 : code == b2 ? n2 : code == b3 ? n3 : nR;
+        }
+        const uint64_t o = col_base + eoff[k] + p;
+        int bi = -1;
+        uint8_t q = 0;
+        const bool resolved = incol ? column_call_fast_lds(sT, KC, ll, obs, &bi, &q) : true;
+        const uint32_t depth = obs[0] + obs[1] + obs[2] + obs[3];
+        push_full(incol && !resolved, o, ll, obs);
+        if (incol) {
+          if (resolved) {
+            const uint32_t err = depth - (bi == 0 ? obs[0] : bi == 1 ? obs[1] : bi == 2 ? obs[2] : bi == 3 ? obs[3] : 0u);
+            uint8_t ob, oq;
+            if (depth < 1) { ob = 15; oq = 0; }
+            else if (q < FGX_MIN_PHRED) { ob = 15; oq = FGX_MIN_PHRED; }
+            else { ob = bi >= 0 ? (uint8_t)(1u << bi) : (uint8_t)15; oq = q; }
+            P.col_code[o] = ob; P.col_qual[o] = oq; P.col_err[o] = (uint16_t)err;
+          }
+          P.col_obs[o] = obs[0] | (obs[1] << 8) | (obs[2] << 16) | (obs[3] << 24);
+          dm_fu[k] = depth > dm_fu[k] ? depth : dm_fu[k];
+          if (p < plen) dm_tr[k] = depth > dm_tr[k] ? depth : dm_tr[k];
+        }
+      }
+      continue;
+    }
     for (uint32_t p = lane; p < elen[k]; p += 64) {
       const uint64_t o = col_base + eoff[k] + p;
       uint32_t depth, obs[4];
@@ -2465,6 +2549,7 @@ struct EmitCtx {
 __device__ __forceinline__ uint32_t gld32u(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 __device__ __forceinline__ uint2 gld64u(const uint8_t* p) { uint2 v; __builtin_memcpy(&v, p, 8); return v; }
 __device__ __forceinline__ void gst32u(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+__device__ __forceinline__ void gst16u(uint8_t* p, uint32_t v) { const uint16_t w = (uint16_t)v; __builtin_memcpy(p, &w, 2); }
 
 __device__ __forceinline__ void emit_core(uint8_t* q, uint32_t lane, const EmitCtx& X) {
   // block_size + fixed core: ref_id -1, pos -1, l_read_name, mapq 0, bin 4680, n_cigar_op 0, flag, l_seq, next_ref -1, next_pos -1, tlen 0
@@ -3070,23 +3155,26 @@ struct FieldWriter {
 template <uint32_t SLOTS, class B>      // string field of L bytes after a 3-byte `xyZ` header and before a NUL
 __device__ __forceinline__ void put_string(FieldWriter& W, char t0, char t1, uint32_t L, B byte_of) {
   W.small(3, [&](uint32_t i) { return i == 0 ? (uint8_t)t0 : i == 1 ? (uint8_t)t1 : (uint8_t)'Z'; });
+  // a lane's two positions are neighbours in the record: ONE 16-bit store (gfx950 takes them unaligned) instead of two byte stores
 #pragma unroll
-  for (uint32_t t = 0; t < SLOTS; t++)
-#pragma unroll
-    for (uint32_t k = 0; k < 2; k++) { const uint32_t p = 128 * t + 2 * W.lane + k; if (p < L) W.q[p] = byte_of(t, k); }
+  for (uint32_t t = 0; t < SLOTS; t++) {
+    const uint32_t p = 128 * t + 2 * W.lane;
+    if (p + 1 < L) gst16u(W.q + p, (uint32_t)(uint8_t)byte_of(t, 0) | ((uint32_t)(uint8_t)byte_of(t, 1) << 8));
+    else if (p < L) W.q[p] = byte_of(t, 0);
+  }
   if (W.lane == 0) W.q[L] = 0;
   W.q += L + 1;
 }
 template <uint32_t SLOTS, class V>      // B:s array of L int16 values
 __device__ __forceinline__ void put_i16(FieldWriter& W, char t0, char t1, uint32_t L, V val_of) {
   W.small(8, [&](uint32_t i) { return i == 0 ? (uint8_t)t0 : i == 1 ? (uint8_t)t1 : i == 2 ? (uint8_t)'B' : i == 3 ? (uint8_t)'s' : (uint8_t)(L >> (8 * ((i - 4) & 3))); });
+  // a lane's two int16 values are four consecutive bytes: one (unaligned) dword store instead of four byte stores
 #pragma unroll
-  for (uint32_t t = 0; t < SLOTS; t++)
-#pragma unroll
-    for (uint32_t k = 0; k < 2; k++) {
-      const uint32_t p = 128 * t + 2 * W.lane + k;
-      if (p < L) { const uint32_t v = val_of(t, k); W.q[2 * p] = (uint8_t)v; W.q[2 * p + 1] = (uint8_t)(v >> 8); }
-    }
+  for (uint32_t t = 0; t < SLOTS; t++) {
+    const uint32_t p = 128 * t + 2 * W.lane;
+    if (p + 1 < L) gst32u(W.q + 2 * p, ((uint32_t)val_of(t, 0) & 0xFFFFu) | ((uint32_t)val_of(t, 1) << 16));
+    else if (p < L) gst16u(W.q + 2 * p, (uint32_t)val_of(t, 0));
+  }
   W.q += 2 * L;
 }
 template <uint32_t SLOTS, class C, class Q>   // 4-bit packed bases, then qualities
@@ -3098,9 +3186,11 @@ __device__ __forceinline__ void put_seq_qual(FieldWriter& W, uint32_t L, C code_
   }
   W.q += (L + 1) / 2;
 #pragma unroll
-  for (uint32_t t = 0; t < SLOTS; t++)
-#pragma unroll
-    for (uint32_t k = 0; k < 2; k++) { const uint32_t p = 128 * t + 2 * W.lane + k; if (p < L) W.q[p] = (uint8_t)qual_of(t, k); }
+  for (uint32_t t = 0; t < SLOTS; t++) {
+    const uint32_t p = 128 * t + 2 * W.lane;
+    if (p + 1 < L) gst16u(W.q + p, ((uint32_t)qual_of(t, 0) & 0xFFu) | (((uint32_t)qual_of(t, 1) & 0xFFu) << 8));
+    else if (p < L) W.q[p] = (uint8_t)qual_of(t, 0);
+  }
   W.q += L;
 }
 
