@@ -3661,7 +3661,8 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
     // simplex families of more than 64 records: no wavefront-per-family kernel takes them — the first kernel that sees one puts it on
     // k_family's list (round 3 walked them through k_simplex_wave2 and three k_family_wave<0> launches first: 2 ms per 1 M long-tail families)
     uint32_t* d_cnt_big = (uint32_t*)(misc + 37);
-    if (!duplex && !codec) { d_big.reserve((size_t)n_grp * 4); P.big = d_big.as<uint32_t>(); P.n_big = d_cnt_big; }
+    // (not with direct records: their merge pass walks ONE list of the families that left the split pipeline — the route list)
+    if (!duplex && !codec && !direct) { d_big.reserve((size_t)n_grp * 4); P.big = d_big.as<uint32_t>(); P.n_big = d_cnt_big; }
     uint32_t* d_cnt = (uint32_t*)(misc + 31);
     uint32_t n_cur = n_grp;
     const uint32_t* cur_list = nullptr;

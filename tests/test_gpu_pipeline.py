@@ -182,8 +182,9 @@ def test_run_bam_reports_a_truncated_file(tmp_path):
 
 
 def test_run_bam_edge_files(tmp_path):
-    """A header-only file; one family of 300 records (larger than any device kernel takes: the batch goes through the host entry, and with
-    64 KiB chunks the group is the leftover of chunk after chunk until the file ends); records without the group tag in between."""
+    """A header-only file; one family of 600 records (300 per end: more than any device kernel takes — the streaming kernels of
+    simplex_deep.inc stop at 255 retained reads per end — so the batch goes through the host entry, and with 64 KiB chunks the group is the
+    leftover of chunk after chunk until the file ends); records without the group tag in between."""
     refs = [("chr1", 1000000)]
     src, dst = str(tmp_path / "in.bam"), str(tmp_path / "out.bam")
     c = _caller()
@@ -193,9 +194,13 @@ def test_run_bam_edge_files(tmp_path):
     text, orefs, stream, off, ln = bgzf.read_bam(dst)
     assert st["consensus_records"] == 0 and len(off) == 0 and text.startswith("@HD")
     # one big family
-    g = simulate_grouped_reads(1, family_size=150)
+    g = simulate_grouped_reads(1, family_size=300)
     st = _run_and_compare(tmp_path, c, fgx_opts.defaults(min_reads=1), g, 50, 1 << 16)
     assert st["chunks"] >= 1 and st["deferred_groups"] == 1
+    # ... and one of 300 records: the device's since round 4
+    g = simulate_grouped_reads(1, family_size=150)
+    st = _run_and_compare(tmp_path, c, fgx_opts.defaults(min_reads=1), g, 50, 1 << 16)
+    assert st["chunks"] >= 1 and st["deferred_groups"] == 0
     # untagged records between the families: MiGrouper skips them (mi_group.rs:285-290)
     g = simulate_grouped_reads(400, family_size=3)
     recs = [bytes(g.blob[int(o) - 4:int(o) + int(l)]) for o, l in zip(g.rec_off, g.rec_len)]
@@ -273,9 +278,9 @@ def test_run_bam_with_rejects_simplex(tmp_path):
 
 
 def test_run_bam_with_rejects_takes_the_host_entry_when_the_side_kernels_refuse(tmp_path):
-    """A family of 300 records is outside the reject side kernels' scope (and the device pipeline's): that batch goes through the host entry
+    """A family of 600 records is outside the reject side kernels' scope (and the device pipeline's): that batch goes through the host entry
     in one piece, rejects included; and the duplex caller, whose `--rejects` the device entry does not serve, does so for every batch."""
-    big = simulate_grouped_reads(1, family_size=150)
+    big = simulate_grouped_reads(1, family_size=300)
     small = simulate_grouped_reads(300, family_size=1, family_size_max=5, seed=7)
     recs = [small.records(i) for i in range(150)] + [big.records(0)] + [small.records(i) for i in range(150, 300)]
     from fgumi_amd import GroupedReads

@@ -5,7 +5,7 @@
 # usage: bash tools/profile_round.sh <tag>        results land in gpurun_out/<tag>/ ; copy the summaries to profiles/
 TAG=$1; R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 cd $R
-timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest.log
+timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider -rfE > $OUT/pytest.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest.log
 tail -3 $OUT/pytest.log
 cd /tmp; export TMPDIR=/tmp
 i=0
@@ -13,7 +13,7 @@ for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_
          "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY" \
          "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc -o pmc$i -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc$i.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc -o pmc$i -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-strong-block > $OUT/pmc$i.log 2>&1
 done
 python $R/tools/pmc_parse.py $OUT/pmc 3 > $OUT/pmc_5M_families.json
 cp $OUT/pmc_5M_families.json $R/profiles/${TAG}_pmc_5M_families.json
