@@ -359,7 +359,7 @@ def main():
                          # from the committed PMC passes (`traffic_source`), NOT measured in this run
                          "traffic": ((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0) if (pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc) else None,
                          "traffic_source": pmc_file,
-                         "kernel": ("k_family stage (k_split_parse + k_split_cols + k_split_finish | k_simplex_seg, then k_simplex_wave2 / k_family_wave / k_family for what is left, + k_call_full)"
+                         "kernel": ("k_family stage (k_split_parse + k_split_cols + k_split_finish | k_simplex_seg, then k_simplex_wave2 / k_family_wave for what is left, k_deep_parse + k_deep_cols for families of more than 64 records, k_family behind them, + k_call_full)"
                                     if not (duplex or codec) else "k_family stage (k_family_wave + k_call_full)"),
                          "kernel_ms": k_family_ms / steps, "k_emit_ms": k_emit_ms / steps,
                          "device_ms_per_step": k_total_ms / steps, "algorithmic_bytes_per_launch": alg_read + alg_write,
