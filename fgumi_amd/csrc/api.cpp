@@ -48,7 +48,10 @@ void DevBuf::reserve(size_t n) {
   if (p) hip_check(hipFree(p), "hipFree");
   p = nullptr;
   cap = 0;
-  hip_check(hipMalloc(&p, want), "hipMalloc");
+  {
+    const hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { p = nullptr; throw std::runtime_error(std::string("hipMalloc of ") + std::to_string(want) + " bytes: " + hipGetErrorString(e)); }
+  }
   cap = want;
 }
 void DevBuf::free_() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
@@ -518,6 +521,14 @@ static int hybrid_after_upload(fgx_caller* c, general_fn general, const uint8_t*
                                const uint32_t* rec_len, uint32_t n_rec, const uint32_t* grp_first, uint32_t n_grp, fgx_output* out,
                                uint8_t* dst, uint64_t dst_cap);
 
+// The methylation-aware mode in the device-resident pipeline (round 4; FGX_METH_DEVICE=0 opts out): simplex caller, a reference handed over,
+// no --trim, no --rejects.  Everything else of the mode stays on the general path.
+static bool meth_device_enabled(const fgx_caller* c) {
+  if (c->opt.caller_kind != FGX_CALLER_SIMPLEX || c->opt.trim || c->opt.track_rejects || !c->genome) return false;
+  const char* e = getenv("FGX_METH_DEVICE");
+  return !(e && e[0] == '0');
+}
+
 static int process_hybrid(fgx_caller* c, general_fn general, const uint8_t* records, uint64_t records_len, const uint64_t* rec_off,
                           const uint32_t* rec_len, uint32_t n_rec, const uint32_t* grp_first, uint32_t n_grp, fgx_output* out) {
   // --rejects (record copies in input order) and the methylation-aware mode (reference lookups per source read) are decided by the
@@ -528,7 +539,7 @@ static int process_hybrid(fgx_caller* c, general_fn general, const uint8_t* reco
                            rejects_device_enabled();
   c->last_canon_molecules = 0;
   c->last_deferred_groups = n_grp;          // (diagnostics, fgx_debug_last_deferral: the whole batch on the general path counts as every group deferred)
-  if ((c->opt.track_rejects && !dev_rejects) || c->opt.methylation_mode != FGX_METHYLATION_DISABLED || n_grp == 0) return run_general(c, general, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
+  if ((c->opt.track_rejects && !dev_rejects) || (c->opt.methylation_mode != FGX_METHYLATION_DISABLED && !meth_device_enabled(c)) || n_grp == 0) return run_general(c, general, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
   if (!c->fast) c->fast = new FastState();
   auto t0 = clk::now();
   hybrid_upload(c, records, records_len, rec_off, rec_len, n_rec, grp_first, n_grp);
@@ -897,7 +908,9 @@ int fgx_process_batch_device(fgx_caller* c, const void* d_records, uint64_t reco
     }
     const bool dev_rejects = c->opt.track_rejects && c->opt.caller_kind == FGX_CALLER_SIMPLEX && rejects_device_enabled();
     if (c->opt.track_rejects && !dev_rejects) { c->err = "fgx_process_batch_device: --rejects needs the host path (fgx_process_batch)"; return 1; }
-    if (c->opt.methylation_mode != FGX_METHYLATION_DISABLED) { c->err = "fgx_process_batch_device: the methylation-aware mode needs the host entry (fgx_process_batch)"; return 1; }
+    // methylation-aware mode: the simplex caller without --trim runs on the streaming kernels (simplex_deep.inc); FGX_METH_DEVICE=0, duplex or
+    // --trim: the host entry (general path)
+    if (c->opt.methylation_mode != FGX_METHYLATION_DISABLED && !meth_device_enabled(c)) { c->err = "fgx_process_batch_device: the methylation-aware mode of this caller needs the host entry (fgx_process_batch)"; return 1; }
     if (!c->fast) c->fast = new FastState();
     c->fast->has_last = false;   // set again only when this batch succeeds
     c->last_group_off = nullptr;
@@ -1233,6 +1246,7 @@ uint32_t fgx_debug_last_split_chunks(const fgx_caller* c) { return (c && c->fast
 // families of the last device batch that went to the workgroup-per-family kernel because they have more than 64 records / that the split
 // pipeline handed down the k_simplex_wave2 chain
 uint32_t fgx_debug_last_big_families(const fgx_caller* c) { return (c && c->fast) ? c->fast->fp.last_big_families : 0u; }
+uint32_t fgx_debug_last_meth_device(const fgx_caller* c) { return (c && c->fast) ? c->fast->fp.last_meth_device : 0u; }
 uint32_t fgx_debug_last_deep_families(const fgx_caller* c) { return (c && c->fast) ? c->fast->fp.last_deep_families : 0u; }
 uint32_t fgx_debug_last_routed(const fgx_caller* c) { return (c && c->fast) ? c->fast->fp.last_routed : 0u; }
 int fgx_debug_last_direct(const fgx_caller* c) { return (c && c->fast) ? c->fast->fp.last_direct : 0; }

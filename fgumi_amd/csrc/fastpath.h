@@ -16,9 +16,11 @@ struct EndDesc {            // one consensus read (a family end), written by the
   uint32_t rec_size;        // BAM block_size of the record to emit
   uint16_t mi_off, cb_off;
   uint8_t mi_len, cb_len, rx_len, type;   // type: 0 fragment, 1 R1, 2 R2
-  uint8_t has_cb, has_rx, valid, _pad;
+  uint8_t has_cb, has_rx, valid, meth;   // meth (methylation-aware mode): bit 0 the call was annotated (cu / ct, MM / ML follow RX), bit 1 the MM / ML strand is the top strand
   char rx[FAST_RX_CAP];
 };
+// methylation-aware mode: what k_meth_sizes found for a record — the bytes of the standard record (the methylation tags follow them), ML entries, characters of the MM entries
+struct MethSlot { uint32_t std_size, n_ml, mm_len, _pad; };
 
 struct DuplexDesc {         // one duplex consensus record (slot 3g+1 = R1, 3g+2 = R2), written by k_family_wave<1>, consumed by k_emit_duplex
   uint64_t a_off, b_off;    // first column of the AB-side strand and of the BA-side strand (b = a when a single strand is passed through)
@@ -148,6 +150,12 @@ struct FastParams {
   uint32_t lds_tile_bytes;
   uint32_t lds_wave_bytes;
   FullItem* full_items; uint32_t* full_count; uint32_t full_cap;   // N_LISTS append lists of `full_cap` items each
+  // methylation-aware mode on the streaming kernels (simplex_deep.inc; meth_mode = FGX_METHYLATION_*, 0: off): the genome of fgx_set_reference
+  // (contig i = [contig_off[i], + contig_len[i])), and per scratch column: the reference shows a cytosine of the call's strand | unconverted |
+  // converted source bases (methylation.rs:193-242)
+  uint32_t meth_mode, n_ref;
+  const uint8_t* genome; const uint64_t* contig_off; const uint64_t* contig_len;
+  uint8_t* meth_flag; uint16_t* meth_u; uint16_t* meth_t;
   // duplex (k_family_wave<1>)
   uint32_t dmin_total, dmin_xy, dmin_yx; int64_t dmax_reads;
   uint32_t* col_obs;               // per column: observation counts of A,C,G,T, one byte each
@@ -206,6 +214,8 @@ struct FastPath {
   uint32_t last_big_families = 0;          // ... in the last batch
   uint32_t last_deep_families = 0;         // ... of which k_deep_parse + k_deep_cols (simplex_deep.inc) took
   DevBuf d_deep_sizes, d_deep_row0, d_deep_rows, d_deep_fams, d_deep_out;
+  DevBuf d_mflag, d_mu, d_mt, d_mslot, d_mcontigs;   // methylation-aware mode: per-column annotation, per-slot tag sizes, the contig table
+  uint32_t last_meth_device = 0;           // families of the last batch that the device pipeline decided in the methylation-aware mode
   uint32_t last_routed = 0;                // families the split pipeline handed to the k_simplex_wave2 chain in the last batch
   DevBuf d_dir_size, d_dir_off, d_dir_base, d_slot_desc, d_slot_err, d_out2, d_scan_tmp2;   // direct records (simplex_split.inc, fastpath.h)
   bool direct_off = false;                // a batch whose predicted record sizes did not hold: this caller stays on the scratch path (diagnostics: last_direct)

@@ -3475,7 +3475,7 @@ __global__ void k_reduce_stats(const unsigned long long* __restrict__ slots, uns
 void FastPath::release() {
   for (DevBuf* b : {&d_ends, &d_sizes, &d_offsets, &d_code, &d_qual, &d_depth, &d_err, &d_misc, &d_deferred, &d_out, &d_scan_tmp, &d_strings, &d_obs, &d_retry2,
                     &d_retry, &d_bound, &d_colbase, &d_statslots, &d_full_items, &d_full_count, &d_retry_old, &d_w2img, &d_famdesc, &d_fwimg,
-                    &d_split_rec, &d_split_fam, &d_split_out, &d_route, &d_s2img, &d_dir_size, &d_dir_off, &d_dir_base, &d_slot_desc, &d_slot_err, &d_out2, &d_scan_tmp2, &d_big, &d_deep_sizes, &d_deep_row0, &d_deep_rows, &d_deep_fams, &d_deep_out})
+                    &d_split_rec, &d_split_fam, &d_split_out, &d_route, &d_s2img, &d_dir_size, &d_dir_off, &d_dir_base, &d_slot_desc, &d_slot_err, &d_out2, &d_scan_tmp2, &d_big, &d_deep_sizes, &d_deep_row0, &d_deep_rows, &d_deep_fams, &d_deep_out, &d_mflag, &d_mu, &d_mt, &d_mslot, &d_mcontigs})
     b->free_();
   for (int i = 0; i < 4; i++) if (ev[i]) { (void)hipEventDestroy(ev[i]); ev[i] = nullptr; }
   if (s2) {
@@ -3541,7 +3541,12 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
   uint32_t seg_bytes = 11776;   // 4 wavefronts x 11776 B + the static tables = 3 workgroups per CU
   if (const char* e = getenv("FGX_SEG_BYTES")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 4096 && v <= 32768) seg_bytes = v & ~63u; }
   const double mean_span = (double)blob_len / (double)n_grp + 48.0;   // mean bytes of a family + alignment / read-ahead slack
-  const bool simplex_v2 = !duplex && !codec && !o.trim && use_v2;
+  // Methylation-aware mode (simplex, a reference set, no --trim): the streaming kernels of simplex_deep.inc are the whole pipeline — every
+  // family on their list, the reference lookup / counts / normalisation in k_deep_cols<1>, MM / ML / cu / ct behind the standard record
+  // (k_meth_sizes, k_meth_tail); a family outside their shape is deferred to the general path, which knows the mode.
+  const bool meth_dev = !duplex && !codec && !o.trim && o.methylation_mode != FGX_METHYLATION_DISABLED && c->genome != nullptr;
+  last_meth_device = 0;
+  const bool simplex_v2 = !duplex && !codec && !o.trim && use_v2 && !meth_dev;
   const bool seg4 = simplex_v2 && use_seg && mean_span + (16 * 8 + 64) <= seg_bytes / 4;
   hipLaunchKernelGGL(k_col_bound, dim3((n_grp + 255) / 256), dim3(256), 0, s, d_grp_first, d_rec_len, d_rec_off, n_grp, d_bound.as<uint64_t>(), duplex ? 4u : codec ? 2u : 3u,
                      d_famdesc.as<uint4>(), misc + 35);
@@ -3569,7 +3574,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
   // size prediction; step 33.7 -> 40.2 ms with the merge, ~34 ms without: profiles/r04_experiments.md) — vector-instruction issue is what the
   // stage is short of, and the record's constant bytes cost as many instructions written from here as from there.
   const bool direct_env = [] { const char* e = getenv("FGX_DIRECT"); return e && e[0] == '1'; }();   // (read per batch: tools/direct_check.py switches it between two runs of one process)
-  const bool direct = use_split && direct_env && !direct_off;
+  const bool direct = use_split && direct_env && !direct_off && !meth_dev;
   last_direct = 0;
   last_routed = 0; last_big_families = 0; last_deep_families = 0;
   uint64_t col_cap = lastb[0] + lastb[1] + 64;
@@ -3587,6 +3592,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
     hip_check(hipMemsetAsync(d_sizes.p, 0, (size_t)n_slots * 8, s), "memset");
   }
   d_code.reserve(col_cap + 64); d_qual.reserve(col_cap + 64); d_err.reserve(col_cap * 2 + 64);   // (+ slack: k_emit reads whole dwords)
+  if (meth_dev) { d_mflag.reserve(col_cap + 64); d_mu.reserve(col_cap * 2 + 64); d_mt.reserve(col_cap * 2 + 64); d_mslot.reserve((size_t)n_slots * sizeof(MethSlot) + 64); }
   if (duplex) d_obs.reserve(col_cap * 4); else d_depth.reserve(col_cap * 2 + 64);
 
   FastParams P;
@@ -3623,6 +3629,18 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
   P.prefix_len = (uint32_t)c->prefix.size(); P.rg_len = (uint32_t)c->rg.size();
   P.ends = d_ends.as<EndDesc>(); P.rec_sizes = d_sizes.as<uint64_t>();
   P.col_code = d_code.as<uint8_t>(); P.col_qual = d_qual.as<uint8_t>(); P.col_depth = d_depth.as<uint16_t>(); P.col_err = d_err.as<uint16_t>();
+  if (meth_dev) {
+    const GenomeRef* gr = c->genome.get();
+    const uint32_t n_ref = (uint32_t)gr->off.size();
+    d_mcontigs.reserve((size_t)(n_ref + 1) * 16 + 64);
+    if (n_ref) {
+      hip_check(hipMemcpyAsync(d_mcontigs.p, gr->off.data(), (size_t)n_ref * 8, hipMemcpyHostToDevice, s), "H2D contig offsets");
+      hip_check(hipMemcpyAsync(d_mcontigs.as<uint64_t>() + n_ref, gr->len.data(), (size_t)n_ref * 8, hipMemcpyHostToDevice, s), "H2D contig lengths");
+    }
+    P.meth_mode = o.methylation_mode; P.n_ref = n_ref; P.genome = (const uint8_t*)gr->d_genome.p;
+    P.contig_off = d_mcontigs.as<uint64_t>(); P.contig_len = d_mcontigs.as<uint64_t>() + n_ref;
+    P.meth_flag = d_mflag.as<uint8_t>(); P.meth_u = d_mu.as<uint16_t>(); P.meth_t = d_mt.as<uint16_t>();
+  }
   P.col_base = d_colbase.as<uint64_t>();
   if (direct) {
     P.dir_size = d_dir_size.as<uint32_t>(); P.dir_off = d_dir_off.as<uint64_t>(); P.out = d_out.as<uint8_t>(); P.out_cap = dir_cap;
@@ -3664,7 +3682,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
     // (not with direct records: their merge pass walks ONE list of the families that left the split pipeline — the route list)
     if (!duplex && !codec && !direct) { d_big.reserve((size_t)n_grp * 4); P.big = d_big.as<uint32_t>(); P.n_big = d_cnt_big; }
     uint32_t* d_cnt = (uint32_t*)(misc + 31);
-    uint32_t n_cur = n_grp;
+    uint32_t n_cur = meth_dev ? 0u : n_grp;       // (methylation-aware mode: no wavefront-per-family kernel runs)
     const uint32_t* cur_list = nullptr;
     int out_list = 0;
     // Simplex, no --trim: k_simplex_wave2 (two-accumulator column loop) takes the families of the common record shape over the same
@@ -3937,12 +3955,17 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       hip_check(hipMemcpyAsync(&n_big, d_cnt_big, 4, hipMemcpyDeviceToHost, s), "D2H");
       hip_check(hipStreamSynchronize(s), "sync");
     }
+    if (meth_dev) {
+      d_big.reserve((size_t)n_grp * 4);
+      hipLaunchKernelGGL(k_iota, dim3((n_grp + 255) / 256), dim3(256), 0, s, d_big.as<uint32_t>(), n_grp);
+      n_big = n_grp;
+    }
     last_big_families = n_big;
     last_deep_families = 0;
     // ---- deep families: k_deep_parse + k_deep_cols (simplex_deep.inc) take the big list; what is outside their shape goes on to k_family ----
     const bool use_deep = [] { const char* e = getenv("FGX_DEEP"); return !(e && e[0] == '0'); }();   // (read per batch)
     const uint32_t* big_list = d_big.as<uint32_t>();
-    if (n_big && use_deep && !o.trim) {
+    if (n_big && (use_deep || meth_dev) && !o.trim) {
       if (!d_s2img.p) {   // (the column kernel's LDS tables: the split pipeline's image)
         S2Lds* img = new S2Lds;
         build_s2_image(*img, c->h_tables.t);
@@ -3963,6 +3986,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       hip_check(hipMemcpyAsync(&lastr[1], d_deep_sizes.as<uint64_t>() + (n_big - 1), 8, hipMemcpyDeviceToHost, s), "D2H");
       hip_check(hipStreamSynchronize(s), "sync");
       const uint64_t n_rows = lastr[0] + lastr[1];
+      if (n_rows > (uint64_t)n_rec) throw std::runtime_error("device pipeline: " + std::to_string(n_rows) + " rows for the streaming kernels, more than the batch has records");
       d_deep_rows.reserve((size_t)n_rows * sizeof(DeepRow) + 64); d_deep_fams.reserve((size_t)n_big * sizeof(DeepFam) + 64); d_deep_out.reserve((size_t)n_big * 4 + 64);
       uint32_t* d_cnt_deep = (uint32_t*)(misc + 38);
       DeepParams DP;
@@ -3972,13 +3996,15 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       PD.group_list = nullptr;
       hipLaunchKernelGGL(k_deep_parse, dim3(n_big), dim3(DEEP_NT), 0, s, PD, DP);
       hip_check(hipGetLastError(), "k_deep_parse launch");
-      hipLaunchKernelGGL(k_deep_cols, dim3((n_big + 3) / 4), dim3(256), 0, s, PD, DP);
+      if (meth_dev) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_deep_cols<1>), dim3((n_big + 3) / 4), dim3(256), 0, s, PD, DP);
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_deep_cols<0>), dim3((n_big + 3) / 4), dim3(256), 0, s, PD, DP);
       hip_check(hipGetLastError(), "k_deep_cols launch");
       uint32_t n_left = 0;
       hip_check(hipMemcpyAsync(&n_left, d_cnt_deep, 4, hipMemcpyDeviceToHost, s), "D2H");
       hip_check(hipStreamSynchronize(s), "sync");
       last_deep_families = n_big - n_left;
       big_list = d_deep_out.as<uint32_t>(); n_big = n_left;
+      if (meth_dev) { last_meth_device = n_grp; n_big = 0; }   // (what the streaming kernels refused is on the deferred list: the general path's)
     }
     // more than 64 records (the list the first kernels filled), or more bytes than the largest slice (what the chain left): one workgroup per family
     for (int pass = 0; pass < 2 && !duplex && !codec; pass++) {
@@ -4026,6 +4052,10 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       hip_check(hipGetLastError(), "k_call_full launch");
     }
   }
+  if (meth_dev) {   // the methylation tags' share of the record sizes: the consensus bases are final now
+    hipLaunchKernelGGL(k_meth_sizes, dim3((n_slots + 255) / 256), dim3(256), 0, s, P, n_slots, d_mslot.as<MethSlot>());
+    hip_check(hipGetLastError(), "k_meth_sizes launch");
+  }
   // ---- direct records: cE of the records whose columns had errors; did every prediction hold; is there anything to merge? ----------
   bool dir_pure = false;
   uint32_t dir_routed = 0;
@@ -4071,6 +4101,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
     hip_check(hipMemcpyAsync(&last[1], d_sizes.as<uint64_t>() + (n_slots - 1), 8, hipMemcpyDeviceToHost, s), "D2H");
     hip_check(hipStreamSynchronize(s), "sync");
     out_len = last[0] + last[1];
+    if (out_len > (1ull << 40)) throw std::runtime_error("device pipeline: the scan of the record sizes gives " + std::to_string(out_len) + " bytes of output (a record size is corrupt)");
     if (direct) { d_out2.reserve(out_len + 16); out_ptr = d_out2.as<uint8_t>(); }   // the merged stream: d_out holds the directly written records
     else { d_out.reserve(out_len + 16); out_ptr = d_out.as<uint8_t>(); }
   }
@@ -4119,6 +4150,10 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
     }
   } else hipLaunchKernelGGL(k_emit, dim3((n_grp + 3) / 4), dim3(256), 0, s, E);   // one wavefront per family (slots 3g .. 3g + 2)
   hip_check(hipGetLastError(), "k_emit launch");
+  if (meth_dev) {
+    hipLaunchKernelGGL(k_meth_tail, dim3((n_slots + 255) / 256), dim3(256), 0, s, P, n_slots, d_mslot.as<MethSlot>(), d_offsets.as<uint64_t>(), out_ptr);
+    hip_check(hipGetLastError(), "k_meth_tail launch");
+  }
   hip_check(hipEventRecord(ev[3], s), "event");
   hip_check(hipEventRecord(c->ev1, s), "event");
   hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(64), 0, s, d_statslots.as<unsigned long long>(), misc);

@@ -18,6 +18,13 @@ from fgumi_amd._lib import Options, Output, lib
 pytestmark = pytest.mark.gpu
 
 
+LAST = {}
+lib.fgx_debug_last_meth_device.restype = C.c_uint32
+lib.fgx_debug_last_meth_device.argtypes = [C.c_void_p]
+lib.fgx_debug_last_deferral.restype = None
+lib.fgx_debug_last_deferral.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+
+
 def oracle(o, contigs, g, batch_groups=50):
     orc.set_reference(contigs)
     try:
@@ -48,6 +55,9 @@ def product(o, contigs, g, general_only=False):
         out = Output()
         rc = lib.fgx_process_batch(h, g.blob.ctypes.data, g.blob.size, g.rec_off.ctypes.data, g.rec_len.ctypes.data, g.n_rec, g.grp_first.ctypes.data, g.n_grp, C.byref(out))
         assert rc == 0, lib.fgx_last_error(h).decode()
+        d2 = (C.c_uint64 * 2)()
+        lib.fgx_debug_last_deferral(h, d2)
+        LAST.update(meth_device=int(lib.fgx_debug_last_meth_device(h)), deferred=int(d2[0]), groups=int(g.n_grp))   # which way the (last) batch went
         return dict(data=C.string_at(out.data, out.data_len) if out.data_len else b"", count=int(out.count), stats=np.array(list(out.stats), dtype=np.uint64),
                     rejects=C.string_at(out.rejects, out.rejects_len) if out.rejects_len else b"", n_rejects=int(out.n_rejects))
     finally:
@@ -108,6 +118,58 @@ def test_simplex_em_seq_like_batches(mode, kw):
     want = same(fgx_opts.defaults(methylation_mode=mode, **kw), contigs, groups)
     recs = [bamutil.parse(r) for r in split_records(want["data"])]
     assert sum("MM" in r["tags"] for r in recs) > 200 and sum("cu" in r["tags"] for r in recs) > 800
+    # round 4: the simplex caller's mode runs in the device-resident pipeline (the streaming kernels of simplex_deep.inc) unless --trim or
+    # --rejects ask for the general path; families outside their shape (indel / clipped anchors: a third of these groups) are deferred to it
+    on_device = not kw.get("trim") and not kw.get("track_rejects")
+    assert (LAST["meth_device"] == LAST["groups"] and 0 < LAST["deferred"] < LAST["groups"]) if on_device else LAST["meth_device"] == 0, LAST
+
+
+def test_simplex_mode_on_the_device_equals_the_general_path(monkeypatch):
+    """FGX_METH_DEVICE=0 sends the same batch through the general path: the same bytes, the oracle's."""
+    rng = methsim.seeded(401)
+    contigs = methsim.genome(rng)
+    groups = methsim.simplex_groups(rng, contigs, 900, depth=(1, 40), read_len=(30, 160))
+    o = fgx_opts.defaults(methylation_mode=1, min_reads=1)
+    same(o, contigs, groups)
+    assert LAST["meth_device"] == LAST["groups"], LAST
+    monkeypatch.setenv("FGX_METH_DEVICE", "0")
+    same(o, contigs, groups)
+    assert LAST["meth_device"] == 0, LAST
+
+
+def test_simplex_mode_in_the_device_resident_entry():
+    """fgx_process_batch_device with the mode on (simplex, a reference set): records in HBM in, records with MM / ML / cu / ct in HBM out; the
+    families the streaming kernels defer are named in the deferred list (here: none — plain reads only)."""
+    import random
+    rng = random.Random(5)
+    contig = bytes(rng.choice(b"ACGT") for _ in range(3000))
+    groups = []
+    for gi in range(400):
+        pos, L, n = rng.randrange(0, 2700), rng.choice([50, 100, 150]), rng.randrange(1, 12)
+        rev = gi % 3 == 0
+        reads = []
+        for i in range(n):
+            seq = bytearray(contig[pos:pos + L])
+            for j in range(L):
+                if seq[j] == (ord("G") if rev else ord("C")) and rng.random() < 0.7:
+                    seq[j] = ord("A") if rev else ord("T")                     # conversion on the read's own strand
+                if rng.random() < 0.01:
+                    seq[j] = rng.choice(b"ACGT")
+            reads.append(bamutil.make_record(f"g{gi}_{i}", seq.decode(), [rng.choice([8, 25, 37]) for _ in range(L)], flag=0x10 if rev else 0, ref_id=0, pos=pos,
+                                             tags=[("MI", "Z", str(gi)), ("RX", "Z", "ACGTAC")]))
+        groups.append(reads)
+    g = GroupedReads.from_groups(groups)
+    o = fgx_opts.defaults(min_reads=1, methylation_mode=1)
+    want = oracle(o, [contig], g)
+    assert b"MM" in want["data"]
+    c = VanillaUmiConsensusCaller("", "A", VanillaUmiConsensusOptions(min_reads=1, min_consensus_base_quality=2, cell_tag="CB", methylation_mode=MethylationMode.EmSeq),
+                                  overlapping_consensus=True)
+    c.set_reference({"chr1": contig}, ["chr1"])
+    out = c.process_batch_device(g.to_device())
+    assert out.n_deferred == 0 and out.to_host() == want["data"]
+    assert np.array_equal(np.array(c.last_stats_array, dtype=np.uint64), want["stats"])
+    assert lib.fgx_debug_last_meth_device(c._h) == g.n_grp
+    c.close()
 
 
 @pytest.mark.parametrize("mode,min_reads,kw", [
