@@ -213,7 +213,7 @@ struct FastPath {
   DevBuf d_big;                            // simplex families of more than 64 records: k_family's list, filled by the first kernel that sees them
   uint32_t last_big_families = 0;          // ... in the last batch
   uint32_t last_deep_families = 0;         // ... of which k_deep_parse + k_deep_cols (simplex_deep.inc) took
-  DevBuf d_deep_sizes, d_deep_row0, d_deep_rows, d_deep_fams, d_deep_out;
+  DevBuf d_deep_sizes, d_deep_row0, d_deep_rows, d_deep_fams, d_deep_out, d_deep_out2;
   DevBuf d_mflag, d_mu, d_mt, d_mslot, d_mcontigs;   // methylation-aware mode: per-column annotation, per-slot tag sizes, the contig table
   uint32_t last_meth_device = 0;           // families of the last batch that the device pipeline decided in the methylation-aware mode
   uint32_t last_routed = 0;                // families the split pipeline handed to the k_simplex_wave2 chain in the last batch

@@ -3475,7 +3475,7 @@ __global__ void k_reduce_stats(const unsigned long long* __restrict__ slots, uns
 void FastPath::release() {
   for (DevBuf* b : {&d_ends, &d_sizes, &d_offsets, &d_code, &d_qual, &d_depth, &d_err, &d_misc, &d_deferred, &d_out, &d_scan_tmp, &d_strings, &d_obs, &d_retry2,
                     &d_retry, &d_bound, &d_colbase, &d_statslots, &d_full_items, &d_full_count, &d_retry_old, &d_w2img, &d_famdesc, &d_fwimg,
-                    &d_split_rec, &d_split_fam, &d_split_out, &d_route, &d_s2img, &d_dir_size, &d_dir_off, &d_dir_base, &d_slot_desc, &d_slot_err, &d_out2, &d_scan_tmp2, &d_big, &d_deep_sizes, &d_deep_row0, &d_deep_rows, &d_deep_fams, &d_deep_out, &d_mflag, &d_mu, &d_mt, &d_mslot, &d_mcontigs})
+                    &d_split_rec, &d_split_fam, &d_split_out, &d_route, &d_s2img, &d_dir_size, &d_dir_off, &d_dir_base, &d_slot_desc, &d_slot_err, &d_out2, &d_scan_tmp2, &d_big, &d_deep_sizes, &d_deep_row0, &d_deep_rows, &d_deep_fams, &d_deep_out, &d_deep_out2, &d_mflag, &d_mu, &d_mt, &d_mslot, &d_mcontigs})
     b->free_();
   for (int i = 0; i < 4; i++) if (ev[i]) { (void)hipEventDestroy(ev[i]); ev[i] = nullptr; }
   if (s2) {
@@ -3975,36 +3975,55 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
         delete img;
       }
       P.s2_image = d_s2img.p;
-      d_deep_sizes.reserve((size_t)n_big * 8 + 64); d_deep_row0.reserve((size_t)n_big * 8 + 64);
-      hipLaunchKernelGGL(k_deep_sizes, dim3((n_big + 255) / 256), dim3(256), 0, s, d_big.as<uint32_t>(), n_big, d_grp_first, d_deep_sizes.as<uint64_t>());
-      size_t tb = 0;
-      (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_deep_sizes.as<uint64_t>(), d_deep_row0.as<uint64_t>(), (int)n_big, s);
-      d_scan_tmp.reserve(tb);
-      hip_check(hipcub::DeviceScan::ExclusiveSum(d_scan_tmp.p, tb, d_deep_sizes.as<uint64_t>(), d_deep_row0.as<uint64_t>(), (int)n_big, s), "scan of the deep families' records");
-      uint64_t lastr[2] = {0, 0};
-      hip_check(hipMemcpyAsync(&lastr[0], d_deep_row0.as<uint64_t>() + (n_big - 1), 8, hipMemcpyDeviceToHost, s), "D2H");
-      hip_check(hipMemcpyAsync(&lastr[1], d_deep_sizes.as<uint64_t>() + (n_big - 1), 8, hipMemcpyDeviceToHost, s), "D2H");
-      hip_check(hipStreamSynchronize(s), "sync");
-      const uint64_t n_rows = lastr[0] + lastr[1];
-      if (n_rows > (uint64_t)n_rec) throw std::runtime_error("device pipeline: " + std::to_string(n_rows) + " rows for the streaming kernels, more than the batch has records");
-      d_deep_rows.reserve((size_t)n_rows * sizeof(DeepRow) + 64); d_deep_fams.reserve((size_t)n_big * sizeof(DeepFam) + 64); d_deep_out.reserve((size_t)n_big * 4 + 64);
       uint32_t* d_cnt_deep = (uint32_t*)(misc + 38);
-      DeepParams DP;
-      DP.list = d_big.as<uint32_t>(); DP.n_list = n_big; DP.row0 = d_deep_row0.as<uint64_t>();
-      DP.rows = d_deep_rows.as<DeepRow>(); DP.fams = d_deep_fams.as<DeepFam>(); DP.out_list = d_deep_out.as<uint32_t>(); DP.n_out = d_cnt_deep;
-      FastParams PD = P;
-      PD.group_list = nullptr;
-      hipLaunchKernelGGL(k_deep_parse, dim3(n_big), dim3(DEEP_NT), 0, s, PD, DP);
-      hip_check(hipGetLastError(), "k_deep_parse launch");
-      if (meth_dev) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_deep_cols<1>), dim3((n_big + 3) / 4), dim3(256), 0, s, PD, DP);
-      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_deep_cols<0>), dim3((n_big + 3) / 4), dim3(256), 0, s, PD, DP);
-      hip_check(hipGetLastError(), "k_deep_cols launch");
-      uint32_t n_left = 0;
-      hip_check(hipMemcpyAsync(&n_left, d_cnt_deep, 4, hipMemcpyDeviceToHost, s), "D2H");
-      hip_check(hipStreamSynchronize(s), "sync");
-      last_deep_families = n_big - n_left;
-      big_list = d_deep_out.as<uint32_t>(); n_big = n_left;
-      if (meth_dev) { last_meth_device = n_grp; n_big = 0; }   // (what the streaming kernels refused is on the deferred list: the general path's)
+      // one pass of the streaming kernels over a family list; returns how many families it handed on (to `out_list`)
+      auto deep_pass = [&](const uint32_t* list, uint32_t n_list, bool small, uint32_t* out_list) -> uint32_t {
+        d_deep_sizes.reserve((size_t)n_list * 8 + 64); d_deep_row0.reserve((size_t)n_list * 8 + 64);
+        hipLaunchKernelGGL(k_deep_sizes, dim3((n_list + 255) / 256), dim3(256), 0, s, list, n_list, d_grp_first, d_deep_sizes.as<uint64_t>());
+        size_t tb = 0;
+        (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_deep_sizes.as<uint64_t>(), d_deep_row0.as<uint64_t>(), (int)n_list, s);
+        d_scan_tmp.reserve(tb);
+        hip_check(hipcub::DeviceScan::ExclusiveSum(d_scan_tmp.p, tb, d_deep_sizes.as<uint64_t>(), d_deep_row0.as<uint64_t>(), (int)n_list, s), "scan of the deep families' records");
+        uint64_t lastr[2] = {0, 0};
+        hip_check(hipMemcpyAsync(&lastr[0], d_deep_row0.as<uint64_t>() + (n_list - 1), 8, hipMemcpyDeviceToHost, s), "D2H");
+        hip_check(hipMemcpyAsync(&lastr[1], d_deep_sizes.as<uint64_t>() + (n_list - 1), 8, hipMemcpyDeviceToHost, s), "D2H");
+        hip_check(hipStreamSynchronize(s), "sync");
+        const uint64_t n_rows = lastr[0] + lastr[1];
+        if (n_rows > (uint64_t)n_rec) throw std::runtime_error("device pipeline: " + std::to_string(n_rows) + " rows for the streaming kernels, more than the batch has records");
+        d_deep_rows.reserve((size_t)n_rows * sizeof(DeepRow) + 64); d_deep_fams.reserve((size_t)n_list * sizeof(DeepFam) + 64);
+        hip_check(hipMemsetAsync(d_cnt_deep, 0, 4, s), "memset");
+        DeepParams DP;
+        DP.list = list; DP.n_list = n_list; DP.row0 = d_deep_row0.as<uint64_t>();
+        DP.rows = d_deep_rows.as<DeepRow>(); DP.fams = d_deep_fams.as<DeepFam>(); DP.out_list = out_list; DP.n_out = d_cnt_deep;
+        FastParams PD = P;
+        PD.group_list = nullptr;
+        if (small) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_deep_parse<64, 64>), dim3(n_list), dim3(64), 0, s, PD, DP);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_deep_parse<256, DEEP_MAX>), dim3(n_list), dim3(256), 0, s, PD, DP);
+        hip_check(hipGetLastError(), "k_deep_parse launch");
+        if (meth_dev) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_deep_cols<1>), dim3((n_list + 3) / 4), dim3(256), 0, s, PD, DP);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_deep_cols<0>), dim3((n_list + 3) / 4), dim3(256), 0, s, PD, DP);
+        hip_check(hipGetLastError(), "k_deep_cols launch");
+        uint32_t n_left = 0;
+        hip_check(hipMemcpyAsync(&n_left, d_cnt_deep, 4, hipMemcpyDeviceToHost, s), "D2H");
+        hip_check(hipStreamSynchronize(s), "sync");
+        return n_left;
+      };
+      d_deep_out.reserve((size_t)n_big * 4 + 64);
+      if (meth_dev) {
+        // every family: the wavefront-sized build of the record kernel first, the workgroup-sized one for the families above 64 records;
+        // what neither takes is on the deferred list (the general path knows the mode)
+        const uint32_t n_large = deep_pass(d_big.as<uint32_t>(), n_big, true, d_deep_out.as<uint32_t>());
+        if (n_large) {
+          d_deep_out2.reserve((size_t)n_large * 4 + 64);
+          (void)deep_pass(d_deep_out.as<uint32_t>(), n_large, false, d_deep_out2.as<uint32_t>());
+        }
+        last_deep_families = n_big;
+        last_meth_device = n_grp; n_big = 0;
+      } else {
+        const uint32_t n_left = deep_pass(d_big.as<uint32_t>(), n_big, false, d_deep_out.as<uint32_t>());
+        last_deep_families = n_big - n_left;
+        big_list = d_deep_out.as<uint32_t>(); n_big = n_left;
+      }
     }
     // more than 64 records (the list the first kernels filled), or more bytes than the largest slice (what the chain left): one workgroup per family
     for (int pass = 0; pass < 2 && !duplex && !codec; pass++) {
@@ -4053,7 +4072,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
     }
   }
   if (meth_dev) {   // the methylation tags' share of the record sizes: the consensus bases are final now
-    hipLaunchKernelGGL(k_meth_sizes, dim3((n_slots + 255) / 256), dim3(256), 0, s, P, n_slots, d_mslot.as<MethSlot>());
+    hipLaunchKernelGGL(k_meth_sizes, dim3((n_slots + 3) / 4), dim3(256), 0, s, P, n_slots, d_mslot.as<MethSlot>());
     hip_check(hipGetLastError(), "k_meth_sizes launch");
   }
   // ---- direct records: cE of the records whose columns had errors; did every prediction hold; is there anything to merge? ----------
@@ -4151,7 +4170,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
   } else hipLaunchKernelGGL(k_emit, dim3((n_grp + 3) / 4), dim3(256), 0, s, E);   // one wavefront per family (slots 3g .. 3g + 2)
   hip_check(hipGetLastError(), "k_emit launch");
   if (meth_dev) {
-    hipLaunchKernelGGL(k_meth_tail, dim3((n_slots + 255) / 256), dim3(256), 0, s, P, n_slots, d_mslot.as<MethSlot>(), d_offsets.as<uint64_t>(), out_ptr);
+    hipLaunchKernelGGL(k_meth_tail, dim3((n_slots + 3) / 4), dim3(256), 0, s, P, n_slots, d_mslot.as<MethSlot>(), d_offsets.as<uint64_t>(), out_ptr);
     hip_check(hipGetLastError(), "k_meth_tail launch");
   }
   hip_check(hipEventRecord(ev[3], s), "event");
