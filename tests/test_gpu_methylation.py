@@ -265,9 +265,9 @@ def test_python_mirror_of_set_reference():
 
 
 def test_run_bam_with_the_methylation_aware_mode(tmp_path):
-    """BAM file in, consensus BAM file out with `--methylation-mode em-seq` (simplex.rs:240-245): the streaming pipeline sends every batch of
-    such a caller through the host entry (the annotation runs on the general path) — same records as the oracle's, MM / ML / cu / ct included,
-    over one chunk and over many."""
+    """BAM file in, consensus BAM file out with `--methylation-mode em-seq` (simplex.rs:240-245): since round 4 the streaming pipeline keeps
+    such a caller's batches on the device (the streaming kernels of simplex_deep.inc; the families they defer are resubmitted to the general
+    path) — same records as the oracle's, MM / ML / cu / ct included, over one chunk and over many."""
     from fgumi_amd import bgzf
     rng = methsim.seeded(77)
     contigs = methsim.genome(rng, n_contigs=3, length=4000)
