@@ -76,6 +76,8 @@ int FastPath::run(fgx_caller* c, const uint8_t* blob, uint64_t blob_len, const u
     if (!h) throw std::runtime_error(std::string("apiemu helper caller: ") + fgx_global_error());
   }
   h->opt.track_rejects = 0;
+  h->genome = c->genome;                          // (methylation-aware mode, round 4: the simplex caller's batches come through here)
+  last_meth_device = (c->opt.methylation_mode != FGX_METHYLATION_DISABLED && c->genome) ? n_grp : 0u;   // (what the real pipeline reports: every family on the streaming kernels)
   const char* mode_s = getenv("APIEMU_DEFER");
   const std::string mode = mode_s ? mode_s : "indel";
   std::vector<uint32_t> def;
@@ -83,7 +85,7 @@ int FastPath::run(fgx_caller* c, const uint8_t* blob, uint64_t blob_len, const u
   std::vector<uint32_t> k_len, k_grp(1, 0), kept;
   for (uint32_t g = 0; g < n_grp; g++) {
     const uint32_t r0 = grp_first[g], r1 = grp_first[g + 1];
-    bool d = r1 == r0 || r1 - r0 > 128;
+    bool d = r1 == r0 || r1 - r0 > 510;             // (the real pipeline: up to 255 retained reads per end since round 4 — simplex_deep.inc; 128 records before)
     if (mode != "none")
       for (uint32_t r = r0; r < r1 && !d; r++) {
         if (rec_len[r] < 32 || rec_off[r] + rec_len[r] > blob_len) { d = true; break; }
