@@ -1,7 +1,8 @@
 #!/bin/bash
 # usage: bash tools/gpu_meth_bench.sh <tag> — methylation / deep tests, then the device methylation bench under rocprofv3 (kernel stats)
 TAG=$1; R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT; cd $R
-bash tools/gpu_meth.sh $TAG
+timeout 1500 python -m pytest tests/test_gpu_methylation.py tests/test_gpu_deep_families.py -m gpu -q -p no:cacheprovider -rfEs --timeout 900 > $OUT/pytest_meth.log 2>&1; echo "pytest rc=$?"
+grep -E "passed|failed|^FAILED|^ERROR|^E  " $OUT/pytest_meth.log | head -40
 cd /tmp; export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o meth -- python $R/tools/bench_methylation_device.py --steps 3 > $OUT/meth_bench.log 2>&1
 grep '^{' $OUT/meth_bench.log | cut -c1-900
