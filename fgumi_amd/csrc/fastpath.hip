@@ -3440,12 +3440,29 @@ __global__ void k_col_bound(const uint32_t* __restrict__ grp_first, const uint32
   {
     uint32_t mine = 0;
     if (g < n_grp) { const uint32_t n = grp_first[g + 1] - grp_first[g]; mine = (grp_first[g + 1] >= grp_first[g] && n <= 64u) ? n : 0u; }
+    // one global atomic per WORKGROUP (a wavefront's sum goes through LDS first): 78 k same-address atomics per 5 M families were most of this kernel's 1 ms
+    __shared__ unsigned int s_tot;
+    if (threadIdx.x == 0) s_tot = 0;
+    __syncthreads();
     const uint32_t tot = wave_sum(mine);
-    if ((threadIdx.x & 63) == 0 && tot) atomicAdd(small_recs, (unsigned long long)tot);
+    if ((threadIdx.x & 63) == 0 && tot) atomicAdd(&s_tot, tot);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_tot) atomicAdd(small_recs, (unsigned long long)s_tot);
   }
   if (g >= n_grp) return;
   uint32_t a = grp_first[g], b = grp_first[g + 1], mx = 0;
-  for (uint32_t r = a; r < b; r++) { uint32_t l = rec_len[r]; mx = l > mx ? l : mx; }
+  {   // the family's longest record: four lengths per load where the table allows it (a thread-per-family loop of single loads cost 1 ms per 80 M records)
+    uint32_t r = a;
+    if (((uintptr_t)rec_len & 15u) == 0) {
+      for (; r < b && (r & 3u); r++) { const uint32_t l = rec_len[r]; mx = l > mx ? l : mx; }
+      for (; r + 4 <= b; r += 4) {
+        const uint4 v = *(const uint4*)(rec_len + r);
+        const uint32_t m01 = v.x > v.y ? v.x : v.y, m23 = v.z > v.w ? v.z : v.w, m4 = m01 > m23 ? m01 : m23;
+        mx = m4 > mx ? m4 : mx;
+      }
+    }
+    for (; r < b; r++) { const uint32_t l = rec_len[r]; mx = l > mx ? l : mx; }
+  }
   uint32_t lb = mx > 33 ? (mx - 33) * 2 / 3 + 1 : 1;
   uint32_t ends = (b - a) < max_ends ? (b - a) : max_ends;
   bound[g] = (uint64_t)ends * lb;
@@ -3548,7 +3565,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
   last_meth_device = 0;
   const bool simplex_v2 = !duplex && !codec && !o.trim && use_v2 && !meth_dev;
   const bool seg4 = simplex_v2 && use_seg && mean_span + (16 * 8 + 64) <= seg_bytes / 4;
-  hipLaunchKernelGGL(k_col_bound, dim3((n_grp + 255) / 256), dim3(256), 0, s, d_grp_first, d_rec_len, d_rec_off, n_grp, d_bound.as<uint64_t>(), duplex ? 4u : codec ? 2u : 3u,
+  hipLaunchKernelGGL(k_col_bound, dim3((n_grp + 1023) / 1024), dim3(1024), 0, s, d_grp_first, d_rec_len, d_rec_off, n_grp, d_bound.as<uint64_t>(), duplex ? 4u : codec ? 2u : 3u,
                      d_famdesc.as<uint4>(), misc + 35);
   {
     size_t tb = 0;
