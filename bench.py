@@ -138,7 +138,7 @@ def end_to_end(caller, families, depth, read_length, directory):
     best = None
     for _ in range(2):
         t = time.perf_counter()
-        st = caller.run_bam(gin, gout, header_text=bgzf.consensus_header("A", "Read group", 0, "fgumi simplex"), chunk_raw_bytes=512 << 20)
+        st = caller.run_bam(gin, gout, header_text=bgzf.consensus_header("A", "Read group", 0, "fgumi simplex"), chunk_raw_bytes=int(os.environ.get("FGX_BENCH_E2E_CHUNK_MB", "512")) << 20)
         wall = time.perf_counter() - t
         if best is None or wall < best[0]:
             best = (wall, st)
