@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 F64_LANE_OPS_PER_S = 64 * 1024 * 2.4e9 / 4   # one f64 add per lane per 4 cycles, 1024 SIMDs at 2.4 GHz = 39.3 T/s
+E2E_CHUNK_MB = 128              # compressed bytes per chunk of the file -> file leg (FGX_BENCH_E2E_CHUNK_MB; tools/e2e_chunk_sweep.py)
 F64_OPS_PER_OBSERVATION = 8     # two Kahan chains (the base seen, any other base) x 4 dependent add/sub
 
 
@@ -116,16 +117,12 @@ def cpu_baseline(n_families, family_size, read_length, threads, duplex=False, co
                        f"compute-only (records in RAM -> per-batch ConsensusOutput bytes), batches of {bg} MI groups pulled by the worker threads")
 
 
-def end_to_end(caller, families, depth, read_length, directory):
-    """BAM file in -> consensus BAM file out through the streaming pipeline (fgx_run_bam: BGZF inflate + boundaries + MI grouping + consensus + block
-    CRCs on the device, level-1 deflate on the host cores, five overlapping stages) on a bounded file of the same workload: what a user of the
-    command sees, next to the device-resident `value`.  Best of two runs, input file in the page cache."""
+def write_grouped_bam(path, families, depth, read_length):
+    """The grouped input BAM of the file -> file leg (level-1 BGZF, 125 000 families per slab); returns its record count."""
     from fgumi_amd import bgzf, simulate_grouped_reads
-    os.makedirs(directory, exist_ok=True)
     refs = [(f"chr{i + 1}", 2147483647) for i in range(24)]
-    gin, gout = os.path.join(directory, "grouped.bam"), os.path.join(directory, "consensus.bam")
     n_rec, slab = 0, 125000
-    with open(gin, "wb") as f:
+    with open(path, "wb") as f:
         for b in bgzf.bgzf_compress(bgzf.bam_header_bytes(bgzf.grouped_input_header(refs), refs), 1, None):
             f.write(b)
         for lo in range(0, families, slab):
@@ -135,26 +132,44 @@ def end_to_end(caller, families, depth, read_length, directory):
             f.write(memoryview(nat[0]))
             del g, nat
         f.write(bgzf.BGZF_EOF)
+    return n_rec
+
+
+def end_to_end(caller, families, depth, read_length, directory, chunk_mb=None, grouped=None):
+    """BAM file in -> consensus BAM file out through the streaming pipeline (fgx_run_bam: BGZF inflate + boundaries + MI grouping + consensus + block
+    CRCs on the device, level-1 deflate on the host cores, five overlapping stages, several chunks on their way into the device at once) on a
+    bounded file of the same workload: what a user of the command sees, next to the device-resident `value`.  Best of two runs, input file in
+    the page cache.  `grouped` = (path, records) of an input written before (tools/e2e_chunk_sweep.py)."""
+    from fgumi_amd import bgzf
+    os.makedirs(directory, exist_ok=True)
+    gin, gout = os.path.join(directory, "grouped.bam"), os.path.join(directory, "consensus.bam")
+    if grouped:
+        gin, n_rec = grouped
+    else:
+        n_rec = write_grouped_bam(gin, families, depth, read_length)
+    if chunk_mb is None:
+        chunk_mb = int(os.environ.get("FGX_BENCH_E2E_CHUNK_MB", str(E2E_CHUNK_MB)))
     best = None
     for _ in range(2):
         t = time.perf_counter()
-        st = caller.run_bam(gin, gout, header_text=bgzf.consensus_header("A", "Read group", 0, "fgumi simplex"), chunk_raw_bytes=int(os.environ.get("FGX_BENCH_E2E_CHUNK_MB", "512")) << 20)
+        st = caller.run_bam(gin, gout, header_text=bgzf.consensus_header("A", "Read group", 0, "fgumi simplex"), chunk_raw_bytes=chunk_mb << 20)
         wall = time.perf_counter() - t
         if best is None or wall < best[0]:
             best = (wall, st)
     wall, st = best
-    for pth in (gin, gout):
+    for pth in (gout,) if grouped else (gin, gout):
         try:
             os.remove(pth)
         except OSError:
             pass
     stages = {k: st["seconds_" + k] for k in ("read", "inflate", "device", "deflate", "write")}
     return dict(metric="BAM file in -> consensus BAM file out (fgx_run_bam), raw reads/s", value=n_rec / wall, unit="raw reads/s", families=families, raw_reads=n_rec,
-                total_s=wall, chunks=int(st["chunks"]), stage_busy_s=stages, bottleneck=max(stages, key=stages.get),
+                total_s=wall, chunks=int(st["chunks"]), chunk_mb=chunk_mb, stage_busy_s=stages, bottleneck=max(stages, key=stages.get),
                 device_stage_s={k: st["seconds_" + k] for k in ("h2d", "device_inflate", "boundaries", "grouping", "consensus", "d2h")},
                 input_bam_bytes=int(st["in_bytes"]), input_uncompressed_bytes=int(st["inflated_bytes"]), output_bam_bytes=int(st["out_file_bytes"]),
                 consensus_records=int(st["consensus_records"]), deferred_groups=int(st["deferred_groups"]),
-                note="bounded sample of the same workload; stages of successive chunks overlap (total_s is below the sum of the busy times); host side = the cores the cgroup grants")
+                note="bounded sample of the same workload; stages of successive chunks overlap (total_s is below the sum of the busy times; the h2d / "
+                     "device_inflate times of chunks on their way in at once overlap one another); host side = the cores the cgroup grants")
 
 
 def pmc_profile(families, depth, read_length):
@@ -198,7 +213,7 @@ def main():
                     help="simplex only: long-tail family sizes in [depth, depth-max] pairs, count ~ size^-1.5 (BASELINE configs[3] shape: --depth 2 --depth-max 50)")
     ap.add_argument("--cpu-sample-families", type=int, default=320000, help="families of the multi-thread CPU leg (320000 x 16 = 5.12 M reads at depth 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--end-to-end-families", type=int, default=250000, help="N=1, simplex: families of the file -> file leg (`end_to_end` in the line); 0 skips it")
+    ap.add_argument("--end-to-end-families", type=int, default=1000000, help="N=1, simplex: families of the file -> file leg (`end_to_end` in the line); 0 skips it")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-strong-block", action="store_true", help="weak runs also time the strong-scaling reading (`strong_scaling` in the line); this skips it")
     ap.add_argument("--reassemble", choices=["auto", "none", "root"], default="auto",

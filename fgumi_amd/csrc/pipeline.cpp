@@ -226,7 +226,7 @@ uint64_t bam_header_size(const uint8_t* p, uint64_t n);
 
 // the five stages over a ring of chunks; `middle` turns chunk.inf into chunk.out (the device stage, or a copy)
 struct Pipeline {
-  static constexpr int N_CHUNKS = 3, N_STAGES = 5;
+  static constexpr int N_CHUNKS = 8, N_STAGES = 5;   // (N_CHUNKS: one chunk per stage + the chunks the device stage has on their way in, PipeState::NB - 1)
   Chunk chunks[N_CHUNKS];
   std::mutex m;
   std::condition_variable cv;
@@ -566,12 +566,18 @@ thread_local std::string t_perr;
 // what fgx_run_bam keeps between runs: the pinned chunk buffers and the device buffers (allocating 3 x ~1 GB of pinned memory takes
 // longer than a whole chunk's work)
 struct PipeState {
+  // A ring of NB stream buffers: chunk `seq` lives in D[seq % NB].  While the device stage works on one chunk, up to NB - 1 later chunks
+  // are on their way in, each on its OWN stream — the inflate kernel is a latency chain per BGZF block (bgzf_device.hip) that a single
+  // chunk's blocks do not fill the chip with, so the chunks' kernels run side by side, and the uploads run under them.
+  static constexpr int NB = 5;
   Pipeline P;
-  fgx::DevBuf D[2], d_off, d_len, d_koff, d_klen, d_grp, d_raw, d_blk, d_slots, d_dscratch, d_dmeta, d_packed, d_crcs;
-  uint64_t pad[2] = {0, 0};          // bytes of D[i] in front of a chunk's inflated stream: room for what the chunk before it leaves over
-  hipStream_t s_in = nullptr;        // uploads and inflates the NEXT chunk while the device stage works on this one
-  hipEvent_t ev_up0 = nullptr, ev_up1 = nullptr, ev_in = nullptr;   // upload begins / upload done / stream inflated and checked
-  uint32_t* h_status = nullptr;      // (pinned) the inflate kernels' status word
+  fgx::DevBuf D[NB], d_raw[NB], d_blk[NB], d_off, d_len, d_koff, d_klen, d_grp, d_slots, d_dscratch, d_dmeta, d_packed, d_crcs;
+  uint64_t pad[NB] = {0, 0, 0, 0, 0};   // bytes of D[i] in front of a chunk's inflated stream: room for what the chunk before it leaves over
+  uint64_t fill_len[NB] = {0, 0, 0, 0, 0};   // inflated bytes of the stream D[i] holds (or is being filled with)
+  hipStream_t s_in[NB] = {};          // uploads and inflates a LATER chunk while the device stage works on this one
+  hipEvent_t ev_up0[NB] = {}, ev_up1[NB] = {}, ev_in[NB] = {};   // upload begins / upload done / stream inflated and checked
+  uint32_t* h_status = nullptr;       // (pinned) the inflate kernels' status words, 16 words apart
+  uint32_t last_max_ahead = 0;        // (diagnostics) the most later chunks that were on their way at once in the last run
 };
 
 }  // namespace
@@ -580,9 +586,12 @@ namespace fgx {
 void pipeline_release(fgx_caller* c) {
   if (!c || !c->pipe_state) return;
   PipeState* S = (PipeState*)c->pipe_state;
-  for (auto* b : {&S->D[0], &S->D[1], &S->d_off, &S->d_len, &S->d_koff, &S->d_klen, &S->d_grp, &S->d_raw, &S->d_blk, &S->d_slots, &S->d_dscratch, &S->d_dmeta, &S->d_packed, &S->d_crcs}) b->free_();
-  if (S->s_in) { (void)hipStreamSynchronize(S->s_in); (void)hipStreamDestroy(S->s_in); }
-  for (hipEvent_t e : {S->ev_up0, S->ev_up1, S->ev_in}) if (e) (void)hipEventDestroy(e);
+  for (int i = 0; i < PipeState::NB; i++) {
+    if (S->s_in[i]) { (void)hipStreamSynchronize(S->s_in[i]); (void)hipStreamDestroy(S->s_in[i]); }
+    for (hipEvent_t e : {S->ev_up0[i], S->ev_up1[i], S->ev_in[i]}) if (e) (void)hipEventDestroy(e);
+    for (auto* b : {&S->D[i], &S->d_raw[i], &S->d_blk[i]}) b->free_();
+  }
+  for (auto* b : {&S->d_off, &S->d_len, &S->d_koff, &S->d_klen, &S->d_grp, &S->d_slots, &S->d_dscratch, &S->d_dmeta, &S->d_packed, &S->d_crcs}) b->free_();
   if (S->h_status) (void)hipHostFree(S->h_status);
   delete S;
   c->pipe_state = nullptr;
@@ -605,6 +614,8 @@ int fgx_bgzf_recompress_file(const char* in_path, const char* out_path, uint32_t
   return rc;
 }
 const char* fgx_pipeline_last_error(void) { return t_perr.c_str(); }
+// (diagnostics, tests) the most later chunks fgx_run_bam had on their way beside the one in its device stage, last run of this caller
+uint32_t fgx_debug_last_chunks_ahead(const fgx_caller* c) { return (c && c->pipe_state) ? ((const PipeState*)c->pipe_state)->last_max_ahead : 0u; }
 
 // The device's BGZF inflate (+ CRC-32 check) alone, for measurements and tests: the whole blocks of raw[0 .. raw_len) are uploaded once and
 // inflated `reps` times; *ms = average device time of one pass (HIP events), *inflated_len = bytes produced.  When `out` is given
@@ -687,14 +698,19 @@ int fgx_run_bam_rejects(fgx_caller* c, const char* in_path, const char* out_path
     PipeState* S = (PipeState*)c->pipe_state;
     fgx::DevBuf* D = S->D;
     fgx::DevBuf &d_off = S->d_off, &d_len = S->d_len, &d_koff = S->d_koff, &d_klen = S->d_klen, &d_grp = S->d_grp;
-    if (!S->s_in) {
-      fgx::hip_check(hipStreamCreateWithFlags(&S->s_in, hipStreamNonBlocking), "hipStreamCreate");
-      for (hipEvent_t* e : {&S->ev_up0, &S->ev_up1, &S->ev_in}) fgx::hip_check(hipEventCreate(e), "hipEventCreate");
-      fgx::hip_check(hipHostMalloc((void**)&S->h_status, 64, hipHostMallocDefault), "hipHostMalloc");
+    constexpr int NB = PipeState::NB;
+    if (!S->h_status) {
+      for (int i = 0; i < NB; i++) {
+        fgx::hip_check(hipStreamCreateWithFlags(&S->s_in[i], hipStreamNonBlocking), "hipStreamCreate");
+        for (hipEvent_t* e : {&S->ev_up0[i], &S->ev_up1[i], &S->ev_in[i]}) fgx::hip_check(hipEventCreate(e), "hipEventCreate");
+      }
+      fgx::hip_check(hipHostMalloc((void**)&S->h_status, 64 * NB, hipHostMallocDefault), "hipHostMalloc");
     }
+    // chunks on their way in beside the one in the device stage (FGX_PIPE_AHEAD = 1 .. NB - 1: a measuring knob)
+    const uint64_t max_ahead = [] { const char* e = getenv("FGX_PIPE_AHEAD"); const int v = e ? atoi(e) : 0; return (uint64_t)((v >= 1 && v < NB) ? v : NB - 1); }();
     // Layout of D[i]: [ front pad | the chunk's inflated stream | slack ].  What a chunk leaves over (its last MI group and the
     // partial record behind it) is copied to the END of the other buffer's pad, so the next chunk's stream can be uploaded and
-    // inflated to a fixed place BEFORE that length is known — on s_in, under this chunk's boundaries / grouping / consensus / download.
+    // inflated to a fixed place BEFORE that length is known — on s_in[.], under this chunk's boundaries / grouping / consensus / download.
     const uint64_t FRONT_PAD = [] { const char* e = getenv("FGX_FRONT_PAD"); const long long v = e ? atoll(e) : 0; return v >= 256 ? ((uint64_t)v + 255) & ~255ull : 8ull << 20; }();   // (the variable: for the test of the widening path)
     uint64_t left_len = 0;                 // bytes the previous chunk left in front of D[cur]'s stream
     int cur = 0;
@@ -703,15 +719,14 @@ int fgx_run_bam_rejects(fgx_caller* c, const char* in_path, const char* out_path
     const bool device_inflate = !(flags & FGX_RUN_HOST_INFLATE);
     const bool device_deflate = (flags & FGX_RUN_DEVICE_DEFLATE) != 0 && level == 1;
     double sec_defl = 0;
-    fgx::DevBuf &d_raw = S->d_raw, &d_blk = S->d_blk;
     std::vector<uint8_t> h_blob; std::vector<uint64_t> h_off; std::vector<uint32_t> h_len, h_grp;   // (only for chunks with deferred families)
     Pipeline* P = &S->P;
     P->reset();
     const bool want_rej = rejects_path != nullptr;
     if (want_rej) P->rej_path = rejects_path;
     uint64_t n_rejected = 0;
-    bool ahead = false;                    // the chunk after the one in the device stage is already on its way into D[cur ^ 1]
-    uint64_t ahead_seq = 0, ahead_inf_len = 0;
+    S->last_max_ahead = 0;
+    uint64_t n_filled = 0;                 // chunks 0 .. n_filled - 1 are in their buffers or on their way (chunk q into D[q % NB])
     // room for a stream of inf_len bytes behind the pad of D[buf]; `preserve` bytes at the end of the pad survive a regrowth
     auto ensure_room = [&](int buf, uint64_t inf_len, uint64_t preserve) {
       if (!S->pad[buf] || !D[buf].cap) S->pad[buf] = FRONT_PAD;
@@ -733,44 +748,65 @@ int fgx_run_bam_rejects(fgx_caller* c, const char* in_path, const char* out_path
       S->pad[buf] = new_pad;
     };
     // chunk `ch` into D[buf]: the compressed bytes and block descriptors over PCIe, DEFLATE + CRC-32 on the device (or, with
-    // FGX_RUN_HOST_INFLATE, the inflated bytes over PCIe) — queued on s_in, ev_in marks the end
+    // FGX_RUN_HOST_INFLATE, the inflated bytes over PCIe) — queued on the buffer's own stream, ev_in[buf] marks the end
     auto launch_fill = [&](Chunk& ch, int buf, uint64_t preserve) {
       ensure_room(buf, ch.inf_len, preserve);
+      S->fill_len[buf] = ch.inf_len;
       uint8_t* dst = (uint8_t*)D[buf].p + S->pad[buf];
-      hipStream_t si = S->s_in;
-      fgx::hip_check(hipEventRecord(S->ev_up0, si), "hipEventRecord");
+      hipStream_t si = S->s_in[buf];
+      uint32_t* const h_status = S->h_status + 16 * buf;
+      fgx::DevBuf &d_raw = S->d_raw[buf], &d_blk = S->d_blk[buf];
+      fgx::hip_check(hipEventRecord(S->ev_up0[buf], si), "hipEventRecord");
       if (device_inflate) {
         const size_t blk_bytes = ch.dev_blocks.size() * sizeof(fgx::BgzfDevBlock);
         d_raw.reserve(ch.raw_len + 64);
         d_blk.reserve(blk_bytes + 64 + 16);
         fgx::hip_check(hipMemcpyAsync(d_raw.p, ch.inf.p, ch.raw_len + 64, hipMemcpyHostToDevice, si), "H2D compressed chunk");
         if (blk_bytes) fgx::hip_check(hipMemcpyAsync(d_blk.p, ch.dev_blocks.data(), blk_bytes, hipMemcpyHostToDevice, si), "H2D block table");
-        fgx::hip_check(hipEventRecord(S->ev_up1, si), "hipEventRecord");
+        fgx::hip_check(hipEventRecord(S->ev_up1[buf], si), "hipEventRecord");
         fgx::bgzf_inflate_launch(si, d_raw.as<uint8_t>(), d_blk.as<fgx::BgzfDevBlock>(), (uint32_t)ch.dev_blocks.size(), dst,
-                                 (uint32_t*)((uint8_t*)d_blk.p + ((blk_bytes + 15) & ~(size_t)15)), S->h_status);
+                                 (uint32_t*)((uint8_t*)d_blk.p + ((blk_bytes + 15) & ~(size_t)15)), h_status);
       } else {
-        *S->h_status = 0;
+        *h_status = 0;
         if (ch.inf_len) fgx::hip_check(hipMemcpyAsync(dst, ch.inf.p, ch.inf_len, hipMemcpyHostToDevice, si), "H2D chunk");
-        fgx::hip_check(hipEventRecord(S->ev_up1, si), "hipEventRecord");
+        fgx::hip_check(hipEventRecord(S->ev_up1[buf], si), "hipEventRecord");
       }
-      fgx::hip_check(hipEventRecord(S->ev_in, si), "hipEventRecord");
+      fgx::hip_check(hipEventRecord(S->ev_in[buf], si), "hipEventRecord");
     };
-    const int rc = P->run(in_path, out_path, out_header, out_header_len, threads, level, chunk_raw_bytes ? chunk_raw_bytes : (512ull << 20), true, device_inflate,
+    const int rc = P->run(in_path, out_path, out_header, out_header_len, threads, level, chunk_raw_bytes ? chunk_raw_bytes : (128ull << 20), true, device_inflate,
                           [&](Chunk& ch, uint64_t seq) {
       fgx::hip_check(hipSetDevice(c->device), "hipSetDevice");
       ch.out_len = 0; ch.packed_len = 0; ch.precompressed = false; ch.have_crcs = false;
-      // ---- this chunk's stream: started while the chunk before was worked on, or now ----
-      if (!(ahead && ahead_seq == seq)) launch_fill(ch, cur, left_len);
-      ahead = false;
-      fgx::hip_check(hipEventSynchronize(S->ev_in), "hipEventSynchronize");
+      // ---- this chunk's stream: started while an earlier chunk was worked on, or now ----
+      cur = (int)(seq % NB);
+      if (n_filled <= seq) { launch_fill(ch, cur, left_len); n_filled = seq + 1; }
+      // ---- the next chunks, as soon as the host stages have them ready: upload + inflate under everything below ----
+      auto try_ahead = [&] {
+        while (!ch.last && n_filled <= seq + max_ahead && P->staged(n_filled)) {
+          Chunk& nx = P->chunks[n_filled % Pipeline::N_CHUNKS];
+          launch_fill(nx, (int)(n_filled % NB), 0);
+          n_filled++;
+          if (n_filled - 1 - seq > S->last_max_ahead) S->last_max_ahead = (uint32_t)(n_filled - 1 - seq);
+          if (nx.last) break;
+        }
+      };
+      // (the wait for this chunk's stream polls: a chunk the host stages deliver meanwhile starts at once, not when this wait ends)
+      for (;;) {
+        const hipError_t q = hipEventQuery(S->ev_in[cur]);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) fgx::hip_check(q, "hipEventQuery");
+        try_ahead();
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+      }
       {
+        // (with several chunks on their way these are the chunk's OWN upload and inflate times: they overlap one another's)
         float ms_up = 0, ms_in = 0;
-        fgx::hip_check(hipEventElapsedTime(&ms_up, S->ev_up0, S->ev_up1), "hipEventElapsedTime");
-        fgx::hip_check(hipEventElapsedTime(&ms_in, S->ev_up1, S->ev_in), "hipEventElapsedTime");
+        fgx::hip_check(hipEventElapsedTime(&ms_up, S->ev_up0[cur], S->ev_up1[cur]), "hipEventElapsedTime");
+        fgx::hip_check(hipEventElapsedTime(&ms_in, S->ev_up1[cur], S->ev_in[cur]), "hipEventElapsedTime");
         sec_h2d += ms_up * 1e-3;
         if (device_inflate) sec_infl += ms_in * 1e-3;
       }
-      if (fgx::bgzf_inflate_status(c, *S->h_status) != 0) throw std::runtime_error(c->err);
+      if (fgx::bgzf_inflate_status(c, S->h_status[16 * cur]) != 0) throw std::runtime_error(c->err);
       uint64_t h = 0;
       if (!header_done) {
         h = device_inflate ? ch.header_size : bam_header_size(ch.inf.p, ch.inf_len);
@@ -790,13 +826,6 @@ int fgx_run_bam_rejects(fgx_caller* c, const char* in_path, const char* out_path
         P->rej_header.resize(h);
         fgx::hip_check(hipMemcpy(P->rej_header.data(), base + (lead - base_off), h, hipMemcpyDeviceToHost), "D2H header");
       }
-      // ---- the next chunk, if the host stages have it ready: upload + inflate under everything below ----
-      auto try_ahead = [&] {
-        if (ahead || ch.last || !P->staged(seq + 1)) return;
-        Chunk& nx = P->chunks[(seq + 1) % Pipeline::N_CHUNKS];
-        launch_fill(nx, cur ^ 1, 0);
-        ahead = true; ahead_seq = seq + 1; ahead_inf_len = nx.inf_len;
-      };
       try_ahead();
       auto t0 = Clock::now();
       // ---- record boundaries ----
@@ -931,15 +960,15 @@ int fgx_run_bam_rejects(fgx_caller* c, const char* in_path, const char* out_path
         st->groups += batch_grp;
         st->kept_records += batch_rec;
       }
-      // ---- what stays behind moves in front of the other buffer's stream ----
+      // ---- what stays behind moves in front of the next buffer's stream ----
       const uint64_t keep = total - batch_end;
-      const int nb = cur ^ 1;
+      const int nb = (int)((seq + 1) % NB);
       if (!ch.last) {
         try_ahead();
-        if (ahead) {
+        if (n_filled > seq + 1) {                                // (the next chunk is in D[nb] or on its way)
           if (keep > S->pad[nb]) {                               // (an enormous last group: wait for the stream, move it behind a wider pad)
-            fgx::hip_check(hipEventSynchronize(S->ev_in), "hipEventSynchronize");
-            widen_pad(nb, keep, ahead_inf_len, ahead_inf_len);   // (`ahead` stays: the stream is in place, its events have fired)
+            fgx::hip_check(hipEventSynchronize(S->ev_in[nb]), "hipEventSynchronize");
+            widen_pad(nb, keep, S->fill_len[nb], S->fill_len[nb]);   // (the stream stays in place, its events have fired)
           }
         } else {
           if (!S->pad[nb] || !D[nb].cap) S->pad[nb] = FRONT_PAD;
@@ -949,10 +978,10 @@ int fgx_run_bam_rejects(fgx_caller* c, const char* in_path, const char* out_path
         if (keep) fgx::hip_check(hipMemcpyAsync((uint8_t*)D[nb].p + S->pad[nb] - keep, base + batch_end, keep, hipMemcpyDeviceToDevice, s), "D2D leftover");
       }
       fgx::hip_check(hipStreamSynchronize(s), "sync");
-      left_len = keep; cur ^= 1;
+      left_len = keep;
       st->chunks = seq + 1;
     });
-    (void)hipStreamSynchronize(S->s_in);   // (a failed run may leave the next chunk's upload in flight)
+    for (int i = 0; i < NB; i++) (void)hipStreamSynchronize(S->s_in[i]);   // (a failed run may leave later chunks' uploads in flight)
     st->in_bytes = P->in_bytes; st->inflated_bytes = P->inflated_bytes; st->out_bytes = P->out_bytes; st->out_file_bytes = P->out_file_bytes;
     st->seconds_read = P->busy[0]; st->seconds_inflate = P->busy[1]; st->seconds_device = P->busy[2]; st->seconds_deflate = P->busy[3]; st->seconds_write = P->busy[4];
     st->seconds_device_inflate = sec_infl; st->device_inflate = device_inflate ? 1u : 0u;

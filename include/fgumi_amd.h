@@ -379,7 +379,9 @@ int fgx_record_boundaries_device(fgx_caller* c, const void* d_stream, uint64_t s
 
 /* A BAM file in, a consensus BAM file out (fgumi_amd/csrc/pipeline.cpp): read -> BGZF inflate (worker pool, pinned buffers) ->
  * upload -> record boundaries -> MI grouping -> consensus batch -> download -> BGZF deflate -> write, as five overlapping stages
- * over chunks of `chunk_raw_bytes` compressed bytes (0 = 512 MiB: the device inflate runs a lane per BGZF block, so a chunk should hold tens of thousands of them).  Stands in, for this path, for the reader / FindBoundaries /
+ * over chunks of `chunk_raw_bytes` compressed bytes (0 = 128 MiB; the device inflate runs a lane per BGZF block and one chunk's blocks
+ * do not fill the chip, so up to four later chunks are uploaded and inflated, each on its own stream, while the device stage works on
+ * one — FGX_PIPE_AHEAD=1..4).  Stands in, for this path, for the reader / FindBoundaries /
  * group / process / compress / write steps of src/lib/unified_pipeline/bam.rs around `process_fn`.  `out_header` = the
  * uncompressed BAM header of the output ("BAM\1", l_text, text, n_ref = 0): written as its own BGZF block(s).  A group that
  * reaches the end of a chunk waits for the next chunk (it may continue there).  `threads` = pool size (0 = all cores).
@@ -391,7 +393,8 @@ typedef struct fgx_bam_run_stats {
   double seconds_total;
   double seconds_read, seconds_inflate, seconds_device, seconds_deflate, seconds_write;     /* busy time of the five stage threads */
   double seconds_h2d, seconds_boundaries, seconds_grouping, seconds_consensus, seconds_d2h; /* inside the device stage */
-  double seconds_device_inflate;                                                            /* inside the device stage (0 with FGX_RUN_HOST_INFLATE) */
+  double seconds_device_inflate;                                                            /* inside the device stage (0 with FGX_RUN_HOST_INFLATE); h2d and this one are sums of
+                                                                                               every chunk's own upload / inflate time: chunks on their way in at once overlap */
   uint32_t boundary_repair_rounds, device_inflate;
   double seconds_device_deflate;                                                            /* inside the device stage (FGX_RUN_DEVICE_DEFLATE) */
   uint32_t device_deflate, _pad;

@@ -49,6 +49,7 @@ hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
 }
 
