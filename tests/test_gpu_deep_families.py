@@ -129,3 +129,29 @@ def test_an_end_of_more_than_255_reads_leaves_the_streaming_kernels():
     assert out.data == want["data"]
     assert lib.fgx_debug_last_big_families(c._h) == 12 and lib.fgx_debug_last_deep_families(c._h) == 0
     c.close()
+
+
+def _with_low_qualities(g, every=37, values=(0, 1, 2, 0, 5)):
+    """The batch with every `every`-th quality byte of every record replaced by one of `values` (in place of the simulator's 30 - 40)."""
+    import dataclasses
+    blob = np.array(g.blob, copy=True)
+    k = 0
+    for o in np.asarray(g.rec_off, dtype=np.int64):          # (rec_off: the record's body, behind its block_size)
+        l_name, n_cig, l_seq = int(blob[o + 8]), int(blob[o + 12]) | (int(blob[o + 13]) << 8), int(blob[o + 16:o + 20].view(np.uint32)[0])
+        q0 = o + 32 + l_name + 4 * n_cig + (l_seq + 1) // 2
+        for i in range(every - 1 - (k % 7), l_seq, every):      # (never 0xFF in the first byte: that would mean "no qualities")
+            blob[q0 + i] = values[k % len(values)]
+            k += 1
+    assert k > 0
+    return dataclasses.replace(g, blob=blob)
+
+
+@pytest.mark.parametrize("min_bq", [0, 1, 3])
+def test_quality_zero_observations_when_the_quality_floor_admits_them(min_bq):
+    """`correct[0]` is ln 0 = -inf (phred 0: the base is wrong with certainty).  With --min-input-base-quality 0 such a base IS an
+    observation: the reference's sums become -inf and call_full decides.  The split pipeline's f32 table holds a finite stand-in for
+    that entry (its sums are built with multiply-adds: 0 x inf would poison every column that merely SEES a quality 0 below the floor);
+    a column that adds it fails every gate and is recomputed exactly by k_call_full.  Floors 1 and 3: the same bytes are below the floor."""
+    g = _with_low_qualities(simulate_grouped_reads(1500, family_size=2, family_size_max=12, error_rate_ppm=2000))
+    path = _run(g, dict(min_input_base_quality=min_bq), dict(min_input_base_quality=min_bq))
+    assert path["chunks"] >= 1 and path["deferred"] == 0, path
