@@ -246,9 +246,20 @@ __device__ __forceinline__ void wave_sync() {
 }
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }   // v is the same in every lane: say so
 __device__ __forceinline__ uint32_t rlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
-__device__ __forceinline__ uint32_t wave_max(uint32_t v) { for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_xor(v, o); v = t > v ? t : v; } return v; }
-__device__ __forceinline__ uint32_t wave_min(uint32_t v) { for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_xor(v, o); v = t < v ? t : v; } return v; }
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
+// Wavefront reductions of a 32-bit value through the data-parallel primitives of the vector ALU: quad swap, quad-pair swap, half-row mirror,
+// row mirror (every lane of a row of 16 then holds the row's result), row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3 — six
+// instructions, each with its operation folded in, the total in lane 63, returned as a scalar.  (A butterfly of __shfl_xor is six LDS
+// permutes + six operations + their addresses.)  `idn` = the operation's identity: what a lane outside a step's row mask contributes.
+template <int CTRL, int ROWS> __device__ __forceinline__ uint32_t wave_dpp(uint32_t idn, uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)idn, (int)v, CTRL, ROWS, 0xF, false); }
+#define FGX_WAVE_REDUCE(v, idn, OP) do { \
+    v = OP(v, wave_dpp<0xB1, 0xF>(idn, v)); v = OP(v, wave_dpp<0x4E, 0xF>(idn, v)); v = OP(v, wave_dpp<0x141, 0xF>(idn, v)); v = OP(v, wave_dpp<0x140, 0xF>(idn, v)); \
+    v = OP(v, wave_dpp<0x142, 0xA>(idn, v)); v = OP(v, wave_dpp<0x143, 0xC>(idn, v)); } while (0)
+__device__ __forceinline__ uint32_t wr_max(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t wr_min(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint32_t wr_add(uint32_t a, uint32_t b) { return a + b; }
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) { FGX_WAVE_REDUCE(v, 0u, wr_max); return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
+__device__ __forceinline__ uint32_t wave_min(uint32_t v) { FGX_WAVE_REDUCE(v, 0xFFFFFFFFu, wr_min); return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) { FGX_WAVE_REDUCE(v, 0u, wr_add); return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
 __device__ __forceinline__ unsigned long long wave_max64(unsigned long long v) { for (int o = 32; o > 0; o >>= 1) { unsigned long long t = __shfl_xor(v, o); v = t > v ? t : v; } return v; }
 __device__ __forceinline__ unsigned long long wave_min64(unsigned long long v) { for (int o = 32; o > 0; o >>= 1) { unsigned long long t = __shfl_xor(v, o); v = t < v ? t : v; } return v; }
 __device__ __forceinline__ uint8_t comp_code(uint8_t c) { return (uint8_t)((0xF7B3D591E6A2C480ULL >> (4 * (c & 15))) & 15); }
@@ -2540,6 +2551,9 @@ __device__ __forceinline__ uint8_t int_tag_byte(uint32_t j, char a, char b, uint
 // wavefront, not by bytes: so (hot path, consensus <= 192 columns and short names/tags) EVERY load of the record is
 // issued before the first store — one wait instead of one per field — descriptor fields are scalar loads, and every
 // field group is one full-wave store in which each lane computes the byte it owns (fixed header bytes included).
+#ifndef FGX_EMIT_FLAT
+#define FGX_EMIT_FLAT 1   /* k_emit's small fields as straight-line code (0: the nested conditionals of rounds 2 - 4, for measurements) */
+#endif
 struct EmitCtx {
   uint8_t* q; const uint8_t* first; const uint8_t* code; const uint8_t* cq; const uint16_t* cd; const uint16_t* ce;
   uint32_t Lc, name_len, mi_len, mi_off, flag, rec_size;
@@ -2592,11 +2606,7 @@ __device__ void emit_generic(const EmitParams& P, const EndDesc& D, const EmitCt
   q += Lc;
   for (uint32_t i = lane; i < 3 + P.rg_len + 1; i += 64) q[i] = i == 0 ? 'R' : i == 1 ? 'G' : i == 2 ? 'Z' : i - 3 < P.rg_len ? (uint8_t)P.rg[i - 3] : 0;
   q += 3 + P.rg_len + 1;
-  for (int o = 32; o > 0; o >>= 1) {
-    uint32_t a = __shfl_xor(maxd, o), b = __shfl_xor(mind, o);
-    maxd = a > maxd ? a : maxd; mind = b < mind ? b : mind;
-    sumd += __shfl_xor(sumd, o); sume += __shfl_xor(sume, o);
-  }
+  maxd = wave_max(maxd); mind = wave_min(mind); sumd = wave_sum(sumd); sume = wave_sum(sume);
   if (Lc == 0) { maxd = 0; mind = 0; }
   const float ce_rate = sumd > 0 ? (float)sume / (float)sumd : 0.0f;
   const uint32_t n_cd = 3 + int_tag_width(maxd), n_cm = 3 + int_tag_width(mind);
@@ -2683,7 +2693,14 @@ __device__ __forceinline__ void emit_load(const EmitParams& P, const EndDesc& D,
   const uint32_t ni = lane > P.prefix_len ? lane - P.prefix_len - 1 : 0;
   const uint8_t pfx = (uint8_t)P.prefix[lane < P.prefix_len ? lane : 0];                       // d_strings keeps 16 bytes of slack
   const uint8_t nmb = X.first[mi_off + (ni < mi_len ? ni : mi_len)];                            // index mi_len is the tag's NUL
+#if FGX_EMIT_FLAT
+  {   // (nmb is the tag's NUL from lane name_len on: two one-level selects)
+    const uint8_t colon_or_mi = lane == P.prefix_len ? (uint8_t)':' : nmb;
+    R.nb = lane < P.prefix_len ? pfx : colon_or_mi;
+  }
+#else
   R.nb = lane < P.prefix_len ? pfx : lane == P.prefix_len ? (uint8_t)':' : lane < name_len ? nmb : (uint8_t)0;
+#endif
   R.rgb = (uint8_t)P.rg[j3 < P.rg_len ? j3 : 0];
   R.mib = X.first[mi_off + (j3 < mi_len ? j3 : mi_len)];
   const uint8_t* fk = R.has_cb ? P.blob + uniform_u64(D.kept_off) + uni(D.cb_off) : X.first;
@@ -2707,21 +2724,37 @@ __device__ __forceinline__ void emit_store(const EmitParams& P, const EndDesc& D
     if (lo_own) { maxd = dl > maxd ? dl : maxd; mind = dl < mind ? dl : mind; sumd += dl; sume += el; }
     if (in) { maxd = dh > maxd ? dh : maxd; mind = dh < mind ? dh : mind; sumd += dh; sume += eh; }
   }
-  for (int o = 32; o > 0; o >>= 1) {
-    uint32_t a = __shfl_xor(maxd, o), b = __shfl_xor(mind, o);
-    maxd = a > maxd ? a : maxd; mind = b < mind ? b : mind;
-    sumd += __shfl_xor(sumd, o); sume += __shfl_xor(sume, o);
-  }
+  maxd = wave_max(maxd); mind = wave_min(mind); sumd = wave_sum(sumd); sume = wave_sum(sume);
   maxd = uni(maxd); mind = uni(mind); sumd = uni(sumd); sume = uni(sume);   // (every lane holds the totals: the tag widths below, and with them every later address, are scalar)
   const float ce_rate = sumd > 0 ? (float)sume / (float)sumd : 0.0f;
   const uint32_t n_cd = 3 + int_tag_width(maxd), n_cm = 3 + int_tag_width(mind);
 
   // ---- stores -----------------------------------------------------------------------------------------------------------
   uint8_t* q = X.q;
+#if FGX_EMIT_FLAT
+  // The small fields are chains of "lane k holds byte k" choices over wave-uniform values.  Written as nested conditionals they compile into
+  // nested exec-mask regions (the kernel executed more scalar instructions than vector ones: 611 against 530 per family); written as below
+  // — uniform words built by the scalar unit, a lane's byte taken with one shift, one-level selects — they are straight-line code.
+  const uint32_t l3 = lane < 3u ? lane : 3u, sh3 = 8u * l3;                             // (a 24-bit header word >> sh3: its byte for lanes 0 - 2, 0 from lane 3 on)
+  auto ztag = [&](uint32_t c3, uint32_t len, uint32_t body) -> uint32_t {               // byte `lane` of the tag  XY:Z:<len bytes> NUL
+    const uint32_t u = (lane - 3u < len) ? body : 0u;                                    // (unsigned: false for lanes 0 - 2)
+    return (c3 >> sh3) | u;
+  };
+  {   // block_size + fixed core: ref_id -1, pos -1, l_read_name, mapq 0, bin 4680, n_cigar_op 0, flag, l_seq, next_ref -1, next_pos -1, tlen 0
+    uint32_t v = 0xFFFFFFFFu;
+    if (lane == 0) v = X.rec_size;
+    if (lane == 3) v = (name_len + 1) | (4680u << 16);
+    if (lane == 4) v = X.flag << 16;
+    if (lane == 5) v = Lc;
+    if (lane == 8) v = 0u;
+    if (lane < 9) gst32u(q + 4 * lane, v);
+  }
+#else
   if (lane < 9) {   // block_size + fixed core: ref_id -1, pos -1, l_read_name, mapq 0, bin 4680, n_cigar_op 0, flag, l_seq, next_ref -1, next_pos -1, tlen 0
     const uint32_t v = lane == 0 ? X.rec_size : lane == 3 ? ((name_len + 1) | (4680u << 16)) : lane == 4 ? (X.flag << 16) : lane == 5 ? Lc : lane == 8 ? 0u : 0xFFFFFFFFu;
     gst32u(q + 4 * lane, v);
   }
+#endif
   q += 36;
   if (lane < name_len + 1) q[lane] = R.nb;
   q += name_len + 1;
@@ -2736,6 +2769,32 @@ __device__ __forceinline__ void emit_store(const EmitParams& P, const EndDesc& D
   q += seq_bytes;
   if (4 * lane < Lc) gst32u(q + qo, R.qw);
   q += Lc;
+#if FGX_EMIT_FLAT
+  {
+    const uint32_t b = ztag('R' | ('G' << 8) | ('Z' << 16), P.rg_len, R.rgb);
+    if (lane < 3 + P.rg_len + 1) q[lane] = (uint8_t)b;
+  }
+  q += 3 + P.rg_len + 1;
+  {   // cD cM cE and, when asked for, the header of the cd array right behind them: one store.  Four uniform 64-bit words (an integer tag
+      // is `ab` + its type + one or two value bytes, cE is `cEf` + the four bytes of the rate, the array header `cdBs` + its count)
+    const uint32_t n3 = n_cd + n_cm + 7, nh = P.per_base_tags ? 8u : 0u;
+    auto int_word = [](uint32_t a, uint32_t b, uint32_t v) -> unsigned long long {
+      const uint32_t ty = v <= 127 ? (uint32_t)'c' : v <= 255 ? (uint32_t)'C' : (uint32_t)'S';
+      return (unsigned long long)(a | (b << 8) | (ty << 16)) | ((unsigned long long)v << 24);
+    };
+    const unsigned long long w_cd = int_word('c', 'D', maxd), w_cm = int_word('c', 'M', mind);
+    const unsigned long long w_ce = (unsigned long long)('c' | ('E' << 8) | ('f' << 16)) | ((unsigned long long)__float_as_uint(ce_rate) << 24);
+    const unsigned long long w_hd = (unsigned long long)('c' | ('d' << 8) | ('B' << 16) | ('s' << 24)) | ((unsigned long long)Lc << 32);
+    unsigned long long w = w_hd;
+    uint32_t k = lane - n3;
+    if (lane < n3) { w = w_ce; k = lane - n_cd - n_cm; }
+    if (lane < n_cd + n_cm) { w = w_cm; k = lane - n_cd; }
+    if (lane < n_cd) { w = w_cd; k = lane; }
+    const uint32_t b = (uint32_t)(w >> (8u * (k & 7u)));
+    if (lane < n3 + nh) q[lane] = (uint8_t)b;
+    q += n3;
+  }
+#else
   if (lane < 3 + P.rg_len + 1) q[lane] = lane == 0 ? 'R' : lane == 1 ? 'G' : lane == 2 ? 'Z' : j3 < P.rg_len ? R.rgb : (uint8_t)0;
   q += 3 + P.rg_len + 1;
   {   // cD cM cE and, when asked for, the header of the cd array right behind them: one store
@@ -2747,6 +2806,7 @@ __device__ __forceinline__ void emit_store(const EmitParams& P, const EndDesc& D
     }
     q += n3;
   }
+#endif
   if (P.per_base_tags) {
     q += 8;
 #pragma unroll
@@ -2758,10 +2818,28 @@ __device__ __forceinline__ void emit_store(const EmitParams& P, const EndDesc& D
     for (int t = 0; t < 2; t++) if (4 * (lane + 64 * t) < 2 * Lc) gst32u(q + R.ao[t], R.ew[t]);
     q += 2 * Lc;
   }
+#if FGX_EMIT_FLAT
+  {
+    const uint32_t b = ztag((uint32_t)(uint8_t)P.tag0 | ((uint32_t)(uint8_t)P.tag1 << 8) | ('Z' << 16), mi_len, R.mib);
+    if (lane < 3 + mi_len + 1) q[lane] = (uint8_t)b;
+  }
+  q += 3 + mi_len + 1;
+  if (has_cb) {
+    const uint32_t b = ztag((uint32_t)(uint8_t)P.cell0 | ((uint32_t)(uint8_t)P.cell1 << 8) | ('Z' << 16), cb_len, R.cbb);
+    if (lane < 3 + cb_len + 1) q[lane] = (uint8_t)b;
+    q += 3 + cb_len + 1;
+  }
+  if (has_rx) {
+    const uint32_t b = ztag('R' | ('X' << 8) | ('Z' << 16), rx_len, R.rxb);
+    if (lane < 3 + rx_len + 1) q[lane] = (uint8_t)b;
+  }
+  (void)j3;
+#else
   if (lane < 3 + mi_len + 1) q[lane] = lane == 0 ? (uint8_t)P.tag0 : lane == 1 ? (uint8_t)P.tag1 : lane == 2 ? 'Z' : j3 < mi_len ? R.mib : (uint8_t)0;
   q += 3 + mi_len + 1;
   if (has_cb) { if (lane < 3 + cb_len + 1) q[lane] = lane == 0 ? (uint8_t)P.cell0 : lane == 1 ? (uint8_t)P.cell1 : lane == 2 ? 'Z' : j3 < cb_len ? R.cbb : (uint8_t)0; q += 3 + cb_len + 1; }
   if (has_rx) { if (lane < 3 + rx_len + 1) q[lane] = lane == 0 ? 'R' : lane == 1 ? 'X' : lane == 2 ? 'Z' : j3 < rx_len ? R.rxb : (uint8_t)0; }
+#endif
 }
 #ifndef FGX_EMIT_OCC
 #define FGX_EMIT_OCC 7   /* wavefronts per SIMD the register allocation of k_emit aims at */
