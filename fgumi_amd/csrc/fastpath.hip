@@ -3196,7 +3196,68 @@ __global__ __launch_bounds__(256) void k_emit_codec(CodecEmitParams P) {
 // budget (or have unusually long names / tags) are left to the per-field kernels, which skip what is done here.
 // -----------------------------------------------------------------------------------------------------
 // shared field writers (q advances; every lane calls them)
-struct FieldWriter {
+// (The small fields are written as straight-line code — uniform words built by the scalar unit, a lane's byte taken with one shift,
+// one-level selects —: nested conditionals over the lane number compile into nested exec-mask regions, and the record writers were bound by
+// scalar instructions, profiles/r04_experiments.md.)
+struct FieldWriterFlat {
+  uint8_t* q; uint32_t lane;
+  __device__ __forceinline__ uint32_t sh3() const { return 8u * (lane < 3u ? lane : 3u); }   // (a 24-bit header word >> sh3: its byte for lanes 0 - 2, 0 from lane 3 on)
+  // one store: bytes [0, n) with n <= 64, byte i = f(i)
+  template <class F> __device__ __forceinline__ void small(uint32_t n, F f) { const uint8_t b = f(lane); if (lane < n) q[lane] = b; q += n; }
+  __device__ __forceinline__ void z_small(char t0, char t1, const uint8_t* src, uint32_t n) {       // Z tag, n + 4 <= 64
+    const uint32_t k = lane >= 3 ? lane - 3 : 0;
+    const uint32_t b = src[k < n ? k : (n ? n - 1 : 0)];
+    const uint32_t c3 = (uint32_t)(uint8_t)t0 | ((uint32_t)(uint8_t)t1 << 8) | ((uint32_t)'Z' << 16);
+    const uint32_t u = (lane - 3u < n) ? b : 0u;                                                      // (unsigned: false for lanes 0 - 2)
+    const uint32_t v = (c3 >> sh3()) | u;
+    if (lane < 3 + n + 1) q[lane] = (uint8_t)v;
+    q += 3 + n + 1;
+  }
+  __device__ __forceinline__ void scalars(char s, bool m_second, uint32_t dmax, uint32_t dmin, float rate) {   // <s>D <s>E <s>M (duplex) or <s>D <s>M <s>E (CODEC)
+    // three uniform words: an integer tag here is `<s>D` + its type + ONE value byte (4 bytes), the rate `<s>Ef` + its four bytes (7)
+    auto int_word = [&](uint32_t b, uint32_t v) -> unsigned long long {
+      const uint32_t ty = v <= 127 ? (uint32_t)'c' : v <= 255 ? (uint32_t)'C' : (uint32_t)'S';
+      return (unsigned long long)((uint32_t)(uint8_t)s | (b << 8) | (ty << 16) | ((v & 0xFFu) << 24));
+    };
+    const unsigned long long wD = int_word('D', dmax), wM = int_word('M', dmin);
+    const unsigned long long wE = (unsigned long long)((uint32_t)(uint8_t)s | ((uint32_t)'E' << 8) | ((uint32_t)'f' << 16)) | ((unsigned long long)__float_as_uint(rate) << 24);
+    const unsigned long long w2 = m_second ? wM : wE, w3 = m_second ? wE : wM;
+    const uint32_t n2 = m_second ? 4u : 7u;
+    unsigned long long w = wD;
+    uint32_t k = lane;
+    if (lane >= 4u) { w = w2; k = lane - 4u; }
+    if (lane >= 4u + n2) { w = w3; k = lane - 4u - n2; }
+    const uint32_t v = (uint32_t)(w >> (8u * (k & 7u)));
+    if (lane < 15) q[lane] = (uint8_t)v;
+    q += 15;
+  }
+  __device__ __forceinline__ void header3(char t0, char t1) {                                        // `xyZ`
+    const uint32_t c3 = (uint32_t)(uint8_t)t0 | ((uint32_t)(uint8_t)t1 << 8) | ((uint32_t)'Z' << 16);
+    const uint32_t v = c3 >> sh3();
+    if (lane < 3) q[lane] = (uint8_t)v;
+    q += 3;
+  }
+  __device__ __forceinline__ void header8(char t0, char t1, uint32_t L) {                            // `xyBs` + the count
+    const unsigned long long w = (unsigned long long)((uint32_t)(uint8_t)t0 | ((uint32_t)(uint8_t)t1 << 8) | ((uint32_t)'B' << 16) | ((uint32_t)'s' << 24)) | ((unsigned long long)L << 32);
+    const uint32_t v = (uint32_t)(w >> (8u * (lane & 7u)));
+    if (lane < 8) q[lane] = (uint8_t)v;
+    q += 8;
+  }
+  __device__ __forceinline__ void core(uint32_t rec_size, uint32_t name_len, uint32_t flag, uint32_t L) {
+    uint32_t v = 0xFFFFFFFFu;
+    if (lane == 0) v = rec_size;
+    if (lane == 3) v = (name_len + 1) | (4680u << 16);
+    if (lane == 4) v = flag << 16;
+    if (lane == 5) v = L;
+    if (lane == 8) v = 0u;
+    if (lane < 9) gst32u(q + 4 * lane, v);
+    q += 36;
+  }
+};
+
+// the same fields as nested conditionals (rounds 2 - 4): k_emit_codec_fast keeps them — the straight-line forms cost it four registers and with
+// them a wavefront per SIMD (79 -> 83; 0.54 -> 0.53 G raw reads/s, profiles/r04_experiments.md)
+struct FieldWriterNested {
   uint8_t* q; uint32_t lane;
   // one store: bytes [0, n) with n <= 64, byte i = f(i)
   template <class F> __device__ __forceinline__ void small(uint32_t n, F f) { if (lane < n) q[lane] = f(lane); q += n; }
@@ -3220,6 +3281,10 @@ struct FieldWriter {
     if (lane < 15) q[lane] = v;
     q += 15;
   }
+  __device__ __forceinline__ void header3(char t0, char t1) { small(3, [&](uint32_t i) { return i == 0 ? (uint8_t)t0 : i == 1 ? (uint8_t)t1 : (uint8_t)'Z'; }); }
+  __device__ __forceinline__ void header8(char t0, char t1, uint32_t L) {
+    small(8, [&](uint32_t i) { return i == 0 ? (uint8_t)t0 : i == 1 ? (uint8_t)t1 : i == 2 ? (uint8_t)'B' : i == 3 ? (uint8_t)'s' : (uint8_t)(L >> (8 * ((i - 4) & 3))); });
+  }
   __device__ __forceinline__ void core(uint32_t rec_size, uint32_t name_len, uint32_t flag, uint32_t L) {
     if (lane < 36) {
       const uint32_t dw = lane >> 2;
@@ -3230,9 +3295,9 @@ struct FieldWriter {
   }
 };
 
-template <uint32_t SLOTS, class B>      // string field of L bytes after a 3-byte `xyZ` header and before a NUL
-__device__ __forceinline__ void put_string(FieldWriter& W, char t0, char t1, uint32_t L, B byte_of) {
-  W.small(3, [&](uint32_t i) { return i == 0 ? (uint8_t)t0 : i == 1 ? (uint8_t)t1 : (uint8_t)'Z'; });
+template <uint32_t SLOTS, class FW, class B>      // string field of L bytes after a 3-byte `xyZ` header and before a NUL
+__device__ __forceinline__ void put_string(FW& W, char t0, char t1, uint32_t L, B byte_of) {
+  W.header3(t0, t1);
   // a lane's two positions are neighbours in the record: ONE 16-bit store (gfx950 takes them unaligned) instead of two byte stores
 #pragma unroll
   for (uint32_t t = 0; t < SLOTS; t++) {
@@ -3243,9 +3308,9 @@ __device__ __forceinline__ void put_string(FieldWriter& W, char t0, char t1, uin
   if (W.lane == 0) W.q[L] = 0;
   W.q += L + 1;
 }
-template <uint32_t SLOTS, class V>      // B:s array of L int16 values
-__device__ __forceinline__ void put_i16(FieldWriter& W, char t0, char t1, uint32_t L, V val_of) {
-  W.small(8, [&](uint32_t i) { return i == 0 ? (uint8_t)t0 : i == 1 ? (uint8_t)t1 : i == 2 ? (uint8_t)'B' : i == 3 ? (uint8_t)'s' : (uint8_t)(L >> (8 * ((i - 4) & 3))); });
+template <uint32_t SLOTS, class FW, class V>      // B:s array of L int16 values
+__device__ __forceinline__ void put_i16(FW& W, char t0, char t1, uint32_t L, V val_of) {
+  W.header8(t0, t1, L);
   // a lane's two int16 values are four consecutive bytes: one (unaligned) dword store instead of four byte stores
 #pragma unroll
   for (uint32_t t = 0; t < SLOTS; t++) {
@@ -3255,8 +3320,8 @@ __device__ __forceinline__ void put_i16(FieldWriter& W, char t0, char t1, uint32
   }
   W.q += 2 * L;
 }
-template <uint32_t SLOTS, class C, class Q>   // 4-bit packed bases, then qualities
-__device__ __forceinline__ void put_seq_qual(FieldWriter& W, uint32_t L, C code_of, Q qual_of) {
+template <uint32_t SLOTS, class FW, class C, class Q>   // 4-bit packed bases, then qualities
+__device__ __forceinline__ void put_seq_qual(FW& W, uint32_t L, C code_of, Q qual_of) {
 #pragma unroll
   for (uint32_t t = 0; t < SLOTS; t++) {
     const uint32_t p = 128 * t + 2 * W.lane;
@@ -3336,9 +3401,9 @@ __global__ __launch_bounds__(256) void k_emit_duplex_fast(DuplexEmitParams P) {
   if (!has_ba) { bmax = 0; bmin = 0; bsd = 0; bse = 0; }
   const float a_rate = asd ? (float)ase / (float)asd : 0.0f, b_rate = bsd ? (float)bse / (float)bsd : 0.0f, c_rate = csd ? (float)cse / (float)csd : 0.0f;
   // ---- stores ------------------------------------------------------------------------------------------------------------------
-  FieldWriter W{P.out + P.out_off[slot], lane};
+  FieldWriterFlat W{P.out + P.out_off[slot], lane};
   W.core(D.rec_size, name_len, flag, L);
-  W.small(name_len + 1, [&](uint32_t i) { return i < P.prefix_len ? pfx : i == P.prefix_len ? (uint8_t)':' : i < name_len ? nmb : (uint8_t)0; });
+  W.small(name_len + 1, [&](uint32_t i) { const uint8_t x = i == P.prefix_len ? (uint8_t)':' : nmb, y = i < P.prefix_len ? pfx : x; return i < name_len ? y : (uint8_t)0; });   // (three one-level selects)
   put_seq_qual<DUP_SLOTS>(W, L, [&](uint32_t t, uint32_t k) { return (w0[t][k] >> 8) & 15; }, [&](uint32_t t, uint32_t k) { return w2[t][k] & 0xFF; });
   W.z_small('M', 'I', first + mi_off, mi_len);
   if (has_cb) W.z_small(P.cell0, P.cell1, P.blob + P.rec_off[D.cb_rec] + D.cb_off, cb_len);
@@ -3475,7 +3540,7 @@ __global__ __launch_bounds__(256) void k_emit_codec_fast(CodecEmitParams P) {
   }
   const float a_rate = asd ? (float)ase / (float)asd : 0.0f, b_rate = bsd ? (float)bse / (float)bsd : 0.0f, c_rate = csd ? (float)cse / (float)csd : 0.0f;
   // ---- the fields that are not indexed by position ----------------------------------------------------------------------------
-  FieldWriter W{rec, lane};
+  FieldWriterNested W{rec, lane};
   W.core(D.rec_size, name_len, (uint32_t)bam::F_UNMAPPED, C);
   W.small(name_len + 1, [&](uint32_t i) { return i < P.prefix_len ? pfx : i == P.prefix_len ? (uint8_t)':' : i < name_len ? nmb : (uint8_t)0; });
   W.q = q_rg;
