@@ -224,7 +224,7 @@ fgx_caller* fgx_create(const fgx_options* opts) {
     c->opt.read_group_id = nullptr;
     if (opts->device >= 0) c->device = opts->device; else hip_check(hipGetDevice(&c->device), "hipGetDevice");
     hip_check(hipSetDevice(c->device), "hipSetDevice");
-    hip_check(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate");
+    create_compute_stream(&c->stream);
     hip_check(hipEventCreate(&c->ev0), "hipEventCreate");
     hip_check(hipEventCreate(&c->ev1), "hipEventCreate");
     memset(&c->h_tables, 0, sizeof(c->h_tables));

@@ -214,6 +214,19 @@ int bgzf_deflate_device(fgx_caller* c, const uint8_t* d_in, uint64_t len, DevBuf
 // merging them into the device's record stream on the host; -1 = not possible here, take the whole-batch way
 int resubmit_deferred(fgx_caller* c, const uint8_t* d_blob, const uint64_t* d_rec_off, const uint32_t* d_rec_len, uint32_t n_rec, const uint32_t* d_grp_first, uint32_t n_grp,
                       const fgx_output* dev, uint32_t n_def, const uint32_t* d_def, fgx_output* merged);
+// The streams the consensus kernels run on are created with the device's HIGHEST priority: fgx_run_bam fills up to four later chunks on
+// streams of their own (normal priority), a process has few hardware queues, and a short consensus kernel queued behind a 30 ms inflate
+// kernel in a shared queue cost the device stage more than the overlap gave it (FGX_STREAM_PRIORITY=0: normal priority, for measurements).
+inline void create_compute_stream(hipStream_t* s) {
+  static const bool high = [] { const char* e = getenv("FGX_STREAM_PRIORITY"); return !(e && e[0] == '0'); }();
+  int least = 0, greatest = 0;
+  if (high && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least) {
+    hip_check(hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest), "hipStreamCreateWithPriority");
+    return;
+  }
+  hip_check(hipStreamCreateWithFlags(s, hipStreamNonBlocking), "hipStreamCreate");
+}
+
 // pipeline.cpp — frees what fgx_run_bam keeps in c->pipe_state
 void pipeline_release(fgx_caller* c);
 // filter.hip — `fgumi filter` on the device

@@ -3880,7 +3880,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       d_split_rec.reserve((size_t)n_rec * sizeof(SplitRec) + 64);
       d_split_fam.reserve((size_t)n_grp * sizeof(SplitFam) + 64);
       P.split_rec = d_split_rec.as<SplitRec>(); P.split_fam = d_split_fam.as<SplitFam>();
-      if (!s2) { hip_check(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking), "hipStreamCreate"); for (int i = 0; i < MAX_CHUNKS; i++) { hip_check(hipEventCreateWithFlags(&ev_chunk[i], hipEventDisableTiming), "hipEventCreate"); hip_check(hipEventCreateWithFlags(&ev_cols[i], hipEventDisableTiming), "hipEventCreate"); } hip_check(hipEventCreateWithFlags(&ev_fin, hipEventDisableTiming), "hipEventCreate"); hip_check(hipEventCreateWithFlags(&ev_sample, hipEventDisableTiming), "hipEventCreate"); }
+      if (!s2) { create_compute_stream(&s2); for (int i = 0; i < MAX_CHUNKS; i++) { hip_check(hipEventCreateWithFlags(&ev_chunk[i], hipEventDisableTiming), "hipEventCreate"); hip_check(hipEventCreateWithFlags(&ev_cols[i], hipEventDisableTiming), "hipEventCreate"); } hip_check(hipEventCreateWithFlags(&ev_fin, hipEventDisableTiming), "hipEventCreate"); hip_check(hipEventCreateWithFlags(&ev_sample, hipEventDisableTiming), "hipEventCreate"); }
       FastParams PK;
       memset(&PK, 0, sizeof(PK));
       PK.blob = d_blob; PK.rec_off = d_rec_off; PK.rec_len = d_rec_len; PK.grp_first = d_grp_first; PK.blob_len = blob_len;

@@ -43,6 +43,8 @@ hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 const char* hipGetErrorString(hipError_t) { return "apiemu"; }
 hipError_t hipGetLastError(void) { return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned int) { *s = nullptr; return hipSuccess; }
+hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned int, int) { *s = nullptr; return hipSuccess; }
+hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) { *least = 0; *greatest = -1; return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
