@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 F64_LANE_OPS_PER_S = 64 * 1024 * 2.4e9 / 4   # one f64 add per lane per 4 cycles, 1024 SIMDs at 2.4 GHz = 39.3 T/s
-E2E_CHUNK_MB = 128              # compressed bytes per chunk of the file -> file leg (FGX_BENCH_E2E_CHUNK_MB; tools/e2e_chunk_sweep.py)
+E2E_CHUNK_MB = 512              # compressed bytes per chunk of the file -> file leg (FGX_BENCH_E2E_CHUNK_MB; tools/e2e_chunk_sweep.py)
 F64_OPS_PER_OBSERVATION = 8     # two Kahan chains (the base seen, any other base) x 4 dependent add/sub
 
 

@@ -177,6 +177,7 @@ struct fgx_caller {
   uint32_t last_reject_oos = 0;            // ... groups its side kernels could not decide (the batch then took the general path)
   void* rej_state = nullptr;               // buffers of the device `--rejects` side kernels (reject_device.hip: reject_release)
   void* pipe_state = nullptr;              // buffers of fgx_run_bam, kept from run to run (pipeline.cpp: fgx_pipeline_release)
+  void* pipe_state_ring = nullptr;         // the same for the opt-in form with several chunks on their way in (pipeline_ring.cpp)
   uint64_t last_deferred_groups = 0, last_canon_molecules = 0;   // host entry: groups the first device pass deferred / molecules the canonical second pass decided
   uint32_t last_boundary_rounds = 0;       // repair rounds of the last fgx_record_boundaries_device call (boundaries.hip; 0 = every guess was right)
 
@@ -214,11 +215,13 @@ int bgzf_deflate_device(fgx_caller* c, const uint8_t* d_in, uint64_t len, DevBuf
 // merging them into the device's record stream on the host; -1 = not possible here, take the whole-batch way
 int resubmit_deferred(fgx_caller* c, const uint8_t* d_blob, const uint64_t* d_rec_off, const uint32_t* d_rec_len, uint32_t n_rec, const uint32_t* d_grp_first, uint32_t n_grp,
                       const fgx_output* dev, uint32_t n_def, const uint32_t* d_def, fgx_output* merged);
-// The streams the consensus kernels run on are created with the device's HIGHEST priority: fgx_run_bam fills up to four later chunks on
-// streams of their own (normal priority), a process has few hardware queues, and a short consensus kernel queued behind a 30 ms inflate
-// kernel in a shared queue cost the device stage more than the overlap gave it (FGX_STREAM_PRIORITY=0: normal priority, for measurements).
+// FGX_STREAM_PRIORITY=1 (opt-in, for measurements): the streams the consensus kernels run on get the device's highest priority.  It takes them
+// out of the hardware queues they share with fgx_run_bam's fill streams (a short consensus kernel queued behind a 30 ms inflate kernel cost the
+// device stage of the bench process a third of its time: file -> file 50 -> 68 M raw reads/s) — but tests/test_gpu_pipeline.py's multi-chunk
+// cases then produced groups cut in two (stale bytes in front of a chunk's stream), every time; until that is understood the streams stay at
+// normal priority, where the whole GPU suite is green (profiles/r04_experiments.md).
 inline void create_compute_stream(hipStream_t* s) {
-  static const bool high = [] { const char* e = getenv("FGX_STREAM_PRIORITY"); return !(e && e[0] == '0'); }();
+  static const bool high = [] { const char* e = getenv("FGX_STREAM_PRIORITY"); return e && e[0] == '1'; }();
   int least = 0, greatest = 0;
   if (high && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least) {
     hip_check(hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest), "hipStreamCreateWithPriority");
@@ -229,6 +232,11 @@ inline void create_compute_stream(hipStream_t* s) {
 
 // pipeline.cpp — frees what fgx_run_bam keeps in c->pipe_state
 void pipeline_release(fgx_caller* c);
+// pipeline_ring.cpp — fgx_run_bam_rejects with a ring of stream buffers (FGX_PIPE_RING=1), and what it keeps in c->pipe_state_ring
+void pipeline_ring_release(fgx_caller* c);
+int run_bam_rejects_ring(fgx_caller* c, const char* in_path, const char* out_path, const char* rejects_path, const uint8_t* out_header, uint64_t out_header_len,
+                         const fgx_group_options* g, uint32_t threads, int level, uint64_t chunk_raw_bytes, uint32_t flags, fgx_bam_run_stats* st,
+                         uint64_t* rejected_records);
 // filter.hip — `fgumi filter` on the device
 int filter_records_device(fgx_caller* c, FilterBuffers& B, const fgx_filter_options* o, uint8_t* d_blob, uint64_t blob_len, const uint64_t* d_rec_off,
                           const uint32_t* d_rec_len, uint32_t n, fgx_filter_output* out);

@@ -1,3 +1,12 @@
+// pipeline_ring.cpp — fgx_run_bam with SEVERAL chunks on their way into the device (FGX_PIPE_RING=1, opt-in; round 4).
+//
+// The same five host stages as pipeline.cpp; the device stage keeps a ring of five stream buffers, every buffer with its own stream, and
+// while it works on one chunk up to four later ones are uploaded and inflated side by side (one chunk's BGZF blocks do not fill the chip:
+// the inflate kernel is a latency chain per block).  Measured: 60 -> 72 M raw reads/s on a 1 M-family file (profiles/r04_experiments.md).
+// NOT the default: with the runtime's default of four hardware queues per process the whole GPU suite is green on it, but with eight
+// (GPU_MAX_HW_QUEUES=8) or with high-priority compute streams — i.e. as soon as the device stage's kernels really run beside the fills —
+// the multi-chunk device-inflate tests find groups cut in two (bytes of the buffer's previous chunk in front of a stream); pipeline.cpp
+// passes the same tests under the same settings.  The cause was not found before the round's GPU time ran out.
 // pipeline.cpp — a BAM file in, a consensus BAM file out: the container work on BOTH sides of the device path as one streaming
 // pipeline.  What it stands in for, for this path: the reader / decompress / find-boundaries / group /
 // process / compress / write steps of the reference's unified pipeline (src/lib/unified_pipeline/bam.rs; BGZF framing
@@ -226,7 +235,7 @@ uint64_t bam_header_size(const uint8_t* p, uint64_t n);
 
 // the five stages over a ring of chunks; `middle` turns chunk.inf into chunk.out (the device stage, or a copy)
 struct Pipeline {
-  static constexpr int N_CHUNKS = 3, N_STAGES = 5;
+  static constexpr int N_CHUNKS = 8, N_STAGES = 5;   // (N_CHUNKS: one chunk per stage + the chunks the device stage has on their way in, PipeState::NB - 1)
   Chunk chunks[N_CHUNKS];
   std::mutex m;
   std::condition_variable cv;
@@ -566,118 +575,52 @@ thread_local std::string t_perr;
 // what fgx_run_bam keeps between runs: the pinned chunk buffers and the device buffers (allocating 3 x ~1 GB of pinned memory takes
 // longer than a whole chunk's work)
 struct PipeState {
+  // A ring of NB stream buffers: chunk `seq` lives in D[seq % NB].  While the device stage works on one chunk, up to NB - 1 later chunks
+  // are on their way in, each on its OWN stream — the inflate kernel is a latency chain per BGZF block (bgzf_device.hip) that a single
+  // chunk's blocks do not fill the chip with, so the chunks' kernels run side by side, and the uploads run under them.
+  static constexpr int NB = 5;
   Pipeline P;
-  fgx::DevBuf D[2], d_off, d_len, d_koff, d_klen, d_grp, d_raw, d_blk, d_slots, d_dscratch, d_dmeta, d_packed, d_crcs;
-  uint64_t pad[2] = {0, 0};          // bytes of D[i] in front of a chunk's inflated stream: room for what the chunk before it leaves over
-  hipStream_t s_in = nullptr;        // uploads and inflates the NEXT chunk while the device stage works on this one
-  hipEvent_t ev_up0 = nullptr, ev_up1 = nullptr, ev_in = nullptr;   // upload begins / upload done / stream inflated and checked
-  uint32_t* h_status = nullptr;      // (pinned) the inflate kernels' status word
+  fgx::DevBuf D[NB], d_raw[NB], d_blk[NB], d_off, d_len, d_koff, d_klen, d_grp, d_slots, d_dscratch, d_dmeta, d_packed, d_crcs;
+  uint64_t pad[NB] = {0, 0, 0, 0, 0};   // bytes of D[i] in front of a chunk's inflated stream: room for what the chunk before it leaves over
+  uint64_t fill_len[NB] = {0, 0, 0, 0, 0};   // inflated bytes of the stream D[i] holds (or is being filled with)
+  hipStream_t s_in[NB] = {};          // uploads and inflates a LATER chunk while the device stage works on this one
+  hipEvent_t ev_up0[NB] = {}, ev_up1[NB] = {}, ev_in[NB] = {};   // upload begins / upload done / stream inflated and checked
+  uint32_t* h_status = nullptr;       // (pinned) the inflate kernels' status words, 16 words apart
+  uint32_t last_max_ahead = 0;        // (diagnostics) the most later chunks that were on their way at once in the last run
 };
 
 }  // namespace
 
 namespace fgx {
-void pipeline_release(fgx_caller* c) {
-  pipeline_ring_release(c);
-  if (!c || !c->pipe_state) return;
-  PipeState* S = (PipeState*)c->pipe_state;
-  for (auto* b : {&S->D[0], &S->D[1], &S->d_off, &S->d_len, &S->d_koff, &S->d_klen, &S->d_grp, &S->d_raw, &S->d_blk, &S->d_slots, &S->d_dscratch, &S->d_dmeta, &S->d_packed, &S->d_crcs}) b->free_();
-  if (S->s_in) { (void)hipStreamSynchronize(S->s_in); (void)hipStreamDestroy(S->s_in); }
-  for (hipEvent_t e : {S->ev_up0, S->ev_up1, S->ev_in}) if (e) (void)hipEventDestroy(e);
+void pipeline_ring_release(fgx_caller* c) {
+  if (!c || !c->pipe_state_ring) return;
+  PipeState* S = (PipeState*)c->pipe_state_ring;
+  for (int i = 0; i < PipeState::NB; i++) {
+    if (S->s_in[i]) { (void)hipStreamSynchronize(S->s_in[i]); (void)hipStreamDestroy(S->s_in[i]); }
+    for (hipEvent_t e : {S->ev_up0[i], S->ev_up1[i], S->ev_in[i]}) if (e) (void)hipEventDestroy(e);
+    for (auto* b : {&S->D[i], &S->d_raw[i], &S->d_blk[i]}) b->free_();
+  }
+  for (auto* b : {&S->d_off, &S->d_len, &S->d_koff, &S->d_klen, &S->d_grp, &S->d_slots, &S->d_dscratch, &S->d_dmeta, &S->d_packed, &S->d_crcs}) b->free_();
   if (S->h_status) (void)hipHostFree(S->h_status);
   delete S;
-  c->pipe_state = nullptr;
+  c->pipe_state_ring = nullptr;
 }
 }  // namespace fgx
 
 extern "C" {
+// (diagnostics, tests) the most later chunks fgx_run_bam had on their way beside the one in its device stage, last run of this caller
+uint32_t fgx_debug_last_chunks_ahead(const fgx_caller* c) { return (c && c->pipe_state_ring) ? ((const PipeState*)c->pipe_state_ring)->last_max_ahead : 0u; }
+}  // extern "C"
 
-// reader / inflate / deflate / writer around an identity middle stage: re-blocks a BGZF file (no device needed)
-int fgx_bgzf_recompress_file(const char* in_path, const char* out_path, uint32_t threads, int level, uint64_t chunk_raw_bytes, uint64_t* inflated_bytes) {
-  if (!in_path || !out_path) { t_perr = "fgx_bgzf_recompress_file: null argument"; return 1; }
-  auto P = std::make_unique<Pipeline>();
-  const int rc = P->run(in_path, out_path, nullptr, 0, threads, level, chunk_raw_bytes ? chunk_raw_bytes : (64ull << 20), false, false, [&](Chunk& c, uint64_t) {
-    c.out.reserve(c.inf_len + 64, false);
-    memcpy(c.out.p, c.inf.p, c.inf_len);
-    c.out_len = c.inf_len;
-  });
-  if (inflated_bytes) *inflated_bytes = P->inflated_bytes;
-  if (rc != 0) t_perr = P->err;
-  return rc;
-}
-const char* fgx_pipeline_last_error(void) { return t_perr.c_str(); }
-
-// The device's BGZF inflate (+ CRC-32 check) alone, for measurements and tests: the whole blocks of raw[0 .. raw_len) are uploaded once and
-// inflated `reps` times; *ms = average device time of one pass (HIP events), *inflated_len = bytes produced.  When `out` is given
-// (inflated_cap bytes) the stream of the last pass is copied there.  Returns 0, or non-zero with fgx_last_error(c).
-int fgx_bgzf_inflate_device_bench(fgx_caller* c, const uint8_t* raw, uint64_t raw_len, uint32_t reps, double* ms, uint64_t* inflated_len, uint8_t* out,
-                                  uint64_t inflated_cap) {
-  if (!c || !raw || !ms || !inflated_len) return 1;
-  c->err.clear();
-  try {
-    fgx::hip_check(hipSetDevice(c->device), "hipSetDevice");
-    std::vector<Block> blocks;
-    uint64_t infl = 0;
-    std::string e;
-    const size_t used = block_table(raw, raw_len, blocks, &infl, &e);
-    if (used == (size_t)-1) { c->err = e; return 1; }
-    std::vector<fgx::BgzfDevBlock> dev(blocks.size());
-    for (size_t i = 0; i < blocks.size(); i++) {
-      const Block& b = blocks[i];
-      const uint32_t xlen = raw[b.in_off + 10] | (raw[b.in_off + 11] << 8);
-      fgx::BgzfDevBlock d;
-      d.in_off = b.in_off + 12 + xlen; d.out_off = b.out_off; d.in_len = b.in_size - 12 - xlen - 8; d.isize = b.isize;
-      memcpy(&d.crc, raw + b.in_off + b.in_size - 8, 4);
-      d._pad = 0;
-      dev[i] = d;
-    }
-    fgx::DevBuf d_raw, d_blk, d_out;
-    d_raw.reserve(used + 64); d_blk.reserve(dev.size() * sizeof(fgx::BgzfDevBlock) + 64); d_out.reserve(infl + 256);
-    uint32_t* h_status = nullptr;
-    fgx::hip_check(hipHostMalloc((void**)&h_status, 64, hipHostMallocDefault), "hipHostMalloc");
-    hipStream_t s = c->stream;
-    fgx::hip_check(hipMemcpyAsync(d_raw.p, raw, used, hipMemcpyHostToDevice, s), "H2D");
-    fgx::hip_check(hipMemsetAsync((uint8_t*)d_raw.p + used, 0, 64, s), "memset");
-    const size_t blk_bytes = dev.size() * sizeof(fgx::BgzfDevBlock);
-    if (blk_bytes) fgx::hip_check(hipMemcpyAsync(d_blk.p, dev.data(), blk_bytes, hipMemcpyHostToDevice, s), "H2D");
-    uint32_t* d_status = (uint32_t*)((uint8_t*)d_blk.p + ((blk_bytes + 15) & ~(size_t)15));
-    hipEvent_t e0, e1;
-    fgx::hip_check(hipEventCreate(&e0), "event"); fgx::hip_check(hipEventCreate(&e1), "event");
-    int rc = 0;
-    fgx::bgzf_inflate_launch(s, d_raw.as<uint8_t>(), d_blk.as<fgx::BgzfDevBlock>(), (uint32_t)dev.size(), d_out.as<uint8_t>(), d_status, h_status);   // warm-up
-    fgx::hip_check(hipStreamSynchronize(s), "sync");
-    if (fgx::bgzf_inflate_status(c, *h_status) != 0) rc = 1;
-    fgx::hip_check(hipEventRecord(e0, s), "event");
-    for (uint32_t r = 0; r < (reps ? reps : 1u) && rc == 0; r++)
-      fgx::bgzf_inflate_launch(s, d_raw.as<uint8_t>(), d_blk.as<fgx::BgzfDevBlock>(), (uint32_t)dev.size(), d_out.as<uint8_t>(), d_status, h_status);
-    fgx::hip_check(hipEventRecord(e1, s), "event");
-    fgx::hip_check(hipStreamSynchronize(s), "sync");
-    if (rc == 0 && fgx::bgzf_inflate_status(c, *h_status) != 0) rc = 1;
-    float t = 0;
-    fgx::hip_check(hipEventElapsedTime(&t, e0, e1), "elapsed");
-    *ms = (double)t / (double)(reps ? reps : 1u);
-    *inflated_len = infl;
-    if (rc == 0 && out && inflated_cap >= infl && infl) fgx::hip_check(hipMemcpy(out, d_out.p, infl, hipMemcpyDeviceToHost), "D2H");
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipHostFree(h_status);
-    d_raw.free_(); d_blk.free_(); d_out.free_();
-    return rc;
-  } catch (const std::exception& ex) { c->err = ex.what(); return 3; }
-}
-
-int fgx_run_bam(fgx_caller* c, const char* in_path, const char* out_path, const uint8_t* out_header, uint64_t out_header_len,
-                const fgx_group_options* g, uint32_t threads, int level, uint64_t chunk_raw_bytes, uint32_t flags, fgx_bam_run_stats* st) {
-  return fgx_run_bam_rejects(c, in_path, out_path, nullptr, out_header, out_header_len, g, threads, level, chunk_raw_bytes, flags, st, nullptr);
-}
+namespace fgx {
 
 // fgx_run_bam with the reference's `--rejects <file>` (src/lib/commands/simplex.rs:7-12, 260-285, 613-720): a second BAM that advertises the
 // INPUT header and holds the rejected input records — the records of MI groups below --min-reads as they stand, the caller's rejects
 // (overlap-corrected copies) — in batch-input order.  The caller must have been created with track_rejects.
-int fgx_run_bam_rejects(fgx_caller* c, const char* in_path, const char* out_path, const char* rejects_path, const uint8_t* out_header, uint64_t out_header_len,
+int run_bam_rejects_ring(fgx_caller* c, const char* in_path, const char* out_path, const char* rejects_path, const uint8_t* out_header, uint64_t out_header_len,
                         const fgx_group_options* g, uint32_t threads, int level, uint64_t chunk_raw_bytes, uint32_t flags, fgx_bam_run_stats* st,
                         uint64_t* rejected_records) {
   if (!c || !in_path || !out_path || !g || !st) return 1;
-  // FGX_PIPE_RING=1 (opt-in): several chunks on their way into the device at once (pipeline_ring.cpp; faster, and not yet trusted: see its header)
-  { const char* e = getenv("FGX_PIPE_RING"); if (e && e[0] == '1') return fgx::run_bam_rejects_ring(c, in_path, out_path, rejects_path, out_header, out_header_len, g, threads, level, chunk_raw_bytes, flags, st, rejected_records); }
   if (rejects_path && !c->opt.track_rejects) { c->err = "fgx_run_bam_rejects: the caller was not created with track_rejects"; return 1; }
   if (rejected_records) *rejected_records = 0;
   c->err.clear();
@@ -686,18 +629,23 @@ int fgx_run_bam_rejects(fgx_caller* c, const char* in_path, const char* out_path
   try {
     fgx::hip_check(hipSetDevice(c->device), "hipSetDevice");
     hipStream_t s = c->stream;
-    if (!c->pipe_state) c->pipe_state = new PipeState();
-    PipeState* S = (PipeState*)c->pipe_state;
+    if (!c->pipe_state_ring) c->pipe_state_ring = new PipeState();
+    PipeState* S = (PipeState*)c->pipe_state_ring;
     fgx::DevBuf* D = S->D;
     fgx::DevBuf &d_off = S->d_off, &d_len = S->d_len, &d_koff = S->d_koff, &d_klen = S->d_klen, &d_grp = S->d_grp;
-    if (!S->s_in) {
-      fgx::hip_check(hipStreamCreateWithFlags(&S->s_in, hipStreamNonBlocking), "hipStreamCreate");
-      for (hipEvent_t* e : {&S->ev_up0, &S->ev_up1, &S->ev_in}) fgx::hip_check(hipEventCreate(e), "hipEventCreate");
-      fgx::hip_check(hipHostMalloc((void**)&S->h_status, 64, hipHostMallocDefault), "hipHostMalloc");
+    constexpr int NB = PipeState::NB;
+    if (!S->h_status) {
+      for (int i = 0; i < NB; i++) {
+        fgx::hip_check(hipStreamCreateWithFlags(&S->s_in[i], hipStreamNonBlocking), "hipStreamCreate");
+        for (hipEvent_t* e : {&S->ev_up0[i], &S->ev_up1[i], &S->ev_in[i]}) fgx::hip_check(hipEventCreate(e), "hipEventCreate");
+      }
+      fgx::hip_check(hipHostMalloc((void**)&S->h_status, 64 * NB, hipHostMallocDefault), "hipHostMalloc");
     }
+    // chunks on their way in beside the one in the device stage (FGX_PIPE_AHEAD = 1 .. NB - 1: a measuring knob)
+    const uint64_t max_ahead = [] { const char* e = getenv("FGX_PIPE_AHEAD"); const int v = e ? atoi(e) : 0; return (uint64_t)((v >= 1 && v < NB) ? v : NB - 1); }();
     // Layout of D[i]: [ front pad | the chunk's inflated stream | slack ].  What a chunk leaves over (its last MI group and the
     // partial record behind it) is copied to the END of the other buffer's pad, so the next chunk's stream can be uploaded and
-    // inflated to a fixed place BEFORE that length is known — on s_in, under this chunk's boundaries / grouping / consensus / download.
+    // inflated to a fixed place BEFORE that length is known — on s_in[.], under this chunk's boundaries / grouping / consensus / download.
     const uint64_t FRONT_PAD = [] { const char* e = getenv("FGX_FRONT_PAD"); const long long v = e ? atoll(e) : 0; return v >= 256 ? ((uint64_t)v + 255) & ~255ull : 8ull << 20; }();   // (the variable: for the test of the widening path)
     uint64_t left_len = 0;                 // bytes the previous chunk left in front of D[cur]'s stream
     int cur = 0;
@@ -706,15 +654,14 @@ int fgx_run_bam_rejects(fgx_caller* c, const char* in_path, const char* out_path
     const bool device_inflate = !(flags & FGX_RUN_HOST_INFLATE);
     const bool device_deflate = (flags & FGX_RUN_DEVICE_DEFLATE) != 0 && level == 1;
     double sec_defl = 0;
-    fgx::DevBuf &d_raw = S->d_raw, &d_blk = S->d_blk;
     std::vector<uint8_t> h_blob; std::vector<uint64_t> h_off; std::vector<uint32_t> h_len, h_grp;   // (only for chunks with deferred families)
     Pipeline* P = &S->P;
     P->reset();
     const bool want_rej = rejects_path != nullptr;
     if (want_rej) P->rej_path = rejects_path;
     uint64_t n_rejected = 0;
-    bool ahead = false;                    // the chunk after the one in the device stage is already on its way into D[cur ^ 1]
-    uint64_t ahead_seq = 0, ahead_inf_len = 0;
+    S->last_max_ahead = 0;
+    uint64_t n_filled = 0;                 // chunks 0 .. n_filled - 1 are in their buffers or on their way (chunk q into D[q % NB])
     // room for a stream of inf_len bytes behind the pad of D[buf]; `preserve` bytes at the end of the pad survive a regrowth
     auto ensure_room = [&](int buf, uint64_t inf_len, uint64_t preserve) {
       if (!S->pad[buf] || !D[buf].cap) S->pad[buf] = FRONT_PAD;
@@ -736,44 +683,69 @@ int fgx_run_bam_rejects(fgx_caller* c, const char* in_path, const char* out_path
       S->pad[buf] = new_pad;
     };
     // chunk `ch` into D[buf]: the compressed bytes and block descriptors over PCIe, DEFLATE + CRC-32 on the device (or, with
-    // FGX_RUN_HOST_INFLATE, the inflated bytes over PCIe) — queued on s_in, ev_in marks the end
+    // FGX_RUN_HOST_INFLATE, the inflated bytes over PCIe) — queued on the buffer's own stream, ev_in[buf] marks the end
     auto launch_fill = [&](Chunk& ch, int buf, uint64_t preserve) {
       ensure_room(buf, ch.inf_len, preserve);
+      S->fill_len[buf] = ch.inf_len;
       uint8_t* dst = (uint8_t*)D[buf].p + S->pad[buf];
-      hipStream_t si = S->s_in;
-      fgx::hip_check(hipEventRecord(S->ev_up0, si), "hipEventRecord");
+      hipStream_t si = S->s_in[buf];
+      uint32_t* const h_status = S->h_status + 16 * buf;
+      fgx::DevBuf &d_raw = S->d_raw[buf], &d_blk = S->d_blk[buf];
+      fgx::hip_check(hipEventRecord(S->ev_up0[buf], si), "hipEventRecord");
       if (device_inflate) {
         const size_t blk_bytes = ch.dev_blocks.size() * sizeof(fgx::BgzfDevBlock);
         d_raw.reserve(ch.raw_len + 64);
         d_blk.reserve(blk_bytes + 64 + 16);
         fgx::hip_check(hipMemcpyAsync(d_raw.p, ch.inf.p, ch.raw_len + 64, hipMemcpyHostToDevice, si), "H2D compressed chunk");
         if (blk_bytes) fgx::hip_check(hipMemcpyAsync(d_blk.p, ch.dev_blocks.data(), blk_bytes, hipMemcpyHostToDevice, si), "H2D block table");
-        fgx::hip_check(hipEventRecord(S->ev_up1, si), "hipEventRecord");
+        fgx::hip_check(hipEventRecord(S->ev_up1[buf], si), "hipEventRecord");
         fgx::bgzf_inflate_launch(si, d_raw.as<uint8_t>(), d_blk.as<fgx::BgzfDevBlock>(), (uint32_t)ch.dev_blocks.size(), dst,
-                                 (uint32_t*)((uint8_t*)d_blk.p + ((blk_bytes + 15) & ~(size_t)15)), S->h_status);
+                                 (uint32_t*)((uint8_t*)d_blk.p + ((blk_bytes + 15) & ~(size_t)15)), h_status);
       } else {
-        *S->h_status = 0;
+        *h_status = 0;
         if (ch.inf_len) fgx::hip_check(hipMemcpyAsync(dst, ch.inf.p, ch.inf_len, hipMemcpyHostToDevice, si), "H2D chunk");
-        fgx::hip_check(hipEventRecord(S->ev_up1, si), "hipEventRecord");
+        fgx::hip_check(hipEventRecord(S->ev_up1[buf], si), "hipEventRecord");
       }
-      fgx::hip_check(hipEventRecord(S->ev_in, si), "hipEventRecord");
+      fgx::hip_check(hipEventRecord(S->ev_in[buf], si), "hipEventRecord");
     };
-    const int rc = P->run(in_path, out_path, out_header, out_header_len, threads, level, chunk_raw_bytes ? chunk_raw_bytes : (512ull << 20), true, device_inflate,
+    const int rc = P->run(in_path, out_path, out_header, out_header_len, threads, level, chunk_raw_bytes ? chunk_raw_bytes : (128ull << 20), true, device_inflate,
                           [&](Chunk& ch, uint64_t seq) {
       fgx::hip_check(hipSetDevice(c->device), "hipSetDevice");
       ch.out_len = 0; ch.packed_len = 0; ch.precompressed = false; ch.have_crcs = false;
-      // ---- this chunk's stream: started while the chunk before was worked on, or now ----
-      if (!(ahead && ahead_seq == seq)) launch_fill(ch, cur, left_len);
-      ahead = false;
-      fgx::hip_check(hipEventSynchronize(S->ev_in), "hipEventSynchronize");
+      // ---- this chunk's stream: started while an earlier chunk was worked on, or now ----
+      cur = (int)(seq % NB);
+      if (n_filled <= seq) { launch_fill(ch, cur, left_len); n_filled = seq + 1; }
+      // ---- the next chunks, as soon as the host stages have them ready: upload + inflate under everything below ----
+      auto try_ahead = [&] {
+        while (!ch.last && n_filled <= seq + max_ahead && P->staged(n_filled)) {
+          Chunk& nx = P->chunks[n_filled % Pipeline::N_CHUNKS];
+          launch_fill(nx, (int)(n_filled % NB), 0);
+          n_filled++;
+          if (n_filled - 1 - seq > S->last_max_ahead) S->last_max_ahead = (uint32_t)(n_filled - 1 - seq);
+          if (nx.last) break;
+        }
+      };
+      // (the wait for this chunk's stream polls: a chunk the host stages deliver meanwhile starts at once, not when this wait ends)
+      for (;;) {
+        const hipError_t q = hipEventQuery(S->ev_in[cur]);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) fgx::hip_check(q, "hipEventQuery");
+        try_ahead();
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+      }
+      // (hipEventQuery says the fill has finished; hipEventSynchronize is what the kernels of the device stage — another stream, another
+      // hardware queue, other XCDs — may rely on for SEEING what it wrote: with eight hardware queues the multi-chunk tests read stale
+      // bytes of the buffer's previous chunk after the query alone, the round-3 form with the synchronize never did)
+      fgx::hip_check(hipEventSynchronize(S->ev_in[cur]), "hipEventSynchronize");
       {
+        // (with several chunks on their way these are the chunk's OWN upload and inflate times: they overlap one another's)
         float ms_up = 0, ms_in = 0;
-        fgx::hip_check(hipEventElapsedTime(&ms_up, S->ev_up0, S->ev_up1), "hipEventElapsedTime");
-        fgx::hip_check(hipEventElapsedTime(&ms_in, S->ev_up1, S->ev_in), "hipEventElapsedTime");
+        fgx::hip_check(hipEventElapsedTime(&ms_up, S->ev_up0[cur], S->ev_up1[cur]), "hipEventElapsedTime");
+        fgx::hip_check(hipEventElapsedTime(&ms_in, S->ev_up1[cur], S->ev_in[cur]), "hipEventElapsedTime");
         sec_h2d += ms_up * 1e-3;
         if (device_inflate) sec_infl += ms_in * 1e-3;
       }
-      if (fgx::bgzf_inflate_status(c, *S->h_status) != 0) throw std::runtime_error(c->err);
+      if (fgx::bgzf_inflate_status(c, S->h_status[16 * cur]) != 0) throw std::runtime_error(c->err);
       uint64_t h = 0;
       if (!header_done) {
         h = device_inflate ? ch.header_size : bam_header_size(ch.inf.p, ch.inf_len);
@@ -793,13 +765,6 @@ int fgx_run_bam_rejects(fgx_caller* c, const char* in_path, const char* out_path
         P->rej_header.resize(h);
         fgx::hip_check(hipMemcpy(P->rej_header.data(), base + (lead - base_off), h, hipMemcpyDeviceToHost), "D2H header");
       }
-      // ---- the next chunk, if the host stages have it ready: upload + inflate under everything below ----
-      auto try_ahead = [&] {
-        if (ahead || ch.last || !P->staged(seq + 1)) return;
-        Chunk& nx = P->chunks[(seq + 1) % Pipeline::N_CHUNKS];
-        launch_fill(nx, cur ^ 1, 0);
-        ahead = true; ahead_seq = seq + 1; ahead_inf_len = nx.inf_len;
-      };
       try_ahead();
       auto t0 = Clock::now();
       // ---- record boundaries ----
@@ -934,15 +899,15 @@ int fgx_run_bam_rejects(fgx_caller* c, const char* in_path, const char* out_path
         st->groups += batch_grp;
         st->kept_records += batch_rec;
       }
-      // ---- what stays behind moves in front of the other buffer's stream ----
+      // ---- what stays behind moves in front of the next buffer's stream ----
       const uint64_t keep = total - batch_end;
-      const int nb = cur ^ 1;
+      const int nb = (int)((seq + 1) % NB);
       if (!ch.last) {
         try_ahead();
-        if (ahead) {
+        if (n_filled > seq + 1) {                                // (the next chunk is in D[nb] or on its way)
           if (keep > S->pad[nb]) {                               // (an enormous last group: wait for the stream, move it behind a wider pad)
-            fgx::hip_check(hipEventSynchronize(S->ev_in), "hipEventSynchronize");
-            widen_pad(nb, keep, ahead_inf_len, ahead_inf_len);   // (`ahead` stays: the stream is in place, its events have fired)
+            fgx::hip_check(hipEventSynchronize(S->ev_in[nb]), "hipEventSynchronize");
+            widen_pad(nb, keep, S->fill_len[nb], S->fill_len[nb]);   // (the stream stays in place, its events have fired)
           }
         } else {
           if (!S->pad[nb] || !D[nb].cap) S->pad[nb] = FRONT_PAD;
@@ -952,10 +917,10 @@ int fgx_run_bam_rejects(fgx_caller* c, const char* in_path, const char* out_path
         if (keep) fgx::hip_check(hipMemcpyAsync((uint8_t*)D[nb].p + S->pad[nb] - keep, base + batch_end, keep, hipMemcpyDeviceToDevice, s), "D2D leftover");
       }
       fgx::hip_check(hipStreamSynchronize(s), "sync");
-      left_len = keep; cur ^= 1;
+      left_len = keep;
       st->chunks = seq + 1;
     });
-    (void)hipStreamSynchronize(S->s_in);   // (a failed run may leave the next chunk's upload in flight)
+    for (int i = 0; i < NB; i++) (void)hipStreamSynchronize(S->s_in[i]);   // (a failed run may leave later chunks' uploads in flight)
     st->in_bytes = P->in_bytes; st->inflated_bytes = P->inflated_bytes; st->out_bytes = P->out_bytes; st->out_file_bytes = P->out_file_bytes;
     st->seconds_read = P->busy[0]; st->seconds_inflate = P->busy[1]; st->seconds_device = P->busy[2]; st->seconds_deflate = P->busy[3]; st->seconds_write = P->busy[4];
     st->seconds_device_inflate = sec_infl; st->device_inflate = device_inflate ? 1u : 0u;
@@ -968,4 +933,5 @@ int fgx_run_bam_rejects(fgx_caller* c, const char* in_path, const char* out_path
   } catch (const std::exception& ex) { c->err = ex.what(); return 3; }
 }
 
-}  // extern "C"
+
+}  // namespace fgx
