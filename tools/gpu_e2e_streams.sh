@@ -1,8 +1,8 @@
 #!/bin/bash
-# the bench line's file -> file leg in the bench process itself (after the 5 M-family steps: the caller's second stream exists, its buffers are
+# the bench line's file -> file leg (ring form of fgx_run_bam, FGX_PIPE_RING=1) in the bench process itself (after the 5 M-family steps: the caller's second stream exists, its buffers are
 # large), with the compute streams at normal / highest priority and with eight hardware queues.  usage: bash tools/gpu_e2e_streams.sh <tag>
 TAG=$1; R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT; cd $R
-run() { local name=$1; shift; env "$@" timeout 300 python bench.py --steps 3 --warmup 1 > $OUT/$name.json 2> $OUT/$name.err
+run() { local name=$1; shift; env FGX_PIPE_RING=1 "$@" timeout 300 python bench.py --steps 3 --warmup 1 > $OUT/$name.json 2> $OUT/$name.err
   python - $OUT/$name.json $name <<'PY'
 import json,sys
 d=json.load(open(sys.argv[1])); e=d['end_to_end']
