@@ -40,6 +40,7 @@
 #include <cstdlib>
 #include <type_traits>
 #include "fastpath.h"
+#include "gate_core.h"
 
 namespace fgx {
 
@@ -998,7 +999,6 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
 // GPU — the four likelihoods stay in registers (selects instead of dynamic indexing, which would go through scratch
 // memory) and the bracket q with thresholds[q] <= gap < thresholds[q+1] comes from the qguess hint plus ONE parallel
 // probe of five neighbouring thresholds instead of a 7-step dependent binary search through LDS.
-struct CallConst { double cap_threshold, half_cerr_at_cap; uint32_t cap; };
 __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long u) {
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
   return ((unsigned long long)hi << 32) | lo;

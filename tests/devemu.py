@@ -42,6 +42,7 @@ def lib():
         VP, U32, U64 = C.c_void_p, C.c_uint32, C.c_uint64
         L.demu_simplex_rejects.argtypes = [VP, VP, U64, VP, VP, U32, VP, U32, VP, U64, VP, VP, VP]
         L.demu_canon.argtypes = [VP, C.c_int, VP, VP, VP, VP, VP, U32, VP, VP, VP, VP, VP, VP]
+        L.demu_gates.argtypes = [C.c_uint8, C.c_uint8, U32, U32, VP, U32, VP, VP, VP, VP, VP, VP]
         _lib = L
     return _lib
 
@@ -90,3 +91,19 @@ def canon(o, codec, g, deferred):
             pre.append(int.from_bytes(bytes(out[o0 - 4:o0]), "little"))
         res.append((int(status[k]), recs, pre, [int(x) for x in delta[5 * k:5 * k + 5]]))
     return res
+
+
+def gates(pre, post, quals, n, m=None, tie=0):
+    """The three unanimous-column gates (gate_core.h) on single-base columns: quals = (count, stride) uint8, n = observations per column,
+    m = the member count the pre-gate's bound is built for (>= n; default n).  Returns (q_exact, q_approx, q_pre, f32 sums): int32 arrays
+    with -1 where a gate does not answer."""
+    L = lib()
+    quals = np.ascontiguousarray(quals, dtype=np.uint8)
+    n = np.ascontiguousarray(n, dtype=np.uint32)
+    m = n if m is None else np.ascontiguousarray(m, dtype=np.uint32)
+    cnt = quals.shape[0]
+    qe, qa, qp = (np.zeros(cnt, dtype=np.int32) for _ in range(3))
+    sums = np.zeros((cnt, 2), dtype=np.float32)
+    rc = L.demu_gates(pre, post, tie, cnt, quals.ctypes.data, quals.shape[1], n.ctypes.data, m.ctypes.data, qe.ctypes.data, qa.ctypes.data, qp.ctypes.data, sums.ctypes.data)
+    assert rc == 0
+    return qe, qa, qp, sums

@@ -77,6 +77,8 @@ double fgx_caller::run_columns(fgx::ColumnBatch&, fgx::ColParams) { return 0.0; 
 
 using namespace fgx;
 
+#include "../../fgumi_amd/csrc/gate_core.h"
+
 extern "C" {
 
 // simplex_rejects_device over a batch held in host memory.  Returns 0; *n_oos > 0 = nothing written.
@@ -119,6 +121,39 @@ int demu_canon(const fgx_options* o, int codec, const uint8_t* blob, const uint6
   for (uint32_t k = 0; k < nd; k++) { delta5[5 * k] = delta[k].minority; for (int i = 0; i < 4; i++) delta5[5 * k + 1 + i] = delta[k].ov[i]; }
   slabs.free_();
   return rc;
+}
+
+// The unanimous-column gates of the simplex kernels (gate_core.h) on the host: for `count` single-base columns — column i observes the
+// n[i] qualities quals[i * stride ..] in this order — the answer of the exact gate on Kahan sums (unanimous_call_lds: k_simplex_wave2,
+// k_simplex_seg, k_deep_cols), of the approximate gate on f32 sums (unanimous_call_approx: k_split_cols) and of its f32 pre-gate for the
+// cap (s2_cap_pregate, with the run's member count m[i] >= n[i]): a quality, or -1 where the gate does not answer.
+int demu_gates(uint8_t pre, uint8_t post, uint32_t tie, uint32_t count, const uint8_t* quals, uint32_t stride, const uint32_t* n, const uint32_t* m,
+               int32_t* q_exact, int32_t* q_approx, int32_t* q_pre, float* sums_f32) {
+  fgx::ConsensusTables t;
+  memset(&t, 0, sizeof(t));
+  fgx::build_tables(t, pre, post, tie);
+  fgx::GateTables G;
+  fgx::fill_gate_tables(G, t);
+  fgx::CallConst K;
+  K.cap = G.cap; K.cap_threshold = G.cap_threshold; K.half_cerr_at_cap = G.half_cerr_at_cap;
+  static float pairf[256][2];
+  fgx::fill_pairs_f32(pairf, 256, t);
+  for (uint32_t i = 0; i < count; i++) {
+    double w = 0.0, cw = 0.0, l = 0.0, cl = 0.0;
+    float acc[2] = {0.0f, 0.0f};
+    for (uint32_t j = 0; j < n[i]; j++) {
+      const uint32_t qb = quals[(size_t)i * stride + j], q = qb < 93 ? qb : 93;
+      { const double y = t.correct[q] - cw, s = w + y; cw = (s - w) - y; w = s; }                  // (kahan2, chain_observe.inc)
+      { const double y = t.error_per_alt[q] - cl, s = l + y; cl = (s - l) - y; l = s; }
+      acc[0] = __builtin_fmaf(pairf[qb][0], 1.0f, acc[0]); acc[1] = __builtin_fmaf(pairf[qb][1], 1.0f, acc[1]);   // (S2_OBSERVE: pair * sel + acc, sel = 1)
+    }
+    uint32_t q = 0;
+    q_exact[i] = fgx::unanimous_call_lds(G, t.cerr_min, K, w, l, &q) ? (int32_t)q : -1;
+    q_approx[i] = fgx::unanimous_call_approx(G, K, acc[0], acc[1], n[i], &q) ? (int32_t)q : -1;
+    q_pre[i] = fgx::s2_cap_pregate(fgx::s2_pregate_consts(G, m[i]), acc[0], acc[1]) ? (int32_t)K.cap : -1;
+    if (sums_f32) { sums_f32[2 * (size_t)i] = acc[0]; sums_f32[2 * (size_t)i + 1] = acc[1]; }
+  }
+  return 0;
 }
 
 }  // extern "C"
