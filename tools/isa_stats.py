@@ -6,7 +6,12 @@ the VALU count of a hot loop body predicts its time well enough to rank variants
 
   tools/isa_stats.py fgumi_amd/csrc/fastpath.hip [-D...] [--kernel k_split_cols] [--loops] [--min-loop 8]
 
-Counts are STATIC (instructions in the body, not executed instructions: a body with internal branches counts every side once)."""
+Counts are STATIC (instructions in the body, not executed instructions: a body with internal branches counts every side once).
+Round 4 added two columns that turned out to matter as much as the VALU count: `slow` = vector instructions that issue at a quarter of the
+rate (v_mul_lo_u32 / v_mul_hi_u32 / v_mad_u64_u32, transcendentals, f64 conversions — per the ISA guide, not measured here —: counted in `valu` too) and `xmask` = exec-mask saves
+(s_and_saveexec / s_or_saveexec / s_andn2_saveexec: one per divergent region the compiler built — nested conditionals over the lane number
+cost k_emit more scalar than vector instructions, profiles/r04_experiments.md); a scalar instruction takes a SIMD's issue slot like a
+vector one (tools/ubench/valu_rate.hip)."""
 import collections
 import os
 import re
@@ -15,6 +20,9 @@ import sys
 import tempfile
 
 CLASSES = ["valu", "salu", "lds", "vmem", "smem", "wait", "branch", "other"]
+EXTRA = ["slow", "xmask"]          # sub-counts (of valu / salu), printed behind the classes
+SLOW = ("v_mul_lo_u32", "v_mul_hi_u32", "v_mul_lo_i32", "v_mul_hi_i32", "v_mad_u64_u32", "v_mad_i64_i32", "v_rcp_", "v_rsq_", "v_sqrt_", "v_log_", "v_exp_", "v_sin_", "v_cos_",
+        "v_cvt_f64_", "v_cvt_u32_f64", "v_cvt_i32_f64", "v_cvt_f32_f64")      # (f64 add / mul / fma issue at the full rate on this part: tools/ubench/valu_rate.hip)
 
 
 def classify(op):
@@ -85,9 +93,15 @@ def parse(asm):
         if not re.match(r"^[a-z]", op):
             continue
         k = classify(op)
-        cur["total"][k] += 1
-        if block_loop is not None:
-            cur["loops"][block_loop]["counts"][k] += 1
+        ks = [k]
+        if k == "valu" and op.startswith(SLOW):
+            ks.append("slow")
+        if k == "salu" and "saveexec" in op:
+            ks.append("xmask")
+        for kk in ks:
+            cur["total"][kk] += 1
+            if block_loop is not None:
+                cur["loops"][block_loop]["counts"][kk] += 1
     return kernels
 
 
@@ -120,7 +134,7 @@ def main():
     kernels = parse(asm)
     names = demangle(list(kernels))
     print(f"# {src} {' '.join(flags)}  (static counts; gfx950)")
-    print(f"{'kernel':60s} " + " ".join(f"{c:>7s}" for c in CLASSES))
+    print(f"{'kernel':60s} " + " ".join(f"{c:>7s}" for c in CLASSES + EXTRA))
     for k, d in kernels.items():
         nm = names[k]
         nm = nm.replace("(anonymous namespace)::", "").replace("fgx::", "")
@@ -129,13 +143,13 @@ def main():
             continue
         if want and want not in nm:
             continue
-        print(f"{nm[:60]:60s} " + " ".join(f"{d['total'][c]:7d}" for c in CLASSES))
+        print(f"{nm[:60]:60s} " + " ".join(f"{d['total'][c]:7d}" for c in CLASSES + EXTRA))
         if show_loops:
             for h, L in d["loops"].items():
-                n = sum(L["counts"].values())
+                n = sum(L["counts"][c] for c in CLASSES)
                 if n < min_loop:
                     continue
-                print(f"    loop {h:12s} depth {L['depth']}  " + " ".join(f"{c}={L['counts'][c]}" for c in CLASSES if L["counts"][c]))
+                print(f"    loop {h:12s} depth {L['depth']}  " + " ".join(f"{c}={L['counts'][c]}" for c in CLASSES + EXTRA if L["counts"][c]))
     return 0
 
 
