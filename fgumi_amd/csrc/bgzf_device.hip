@@ -161,10 +161,10 @@ __global__ __launch_bounds__(256) void k_bgzf_pack(const uint8_t* __restrict__ s
 // inflates `n` blocks (descriptors in device memory) from d_raw into d_out and checks every block's CRC-32: the kernels and the
 // copy of the status word (into PINNED host memory, `h_status`) are queued on `s`; nothing waits.  After `s` has drained,
 // bgzf_inflate_status() turns the word into 0, or 1 with c->err naming the first failing block.
-void bgzf_inflate_launch(hipStream_t s, const uint8_t* d_raw, const BgzfDevBlock* d_blk, uint32_t n, uint8_t* d_out, uint32_t* d_status, uint32_t* h_status) {
+void bgzf_inflate_launch(hipStream_t s, const uint8_t* d_raw, const BgzfDevBlock* d_blk, uint32_t n, uint8_t* d_out, uint32_t* d_status, uint32_t* h_status, bool clear_status) {
   *h_status = 0;
   if (n == 0) return;
-  hip_check(hipMemsetAsync(d_status, 0, 4, s), "memset");
+  if (clear_status) hip_check(hipMemsetAsync(d_status, 0, 4, s), "memset");
   static const uint32_t lanes = [] { const char* e = getenv("FGX_INFL_LANES"); const int v = e ? atoi(e) : 0; return (v == 4 || v == 16 || v == 32 || v == 64) ? (uint32_t)v : INFL_LANES; }();   // (a measuring knob: profiles/r03_experiments.md)
   if (lanes == 4) hipLaunchKernelGGL(k_bgzf_inflate<4>, dim3((n + 3) / 4), dim3(4), 0, s, d_raw, d_blk, n, d_out, d_status);
   else if (lanes == 16) hipLaunchKernelGGL(k_bgzf_inflate<16>, dim3((n + 15) / 16), dim3(16), 0, s, d_raw, d_blk, n, d_out, d_status);

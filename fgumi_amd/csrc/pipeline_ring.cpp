@@ -25,7 +25,7 @@ struct PipeState {
   uint64_t fill_len[NB] = {0, 0, 0, 0, 0};   // inflated bytes of the stream D[i] holds (or is being filled with)
   hipStream_t s_in[NB] = {};          // uploads and inflates a LATER chunk while the device stage works on this one
   hipEvent_t ev_up0[NB] = {}, ev_up1[NB] = {}, ev_in[NB] = {};   // upload begins / upload done / stream inflated and checked
-  uint32_t* h_status = nullptr;       // (pinned) the inflate kernels' status words, 16 words apart
+  uint32_t* h_status = nullptr;       // (pinned) the inflate kernels' status words, 16 words apart; behind them 64 zero bytes (the source of the status clears)
   uint32_t last_max_ahead = 0;        // (diagnostics) the most later chunks that were on their way at once in the last run
 };
 
@@ -79,7 +79,8 @@ int run_bam_rejects_ring(fgx_caller* c, const char* in_path, const char* out_pat
         fgx::hip_check(hipStreamCreateWithFlags(&S->s_in[i], hipStreamNonBlocking), "hipStreamCreate");
         for (hipEvent_t* e : {&S->ev_up0[i], &S->ev_up1[i], &S->ev_in[i]}) fgx::hip_check(hipEventCreate(e), "hipEventCreate");
       }
-      fgx::hip_check(hipHostMalloc((void**)&S->h_status, 64 * NB, hipHostMallocDefault), "hipHostMalloc");
+      fgx::hip_check(hipHostMalloc((void**)&S->h_status, 64 * NB + 64, hipHostMallocDefault), "hipHostMalloc");
+      memset(S->h_status, 0, 64 * NB + 64);
     }
     // chunks on their way in beside the one in the device stage (FGX_PIPE_AHEAD = 1 .. NB - 1: a measuring knob)
     const uint64_t max_ahead = [] { const char* e = getenv("FGX_PIPE_AHEAD"); const int v = e ? atoi(e) : 0; return (uint64_t)((v >= 1 && v < NB) ? v : NB - 1); }();
@@ -138,9 +139,11 @@ int run_bam_rejects_ring(fgx_caller* c, const char* in_path, const char* out_pat
         d_blk.reserve(blk_bytes + 64 + 16);
         fgx::hip_check(hipMemcpyAsync(d_raw.p, ch.inf.p, ch.raw_len + 64, hipMemcpyHostToDevice, si), "H2D compressed chunk");
         if (blk_bytes) fgx::hip_check(hipMemcpyAsync(d_blk.p, ch.dev_blocks.data(), blk_bytes, hipMemcpyHostToDevice, si), "H2D block table");
+        // (the device's status word is cleared by a COPY of zeros, ordered like the uploads around it, not by hipMemsetAsync: bgzf_inflate_launch's note)
+        uint32_t* const d_status = (uint32_t*)((uint8_t*)d_blk.p + ((blk_bytes + 15) & ~(size_t)15));
+        fgx::hip_check(hipMemcpyAsync(d_status, S->h_status + 16 * NB, 16, hipMemcpyHostToDevice, si), "H2D status clear");
         fgx::hip_check(hipEventRecord(S->ev_up1[buf], si), "hipEventRecord");
-        fgx::bgzf_inflate_launch(si, d_raw.as<uint8_t>(), d_blk.as<fgx::BgzfDevBlock>(), (uint32_t)ch.dev_blocks.size(), dst,
-                                 (uint32_t*)((uint8_t*)d_blk.p + ((blk_bytes + 15) & ~(size_t)15)), h_status);
+        fgx::bgzf_inflate_launch(si, d_raw.as<uint8_t>(), d_blk.as<fgx::BgzfDevBlock>(), (uint32_t)ch.dev_blocks.size(), dst, d_status, h_status, false);
       } else {
         *h_status = 0;
         if (ch.inf_len) fgx::hip_check(hipMemcpyAsync(dst, ch.inf.p, ch.inf_len, hipMemcpyHostToDevice, si), "H2D chunk");

@@ -29,29 +29,112 @@
 #include "../../fgumi_amd/csrc/fastpath.h"
 
 // ---- fake HIP runtime ---------------------------------------------------------------------------------------------------------------
+// Two modes.  Default: device memory is host memory, copies are memcpy, streams and events do nothing (everything happens where it is
+// called).  APIEMU_ASYNC=1: a stream is a worker thread with a queue — asynchronous copies, memsets, the BGZF inflate stand-in and event
+// records are queued and run in order per stream, with random pauses, truly beside the calling thread and beside one another; events
+// complete when their record is reached; hipStreamSynchronize / hipEventSynchronize wait, hipEventQuery answers hipErrorNotReady,
+// hipFree waits for every stream (it is a device-wide synchronisation), hipMemcpy is immediate (the legacy null stream does not wait for
+// non-blocking streams).  A missing ordering in fgx_run_bam's host logic — a copy or a fill racing a reader it should wait for —
+// then shows as a byte mismatch on the CPU (tests/test_apiemu.py::test_pipeline_under_asynchronous_streams).
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <random>
+#include <thread>
+namespace emu {
+static bool async_on() { static const bool on = [] { const char* e = getenv("APIEMU_ASYNC"); return e && e[0] == '1'; }(); return on; }
+struct Stream {
+  std::thread th; std::mutex m; std::condition_variable cv, idle; std::deque<std::function<void()>> q; bool stop = false, busy = false;
+};
+struct Event { std::atomic<long> gen{0}, done{0}; };
+static std::mutex g_reg_m;
+static std::vector<Stream*> g_streams;
+static void pause_a_little() {
+  static thread_local std::mt19937 rng((uint32_t)std::hash<std::thread::id>()(std::this_thread::get_id()));
+  static const uint32_t unit = [] { const char* e = getenv("APIEMU_PAUSE_US"); const int v = e ? atoi(e) : 0; return (uint32_t)(v > 0 ? v : 20); }();
+  const uint32_t r = rng() % 8;
+  if (r < 3) std::this_thread::sleep_for(std::chrono::microseconds(unit * (1 + rng() % 40)));   // (0.02 - 0.8 ms with the default unit, three times in eight)
+  else if (r == 3) std::this_thread::yield();
+}
+static void worker(Stream* s) {
+  for (;;) {
+    std::function<void()> f;
+    {
+      std::unique_lock<std::mutex> l(s->m);
+      s->cv.wait(l, [&] { return s->stop || !s->q.empty(); });
+      if (s->q.empty()) return;
+      f = std::move(s->q.front()); s->q.pop_front(); s->busy = true;
+    }
+    pause_a_little();
+    f();
+    { std::lock_guard<std::mutex> l(s->m); s->busy = false; }
+    s->idle.notify_all();
+  }
+}
+static Stream* create() {
+  Stream* s = new Stream();
+  s->th = std::thread(worker, s);
+  std::lock_guard<std::mutex> l(g_reg_m);
+  g_streams.push_back(s);
+  return s;
+}
+static void enqueue(Stream* s, std::function<void()> f) { { std::lock_guard<std::mutex> l(s->m); s->q.push_back(std::move(f)); } s->cv.notify_one(); }
+static void drain(Stream* s) { std::unique_lock<std::mutex> l(s->m); s->idle.wait(l, [&] { return s->q.empty() && !s->busy; }); }
+static void drain_all() {
+  std::vector<Stream*> v;
+  { std::lock_guard<std::mutex> l(g_reg_m); v = g_streams; }
+  for (Stream* s : v) drain(s);
+}
+static void destroy(Stream* s) {
+  drain(s);
+  { std::lock_guard<std::mutex> l(s->m); s->stop = true; }
+  s->cv.notify_all();
+  s->th.join();
+  { std::lock_guard<std::mutex> l(g_reg_m); for (size_t i = 0; i < g_streams.size(); i++) if (g_streams[i] == s) { g_streams.erase(g_streams.begin() + i); break; } }
+  delete s;
+}
+static Stream* of(hipStream_t s) { return (Stream*)s; }
+}  // namespace emu
 extern "C" {
 hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
-hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+hipError_t hipFree(void* p) { if (emu::async_on()) emu::drain_all(); free(p); return hipSuccess; }
 hipError_t hipHostMalloc(void** p, size_t n, unsigned int) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) memmove(d, s, n); return hipSuccess; }
-hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { if (n) memmove(d, s, n); return hipSuccess; }
-hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { if (n) memset(d, v, n); return hipSuccess; }
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t st) {
+  if (emu::async_on() && st) { if (n) emu::enqueue(emu::of(st), [d, s, n] { memmove(d, s, n); }); return hipSuccess; }
+  if (n) memmove(d, s, n);
+  return hipSuccess;
+}
+hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st) {
+  if (emu::async_on() && st) { if (n) emu::enqueue(emu::of(st), [d, v, n] { memset(d, v, n); }); return hipSuccess; }
+  if (n) memset(d, v, n);
+  return hipSuccess;
+}
 hipError_t hipSetDevice(int) { return hipSuccess; }
 hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 const char* hipGetErrorString(hipError_t) { return "apiemu"; }
 hipError_t hipGetLastError(void) { return hipSuccess; }
-hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned int) { *s = nullptr; return hipSuccess; }
-hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned int, int) { *s = nullptr; return hipSuccess; }
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned int) { *s = emu::async_on() ? (hipStream_t)emu::create() : nullptr; return hipSuccess; }
+hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned int, int) { *s = emu::async_on() ? (hipStream_t)emu::create() : nullptr; return hipSuccess; }
 hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) { *least = 0; *greatest = -1; return hipSuccess; }
-hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
-hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
-hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
-hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
-hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
-hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
-hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
+hipError_t hipStreamDestroy(hipStream_t s) { if (emu::async_on() && s) emu::destroy(emu::of(s)); return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t s) { if (emu::async_on() && s) emu::drain(emu::of(s)); return hipSuccess; }
+hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t) new emu::Event(); return hipSuccess; }
+hipError_t hipEventDestroy(hipEvent_t e) { delete (emu::Event*)e; return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) {
+  emu::Event* ev = (emu::Event*)e;
+  const long g = ++ev->gen;
+  if (emu::async_on() && s) emu::enqueue(emu::of(s), [ev, g] { ev->done = g; });
+  else ev->done = g;
+  return hipSuccess;
+}
+hipError_t hipEventSynchronize(hipEvent_t e) { emu::Event* ev = (emu::Event*)e; while (ev->done.load() < ev->gen.load()) std::this_thread::sleep_for(std::chrono::microseconds(20)); return hipSuccess; }
+hipError_t hipEventQuery(hipEvent_t e) { emu::Event* ev = (emu::Event*)e; return ev->done.load() < ev->gen.load() ? hipErrorNotReady : hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
 }
 
@@ -139,6 +222,7 @@ void FastPath::release() {
 }  // namespace fgx
 
 // ---- the lane-per-item kernels, compiled for the host (tests/devemu's shim; this file's runtime definitions stay as they are) -------
+static inline void emu_before_op(hipStream_t s) { if (emu::async_on() && s) emu::drain(emu::of(s)); }
 #define DEVEMU_EMBEDDED 1
 #include "../devemu/devemu.cpp"
 // the general path's kernels, FindBoundaries and the MI grouper are lane-per-item kernels (around scans) as well: the real sources, on the host
@@ -149,7 +233,16 @@ void FastPath::release() {
 // ---- BGZF on the "device": zlib stands in for k_bgzf_inflate / k_bgzf_crc / k_bgzf_crc_blocks (LDS tables, 64-lane CRC folds) -----------
 #include <zlib.h>
 namespace fgx {
-void bgzf_inflate_launch(hipStream_t, const uint8_t* d_raw, const BgzfDevBlock* d_blk, uint32_t n, uint8_t* d_out, uint32_t* d_status, uint32_t* h_status) {
+static void inflate_blocks(const uint8_t* d_raw, const BgzfDevBlock* d_blk, uint32_t n, uint8_t* d_out, uint32_t* d_status, uint32_t* h_status);
+void bgzf_inflate_launch(hipStream_t s, const uint8_t* d_raw, const BgzfDevBlock* d_blk, uint32_t n, uint8_t* d_out, uint32_t* d_status, uint32_t* h_status, bool) {
+  if (emu::async_on() && s) {      // (as the real launch: the host's status word is cleared now, everything else is queued on the stream)
+    *h_status = 0;
+    emu::enqueue(emu::of(s), [=] { inflate_blocks(d_raw, d_blk, n, d_out, d_status, h_status); });
+    return;
+  }
+  inflate_blocks(d_raw, d_blk, n, d_out, d_status, h_status);
+}
+static void inflate_blocks(const uint8_t* d_raw, const BgzfDevBlock* d_blk, uint32_t n, uint8_t* d_out, uint32_t* d_status, uint32_t* h_status) {
   uint32_t st = 0;
   for (uint32_t i = 0; i < n && !st; i++) {
     const BgzfDevBlock& b = d_blk[i];

@@ -35,25 +35,34 @@ template <class F> void launch(dim3 grid, dim3 block, F&& body) {
 #define threadIdx devemu::g_thread
 #define gridDim devemu::g_grid
 #define blockDim devemu::g_bdim
-#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) devemu::launch((grid), (block), [&] { kernel(__VA_ARGS__); })
+// (embedded in tests/apiemu, whose fake runtime may run streams as worker threads: what is queued on `stream` finishes before an
+// operation of these sources — executed where it is called — starts: in-order streams)
+#ifdef DEVEMU_EMBEDDED
+#define DEVEMU_ORDER(stream) emu_before_op(stream)
+#else
+#define DEVEMU_ORDER(stream) ((void)0)
+#endif
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) (DEVEMU_ORDER(stream), devemu::launch((grid), (block), [&] { kernel(__VA_ARGS__); }))
 template <class T, class U> static inline T emu_atomic_add(T* p, U v) { const T o = *p; *p = (T)(o + (T)v); return o; }
 template <class T, class U> static inline T emu_atomic_max(T* p, U v) { const T o = *p; if ((T)v > o) *p = (T)v; return o; }
 #define atomicAdd emu_atomic_add
 #define atomicMax emu_atomic_max
-#define hipMemsetAsync(p, v, n, s) (memset((p), (v), (n)), hipSuccess)
-#define hipMemcpyAsync(d, s, n, k, st) (memcpy((d), (s), (n)), hipSuccess)
-#define hipStreamSynchronize(s) (hipSuccess)
+#define hipMemsetAsync(p, v, n, s) (DEVEMU_ORDER(s), memset((p), (v), (n)), hipSuccess)
+#define hipMemcpyAsync(d, s, n, k, st) (DEVEMU_ORDER(st), memcpy((d), (s), (n)), hipSuccess)
+#define hipStreamSynchronize(s) (DEVEMU_ORDER(s), hipSuccess)
 #define hipGetLastError() (hipSuccess)
 namespace hipcub {
 struct DeviceScan {
-  template <class In, class Out> static hipError_t ExclusiveSum(void* tmp, size_t& bytes, In in, Out out, int n, hipStream_t) {
+  template <class In, class Out> static hipError_t ExclusiveSum(void* tmp, size_t& bytes, In in, Out out, int n, hipStream_t st) {
     if (!tmp) { bytes = 16; return hipSuccess; }
+    DEVEMU_ORDER(st);
     unsigned long long run = 0;
     for (int i = 0; i < n; i++) { const unsigned long long v = in[i]; out[i] = run; run += v; }
     return hipSuccess;
   }
-  template <class In, class Out> static hipError_t InclusiveSum(void* tmp, size_t& bytes, In in, Out out, int n, hipStream_t) {
+  template <class In, class Out> static hipError_t InclusiveSum(void* tmp, size_t& bytes, In in, Out out, int n, hipStream_t st) {
     if (!tmp) { bytes = 16; return hipSuccess; }
+    DEVEMU_ORDER(st);
     unsigned long long run = 0;
     for (int i = 0; i < n; i++) { run += in[i]; out[i] = run; }
     return hipSuccess;
