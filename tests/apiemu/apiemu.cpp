@@ -103,7 +103,16 @@ hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? h
 hipError_t hipFree(void* p) { if (emu::async_on()) emu::drain_all(); free(p); return hipSuccess; }
 hipError_t hipHostMalloc(void** p, size_t n, unsigned int) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
-hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) memmove(d, s, n); return hipSuccess; }
+// (APIEMU_D2D_LATE=1, with APIEMU_ASYNC=1: a device-to-device hipMemcpy returns at once and the bytes move on a stream of its own — "for
+// transfers from device memory to device memory no host-side synchronization is performed": whoever reads the destination without a
+// device-wide synchronisation in between reads what was there before)
+static emu::Stream* null_stream() { static emu::Stream* s = emu::create(); return s; }
+hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind k) {
+  static const bool late = [] { const char* e = getenv("APIEMU_D2D_LATE"); return e && e[0] == '1'; }();
+  if (late && emu::async_on() && k == hipMemcpyDeviceToDevice) { if (n) emu::enqueue(null_stream(), [d, s, n] { memmove(d, s, n); }); return hipSuccess; }
+  if (n) memmove(d, s, n);
+  return hipSuccess;
+}
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t st) {
   if (emu::async_on() && st) { if (n) emu::enqueue(emu::of(st), [d, s, n] { memmove(d, s, n); }); return hipSuccess; }
   if (n) memmove(d, s, n);

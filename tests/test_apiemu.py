@@ -544,7 +544,8 @@ def check_pipeline_async(rounds, chunk):
         c.close()
 
 
-@pytest.mark.parametrize("flags", [dict(), dict(FGX_PIPE_RING=1, FGX_PIPE_AHEAD=1), dict(FGX_PIPE_RING=1, FGX_PIPE_AHEAD=4), dict(FGX_PIPE_RING=1, FGX_PIPE_AHEAD=4, FGX_FRONT_PAD=256)])
+@pytest.mark.parametrize("flags", [dict(), dict(FGX_PIPE_RING=1, FGX_PIPE_AHEAD=1), dict(FGX_PIPE_RING=1, FGX_PIPE_AHEAD=4), dict(FGX_PIPE_RING=1, FGX_PIPE_AHEAD=4, FGX_FRONT_PAD=256),
+                                   dict(APIEMU_D2D_LATE=1, FGX_FRONT_PAD=256), dict(APIEMU_D2D_LATE=1, FGX_PIPE_RING=1, FGX_PIPE_AHEAD=4, FGX_FRONT_PAD=256)])   # (+ device-to-device hipMemcpy that returns before the bytes move)
 def test_pipeline_under_asynchronous_streams(flags):
     """Both forms of fgx_run_bam with truly asynchronous streams in the emulation (the GPU with eight hardware queues is where the ring form
     failed: DESIGN.md section 9; this is the part of that question the CPU can answer — whether the HOST logic orders what it must)."""
