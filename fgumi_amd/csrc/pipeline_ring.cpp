@@ -84,6 +84,11 @@ int run_bam_rejects_ring(fgx_caller* c, const char* in_path, const char* out_pat
     }
     // chunks on their way in beside the one in the device stage (FGX_PIPE_AHEAD = 1 .. NB - 1: a measuring knob)
     const uint64_t max_ahead = [] { const char* e = getenv("FGX_PIPE_AHEAD"); const int v = e ? atoi(e) : 0; return (uint64_t)((v >= 1 && v < NB) ? v : NB - 1); }();
+    // two knobs that bring this form back to pipeline.cpp's behaviour one step at a time (for the hunt of DESIGN.md section 9 item 1):
+    // FGX_PIPE_POLL_AHEAD=0 — no fill is started while the wait for the current chunk's fill lasts (fills strictly one after the other when
+    // FGX_PIPE_AHEAD=1); FGX_PIPE_ONE_STREAM=1 — every fill on the same stream (the ring of buffers stays)
+    const bool poll_ahead = [] { const char* e = getenv("FGX_PIPE_POLL_AHEAD"); return !(e && e[0] == '0'); }();
+    const bool one_stream = [] { const char* e = getenv("FGX_PIPE_ONE_STREAM"); return e && e[0] == '1'; }();
     // Layout of D[i]: [ front pad | the chunk's inflated stream | slack ].  What a chunk leaves over (its last MI group and the
     // partial record behind it) is copied to the END of the other buffer's pad, so the next chunk's stream can be uploaded and
     // inflated to a fixed place BEFORE that length is known — on s_in[.], under this chunk's boundaries / grouping / consensus / download.
@@ -129,7 +134,7 @@ int run_bam_rejects_ring(fgx_caller* c, const char* in_path, const char* out_pat
       ensure_room(buf, ch.inf_len, preserve);
       S->fill_len[buf] = ch.inf_len;
       uint8_t* dst = (uint8_t*)D[buf].p + S->pad[buf];
-      hipStream_t si = S->s_in[buf];
+      hipStream_t si = S->s_in[one_stream ? 0 : buf];
       uint32_t* const h_status = S->h_status + 16 * buf;
       fgx::DevBuf &d_raw = S->d_raw[buf], &d_blk = S->d_blk[buf];
       fgx::hip_check(hipEventRecord(S->ev_up0[buf], si), "hipEventRecord");
@@ -173,7 +178,7 @@ int run_bam_rejects_ring(fgx_caller* c, const char* in_path, const char* out_pat
         const hipError_t q = hipEventQuery(S->ev_in[cur]);
         if (q == hipSuccess) break;
         if (q != hipErrorNotReady) fgx::hip_check(q, "hipEventQuery");
-        try_ahead();
+        if (poll_ahead) try_ahead();
         std::this_thread::sleep_for(std::chrono::microseconds(50));
       }
       // (hipEventQuery says the fill has finished; hipEventSynchronize is what the kernels of the device stage — another stream, another
