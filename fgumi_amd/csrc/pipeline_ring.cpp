@@ -89,6 +89,9 @@ int run_bam_rejects_ring(fgx_caller* c, const char* in_path, const char* out_pat
     // FGX_PIPE_AHEAD=1); FGX_PIPE_ONE_STREAM=1 — every fill on the same stream (the ring of buffers stays)
     const bool poll_ahead = [] { const char* e = getenv("FGX_PIPE_POLL_AHEAD"); return !(e && e[0] == '0'); }();
     const bool one_stream = [] { const char* e = getenv("FGX_PIPE_ONE_STREAM"); return e && e[0] == '1'; }();
+    // FGX_PIPE_WAIT_EVENT=1: the compute stream waits for the fill's event ON THE DEVICE as well (hipStreamWaitEvent) — the first candidate
+    // fix: a dependency between the two hardware queues that the host's wait alone does not create
+    const bool wait_event = [] { const char* e = getenv("FGX_PIPE_WAIT_EVENT"); return e && e[0] == '1'; }();
     // Layout of D[i]: [ front pad | the chunk's inflated stream | slack ].  What a chunk leaves over (its last MI group and the
     // partial record behind it) is copied to the END of the other buffer's pad, so the next chunk's stream can be uploaded and
     // inflated to a fixed place BEFORE that length is known — on s_in[.], under this chunk's boundaries / grouping / consensus / download.
@@ -185,6 +188,7 @@ int run_bam_rejects_ring(fgx_caller* c, const char* in_path, const char* out_pat
       // hardware queue, other XCDs — may rely on for SEEING what it wrote: with eight hardware queues the multi-chunk tests read stale
       // bytes of the buffer's previous chunk after the query alone, the round-3 form with the synchronize never did)
       fgx::hip_check(hipEventSynchronize(S->ev_in[cur]), "hipEventSynchronize");
+      if (wait_event) fgx::hip_check(hipStreamWaitEvent(s, S->ev_in[cur], 0), "hipStreamWaitEvent");
       {
         // (with several chunks on their way these are the chunk's OWN upload and inflate times: they overlap one another's)
         float ms_up = 0, ms_in = 0;

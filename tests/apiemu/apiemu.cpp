@@ -142,6 +142,12 @@ hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) {
   else ev->done = g;
   return hipSuccess;
 }
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned int) {
+  emu::Event* ev = (emu::Event*)e;
+  const long g = ev->gen.load();
+  if (emu::async_on() && s) emu::enqueue(emu::of(s), [ev, g] { while (ev->done.load() < g) std::this_thread::sleep_for(std::chrono::microseconds(20)); });
+  return hipSuccess;
+}
 hipError_t hipEventSynchronize(hipEvent_t e) { emu::Event* ev = (emu::Event*)e; while (ev->done.load() < ev->gen.load()) std::this_thread::sleep_for(std::chrono::microseconds(20)); return hipSuccess; }
 hipError_t hipEventQuery(hipEvent_t e) { emu::Event* ev = (emu::Event*)e; return ev->done.load() < ev->gen.load() ? hipErrorNotReady : hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
