@@ -26,6 +26,7 @@ struct PipeState {
   hipStream_t s_in[NB] = {};          // uploads and inflates a LATER chunk while the device stage works on this one
   hipEvent_t ev_up0[NB] = {}, ev_up1[NB] = {}, ev_in[NB] = {};   // upload begins / upload done / stream inflated and checked
   uint32_t* h_status = nullptr;       // (pinned) the inflate kernels' status words, 16 words apart; behind them 64 zero bytes (the source of the status clears)
+  HostBuf h_blk[NB];                  // FGX_PIPE_PINNED_TABLE=1: a chunk's block table goes through pinned memory (a truly asynchronous copy, ordered on its stream)
   uint32_t last_max_ahead = 0;        // (diagnostics) the most later chunks that were on their way at once in the last run
 };
 
@@ -91,6 +92,8 @@ int run_bam_rejects_ring(fgx_caller* c, const char* in_path, const char* out_pat
     const bool one_stream = [] { const char* e = getenv("FGX_PIPE_ONE_STREAM"); return e && e[0] == '1'; }();
     // FGX_PIPE_WAIT_EVENT=1: the compute stream waits for the fill's event ON THE DEVICE as well (hipStreamWaitEvent) — the first candidate
     // fix: a dependency between the two hardware queues that the host's wait alone does not create
+    // FGX_PIPE_PINNED_TABLE=1: the block table is uploaded from pinned memory (the pageable vector it lives in makes the copy a staged one)
+    const bool pinned_table = [] { const char* e = getenv("FGX_PIPE_PINNED_TABLE"); return e && e[0] == '1'; }();
     const bool wait_event = [] { const char* e = getenv("FGX_PIPE_WAIT_EVENT"); return e && e[0] == '1'; }();
     // Layout of D[i]: [ front pad | the chunk's inflated stream | slack ].  What a chunk leaves over (its last MI group and the
     // partial record behind it) is copied to the END of the other buffer's pad, so the next chunk's stream can be uploaded and
@@ -146,7 +149,9 @@ int run_bam_rejects_ring(fgx_caller* c, const char* in_path, const char* out_pat
         d_raw.reserve(ch.raw_len + 64);
         d_blk.reserve(blk_bytes + 64 + 16);
         fgx::hip_check(hipMemcpyAsync(d_raw.p, ch.inf.p, ch.raw_len + 64, hipMemcpyHostToDevice, si), "H2D compressed chunk");
-        if (blk_bytes) fgx::hip_check(hipMemcpyAsync(d_blk.p, ch.dev_blocks.data(), blk_bytes, hipMemcpyHostToDevice, si), "H2D block table");
+        const void* blk_src = ch.dev_blocks.data();
+        if (pinned_table && blk_bytes) { S->h_blk[buf].reserve(blk_bytes, true); memcpy(S->h_blk[buf].p, ch.dev_blocks.data(), blk_bytes); blk_src = S->h_blk[buf].p; }
+        if (blk_bytes) fgx::hip_check(hipMemcpyAsync(d_blk.p, blk_src, blk_bytes, hipMemcpyHostToDevice, si), "H2D block table");
         // (the device's status word is cleared by a COPY of zeros, ordered like the uploads around it, not by hipMemsetAsync: bgzf_inflate_launch's note)
         uint32_t* const d_status = (uint32_t*)((uint8_t*)d_blk.p + ((blk_bytes + 15) & ~(size_t)15));
         fgx::hip_check(hipMemcpyAsync(d_status, S->h_status + 16 * NB, 16, hipMemcpyHostToDevice, si), "H2D status clear");

@@ -11,6 +11,7 @@ run own_streams        FGX_PIPE_AHEAD=1 FGX_PIPE_POLL_AHEAD=0 FGX_PIPE_ONE_STREA
 run poll_ahead         FGX_PIPE_AHEAD=1 FGX_PIPE_POLL_AHEAD=1 FGX_PIPE_ONE_STREAM=1     # + the next fill may start while the current one runs (same stream: still one after the other on the device)
 run two_fills_at_once  FGX_PIPE_AHEAD=1 FGX_PIPE_POLL_AHEAD=1 FGX_PIPE_ONE_STREAM=0     # + on its own stream: two inflate kernels side by side
 run own_streams_wait  FGX_PIPE_AHEAD=1 FGX_PIPE_POLL_AHEAD=0 FGX_PIPE_ONE_STREAM=0 FGX_PIPE_WAIT_EVENT=1   # the failing step + the compute stream waiting for the fill's event on the device
+run own_streams_pinned FGX_PIPE_AHEAD=1 FGX_PIPE_POLL_AHEAD=0 FGX_PIPE_ONE_STREAM=0 FGX_PIPE_PINNED_TABLE=1  # the failing step + the block table through pinned memory
 run four_ahead_wait    FGX_PIPE_AHEAD=4 FGX_PIPE_POLL_AHEAD=1 FGX_PIPE_ONE_STREAM=0 FGX_PIPE_WAIT_EVENT=1
 run four_ahead_1stream FGX_PIPE_AHEAD=4 FGX_PIPE_POLL_AHEAD=1 FGX_PIPE_ONE_STREAM=1
 run four_ahead         FGX_PIPE_AHEAD=4 FGX_PIPE_POLL_AHEAD=1 FGX_PIPE_ONE_STREAM=0
