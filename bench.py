@@ -168,6 +168,9 @@ def end_to_end(caller, families, depth, read_length, directory, chunk_mb=None, g
                 device_stage_s={k: st["seconds_" + k] for k in ("h2d", "device_inflate", "boundaries", "grouping", "consensus", "d2h")},
                 input_bam_bytes=int(st["in_bytes"]), input_uncompressed_bytes=int(st["inflated_bytes"]), output_bam_bytes=int(st["out_file_bytes"]),
                 consensus_records=int(st["consensus_records"]), deferred_groups=int(st["deferred_groups"]),
+                # (every simulated family is a pair family above --min-reads: two consensus records each — a group cut in two at a chunk border,
+                # the failure form of the opt-in ring pipeline on some runtime settings, would show here)
+                consensus_records_expected=2 * families, records_as_expected=bool(int(st["consensus_records"]) == 2 * families),
                 note="bounded sample of the same workload; stages of successive chunks overlap (total_s is below the sum of the busy times; the h2d / "
                      "device_inflate times of chunks on their way in at once overlap one another); host side = the cores the cgroup grants")
 
