@@ -137,7 +137,7 @@ def write_grouped_bam(path, families, depth, read_length):
 
 def end_to_end(caller, families, depth, read_length, directory, chunk_mb=None, grouped=None):
     """BAM file in -> consensus BAM file out through the streaming pipeline (fgx_run_bam: BGZF inflate + boundaries + MI grouping + consensus + block
-    CRCs on the device, level-1 deflate on the host cores, five overlapping stages, several chunks on their way into the device at once) on a
+    CRCs on the device, level-1 deflate on the host cores, five overlapping stages, the next chunk uploading and inflating while the device stage works on this one) on a
     bounded file of the same workload: what a user of the command sees, next to the device-resident `value`.  Best of two runs, input file in
     the page cache.  `grouped` = (path, records) of an input written before (tools/e2e_chunk_sweep.py)."""
     from fgumi_amd import bgzf
@@ -168,11 +168,9 @@ def end_to_end(caller, families, depth, read_length, directory, chunk_mb=None, g
                 device_stage_s={k: st["seconds_" + k] for k in ("h2d", "device_inflate", "boundaries", "grouping", "consensus", "d2h")},
                 input_bam_bytes=int(st["in_bytes"]), input_uncompressed_bytes=int(st["inflated_bytes"]), output_bam_bytes=int(st["out_file_bytes"]),
                 consensus_records=int(st["consensus_records"]), deferred_groups=int(st["deferred_groups"]),
-                # (every simulated family is a pair family above --min-reads: two consensus records each — a group cut in two at a chunk border,
-                # the failure form of the opt-in ring pipeline on some runtime settings, would show here)
+                # (every simulated family is a pair family above --min-reads: two consensus records each — a group cut in two at a chunk border would show here)
                 consensus_records_expected=2 * families, records_as_expected=bool(int(st["consensus_records"]) == 2 * families),
-                note="bounded sample of the same workload; stages of successive chunks overlap (total_s is below the sum of the busy times; the h2d / "
-                     "device_inflate times of chunks on their way in at once overlap one another); host side = the cores the cgroup grants")
+                note="bounded sample of the same workload; stages of successive chunks overlap (total_s is below the sum of the busy times); host side = the cores the cgroup grants")
 
 
 def pmc_profile(families, depth, read_length):

@@ -20,7 +20,7 @@ SOURCES = ["kernels.hip", "api.cpp", "simplex_host.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-pthread"]
 EXTRA = ("fastpath.hip", "grouping.hip", "boundaries.hip", "bgzf_device.hip", "filter.hip", "canon_device.hip", "reject_device.hip", "duplex_host.cpp",
-         "codec_host.cpp", "bgzf_host.cpp", "pipeline.cpp", "pipeline_ring.cpp")
+         "codec_host.cpp", "bgzf_host.cpp", "pipeline.cpp")
 
 
 def sources():

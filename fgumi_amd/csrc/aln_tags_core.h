@@ -153,7 +153,7 @@ FGX_ALN_HD inline void plan(const uint8_t* rec, uint32_t len, const uint8_t* gen
                             Geometry& G) {
   P = Plan{};
   P.aux_off = len; P.new_len = len;
-  if (len < 36) { P.status = ALN_TOO_SHORT; return; }
+  if (len < 32) { P.status = ALN_TOO_SHORT; return; }     // MIN_BAM_RECORD_LEN (crates/fgumi-raw-bam/src/fields.rs:31; alignment_tags.rs:264)
   const uint32_t l_name = rec[8], n_ops = (uint32_t)rec[12] | ((uint32_t)rec[13] << 8), flag = (uint32_t)rec[14] | ((uint32_t)rec[15] << 8), l_seq = rd32u(rec + 16);
   G.cig_off = 32 + l_name; G.n_ops = n_ops; G.l_seq = l_seq;
   const uint64_t seq_off = 32ull + l_name + 4ull * n_ops, qual_off = seq_off + ((uint64_t)l_seq + 1) / 2, aux_off = qual_off + l_seq;

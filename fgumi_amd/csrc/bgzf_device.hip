@@ -156,15 +156,19 @@ __global__ __launch_bounds__(256) void k_bgzf_pack(const uint8_t* __restrict__ s
   if (i < n) for (uint32_t k = i; k < n && k < i + 16; k++) d[k] = s[k];
 }
 
+__global__ void k_bgzf_clear_status(uint32_t* status) { *status = 0u; }
+
 }  // namespace
 
 // inflates `n` blocks (descriptors in device memory) from d_raw into d_out and checks every block's CRC-32: the kernels and the
 // copy of the status word (into PINNED host memory, `h_status`) are queued on `s`; nothing waits.  After `s` has drained,
 // bgzf_inflate_status() turns the word into 0, or 1 with c->err naming the first failing block.
-void bgzf_inflate_launch(hipStream_t s, const uint8_t* d_raw, const BgzfDevBlock* d_blk, uint32_t n, uint8_t* d_out, uint32_t* d_status, uint32_t* h_status, bool clear_status) {
+void bgzf_inflate_launch(hipStream_t s, const uint8_t* d_raw, const BgzfDevBlock* d_blk, uint32_t n, uint8_t* d_out, uint32_t* d_status, uint32_t* h_status) {
   *h_status = 0;
   if (n == 0) return;
-  if (clear_status) hip_check(hipMemsetAsync(d_status, 0, 4, s), "memset");
+  // the status word is cleared by a KERNEL on the same stream: kernels of one stream run in order, where hipMemsetAsync has been seen to run out
+  // of order with the kernels around it on this runtime (boundaries.hip) — a late clear would wipe an inflate or CRC error
+  hipLaunchKernelGGL(k_bgzf_clear_status, dim3(1), dim3(1), 0, s, d_status);
   static const uint32_t lanes = [] { const char* e = getenv("FGX_INFL_LANES"); const int v = e ? atoi(e) : 0; return (v == 4 || v == 16 || v == 32 || v == 64) ? (uint32_t)v : INFL_LANES; }();   // (a measuring knob: profiles/r03_experiments.md)
   if (lanes == 4) hipLaunchKernelGGL(k_bgzf_inflate<4>, dim3((n + 3) / 4), dim3(4), 0, s, d_raw, d_blk, n, d_out, d_status);
   else if (lanes == 16) hipLaunchKernelGGL(k_bgzf_inflate<16>, dim3((n + 15) / 16), dim3(16), 0, s, d_raw, d_blk, n, d_out, d_status);

@@ -177,7 +177,6 @@ struct fgx_caller {
   uint32_t last_reject_oos = 0;            // ... groups its side kernels could not decide (the batch then took the general path)
   void* rej_state = nullptr;               // buffers of the device `--rejects` side kernels (reject_device.hip: reject_release)
   void* pipe_state = nullptr;              // buffers of fgx_run_bam, kept from run to run (pipeline.cpp: fgx_pipeline_release)
-  void* pipe_state_ring = nullptr;         // the same for the opt-in form with several chunks on their way in (pipeline_ring.cpp)
   uint64_t last_deferred_groups = 0, last_canon_molecules = 0;   // host entry: groups the first device pass deferred / molecules the canonical second pass decided
   uint32_t last_boundary_rounds = 0;       // repair rounds of the last fgx_record_boundaries_device call (boundaries.hip; 0 = every guess was right)
 
@@ -207,10 +206,7 @@ int record_boundaries_device(fgx_caller* c, const uint8_t* d_stream, uint64_t le
                              uint64_t cap, uint64_t* n_rec, uint64_t* consumed);
 // bgzf_device.hip — BGZF inflate on the device: one descriptor per block (offsets into the compressed bytes / the inflated stream)
 struct BgzfDevBlock { uint64_t in_off, out_off; uint32_t in_len, isize, crc, _pad; };   // in_off / in_len: the raw DEFLATE payload
-// (clear_status = false: the caller has zeroed *d_status on this stream already — pipeline_ring.cpp does it with an ordered copy, because
-// hipMemsetAsync has been seen to run out of order with the kernels around it on this runtime, boundaries.hip, and a late one would wipe an error)
-void bgzf_inflate_launch(hipStream_t s, const uint8_t* d_raw, const BgzfDevBlock* d_blk, uint32_t n, uint8_t* d_out, uint32_t* d_status, uint32_t* h_status_pinned,
-                         bool clear_status = true);
+void bgzf_inflate_launch(hipStream_t s, const uint8_t* d_raw, const BgzfDevBlock* d_blk, uint32_t n, uint8_t* d_out, uint32_t* d_status, uint32_t* h_status_pinned);
 int bgzf_inflate_status(fgx_caller* c, uint32_t status_word);
 void bgzf_crc_blocks_device(fgx_caller* c, const uint8_t* d_in, uint64_t len, uint32_t* d_crcs);
 int bgzf_deflate_device(fgx_caller* c, const uint8_t* d_in, uint64_t len, DevBuf& slots, DevBuf& scratch, DevBuf& meta, DevBuf& packed, uint64_t* packed_len);
@@ -235,11 +231,6 @@ inline void create_compute_stream(hipStream_t* s) {
 
 // pipeline.cpp — frees what fgx_run_bam keeps in c->pipe_state
 void pipeline_release(fgx_caller* c);
-// pipeline_ring.cpp — fgx_run_bam_rejects with a ring of stream buffers (FGX_PIPE_RING=1), and what it keeps in c->pipe_state_ring
-void pipeline_ring_release(fgx_caller* c);
-int run_bam_rejects_ring(fgx_caller* c, const char* in_path, const char* out_path, const char* rejects_path, const uint8_t* out_header, uint64_t out_header_len,
-                         const fgx_group_options* g, uint32_t threads, int level, uint64_t chunk_raw_bytes, uint32_t flags, fgx_bam_run_stats* st,
-                         uint64_t* rejected_records);
 // filter.hip — `fgumi filter` on the device
 int filter_records_device(fgx_caller* c, FilterBuffers& B, const fgx_filter_options* o, uint8_t* d_blob, uint64_t blob_len, const uint64_t* d_rec_off,
                           const uint32_t* d_rec_len, uint32_t n, fgx_filter_output* out);

@@ -38,7 +38,6 @@ struct PipeState {
 
 namespace fgx {
 void pipeline_release(fgx_caller* c) {
-  pipeline_ring_release(c);
   if (!c || !c->pipe_state) return;
   PipeState* S = (PipeState*)c->pipe_state;
   for (auto* b : {&S->D[0], &S->D[1], &S->d_off, &S->d_len, &S->d_koff, &S->d_klen, &S->d_grp, &S->d_raw, &S->d_blk, &S->d_slots, &S->d_dscratch, &S->d_dmeta, &S->d_packed, &S->d_crcs}) b->free_();
@@ -91,18 +90,30 @@ int fgx_bgzf_inflate_device_bench(fgx_caller* c, const uint8_t* raw, uint64_t ra
       d._pad = 0;
       dev[i] = d;
     }
-    fgx::DevBuf d_raw, d_blk, d_out;
+    // everything this entry allocates is released on every way out (a hip_check that throws included)
+    struct Scope {
+      fgx::DevBuf d_raw, d_blk, d_out;
+      uint32_t* h_status = nullptr;
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      ~Scope() {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        if (h_status) (void)hipHostFree(h_status);
+        d_raw.free_(); d_blk.free_(); d_out.free_();
+      }
+    } R;
+    fgx::DevBuf &d_raw = R.d_raw, &d_blk = R.d_blk, &d_out = R.d_out;
     d_raw.reserve(used + 64); d_blk.reserve(dev.size() * sizeof(fgx::BgzfDevBlock) + 64); d_out.reserve(infl + 256);
-    uint32_t* h_status = nullptr;
-    fgx::hip_check(hipHostMalloc((void**)&h_status, 64, hipHostMallocDefault), "hipHostMalloc");
+    fgx::hip_check(hipHostMalloc((void**)&R.h_status, 64, hipHostMallocDefault), "hipHostMalloc");
+    uint32_t* const h_status = R.h_status;
     hipStream_t s = c->stream;
     fgx::hip_check(hipMemcpyAsync(d_raw.p, raw, used, hipMemcpyHostToDevice, s), "H2D");
     fgx::hip_check(hipMemsetAsync((uint8_t*)d_raw.p + used, 0, 64, s), "memset");
     const size_t blk_bytes = dev.size() * sizeof(fgx::BgzfDevBlock);
     if (blk_bytes) fgx::hip_check(hipMemcpyAsync(d_blk.p, dev.data(), blk_bytes, hipMemcpyHostToDevice, s), "H2D");
     uint32_t* d_status = (uint32_t*)((uint8_t*)d_blk.p + ((blk_bytes + 15) & ~(size_t)15));
-    hipEvent_t e0, e1;
-    fgx::hip_check(hipEventCreate(&e0), "event"); fgx::hip_check(hipEventCreate(&e1), "event");
+    fgx::hip_check(hipEventCreate(&R.e0), "event"); fgx::hip_check(hipEventCreate(&R.e1), "event");
+    const hipEvent_t e0 = R.e0, e1 = R.e1;
     int rc = 0;
     fgx::bgzf_inflate_launch(s, d_raw.as<uint8_t>(), d_blk.as<fgx::BgzfDevBlock>(), (uint32_t)dev.size(), d_out.as<uint8_t>(), d_status, h_status);   // warm-up
     fgx::hip_check(hipStreamSynchronize(s), "sync");
@@ -118,8 +129,6 @@ int fgx_bgzf_inflate_device_bench(fgx_caller* c, const uint8_t* raw, uint64_t ra
     *ms = (double)t / (double)(reps ? reps : 1u);
     *inflated_len = infl;
     if (rc == 0 && out && inflated_cap >= infl && infl) fgx::hip_check(hipMemcpy(out, d_out.p, infl, hipMemcpyDeviceToHost), "D2H");
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipHostFree(h_status);
-    d_raw.free_(); d_blk.free_(); d_out.free_();
     return rc;
   } catch (const std::exception& ex) { c->err = ex.what(); return 3; }
 }
@@ -136,8 +145,6 @@ int fgx_run_bam_rejects(fgx_caller* c, const char* in_path, const char* out_path
                         const fgx_group_options* g, uint32_t threads, int level, uint64_t chunk_raw_bytes, uint32_t flags, fgx_bam_run_stats* st,
                         uint64_t* rejected_records) {
   if (!c || !in_path || !out_path || !g || !st) return 1;
-  // FGX_PIPE_RING=1 (opt-in): several chunks on their way into the device at once (pipeline_ring.cpp; faster, and not yet trusted: see its header)
-  { const char* e = getenv("FGX_PIPE_RING"); if (e && e[0] == '1') return fgx::run_bam_rejects_ring(c, in_path, out_path, rejects_path, out_header, out_header_len, g, threads, level, chunk_raw_bytes, flags, st, rejected_records); }
   if (rejects_path && !c->opt.track_rejects) { c->err = "fgx_run_bam_rejects: the caller was not created with track_rejects"; return 1; }
   if (rejected_records) *rejected_records = 0;
   c->err.clear();

@@ -1,6 +1,5 @@
 // pipeline_stages.h — the host stages of fgx_run_bam (reader, inflate / staging, the middle stage's frame, deflate, writer: a thread each
-// over a ring of chunks), shared by pipeline.cpp (one chunk ahead, the default) and pipeline_ring.cpp (several chunks on their way into the
-// device, opt-in).  Everything has internal linkage: each of the two translation units compiles its own copy.
+// over a ring of chunks) for pipeline.cpp (one chunk ahead).  Everything has internal linkage.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <fcntl.h>

@@ -194,14 +194,19 @@ class ConsensusFilter:
 
     def set_reference(self, reference, ref_names: Sequence[str]):
         """`--ref <fasta>`: `reference` maps a contig name to its bases, `ref_names[i]` = the name of contig i of the BAM header (a record's
-        reference id).  Like the command's loader this fails when a header contig is missing from the FASTA (`ReferenceReader` would hand back an
-        error at the first record that needs it; filter.rs opens the FASTA up front).  `set_reference(None, [])` drops the reference again."""
+        reference id).  A header contig that `reference` lacks raises `KeyError` HERE: the reference fails with "Reference not found: <contig>"
+        at the first record that needs the contig (alignment_tags.rs:482) — an empty stand-in would instead surface as a generic
+        out-of-range error there, and the reference-dependent methylation filters would read every base of that contig as unknown.
+        `set_reference(None, [])` drops the reference again."""
         names = list(ref_names or [])
         if reference is None or not names:
             self._check(lib.fgx_set_reference(self._h, 0, None, None))
             self._o.regenerate_alignment_tags = 0
             return
-        seqs = [bytes(reference.get(n, b"")) for n in names]
+        missing = [n for n in names if n not in reference]
+        if missing:
+            raise KeyError(f"Reference not found: {missing[0]} (header contig absent from the FASTA; {len(missing)} of {len(names)} missing)")
+        seqs = [bytes(reference[n]) for n in names]
         bufs = [C.create_string_buffer(s, max(1, len(s))) for s in seqs]
         ptrs = (C.c_void_p * len(seqs))(*[C.cast(b, C.c_void_p).value for b in bufs])
         lens = (C.c_uint64 * len(seqs))(*[len(s) for s in seqs])

@@ -380,8 +380,7 @@ int fgx_record_boundaries_device(fgx_caller* c, const void* d_stream, uint64_t s
 /* A BAM file in, a consensus BAM file out (fgumi_amd/csrc/pipeline.cpp): read -> BGZF inflate (worker pool, pinned buffers) ->
  * upload -> record boundaries -> MI grouping -> consensus batch -> download -> BGZF deflate -> write, as five overlapping stages
  * over chunks of `chunk_raw_bytes` compressed bytes (0 = 512 MiB: the device inflate runs a lane per BGZF block, so a chunk should hold
- * tens of thousands of them; FGX_PIPE_RING=1 opts into the form with up to four later chunks on their way in at once, 0 = 128 MiB there
- * — pipeline_ring.cpp).  Stands in, for this path, for the reader / FindBoundaries /
+ * tens of thousands of them).  Stands in, for this path, for the reader / FindBoundaries /
  * group / process / compress / write steps of src/lib/unified_pipeline/bam.rs around `process_fn`.  `out_header` = the
  * uncompressed BAM header of the output ("BAM\1", l_text, text, n_ref = 0): written as its own BGZF block(s).  A group that
  * reaches the end of a chunk waits for the next chunk (it may continue there).  `threads` = pool size (0 = all cores).

@@ -327,7 +327,7 @@ inline void update_int_tag(Bytes& rec, const char tag[2], int32_t value) {   // 
 // header = seqs[i], as fgx_set_reference / orc_set_reference hand it over; a contig the FASTA lacks is empty).  Returns true when the tags
 // were recomputed, false when they were removed.
 inline bool regenerate_alignment_tags_raw(Bytes& rec, const Reference& ref) {
-  if (rec.size() < 36) throw OracleError{"BAM record too short (minimum 36 bytes)"};
+  if (rec.size() < 32) throw OracleError{"BAM record too short (minimum 32 bytes)"};   // MIN_BAM_RECORD_LEN = 32 (fgumi-raw-bam/src/fields.rs:31)
   RecView v0(rec.data(), rec.size());
   if (v0.flags() & flags::UNMAPPED) { remove_tag(rec, "NM"); remove_tag(rec, "UQ"); remove_tag(rec, "MD"); return false; }
   int32_t ref_id = v0.ref_id();

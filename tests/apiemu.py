@@ -11,7 +11,7 @@ BUILD = os.path.join(ROOT, "tests", "hostemu", "_build")
 TSAN = os.environ.get("HOSTEMU_SANITIZE") == "thread"    # ThreadSanitizer build (the sharded general path, the host threads of the canonical pass)
 SANITIZE = os.environ.get("HOSTEMU_SANITIZE") == "1"     # tools/sanitize_host.sh: ASan + UBSan build, loaded under LD_PRELOAD of the ASan runtime (children inherit it)
 OUT = os.path.join(BUILD, "libapiemu_tsan.so" if TSAN else "libapiemu_san.so" if SANITIZE else "libapiemu.so")
-HOST = ["api.cpp", "simplex_host.cpp", "duplex_host.cpp", "codec_host.cpp", "bgzf_host.cpp", "pipeline.cpp", "pipeline_ring.cpp"]
+HOST = ["api.cpp", "simplex_host.cpp", "duplex_host.cpp", "codec_host.cpp", "bgzf_host.cpp", "pipeline.cpp"]
 CL = "/opt/rocm/lib/llvm/bin/clang++"        # (inflate_core.h uses clang builtins)
 
 

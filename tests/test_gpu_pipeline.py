@@ -111,34 +111,6 @@ def test_bam_file_to_consensus_bam_file_simplex(tmp_path, host_inflate):
     c.close()
 
 
-@pytest.mark.xfail(strict=False, reason="FGX_PIPE_RING=1 is opt-in because this test depends on how the runtime maps streams to hardware queues: green with the default four "
-                                        "(every run of round 4), red with GPU_MAX_HW_QUEUES=8 or high-priority compute streams (DESIGN.md section 9)")
-@pytest.mark.parametrize("ahead", [1, 2, 4])
-def test_several_chunks_on_their_way_in(tmp_path, monkeypatch, ahead):
-    """FGX_PIPE_RING=1 (opt-in, pipeline_ring.cpp): while the device stage works on a chunk, up to FGX_PIPE_AHEAD later chunks (default 4) are
-    uploaded and inflated, each into its own buffer of the ring and on its own stream (a single chunk's BGZF blocks do not fill the chip: the
-    inflate kernels of several chunks run side by side).  The records are the oracle's at every depth, with groups crossing the chunks and
-    leftovers wider than the pad — with the runtime's default of four hardware queues; with GPU_MAX_HW_QUEUES=8 this test FAILS (the reason
-    the form is opt-in: DESIGN.md §9)."""
-    import ctypes as C
-    from fgumi_amd import lib
-    lib.fgx_debug_last_chunks_ahead.restype = C.c_uint32
-    lib.fgx_debug_last_chunks_ahead.argtypes = [C.c_void_p]
-    monkeypatch.setenv("FGX_PIPE_RING", "1")
-    monkeypatch.setenv("FGX_PIPE_AHEAD", str(ahead))
-    g = simulate_grouped_reads(5000, family_size=2, family_size_max=30)
-    c = _caller()
-    st = _run_and_compare(tmp_path, c, fgx_opts.defaults(min_reads=1), g, 50, 1 << 16)
-    assert st["chunks"] > 20
-    assert 1 <= lib.fgx_debug_last_chunks_ahead(c._h) <= ahead        # (how far ahead depends on how fast the host stages deliver)
-    monkeypatch.setenv("FGX_FRONT_PAD", "256")
-    c2 = _caller()
-    st = _run_and_compare(tmp_path, c2, fgx_opts.defaults(min_reads=1), g, 50, 1 << 16)
-    assert st["chunks"] > 20
-    c.close()
-    c2.close()
-
-
 @pytest.mark.parametrize("host_inflate", [False, True])
 def test_a_leftover_larger_than_the_front_pad_widens_it(tmp_path, monkeypatch, host_inflate):
     """The next chunk is uploaded and inflated behind a front pad while this one is worked on; what this chunk leaves over (its last MI

@@ -1,6 +1,6 @@
-"""The file -> file leg of bench.py (fgx_run_bam) over chunk sizes and numbers of chunks on their way into the device at once
-(FGX_PIPE_AHEAD): one input file per size, every combination twice (best of two inside bench.end_to_end).  Run on the GPU box:
-    [E2E_SWEEP_AHEAD=0,1,3,4] [E2E_SWEEP_MB=512,256,128,64,32] python tools/e2e_chunk_sweep.py [families ...]      (default 250000 1000000)"""
+"""The file -> file leg of bench.py (fgx_run_bam) over chunk sizes: one input file per size, every size twice (best of two inside
+bench.end_to_end).  Run on the GPU box:
+    [E2E_SWEEP_MB=512,256,128,64,32] python tools/e2e_chunk_sweep.py [families ...]      (default 250000 1000000)"""
 import json
 import os
 import sys
@@ -16,9 +16,7 @@ rows = []
 for fam in [int(a) for a in sys.argv[1:]] or [250000, 1000000]:
     path = os.path.join(d, f"grouped_{fam}.bam")
     n_rec = bench.write_grouped_bam(path, fam, 8, 150)
-    for ahead in [int(a) for a in os.environ.get("E2E_SWEEP_AHEAD", "0,1,3,4").split(",")]:     # 0 = the default pipeline (pipeline.cpp), k > 0 = the ring form with k chunks ahead
-        os.environ["FGX_PIPE_RING"] = "1" if ahead else "0"
-        os.environ["FGX_PIPE_AHEAD"] = str(max(ahead, 1))
+    for ahead in [0]:
         for mb in [int(a) for a in os.environ.get("E2E_SWEEP_MB", "512,256,128,64,32").split(",")]:
             r = bench.end_to_end(c, fam, 8, 150, d, chunk_mb=mb, grouped=(path, n_rec))
             row = dict(families=fam, ahead=ahead, chunk_mb=mb, M_reads_s=round(r["value"] / 1e6, 1), chunks=r["chunks"], total_s=round(r["total_s"], 4), bottleneck=r["bottleneck"],
