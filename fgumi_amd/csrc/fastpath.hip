@@ -3772,6 +3772,10 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
   P.fw_image = d_fwimg.p;
   P.min_reads = o.min_reads; P.max_reads = o.max_reads;
   P.min_input_bq = o.min_input_base_quality; P.min_cons_bq = o.min_consensus_base_quality;
+  {   // k_split_cols's sum-free observation step: from how many agreeing observations a column is the cap whatever their qualities (gate_core.h)
+    static const int nosum_env = [] { const char* e = getenv("FGX_S2_NOSUM"); return e ? atoi(e) : 1; }();      // (measurement knob: 0 = every end through the f32 sums)
+    P.s2_nsafe = nosum_env ? unanimous_cap_depth(c->h_tables.t, (uint32_t)o.min_input_base_quality & 0xFFu, 64u) : FGX_NEVER_CAP;
+  }
   P.trim = o.trim; P.overlap = o.overlapping_consensus;
   if (duplex) {   // single-strand caller of the duplex caller (duplex_caller.rs:474-489): min_reads 1, min consensus base quality 2
     P.min_reads = 1; P.max_reads = -1; P.min_cons_bq = FGX_MIN_PHRED;

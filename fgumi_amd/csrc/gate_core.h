@@ -144,4 +144,34 @@ FGX_HD bool s2_cap_pregate(const S2PreGate& g, float wf, float lf) {
 }
 
 
+// The cap WITHOUT sums (round 5: k_split_cols's hot loop).  A single-base column of n observations whose qualities all lie in
+// [min_bq, 93] (bytes above 93 count as 93, base_builder.rs:836-868) has the reference's gap w - l >= n dmin - (Kahan error), dmin = the
+// smallest correct[q] - error_per_alt[q] of that range.  try_unanimous_fast_path (base_builder.rs:883-994) answers the cap as soon as
+// gap - thresholds[cap] >= ln 2 and 16 (eps / 2) (|w| + |l|) < cerr_min[cap - 1] / 2 — so from
+//     n_safe = the smallest n with  n dmin >= thresholds[cap] + ln 2 + slack
+// observations on EVERY such column is (base, cap), whatever the qualities are: the loop then needs the OR of the bases and a count, no
+// table, no sum.  `slack` covers the two Kahan sums (each within 2 eps sum|x| + O(n eps^2) of its real value; 4 eps n_max mag is generous)
+// and the roundings of the gate's own subtraction; the margin budget is checked for the deepest column the caller will ask about (n_max).
+// Returns FGX_NEVER_CAP when the table has a non-finite entry in the range (quality 0: ln 0), dmin <= 0, or the budget fails: the caller
+// then keeps to the sums.  The tests run the oracle's ConsensusBaseBuilder over columns at and above n_safe (tests/test_gate_core.py).
+#define FGX_NEVER_CAP 0xFFFFFFFFu
+FGX_HD uint32_t unanimous_cap_depth(const ConsensusTables& t, uint32_t min_bq, uint32_t n_max) {
+  const uint32_t lo = min_bq < 93u ? min_bq : 93u;
+  double dmin = 1.0e300, mag = 0.0;
+  for (uint32_t q = lo; q <= 93u; q++) {
+    const double c = t.correct[q], e = t.error_per_alt[q];
+    if (!m_isfinite(c) || !m_isfinite(e)) return FGX_NEVER_CAP;
+    const double d = c - e, a = m_fabs(c) + m_fabs(e);
+    dmin = d < dmin ? d : dmin; mag = a > mag ? a : mag;
+  }
+  const double need = t.cap_threshold + FGX_LN_2;
+  if (!(dmin > 0.0) || !m_isfinite(need) || t.cap < 2u || t.cap > 93u) return FGX_NEVER_CAP;
+  const double kahan = 4.0 * FGX_DBL_EPSILON * (double)n_max * mag;
+  if (!(16.0 * (FGX_DBL_EPSILON / 2.0) * (double)n_max * mag * 1.000001 + kahan < t.half_cerr_at_cap)) return FGX_NEVER_CAP;
+  for (uint32_t n = 1; n <= n_max; n++)
+    if ((double)n * dmin * (1.0 - 1.0e-12) - kahan - 1.0e-9 >= need) return n;
+  return FGX_NEVER_CAP;
+}
+
+
 }  // namespace fgx

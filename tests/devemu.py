@@ -43,6 +43,8 @@ def lib():
         L.demu_simplex_rejects.argtypes = [VP, VP, U64, VP, VP, U32, VP, U32, VP, U64, VP, VP, VP]
         L.demu_canon.argtypes = [VP, C.c_int, VP, VP, VP, VP, VP, U32, VP, VP, VP, VP, VP, VP]
         L.demu_gates.argtypes = [C.c_uint8, C.c_uint8, U32, U32, VP, U32, VP, VP, VP, VP, VP, VP]
+        L.demu_cap_depth.argtypes = [C.c_uint8, C.c_uint8, U32, U32, U32, VP]
+        L.demu_cap_depth.restype = U32
         _lib = L
     return _lib
 
@@ -107,3 +109,10 @@ def gates(pre, post, quals, n, m=None, tie=0):
     rc = L.demu_gates(pre, post, tie, cnt, quals.ctypes.data, quals.shape[1], n.ctypes.data, m.ctypes.data, qe.ctypes.data, qa.ctypes.data, qp.ctypes.data, sums.ctypes.data)
     assert rc == 0
     return qe, qa, qp, sums
+
+
+def cap_depth(pre, post, min_bq, n_max=64, tie=0):
+    """unanimous_cap_depth (gate_core.h): (n_safe or None when the table never allows the shortcut, cap)."""
+    cap = C.c_uint32(0)
+    n = lib().demu_cap_depth(pre, post, tie, min_bq, n_max, C.addressof(cap))
+    return (None if n == 0xFFFFFFFF else int(n)), int(cap.value)

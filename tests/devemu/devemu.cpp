@@ -165,4 +165,13 @@ int demu_gates(uint8_t pre, uint8_t post, uint32_t tie, uint32_t count, const ui
   return 0;
 }
 
+// unanimous_cap_depth (gate_core.h): the observation count from which a single-base column with every quality >= min_bq is the cap
+uint32_t demu_cap_depth(uint8_t pre, uint8_t post, uint32_t tie, uint32_t min_bq, uint32_t n_max, uint32_t* cap) {
+  fgx::ConsensusTables t;
+  memset(&t, 0, sizeof(t));
+  fgx::build_tables(t, pre, post, tie);
+  if (cap) *cap = t.cap;
+  return fgx::unanimous_cap_depth(t, min_bq, n_max);
+}
+
 }  // extern "C"

@@ -125,3 +125,38 @@ def test_every_two_quality_column_up_to_40_reads(pre, post):
             bld.add("C", int(q[i, j]))
         got = bld.fast_path()
         assert got == (None if qe[i] < 0 else ("C", int(qe[i]))), (i, got, qe[i])
+
+
+@pytest.mark.parametrize("pre,post", SETTINGS)
+@pytest.mark.parametrize("min_bq", [0, 2, 10, 20, 40])
+def test_from_the_cap_depth_on_every_single_base_column_is_the_cap(pre, post, min_bq):
+    """unanimous_cap_depth (round 5: k_split_cols decides the usual column from the OR of its bases and a count): n_safe agreeing observations
+    of ANY qualities >= the floor make the reference's fast path answer (base, cap) — checked on the oracle's ConsensusBaseBuilder with the
+    worst quality of the range repeated, random qualities, bytes above 93, and depths up to the 64 the bound is built for; one observation
+    fewer of the worst quality does NOT (the depth is tight, i.e. the function is not vacuous)."""
+    n_safe, cap = devemu.cap_depth(pre, post, min_bq)
+    b = orc.Builder(pre, post)
+    if min_bq == 0:
+        assert n_safe is None                                      # quality 0 is ln 0: never
+        return
+    if n_safe is None:
+        return                                                     # (a table that never reaches the budget: the kernel keeps to the sums)
+    assert 1 <= n_safe <= 64
+    rng = np.random.default_rng(pre * 1000 + post * 10 + min_bq)
+
+    def call(quals):
+        b.reset()
+        for q in quals:
+            b.add("G", int(min(q, 93)))
+        return b.fast_path()
+    # the worst quality of the range: the one whose n_safe-fold column has the smallest gap = the floor itself or 93 (the table is monotone
+    # in neither direction at the extremes), so try every quality of the range at exactly n_safe
+    for q in range(min(min_bq, 93), 94):
+        assert call([q] * n_safe) == ("G", cap), (q, n_safe)
+        assert call([q] * 64) == ("G", cap), (q, 64)
+    for _ in range(3000):
+        n = int(rng.integers(n_safe, 65))
+        quals = rng.integers(min_bq, 256 if rng.random() < 0.1 else 94, size=n)
+        assert call(quals) == ("G", cap), (n, quals.tolist())
+    if n_safe > 1:
+        assert any(call([q] * (n_safe - 1)) != ("G", cap) for q in range(min(min_bq, 93), 94))
