@@ -238,9 +238,10 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl")
-    # `auto` = none: the single-writer gather is a second timed loop over RCCL point-to-point that no multi-GPU box has run yet — the
-    # driver's scaling runs get the compute line unconditionally; `--reassemble root` adds the gather figures beside it
-    reassemble = args.reassemble if args.reassemble != "auto" else "none"
+    # `auto`: with more than one rank the single-writer gather (sizes all_gather + one batch_isend_irecv group into rank 0) is timed in
+    # a SECOND loop and reported beside `value` (value_with_reassembly_on_root / gather_GBs_into_root), never instead of it; a failure of that
+    # loop is reported in `reassemble_error` and costs nothing else of the line.  One rank: nothing to gather.
+    reassemble = args.reassemble if args.reassemble != "auto" else ("root" if world > 1 else "none")
 
     from fgumi_amd import (CodecConsensusCaller, CodecConsensusOptions, DuplexConsensusCaller, VanillaUmiConsensusCaller,
                            VanillaUmiConsensusOptions, simulated_family_bytes)
@@ -300,16 +301,19 @@ def main():
         for _ in range(warmup):
             out = caller.process_batch_device(dg)
         dt, out, k_family_ms, k_emit_ms, k_total_ms, _ = timed_loop(steps, False)           # the K timed steps: `value`
-        dt_gather, gathered_bytes = None, 0
+        dt_gather, gathered_bytes, gather_error = None, 0, None
         if with_gather:                                                                      # the same K steps with the gather to rank 0
-            r = timed_loop(steps, True)
-            dt_gather, gathered_bytes = r[0], r[5]
+            try:
+                r = timed_loop(steps, True)
+                dt_gather, gathered_bytes = r[0], r[5]
+            except Exception as ex:                                                          # (the compute line stands on its own)
+                gather_error = str(ex)[:300]
         per_rank = gather_sizes([out.data_len, out.count, dg.n_rec, out.n_deferred, fam, shard_bytes,
                                  int(round(k_family_ms / steps * 1e3)), int(round(k_emit_ms / steps * 1e3))], "cuda")   # rank (= input) order
         # the batch counters (ConsensusCallingStats / RejectionReason order, then the overlap CorrectionStats) summed over the ranks
         counters = sum_over_ranks(caller.last_stats_array, "cuda")
         res = dict(dt=dt, out_count=int(out.count), n_rec=int(dg.n_rec), fam=fam, k_family_ms=k_family_ms, k_emit_ms=k_emit_ms, k_total_ms=k_total_ms,
-                   dt_gather=dt_gather, gathered_bytes=gathered_bytes, per_rank=per_rank, counters=counters, full_columns=caller.last_timing.get("full_columns"))
+                   dt_gather=dt_gather, gathered_bytes=gathered_bytes, gather_error=gather_error, per_rank=per_rank, counters=counters, full_columns=caller.last_timing.get("full_columns"))
         del dg, out
         torch.cuda.empty_cache()
         return res
@@ -362,7 +366,7 @@ def main():
                        "deferred_families": total_def, "output_bytes": total_bytes,
                        "reassemble": ("none (payloads stay on their ranks: a writer per rank; --reassemble root times the single-writer gather beside)" if reassemble == "none"
                                       else "none in `value` (payloads stay on their ranks); gather to rank 0 timed beside"),
-                       "reassembled_bytes_on_rank0": gathered_bytes,
+                       "reassembled_bytes_on_rank0": gathered_bytes, "reassemble_error": M.get("gather_error"),
                        "value_with_reassembly_on_root": (total_raw * steps / dt_gather) if dt_gather else None,
                        "ms_per_step_with_reassembly_on_root": (dt_gather / steps * 1e3) if dt_gather else None,
                        "gather_GBs_into_root": ((gathered_bytes - int(per_rank[0, 0])) * steps / max(dt_gather - dt, 1e-9) / 1e9) if (dt_gather and dt_gather > dt) else None,
@@ -375,11 +379,14 @@ def main():
                          # from the committed PMC passes (`traffic_source`), NOT measured in this run
                          "traffic": ((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0) if (pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc) else None,
                          "traffic_source": pmc_file,
-                         "kernel": ("k_family stage (k_split_parse + k_split_cols + k_split_finish | k_simplex_seg, then k_simplex_wave2 / k_family_wave for what is left, k_deep_parse + k_deep_cols for families of more than 64 records, k_family behind them, + k_call_full)"
-                                    if not (duplex or codec) else "k_family stage (k_family_wave + k_call_full)"),
+                         "kernel": ("k_split_cols" if plain else "k_family_wave" if (duplex or codec) else "k_split_cols"),
+                         "kernel_stage": ("the family stage the HIP events bracket: k_split_parse + k_split_cols + k_split_finish | k_simplex_seg, then k_simplex_wave2 / "
+                                          "k_family_wave for what is left, k_deep_parse + k_deep_cols for families of more than 64 records, k_family behind them, + k_call_full"
+                                          if not (duplex or codec) else "k_family_wave + k_call_full"),
                          "kernel_ms": k_family_ms / steps, "k_emit_ms": k_emit_ms / steps,
                          "device_ms_per_step": k_total_ms / steps, "algorithmic_bytes_per_launch": alg_read + alg_write,
                          "read_only_GBs": alg_read / k_avg_s / 1e9 if k_avg_s > 0 else 0.0,
+                         "read_only_frac": (alg_read / k_avg_s / 1e9 / HBM_PEAK_GBS) if k_avg_s > 0 else 0.0,   # north_star's target reads this one (>= 0.40)
                          # the bound that binds this kernel is vector-ALU issue, not HBM:
                          "f64_ops_per_observation": F64_OPS_PER_OBSERVATION,
                          "valu_floor_ms": valu_floor_ms,
