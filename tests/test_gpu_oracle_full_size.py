@@ -1,7 +1,8 @@
 """ORACLE parity at BASELINE.json's own sizes, on the code path bench.py times.
 
 The whole batch (configs[1]: 5 M simplex families x 8 pairs x 150 bp = 80 M reads; configs[2]: 2 M duplex molecules of 6+6 pairs;
-configs[4]: 1 M CODEC molecules of 4 pairs of 2x300 bp; the configs[3] long-tail shape at 1 M families of 2..50 pairs) is generated in HBM
+configs[4]: 1 M CODEC molecules of 4 pairs of 2x300 bp; the configs[3] long-tail shape at 1 M and at 5 M families of 2..50 pairs — 5 M = one GPU's
+share of the 40 M-family job) is generated in HBM
 and run ONCE through the device-resident entry — for 5 M simplex families that is the 8-chunk, two-stream split pipeline the bench
 measures (fastpath.hip: n_grp >= 400 000 -> 8 chunks).  Then, shard by shard (`first_family = k * shard`), the same molecules are
 generated again, brought to the host, and decided by the oracle (the C++ restatement of the reference CPU caller,
@@ -57,6 +58,10 @@ CASES = {
                       dict(family_size=4, read_length=300, insert_mean=350, insert_sd=60, codec=1), 1000, 8),
     "simplex_long_tail_config3_shape": (lambda: VanillaUmiConsensusCaller("", "A", VanillaUmiConsensusOptions(min_reads=1, min_consensus_base_quality=2, cell_tag="CB"), overlapping_consensus=True),
                                         lambda: fgx_opts.defaults(min_reads=1), 1_000_000, 500_000, dict(family_size=2, family_size_max=50), 50, None),
+    # configs[3] at ONE GPU's share of the 8-GPU job: 40 M / 8 = 5 M long-tail families (round 5, VERDICT r4 row G2: the chunk count, the list
+    # of families above 64 records and the regrowth of the k_call_full item pool differ from the 1 M case)
+    "simplex_long_tail_config3_share_of_one_gpu": (lambda: VanillaUmiConsensusCaller("", "A", VanillaUmiConsensusOptions(min_reads=1, min_consensus_base_quality=2, cell_tag="CB"), overlapping_consensus=True),
+                                                   lambda: fgx_opts.defaults(min_reads=1), 5_000_000, 500_000, dict(family_size=2, family_size_max=50), 50, None),
 }
 
 
