@@ -84,7 +84,7 @@ EXPORTS = ["fgx_options_default", "fgx_create", "fgx_destroy", "fgx_last_error",
            "fgx_bgzf_inflate", "fgx_bgzf_deflate", "fgx_bgzf_free", "fgx_bgzf_last_error",
            "fgx_sim_generate_host", "fgx_sim_generate_device", "fgx_group_records", "fgx_group_records_device", "fgx_filter_options_default",
            "fgx_filter_records", "fgx_filter_records_device", "fgx_filter_last_output_device",
-           "fgx_record_boundaries_device", "fgx_inflate_block_host", "fgx_deflate_block_host", "fgx_run_bam", "fgx_run_bam_rejects", "fgx_bgzf_inflate_device_bench", "fgx_bgzf_recompress_file", "fgx_pipeline_last_error",
+           "fgx_record_boundaries_device", "fgx_inflate_block_host", "fgx_inflate_block_two_phase_host", "fgx_deflate_block_host", "fgx_run_bam", "fgx_run_bam_rejects", "fgx_bgzf_inflate_device_bench", "fgx_bgzf_recompress_file", "fgx_pipeline_last_error",
            "fgx_set_reference", "fgx_methylation_annotate_host", "fgx_methylation_runs_host", "fgx_methylation_mm_ml_host", "fgx_canon_duplex_host", "fgx_canon_codec_host", "fgx_simplex_rejects_host", "fgx_balanced_shards", "fgx_regenerate_alignment_tags_host"]
 
 _lib = None

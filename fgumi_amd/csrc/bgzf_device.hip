@@ -40,6 +40,94 @@ __global__ __launch_bounds__(INFL_LANES) void k_bgzf_inflate(const uint8_t* __re
   if (st != INFL_OK) atomicMax(status, ((b + 1u) << 4) | (uint32_t)st);      // (which block, why: the highest failing block wins)
 }
 
+// ---- the two-phase form (round 5) ----------------------------------------------------------------------------------------------------------
+// The one-phase kernel above is a chain of ~12 800 symbols per 64 KiB block of BAM records, three quarters of them matches, and every match
+// is a global-memory round trip (its source was written moments ago by the same lane): 2.3 us per symbol, 25 - 31 GB/s for the whole chip
+// however many blocks are in flight (profiles/r04_experiments.md).  Two passes take the round trip out:
+//   k_bgzf_tokenize  a LANE per block, the same decoder with TOK set (inflate_core.h): literals go to their place, a match becomes a
+//                    32-bit entry of the block's list.  No load depends on a store: table lookups in LDS, stores that nobody waits for.
+//   k_bgzf_resolve   a WAVEFRONT per block with the WHOLE block in LDS (64 KiB: two blocks per CU): the block's bytes (literals in place)
+//                    come in with 16-byte loads, the entries are played 64 at a time — a lane per match, a byte loop in LDS, in rounds
+//                    ordered by the frontier rule (inflate_resolve_wave_emulated in inflate_core.h is this schedule on the host) — and the
+//                    block leaves with 16-byte stores.  A match's round trip is an LDS access.  k_bgzf_crc checks the result as before.
+constexpr uint32_t INFL_ENT_STRIDE = (INFL_ENTRY_CAP + 15u) & ~15u;      // entries per block slot
+
+template <uint32_t LANES>
+__global__ __launch_bounds__(LANES) void k_bgzf_tokenize(const uint8_t* __restrict__ raw, const BgzfDevBlock* __restrict__ blk, uint32_t n,
+                                                         uint8_t* __restrict__ out, uint32_t* __restrict__ ent, uint32_t* __restrict__ n_ent,
+                                                         uint32_t* __restrict__ status) {
+  __shared__ InflateFast sF[LANES];
+  InflateSlow W;
+  const uint32_t b = blockIdx.x * LANES + threadIdx.x;
+  if (b >= n) return;
+  const BgzfDevBlock B = blk[b];
+  n_ent[b] = 0;
+  if (B.isize == 0) return;
+  typedef __attribute__((address_space(3))) uint16_t* LdsPtr;
+  uint32_t ne = 0;
+  const int st = inflate_block_t<LdsPtr, true>(raw + B.in_off, B.in_len, out + B.out_off, B.isize, (LdsPtr)sF[threadIdx.x].lit, (LdsPtr)sF[threadIdx.x].dist, W,
+                                               ent + (size_t)b * INFL_ENT_STRIDE, INFL_ENTRY_CAP, &ne);
+  if (st != INFL_OK) { atomicMax(status, ((b + 1u) << 4) | (uint32_t)st); ne = 0; }
+  n_ent[b] = ne;
+}
+
+// inclusive prefix sum over the wavefront (values < 2^20: a block is 64 KiB)
+__device__ __forceinline__ uint32_t infl_wave_scan(uint32_t v, uint32_t lane) {
+#pragma unroll
+  for (uint32_t o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)v, (int)o); if (lane >= o) v += t; }
+  return v;
+}
+
+__global__ __launch_bounds__(64) void k_bgzf_resolve(const BgzfDevBlock* __restrict__ blk, uint32_t n, uint8_t* __restrict__ out, const uint32_t* __restrict__ ent,
+                                                     const uint32_t* __restrict__ n_ent, uint32_t* __restrict__ status) {
+  extern __shared__ __align__(16) uint8_t L[];                  // the block (up to 64 KiB)
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const uint32_t b = blockIdx.x, lane = threadIdx.x;
+  if (b >= n) return;
+  const BgzfDevBlock B = blk[b];
+  const uint32_t isize = B.isize;
+  if (isize == 0 || isize > 65536u) return;                     // (k_bgzf_crc checks the empty block's CRC; a BGZF block never exceeds 64 KiB)
+  const uint32_t ne = n_ent[b];
+  uint8_t* const g = out + B.out_off;
+  // 1. the block as the decoder left it: literals in place, the matches' bytes still undefined (whole 16-byte pieces: the last one may
+  //    take up to 15 bytes of the next block or of the buffer's slack along — they are never stored back)
+  for (uint32_t i = 16u * lane; i < isize; i += 1024u) { u32x4 v; __builtin_memcpy(&v, g + i, 16); *(u32x4*)(L + i) = v; }
+  __syncthreads();
+  // 2. the entries, 64 at a time
+  uint32_t run = 0;
+  const uint32_t* const E = ent + (size_t)b * INFL_ENT_STRIDE;
+  bool bad = false;
+  for (uint32_t e0 = 0; e0 < ne; e0 += 64) {
+    const uint32_t e = e0 + lane < ne ? E[e0 + lane] : 0u;
+    const uint32_t lit = infl_entry_lit(e), len = infl_entry_len(e), dist = infl_entry_dist(e);
+    const uint32_t incl = infl_wave_scan(lit + len, lane);
+    const uint32_t dpos = run + incl - len;                     // where this lane's match begins
+    run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    bool todo = len != 0;
+    if (todo && (dist > dpos || dpos + len > isize)) { bad = true; todo = false; }   // (the decoder checked both: a corrupt list stays harmless)
+    const uint32_t src = dpos - dist, span = len < dist ? len : dist;
+    unsigned long long w = __ballot(todo);
+    while (w) {
+      const uint32_t first = (uint32_t)__builtin_ctzll(w);
+      const uint32_t F = (uint32_t)__builtin_amdgcn_readlane((int)dpos, (int)first);   // every byte below F is final
+      const bool ready = todo && (lane == first || src + span <= F);
+      if (ready) {
+        for (uint32_t k = 0; k < len; k++) L[dpos + k] = L[src + k];
+        todo = false;
+      }
+      __syncthreads();                                          // (one wavefront: orders the LDS writes of this round before the next round's reads)
+      w = __ballot(todo);
+    }
+  }
+  if (ne == 0) return;                                          // (the decoder has reported this block: its list is empty)
+  if (__any(bad) || run != isize) { if (lane == 0) atomicMax(status, ((b + 1u) << 4) | (uint32_t)INFL_SIZE_MISMATCH); return; }
+  __syncthreads();
+  // 4. the block to its place: whole 16-byte pieces, the last bytes one by one (the next block's bytes lie right behind)
+  const uint32_t whole = isize & ~15u;
+  for (uint32_t i = 16u * lane; i < whole; i += 1024u) { const u32x4 v = *(const u32x4*)(L + i); __builtin_memcpy(g + i, &v, 16); }
+  if (lane < isize - whole) g[whole + lane] = L[whole + lane];
+}
+
 // CRC-32 of p[0 .. len) by one wavefront (len > 0): every lane its 1/64 slice (slices end at the block's end), then the fold.  The
 // result is valid in lane 0.
 __device__ __forceinline__ uint32_t wave_crc32(const uint8_t* p, uint32_t len, const uint32_t* tab, uint32_t lane) {
@@ -163,9 +251,32 @@ __global__ void k_bgzf_clear_status(uint32_t* status) { *status = 0u; }
 // inflates `n` blocks (descriptors in device memory) from d_raw into d_out and checks every block's CRC-32: the kernels and the
 // copy of the status word (into PINNED host memory, `h_status`) are queued on `s`; nothing waits.  After `s` has drained,
 // bgzf_inflate_status() turns the word into 0, or 1 with c->err naming the first failing block.
-void bgzf_inflate_launch(hipStream_t s, const uint8_t* d_raw, const BgzfDevBlock* d_blk, uint32_t n, uint8_t* d_out, uint32_t* d_status, uint32_t* h_status) {
+size_t bgzf_inflate_scratch_bytes(uint32_t n_blocks) { return (size_t)n_blocks * ((size_t)INFL_ENT_STRIDE * 4u + 4u) + 64u; }
+bool bgzf_inflate_two_phase() { static const bool on = [] { const char* e = getenv("FGX_INFL_TWO_PHASE"); return !(e && e[0] == '0'); }(); return on; }
+
+void bgzf_inflate_launch(hipStream_t s, const uint8_t* d_raw, const BgzfDevBlock* d_blk, uint32_t n, uint8_t* d_out, uint32_t* d_status, uint32_t* h_status,
+                         void* d_scratch) {
   *h_status = 0;
   if (n == 0) return;
+  if (d_scratch && bgzf_inflate_two_phase()) {
+    // the two-phase form: entries [n x INFL_ENT_STRIDE] then the list lengths [n] in the caller's scratch (bgzf_inflate_scratch_bytes)
+    static bool attr_set = false;
+    if (!attr_set) { hip_check(hipFuncSetAttribute((const void*)k_bgzf_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 65536), "hipFuncSetAttribute(k_bgzf_resolve)"); attr_set = true; }
+    uint32_t* const ent = (uint32_t*)d_scratch;
+    uint32_t* const n_ent = ent + (size_t)n * INFL_ENT_STRIDE;
+    hipLaunchKernelGGL(k_bgzf_clear_status, dim3(1), dim3(1), 0, s, d_status);
+    static const uint32_t tl = [] { const char* e = getenv("FGX_INFL_LANES"); const int v = e ? atoi(e) : 0; return (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) ? (uint32_t)v : 16u; }();
+    if (tl == 4) hipLaunchKernelGGL(k_bgzf_tokenize<4>, dim3((n + 3) / 4), dim3(4), 0, s, d_raw, d_blk, n, d_out, ent, n_ent, d_status);
+    else if (tl == 8) hipLaunchKernelGGL(k_bgzf_tokenize<8>, dim3((n + 7) / 8), dim3(8), 0, s, d_raw, d_blk, n, d_out, ent, n_ent, d_status);
+    else if (tl == 32) hipLaunchKernelGGL(k_bgzf_tokenize<32>, dim3((n + 31) / 32), dim3(32), 0, s, d_raw, d_blk, n, d_out, ent, n_ent, d_status);
+    else if (tl == 64) hipLaunchKernelGGL(k_bgzf_tokenize<64>, dim3((n + 63) / 64), dim3(64), 0, s, d_raw, d_blk, n, d_out, ent, n_ent, d_status);
+    else hipLaunchKernelGGL(k_bgzf_tokenize<16>, dim3((n + 15) / 16), dim3(16), 0, s, d_raw, d_blk, n, d_out, ent, n_ent, d_status);
+    hipLaunchKernelGGL(k_bgzf_resolve, dim3(n), dim3(64), 65536, s, d_blk, n, d_out, (const uint32_t*)ent, (const uint32_t*)n_ent, d_status);
+    hipLaunchKernelGGL(k_bgzf_crc, dim3((n + 3) / 4), dim3(256), 0, s, (const uint8_t*)d_out, d_blk, n, d_status);
+    hip_check(hipMemcpyAsync(h_status, d_status, 4, hipMemcpyDeviceToHost, s), "D2H");
+    hip_check(hipGetLastError(), "bgzf inflate kernels (two-phase)");
+    return;
+  }
   // the status word is cleared by a KERNEL on the same stream: kernels of one stream run in order, where hipMemsetAsync has been seen to run out
   // of order with the kernels around it on this runtime (boundaries.hip) — a late clear would wipe an inflate or CRC error
   hipLaunchKernelGGL(k_bgzf_clear_status, dim3(1), dim3(1), 0, s, d_status);

@@ -115,6 +115,22 @@ int fgx_inflate_block_host(const uint8_t* in, uint32_t in_len, uint8_t* out, uin
   return st;
 }
 
+// The two-phase form (round 5) on the host, for the CPU tests: inflate_block_t<.., TOK> makes the entry list, then either the plain
+// second pass (mode 0: inflate_resolve) or k_bgzf_resolve's schedule emulated lane by lane (mode 1: inflate_resolve_wave_emulated, the
+// batches of 64 entries and the frontier rule, with the "parallel" copies of a round done in REVERSE lane order so that a copy that
+// reads bytes a lower lane of the same round writes would show).  Same contract as fgx_inflate_block_host; *n_entries = the list's length.
+int fgx_inflate_block_two_phase_host(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, int mode, uint32_t* n_entries, uint32_t* rounds) {
+  static thread_local fgx::InflateTables T;
+  static thread_local std::vector<uint32_t> ent(fgx::INFL_ENTRY_CAP);
+  uint32_t ne = 0;
+  const int st = fgx::inflate_block_t<uint16_t*, true>(in, in_len, out, out_len, T.f.lit, T.f.dist, T.w, ent.data(), (uint32_t)ent.size(), &ne);
+  if (n_entries) *n_entries = ne;
+  if (rounds) *rounds = 0;
+  if (st != fgx::INFL_OK) return st;
+  if (mode == 0) return fgx::inflate_resolve(out, out_len, ent.data(), ne) ? 0 : fgx::INFL_SIZE_MISMATCH;
+  return fgx::inflate_resolve_wave_emulated(out, out_len, ent.data(), ne, rounds) ? 0 : fgx::INFL_SIZE_MISMATCH;
+}
+
 // the device's DEFLATE compressor (deflate_core.h) run on the host: the same source, for the CPU tests.  `in` must be readable for
 // 8 bytes past n.  Returns the compressed size, 0 when the stream does not fit `cap` (a block to be stored).
 uint32_t fgx_deflate_block_host(const uint8_t* in, uint32_t n, uint8_t* out, uint32_t cap) {

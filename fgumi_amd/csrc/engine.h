@@ -206,7 +206,12 @@ int record_boundaries_device(fgx_caller* c, const uint8_t* d_stream, uint64_t le
                              uint64_t cap, uint64_t* n_rec, uint64_t* consumed);
 // bgzf_device.hip — BGZF inflate on the device: one descriptor per block (offsets into the compressed bytes / the inflated stream)
 struct BgzfDevBlock { uint64_t in_off, out_off; uint32_t in_len, isize, crc, _pad; };   // in_off / in_len: the raw DEFLATE payload
-void bgzf_inflate_launch(hipStream_t s, const uint8_t* d_raw, const BgzfDevBlock* d_blk, uint32_t n, uint8_t* d_out, uint32_t* d_status, uint32_t* h_status_pinned);
+// `d_scratch` (bgzf_inflate_scratch_bytes(n) bytes of device memory, or null): the entry lists of the two-phase form (k_bgzf_tokenize + k_bgzf_resolve,
+// the default with a scratch; FGX_INFL_TWO_PHASE=0 or no scratch: the one-phase kernel of rounds 2 - 4)
+void bgzf_inflate_launch(hipStream_t s, const uint8_t* d_raw, const BgzfDevBlock* d_blk, uint32_t n, uint8_t* d_out, uint32_t* d_status, uint32_t* h_status_pinned,
+                         void* d_scratch = nullptr);
+size_t bgzf_inflate_scratch_bytes(uint32_t n_blocks);
+bool bgzf_inflate_two_phase();
 int bgzf_inflate_status(fgx_caller* c, uint32_t status_word);
 void bgzf_crc_blocks_device(fgx_caller* c, const uint8_t* d_in, uint64_t len, uint32_t* d_crcs);
 int bgzf_deflate_device(fgx_caller* c, const uint8_t* d_in, uint64_t len, DevBuf& slots, DevBuf& scratch, DevBuf& meta, DevBuf& packed, uint64_t* packed_len);

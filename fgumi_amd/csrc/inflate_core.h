@@ -213,9 +213,25 @@ FGX_HD inline void infl_store_pending(uint8_t* dst, uint32_t n, uint64_t v0, uin
 
 // inflates `in[0 .. in_len)` into `out[0 .. out_len)`; the stream must produce exactly out_len bytes (the block's ISIZE).
 // `in` must be readable for 8 bytes past in_len (no load goes further, also for corrupt input).  F / W: this lane's tables (LDS / private memory on the device).
-template <class FastPtr>
-FGX_HD inline int inflate_block_t(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, FastPtr f_lit, FastPtr f_dist, InflateSlow& W) {
+//
+// TOK (round 5, the two-phase form): the SAME decoder, but a match is not copied — it becomes a 32-bit ENTRY of the block's entry list,
+//     entry = literals in front of it (0 .. 255) << 24 | (distance - 1) << 9 | (length - 2, 0 = no match: a run of 255 literals that goes on)
+// while literals (and stored bytes) still go to their final place in `out`.  Nothing the decoder does then depends on a byte it wrote: no
+// load -> store -> load round trip per match (2.3 us each on the device: what bound the one-phase kernel), only table lookups and stores.  A
+// second pass (inflate_resolve below; k_bgzf_resolve on the device: a wavefront per block with the block in LDS) plays the entries.
+// `ent` holds `ent_cap` entries; INFL_ENTRY_CAP covers every valid stream of up to 64 KiB (a match is >= 3 bytes, a literal-run entry 255).
+constexpr uint32_t INFL_ENTRY_CAP = 65536 / 3 + 65536 / 255 + 2 * 258 + 64;      // 22 681
+FGX_HD inline uint32_t infl_entry(uint32_t lit, uint32_t dist, uint32_t len) { return (lit << 24) | ((dist - 1u) << 9) | (len - 2u); }
+FGX_HD inline uint32_t infl_entry_lit(uint32_t e) { return e >> 24; }
+FGX_HD inline uint32_t infl_entry_len(uint32_t e) { const uint32_t c = e & 511u; return c ? c + 2u : 0u; }
+FGX_HD inline uint32_t infl_entry_dist(uint32_t e) { return ((e >> 9) & 0x7FFFu) + 1u; }
+
+template <class FastPtr, bool TOK = false>
+FGX_HD inline int inflate_block_t(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, FastPtr f_lit, FastPtr f_dist, InflateSlow& W,
+                                  uint32_t* ent = nullptr, uint32_t ent_cap = 0, uint32_t* n_ent = nullptr) {
   constexpr uint32_t LB = FGX_INFL_LIT_BITS, DB = FGX_INFL_DIST_BITS;
+  uint32_t ne = 0, lit_run = 0;                                                 // TOK: entries written, literals since the last entry
+  if (TOK && n_ent) *n_ent = 0;
   static constexpr uint8_t CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
   BitReader r{in, in_len, 0u, 0ull, 0u, 0ull};
   infl_seek(r, 0);
@@ -238,6 +254,10 @@ FGX_HD inline int inflate_block_t(const uint8_t* in, uint32_t in_len, uint8_t* o
       if (pos + len > out_len) return INFL_OUTPUT_OVERFLOW;
       for (uint32_t i = 0; i < len; i++) out[pos + i] = in[src + i];
       pos += len;
+      if (TOK) {   // stored bytes count as literals
+        lit_run += len;
+        while (lit_run >= 255u) { if (ne >= ent_cap) return INFL_OUTPUT_OVERFLOW; ent[ne++] = 255u << 24; lit_run -= 255u; }
+      }
       infl_seek(r, src + len);
     } else if (btype == 1 || btype == 2) {
       uint8_t lens[320];
@@ -290,6 +310,7 @@ FGX_HD inline int inflate_block_t(const uint8_t* in, uint32_t in_len, uint8_t* o
         if (s < 256) {
           if (pos >= out_len) return INFL_OUTPUT_OVERFLOW;
           out[pos++] = (uint8_t)s;
+          if (TOK) { if (++lit_run == 255u) { if (ne >= ent_cap) return INFL_OUTPUT_OVERFLOW; ent[ne++] = 255u << 24; lit_run = 0; } }
           continue;
         }
         if (s == 256) { if (p_len) { infl_store_pending(out + p_pos, p_len, pv0, pv1, pv2, pv3); p_len = 0; } break; }
@@ -301,7 +322,11 @@ FGX_HD inline int inflate_block_t(const uint8_t* in, uint32_t in_len, uint8_t* o
         const uint32_t dist = infl_dist_base((uint32_t)d) + infl_bits(r, infl_dist_extra((uint32_t)d));
         if (dist > pos) return INFL_BAD_DISTANCE;
         if (pos + len > out_len) return INFL_OUTPUT_OVERFLOW;
-        if (dist >= len && len <= 32) {
+        if (TOK) {
+          if (ne >= ent_cap) return INFL_OUTPUT_OVERFLOW;
+          ent[ne++] = infl_entry(lit_run, dist, len);
+          lit_run = 0;
+        } else if (dist >= len && len <= 32) {
           // a short match whose source lies wholly before it (most matches): its bytes are LOADED now and STORED when the next match
           // arrives (or the block ends) — a wavefront's lanes run the loop in step, nearly every step has a lane with a match, and
           // waiting for the match's source inside the step made every step a global-memory round trip.  The stores of the match
@@ -324,7 +349,71 @@ FGX_HD inline int inflate_block_t(const uint8_t* in, uint32_t in_len, uint8_t* o
     if (r.pos - (r.bc >> 3) > in_len) return INFL_INPUT_OVERRUN;   // bits were taken from beyond the payload
     if (bfinal) break;
   }
+  if (TOK) {
+    if (lit_run) { if (ne >= ent_cap) return INFL_OUTPUT_OVERFLOW; ent[ne++] = lit_run << 24; }
+    if (pos == out_len && n_ent) *n_ent = ne;                                    // (a block that failed leaves an EMPTY list: the second pass does nothing)
+  }
   return pos == out_len ? INFL_OK : INFL_SIZE_MISMATCH;
+}
+
+// The second pass in its plain form (the host tests' reference for k_bgzf_resolve): the entries of one block played in order on `out`,
+// whose literal bytes are in place.  Every index was checked by the decoder; the bounds here only keep a corrupt list harmless.
+FGX_HD inline bool inflate_resolve(uint8_t* out, uint32_t out_len, const uint32_t* ent, uint32_t ne) {
+  uint32_t pos = 0;
+  for (uint32_t i = 0; i < ne; i++) {
+    const uint32_t e = ent[i], lit = infl_entry_lit(e), len = infl_entry_len(e), dist = infl_entry_dist(e);
+    pos += lit;
+    if (len) {
+      if (dist > pos || pos + len > out_len) return false;
+      for (uint32_t k = 0; k < len; k++) out[pos + k] = out[pos - dist + k];
+      pos += len;
+    }
+    if (pos > out_len) return false;
+  }
+  return pos == out_len || ne == 0;
+}
+
+// k_bgzf_resolve's SCHEDULE, lane by lane on the host (tests only; the kernel in bgzf_device.hip follows it line by line): the entries in
+// batches of 64, lane j of a batch owning entry j.  A lane's match goes to dpos = (bytes before the batch) + (literals and matches of the
+// lanes below) + its own literals, and copies from src = dpos - dist.  Rounds: with F = dpos of the lowest lane whose match is not copied
+// yet, every byte below F is final (literals are in place, every lower match is done), so a lane may copy when its whole source —
+// min(len, dist) bytes from src — lies below F; the lowest waiting lane always may (its source ends at its own dpos at the latest), so
+// every round makes progress.  Lanes of one round write disjoint ranges and read below F only: they are independent, whatever the order.
+inline bool inflate_resolve_wave_emulated(uint8_t* out, uint32_t out_len, const uint32_t* ent, uint32_t ne, uint32_t* rounds_out) {
+  uint32_t run = 0, rounds = 0;
+  for (uint32_t e0 = 0; e0 < ne; e0 += 64) {
+    uint32_t dpos[64], len[64], dist[64];
+    bool todo[64];
+    uint32_t acc = run;
+    for (uint32_t j = 0; j < 64; j++) {
+      const uint32_t e = e0 + j < ne ? ent[e0 + j] : 0u;
+      len[j] = infl_entry_len(e); dist[j] = infl_entry_dist(e);
+      dpos[j] = acc + infl_entry_lit(e);
+      acc = dpos[j] + len[j];
+      todo[j] = len[j] != 0;
+      if (todo[j] && (dist[j] > dpos[j] || dpos[j] + len[j] > out_len)) return false;
+    }
+    for (;;) {
+      int first = -1;
+      for (int j = 0; j < 64; j++) if (todo[j]) { first = j; break; }
+      if (first < 0) break;
+      const uint32_t F = dpos[first];
+      bool ready[64];
+      for (int j = 0; j < 64; j++) {
+        const uint32_t span = len[j] < dist[j] ? len[j] : dist[j];
+        ready[j] = todo[j] && (j == first || dpos[j] - dist[j] + span <= F);
+      }
+      for (int j = 63; j >= 0; j--) if (ready[j]) {          // (reverse order: the lanes of a round must not depend on one another)
+        for (uint32_t k = 0; k < len[j]; k++) out[dpos[j] + k] = out[dpos[j] - dist[j] + k];
+        todo[j] = false;
+      }
+      rounds++;
+    }
+    run = acc;
+    if (run > out_len) return false;
+  }
+  if (rounds_out) *rounds_out = rounds;
+  return run == out_len || ne == 0;
 }
 
 FGX_HD inline int inflate_block(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, InflateFast& F, InflateSlow& W) {

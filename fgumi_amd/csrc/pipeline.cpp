@@ -27,7 +27,7 @@ thread_local std::string t_perr;
 // longer than a whole chunk's work)
 struct PipeState {
   Pipeline P;
-  fgx::DevBuf D[2], d_off, d_len, d_koff, d_klen, d_grp, d_raw, d_blk, d_slots, d_dscratch, d_dmeta, d_packed, d_crcs;
+  fgx::DevBuf D[2], d_off, d_len, d_koff, d_klen, d_grp, d_raw, d_blk, d_ent, d_slots, d_dscratch, d_dmeta, d_packed, d_crcs;   // (d_ent: the entry lists of the two-phase inflate)
   uint64_t pad[2] = {0, 0};          // bytes of D[i] in front of a chunk's inflated stream: room for what the chunk before it leaves over
   hipStream_t s_in = nullptr;        // uploads and inflates the NEXT chunk while the device stage works on this one
   hipEvent_t ev_up0 = nullptr, ev_up1 = nullptr, ev_in = nullptr;   // upload begins / upload done / stream inflated and checked
@@ -40,7 +40,7 @@ namespace fgx {
 void pipeline_release(fgx_caller* c) {
   if (!c || !c->pipe_state) return;
   PipeState* S = (PipeState*)c->pipe_state;
-  for (auto* b : {&S->D[0], &S->D[1], &S->d_off, &S->d_len, &S->d_koff, &S->d_klen, &S->d_grp, &S->d_raw, &S->d_blk, &S->d_slots, &S->d_dscratch, &S->d_dmeta, &S->d_packed, &S->d_crcs}) b->free_();
+  for (auto* b : {&S->D[0], &S->D[1], &S->d_off, &S->d_len, &S->d_koff, &S->d_klen, &S->d_grp, &S->d_raw, &S->d_blk, &S->d_ent, &S->d_slots, &S->d_dscratch, &S->d_dmeta, &S->d_packed, &S->d_crcs}) b->free_();
   if (S->s_in) { (void)hipStreamSynchronize(S->s_in); (void)hipStreamDestroy(S->s_in); }
   for (hipEvent_t e : {S->ev_up0, S->ev_up1, S->ev_in}) if (e) (void)hipEventDestroy(e);
   if (S->h_status) (void)hipHostFree(S->h_status);
@@ -92,18 +92,19 @@ int fgx_bgzf_inflate_device_bench(fgx_caller* c, const uint8_t* raw, uint64_t ra
     }
     // everything this entry allocates is released on every way out (a hip_check that throws included)
     struct Scope {
-      fgx::DevBuf d_raw, d_blk, d_out;
+      fgx::DevBuf d_raw, d_blk, d_out, d_ent;
       uint32_t* h_status = nullptr;
       hipEvent_t e0 = nullptr, e1 = nullptr;
       ~Scope() {
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
         if (h_status) (void)hipHostFree(h_status);
-        d_raw.free_(); d_blk.free_(); d_out.free_();
+        d_raw.free_(); d_blk.free_(); d_out.free_(); d_ent.free_();
       }
     } R;
     fgx::DevBuf &d_raw = R.d_raw, &d_blk = R.d_blk, &d_out = R.d_out;
     d_raw.reserve(used + 64); d_blk.reserve(dev.size() * sizeof(fgx::BgzfDevBlock) + 64); d_out.reserve(infl + 256);
+    if (fgx::bgzf_inflate_two_phase()) R.d_ent.reserve(fgx::bgzf_inflate_scratch_bytes((uint32_t)dev.size()));
     fgx::hip_check(hipHostMalloc((void**)&R.h_status, 64, hipHostMallocDefault), "hipHostMalloc");
     uint32_t* const h_status = R.h_status;
     hipStream_t s = c->stream;
@@ -115,12 +116,12 @@ int fgx_bgzf_inflate_device_bench(fgx_caller* c, const uint8_t* raw, uint64_t ra
     fgx::hip_check(hipEventCreate(&R.e0), "event"); fgx::hip_check(hipEventCreate(&R.e1), "event");
     const hipEvent_t e0 = R.e0, e1 = R.e1;
     int rc = 0;
-    fgx::bgzf_inflate_launch(s, d_raw.as<uint8_t>(), d_blk.as<fgx::BgzfDevBlock>(), (uint32_t)dev.size(), d_out.as<uint8_t>(), d_status, h_status);   // warm-up
+    fgx::bgzf_inflate_launch(s, d_raw.as<uint8_t>(), d_blk.as<fgx::BgzfDevBlock>(), (uint32_t)dev.size(), d_out.as<uint8_t>(), d_status, h_status, R.d_ent.p);   // warm-up
     fgx::hip_check(hipStreamSynchronize(s), "sync");
     if (fgx::bgzf_inflate_status(c, *h_status) != 0) rc = 1;
     fgx::hip_check(hipEventRecord(e0, s), "event");
     for (uint32_t r = 0; r < (reps ? reps : 1u) && rc == 0; r++)
-      fgx::bgzf_inflate_launch(s, d_raw.as<uint8_t>(), d_blk.as<fgx::BgzfDevBlock>(), (uint32_t)dev.size(), d_out.as<uint8_t>(), d_status, h_status);
+      fgx::bgzf_inflate_launch(s, d_raw.as<uint8_t>(), d_blk.as<fgx::BgzfDevBlock>(), (uint32_t)dev.size(), d_out.as<uint8_t>(), d_status, h_status, R.d_ent.p);
     fgx::hip_check(hipEventRecord(e1, s), "event");
     fgx::hip_check(hipStreamSynchronize(s), "sync");
     if (rc == 0 && fgx::bgzf_inflate_status(c, *h_status) != 0) rc = 1;
@@ -216,8 +217,9 @@ int fgx_run_bam_rejects(fgx_caller* c, const char* in_path, const char* out_path
         fgx::hip_check(hipMemcpyAsync(d_raw.p, ch.inf.p, ch.raw_len + 64, hipMemcpyHostToDevice, si), "H2D compressed chunk");
         if (blk_bytes) fgx::hip_check(hipMemcpyAsync(d_blk.p, ch.dev_blocks.data(), blk_bytes, hipMemcpyHostToDevice, si), "H2D block table");
         fgx::hip_check(hipEventRecord(S->ev_up1, si), "hipEventRecord");
+        if (fgx::bgzf_inflate_two_phase()) S->d_ent.reserve(fgx::bgzf_inflate_scratch_bytes((uint32_t)ch.dev_blocks.size()));
         fgx::bgzf_inflate_launch(si, d_raw.as<uint8_t>(), d_blk.as<fgx::BgzfDevBlock>(), (uint32_t)ch.dev_blocks.size(), dst,
-                                 (uint32_t*)((uint8_t*)d_blk.p + ((blk_bytes + 15) & ~(size_t)15)), S->h_status);
+                                 (uint32_t*)((uint8_t*)d_blk.p + ((blk_bytes + 15) & ~(size_t)15)), S->h_status, S->d_ent.p);
       } else {
         *S->h_status = 0;
         if (ch.inf_len) fgx::hip_check(hipMemcpyAsync(dst, ch.inf.p, ch.inf_len, hipMemcpyHostToDevice, si), "H2D chunk");

@@ -417,6 +417,10 @@ int fgx_run_bam_rejects(fgx_caller* c, const char* in_path, const char* out_path
  * tests without a device.  `in` must be readable for 8 bytes past in_len; `out_len` = the block's ISIZE.  Returns the decoder's
  * status (0 = ok) and, in *crc_out, the CRC-32 of the output computed with the device's 64-slice fold. */
 int fgx_inflate_block_host(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, uint32_t* crc_out);
+/* The two-phase form of the device decoder (round 5: k_bgzf_tokenize + k_bgzf_resolve) on the host, same contract: the decoder leaves the
+ * literals in place and a list of 32-bit match entries (*n_entries of them), a second pass plays the list — mode 0: in order
+ * (inflate_resolve), mode 1: in k_bgzf_resolve's batches of 64 entries with its frontier rule, emulated lane by lane (*rounds = copy rounds). */
+int fgx_inflate_block_two_phase_host(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, int mode, uint32_t* n_entries, uint32_t* rounds);
 /* The device's DEFLATE compressor (fgumi_amd/csrc/deflate_core.h, one GPU lane per BGZF block: greedy LZ77 + one dynamic Huffman
  * code per block) run on the host, for tests without a device.  `in` readable for 8 bytes past n (n <= 65535).  Returns the bytes
  * written to `out`, or 0 when they do not fit `cap` (the caller stores the block). */
