@@ -52,12 +52,59 @@ __global__ __launch_bounds__(INFL_LANES) void k_bgzf_inflate(const uint8_t* __re
 //                    block leaves with 16-byte stores.  A match's round trip is an LDS access.  k_bgzf_crc checks the result as before.
 constexpr uint32_t INFL_ENT_STRIDE = (INFL_ENTRY_CAP + 15u) & ~15u;      // entries per block slot
 
+// The tokenizer's bit reader: a WINDOW of the payload in LDS (INFL_WIN bytes per lane, filled with 16-byte loads), refills out of it.  The
+// one-phase kernel's reader loads 8 bytes from global memory per refill — every ~5 symbols — and on this part a load's s_waitcnt also
+// waits for every store issued before it (vmcnt counts both): with the tokenizer's stores (a literal, an entry per symbol) that was a
+// store's round trip per refill.  With the window the wait comes once per ~70 symbols.  Same contract as BitReader (inflate_core.h): the
+// address stays at base + min(pos, len), nothing beyond len + 24 is read (the raw buffer carries 64 bytes of slack), infl_overrun as there.
+constexpr uint32_t INFL_WIN = 128;
+typedef __attribute__((address_space(3))) uint8_t* LdsBytes;
+struct LdsBitReader {
+  const uint8_t* base; uint32_t len;
+  uint32_t pos; uint64_t bb; uint32_t bc;
+  LdsBytes win; uint32_t wbase, wvalid;           // payload bytes [wbase, wbase + INFL_WIN) are in the window (wvalid = 0: nothing yet)
+};
+__device__ __forceinline__ void infl_fill_window(LdsBitReader& r, uint32_t at) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) u32x4* LdsV;
+  r.wbase = at & ~15u;
+  r.wvalid = 1;
+#pragma unroll
+  for (uint32_t i = 0; i < INFL_WIN / 16; i++) {
+    const uint32_t off = r.wbase + 16u * i;
+    u32x4 v = {0, 0, 0, 0};
+    if (off < r.len + 8u) __builtin_memcpy(&v, r.base + off, 16);
+    *(LdsV)(r.win + 16u * i) = v;
+  }
+}
+__device__ __forceinline__ void infl_refill(LdsBitReader& r) {
+  const uint32_t a = r.pos < r.len ? r.pos : r.len;
+  if (!r.wvalid || a < r.wbase || a + 8u > r.wbase + INFL_WIN) infl_fill_window(r, a);
+  uint64_t v;
+  {
+    typedef __attribute__((address_space(3))) uint32_t* LdsW;
+    const LdsBytes p = r.win + (a - r.wbase);
+    uint32_t lo, hi;
+    __builtin_memcpy(&lo, (const void*)(uint8_t*)p, 4); __builtin_memcpy(&hi, (const void*)((uint8_t*)p + 4), 4);
+    v = (uint64_t)lo | ((uint64_t)hi << 32);
+  }
+  r.bb |= v << r.bc;
+  r.pos += (63u - r.bc) >> 3;
+  r.bc |= 56u;
+}
+__device__ __forceinline__ bool infl_overrun(const LdsBitReader& r) { return r.pos > r.len + 8u; }
+__device__ __forceinline__ void infl_seek(LdsBitReader& r, uint32_t pos) { r.pos = pos; r.bb = 0; r.bc = 0; }
+__device__ __forceinline__ void infl_open(LdsBitReader& r, const uint8_t* in, uint32_t in_len, void* win) {
+  r.base = in; r.len = in_len; r.pos = 0; r.bb = 0; r.bc = 0; r.win = (LdsBytes)(uint8_t*)win; r.wbase = 0; r.wvalid = 0;
+}
+
 template <uint32_t LANES>
 __global__ __launch_bounds__(LANES) void k_bgzf_tokenize(const uint8_t* __restrict__ raw, const BgzfDevBlock* __restrict__ blk, uint32_t n,
                                                          uint8_t* __restrict__ out, uint32_t* __restrict__ ent, uint32_t* __restrict__ n_ent,
                                                          uint32_t* __restrict__ status) {
   __shared__ InflateFast sF[LANES];
-  InflateSlow W;
+  __shared__ InflateSlow sW[LANES];                             // (LDS too: a private-memory load in the rare long-code path made EVERY symbol wait for memory)
+  __shared__ __align__(16) uint8_t sWin[LANES][INFL_WIN];
   const uint32_t b = blockIdx.x * LANES + threadIdx.x;
   if (b >= n) return;
   const BgzfDevBlock B = blk[b];
@@ -65,8 +112,10 @@ __global__ __launch_bounds__(LANES) void k_bgzf_tokenize(const uint8_t* __restri
   if (B.isize == 0) return;
   typedef __attribute__((address_space(3))) uint16_t* LdsPtr;
   uint32_t ne = 0;
-  const int st = inflate_block_t<LdsPtr, true>(raw + B.in_off, B.in_len, out + B.out_off, B.isize, (LdsPtr)sF[threadIdx.x].lit, (LdsPtr)sF[threadIdx.x].dist, W,
-                                               ent + (size_t)b * INFL_ENT_STRIDE, INFL_ENTRY_CAP, &ne);
+  InflateSlow& W = sW[threadIdx.x];
+  const int st = inflate_block_x<LdsPtr, true, LdsBitReader, LdsPtr>(raw + B.in_off, B.in_len, out + B.out_off, B.isize, (LdsPtr)sF[threadIdx.x].lit, (LdsPtr)sF[threadIdx.x].dist,
+                                                                     (LdsPtr)W.lit_count, (LdsPtr)W.dist_count, (LdsPtr)W.lit_sym, (LdsPtr)W.dist_sym, (void*)&sWin[threadIdx.x][0],
+                                                                     ent + (size_t)b * INFL_ENT_STRIDE, INFL_ENTRY_CAP, &ne);
   if (st != INFL_OK) { atomicMax(status, ((b + 1u) << 4) | (uint32_t)st); ne = 0; }
   n_ent[b] = ne;
 }
@@ -80,7 +129,7 @@ __device__ __forceinline__ uint32_t infl_wave_scan(uint32_t v, uint32_t lane) {
 
 __global__ __launch_bounds__(64) void k_bgzf_resolve(const BgzfDevBlock* __restrict__ blk, uint32_t n, uint8_t* __restrict__ out, const uint32_t* __restrict__ ent,
                                                      const uint32_t* __restrict__ n_ent, uint32_t* __restrict__ status) {
-  extern __shared__ __align__(16) uint8_t L[];                  // the block (up to 64 KiB)
+  extern __shared__ __align__(16) uint8_t L[];                  // the block (up to 64 KiB) + 64 bytes of slack for the copies' whole-word loads
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   const uint32_t b = blockIdx.x, lane = threadIdx.x;
   if (b >= n) return;
@@ -112,7 +161,39 @@ __global__ __launch_bounds__(64) void k_bgzf_resolve(const BgzfDevBlock* __restr
       const uint32_t F = (uint32_t)__builtin_amdgcn_readlane((int)dpos, (int)first);   // every byte below F is final
       const bool ready = todo && (lane == first || src + span <= F);
       if (ready) {
-        for (uint32_t k = 0; k < len; k++) L[dpos + k] = L[src + k];
+        if (dist >= len) {
+          // the source lies wholly below the match (nearly every match of BAM data): up to 32 bytes per step, the loads first, then the
+          // stores — two LDS round trips per step instead of one per byte (loads may take up to 7 bytes more than they need: never stored)
+          for (uint32_t k = 0; k < len; k += 32u) {
+            const uint32_t nb = len - k < 32u ? len - k : 32u;
+            const uint8_t* const sp = L + src + k;
+            uint8_t* const dp = L + dpos + k;
+            unsigned long long v0, v1 = 0, v2 = 0, v3 = 0;
+            __builtin_memcpy(&v0, sp, 8);
+            if (nb > 8u) __builtin_memcpy(&v1, sp + 8, 8);
+            if (nb > 16u) __builtin_memcpy(&v2, sp + 16, 8);
+            if (nb > 24u) __builtin_memcpy(&v3, sp + 24, 8);
+            unsigned long long tail = v0;
+            uint32_t done = 0;
+            if (nb >= 8u) { __builtin_memcpy(dp, &v0, 8); tail = v1; done = 8; }
+            if (nb >= 16u) { __builtin_memcpy(dp + 8, &v1, 8); tail = v2; done = 16; }
+            if (nb >= 24u) { __builtin_memcpy(dp + 16, &v2, 8); tail = v3; done = 24; }
+            if (nb >= 32u) { __builtin_memcpy(dp + 24, &v3, 8); done = 32; }
+            uint32_t rest = nb - done;                            // 0 .. 7 bytes out of `tail`
+            uint8_t* tp = dp + done;
+            if (rest & 4u) { const uint32_t w4 = (uint32_t)tail; __builtin_memcpy(tp, &w4, 4); tp += 4; tail >>= 32; }
+            if (rest & 2u) { const uint16_t w2 = (uint16_t)tail; __builtin_memcpy(tp, &w2, 2); tp += 2; tail >>= 16; }
+            if (rest & 1u) *tp = (uint8_t)tail;
+          }
+        } else if (dist == 1u) {
+          // a run of one byte (qualities, padding): the byte replicated, eight at a time
+          const unsigned long long pat = (unsigned long long)L[src] * 0x0101010101010101ull;
+          uint32_t k = 0;
+          for (; k + 8u <= len; k += 8u) __builtin_memcpy(L + dpos + k, &pat, 8);
+          for (; k < len; k++) L[dpos + k] = (uint8_t)pat;
+        } else {
+          for (uint32_t k = 0; k < len; k++) L[dpos + k] = L[src + k];      // the match repeats its own beginning: byte by byte, in order
+        }
         todo = false;
       }
       __syncthreads();                                          // (one wavefront: orders the LDS writes of this round before the next round's reads)
@@ -261,7 +342,7 @@ void bgzf_inflate_launch(hipStream_t s, const uint8_t* d_raw, const BgzfDevBlock
   if (d_scratch && bgzf_inflate_two_phase()) {
     // the two-phase form: entries [n x INFL_ENT_STRIDE] then the list lengths [n] in the caller's scratch (bgzf_inflate_scratch_bytes)
     static bool attr_set = false;
-    if (!attr_set) { hip_check(hipFuncSetAttribute((const void*)k_bgzf_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 65536), "hipFuncSetAttribute(k_bgzf_resolve)"); attr_set = true; }
+    if (!attr_set) { hip_check(hipFuncSetAttribute((const void*)k_bgzf_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 64), "hipFuncSetAttribute(k_bgzf_resolve)"); attr_set = true; }
     uint32_t* const ent = (uint32_t*)d_scratch;
     uint32_t* const n_ent = ent + (size_t)n * INFL_ENT_STRIDE;
     hipLaunchKernelGGL(k_bgzf_clear_status, dim3(1), dim3(1), 0, s, d_status);
@@ -271,7 +352,7 @@ void bgzf_inflate_launch(hipStream_t s, const uint8_t* d_raw, const BgzfDevBlock
     else if (tl == 32) hipLaunchKernelGGL(k_bgzf_tokenize<32>, dim3((n + 31) / 32), dim3(32), 0, s, d_raw, d_blk, n, d_out, ent, n_ent, d_status);
     else if (tl == 64) hipLaunchKernelGGL(k_bgzf_tokenize<64>, dim3((n + 63) / 64), dim3(64), 0, s, d_raw, d_blk, n, d_out, ent, n_ent, d_status);
     else hipLaunchKernelGGL(k_bgzf_tokenize<16>, dim3((n + 15) / 16), dim3(16), 0, s, d_raw, d_blk, n, d_out, ent, n_ent, d_status);
-    hipLaunchKernelGGL(k_bgzf_resolve, dim3(n), dim3(64), 65536, s, d_blk, n, d_out, (const uint32_t*)ent, (const uint32_t*)n_ent, d_status);
+    hipLaunchKernelGGL(k_bgzf_resolve, dim3(n), dim3(64), 65536 + 64, s, d_blk, n, d_out, (const uint32_t*)ent, (const uint32_t*)n_ent, d_status);
     hipLaunchKernelGGL(k_bgzf_crc, dim3((n + 3) / 4), dim3(256), 0, s, (const uint8_t*)d_out, d_blk, n, d_status);
     hip_check(hipMemcpyAsync(h_status, d_status, 4, hipMemcpyDeviceToHost, s), "D2H");
     hip_check(hipGetLastError(), "bgzf inflate kernels (two-phase)");

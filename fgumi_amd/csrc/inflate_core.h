@@ -64,7 +64,9 @@ FGX_HD inline void infl_refill(BitReader& r) {
 // after a refill (bc >= 56): more than 8 bytes past the end means bits beyond the payload HAVE been consumed (pos - bc / 8 > len)
 FGX_HD inline bool infl_overrun(const BitReader& r) { return r.pos > r.len + 8u; }
 FGX_HD inline void infl_seek(BitReader& r, uint32_t pos) { r.pos = pos; r.bb = 0; r.bc = 0; r.nxt = infl_load64(r.base + (pos < r.len ? pos : r.len)); }
-FGX_HD inline uint32_t infl_bits(BitReader& r, uint32_t n) {   // n <= 16, bc >= n
+FGX_HD inline void infl_open(BitReader& r, const uint8_t* in, uint32_t in_len, void*) { r.base = in; r.len = in_len; r.pos = 0; r.bb = 0; r.bc = 0; r.nxt = 0; infl_seek(r, 0); }
+template <class RD>
+FGX_HD inline uint32_t infl_bits(RD& r, uint32_t n) {   // n <= 16, bc >= n
   const uint32_t v = (uint32_t)(r.bb & ((1ull << n) - 1ull));
   r.bb >>= n; r.bc -= n;
   return v;
@@ -77,8 +79,8 @@ FGX_HD inline uint32_t infl_rev(uint32_t code, uint32_t len) {
 
 // canonical Huffman tables from code lengths (RFC 1951 3.2.2).  Returns false for an over-subscribed set; an incomplete set is
 // allowed only for a single code (the one-distance-code case) — what zlib accepts.
-template <class FastPtr>   // uint16_t* on the host; an LDS (address space 3) pointer on the device: ds_read instead of a flat load
-FGX_HD inline bool infl_build(const uint8_t* lens, uint32_t n, uint16_t* count, uint16_t* sym, FastPtr fast, uint32_t fast_bits) {
+template <class FastPtr, class SlowPtr>   // uint16_t* on the host; LDS (address space 3) pointers on the device: ds_read instead of a flat load
+FGX_HD inline bool infl_build(const uint8_t* lens, uint32_t n, SlowPtr count, SlowPtr sym, FastPtr fast, uint32_t fast_bits) {
   for (uint32_t l = 0; l < 16; l++) count[l] = 0;
   for (uint32_t s = 0; s < n; s++) count[lens[s]]++;
   for (uint32_t i = 0; i < (1u << fast_bits); i++) fast[i] = 0;
@@ -108,7 +110,8 @@ FGX_HD inline bool infl_build(const uint8_t* lens, uint32_t n, uint16_t* count, 
 // (The walk used to start at bit 1 and read count[] from private memory — a global-memory round trip per bit, and with sixteen lanes
 // decoding in step nearly every step had a lane on it.)
 struct InflWalk { uint32_t first, index; uint32_t cnt[5]; };
-FGX_HD inline void infl_walk_setup(const uint16_t* count, uint32_t K, InflWalk& w) {
+template <class SlowPtr>
+FGX_HD inline void infl_walk_setup(SlowPtr count, uint32_t K, InflWalk& w) {
   uint32_t first = 0, index = 0;
   for (uint32_t l = 1; l <= K; l++) { index += count[l]; first = (first + count[l]) << 1; }
   w.first = first; w.index = index;
@@ -118,8 +121,8 @@ FGX_HD inline void infl_walk_setup(const uint16_t* count, uint32_t K, InflWalk& 
   }
 }
 // one symbol: the first-level table (K peeked bits), else the walk from bit K + 1 on.  Returns the symbol or -1.
-template <uint32_t K, class FastPtr>
-FGX_HD inline int32_t infl_decode(BitReader& r, FastPtr fast, const InflWalk& w, const uint16_t* sym) {
+template <uint32_t K, class RD, class FastPtr, class SlowPtr>
+FGX_HD inline int32_t infl_decode(RD& r, FastPtr fast, const InflWalk& w, SlowPtr sym) {
   static_assert(K >= 5 && K <= 14, "InflWalk holds the counts of at most ten lengths");
   const uint32_t e = fast[(uint32_t)r.bb & ((1u << K) - 1u)];
   if (e & 15u) { const uint32_t l = e & 15u; r.bb >>= l; r.bc -= l; return (int32_t)(e >> 4); }
@@ -226,15 +229,18 @@ FGX_HD inline uint32_t infl_entry_lit(uint32_t e) { return e >> 24; }
 FGX_HD inline uint32_t infl_entry_len(uint32_t e) { const uint32_t c = e & 511u; return c ? c + 2u : 0u; }
 FGX_HD inline uint32_t infl_entry_dist(uint32_t e) { return ((e >> 9) & 0x7FFFu) + 1u; }
 
-template <class FastPtr, bool TOK = false>
-FGX_HD inline int inflate_block_t(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, FastPtr f_lit, FastPtr f_dist, InflateSlow& W,
+// RD: the bit reader (BitReader: 8-byte loads from `in`; the device's tokenizer brings its own, with a window of the payload in LDS);
+// SlowPtr: where the canonical tables behind the first-level ones live (private memory / LDS).
+template <class FastPtr, bool TOK = false, class RD = BitReader, class SlowPtr = uint16_t*>
+FGX_HD inline int inflate_block_x(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, FastPtr f_lit, FastPtr f_dist,
+                                  SlowPtr w_lit_count, SlowPtr w_dist_count, SlowPtr w_lit_sym, SlowPtr w_dist_sym, void* rd_arg,
                                   uint32_t* ent = nullptr, uint32_t ent_cap = 0, uint32_t* n_ent = nullptr) {
   constexpr uint32_t LB = FGX_INFL_LIT_BITS, DB = FGX_INFL_DIST_BITS;
   uint32_t ne = 0, lit_run = 0;                                                 // TOK: entries written, literals since the last entry
   if (TOK && n_ent) *n_ent = 0;
   static constexpr uint8_t CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-  BitReader r{in, in_len, 0u, 0ull, 0u, 0ull};
-  infl_seek(r, 0);
+  RD r;
+  infl_open(r, in, in_len, rd_arg);
   uint64_t pv0 = 0, pv1 = 0, pv2 = 0, pv3 = 0;                                  // a match whose bytes are loaded and not stored yet (p_len of them at p_pos)
   uint32_t p_pos = 0, p_len = 0;
   uint32_t pos = 0;
@@ -278,13 +284,13 @@ FGX_HD inline int inflate_block_t(const uint8_t* in, uint32_t in_len, uint8_t* o
         infl_refill(r);
         for (uint32_t i = 0; i < hclen; i++) { if (r.bc < 3) infl_refill(r); cl[CL_ORDER[i]] = (uint8_t)infl_bits(r, 3); }
         // the code-length code: its tables live in the distance slots for the moment (19 symbols, up to 7 bits)
-        if (!infl_build(cl, 19, W.dist_count, W.dist_sym, f_dist, DB)) return INFL_BAD_CODE_LENGTHS;
+        if (!infl_build(cl, 19, w_dist_count, w_dist_sym, f_dist, DB)) return INFL_BAD_CODE_LENGTHS;
         InflWalk wc;
-        infl_walk_setup(W.dist_count, DB, wc);
+        infl_walk_setup(w_dist_count, DB, wc);
         uint32_t n = 0;
         while (n < hlit + hdist) {
           if (r.bc < 32) { infl_refill(r); if (infl_overrun(r)) return INFL_INPUT_OVERRUN; }
-          const int32_t s = infl_decode<DB>(r, f_dist, wc, W.dist_sym);
+          const int32_t s = infl_decode<DB>(r, f_dist, wc, w_dist_sym);
           if (s < 0) return INFL_BAD_CODE_LENGTHS;
           if (s < 16) lens[n++] = (uint8_t)s;
           else {
@@ -298,14 +304,14 @@ FGX_HD inline int inflate_block_t(const uint8_t* in, uint32_t in_len, uint8_t* o
         }
         if (lens[256] == 0) return INFL_BAD_CODE_LENGTHS;        // no end-of-block code
       }
-      if (!infl_build(lens, hlit, W.lit_count, W.lit_sym, f_lit, LB)) return INFL_BAD_CODE_LENGTHS;
-      if (!infl_build(lens + hlit, hdist, W.dist_count, W.dist_sym, f_dist, DB)) return INFL_BAD_CODE_LENGTHS;
+      if (!infl_build(lens, hlit, w_lit_count, w_lit_sym, f_lit, LB)) return INFL_BAD_CODE_LENGTHS;
+      if (!infl_build(lens + hlit, hdist, w_dist_count, w_dist_sym, f_dist, DB)) return INFL_BAD_CODE_LENGTHS;
       InflWalk wl, wd;
-      infl_walk_setup(W.lit_count, LB, wl);
-      infl_walk_setup(W.dist_count, DB, wd);
+      infl_walk_setup(w_lit_count, LB, wl);
+      infl_walk_setup(w_dist_count, DB, wd);
       for (;;) {
         if (r.bc < 48) { infl_refill(r); if (infl_overrun(r)) return INFL_INPUT_OVERRUN; }   // a length + distance pair takes at most 15 + 5 + 15 + 13 = 48 bits
-        int32_t s = infl_decode<LB>(r, f_lit, wl, W.lit_sym);
+        int32_t s = infl_decode<LB>(r, f_lit, wl, w_lit_sym);
         if (s < 0) return INFL_BAD_SYMBOL;
         if (s < 256) {
           if (pos >= out_len) return INFL_OUTPUT_OVERFLOW;
@@ -317,7 +323,7 @@ FGX_HD inline int inflate_block_t(const uint8_t* in, uint32_t in_len, uint8_t* o
         s -= 257;
         if (s >= 29) return INFL_BAD_SYMBOL;
         const uint32_t len = infl_len_base((uint32_t)s) + infl_bits(r, infl_len_extra((uint32_t)s));
-        const int32_t d = infl_decode<DB>(r, f_dist, wd, W.dist_sym);
+        const int32_t d = infl_decode<DB>(r, f_dist, wd, w_dist_sym);
         if (d < 0 || d >= 30) return INFL_BAD_DISTANCE;
         const uint32_t dist = infl_dist_base((uint32_t)d) + infl_bits(r, infl_dist_extra((uint32_t)d));
         if (dist > pos) return INFL_BAD_DISTANCE;
@@ -354,6 +360,13 @@ FGX_HD inline int inflate_block_t(const uint8_t* in, uint32_t in_len, uint8_t* o
     if (pos == out_len && n_ent) *n_ent = ne;                                    // (a block that failed leaves an EMPTY list: the second pass does nothing)
   }
   return pos == out_len ? INFL_OK : INFL_SIZE_MISMATCH;
+}
+
+template <class FastPtr, bool TOK = false>
+FGX_HD inline int inflate_block_t(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, FastPtr f_lit, FastPtr f_dist, InflateSlow& W,
+                                  uint32_t* ent = nullptr, uint32_t ent_cap = 0, uint32_t* n_ent = nullptr) {
+  return inflate_block_x<FastPtr, TOK, BitReader, uint16_t*>(in, in_len, out, out_len, f_lit, f_dist, W.lit_count, W.dist_count, W.lit_sym, W.dist_sym, nullptr, ent, ent_cap,
+                                                             n_ent);
 }
 
 // The second pass in its plain form (the host tests' reference for k_bgzf_resolve): the entries of one block played in order on `out`,
