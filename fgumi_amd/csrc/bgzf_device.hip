@@ -69,13 +69,17 @@ __device__ __forceinline__ void infl_fill_window(LdsBitReader& r, uint32_t at) {
   typedef __attribute__((address_space(3))) u32x4* LdsV;
   r.wbase = at & ~15u;
   r.wvalid = 1;
+  // all the loads first (addresses clamped to len + 8: a piece beyond that is never read — the refill's address stays at or below len), ONE
+  // wait, then the LDS stores; piece by piece, each behind its own predicate, the compiler made eight round trips of it
+  u32x4 v[INFL_WIN / 16];
+  const uint32_t lim = r.len + 8u;
 #pragma unroll
   for (uint32_t i = 0; i < INFL_WIN / 16; i++) {
     const uint32_t off = r.wbase + 16u * i;
-    u32x4 v = {0, 0, 0, 0};
-    if (off < r.len + 8u) __builtin_memcpy(&v, r.base + off, 16);
-    *(LdsV)(r.win + 16u * i) = v;
+    __builtin_memcpy(&v[i], r.base + (off < lim ? off : lim), 16);
   }
+#pragma unroll
+  for (uint32_t i = 0; i < INFL_WIN / 16; i++) *(LdsV)(r.win + 16u * i) = v[i];
 }
 __device__ __forceinline__ void infl_refill(LdsBitReader& r) {
   const uint32_t a = r.pos < r.len ? r.pos : r.len;
@@ -207,6 +211,62 @@ __global__ __launch_bounds__(64) void k_bgzf_resolve(const BgzfDevBlock* __restr
   const uint32_t whole = isize & ~15u;
   for (uint32_t i = 16u * lane; i < whole; i += 1024u) { const u32x4 v = *(const u32x4*)(L + i); __builtin_memcpy(g + i, &v, 16); }
   if (lane < isize - whole) g[whole + lane] = L[whole + lane];
+}
+
+// The same schedule on GLOBAL memory (the default): a wavefront per block, the block where it lies in `out` (its literals are in place), no LDS at
+// all — so a CU holds 32 blocks instead of the two that fit its LDS.  A round is then a cache round trip instead of an LDS access, but the
+// pass is bound by how many blocks are in flight, not by the latency of one (k_bgzf_resolve: 10.4 ms per 11 738 blocks with 512 in flight).
+// Ordering: the lanes of a round read below the frontier and write above it; the stores of a round are made visible to the wavefront's
+// later loads by a workgroup-scope release / acquire fence (one wavefront = one workgroup: the same L1).
+__global__ __launch_bounds__(64) void k_bgzf_resolve_global(const BgzfDevBlock* __restrict__ blk, uint32_t n, uint8_t* out, const uint32_t* __restrict__ ent,
+                                                            const uint32_t* __restrict__ n_ent, uint32_t* __restrict__ status) {
+  const uint32_t b = blockIdx.x, lane = threadIdx.x;
+  if (b >= n) return;
+  const BgzfDevBlock B = blk[b];
+  const uint32_t isize = B.isize;
+  if (isize == 0 || isize > 65536u) return;
+  const uint32_t ne = n_ent[b];
+  if (ne == 0) return;                                          // (the decoder has reported this block: its list is empty)
+  uint8_t* const L = out + B.out_off;
+  uint32_t run = 0;
+  const uint32_t* const E = ent + (size_t)b * INFL_ENT_STRIDE;
+  bool bad = false;
+  for (uint32_t e0 = 0; e0 < ne; e0 += 64) {
+    const uint32_t e = e0 + lane < ne ? E[e0 + lane] : 0u;
+    const uint32_t lit = infl_entry_lit(e), len = infl_entry_len(e), dist = infl_entry_dist(e);
+    const uint32_t incl = infl_wave_scan(lit + len, lane);
+    const uint32_t dpos = run + incl - len;
+    run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    bool todo = len != 0;
+    if (todo && (dist > dpos || dpos + len > isize)) { bad = true; todo = false; }
+    const uint32_t src = dpos - dist, span = len < dist ? len : dist;
+    unsigned long long w = __ballot(todo);
+    while (w) {
+      const uint32_t first = (uint32_t)__builtin_ctzll(w);
+      const uint32_t F = (uint32_t)__builtin_amdgcn_readlane((int)dpos, (int)first);
+      const bool ready = todo && (lane == first || src + span <= F);
+      if (ready) {
+        if (dist >= len) {
+          for (uint32_t k = 0; k < len; k += 32u) {
+            const uint32_t nb = len - k < 32u ? len - k : 32u;
+            const uint8_t* const sp = L + src + k;
+            uint8_t* const dp = L + dpos + k;
+            unsigned long long v0, v1 = 0, v2 = 0, v3 = 0;      // (loads may take up to 7 bytes more than they need: inside the stream or its slack, never stored)
+            __builtin_memcpy(&v0, sp, 8);
+            if (nb > 8u) __builtin_memcpy(&v1, sp + 8, 8);
+            if (nb > 16u) __builtin_memcpy(&v2, sp + 16, 8);
+            if (nb > 24u) __builtin_memcpy(&v3, sp + 24, 8);
+            infl_store_pending(dp, nb, v0, v1, v2, v3);
+          }
+        } else infl_copy_match(L + dpos, dist, len);            // the match repeats its own beginning (one lane, in order)
+        todo = false;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      w = __ballot(todo);
+    }
+  }
+  if (__any(bad) || run != isize) { if (lane == 0) atomicMax(status, ((b + 1u) << 4) | (uint32_t)INFL_SIZE_MISMATCH); }
 }
 
 // CRC-32 of p[0 .. len) by one wavefront (len > 0): every lane its 1/64 slice (slices end at the block's end), then the fold.  The
@@ -352,7 +412,9 @@ void bgzf_inflate_launch(hipStream_t s, const uint8_t* d_raw, const BgzfDevBlock
     else if (tl == 32) hipLaunchKernelGGL(k_bgzf_tokenize<32>, dim3((n + 31) / 32), dim3(32), 0, s, d_raw, d_blk, n, d_out, ent, n_ent, d_status);
     else if (tl == 64) hipLaunchKernelGGL(k_bgzf_tokenize<64>, dim3((n + 63) / 64), dim3(64), 0, s, d_raw, d_blk, n, d_out, ent, n_ent, d_status);
     else hipLaunchKernelGGL(k_bgzf_tokenize<16>, dim3((n + 15) / 16), dim3(16), 0, s, d_raw, d_blk, n, d_out, ent, n_ent, d_status);
-    hipLaunchKernelGGL(k_bgzf_resolve, dim3(n), dim3(64), 65536 + 64, s, d_blk, n, d_out, (const uint32_t*)ent, (const uint32_t*)n_ent, d_status);
+    static const bool in_lds = [] { const char* e = getenv("FGX_INFL_RESOLVE_LDS"); return e && e[0] == '1'; }();      // (measurements: the LDS form)
+    if (in_lds) hipLaunchKernelGGL(k_bgzf_resolve, dim3(n), dim3(64), 65536 + 64, s, d_blk, n, d_out, (const uint32_t*)ent, (const uint32_t*)n_ent, d_status);
+    else hipLaunchKernelGGL(k_bgzf_resolve_global, dim3(n), dim3(64), 0, s, d_blk, n, d_out, (const uint32_t*)ent, (const uint32_t*)n_ent, d_status);
     hipLaunchKernelGGL(k_bgzf_crc, dim3((n + 3) / 4), dim3(256), 0, s, (const uint8_t*)d_out, d_blk, n, d_status);
     hip_check(hipMemcpyAsync(h_status, d_status, 4, hipMemcpyDeviceToHost, s), "D2H");
     hip_check(hipGetLastError(), "bgzf inflate kernels (two-phase)");

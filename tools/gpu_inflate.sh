@@ -10,8 +10,8 @@ if [ "$2" != "notests" ]; then
 fi
 run() { local name=$1; shift; env "$@" timeout 300 python tools/bench_inflate.py --families 150000 --reps 5 > $OUT/$name.json 2> $OUT/$name.err; echo "$name: $(cut -c1-300 $OUT/$name.json) $(tail -1 $OUT/$name.err | cut -c1-200)"; }
 run one_phase FGX_INFL_TWO_PHASE=0
-for l in 8 16 32 64; do run two_phase_$l FGX_INFL_LANES=$l; done
-run two_phase_zlib6 FGX_INFL_LANES=16 BENCH_ZLIB=6
+for l in 8 16 32; do run two_phase_$l FGX_INFL_LANES=$l; done
+run two_phase_lds_resolve FGX_INFL_RESOLVE_LDS=1
 if [ "$3" = "trace" ]; then
   cd /tmp; export TMPDIR=/tmp
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o infl -- python $R/tools/bench_inflate.py --families 150000 --reps 3 > $OUT/trace.log 2>&1
