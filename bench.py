@@ -117,6 +117,73 @@ def cpu_baseline(n_families, family_size, read_length, threads, duplex=False, co
                        f"compute-only (records in RAM -> per-batch ConsensusOutput bytes), batches of {bg} MI groups pulled by the worker threads")
 
 
+def cpu_end_to_end(families, depth, read_length, threads, directory):
+    """The CPU side of the file -> file leg (BASELINE.md 3.2 / SURVEY 8d (b)): a level-1 BGZF grouped BAM -> consensus BAM through host code
+    only — block-parallel zlib inflate and the library's level-1 deflate on `threads` cores, the record chain walk, and the ORACLE for MI
+    grouping and the consensus caller (kind "port": the C++ restatement, batches of 50 MI groups pulled by `threads` workers).  The stages
+    run one after another here; the reference's pipeline overlaps them, so `value` (records / sum of the stages) is a lower bound of a
+    pipelined host path and `value_if_stages_overlapped` (records / the longest stage) an upper bound.  A bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fgx_opts
+    import orc
+    import numpy as np
+    from fgumi_amd import bgzf
+    os.makedirs(directory, exist_ok=True)
+    gin, gout = os.path.join(directory, "cpu_grouped.bam"), os.path.join(directory, "cpu_consensus.bam")
+    n_rec = write_grouped_bam(gin, families, depth, read_length)
+    o = fgx_opts.defaults(min_reads=1)
+    best = None
+    for _ in range(2):
+        st = {}
+        t0 = time.perf_counter()
+        with open(gin, "rb") as f:
+            raw = f.read()
+        st["read"] = time.perf_counter() - t0
+        t = time.perf_counter()
+        stream, own = bgzf.native_inflate(raw, threads)
+        st["inflate"] = time.perf_counter() - t
+        t = time.perf_counter()
+        l_text = int.from_bytes(bytes(stream[4:8]), "little")
+        p = 8 + l_text
+        n_ref = int.from_bytes(bytes(stream[p:p + 4]), "little")
+        p += 4
+        for _r in range(n_ref):
+            l_name = int.from_bytes(bytes(stream[p:p + 4]), "little")
+            p += 8 + l_name
+        rec_off, rec_len = bgzf.record_boundaries(stream, p)
+        st["boundaries"] = time.perf_counter() - t
+        t = time.perf_counter()
+        k_off, k_len, grp = orc.group_records(stream, rec_off, rec_len)
+        st["grouping"] = time.perf_counter() - t
+        t = time.perf_counter()
+        res = orc.process(o, stream, k_off, k_len, grp, batch_groups=50, threads=threads)
+        st["consensus"] = time.perf_counter() - t
+        t = time.perf_counter()
+        hdr = bgzf.bam_header_bytes(bgzf.consensus_header("A", "Read group", 0, "fgumi simplex"), [])
+        body = np.frombuffer(hdr + res["data"], dtype=np.uint8)
+        comp, own2 = bgzf.native_deflate(body, 1, threads, with_eof=True)
+        st["deflate"] = time.perf_counter() - t
+        t = time.perf_counter()
+        with open(gout, "wb") as f:
+            f.write(memoryview(comp))
+        st["write"] = time.perf_counter() - t
+        wall = time.perf_counter() - t0
+        count = int(res["count"])
+        del stream, own, comp, own2, res, body
+        if best is None or wall < best[0]:
+            best = (wall, st, count)
+    wall, st, count = best
+    for pth in (gin, gout):
+        try:
+            os.remove(pth)
+        except OSError:
+            pass
+    return dict(metric="BAM file in -> consensus BAM file out on the host cores (oracle + host BGZF), raw reads/s", value=n_rec / wall, unit="raw reads/s", kind="port",
+                cores=threads, families=families, raw_reads=n_rec, total_s=wall, stage_s=st, value_if_stages_overlapped=n_rec / max(st.values()),
+                consensus_records=count,
+                note="stages run one after another (the reference's pipeline overlaps them): `value` is a lower, `value_if_stages_overlapped` an upper bound; best of two")
+
+
 def write_grouped_bam(path, families, depth, read_length):
     """The grouped input BAM of the file -> file leg (level-1 BGZF, 125 000 families per slab); returns its record count."""
     from fgumi_amd import bgzf, simulate_grouped_reads
@@ -426,7 +493,16 @@ def main():
                 line["end_to_end"] = {"error": str(ex)[:300]}
         if not args.no_cpu_baseline and world == 1 and not args.depth_max:
             # threads = the CPUs the container may really use (cgroup quota): oversubscribing a throttled cgroup only adds queueing
-            line["cpu_baseline"] = cpu_baseline(min(fam, args.cpu_sample_families), args.depth, L, min(os.cpu_count() or 1, cgroup_cpu_quota() or 1 << 30), duplex, codec)
+            T = min(os.cpu_count() or 1, cgroup_cpu_quota() or 1 << 30)
+            line["cpu_baseline"] = cpu_baseline(min(fam, args.cpu_sample_families), args.depth, L, T, duplex, codec)
+            if plain and args.end_to_end_families > 0 and isinstance(line.get("end_to_end"), dict) and "value" in line["end_to_end"]:
+                try:   # the file -> file leg's CPU side (a quarter of its families: ~1 s of host work)
+                    ce = cpu_end_to_end(max(1000, min(args.end_to_end_families, fam) // 4), args.depth, L, T, os.environ.get("FGX_BENCH_TMP", "/tmp/fgx_bench_e2e"))
+                    line["cpu_baseline"]["end_to_end"] = ce
+                    line["end_to_end"]["vs_cpu_end_to_end"] = line["end_to_end"]["value"] / ce["value"]
+                    line["end_to_end"]["vs_cpu_end_to_end_if_its_stages_overlapped"] = line["end_to_end"]["value"] / ce["value_if_stages_overlapped"]
+                except Exception as ex:
+                    line["cpu_baseline"]["end_to_end"] = {"error": str(ex)[:300]}
         print(json.dumps(line))
     if rank == 0:   # profiling builds (-DFGX_PHASE_TIMING=1) expose per-phase cycle totals of the family kernels
         import ctypes

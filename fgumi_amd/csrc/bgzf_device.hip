@@ -406,7 +406,12 @@ void bgzf_inflate_launch(hipStream_t s, const uint8_t* d_raw, const BgzfDevBlock
     uint32_t* const ent = (uint32_t*)d_scratch;
     uint32_t* const n_ent = ent + (size_t)n * INFL_ENT_STRIDE;
     hipLaunchKernelGGL(k_bgzf_clear_status, dim3(1), dim3(1), 0, s, d_status);
-    static const uint32_t tl = [] { const char* e = getenv("FGX_INFL_LANES"); const int v = e ? atoi(e) : 0; return (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) ? (uint32_t)v : 16u; }();
+    // blocks per tokenizer wavefront: the pass is as long as ONE block's chain of symbols whatever the chip has in flight (a 64 KiB block of BAM
+    // records: ~13 000 symbols, ~1.1 us each for a wavefront that has its SIMD to itself), so every wavefront should have a SIMD to itself —
+    // n / 1024 blocks per wavefront, rounded up to a power of two (measured on 11 738 blocks: 8 lanes 22.0 ms, 16 18.3 ms, 32 17.6 ms)
+    static const uint32_t tl_env = [] { const char* e = getenv("FGX_INFL_LANES"); const int v = e ? atoi(e) : 0; return (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) ? (uint32_t)v : 0u; }();
+    uint32_t tl = tl_env;
+    if (!tl) { tl = 8; while (tl < 64u && (uint64_t)tl * 1024u < n) tl <<= 1; }
     if (tl == 4) hipLaunchKernelGGL(k_bgzf_tokenize<4>, dim3((n + 3) / 4), dim3(4), 0, s, d_raw, d_blk, n, d_out, ent, n_ent, d_status);
     else if (tl == 8) hipLaunchKernelGGL(k_bgzf_tokenize<8>, dim3((n + 7) / 8), dim3(8), 0, s, d_raw, d_blk, n, d_out, ent, n_ent, d_status);
     else if (tl == 32) hipLaunchKernelGGL(k_bgzf_tokenize<32>, dim3((n + 31) / 32), dim3(32), 0, s, d_raw, d_blk, n, d_out, ent, n_ent, d_status);
