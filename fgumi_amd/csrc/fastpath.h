@@ -149,6 +149,7 @@ struct FastParams {
   uint32_t* dir_flags;             // [0] families whose records differ in size from the prediction, [1] records past out_cap
   uint32_t lds_tile_bytes;
   uint32_t lds_wave_bytes;
+  uint32_t s2_packed;              // k_split_cols: 1 = ends of at least s2_nsafe rows try the packed pass first (round 5; FGX_S2_PACKED=0: measurements)
   uint32_t s2_nsafe;               // k_split_cols: unanimous_cap_depth(tables, min_input_bq) — agreeing observations from which a column is the cap for certain (gate_core.h)
   FullItem* full_items; uint32_t* full_count; uint32_t full_cap;   // N_LISTS append lists of `full_cap` items each
   // methylation-aware mode on the streaming kernels (simplex_deep.inc; meth_mode = FGX_METHYLATION_*, 0: off): the genome of fgx_set_reference

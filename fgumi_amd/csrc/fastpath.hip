@@ -55,7 +55,12 @@ namespace {
 constexpr int NT = FGX_BLOCK_NT;        // threads per family workgroup
 constexpr int FAST_MAX_READS = 128;     // per-read LDS tables
 constexpr int MAX_MC_OPS = 8;
-constexpr uint32_t MAX_CIG_OPS = 6;     // clips + aligned ops of a read the device pipelines take
+constexpr uint32_t MAX_CIG_OPS = 6;     // clips + aligned ops of a read the WAVEFRONT kernels take
+// Round 5: the workgroup-per-family kernel (k_family: indel / clipped simplex families of up to 128 records) takes reads of up to 16 CIGAR ops
+// and mates whose MC tag holds up to 17 — real aligner output carries such CIGARs in a fraction of a percent of its reads, and round 4 sent
+// every family that holds one through the general path (host orchestration, ~5 M reads/s); the wavefront kernels hand them on
+constexpr uint32_t WG_CIG_OPS = 16;
+constexpr int WG_MC_OPS = 17;
 constexpr int STAT_SLOTS = 1024;        // spread the per-batch counters over many addresses (atomic contention)
 
 struct ReadInfo {          // LDS, one per record of the family
@@ -88,7 +93,7 @@ struct Shared {
   unsigned long long raw_lo, raw_hi;    // byte span of the family's records in the blob
   uint32_t g_wcnt[2][3];                // gates: kept reads per wave and end
   uint32_t g_best[3], g_rxcnt[3], g_rxpos[3], g_rxbad[3];
-  uint32_t scig[FAST_MAX_READS][MAX_CIG_OPS];   // simplified CIGAR of each read (S, H, =, X folded into M, neighbours merged): len << 4 | kind
+  uint32_t scig[FAST_MAX_READS][WG_CIG_OPS];   // simplified CIGAR of each read (S, H, =, X folded into M, neighbours merged): len << 4 | kind
   uint8_t n_scig[FAST_MAX_READS];
   uint8_t b4_order[FAST_MAX_READS];             // alignment filter: members of one end, longest first
   uint16_t b4_mask[FAST_MAX_READS];             // alignment filter: groups a read belongs to
@@ -131,8 +136,7 @@ __device__ inline int32_t name_rank(const uint8_t* name, uint32_t len) {
 // falls past the stored bases (ReadMateAndRefPosIterator, overlapping.rs:565-620)
 __device__ __forceinline__ int32_t map_ref_to_query(const uint32_t* ops, uint32_t n, int64_t ref1, int64_t x, uint32_t l_seq) {
   int64_t ref = ref1, q = 0;
-#pragma unroll
-  for (uint32_t i = 0; i < MAX_CIG_OPS; i++) {
+  for (uint32_t i = 0; i < WG_CIG_OPS; i++) {
     if (i >= n) break;
     const uint32_t t = ops[i] & 15;
     const int64_t len = ops[i] >> 4;
@@ -196,7 +200,7 @@ __device__ inline void alignment_filter(Shared& S, uint32_t e, uint32_t n) {
   uint32_t ng = 0;
   uint8_t founder[MAX_GROUPS];
   uint32_t count[MAX_GROUPS];
-  uint32_t ca[MAX_CIG_OPS], cb[MAX_CIG_OPS];
+  uint32_t ca[WG_CIG_OPS], cb[WG_CIG_OPS];
   for (uint32_t k = 0; k < m; k++) {
     const uint32_t r = S.b4_order[k];
     const uint32_t na = oriented_truncated_cigar(S, r, ca);
@@ -447,13 +451,13 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
         R.flags = flag; R.l_seq = (uint16_t)l_seq; R.seq_off = (uint16_t)seq_off; R.name_len = (uint16_t)(l_name - 1);
         R.pos = (int32_t)rd32(p + 4); R.ref_id = (int32_t)rd32(p);
         R.excluded = (flag & (bam::F_SECONDARY | bam::F_SUPPLEMENTARY)) ? 1 : 0;
-        // CIGAR: up to MAX_CIG_OPS ops of any kind (clips, indels, skips); consensus is called in query space, the CIGAR matters
+        // CIGAR: up to WG_CIG_OPS ops of any kind (clips, indels, skips); consensus is called in query space, the CIGAR matters
         // for the mate clip, the overlap correction and the alignment filter
-        uint32_t ops[MAX_CIG_OPS];
+        uint32_t ops[WG_CIG_OPS];
         uint32_t n_ops = 0;
-        for (uint32_t i = 0; i < MAX_CIG_OPS; i++) ops[i] = 0;
+        for (uint32_t i = 0; i < WG_CIG_OPS; i++) ops[i] = 0;
         if (!R.excluded) {
-          if ((flag & bam::F_UNMAPPED) || n_cig == 0 || n_cig > MAX_CIG_OPS || l_seq == 0 || R.pos < 0) bad = true;
+          if ((flag & bam::F_UNMAPPED) || n_cig == 0 || n_cig > WG_CIG_OPS || l_seq == 0 || R.pos < 0) bad = true;
           else {
             uint64_t qsum = 0;
             uint32_t ns = 0;
@@ -488,10 +492,10 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
         }
         if (!bad && !R.excluded) {
           // mate-overlap clip (raw-bam/overlap.rs:181-207)
-          uint32_t mops[MAX_MC_OPS];
+          uint32_t mops[WG_MC_OPS];
           bool overflow = false;
           bam::Rec v{p, len};
-          uint64_t clip = bam::mate_clip(v, ops, n_ops, mc_off >= 0 ? p + mc_off : nullptr, mc_len, mops, MAX_MC_OPS, &overflow);
+          uint64_t clip = bam::mate_clip(v, ops, n_ops, mc_off >= 0 ? p + mc_off : nullptr, mc_len, mops, WG_MC_OPS, &overflow);
           if (overflow) bad = true;
           R.clip = (uint16_t)(clip > 65535 ? 65535 : clip);
           // name hash for mate pairing (a filter: candidates are compared word by word below): whole 8-byte steps, then one step
@@ -621,15 +625,14 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
       if (A.ref_id != B.ref_id) continue;
       // both CIGARs out of the LDS copy of the records; positions shared by two aligned blocks are corrected (overlapping.rs:236-336)
       uint32_t na = 1, nb = 1;
-      uint32_t oa[MAX_CIG_OPS], ob[MAX_CIG_OPS];
+      uint32_t oa[WG_CIG_OPS], ob[WG_CIG_OPS];
       int32_t rla = A.l_seq, rlb = B.l_seq;
       oa[0] = (uint32_t)A.l_seq << 4; ob[0] = (uint32_t)B.l_seq << 4;     // family of single-block reads: <l_seq>M, nothing to look up
       if (S.any_complex) {
         const uint8_t* pa = blobL + A.goff;
         const uint8_t* pb = blobL + B.goff;
         na = rd16(pa + 12); nb = rd16(pb + 12);
-#pragma unroll
-        for (uint32_t i = 0; i < MAX_CIG_OPS; i++) {
+        for (uint32_t i = 0; i < WG_CIG_OPS; i++) {
           oa[i] = i < na ? rd32(pa + 32 + A.name_len + 1 + 4 * i) : 0u;
           ob[i] = i < nb ? rd32(pb + 32 + B.name_len + 1 + 4 * i) : 0u;
         }
@@ -1177,6 +1180,7 @@ __global__ __launch_bounds__(256, MODE == 1 ? FGX_WAVE_OCC_DUPLEX : FGX_WAVE_OCC
   int32_t pos = 0, ref_id = 0;
   uint32_t mi_lo = 0, mi_len = 0, rx_lo = 0, rx_len = 0, cb_lo = 0, cb_len = 0;   // LDS offsets of tag values
   bool has_mi = false, has_rx = false, has_cb = false, excluded = false, bad = false;
+  bool long_cigar = false;          // simplex: more CIGAR ops than MAX_CIG_OPS — nothing below may index `ops` by them
   bool cplx = false;                // simplex: a CIGAR with I / D / N / P ops — the family goes to the workgroup-per-family kernel
   uint32_t lead_s = 0, m_len = 0;   // query offset of the first aligned base, length of the aligned block
   uint32_t strand = 0;   // duplex: 1 = MI ends in /A, 2 = /B
@@ -1222,7 +1226,8 @@ __global__ __launch_bounds__(256, MODE == 1 ? FGX_WAVE_OCC_DUPLEX : FGX_WAVE_OCC
           }
           if (cplx && MODE == 0) { /* decided below: the whole family moves to the workgroup-per-family kernel */ }
           else if (!okc || m_len == 0 || m_len > 65535 || (unsigned long long)lead_s + m_len + trail_s != l_seq) bad = true;
-        } else bad = true;
+        } else if (MODE == 0 && n_cig <= WG_CIG_OPS) { cplx = true; long_cigar = true; }   // (more ops than this kernel reads: the workgroup kernel's)
+        else bad = true;
       }
       // aux walk in LDS (tags.rs:13-34): first occurrence of MC / <tag> / RX / <cell tag>
       const uint32_t a0 = lo + (uint32_t)aux_off, an = len - (uint32_t)aux_off;
@@ -1245,7 +1250,7 @@ __global__ __launch_bounds__(256, MODE == 1 ? FGX_WAVE_OCC_DUPLEX : FGX_WAVE_OCC
         const bool okp = !(flags & bam::F_MATE_UNMAPPED) && ref_id == mref && rv != mrv;
         strand = (okp && ((long long)mpos + 1 < (long long)pos + 1 + ((long long)l_seq - 1))) ? 1u : 0u;   // `strand` doubles as frself here
       }
-      if (MODE != 2 && !bad && !excluded) {
+      if (MODE != 2 && !bad && !excluded && !long_cigar) {
         // mate-overlap clip (raw-bam/overlap.rs:181-357).  Closed form when the MC tag is one M op and all
         // coordinates are in the ordinary range (no saturating arithmetic can trigger); general code otherwise.
         bool fastclip = false;
@@ -1289,7 +1294,7 @@ __global__ __launch_bounds__(256, MODE == 1 ? FGX_WAVE_OCC_DUPLEX : FGX_WAVE_OCC
           bool overflow = false;
           bam::Rec v{W + lo, len};
           unsigned long long cl = bam::mate_clip(v, ops, n_cig, has_mc ? W + mc_lo : nullptr, mc_len, mops, MAX_MC_OPS, &overflow);
-          if (overflow) bad = true;
+          if (overflow) { if (MODE == 0) cplx = true; else bad = true; }   // (a mate of more ops than this kernel parses: the workgroup kernel's, which takes WG_MC_OPS)
           clip = (uint32_t)(cl > 65535 ? 65535 : cl);
         }
       }
@@ -3659,7 +3664,16 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
   }
   for (;;) {
     const int rc = run_once(c, d_blob, blob_len, d_rec_off, d_rec_len, n_rec, d_grp_first, n_grp, res);
-    if (rc != RUN_AGAIN_LARGER_POOL) return rc;
+    if (rc != RUN_AGAIN_LARGER_POOL) {
+      if (const char* e = getenv("FGX_S2_DEBUG")) if (atoi(e)) {   // (development: the packed pass's counters, cumulative over the process)
+        uint32_t h[64];
+        if (hipDeviceSynchronize() == hipSuccess && hipMemcpyFromSymbol(h, HIP_SYMBOL(g_s2_dbg), sizeof(h)) == hipSuccess) {
+          fprintf(stderr, "[s2 packed] runs tried %u finished %u (columns for k_call_full %u) no room %u shape refused %u", h[0], h[1], h[2], h[3], h[42]);
+          fprintf(stderr, "\n");
+        }
+      }
+      return rc;
+    }
   }
 }
 
@@ -3774,6 +3788,9 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
   P.min_input_bq = o.min_input_base_quality; P.min_cons_bq = o.min_consensus_base_quality;
   {   // k_split_cols's sum-free observation step: from how many agreeing observations a column is the cap whatever their qualities (gate_core.h)
     static const int nosum_env = [] { const char* e = getenv("FGX_S2_NOSUM"); return e ? atoi(e) : 1; }();      // (measurement knob: 0 = every end through the f32 sums)
+    static const int packed_env = [] { const char* e = getenv("FGX_S2_PACKED"); return e ? atoi(e) : 1; }();   // (measurement knob: 0 = the 64-column passes only)
+    static const int s2dbg_env = [] { const char* e = getenv("FGX_S2_DEBUG"); return e ? atoi(e) : 0; }();
+    P.s2_packed = (packed_env ? 1u : 0u) | ((packed_env && s2dbg_env) ? 2u : 0u);
     P.s2_nsafe = nosum_env ? unanimous_cap_depth(c->h_tables.t, (uint32_t)o.min_input_base_quality & 0xFFu, 64u) : FGX_NEVER_CAP;
   }
   P.trim = o.trim; P.overlap = o.overlapping_consensus;
@@ -3941,9 +3958,13 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       // as a whole (depth 12: every family took two launches, 32 ms per 1 M families)
       static const uint32_t s2_bytes_env = [] { const char* e = getenv("FGX_S2_BYTES"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 2048 && v <= 32768 ? (v & ~15) : 0); }();
       static const uint32_t s2_wpb_env = [] { const char* e = getenv("FGX_S2_WPB"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= 4 ? v : 0); }();
-      uint32_t s2_bytes0 = 4352;
+      // (round 5: the packed pass sends every column it does not answer itself to k_call_full — also the one-base columns of too few
+      // observations, which run_cols's gates answer — and keeps an 8-byte descriptor per such column at the top of the slice: 56 bytes per
+      // column, ~14 columns per depth-8 family of `simulate` data; 5632 bytes x 4 wavefronts still leave a CU six workgroups)
+      const bool s2_packed_on = P.s2_packed != 0 && P.s2_nsafe != FGX_NEVER_CAP;
+      uint32_t s2_bytes0 = s2_packed_on ? 5632 : 4352;
       {
-        const uint32_t mean_need = (uint32_t)(mean_recs + 0.999) * 240u + 16u + 400u;
+        const uint32_t mean_need = (uint32_t)(mean_recs + 0.999) * 240u + 16u + (s2_packed_on ? 1680u : 400u);
         if (mean_need > s2_bytes0) s2_bytes0 = std::min<uint32_t>((mean_need + 15u) & ~15u, 17408u);
       }
       if (s2_bytes_env) s2_bytes0 = s2_bytes_env;

@@ -116,9 +116,34 @@ def test_large_family_with_indels_and_clips():
     _run([recs, recs[:40], fr_pair(rng, "solo", "one", 50, 150, "20M4D80M", "100M")])
 
 
-def test_too_many_cigar_ops_defer_to_the_host():
+def test_long_cigars_stay_on_the_device():
+    """Round 5: reads of 7 .. 16 CIGAR ops (and mates whose MC tag is as long) are the workgroup kernel's — round 4 sent every family that
+    held one to the general path.  Families of one such pair, and families in which the long alignment is the majority / the minority of
+    the alignment filter; both mates long; clips around the indels."""
     rng = random.Random(1)
-    _run([fr_pair(rng, "x", "1", 100, 170, "10M1D10M1D10M1D10M1D60M", "100M")], expect_deferred=1)
+    nine = "10M1D10M1D10M1D10M1D60M"                             # 9 ops
+    fifteen = "5M1D" * 7 + "65M"                                # 15 ops
+    sixteen = "2S" + "6M1I" * 7 + "49M"                         # 16 ops, 100 query bases
+    assert qlen(nine) == 100 and qlen(fifteen) == 100 and qlen(sixteen) == 100
+    groups = [fr_pair(rng, "x", "1", 100, 170, nine, "100M")]
+    groups.append(fr_pair(rng, "y", "2", 300, 180, fifteen, nine))
+    groups.append(fr_pair(rng, "z", "3", 500, 170, sixteen, sixteen))
+    for g, (major, minor) in enumerate([(nine, "100M"), ("100M", fifteen), (sixteen, nine)]):
+        recs = []
+        for k in range(7):
+            c = major if k % 3 else minor
+            recs += fr_pair(rng, f"m{g}r{k}", f"M{g}", 800 + 200 * g, 175, c, "100M" if k % 2 else c)
+        groups.append(recs)
+    _run(groups)
+    _run(groups, min_reads=2)
+    _run(groups, overlapping=False)
+
+
+def test_more_than_sixteen_cigar_ops_defer_to_the_host():
+    rng = random.Random(1)
+    seventeen = "5M1D" * 8 + "60M"
+    assert qlen(seventeen) == 100 and len(bamutil.cigar_ops(seventeen)) == 17
+    _run([fr_pair(rng, "x", "1", 100, 170, seventeen, "100M")], expect_deferred=1)
 
 
 def random_cigar(rng, L):

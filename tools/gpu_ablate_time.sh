@@ -41,3 +41,4 @@ PY
 for k in 1 3 4 5 6; do [ -f $R/fgumi_amd/variant_s2abl$k.so ] && run abl$k $R/fgumi_amd/variant_s2abl$k.so; done
 run product $R/fgumi_amd/libfgumi_amd.so
 run product_sums $R/fgumi_amd/libfgumi_amd.so FGX_S2_NOSUM=0
+run product_unpacked $R/fgumi_amd/libfgumi_amd.so FGX_S2_PACKED=0
