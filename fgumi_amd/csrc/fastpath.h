@@ -149,6 +149,7 @@ struct FastParams {
   uint32_t* dir_flags;             // [0] families whose records differ in size from the prediction, [1] records past out_cap
   uint32_t lds_tile_bytes;
   uint32_t lds_wave_bytes;
+  uint32_t s2_partner;             // k_split_cols<.., 1>: a <.., 2> launch over the same families follows (else it hands the families that are not its shape to the next launch)
   uint32_t s2_packed;              // k_split_cols: 1 = ends of at least s2_nsafe rows try the packed pass first (round 5; FGX_S2_PACKED=0: measurements)
   uint32_t s2_nsafe;               // k_split_cols: unanimous_cap_depth(tables, min_input_bq) — agreeing observations from which a column is the cap for certain (gate_core.h)
   FullItem* full_items; uint32_t* full_count; uint32_t full_cap;   // N_LISTS append lists of `full_cap` items each
@@ -236,7 +237,7 @@ struct FastPath {
                const uint32_t* d_grp_first, uint32_t n_grp, FastResult* res);
   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: one flag per FastPath (= per caller = per device), not per process
   bool lds_attr_set = false, s2_attr_set = false, v2_attr_set = false;
-  static constexpr int MAX_CHUNKS = 16;
+  static constexpr int MAX_CHUNKS = 65;
   uint32_t last_split_chunks = 0;         // chunks the record / column pipeline ran the last batch in (0: another head of the chain); diagnostics
   hipStream_t s2 = nullptr;
   hipEvent_t ev_chunk[MAX_CHUNKS] = {}, ev_cols[MAX_CHUNKS] = {}, ev_fin = nullptr, ev_sample = nullptr;

@@ -2466,81 +2466,103 @@ __global__ __launch_bounds__(256) void k_dir_copy(const SplitOut* __restrict__ s
   if (lane < (uint32_t)(bytes - whole)) dst[whole + lane] = src[whole + lane];
 }
 
+// Round 5: two phases per workgroup.  Phase 1 (a thread per item): the sums of an observation item, then the TABLE answer of a column that
+// shows one base (try_unanimous_fast_path, base_builder.rs:883-994) — most observation items of k_split_cols's packed pass are such columns
+// (one base seen fewer times than its gate-free depth) and end here.  What needs the log-sum-exp chain (call_full: several hundred f64
+// instructions through the libm port) is appended to a list in LDS, and phase 2 runs it with the list's entries side by side in the
+// lanes: a wavefront pays for call_full only when it holds such columns, and then with all its lanes busy — before, one such item in
+// 64 kept the whole wavefront in the chain.
 __global__ __launch_bounds__(256) void k_call_full(FullParams P) {
+  __shared__ double sLL[256][4];
+  __shared__ unsigned long long sDest[256];
+  __shared__ uint32_t sObs[256];         // observation counts, a byte each, in the order of sLL; bit 31 of sKind: an observation item (depth counted here)
+  __shared__ uint32_t sKind[256];
+  __shared__ uint32_t sCnt;
+  if (threadIdx.x == 0) sCnt = 0;
+  __syncthreads();
   const uint32_t list = blockIdx.y;
   uint32_t cnt = P.count[list];
   if (cnt > P.cap) cnt = P.cap;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= cnt) return;
-  FullItem it = P.items[(size_t)list * P.cap + i];
-  if (it.chains == FULL_ITEM_CONT) return;                  // observations 16 .. of the column whose head item sits before it (or padding)
-  if (it.chains & FULL_ITEM_OBS) {
-    // a column that showed a second base (k_split_cols): its observations in file order, 16 bits each — the four-lane Kahan sum of
-    // ConsensusBaseBuilder::add (base_builder.rs:836-868), then the call.  More than 16 of them: the following items hold the rest.
-    const uint32_t m = it.chains & 0xFF;
-    ColumnAcc acc;
-    acc.reset();
-    const ConsensusTables& TT = P.T->t;
-    for (uint32_t k0 = 0; k0 < m; k0 += 16) {
-      uint16_t ob16[16];
-      if (k0 == 0) __builtin_memcpy(ob16, it.ll, 32);
-      else __builtin_memcpy(ob16, P.items[(size_t)list * P.cap + i + (k0 >> 4)].ll, 32);
-#pragma unroll
-      for (uint32_t j = 0; j < 16; j++) {
-        if (k0 + j < m) {
-          const uint32_t o = ob16[j], q = o & 0xFF, code = (o >> 8) & 15;
-          const int bl = bam::code_to_lane((uint8_t)code);
-          if (bl != 255 && q >= P.min_input_bq) { const uint32_t qq = q < 93 ? q : 93; acc.add(bl, TT.correct[qq], TT.error_per_alt[qq]); }
-        }
-      }
-    }
-    int bi;
-    uint8_t q;
-    column_call(TT, acc.s, acc.obs, &bi, &q);
-    const uint32_t depth = acc.contributions();
-    const uint32_t err = depth - (bi >= 0 ? acc.obs_of(bi) : 0);
+  // what a decided column leaves (vanilla_caller.rs:1711-1748); `is_obs`: an observation item — its depth is written too
+  auto finish = [&](uint64_t dest, int bi, uint8_t q, uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3, bool is_obs) {
+    const uint32_t depth = o0 + o1 + o2 + o3;
+    const uint32_t err = depth - (bi == 0 ? o0 : bi == 1 ? o1 : bi == 2 ? o2 : bi == 3 ? o3 : 0u);
     const uint8_t code = bi >= 0 ? (uint8_t)(1u << bi) : 15;
     uint8_t ob, oq;
     if (depth < P.min_reads) { ob = 15; oq = 0; }
     else if (q < P.min_cons_bq) { ob = 15; oq = FGX_MIN_PHRED; }
     else { ob = code; oq = q; }
-    if (it.dest & FULL_DEST_DIRECT) { full_patch_direct(P, it.dest, ob, oq, err, depth, true); return; }
-    P.col_code[it.dest] = ob; P.col_qual[it.dest] = oq; P.col_err[it.dest] = (uint16_t)(err < 32767u ? err : 32767u);
-    P.col_depth[it.dest] = (uint16_t)depth;
-    return;
-  }
-  if (it.chains) {   // chains by order of appearance (k_simplex_wave2 / k_simplex_seg): the bases are sorted out here, once per item
-    const uint32_t b1 = it.chains & 15, b2 = (it.chains >> 4) & 15, b3 = (it.chains >> 8) & 15;
-    const double c1 = it.ll[0], c2 = it.ll[1], c3 = it.ll[2], cR = it.ll[3];
-    const uint32_t n1 = it.obs & 0xFF, n2 = (it.obs >> 8) & 0xFF, n3 = (it.obs >> 16) & 0xFF, nR = it.obs >> 24;
-    uint32_t packed = 0;
+    if (dest & FULL_DEST_DIRECT) { full_patch_direct(P, dest, ob, oq, err, depth, is_obs); return; }
+    P.col_code[dest] = ob; P.col_qual[dest] = oq; P.col_err[dest] = (uint16_t)(err < 32767u ? err : 32767u);
+    if (is_obs) P.col_depth[dest] = (uint16_t)depth;
+  };
+  auto push = [&](uint64_t dest, const double* ll, uint32_t obs, uint32_t kind) {
+    const uint32_t k = atomicAdd(&sCnt, 1u);
+    sLL[k][0] = ll[0]; sLL[k][1] = ll[1]; sLL[k][2] = ll[2]; sLL[k][3] = ll[3];
+    sDest[k] = dest; sObs[k] = obs; sKind[k] = kind;
+  };
+  if (i < cnt) {
+    FullItem it = P.items[(size_t)list * P.cap + i];
+    if (it.chains == FULL_ITEM_CONT) { /* observations 16 .. of the column whose head item sits before it (or padding) */ }
+    else if (it.chains & FULL_ITEM_OBS) {
+      // a column k_split_cols did not answer: its observations in file order, 16 bits each — the four-lane Kahan sum of
+      // ConsensusBaseBuilder::add (base_builder.rs:836-868), then the call.  More than 16 of them: the following items hold the rest.
+      const uint32_t m = it.chains & 0xFF;
+      ColumnAcc acc;
+      acc.reset();
+      const ConsensusTables& TT = P.T->t;
+      for (uint32_t k0 = 0; k0 < m; k0 += 16) {
+        uint16_t ob16[16];
+        if (k0 == 0) __builtin_memcpy(ob16, it.ll, 32);
+        else __builtin_memcpy(ob16, P.items[(size_t)list * P.cap + i + (k0 >> 4)].ll, 32);
 #pragma unroll
-    for (uint32_t k = 0; k < 4; k++) {
-      const uint32_t code = 1u << k;
-      it.ll[k] = code == b1 ? c1 : code == b2 ? c2 : code == b3 ? c3 : cR;
-      packed |= (code == b1 ? n1 : code == b2 ? n2 : code == b3 ? n3 : nR) << (8 * k);
+        for (uint32_t j = 0; j < 16; j++) {
+          if (k0 + j < m) {
+            const uint32_t o = ob16[j], q = o & 0xFF, code = (o >> 8) & 15;
+            const int bl = bam::code_to_lane((uint8_t)code);
+            if (bl != 255 && q >= P.min_input_bq) { const uint32_t qq = q < 93 ? q : 93; acc.add(bl, TT.correct[qq], TT.error_per_alt[qq]); }
+          }
+        }
+      }
+      int bi = -1;
+      uint8_t q = FGX_MIN_PHRED;
+      if (acc.contributions() == 0 || unanimous_fast_path(TT, acc.s, acc.obs, &bi, &q)) finish(it.dest, bi, q, acc.obs[0], acc.obs[1], acc.obs[2], acc.obs[3], true);
+      else push(it.dest, acc.s, acc.obs[0] | (acc.obs[1] << 8) | (acc.obs[2] << 16) | (acc.obs[3] << 24), 0x80000000u);
+    } else {
+      if (it.chains) {   // chains by order of appearance (k_simplex_wave2 / k_simplex_seg): the bases are sorted out here, once per item
+        const uint32_t b1 = it.chains & 15, b2 = (it.chains >> 4) & 15, b3 = (it.chains >> 8) & 15;
+        const double c1 = it.ll[0], c2 = it.ll[1], c3 = it.ll[2], cR = it.ll[3];
+        const uint32_t n1 = it.obs & 0xFF, n2 = (it.obs >> 8) & 0xFF, n3 = (it.obs >> 16) & 0xFF, nR = it.obs >> 24;
+        uint32_t packed = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+          const uint32_t code = 1u << k;
+          it.ll[k] = code == b1 ? c1 : code == b2 ? c2 : code == b3 ? c3 : cR;
+          packed |= (code == b1 ? n1 : code == b2 ? n2 : code == b3 ? n3 : nR) << (8 * k);
+        }
+        it.obs = packed;
+      }
+      push(it.dest, it.ll, it.obs, 0u);       // (the kernels that send these have run their gates already)
     }
-    it.obs = packed;
   }
-  const bool is_rx = (it.dest >> 63) != 0;
-  const ConsensusTables& T = is_rx ? P.TU->t : P.T->t;
-  int bi;
-  uint8_t q;
-  call_full(T, it.ll, &bi, &q);
-  if (is_rx) {
-    uint64_t d = it.dest & ~(1ull << 63);
-    P.rx_base[(size_t)(d >> 8) * P.rx_stride + (d & 0xFF)] = bi >= 0 ? "ACGT"[bi] : 'N';
-    return;
+  __syncthreads();
+  const uint32_t todo = sCnt;
+  if (threadIdx.x < todo) {
+    const uint32_t k = threadIdx.x;
+    const uint64_t dest = sDest[k];
+    const double ll[4] = {sLL[k][0], sLL[k][1], sLL[k][2], sLL[k][3]};
+    const uint32_t ob = sObs[k];
+    const bool is_rx = (dest >> 63) != 0;
+    const ConsensusTables& T = is_rx ? P.TU->t : P.T->t;
+    int bi;
+    uint8_t q;
+    call_full(T, ll, &bi, &q);
+    if (is_rx) {
+      const uint64_t d = dest & ~(1ull << 63);
+      P.rx_base[(size_t)(d >> 8) * P.rx_stride + (d & 0xFF)] = bi >= 0 ? "ACGT"[bi] : 'N';
+    } else finish(dest, bi, q, ob & 0xFF, (ob >> 8) & 0xFF, (ob >> 16) & 0xFF, ob >> 24, (sKind[k] >> 31) != 0);
   }
-  uint32_t obs[4] = {it.obs & 0xFF, (it.obs >> 8) & 0xFF, (it.obs >> 16) & 0xFF, it.obs >> 24};
-  uint32_t depth = obs[0] + obs[1] + obs[2] + obs[3];
-  uint32_t err = depth - (bi >= 0 ? obs[bi] : 0);
-  uint8_t code = bi >= 0 ? (uint8_t)(1u << bi) : 15, ob, oq;
-  if (depth < P.min_reads) { ob = 15; oq = 0; }
-  else if (q < P.min_cons_bq) { ob = 15; oq = FGX_MIN_PHRED; }
-  else { ob = code; oq = q; }
-  if (it.dest & FULL_DEST_DIRECT) { full_patch_direct(P, it.dest, ob, oq, err, depth, false); return; }
-  P.col_code[it.dest] = ob; P.col_qual[it.dest] = oq; P.col_err[it.dest] = (uint16_t)(err < 32767u ? err : 32767u);
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -3875,10 +3897,14 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       // k_split_cols over growing LDS slices (4 / 2 / 1 / 1 wavefronts per workgroup); what it does not take is collected in
       // `route` and starts the k_simplex_wave2 chain below
         if (!s2_attr_set) {
-        hip_check(hipFuncSetAttribute((const void*)k_split_cols<0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_split_cols<0, 0, 0>: the device refused the dynamic LDS size");
-        hip_check(hipFuncSetAttribute((const void*)k_split_cols<160, 80, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_split_cols<160, 80, 0>: the device refused the dynamic LDS size");
-        hip_check(hipFuncSetAttribute((const void*)k_split_cols<0, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_split_cols<0, 0, 1>: the device refused the dynamic LDS size");
-        hip_check(hipFuncSetAttribute((const void*)k_split_cols<160, 80, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_split_cols<160, 80, 1>: the device refused the dynamic LDS size");
+        hip_check(hipFuncSetAttribute((const void*)k_split_cols<0, 0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_split_cols<0, 0, 0, 0>: the device refused the dynamic LDS size");
+        hip_check(hipFuncSetAttribute((const void*)k_split_cols<160, 80, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_split_cols<160, 80, 0, 0>: the device refused the dynamic LDS size");
+        hip_check(hipFuncSetAttribute((const void*)k_split_cols<0, 0, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_split_cols<0, 0, 0, 1>: the device refused the dynamic LDS size");
+        hip_check(hipFuncSetAttribute((const void*)k_split_cols<160, 80, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_split_cols<160, 80, 0, 1>: the device refused the dynamic LDS size");
+        hip_check(hipFuncSetAttribute((const void*)k_split_cols<0, 0, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_split_cols<0, 0, 0, 2>: the device refused the dynamic LDS size");
+        hip_check(hipFuncSetAttribute((const void*)k_split_cols<160, 80, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_split_cols<160, 80, 0, 2>: the device refused the dynamic LDS size");
+        hip_check(hipFuncSetAttribute((const void*)k_split_cols<0, 0, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_split_cols<0, 0, 1, 0>: the device refused the dynamic LDS size");
+        hip_check(hipFuncSetAttribute((const void*)k_split_cols<160, 80, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_split_cols<160, 80, 1, 0>: the device refused the dynamic LDS size");
         s2_attr_set = true;
       }
       if (!d_s2img.p) {   // the tables of a caller never change: one image per FastPath
@@ -3951,7 +3977,13 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       const uint32_t n_sample = n_grp < 64u ? n_grp : 64u;
       hip_check(hipMemcpyAsync(fam_sample, d_split_fam.p, (size_t)n_sample * sizeof(SplitFam), hipMemcpyDeviceToHost, s2), "D2H");
       hip_check(hipEventRecord(ev_sample, s2), "event");
-      for (uint32_t ci = 1; ci < n_chunks; ci++) launch_parse(ci);
+      // (round 5) the record kernel is bound by HBM bandwidth (it reads the whole blob: 4.2 TB/s alone on the chip), and a column kernel
+      // beside it gets what is left — with every chunk's record kernel queued up front, the first column kernel took 6.9 ms instead of
+      // 1.7 and the two streams added up like one (gpurun_out timeline, profiles/r05_timeline_*.txt).  Paced: chunk k + 2 is parsed
+      // when the column kernel of chunk k has finished, i.e. under the column kernel of chunk k + 1.
+      static const int pace_env = [] { const char* e = getenv("FGX_S2_PACE"); return e ? atoi(e) : 1; }();      // (measurement knob: 0 = all record kernels up front)
+      const bool paced = pace_env != 0 && n_chunks > 2;
+      for (uint32_t ci = 1; ci < (paced ? 2u : n_chunks); ci++) launch_parse(ci);
       hip_check(hipEventSynchronize(ev_sample), "sync");
       // LDS slice of the first launch: the MEAN family's tile (rows of 160 + 80 bytes) + room for its k_call_full items, at least the
       // 4352 bytes of a 16-record family — a deeper library starts at the slice its families need instead of failing the first launch
@@ -3961,7 +3993,18 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       // (round 5: the packed pass sends every column it does not answer itself to k_call_full — also the one-base columns of too few
       // observations, which run_cols's gates answer — and keeps an 8-byte descriptor per such column at the top of the slice: 56 bytes per
       // column, ~14 columns per depth-8 family of `simulate` data; 5632 bytes x 4 wavefronts still leave a CU six workgroups)
-      const bool s2_packed_on = P.s2_packed != 0 && P.s2_nsafe != FGX_NEVER_CAP;
+      bool s2_packed_on = !direct && P.s2_packed != 0 && P.s2_nsafe != FGX_NEVER_CAP && P.min_reads <= P.s2_nsafe && ((uint32_t)P.min_input_bq & 0xFFu) <= 128u;   // (what run_cols_packed asks of the caller's options)
+      // which of the two first-stage kernels the batch needs: by the sampled families (a family of the other kind still finds its way: the
+      // packed kernel without a partner hands it to the next launch, the partner kernel alone IS the classic kernel)
+      uint32_t n_pk = 0;
+      if (s2_packed_on) for (uint32_t i = 0; i < n_sample; i++) {
+        const SplitFam& F = fam_sample[i];
+        auto ok = [&](uint32_t m) { return m < 2u || (m >= P.s2_nsafe && m <= 17u); };
+        n_pk += (ok(F.m_a) && ok(F.m_b) && ((F.len_a + 7u) >> 3) + ((F.len_b + 7u) >> 3) <= 64u) ? 1u : 0u;
+      }
+      static const int s2_partner_env = [] { const char* e = getenv("FGX_S2_PARTNER"); return e ? atoi(e) : -1; }();   // (measurement knob: 1 = always both kernels, 0 = never)
+      if (s2_packed_on && n_sample && 100ull * n_pk < (unsigned long long)n_sample) s2_packed_on = false;               // under 1 % of its shape: the classic kernel alone
+      const bool s2_partner = s2_packed_on && (s2_partner_env >= 0 ? s2_partner_env != 0 : 100ull * n_pk < 99ull * n_sample);
       uint32_t s2_bytes0 = s2_packed_on ? 5632 : 4352;
       {
         const uint32_t mean_need = (uint32_t)(mean_recs + 0.999) * 240u + 16u + (s2_packed_on ? 1680u : 400u);
@@ -4000,6 +4043,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
         hip_check(hipMemsetAsync(d_cnt, 0, 4, s), "memset");
         FastParams PS = P;
         PS.group_list = s2_list; PS.lds_wave_bytes = st2[ci].bytes;
+        PS.s2_partner = s2_partner ? 1u : 0u;
         PS.retry = last ? nullptr : lists[s2_out]; PS.n_retry = d_cnt;
         if (st2[ci].bytes > 65536u) continue;                 // (more than the attribute limit set above: the family goes down the chain)
         const uint32_t wpb = std::min<uint32_t>(st2[ci].wpb, 65536u / st2[ci].bytes);   // wpb x slice within the 64 KiB requested for k_split_cols
@@ -4008,10 +4052,19 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
           PS.g0 = g_first;
           const dim3 grid((count + wpb - 1) / wpb), block(64 * wpb);
           if (direct) {
-            if (st2[ci].fixed) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<160, 80, 1>), grid, block, lds, s, PS, count);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<0, 0, 1>), grid, block, lds, s, PS, count);
-          } else if (st2[ci].fixed) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<160, 80, 0>), grid, block, lds, s, PS, count);
-          else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<0, 0, 0>), grid, block, lds, s, PS, count);
+            if (st2[ci].fixed) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<160, 80, 1, 0>), grid, block, lds, s, PS, count);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<0, 0, 1, 0>), grid, block, lds, s, PS, count);
+          } else if (ci == 0 && s2_packed_on) {
+            // (round 5) the first stage as two launches over the same families: the packed pass for the families of its shape, run_cols for the rest
+            if (st2[ci].fixed) {
+              hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<160, 80, 0, 1>), grid, block, lds, s, PS, count);
+              if (s2_partner) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<160, 80, 0, 2>), grid, block, lds, s, PS, count);
+            } else {
+              hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<0, 0, 0, 1>), grid, block, lds, s, PS, count);
+              if (s2_partner) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<0, 0, 0, 2>), grid, block, lds, s, PS, count);
+            }
+          } else if (st2[ci].fixed) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<160, 80, 0, 0>), grid, block, lds, s, PS, count);
+          else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<0, 0, 0, 0>), grid, block, lds, s, PS, count);
         };
         if (ci == 0) {   // the first stage takes the families in file order, chunk by chunk behind the record kernel
           for (uint32_t k = 0; k < n_chunks; k++) {
@@ -4026,6 +4079,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
             FastParams PF = P;
             PF.group_list = nullptr; PF.g0 = ga;
             hipLaunchKernelGGL(k_split_finish, dim3((gb - ga + 255) / 256), dim3(256), 0, s2, PF, gb - ga);
+            if (paced && k + 2 < n_chunks) launch_parse(k + 2);
           }
         } else {
           launch_cols(0u, n_s2);
