@@ -2478,11 +2478,14 @@ __global__ __launch_bounds__(256) void k_call_full(FullParams P) {
   __shared__ uint32_t sObs[256];         // observation counts, a byte each, in the order of sLL; bit 31 of sKind: an observation item (depth counted here)
   __shared__ uint32_t sKind[256];
   __shared__ uint32_t sCnt;
-  if (threadIdx.x == 0) sCnt = 0;
-  __syncthreads();
+  __shared__ double sTab[94][2];         // {correct, error_per_alt} by quality: an observation item reads a pair per observation (from global memory that is a dependent ~1 us chain per item)
   const uint32_t list = blockIdx.y;
   uint32_t cnt = P.count[list];
   if (cnt > P.cap) cnt = P.cap;
+  if (blockIdx.x * blockDim.x >= cnt) return;      // (the grid covers every list's capacity: most workgroups have nothing)
+  if (threadIdx.x == 0) sCnt = 0;
+  if (threadIdx.x < 94) { sTab[threadIdx.x][0] = P.T->t.correct[threadIdx.x]; sTab[threadIdx.x][1] = P.T->t.error_per_alt[threadIdx.x]; }
+  __syncthreads();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   // what a decided column leaves (vanilla_caller.rs:1711-1748); `is_obs`: an observation item — its depth is written too
   auto finish = [&](uint64_t dest, int bi, uint8_t q, uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3, bool is_obs) {
@@ -2521,7 +2524,7 @@ __global__ __launch_bounds__(256) void k_call_full(FullParams P) {
           if (k0 + j < m) {
             const uint32_t o = ob16[j], q = o & 0xFF, code = (o >> 8) & 15;
             const int bl = bam::code_to_lane((uint8_t)code);
-            if (bl != 255 && q >= P.min_input_bq) { const uint32_t qq = q < 93 ? q : 93; acc.add(bl, TT.correct[qq], TT.error_per_alt[qq]); }
+            if (bl != 255 && q >= P.min_input_bq) { const uint32_t qq = q < 93 ? q : 93; acc.add(bl, sTab[qq][0], sTab[qq][1]); }
           }
         }
       }
