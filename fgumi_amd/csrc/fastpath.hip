@@ -41,6 +41,7 @@
 #include <type_traits>
 #include "fastpath.h"
 #include "gate_core.h"
+#include "packed_core.h"
 
 namespace fgx {
 

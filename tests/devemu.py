@@ -45,6 +45,9 @@ def lib():
         L.demu_gates.argtypes = [C.c_uint8, C.c_uint8, U32, U32, VP, U32, VP, VP, VP, VP, VP, VP]
         L.demu_cap_depth.argtypes = [C.c_uint8, C.c_uint8, U32, U32, U32, VP]
         L.demu_cap_depth.restype = U32
+        L.demu_packed_end.argtypes = [VP, VP, U32, U32, U32, U32, U32, C.c_int, U32, U32, U32, U32, U32, VP, VP, VP, VP]
+        L.demu_t1.argtypes = [C.c_uint8, C.c_uint8, U32, VP]
+        L.demu_t1.restype = None
         _lib = L
     return _lib
 
@@ -116,3 +119,22 @@ def cap_depth(pre, post, min_bq, n_max=64, tie=0):
     cap = C.c_uint32(0)
     n = lib().demu_cap_depth(pre, post, tie, min_bq, n_max, C.addressof(cap))
     return (None if n == 0xFFFFFFFF else int(n)), int(cap.value)
+
+
+def packed_end(seq, qual, m, len_e, cnt_e, rev, min_bq, nsafe, cap, min_cons_bq=2, min_reads=1):
+    """One end of a family through k_split_cols's packed column pass (packed_core.h) on the host.  seq: (rows, ss) uint8 packed codes, qual:
+    (rows, qs) uint8.  Returns (code, qual, depth, flagged) per consensus column."""
+    L = lib()
+    seq = np.ascontiguousarray(seq, dtype=np.uint8); qual = np.ascontiguousarray(qual, dtype=np.uint8)
+    code = np.zeros(cnt_e, dtype=np.uint8); qo = np.zeros(cnt_e, dtype=np.uint8); dep = np.zeros(cnt_e, dtype=np.uint16); fl = np.zeros(cnt_e, dtype=np.uint8)
+    rc = L.demu_packed_end(seq.ctypes.data, qual.ctypes.data, qual.shape[1], seq.shape[1], m, len_e, cnt_e, 1 if rev else 0, min_bq, nsafe, cap, min_cons_bq, min_reads,
+                           code.ctypes.data, qo.ctypes.data, dep.ctypes.data, fl.ctypes.data)
+    assert rc == 0, rc
+    return code, qo, dep, fl
+
+
+def t1_table(pre, post, tie=0):
+    """S2Lds::t1: the consensus quality of a column that holds ONE observation, by its quality (0xFF: not answered from the table)."""
+    t = np.zeros(96, dtype=np.uint8)
+    lib().demu_t1(pre, post, tie, t.ctypes.data)
+    return t

@@ -87,6 +87,7 @@ double fgx_caller::run_columns(fgx::ColumnBatch&, fgx::ColParams) { return 0.0; 
 using namespace fgx;
 
 #include "../../fgumi_amd/csrc/gate_core.h"
+#include "../../fgumi_amd/csrc/packed_core.h"
 
 extern "C" {
 
@@ -172,6 +173,48 @@ uint32_t demu_cap_depth(uint8_t pre, uint8_t post, uint32_t tie, uint32_t min_bq
   fgx::build_tables(t, pre, post, tie);
   if (cap) *cap = t.cap;
   return fgx::unanimous_cap_depth(t, min_bq, n_max);
+}
+
+// The packed column pass of k_split_cols (packed_core.h) on the host, one END of a family: rows of `qs` quality bytes and `ss` sequence
+// bytes (two 4-bit codes each, as BAM stores them), m rows, reads of lenE bases, cntE consensus columns, reverse or forward.  A "lane"
+// per group of eight positions, exactly as run_cols_packed walks it.  Per column: code / quality / depth as the pass writes them, and
+// flagged[c] = 1 where the column is left to k_call_full (or the one-observation table).
+int demu_packed_end(const uint8_t* seq, const uint8_t* qual, uint32_t qs, uint32_t ss, uint32_t m, uint32_t lenE, uint32_t cntE, int rev, uint32_t min_bq, uint32_t nsafe,
+                    uint32_t cap, uint32_t min_cons_bq, uint32_t min_reads, uint8_t* code, uint8_t* qual_out, uint16_t* depth, uint8_t* flagged) {
+  const uint32_t groups = (lenE + 7u) >> 3;
+  if (qs < 8u * groups || ss < 4u * groups || min_bq > 128u || m > 17u) return 1;
+  const uint32_t mb4 = min_bq * 0x01010101u;
+  for (uint32_t k = 0; k < groups; k++) {
+    uint32_t nfl, nfh;
+    fgx::pk::count_masks(lenE, k, &nfl, &nfh);
+    fgx::pk::Acc A;
+    fgx::pk::acc_reset(A);
+    for (uint32_t j = 0; j < m; j++) {
+      uint32_t qx, qy, b;
+      memcpy(&qx, qual + (size_t)j * qs + 8u * k, 4); memcpy(&qy, qual + (size_t)j * qs + 8u * k + 4, 4); memcpy(&b, seq + (size_t)j * ss + 4u * k, 4);
+      fgx::pk::acc_row(A, qx, qy, b, mb4, nfl, nfh);
+    }
+    fgx::pk::Out F;
+    fgx::pk::finalize(A, true, rev != 0, lenE, cntE, k, nsafe, cap, min_cons_bq, min_reads, F);
+    for (int s_ = 0; s_ < 8; s_++) {
+      const bool valid = ((F.valid2[s_ >> 2] >> (8 * (s_ & 3) + 7)) & 1u) != 0;
+      if (valid != (s_ >= F.lo_s && s_ < F.hi_s)) return 2;                  // the slots [lo_s, hi_s) ARE the columns
+      if (!valid) continue;
+      const int64_t c = (int64_t)F.c_lo + s_;
+      if (c < 0 || c >= (int64_t)cntE) return 3;
+      code[c] = (uint8_t)(F.code2[s_ >> 2] >> (8 * (s_ & 3))); qual_out[c] = (uint8_t)(F.qual2[s_ >> 2] >> (8 * (s_ & 3)));
+      depth[c] = (uint16_t)(F.dep4[s_ >> 1] >> (16 * (s_ & 1))); flagged[c] = (uint8_t)((F.flag2[s_ >> 2] >> (8 * (s_ & 3) + 7)) & 1u);
+    }
+  }
+  return 0;
+}
+
+// S2Lds::t1 (packed_core.h fill_t1): the consensus quality of a column that holds one observation, by its quality
+void demu_t1(uint8_t pre, uint8_t post, uint32_t tie, uint8_t* t1) {
+  fgx::ConsensusTables t;
+  memset(&t, 0, sizeof(t));
+  fgx::build_tables(t, pre, post, tie);
+  fgx::pk::fill_t1(t1, t);
 }
 
 }  // extern "C"
