@@ -4003,7 +4003,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       uint32_t n_pk = 0;
       if (s2_packed_on) for (uint32_t i = 0; i < n_sample; i++) {
         const SplitFam& F = fam_sample[i];
-        auto ok = [&](uint32_t m) { return m < 2u || (m >= P.s2_nsafe && m <= 17u); };
+        auto ok = [&](uint32_t m) { return m < 2u || (m >= P.s2_nsafe && m <= 16u); };
         n_pk += (ok(F.m_a) && ok(F.m_b) && ((F.len_a + 7u) >> 3) + ((F.len_b + 7u) >> 3) <= 64u) ? 1u : 0u;
       }
       static const int s2_partner_env = [] { const char* e = getenv("FGX_S2_PARTNER"); return e ? atoi(e) : -1; }();   // (measurement knob: 1 = always both kernels, 0 = never)
