@@ -514,7 +514,7 @@ def main():
             names = ["-", "stage", "parse", "overlap", "geometry", "gates", "columns", "umi", "descriptors"]
             print("phase share: " + "  ".join(f"{names[i]}={100.0 * ph[i] / tot:.1f}%" for i in range(1, 9)), file=sys.stderr)
             ta = float(sum(ph[1:16])) or 1.0
-            print("phase cycles, share of all 15 slots (k_split_cols: 9..13 = packed pass rows | finalize | list | items | stores): " + " ".join(f"{i}:{100.0 * ph[i] / ta:.1f}" for i in range(1, 16)), file=sys.stderr)
+            print("phase cycles, share of all 15 slots (k_split_cols: 9..13 = packed pass rows | finalize | list | stores | items): " + " ".join(f"{i}:{100.0 * ph[i] / ta:.1f}" for i in range(1, 16)), file=sys.stderr)
             bn = ["raw->lds", "parse", "unpack", "overlap", "geometry", "gates", "columns(to umi)"]
             tb = float(sum(ph[9:16])) or 1.0
             print("k_family (workgroup) share: " + "  ".join(f"{bn[i - 9]}={100.0 * ph[i] / tb:.1f}%" for i in range(9, 16)), file=sys.stderr)
