@@ -50,7 +50,7 @@ __global__ __launch_bounds__(INFL_LANES) void k_bgzf_inflate(const uint8_t* __re
 //                    come in with 16-byte loads, the entries are played 64 at a time — a lane per match, a byte loop in LDS, in rounds
 //                    ordered by the frontier rule (inflate_resolve_wave_emulated in inflate_core.h is this schedule on the host) — and the
 //                    block leaves with 16-byte stores.  A match's round trip is an LDS access.  k_bgzf_crc checks the result as before.
-constexpr uint32_t INFL_ENT_STRIDE = (INFL_ENTRY_CAP + 15u) & ~15u;      // entries per block slot
+static_assert(INFL_ENTRY_CAP >= 65536 / 3 + 65536 / 255 + 2, "infl_entry_cap (engine.h) is the per-ISIZE form of INFL_ENTRY_CAP");
 
 // The tokenizer's bit reader: a WINDOW of the payload in LDS (INFL_WIN bytes per lane, filled with 16-byte loads), refills out of it.  The
 // one-phase kernel's reader loads 8 bytes from global memory per refill — every ~5 symbols — and on this part a load's s_waitcnt also
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(LANES) void k_bgzf_tokenize(const uint8_t* __restri
   InflateSlow& W = sW[threadIdx.x];
   const int st = inflate_block_x<LdsPtr, true, LdsBitReader, LdsPtr>(raw + B.in_off, B.in_len, out + B.out_off, B.isize, (LdsPtr)sF[threadIdx.x].lit, (LdsPtr)sF[threadIdx.x].dist,
                                                                      (LdsPtr)W.lit_count, (LdsPtr)W.dist_count, (LdsPtr)W.lit_sym, (LdsPtr)W.dist_sym, (void*)&sWin[threadIdx.x][0],
-                                                                     ent + (size_t)b * INFL_ENT_STRIDE, INFL_ENTRY_CAP, &ne);
+                                                                     ent + B.ent_off, infl_entry_cap(B.isize), &ne);
   if (st != INFL_OK) { atomicMax(status, ((b + 1u) << 4) | (uint32_t)st); ne = 0; }
   n_ent[b] = ne;
 }
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(64) void k_bgzf_resolve(const BgzfDevBlock* __restr
   __syncthreads();
   // 2. the entries, 64 at a time
   uint32_t run = 0;
-  const uint32_t* const E = ent + (size_t)b * INFL_ENT_STRIDE;
+  const uint32_t* const E = ent + B.ent_off;
   bool bad = false;
   for (uint32_t e0 = 0; e0 < ne; e0 += 64) {
     const uint32_t e = e0 + lane < ne ? E[e0 + lane] : 0u;
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(64) void k_bgzf_resolve_global(const BgzfDevBlock* 
   if (ne == 0) return;                                          // (the decoder has reported this block: its list is empty)
   uint8_t* const L = out + B.out_off;
   uint32_t run = 0;
-  const uint32_t* const E = ent + (size_t)b * INFL_ENT_STRIDE;
+  const uint32_t* const E = ent + B.ent_off;
   bool bad = false;
   for (uint32_t e0 = 0; e0 < ne; e0 += 64) {
     const uint32_t e = e0 + lane < ne ? E[e0 + lane] : 0u;
@@ -392,19 +392,20 @@ __global__ void k_bgzf_clear_status(uint32_t* status) { *status = 0u; }
 // inflates `n` blocks (descriptors in device memory) from d_raw into d_out and checks every block's CRC-32: the kernels and the
 // copy of the status word (into PINNED host memory, `h_status`) are queued on `s`; nothing waits.  After `s` has drained,
 // bgzf_inflate_status() turns the word into 0, or 1 with c->err naming the first failing block.
-size_t bgzf_inflate_scratch_bytes(uint32_t n_blocks) { return (size_t)n_blocks * ((size_t)INFL_ENT_STRIDE * 4u + 4u) + 64u; }
 bool bgzf_inflate_two_phase() { static const bool on = [] { const char* e = getenv("FGX_INFL_TWO_PHASE"); return !(e && e[0] == '0'); }(); return on; }
 
 void bgzf_inflate_launch(hipStream_t s, const uint8_t* d_raw, const BgzfDevBlock* d_blk, uint32_t n, uint8_t* d_out, uint32_t* d_status, uint32_t* h_status,
-                         void* d_scratch) {
+                         void* d_scratch, size_t scratch_bytes) {
   *h_status = 0;
   if (n == 0) return;
-  if (d_scratch && bgzf_inflate_two_phase()) {
-    // the two-phase form: entries [n x INFL_ENT_STRIDE] then the list lengths [n] in the caller's scratch (bgzf_inflate_scratch_bytes)
-    static bool attr_set = false;
-    if (!attr_set) { hip_check(hipFuncSetAttribute((const void*)k_bgzf_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 64), "hipFuncSetAttribute(k_bgzf_resolve)"); attr_set = true; }
+  if (d_scratch && scratch_bytes >= (size_t)n * 4u + 64u && bgzf_inflate_two_phase()) {
+    // the two-phase form: the blocks' entry lists back to back (BgzfDevBlock::ent_off, bgzf_inflate_plan), then the list lengths [n]
+    static const bool in_lds = [] { const char* e = getenv("FGX_INFL_RESOLVE_LDS"); return e && e[0] == '1'; }();      // (measurements: the LDS form of the resolve pass)
+    if (in_lds) {   // (the attribute belongs to a device: set per launch, only when this form is the one in use)
+      hip_check(hipFuncSetAttribute((const void*)k_bgzf_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 64), "hipFuncSetAttribute(k_bgzf_resolve)");
+    }
     uint32_t* const ent = (uint32_t*)d_scratch;
-    uint32_t* const n_ent = ent + (size_t)n * INFL_ENT_STRIDE;
+    uint32_t* const n_ent = (uint32_t*)((uint8_t*)d_scratch + ((scratch_bytes - 64u - (size_t)n * 4u) & ~(size_t)3));
     hipLaunchKernelGGL(k_bgzf_clear_status, dim3(1), dim3(1), 0, s, d_status);
     // blocks per tokenizer wavefront: the pass is as long as ONE block's chain of symbols whatever the chip has in flight (a 64 KiB block of BAM
     // records: ~13 000 symbols, ~1.1 us each for a wavefront that has its SIMD to itself), so every wavefront should have a SIMD to itself —
@@ -417,7 +418,6 @@ void bgzf_inflate_launch(hipStream_t s, const uint8_t* d_raw, const BgzfDevBlock
     else if (tl == 32) hipLaunchKernelGGL(k_bgzf_tokenize<32>, dim3((n + 31) / 32), dim3(32), 0, s, d_raw, d_blk, n, d_out, ent, n_ent, d_status);
     else if (tl == 64) hipLaunchKernelGGL(k_bgzf_tokenize<64>, dim3((n + 63) / 64), dim3(64), 0, s, d_raw, d_blk, n, d_out, ent, n_ent, d_status);
     else hipLaunchKernelGGL(k_bgzf_tokenize<16>, dim3((n + 15) / 16), dim3(16), 0, s, d_raw, d_blk, n, d_out, ent, n_ent, d_status);
-    static const bool in_lds = [] { const char* e = getenv("FGX_INFL_RESOLVE_LDS"); return e && e[0] == '1'; }();      // (measurements: the LDS form)
     if (in_lds) hipLaunchKernelGGL(k_bgzf_resolve, dim3(n), dim3(64), 65536 + 64, s, d_blk, n, d_out, (const uint32_t*)ent, (const uint32_t*)n_ent, d_status);
     else hipLaunchKernelGGL(k_bgzf_resolve_global, dim3(n), dim3(64), 0, s, d_blk, n, d_out, (const uint32_t*)ent, (const uint32_t*)n_ent, d_status);
     hipLaunchKernelGGL(k_bgzf_crc, dim3((n + 3) / 4), dim3(256), 0, s, (const uint8_t*)d_out, d_blk, n, d_status);

@@ -123,7 +123,9 @@ int fgx_inflate_block_two_phase_host(const uint8_t* in, uint32_t in_len, uint8_t
   static thread_local fgx::InflateTables T;
   static thread_local std::vector<uint32_t> ent(fgx::INFL_ENTRY_CAP);
   uint32_t ne = 0;
-  const int st = fgx::inflate_block_t<uint16_t*, true>(in, in_len, out, out_len, T.f.lit, T.f.dist, T.w, ent.data(), (uint32_t)ent.size(), &ne);
+  // (the list gets what the device gives it: the per-ISIZE bound of infl_entry_cap, engine.h — the CPU tests therefore exercise that bound)
+  const uint32_t cap = fgx::infl_entry_cap(out_len) < (uint32_t)ent.size() ? fgx::infl_entry_cap(out_len) : (uint32_t)ent.size();
+  const int st = fgx::inflate_block_t<uint16_t*, true>(in, in_len, out, out_len, T.f.lit, T.f.dist, T.w, ent.data(), cap, &ne);
   if (n_entries) *n_entries = ne;
   if (rounds) *rounds = 0;
   if (st != fgx::INFL_OK) return st;

@@ -8,6 +8,7 @@
 #include "../../include/fgumi_amd.h"
 #include "consensus_math.h"
 #include "methylation_core.h"
+#include "inflate_core.h"
 #include <memory>
 
 namespace fgx {
@@ -205,12 +206,19 @@ int group_records_device(fgx_caller* c, const fgx_group_options* o, const uint8_
 int record_boundaries_device(fgx_caller* c, const uint8_t* d_stream, uint64_t len, uint64_t start, uint64_t* d_rec_off, uint32_t* d_rec_len,
                              uint64_t cap, uint64_t* n_rec, uint64_t* consumed);
 // bgzf_device.hip — BGZF inflate on the device: one descriptor per block (offsets into the compressed bytes / the inflated stream)
-struct BgzfDevBlock { uint64_t in_off, out_off; uint32_t in_len, isize, crc, _pad; };   // in_off / in_len: the raw DEFLATE payload
-// `d_scratch` (bgzf_inflate_scratch_bytes(n) bytes of device memory, or null): the entry lists of the two-phase form (k_bgzf_tokenize + k_bgzf_resolve,
-// the default with a scratch; FGX_INFL_TWO_PHASE=0 or no scratch: the one-phase kernel of rounds 2 - 4)
+struct BgzfDevBlock { uint64_t in_off, out_off; uint32_t in_len, isize, crc, ent_off; };   // in_off / in_len: the raw DEFLATE payload; ent_off: bgzf_inflate_plan
+// Lays the blocks' entry lists out back to back, each sized by ITS ISIZE (round 6; round 5 gave every block the 64 KiB worst case — 90 KB
+// of scratch per block whatever its size, tens of GB for a file of small blocks): fills ent_off and returns the bytes of scratch the
+// two-phase form needs (entries, then one 32-bit list length per block), or 0 when the lists do not fit 32-bit offsets (one-phase form).
+inline size_t bgzf_inflate_plan(BgzfDevBlock* blk, uint32_t n) {
+  uint64_t total = 0;
+  for (uint32_t i = 0; i < n; i++) { blk[i].ent_off = (uint32_t)total; total += infl_entry_cap(blk[i].isize); if (total > 0xFFFF0000ull) return 0; }
+  return (size_t)total * 4u + (size_t)n * 4u + 64u;
+}
+// `d_scratch` (bgzf_inflate_plan's bytes of device memory, or null): the entry lists of the two-phase form (k_bgzf_tokenize + k_bgzf_resolve,
+// the default with a scratch; FGX_INFL_TWO_PHASE=0 or no scratch: the one-phase kernel of rounds 2 - 4).  `scratch_bytes`: what the plan returned.
 void bgzf_inflate_launch(hipStream_t s, const uint8_t* d_raw, const BgzfDevBlock* d_blk, uint32_t n, uint8_t* d_out, uint32_t* d_status, uint32_t* h_status_pinned,
-                         void* d_scratch = nullptr);
-size_t bgzf_inflate_scratch_bytes(uint32_t n_blocks);
+                         void* d_scratch = nullptr, size_t scratch_bytes = 0);
 bool bgzf_inflate_two_phase();
 int bgzf_inflate_status(fgx_caller* c, uint32_t status_word);
 void bgzf_crc_blocks_device(fgx_caller* c, const uint8_t* d_in, uint64_t len, uint32_t* d_crcs);

@@ -87,7 +87,7 @@ int fgx_bgzf_inflate_device_bench(fgx_caller* c, const uint8_t* raw, uint64_t ra
       fgx::BgzfDevBlock d;
       d.in_off = b.in_off + 12 + xlen; d.out_off = b.out_off; d.in_len = b.in_size - 12 - xlen - 8; d.isize = b.isize;
       memcpy(&d.crc, raw + b.in_off + b.in_size - 8, 4);
-      d._pad = 0;
+      d.ent_off = 0;
       dev[i] = d;
     }
     // everything this entry allocates is released on every way out (a hip_check that throws included)
@@ -104,7 +104,8 @@ int fgx_bgzf_inflate_device_bench(fgx_caller* c, const uint8_t* raw, uint64_t ra
     } R;
     fgx::DevBuf &d_raw = R.d_raw, &d_blk = R.d_blk, &d_out = R.d_out;
     d_raw.reserve(used + 64); d_blk.reserve(dev.size() * sizeof(fgx::BgzfDevBlock) + 64); d_out.reserve(infl + 256);
-    if (fgx::bgzf_inflate_two_phase()) R.d_ent.reserve(fgx::bgzf_inflate_scratch_bytes((uint32_t)dev.size()));
+    size_t ent_bytes = fgx::bgzf_inflate_two_phase() ? fgx::bgzf_inflate_plan(dev.data(), (uint32_t)dev.size()) : 0;
+    if (ent_bytes) { try { R.d_ent.reserve(ent_bytes); } catch (const std::exception&) { R.d_ent.free_(); ent_bytes = 0; (void)hipGetLastError(); } }   // (no room for the lists: the one-phase kernel)
     fgx::hip_check(hipHostMalloc((void**)&R.h_status, 64, hipHostMallocDefault), "hipHostMalloc");
     uint32_t* const h_status = R.h_status;
     hipStream_t s = c->stream;
@@ -116,12 +117,12 @@ int fgx_bgzf_inflate_device_bench(fgx_caller* c, const uint8_t* raw, uint64_t ra
     fgx::hip_check(hipEventCreate(&R.e0), "event"); fgx::hip_check(hipEventCreate(&R.e1), "event");
     const hipEvent_t e0 = R.e0, e1 = R.e1;
     int rc = 0;
-    fgx::bgzf_inflate_launch(s, d_raw.as<uint8_t>(), d_blk.as<fgx::BgzfDevBlock>(), (uint32_t)dev.size(), d_out.as<uint8_t>(), d_status, h_status, R.d_ent.p);   // warm-up
+    fgx::bgzf_inflate_launch(s, d_raw.as<uint8_t>(), d_blk.as<fgx::BgzfDevBlock>(), (uint32_t)dev.size(), d_out.as<uint8_t>(), d_status, h_status, ent_bytes ? R.d_ent.p : nullptr, ent_bytes);   // warm-up
     fgx::hip_check(hipStreamSynchronize(s), "sync");
     if (fgx::bgzf_inflate_status(c, *h_status) != 0) rc = 1;
     fgx::hip_check(hipEventRecord(e0, s), "event");
     for (uint32_t r = 0; r < (reps ? reps : 1u) && rc == 0; r++)
-      fgx::bgzf_inflate_launch(s, d_raw.as<uint8_t>(), d_blk.as<fgx::BgzfDevBlock>(), (uint32_t)dev.size(), d_out.as<uint8_t>(), d_status, h_status, R.d_ent.p);
+      fgx::bgzf_inflate_launch(s, d_raw.as<uint8_t>(), d_blk.as<fgx::BgzfDevBlock>(), (uint32_t)dev.size(), d_out.as<uint8_t>(), d_status, h_status, ent_bytes ? R.d_ent.p : nullptr, ent_bytes);
     fgx::hip_check(hipEventRecord(e1, s), "event");
     fgx::hip_check(hipStreamSynchronize(s), "sync");
     if (rc == 0 && fgx::bgzf_inflate_status(c, *h_status) != 0) rc = 1;
@@ -215,11 +216,13 @@ int fgx_run_bam_rejects(fgx_caller* c, const char* in_path, const char* out_path
         d_raw.reserve(ch.raw_len + 64);
         d_blk.reserve(blk_bytes + 64 + 16);
         fgx::hip_check(hipMemcpyAsync(d_raw.p, ch.inf.p, ch.raw_len + 64, hipMemcpyHostToDevice, si), "H2D compressed chunk");
+        // the entry lists of the two-phase inflate: sized block by block from ISIZE; without room for them (or beyond 32-bit offsets) the one-phase kernel
+        size_t ent_bytes = fgx::bgzf_inflate_two_phase() ? fgx::bgzf_inflate_plan(ch.dev_blocks.data(), (uint32_t)ch.dev_blocks.size()) : 0;
+        if (ent_bytes) { try { S->d_ent.reserve(ent_bytes); } catch (const std::exception&) { S->d_ent.free_(); ent_bytes = 0; (void)hipGetLastError(); } }
         if (blk_bytes) fgx::hip_check(hipMemcpyAsync(d_blk.p, ch.dev_blocks.data(), blk_bytes, hipMemcpyHostToDevice, si), "H2D block table");
         fgx::hip_check(hipEventRecord(S->ev_up1, si), "hipEventRecord");
-        if (fgx::bgzf_inflate_two_phase()) S->d_ent.reserve(fgx::bgzf_inflate_scratch_bytes((uint32_t)ch.dev_blocks.size()));
         fgx::bgzf_inflate_launch(si, d_raw.as<uint8_t>(), d_blk.as<fgx::BgzfDevBlock>(), (uint32_t)ch.dev_blocks.size(), dst,
-                                 (uint32_t*)((uint8_t*)d_blk.p + ((blk_bytes + 15) & ~(size_t)15)), S->h_status, S->d_ent.p);
+                                 (uint32_t*)((uint8_t*)d_blk.p + ((blk_bytes + 15) & ~(size_t)15)), S->h_status, ent_bytes ? S->d_ent.p : nullptr, ent_bytes);
       } else {
         *S->h_status = 0;
         if (ch.inf_len) fgx::hip_check(hipMemcpyAsync(dst, ch.inf.p, ch.inf_len, hipMemcpyHostToDevice, si), "H2D chunk");

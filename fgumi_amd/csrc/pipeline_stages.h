@@ -337,7 +337,7 @@ struct PipelineT {
               fgx::BgzfDevBlock d;
               d.in_off = b.in_off + 12 + xlen; d.out_off = b.out_off; d.in_len = b.in_size - 12 - xlen - 8; d.isize = b.isize;
               memcpy(&d.crc, c.raw + b.in_off + b.in_size - 8, 4);
-              d._pad = 0;
+              d.ent_off = 0;                                     // (bgzf_inflate_plan fills it when the chunk is launched)
               c.dev_blocks[i] = d;
             }
             c.header_size = 0;

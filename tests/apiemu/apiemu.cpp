@@ -249,9 +249,8 @@ static inline void emu_before_op(hipStream_t s) { if (emu::async_on() && s) emu:
 #include <zlib.h>
 namespace fgx {
 static void inflate_blocks(const uint8_t* d_raw, const BgzfDevBlock* d_blk, uint32_t n, uint8_t* d_out, uint32_t* d_status, uint32_t* h_status);
-size_t bgzf_inflate_scratch_bytes(uint32_t) { return 64; }
 bool bgzf_inflate_two_phase() { return false; }
-void bgzf_inflate_launch(hipStream_t s, const uint8_t* d_raw, const BgzfDevBlock* d_blk, uint32_t n, uint8_t* d_out, uint32_t* d_status, uint32_t* h_status, void*) {
+void bgzf_inflate_launch(hipStream_t s, const uint8_t* d_raw, const BgzfDevBlock* d_blk, uint32_t n, uint8_t* d_out, uint32_t* d_status, uint32_t* h_status, void*, size_t) {
   if (emu::async_on() && s) {      // (as the real launch: the host's status word is cleared now, everything else is queued on the stream)
     *h_status = 0;
     emu::enqueue(emu::of(s), [=] { inflate_blocks(d_raw, d_blk, n, d_out, d_status, h_status); });
