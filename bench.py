@@ -16,7 +16,9 @@ N>1 (families are independent → no collective on the data path):
                     SO:unsorted in input order, so rank order IS file order).  `root` also times a second loop in which
                     every step ships the payloads to rank 0 in rank order over RCCL point-to-point — the north star's
                     single-writer reassembly — and reports it beside (`value_with_reassembly_on_root`): one root receiving
-                    9 GB per rank and step is bound by its xGMI links, not by the kernels.  `auto` (default) = none.
+                    9 GB per rank and step is bound by its xGMI links, not by the kernels.  `auto` (default) = root beyond one rank.
+                    The gather loops run LAST, after everything else of the line has been measured, under a watchdog: a rank that
+                    fails or hangs in the gather costs `reassemble_error`, never the line.
 """
 import argparse
 import glob
@@ -284,6 +286,8 @@ def main():
     ap.add_argument("--end-to-end-families", type=int, default=1000000, help="N=1, simplex: families of the file -> file leg (`end_to_end` in the line); 0 skips it")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-strong-block", action="store_true", help="weak runs also time the strong-scaling reading (`strong_scaling` in the line); this skips it")
+    ap.add_argument("--no-share-block", action="store_true", help="N=1: skip the `share_of_8` block (one rank's share of an 8-way strong-scaling run, timed on this GPU)")
+    ap.add_argument("--gather-timeout", type=float, default=240.0, help="N>1: seconds the gather loops (run last) may take before the line is printed without them")
     ap.add_argument("--reassemble", choices=["auto", "none", "root"], default="auto",
                     help="root: a second timed loop also gathers the shard payloads to rank 0 in rank (= input) order over RCCL, reported beside `value`; "
                          "auto = none")
@@ -301,10 +305,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # (test hook, tests/test_gpu_distributed.py: FGX_BENCH_TEST_BACKEND=gloo runs the ranks of a multi-rank invocation on ONE GPU — RCCL refuses two
+    # ranks on a device — with the collectives on host tensors; the driver never sets it)
+    test_backend = os.environ.get("FGX_BENCH_TEST_BACKEND")
+    if test_backend:
+        local_rank = 0
+    coll_dev = "cpu" if test_backend else "cuda"
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
+        dist.init_process_group(test_backend or "nccl")
     # `auto`: with more than one rank the single-writer gather (sizes all_gather + one batch_isend_irecv group into rank 0) is timed in
     # a SECOND loop and reported beside `value` (value_with_reassembly_on_root / gather_GBs_into_root), never instead of it; a failure of that
     # loop is reported in `reassemble_error` and costs nothing else of the line.  One rank: nothing to gather.
@@ -328,9 +338,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(scaling, steps, warmup, with_gather):
+    def workload(scaling):
         """One workload (weak: `families` per GPU; strong: `families` in total, cut into contiguous shards of equal record bytes),
-        generated straight into HBM, `warmup` untimed + `steps` timed passes (barrier + synchronize on both sides, MAX over ranks)."""
+        generated straight into HBM."""
         if scaling == "strong" and world > 1:
             # one stream of `families` molecules, cut where the running record bytes reach k/world of the total
             w = simulated_family_bytes(args.families, family_size=args.depth, read_length=args.read_length, duplex=int(duplex), **sim_extra)
@@ -343,49 +353,106 @@ def main():
         dg = caller.simulate_on_device(fam, family_size=args.depth, read_length=args.read_length, first_family=lo, duplex=int(duplex), **sim_extra)
         if shard_bytes is None:
             shard_bytes = int(dg.blob_len)
+        return dg, fam, shard_bytes
 
-        def timed_loop(n_steps, gather):
-            k_family_ms = k_emit_ms = k_total_ms = 0.0
-            gathered = 0
-            out = None
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(n_steps):
-                out = caller.process_batch_device(dg)
-                k_family_ms += caller.last_timing["k_family"]
-                k_emit_ms += caller.last_timing["k_emit"]
-                k_total_ms += caller.last_timing["kernels"]
-                if gather:
-                    whole = gather_payload_to_root(out.as_tensor(local_rank), root=0)
-                    if whole is not None:
-                        gathered = int(whole.numel())
-                    del whole
-            barrier()
-            dt = max_over_ranks(time.perf_counter() - t0, "cuda")                            # MAX over ranks
-            return dt, out, k_family_ms, k_emit_ms, k_total_ms, gathered
+    def timed_loop(dg, n_steps, gather):
+        k_family_ms = k_emit_ms = k_total_ms = 0.0
+        gathered = 0
+        out = None
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            out = caller.process_batch_device(dg)
+            k_family_ms += caller.last_timing["k_family"]
+            k_emit_ms += caller.last_timing["k_emit"]
+            k_total_ms += caller.last_timing["kernels"]
+            if gather:
+                if os.environ.get("FGX_BENCH_TEST_GATHER_FAIL") == str(rank):      # (test hook: one rank fails inside the gather loop)
+                    raise RuntimeError("FGX_BENCH_TEST_GATHER_FAIL")
+                payload = out.as_tensor(local_rank)
+                whole = gather_payload_to_root(payload.cpu() if test_backend else payload, root=0)
+                if whole is not None:
+                    gathered = int(whole.numel())
+                del whole
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0, coll_dev)                            # MAX over ranks
+        return dt, out, k_family_ms, k_emit_ms, k_total_ms, gathered
 
+    def measure(scaling, steps, warmup):
+        """`warmup` untimed + `steps` timed passes over one workload (barrier + synchronize on both sides, MAX over ranks)."""
+        dg, fam, shard_bytes = workload(scaling)
         out = None
         for _ in range(warmup):
             out = caller.process_batch_device(dg)
-        dt, out, k_family_ms, k_emit_ms, k_total_ms, _ = timed_loop(steps, False)           # the K timed steps: `value`
-        dt_gather, gathered_bytes, gather_error = None, 0, None
-        if with_gather:                                                                      # the same K steps with the gather to rank 0
-            try:
-                r = timed_loop(steps, True)
-                dt_gather, gathered_bytes = r[0], r[5]
-            except Exception as ex:                                                          # (the compute line stands on its own)
-                gather_error = str(ex)[:300]
+        dt, out, k_family_ms, k_emit_ms, k_total_ms, _ = timed_loop(dg, steps, False)       # the K timed steps: `value`
         per_rank = gather_sizes([out.data_len, out.count, dg.n_rec, out.n_deferred, fam, shard_bytes,
-                                 int(round(k_family_ms / steps * 1e3)), int(round(k_emit_ms / steps * 1e3))], "cuda")   # rank (= input) order
+                                 int(round(k_family_ms / steps * 1e3)), int(round(k_emit_ms / steps * 1e3))], coll_dev)   # rank (= input) order
         # the batch counters (ConsensusCallingStats / RejectionReason order, then the overlap CorrectionStats) summed over the ranks
-        counters = sum_over_ranks(caller.last_stats_array, "cuda")
+        counters = sum_over_ranks(caller.last_stats_array, coll_dev)
         res = dict(dt=dt, out_count=int(out.count), n_rec=int(dg.n_rec), fam=fam, k_family_ms=k_family_ms, k_emit_ms=k_emit_ms, k_total_ms=k_total_ms,
-                   dt_gather=dt_gather, gathered_bytes=gathered_bytes, gather_error=gather_error, per_rank=per_rank, counters=counters, full_columns=caller.last_timing.get("full_columns"))
+                   dt_gather=None, gathered_bytes=0, gather_error=None, per_rank=per_rank, counters=counters, full_columns=caller.last_timing.get("full_columns"),
+                   chain=last_chain())
         del dg, out
         torch.cuda.empty_cache()
         return res
 
-    M = measure(args.scaling, args.steps, args.warmup, reassemble == "root")
+    def last_chain():
+        """Kernel launches / host synchronisations of the last batch's launch chain (fgx_debug_last_chain; None on a library without it)."""
+        import ctypes
+        from fgumi_amd import lib
+        if not hasattr(lib, "fgx_debug_last_chain"):
+            return None
+        lib.fgx_debug_last_chain.restype = None
+        lib.fgx_debug_last_chain.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
+        o = (ctypes.c_uint32 * 2)()
+        lib.fgx_debug_last_chain(caller._h, o)
+        return {"kernel_launches": int(o[0]), "host_syncs": int(o[1])}
+
+    def share_of_8():
+        """Strong-scaling readiness without an 8-GPU node: the SAME launch chain on what one rank of eight would get —
+        configs[1] / 8 (625 000 depth-8 families) and the first of eight byte-balanced shards of the 5 M long-tail stream (configs[3] shape / 8) —
+        with ms_per_step, kernel launches and host synchronisations per step, and the speedup eight such ranks would show over the whole
+        stream on one GPU (`speedup_if_8` = ms of the whole stream / ms of the share).  N=1 only."""
+        import numpy as np
+        res = {}
+
+        def run(fam, first, steps, **kw):
+            dg = caller.simulate_on_device(fam, read_length=args.read_length, first_family=first, **kw)
+            for _ in range(2):
+                caller.process_batch_device(dg)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = None
+            for _ in range(steps):
+                out = caller.process_batch_device(dg)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            r = dict(families=int(fam), raw_reads=int(dg.n_rec), ms_per_step=ms, value=dg.n_rec / ms * 1e3, deferred_families=int(out.n_deferred), **(last_chain() or {}))
+            del dg, out
+            torch.cuda.empty_cache()
+            return r
+        whole_ms = dt / args.steps * 1e3
+        a = run(args.families // 8, 0, 20, family_size=args.depth)
+        a["whole_stream_ms"] = whole_ms
+        a["speedup_if_8"] = whole_ms / a["ms_per_step"]
+        res["configs1_share"] = a
+        # the long tail: the whole 5 M-family stream on this GPU, then rank 0's shard of its byte-balanced cut into eight
+        lt = dict(family_size=2, family_size_max=50)
+        w = simulated_family_bytes(args.families, read_length=args.read_length, **lt)
+        lo, hi = balanced_shards(w, 8)[0]
+        whole = run(args.families, 0, 3, **lt)
+        b = run(hi - lo, lo, 10, **lt)
+        b["whole_stream_ms"] = whole["ms_per_step"]
+        b["whole_stream_value"] = whole["value"]
+        b["whole_stream_chain"] = {k: whole.get(k) for k in ("kernel_launches", "host_syncs")}
+        b["speedup_if_8"] = whole["ms_per_step"] / b["ms_per_step"]
+        b["shard_bytes_share"] = float(np.asarray(w[lo:hi], dtype=np.float64).sum() / np.asarray(w, dtype=np.float64).sum())
+        res["long_tail_share"] = b
+        res["note"] = ("one rank's share of an 8-way strong-scaling run, measured on ONE GPU: ranks are independent (no data-path collective), so eight of them "
+                       "finish in the time of the slowest share; what does not shrink with the batch — launches, host synchronisations, the tail of every kernel — shows here")
+        return res
+
+    M = measure(args.scaling, args.steps, args.warmup)
     dt, k_family_ms, k_emit_ms, k_total_ms = M["dt"], M["k_family_ms"], M["k_emit_ms"], M["k_total_ms"]
     dt_gather, gathered_bytes, per_rank, counters, fam = M["dt_gather"], M["gathered_bytes"], M["per_rank"], M["counters"], M["fam"]
     total_bytes, total_cons, total_raw, total_def = [int(v) for v in per_rank[:, :4].sum(0).tolist()]
@@ -394,7 +461,7 @@ def main():
     # (`families` per GPU), so its step time is this run's own N=1 reference: speedup_vs_n1 = weak ms_per_step / strong ms_per_step.
     S = None
     if args.scaling == "weak" and not args.no_strong_block:
-        S = measure("strong", max(1, min(args.steps, 10)), 1, reassemble == "root" and world > 1)
+        S = measure("strong", max(1, min(args.steps, 10)), 1)
 
     if rank == 0:
         L = args.read_length
@@ -465,6 +532,7 @@ def main():
                          # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the chip's 1024 SIMDs at 2.4 GHz (committed PMC file / this run's time)
                          "valu_busy_frac": (min(1.0, pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / 2.4e9 / k_avg_s)
                                             if (pmc and "SQ_ACTIVE_INST_VALU" in pmc and k_avg_s > 0) else None),
+                         "valu_busy_frac_assumes": "4 cycles per vector wave-instruction (SQ_ACTIVE_INST_VALU counts quad-cycles); the measured mix of this kernel (tools/ubench/valu_rate.hip) is ~3 (adds) .. ~4.4 (shifts, bfe, compares, f64) cycles, the guide gives 2 for v_fma_f32: read as an estimate",
                          "pmc_kernel": pmc["kernel"] if pmc else None, "pmc_source": pmc_file},
         }
         if S is not None:
@@ -503,7 +571,57 @@ def main():
                     line["end_to_end"]["vs_cpu_end_to_end_if_its_stages_overlapped"] = line["end_to_end"]["value"] / ce["value_if_stages_overlapped"]
                 except Exception as ex:
                     line["cpu_baseline"]["end_to_end"] = {"error": str(ex)[:300]}
-        print(json.dumps(line))
+        if world == 1 and plain and not args.no_share_block and not args.no_cpu_baseline and args.families >= 8:     # (profiling runs — --no-cpu-baseline — time the headline workload alone)
+            try:
+                line["share_of_8"] = share_of_8()
+            except Exception as ex:
+                line["share_of_8"] = {"error": str(ex)[:300]}
+    # ---- the gather to rank 0 (single-writer reassembly), LAST and under a watchdog: every other number of the line is final by now.  A rank that
+    #      throws in the gather leaves the others blocked inside RCCL, where no exception reaches them — so each rank arms a timer: rank 0's prints the
+    #      line as it stands (reassemble_error = the reason) and every rank's ends its process with exit code 0.
+    if reassemble == "root" and world > 1:
+        import threading
+        state = {"line": line if rank == 0 else None, "done": False}
+
+        def bail(reason):
+            if state["done"]:
+                return
+            state["done"] = True
+            if rank == 0:
+                state["line"]["config"]["reassemble_error"] = reason
+                print(json.dumps(state["line"]), flush=True)
+            os._exit(0)
+        timer = threading.Timer(args.gather_timeout, bail, args=(f"the gather loops did not finish within {args.gather_timeout} s (a rank failed or hung); every other field of the line was measured before them",))
+        timer.daemon = True
+        timer.start()
+        try:
+            dg, _fam, _sb = workload(args.scaling)
+            caller.process_batch_device(dg)
+            r = timed_loop(dg, args.steps, True)
+            del dg
+            torch.cuda.empty_cache()
+            rs = None
+            if S is not None:
+                dg, _fam, _sb = workload("strong")
+                caller.process_batch_device(dg)
+                rs = timed_loop(dg, max(1, min(args.steps, 10)), True)
+                del dg
+        except Exception as ex:
+            bail("gather failed on rank %d: %s" % (rank, str(ex)[:300]))
+        timer.cancel()
+        state["done"] = True
+        if rank == 0:
+            dt_gather, gathered_bytes = r[0], r[5]
+            cfg = line["config"]
+            cfg["reassembled_bytes_on_rank0"] = gathered_bytes
+            cfg["value_with_reassembly_on_root"] = total_raw * args.steps / dt_gather
+            cfg["ms_per_step_with_reassembly_on_root"] = dt_gather / args.steps * 1e3
+            cfg["gather_GBs_into_root"] = ((gathered_bytes - int(per_rank[0, 0])) * args.steps / max(dt_gather - dt, 1e-9) / 1e9) if dt_gather > dt else None
+            if rs is not None and "strong_scaling" in line:
+                s_steps = max(1, min(args.steps, 10))
+                line["strong_scaling"]["value_with_reassembly_on_root"] = int(S["per_rank"][:, 2].sum()) * s_steps / rs[0]
+    if rank == 0:
+        print(json.dumps(line), flush=True)
     if rank == 0:   # profiling builds (-DFGX_PHASE_TIMING=1) expose per-phase cycle totals of the family kernels
         import ctypes
         from fgumi_amd import lib

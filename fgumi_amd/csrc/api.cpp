@@ -1248,6 +1248,16 @@ uint32_t fgx_debug_last_split_chunks(const fgx_caller* c) { return (c && c->fast
 uint32_t fgx_debug_last_big_families(const fgx_caller* c) { return (c && c->fast) ? c->fast->fp.last_big_families : 0u; }
 uint32_t fgx_debug_last_meth_device(const fgx_caller* c) { return (c && c->fast) ? c->fast->fp.last_meth_device : 0u; }
 uint32_t fgx_debug_last_deep_families(const fgx_caller* c) { return (c && c->fast) ? c->fast->fp.last_deep_families : 0u; }
+// the split pipeline's first stage in the last device batch: out4[0] families finished by k_split_cols's packed build, [1] by its classic builds
+// (k_split_finish counts both), [2] the build launched first (0 classic alone / no split pipeline, 1 packed alone, 2 packed + partner launch),
+// [3] families the first stage handed to the next launch
+void fgx_debug_last_split_builds(const fgx_caller* c, uint64_t* out4) {
+  if (!out4) return;
+  out4[0] = out4[1] = out4[2] = out4[3] = 0;
+  if (c && c->fast) { const FastPath& f = c->fast->fp; out4[0] = f.last_packed_families; out4[1] = f.last_classic_families; out4[2] = f.last_split_build; out4[3] = f.last_first_stage_retries; }
+}
+// the launch chain of the last device batch: out2[0] kernel launches of FastPath::run_once (the scans of the library not counted), out2[1] host synchronisations in it
+void fgx_debug_last_chain(const fgx_caller* c, uint32_t* out2) { if (out2) { out2[0] = (c && c->fast) ? c->fast->fp.last_launches : 0u; out2[1] = (c && c->fast) ? c->fast->fp.last_host_syncs : 0u; } }
 uint32_t fgx_debug_last_routed(const fgx_caller* c) { return (c && c->fast) ? c->fast->fp.last_routed : 0u; }
 int fgx_debug_last_direct(const fgx_caller* c) { return (c && c->fast) ? c->fast->fp.last_direct : 0; }
 // 1: route everything through the general host path (parity tests of that path); 0: hybrid (default)

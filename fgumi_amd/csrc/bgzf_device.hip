@@ -400,7 +400,7 @@ void bgzf_inflate_launch(hipStream_t s, const uint8_t* d_raw, const BgzfDevBlock
   if (n == 0) return;
   if (d_scratch && scratch_bytes >= (size_t)n * 4u + 64u && bgzf_inflate_two_phase()) {
     // the two-phase form: the blocks' entry lists back to back (BgzfDevBlock::ent_off, bgzf_inflate_plan), then the list lengths [n]
-    static const bool in_lds = [] { const char* e = getenv("FGX_INFL_RESOLVE_LDS"); return e && e[0] == '1'; }();      // (measurements: the LDS form of the resolve pass)
+    static const bool in_lds = [] { const char* e = fgx_knob("FGX_INFL_RESOLVE_LDS"); return e && e[0] == '1'; }();      // (measurements: the LDS form of the resolve pass)
     if (in_lds) {   // (the attribute belongs to a device: set per launch, only when this form is the one in use)
       hip_check(hipFuncSetAttribute((const void*)k_bgzf_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 64), "hipFuncSetAttribute(k_bgzf_resolve)");
     }
@@ -410,7 +410,7 @@ void bgzf_inflate_launch(hipStream_t s, const uint8_t* d_raw, const BgzfDevBlock
     // blocks per tokenizer wavefront: the pass is as long as ONE block's chain of symbols whatever the chip has in flight (a 64 KiB block of BAM
     // records: ~13 000 symbols, ~1.1 us each for a wavefront that has its SIMD to itself), so every wavefront should have a SIMD to itself —
     // n / 1024 blocks per wavefront, rounded up to a power of two (measured on 11 738 blocks: 8 lanes 22.0 ms, 16 18.3 ms, 32 17.6 ms)
-    static const uint32_t tl_env = [] { const char* e = getenv("FGX_INFL_LANES"); const int v = e ? atoi(e) : 0; return (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) ? (uint32_t)v : 0u; }();
+    static const uint32_t tl_env = [] { const char* e = fgx_knob("FGX_INFL_LANES"); const int v = e ? atoi(e) : 0; return (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) ? (uint32_t)v : 0u; }();
     uint32_t tl = tl_env;
     if (!tl) { tl = 8; while (tl < 64u && (uint64_t)tl * 1024u < n) tl <<= 1; }
     if (tl == 4) hipLaunchKernelGGL(k_bgzf_tokenize<4>, dim3((n + 3) / 4), dim3(4), 0, s, d_raw, d_blk, n, d_out, ent, n_ent, d_status);
@@ -428,7 +428,7 @@ void bgzf_inflate_launch(hipStream_t s, const uint8_t* d_raw, const BgzfDevBlock
   // the status word is cleared by a KERNEL on the same stream: kernels of one stream run in order, where hipMemsetAsync has been seen to run out
   // of order with the kernels around it on this runtime (boundaries.hip) — a late clear would wipe an inflate or CRC error
   hipLaunchKernelGGL(k_bgzf_clear_status, dim3(1), dim3(1), 0, s, d_status);
-  static const uint32_t lanes = [] { const char* e = getenv("FGX_INFL_LANES"); const int v = e ? atoi(e) : 0; return (v == 4 || v == 16 || v == 32 || v == 64) ? (uint32_t)v : INFL_LANES; }();   // (a measuring knob: profiles/r03_experiments.md)
+  static const uint32_t lanes = [] { const char* e = fgx_knob("FGX_INFL_LANES"); const int v = e ? atoi(e) : 0; return (v == 4 || v == 16 || v == 32 || v == 64) ? (uint32_t)v : INFL_LANES; }();   // (a measuring knob: profiles/r03_experiments.md)
   if (lanes == 4) hipLaunchKernelGGL(k_bgzf_inflate<4>, dim3((n + 3) / 4), dim3(4), 0, s, d_raw, d_blk, n, d_out, d_status);
   else if (lanes == 16) hipLaunchKernelGGL(k_bgzf_inflate<16>, dim3((n + 15) / 16), dim3(16), 0, s, d_raw, d_blk, n, d_out, d_status);
   else if (lanes == 32) hipLaunchKernelGGL(k_bgzf_inflate<32>, dim3((n + 31) / 32), dim3(32), 0, s, d_raw, d_blk, n, d_out, d_status);

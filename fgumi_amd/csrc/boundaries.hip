@@ -181,7 +181,7 @@ int record_boundaries_device(fgx_caller* c, const uint8_t* d_stream, uint64_t le
   // thousands of rounds instead of one)
   hipLaunchKernelGGL(k_bound_guess, grid, block, 0, s, d_stream, len, start, n_seg, d_first, d_dirty);
   hipLaunchKernelGGL(k_bound_walk, grid, block, 0, s, d_stream, len, n_seg, d_first, d_dirty, 0, d_count, d_end, d_bad);
-  static const bool dbg = [] { const char* e = getenv("FGX_BOUND_DEBUG"); return e && e[0] == '1'; }();
+  static const bool dbg = [] { const char* e = fgx_knob("FGX_BOUND_DEBUG"); return e && e[0] == '1'; }();
   unsigned long long* d_dbg = d_ctr + 4;                       // 1 + 12 x 4 words (measurement aid: the first corrections of round 0)
   if (dbg) hip_check(hipMemsetAsync(d_dbg, 0, 8 * 64, s), "memset");
   uint32_t rounds = 0;

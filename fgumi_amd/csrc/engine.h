@@ -8,8 +8,17 @@
 #include "../../include/fgumi_amd.h"
 #include "consensus_math.h"
 #include "methylation_core.h"
-#include "inflate_core.h"
 #include <memory>
+
+// Measurement-only switches — launch shapes, pacing, wavefronts per workgroup, verbose / debug prints — exist only in PROFILING builds
+// (`python -m fgumi_amd.build --variant knobs -DFGX_KNOBS=1`, then FGX_LIB=fgumi_amd/variant_knobs.so): fgx_knob() is a constant nullptr in the
+// product library, which therefore reads none of them (23 of the 37 environment variables of round 5).  What users and
+// tests switch — the opt-outs of DESIGN §3 (FGX_SPLIT, FGX_DIRECT, FGX_S2_PACKED, FGX_SPLIT_CHUNKS, FGX_DEEP, FGX_METH_DEVICE, FGX_POOL_*,
+// the canonical passes, FGX_INFL_TWO_PHASE, ...) — stays with getenv.
+#ifndef FGX_KNOBS
+#define FGX_KNOBS 0
+#endif
+inline const char* fgx_knob(const char* name) { return FGX_KNOBS ? getenv(name) : nullptr; }
 
 namespace fgx {
 
@@ -207,12 +216,15 @@ int record_boundaries_device(fgx_caller* c, const uint8_t* d_stream, uint64_t le
                              uint64_t cap, uint64_t* n_rec, uint64_t* consumed);
 // bgzf_device.hip — BGZF inflate on the device: one descriptor per block (offsets into the compressed bytes / the inflated stream)
 struct BgzfDevBlock { uint64_t in_off, out_off; uint32_t in_len, isize, crc, ent_off; };   // in_off / in_len: the raw DEFLATE payload; ent_off: bgzf_inflate_plan
+// entries the tokenizer can write for a block of `isize` bytes (= inflate_core.h infl_entry_cap; restated here because the host-compiled test
+// builds that include this header do not take inflate_core.h's compiler builtins — bgzf_device.hip asserts that the two agree)
+constexpr uint32_t bgzf_entry_cap(uint32_t isize) { return (isize / 3u + isize / 255u + 2u + 15u) & ~15u; }
 // Lays the blocks' entry lists out back to back, each sized by ITS ISIZE (round 6; round 5 gave every block the 64 KiB worst case — 90 KB
 // of scratch per block whatever its size, tens of GB for a file of small blocks): fills ent_off and returns the bytes of scratch the
 // two-phase form needs (entries, then one 32-bit list length per block), or 0 when the lists do not fit 32-bit offsets (one-phase form).
 inline size_t bgzf_inflate_plan(BgzfDevBlock* blk, uint32_t n) {
   uint64_t total = 0;
-  for (uint32_t i = 0; i < n; i++) { blk[i].ent_off = (uint32_t)total; total += infl_entry_cap(blk[i].isize); if (total > 0xFFFF0000ull) return 0; }
+  for (uint32_t i = 0; i < n; i++) { blk[i].ent_off = (uint32_t)total; total += bgzf_entry_cap(blk[i].isize); if (total > 0xFFFF0000ull) return 0; }
   return (size_t)total * 4u + (size_t)n * 4u + 64u;
 }
 // `d_scratch` (bgzf_inflate_plan's bytes of device memory, or null): the entry lists of the two-phase form (k_bgzf_tokenize + k_bgzf_resolve,
@@ -233,7 +245,7 @@ int resubmit_deferred(fgx_caller* c, const uint8_t* d_blob, const uint64_t* d_re
 // cases then produced groups cut in two (stale bytes in front of a chunk's stream), every time; until that is understood the streams stay at
 // normal priority, where the whole GPU suite is green (profiles/r04_experiments.md).
 inline void create_compute_stream(hipStream_t* s) {
-  static const bool high = [] { const char* e = getenv("FGX_STREAM_PRIORITY"); return e && e[0] == '1'; }();
+  static const bool high = [] { const char* e = fgx_knob("FGX_STREAM_PRIORITY"); return e && e[0] == '1'; }();
   int least = 0, greatest = 0;
   if (high && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least) {
     hip_check(hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest), "hipStreamCreateWithPriority");

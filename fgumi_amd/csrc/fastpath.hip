@@ -62,6 +62,7 @@ constexpr uint32_t MAX_CIG_OPS = 6;     // clips + aligned ops of a read the WAV
 // every family that holds one through the general path (host orchestration, ~5 M reads/s); the wavefront kernels hand them on
 constexpr uint32_t WG_CIG_OPS = 16;
 constexpr int WG_MC_OPS = 17;
+constexpr uint32_t COL_BOUND_PAD = 48;   // columns on top of a family's column bound: the padding of the packed build's scratch layout (simplex_split.inc, round 6)
 constexpr int STAT_SLOTS = 1024;        // spread the per-batch counters over many addresses (atomic contention)
 
 struct ReadInfo {          // LDS, one per record of the family
@@ -313,12 +314,20 @@ struct AuxTags {
   uint32_t got, oddw;                          // keys found with a Z value ; <tag> / RX / <cell tag> values longer than 255 bytes
   uint32_t pk_mc, pk_mi, pk_rx, pk_cb;         // value offset in LDS | value length << 16
 };
-// cls: aux value type -> 1 / 2 / 4 (fixed size), 8 (Z), 16 (H), 32 (B), 0 (unknown)
-__device__ __forceinline__ void fill_tag_classes(uint8_t* cls) {
-  for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
-    const int fx = bam::tag_fixed_size((uint8_t)i);
-    cls[i] = (uint8_t)(fx ? fx : i == 'Z' ? 8 : i == 'H' ? 16 : i == 'B' ? 32 : 0);
+// cls: aux value type -> 1 / 2 / 4 (fixed size), 8 (Z), 16 (H), 32 (B), 0 (unknown).  The table lies in device memory, built at compile time
+// (round 6): a wavefront copies it with one load and one LDS store.  Until round 5 every workgroup COMPUTED its 256 entries (a switch per
+// entry: ~190 vector instructions per wavefront — a quarter of k_split_parse's instructions per family, whose wavefronts live for one round
+// of 64 records).
+struct TagClassTable {
+  uint8_t v[256];
+  constexpr TagClassTable() : v{} {
+    v['A'] = 1; v['c'] = 1; v['C'] = 1; v['s'] = 2; v['S'] = 2; v['i'] = 4; v['I'] = 4; v['f'] = 4; v['Z'] = 8; v['H'] = 16; v['B'] = 32;
   }
+};
+__device__ const TagClassTable g_tag_classes = TagClassTable();
+static_assert(TagClassTable().v['i'] == 4 && TagClassTable().v['Z'] == 8 && TagClassTable().v['x'] == 0, "tag classes");
+__device__ __forceinline__ void fill_tag_classes(uint8_t* cls /* 256 bytes of LDS, 4-byte aligned */) {
+  if (threadIdx.x < 64u) ((uint32_t*)cls)[threadIdx.x] = ((const uint32_t*)g_tag_classes.v)[threadIdx.x];
 }
 template <class ParamsT>
 __device__ __forceinline__ void aux_walk(const uint8_t* W, const uint8_t* cls_of, uint32_t a0, uint32_t an, const ParamsT& P, AuxTags& A) {
@@ -379,7 +388,7 @@ __global__ __launch_bounds__(NT) void k_family(FastParams P) {
   extern __shared__ __align__(16) uint8_t dyn[];
   __shared__ Shared S;
   __shared__ __align__(16) double sPairB[94][2];   // {correct[q], error_per_alt[q]}: one LDS read per observation instead of two global ones
-  __shared__ uint8_t sTagCls[256];                 // aux value type classes (aux_walk)
+  __shared__ __align__(16) uint8_t sTagCls[256];   // aux value type classes (aux_walk)
   const uint32_t tid = threadIdx.x;
   if (tid < 94) { sPairB[tid][0] = P.T->t.correct[tid]; sPairB[tid][1] = P.T->t.error_per_alt[tid]; }
   fill_tag_classes(sTagCls);
@@ -2872,6 +2881,173 @@ __device__ __forceinline__ void emit_store(const EmitParams& P, const EndDesc& D
   if (has_rx) { if (lane < 3 + rx_len + 1) q[lane] = lane == 0 ? 'R' : lane == 1 ? 'X' : lane == 2 ? 'Z' : j3 < rx_len ? R.rxb : (uint8_t)0; }
 #endif
 }
+
+// ---- round 6: BOTH records of a pair family at once — record R1 in lanes 0 - 31, record R2 in lanes 32 - 63 -----------------------------------
+// k_emit executed 450 vector + 357 scalar instructions per family for two records written one after the other (profiles/r05y_pmc_5M_families.json):
+// most of them for the small fields (a store per field, a lane per byte, a dozen of 64 lanes busy) and for wave-uniform address arithmetic that is
+// redone per record.  Here the two records share every instruction.  A lane takes EIGHT columns of its half's record — 8 B of codes -> 4 B of
+// packed bases, 8 B of qualities, 16 B each of cd / ce: 19 lanes of a half for 150 columns, the group of the last lane pulled back so that it ends
+// with the record (an overlapping store of the same values; its duplicate columns are masked out of the sums) —, the small fields are a lane per
+// byte of the half's record, and every address is ONE scalar base (record R1, the scratch columns of R1) + a 32-bit lane offset: R2 follows R1
+// in the output, and its columns follow R1's in the scratch.  cD / cM / cE: the four reductions stop at the half (five DPP steps).
+// Taken when both records are there, 8 <= Lc <= 256 and every string field fits 32 lanes; returns false (nothing touched) otherwise.
+#ifndef FGX_EMIT_PAIR
+#define FGX_EMIT_PAIR 1
+#endif
+typedef unsigned short em_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t em_pkmax(uint32_t a, uint32_t b) { em_u16x2 x, y; __builtin_memcpy(&x, &a, 4); __builtin_memcpy(&y, &b, 4); x = __builtin_elementwise_max(x, y); uint32_t r; __builtin_memcpy(&r, &x, 4); return r; }
+__device__ __forceinline__ uint32_t em_pkmin(uint32_t a, uint32_t b) { em_u16x2 x, y; __builtin_memcpy(&x, &a, 4); __builtin_memcpy(&y, &b, 4); x = __builtin_elementwise_min(x, y); uint32_t r; __builtin_memcpy(&r, &x, 4); return r; }
+__device__ __forceinline__ uint32_t em_sum2(uint32_t pair, uint32_t acc) { em_u16x2 x; const em_u16x2 one = {1, 1}; __builtin_memcpy(&x, &pair, 4); return __builtin_amdgcn_udot2(x, one, acc, false); }   // acc + both 16-bit halves
+// reductions over each HALF of the wavefront: the four row-local steps of FGX_WAVE_REDUCE, then row_bcast:15 into rows 1 and 3 — lane 31 holds the
+// result of lanes 0 - 31, lane 63 that of lanes 32 - 63
+#define FGX_HALF_REDUCE(v, idn, OP) do { \
+    v = OP(v, wave_dpp<0xB1, 0xF>(idn, v)); v = OP(v, wave_dpp<0x4E, 0xF>(idn, v)); v = OP(v, wave_dpp<0x141, 0xF>(idn, v)); v = OP(v, wave_dpp<0x140, 0xF>(idn, v)); \
+    v = OP(v, wave_dpp<0x142, 0xA>(idn, v)); } while (0)
+__device__ __forceinline__ bool emit_pair(const EmitParams& P, const EndDesc* D /* [3]: slots F, R1, R2 in LDS */, uint64_t oo1, uint64_t oo2, uint32_t lane) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const EndDesc& D1 = D[1];
+  const EndDesc& D2 = D[2];
+  const uint32_t Lc1 = uni(D1.cons_len), Lc2 = uni(D2.cons_len);
+  const uint32_t mi_len = uni(D1.mi_len), mi_off = uni(D1.mi_off);
+  const uint64_t first_off = uniform_u64(D1.first_off);
+  const uint64_t col1 = uniform_u64(D1.col_off), col2 = uniform_u64(D2.col_off);
+  const bool hcb1 = uni(D1.has_cb) != 0, hcb2 = uni(D2.has_cb) != 0, hrx1 = uni(D1.has_rx) != 0, hrx2 = uni(D2.has_rx) != 0;
+  const uint32_t cbl1 = hcb1 ? uni(D1.cb_len) : 0u, cbl2 = hcb2 ? uni(D2.cb_len) : 0u, rxl1 = hrx1 ? uni(D1.rx_len) : 0u, rxl2 = hrx2 ? uni(D2.rx_len) : 0u;
+  const uint32_t name_len = P.prefix_len + 1u + mi_len, rg_len = P.rg_len;
+  const bool ok = Lc1 >= 8u && Lc1 <= 256u && Lc2 >= 8u && Lc2 <= 256u && name_len + 1u <= 32u && rg_len + 4u <= 32u && mi_len + 4u <= 32u &&
+                  cbl1 + 4u <= 32u && cbl2 + 4u <= 32u && rxl1 + 4u <= 32u && rxl2 + 4u <= 32u && rxl1 <= (uint32_t)FAST_RX_CAP && rxl2 <= (uint32_t)FAST_RX_CAP &&
+                  uniform_u64(D2.first_off) == first_off && uni(D2.mi_len) == mi_len && uni(D2.mi_off) == mi_off &&
+                  col2 >= col1 && col2 - col1 < (1ull << 30) && oo2 > oo1 && oo2 - oo1 < (1ull << 30);
+  if (!ok) return false;
+  const uint32_t l = lane & 31u;
+  const bool hb = lane >= 32u;
+  const uint32_t Lc = hb ? Lc2 : Lc1;
+  const uint32_t dcol = hb ? (uint32_t)(col2 - col1) : 0u, dq = hb ? (uint32_t)(oo2 - oo1) : 0u;
+  const uint32_t d_type = hb ? uni(D2.type) : uni(D1.type), rec_size = hb ? uni(D2.rec_size) : uni(D1.rec_size);
+  const bool hcb = hb ? hcb2 : hcb1, hrx = hb ? hrx2 : hrx1;
+  const uint32_t cb_len = hb ? cbl2 : cbl1, rx_len = hb ? rxl2 : rxl1;
+  // ---- loads: everything the two records read, before the first store ---------------------------------------------------------------------
+  const uint32_t n0 = 8u * l;
+  const bool pay = n0 < Lc;                                                             // this lane holds columns of its record
+  const uint32_t c0 = min(n0, Lc - 8u);                                                 // first column of the lane's group (the last group is pulled back)
+  const uint32_t cs = min(n0, ((Lc + 1u) & ~1u) - 8u);                                  // ... of its group of packed bases: even (column Lc may be read: slack)
+  const uint8_t* const code = P.col_code + col1;
+  const uint8_t* const cq = P.col_qual + col1;
+  const uint8_t* const cdb = (const uint8_t*)(P.col_depth + col1);
+  const uint8_t* const ceb = (const uint8_t*)(P.col_err + col1);
+  const uint2 cw = gld64u(code + (dcol + cs));
+  const uint2 qw = gld64u(cq + (dcol + c0));
+  u32x4 dv, ev;
+  __builtin_memcpy(&dv, cdb + 2u * (dcol + c0), 16);
+  __builtin_memcpy(&ev, ceb + 2u * (dcol + c0), 16);
+  const uint8_t* const first = P.blob + first_off;
+  const uint32_t j3 = l >= 3u ? l - 3u : 0u;
+  const uint32_t ni = l > P.prefix_len ? l - P.prefix_len - 1u : 0u;
+  const uint8_t pfx = (uint8_t)P.prefix[l < P.prefix_len ? l : 0u];                     // d_strings keeps 16 bytes of slack
+  const uint8_t nmb = first[mi_off + (ni < mi_len ? ni : mi_len)];                      // index mi_len is the tag's NUL
+  const uint8_t rgb = (uint8_t)P.rg[j3 < rg_len ? j3 : 0u];
+  const uint8_t mib = first[mi_off + (j3 < mi_len ? j3 : mi_len)];
+  uint8_t cbb = 0;
+  if (hcb1 || hcb2) {                                                                   // (wave-uniform; the half without the tag reads byte 0 of the family's first record)
+    const uint64_t k1 = hcb1 ? uniform_u64(D1.kept_off) + uni(D1.cb_off) : first_off, k2 = hcb2 ? uniform_u64(D2.kept_off) + uni(D2.cb_off) : first_off;
+    const uint8_t* const fk = P.blob + (hb ? k2 : k1);
+    cbb = fk[j3 < cb_len ? j3 : 0u];
+  }
+  const uint8_t rxb = (uint8_t)D[hb ? 2 : 1].rx[j3 < (uint32_t)FAST_RX_CAP ? j3 : 0u];
+  // ---- cD / cM / cE (vanilla_caller.rs:1800-1810): max / min depth, sum of errors / sum of depths as f32, per half -------------------------
+  uint32_t maxd, mind, sumd = 0, sume = 0;
+  {
+    const uint32_t skip16 = 16u * (n0 - c0);                                            // bits of duplicate columns at the low end of a pulled-back group
+    const uint32_t d4[4] = {dv.x, dv.y, dv.z, dv.w}, e4[4] = {ev.x, ev.y, ev.z, ev.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int32_t sb = (int32_t)skip16 - 32 * k;
+      const uint32_t m = sb <= 0 ? 0xFFFFFFFFu : sb == 16 ? 0xFFFF0000u : 0u;
+      sumd = em_sum2(d4[k] & m, sumd); sume = em_sum2(e4[k] & m, sume);
+    }
+    const uint32_t mx = em_pkmax(em_pkmax(d4[0], d4[1]), em_pkmax(d4[2], d4[3])), mn = em_pkmin(em_pkmin(d4[0], d4[1]), em_pkmin(d4[2], d4[3]));   // (duplicates do not move a maximum)
+    maxd = max(mx & 0xFFFFu, mx >> 16); mind = min(mn & 0xFFFFu, mn >> 16);
+    if (!pay) { maxd = 0u; mind = 0xFFFFFFFFu; sumd = 0u; sume = 0u; }
+  }
+  FGX_HALF_REDUCE(maxd, 0u, wr_max); FGX_HALF_REDUCE(mind, 0xFFFFFFFFu, wr_min); FGX_HALF_REDUCE(sumd, 0u, wr_add); FGX_HALF_REDUCE(sume, 0u, wr_add);
+  maxd = hb ? rlane(maxd, 63) : rlane(maxd, 31); mind = hb ? rlane(mind, 63) : rlane(mind, 31);
+  sumd = hb ? rlane(sumd, 63) : rlane(sumd, 31); sume = hb ? rlane(sume, 63) : rlane(sume, 31);
+  const float ce_rate = sumd > 0u ? (float)sume / (float)sumd : 0.0f;
+  const uint32_t n_cd = 3u + int_tag_width(maxd), n_cm = 3u + int_tag_width(mind);
+  // ---- where the fields of the half's record lie (offsets from record R1's first byte) ----------------------------------------------------
+  const uint32_t seq_bytes = (Lc + 1u) >> 1;
+  const uint32_t o_seq = dq + 36u + name_len + 1u, o_qual = o_seq + seq_bytes, o_rg = o_qual + Lc, o_t3 = o_rg + 3u + rg_len + 1u;
+  const uint32_t n3 = n_cd + n_cm + 7u, nh = P.per_base_tags ? 8u : 0u;
+  const uint32_t o_cd = o_t3 + n3 + 8u, o_ceh = o_cd + 2u * Lc, o_ce = o_ceh + 8u;
+  const uint32_t o_mi = P.per_base_tags ? o_ce + 2u * Lc : o_t3 + n3;
+  const uint32_t o_cb = o_mi + 3u + mi_len + 1u, o_rx = o_cb + (hcb ? 3u + cb_len + 1u : 0u);
+  uint8_t* const q = P.out + (oo1 - P.out_base);
+  const uint32_t l3 = l < 3u ? l : 3u, sh3 = 8u * l3;                                   // (a 24-bit header word >> sh3: its byte for lanes 0 - 2 of the half, 0 from lane 3 on)
+  auto ztag = [&](uint32_t c3, uint32_t len, uint32_t body) -> uint32_t { const uint32_t u = (l - 3u < len) ? body : 0u; return (c3 >> sh3) | u; };   // byte l of  XY:Z:<len bytes> NUL
+  // ---- stores ---------------------------------------------------------------------------------------------------------------------------------
+  {   // block_size + fixed core: ref_id -1, pos -1, l_read_name, mapq 0, bin 4680, n_cigar_op 0, flag, l_seq, next_ref -1, next_pos -1, tlen 0
+    uint32_t flag = bam::F_UNMAPPED;
+    if (d_type == 1u) flag |= bam::F_PAIRED | bam::F_FIRST | bam::F_MATE_UNMAPPED;
+    else if (d_type == 2u) flag |= bam::F_PAIRED | bam::F_LAST | bam::F_MATE_UNMAPPED;
+    uint32_t v = 0xFFFFFFFFu;
+    if (l == 0u) v = rec_size;
+    if (l == 3u) v = (name_len + 1u) | (4680u << 16);
+    if (l == 4u) v = flag << 16;
+    if (l == 5u) v = Lc;
+    if (l == 8u) v = 0u;
+    if (l < 9u) gst32u(q + (dq + 4u * l), v);
+  }
+  if (l < name_len + 1u) {
+    const uint8_t colon_or_mi = l == P.prefix_len ? (uint8_t)':' : nmb;                 // (nmb is the tag's NUL from lane name_len on)
+    q[dq + 36u + l] = l < P.prefix_len ? pfx : colon_or_mi;
+  }
+  if (pay) {
+    // eight columns -> four bytes, high nibble first; a column past the end packs as 0 (only column cs + 7 can be: Lc odd)
+    uint32_t lo4 = cw.x, hi4 = cw.y;
+    if (cs + 7u >= Lc) hi4 &= 0x00FFFFFFu;
+    const uint32_t t = (lo4 << 4) | (lo4 >> 8), u = (hi4 << 4) | (hi4 >> 8);            // bytes 0 and 2: (code << 4) | next code
+    gst32u(q + (o_seq + (cs >> 1)), __builtin_amdgcn_perm(u, t, 0x06040200u));
+    __builtin_memcpy(q + (o_qual + c0), &qw, 8);
+  }
+  {
+    const uint32_t b = ztag('R' | ('G' << 8) | ('Z' << 16), rg_len, rgb);
+    if (l < 3u + rg_len + 1u) q[o_rg + l] = (uint8_t)b;
+  }
+  {   // cD cM cE and, when asked for, the header of the cd array right behind them: one store
+    auto int_word = [](uint32_t a, uint32_t b, uint32_t v) -> unsigned long long {
+      const uint32_t ty = v <= 127u ? (uint32_t)'c' : v <= 255u ? (uint32_t)'C' : (uint32_t)'S';
+      return (unsigned long long)(a | (b << 8) | (ty << 16)) | ((unsigned long long)v << 24);
+    };
+    const unsigned long long w_cd = int_word('c', 'D', maxd), w_cm = int_word('c', 'M', mind);
+    const unsigned long long w_ce = (unsigned long long)('c' | ('E' << 8) | ('f' << 16)) | ((unsigned long long)__float_as_uint(ce_rate) << 24);
+    const unsigned long long w_hd = (unsigned long long)('c' | ('d' << 8) | ('B' << 16) | ('s' << 24)) | ((unsigned long long)Lc << 32);
+    unsigned long long w = w_hd;
+    uint32_t k = l - n3;
+    if (l < n3) { w = w_ce; k = l - n_cd - n_cm; }
+    if (l < n_cd + n_cm) { w = w_cm; k = l - n_cd; }
+    if (l < n_cd) { w = w_cd; k = l; }
+    const uint32_t b = (uint32_t)(w >> (8u * (k & 7u)));
+    if (l < n3 + nh) q[o_t3 + l] = (uint8_t)b;
+  }
+  if (P.per_base_tags) {
+    if (pay) __builtin_memcpy(q + (o_cd + 2u * c0), &dv, 16);
+    if (l < 2u) gst32u(q + (o_ceh + 4u * l), l == 0u ? ('c' | ('e' << 8) | ('B' << 16) | ('s' << 24)) : Lc);
+    if (pay) __builtin_memcpy(q + (o_ce + 2u * c0), &ev, 16);
+  }
+  {
+    const uint32_t b = ztag((uint32_t)(uint8_t)P.tag0 | ((uint32_t)(uint8_t)P.tag1 << 8) | ('Z' << 16), mi_len, mib);
+    if (l < 3u + mi_len + 1u) q[o_mi + l] = (uint8_t)b;
+  }
+  if (hcb1 || hcb2) {
+    const uint32_t b = ztag((uint32_t)(uint8_t)P.cell0 | ((uint32_t)(uint8_t)P.cell1 << 8) | ('Z' << 16), cb_len, cbb);
+    if (hcb && l < 3u + cb_len + 1u) q[o_cb + l] = (uint8_t)b;
+  }
+  if (hrx1 || hrx2) {
+    const uint32_t b = ztag('R' | ('X' << 8) | ('Z' << 16), rx_len, rxb);
+    if (hrx && l < 3u + rx_len + 1u) q[o_rx + l] = (uint8_t)b;
+  }
+  return true;
+}
 #ifndef FGX_EMIT_OCC
 #define FGX_EMIT_OCC 7   /* wavefronts per SIMD the register allocation of k_emit aims at */
 #endif
@@ -2912,6 +3088,9 @@ __global__ __launch_bounds__(256, FGX_EMIT_OCC) void k_emit(EmitParams P) {
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(oo >> 32), k) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)oo, k);
   };
   if (v0) { EmitLoads R0; emit_load(P, sD[wv][0], off_of(0), lane, R0); emit_store(P, sD[wv][0], lane, R0); }   // a fragment record: families of single reads
+#if FGX_EMIT_PAIR
+  if (!v0 && v1 && v2 && emit_pair(P, &sD[wv][0], off_of(1), off_of(2), lane)) return;   // (round 6) the usual pair family: both records side by side in the halves of the wavefront
+#endif
   // the two records of a pair family: both records' loads, then both records' stores
   EmitLoads R1, R2;
   if (v1) emit_load(P, sD[wv][1], off_of(1), lane, R1);
@@ -3639,7 +3818,7 @@ __global__ void k_col_bound(const uint32_t* __restrict__ grp_first, const uint32
   }
   uint32_t lb = mx > 33 ? (mx - 33) * 2 / 3 + 1 : 1;
   uint32_t ends = (b - a) < max_ends ? (b - a) : max_ends;
-  bound[g] = (uint64_t)ends * lb;
+  bound[g] = (uint64_t)ends * lb + COL_BOUND_PAD;
   uint64_t lo = 0;
   uint32_t span = 0xFFFFFFFFu;                               // no usable span (empty group, descending or far-apart records)
   if (b > a) {
@@ -3651,11 +3830,11 @@ __global__ void k_col_bound(const uint32_t* __restrict__ grp_first, const uint32
 }
 
 __global__ void k_reduce_stats(const unsigned long long* __restrict__ slots, unsigned long long* __restrict__ out) {
-  uint32_t k = threadIdx.x;   // one thread per counter
-  if (k >= FGX_STATS_LEN) return;
+  uint32_t k = threadIdx.x;   // one thread per counter; the slots' entries 28 .. 31 are diagnostics (k_split_finish: families per build) and go to out[40 ..]
+  if (k >= 32) return;
   unsigned long long v = 0;
   for (int i = 0; i < STAT_SLOTS; i++) v += slots[(size_t)i * 32 + k];
-  out[k] = v;
+  out[k < FGX_STATS_LEN ? k : 40 + (k - FGX_STATS_LEN)] = v;
 }
 
 }  // namespace
@@ -3663,6 +3842,8 @@ __global__ void k_reduce_stats(const unsigned long long* __restrict__ slots, uns
 // -----------------------------------------------------------------------------------------------------
 // host driver
 // -----------------------------------------------------------------------------------------------------
+// diagnostics of a batch (fgx_debug_last_chain: bench.py's share_of_8 block): kernel launches and host synchronisations of FastPath::run_once
+#define FGX_SYNC(st) do { last_host_syncs++; hip_check(hipStreamSynchronize(st), "sync"); } while (0)
 void FastPath::release() {
   for (DevBuf* b : {&d_ends, &d_sizes, &d_offsets, &d_code, &d_qual, &d_depth, &d_err, &d_misc, &d_deferred, &d_out, &d_scan_tmp, &d_strings, &d_obs, &d_retry2,
                     &d_retry, &d_bound, &d_colbase, &d_statslots, &d_full_items, &d_full_count, &d_retry_old, &d_w2img, &d_famdesc, &d_fwimg,
@@ -3691,7 +3872,7 @@ int FastPath::run(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const
   for (;;) {
     const int rc = run_once(c, d_blob, blob_len, d_rec_off, d_rec_len, n_rec, d_grp_first, n_grp, res);
     if (rc != RUN_AGAIN_LARGER_POOL) {
-      if (const char* e = getenv("FGX_S2_DEBUG")) if (atoi(e)) {   // (development: the packed pass's counters, cumulative over the process)
+      if (const char* e = fgx_knob("FGX_S2_DEBUG")) if (atoi(e)) {   // (development: the packed pass's counters, cumulative over the process)
         uint32_t h[64];
         if (hipDeviceSynchronize() == hipSuccess && hipMemcpyFromSymbol(h, HIP_SYMBOL(g_s2_dbg), sizeof(h)) == hipSuccess) {
           fprintf(stderr, "[s2 packed] runs tried %u finished %u (columns for k_call_full %u) no room %u shape refused %u", h[0], h[1], h[2], h[3], h[42]);
@@ -3709,6 +3890,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
   const bool duplex = o.caller_kind == FGX_CALLER_DUPLEX, codec = o.caller_kind == FGX_CALLER_CODEC;
   hipStream_t s = c->stream;
   memset(res, 0, sizeof(*res));
+  last_launches = 0; last_host_syncs = 0;
   if (n_grp == 0) return 0;
   const uint32_t n_slots = 3 * n_grp;   // simplex: Fragment, R1, R2 of each family; duplex: slot 0 unused, R1, R2
   d_ends.reserve((size_t)n_slots * (duplex ? sizeof(DuplexDesc) : codec ? sizeof(CodecDesc) : sizeof(EndDesc)));
@@ -3716,8 +3898,8 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
   d_offsets.reserve((size_t)n_slots * 8);
   d_deferred.reserve((size_t)n_grp * 4);
   // misc: [0..28) stats, [28] col_cursor, [29] n_deferred (u32 in low half), [30] valid count
-  d_misc.reserve(40 * 8);   // ... [31] n_retry, [32] n_retry_old (k_simplex_wave2 → k_family_wave<0>)
-  hip_check(hipMemsetAsync(d_misc.p, 0, 40 * 8, s), "memset");
+  d_misc.reserve(48 * 8);   // ... [31] n_retry, [32] n_retry_old (k_simplex_wave2 → k_family_wave<0>); [40 .. 44) diagnostics (k_reduce_stats)
+  hip_check(hipMemsetAsync(d_misc.p, 0, 48 * 8, s), "memset");
   // strings: prefix | rg
   std::string strs = c->prefix + c->rg;
   d_strings.reserve(strs.size() + 16);
@@ -3735,11 +3917,11 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
   // Simplex without --trim: which head of the launch chain?  Shallow families (the mean family fits a quarter of a wave's LDS
   // slice) start at k_simplex_seg<4>; everything else at the split pipeline (k_split_parse + k_split_cols, simplex_split.inc),
   // whose record kernel also leaves what k_col_bound would (column bound, byte-span descriptor).
-  static const bool use_v2 = [] { const char* e = getenv("FGX_V2"); return !(e && e[0] == '0'); }();
-  static const bool use_seg = [] { const char* e = getenv("FGX_SEG"); return !(e && e[0] == '0'); }();
+  static const bool use_v2 = [] { const char* e = fgx_knob("FGX_V2"); return !(e && e[0] == '0'); }();
+  static const bool use_seg = [] { const char* e = fgx_knob("FGX_SEG"); return !(e && e[0] == '0'); }();
   const bool use_split_env = [] { const char* e = getenv("FGX_SPLIT"); return !(e && e[0] == '0'); }();   // (read per batch: tests switch it inside one process)
   uint32_t seg_bytes = 11776;   // 4 wavefronts x 11776 B + the static tables = 3 workgroups per CU
-  if (const char* e = getenv("FGX_SEG_BYTES")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 4096 && v <= 32768) seg_bytes = v & ~63u; }
+  if (const char* e = fgx_knob("FGX_SEG_BYTES")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 4096 && v <= 32768) seg_bytes = v & ~63u; }
   const double mean_span = (double)blob_len / (double)n_grp + 48.0;   // mean bytes of a family + alignment / read-ahead slack
   // Methylation-aware mode (simplex, a reference set, no --trim): the streaming kernels of simplex_deep.inc are the whole pipeline — every
   // family on their list, the reference lookup / counts / normalisation in k_deep_cols<1>, MM / ML / cu / ct behind the standard record
@@ -3748,8 +3930,60 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
   last_meth_device = 0;
   const bool simplex_v2 = !duplex && !codec && !o.trim && use_v2 && !meth_dev;
   const bool seg4 = simplex_v2 && use_seg && mean_span + (16 * 8 + 64) <= seg_bytes / 4;
-  hipLaunchKernelGGL(k_col_bound, dim3((n_grp + 1023) / 1024), dim3(1024), 0, s, d_grp_first, d_rec_len, d_rec_off, n_grp, d_bound.as<uint64_t>(), duplex ? 4u : codec ? 2u : 3u,
-                     d_famdesc.as<uint4>(), misc + 35);
+  // the split pipeline's geometry: families per wavefront of the record kernel (as many as fill its 64 lanes on average), chunks, families per chunk
+  const double mean_recs = (double)n_rec / (double)n_grp;
+  auto split_geometry = [&](uint32_t& fpw, uint32_t& n_chunks, uint32_t& chunk_fam_raw, uint32_t& chunk_fam) {
+    fpw = mean_recs >= 1.0 ? (uint32_t)(64.0 / mean_recs) : 16u;
+    fpw = fpw < 1u ? 1u : fpw > 16u ? 16u : fpw;
+    if (const char* e = fgx_knob("FGX_SPLIT_FPW")) { const int v = atoi(e); if (v >= 1 && v <= 32) fpw = (uint32_t)v; }   // (measurement knob)
+    static const int chunks_env = [] { const char* e = getenv("FGX_SPLIT_CHUNKS"); return e ? atoi(e) : 0; }();      // (measurement knob)
+    // chunks of at least ~150 000 families (a column kernel of 37 500 workgroups: 20 rounds of the chip's resident workgroups, so that its tail — the
+    // last round runs with a part of the chip — stays a few per cent), eight at most: one rank's share of an 8-way strong-scaling run (625 000
+    // families) took 8 chunks of 78 000 until round 6 and spent a third of its step in launch gaps and kernel tails (bench.py share_of_8)
+    n_chunks = chunks_env >= 1 ? (uint32_t)chunks_env : std::min<uint32_t>(8u, std::max<uint32_t>(1u, n_grp / 150000u));
+    if (n_chunks > (uint32_t)MAX_CHUNKS - 1) n_chunks = MAX_CHUNKS - 1;   // (the last event marks where the second stream starts)
+    chunk_fam_raw = (n_grp + n_chunks - 1) / n_chunks;
+    chunk_fam = ((chunk_fam_raw + 4 * fpw - 1) / (4 * fpw)) * (4 * fpw);      // whole workgroups of both kernels per chunk
+  };
+  auto split_streams = [&]() {
+    if (!s2) { create_compute_stream(&s2); for (int i = 0; i < MAX_CHUNKS; i++) { hip_check(hipEventCreateWithFlags(&ev_chunk[i], hipEventDisableTiming), "hipEventCreate"); hip_check(hipEventCreateWithFlags(&ev_cols[i], hipEventDisableTiming), "hipEventCreate"); } hip_check(hipEventCreateWithFlags(&ev_fin, hipEventDisableTiming), "hipEventCreate"); hip_check(hipEventCreateWithFlags(&ev_sample, hipEventDisableTiming), "hipEventCreate"); }
+  };
+  auto split_parse_params = [&](FastParams& PK) {
+    memset(&PK, 0, sizeof(PK));
+    PK.blob = d_blob; PK.rec_off = d_rec_off; PK.rec_len = d_rec_len; PK.grp_first = d_grp_first; PK.blob_len = blob_len;
+    PK.min_reads = o.min_reads; PK.max_reads = o.max_reads; PK.overlap = o.overlapping_consensus;
+    PK.tag0 = o.tag[0]; PK.tag1 = o.tag[1]; PK.cell0 = o.cell_tag[0]; PK.cell1 = o.cell_tag[1];
+    PK.prefix_len = (uint32_t)c->prefix.size();
+    PK.split_rec = d_split_rec.as<SplitRec>(); PK.split_fam = d_split_fam.as<SplitFam>();
+  };
+  // (round 6) The record kernel of the FIRST chunk starts before the column bounds are counted and scanned: it needs nothing of them, and the host
+  // waits for its first families anyway (their tile strides pick the column kernel's build).  Before, the second stream started behind
+  // k_col_bound + scan + a host synchronisation: 0.37 ms into the step.  Launched when the batch can take the split pipeline at all; should the count of
+  // small families then say otherwise (below), its descriptors are simply not used.
+  bool early_parse = false;
+  {
+    const bool direct_env0 = [] { const char* e = getenv("FGX_DIRECT"); return e && e[0] == '1'; }();
+    static const bool early_env = [] { const char* e = fgx_knob("FGX_S2_EARLY"); return !(e && e[0] == '0'); }();      // (measurement knob)
+    if (simplex_v2 && use_split_env && !seg4 && !direct_env0 && early_env) {
+      d_split_rec.reserve((size_t)n_rec * sizeof(SplitRec) + 64);
+      d_split_fam.reserve((size_t)n_grp * sizeof(SplitFam) + 64);
+      split_streams();
+      uint32_t fpw, n_chunks, chunk_fam_raw, chunk_fam;
+      split_geometry(fpw, n_chunks, chunk_fam_raw, chunk_fam);
+      FastParams PK;
+      split_parse_params(PK);
+      hip_check(hipEventRecord(ev_chunk[MAX_CHUNKS - 1], s), "event");      // (behind what the stream holds: the batch's buffers, the memsets)
+      hip_check(hipStreamWaitEvent(s2, ev_chunk[MAX_CHUNKS - 1], 0), "wait");
+      const uint32_t gb = (uint32_t)std::min<uint64_t>(chunk_fam, n_grp);
+      const uint64_t waves = ((uint64_t)gb + fpw - 1) / fpw;
+      do { last_launches++; hipLaunchKernelGGL(k_split_parse, dim3((uint32_t)((waves + 1) / 2)), dim3(128), 0, s2, PK, 0u, gb, fpw, (uint64_t*)nullptr, 3u, (uint4*)nullptr); } while (0);
+      hip_check(hipGetLastError(), "k_split_parse launch (first chunk, early)");
+      hip_check(hipEventRecord(ev_chunk[0], s2), "event");
+      early_parse = true;
+    }
+  }
+  do { last_launches++; hipLaunchKernelGGL(k_col_bound, dim3((n_grp + 1023) / 1024), dim3(1024), 0, s, d_grp_first, d_rec_len, d_rec_off, n_grp, d_bound.as<uint64_t>(), duplex ? 4u : codec ? 2u : 3u,
+                     d_famdesc.as<uint4>(), misc + 35); } while (0);
   {
     size_t tb = 0;
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_bound.as<uint64_t>(), d_colbase.as<uint64_t>(), (int)n_grp, s);
@@ -3761,7 +3995,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
   hip_check(hipMemcpyAsync(&lastb[1], d_bound.as<uint64_t>() + (n_grp - 1), 8, hipMemcpyDeviceToHost, s), "D2H");
   unsigned long long small_recs = 0;
   hip_check(hipMemcpyAsync(&small_recs, misc + 35, 8, hipMemcpyDeviceToHost, s), "D2H");
-  hip_check(hipStreamSynchronize(s), "sync");
+  FGX_SYNC(s);
   // The split pipeline is the faster head for every family it keeps (depth 8: 25.7 against 37 ms per 5 M families) — since round 4 that is
   // every family of up to 64 records in the common shape (an end of more than 16 reads sends its disagreeing columns to k_call_full as
   // several items); larger families it only measures and hands to k_family.  Split when at least half of the reads sit in families of
@@ -3776,7 +4010,8 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
   const bool direct_env = [] { const char* e = getenv("FGX_DIRECT"); return e && e[0] == '1'; }();   // (read per batch: tools/direct_check.py switches it between two runs of one process)
   const bool direct = use_split && direct_env && !direct_off && !meth_dev;
   last_direct = 0;
-  last_routed = 0; last_big_families = 0; last_deep_families = 0;
+  if (early_parse && !use_split) hip_check(hipStreamWaitEvent(s, ev_chunk[0], 0), "wait");   // (its descriptors are not used; nothing of this batch may still run when the call returns)
+  last_routed = 0; last_big_families = 0; last_deep_families = 0; last_packed_families = 0; last_classic_families = 0; last_split_build = 0; last_first_stage_retries = 0;
   uint64_t col_cap = lastb[0] + lastb[1] + 64;
   uint64_t dir_cap = 0;
   if (direct) {
@@ -3806,16 +4041,16 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
     build_fw_image(*img, c->h_tables.t);
     d_fwimg.reserve(sizeof(FwLds));
     hip_check(hipMemcpyAsync(d_fwimg.p, img, sizeof(FwLds), hipMemcpyHostToDevice, s), "H2D fw image");
-    hip_check(hipStreamSynchronize(s), "sync");
+    FGX_SYNC(s);
     delete img;
   }
   P.fw_image = d_fwimg.p;
   P.min_reads = o.min_reads; P.max_reads = o.max_reads;
   P.min_input_bq = o.min_input_base_quality; P.min_cons_bq = o.min_consensus_base_quality;
   {   // k_split_cols's sum-free observation step: from how many agreeing observations a column is the cap whatever their qualities (gate_core.h)
-    static const int nosum_env = [] { const char* e = getenv("FGX_S2_NOSUM"); return e ? atoi(e) : 1; }();      // (measurement knob: 0 = every end through the f32 sums)
+    static const int nosum_env = [] { const char* e = fgx_knob("FGX_S2_NOSUM"); return e ? atoi(e) : 1; }();      // (measurement knob: 0 = every end through the f32 sums)
     static const int packed_env = [] { const char* e = getenv("FGX_S2_PACKED"); return e ? atoi(e) : 1; }();   // (measurement knob: 0 = the 64-column passes only)
-    static const int s2dbg_env = [] { const char* e = getenv("FGX_S2_DEBUG"); return e ? atoi(e) : 0; }();
+    static const int s2dbg_env = [] { const char* e = fgx_knob("FGX_S2_DEBUG"); return e ? atoi(e) : 0; }();
     P.s2_packed = (packed_env ? 1u : 0u) | ((packed_env && s2dbg_env) ? 2u : 0u);
     P.s2_nsafe = nosum_env ? unanimous_cap_depth(c->h_tables.t, (uint32_t)o.min_input_base_quality & 0xFFu, 64u) : FGX_NEVER_CAP;
   }
@@ -3867,7 +4102,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
   hip_check(hipMemsetAsync(d_full_count.p, 0, (size_t)N_LISTS * 4, s), "memset");
   P.full_items = d_full_items.as<FullItem>(); P.full_count = d_full_count.as<uint32_t>(); P.full_cap = full_cap;
   uint32_t wave_bytes = duplex ? lds_wave_bytes_duplex : codec ? lds_wave_bytes_codec : lds_wave_bytes;
-  if (const char* e = getenv("FGX_WAVE_BYTES")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 1024 && v <= 22016) wave_bytes = v & ~15u; }   // tuning knob
+  if (const char* e = fgx_knob("FGX_WAVE_BYTES")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 1024 && v <= 22016) wave_bytes = v & ~15u; }   // tuning knob
   P.lds_wave_bytes = wave_bytes;
   P.lds_tile_bytes = lds_tile_bytes_large;
 
@@ -3886,6 +4121,8 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
     // simplex families of more than 64 records: no wavefront-per-family kernel takes them — the first kernel that sees one puts it on
     // k_family's list (round 3 walked them through k_simplex_wave2 and three k_family_wave<0> launches first: 2 ms per 1 M long-tail families)
     uint32_t* d_cnt_big = (uint32_t*)(misc + 37);
+    uint32_t h_route_seen = 0, h_big_seen = 0;
+    bool split_counts_seen = false;
     // (not with direct records: their merge pass walks ONE list of the families that left the split pipeline — the route list)
     if (!duplex && !codec && !direct) { d_big.reserve((size_t)n_grp * 4); P.big = d_big.as<uint32_t>(); P.n_big = d_cnt_big; }
     uint32_t* d_cnt = (uint32_t*)(misc + 31);
@@ -3912,11 +4149,11 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
         s2_attr_set = true;
       }
       if (!d_s2img.p) {   // the tables of a caller never change: one image per FastPath
-        S2Lds* img = new S2Lds;
+        S2Image* img = new S2Image;
         build_s2_image(*img, c->h_tables.t);
-        d_s2img.reserve(sizeof(S2Lds));
-        hip_check(hipMemcpyAsync(d_s2img.p, img, sizeof(S2Lds), hipMemcpyHostToDevice, s), "H2D s2 image");
-        hip_check(hipStreamSynchronize(s), "sync");
+        d_s2img.reserve(sizeof(S2Image));
+        hip_check(hipMemcpyAsync(d_s2img.p, img, sizeof(S2Image), hipMemcpyHostToDevice, s), "H2D s2 image");
+        FGX_SYNC(s);
         delete img;
       }
       d_route.reserve((size_t)n_grp * 4);
@@ -3931,27 +4168,17 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       d_split_rec.reserve((size_t)n_rec * sizeof(SplitRec) + 64);
       d_split_fam.reserve((size_t)n_grp * sizeof(SplitFam) + 64);
       P.split_rec = d_split_rec.as<SplitRec>(); P.split_fam = d_split_fam.as<SplitFam>();
-      if (!s2) { create_compute_stream(&s2); for (int i = 0; i < MAX_CHUNKS; i++) { hip_check(hipEventCreateWithFlags(&ev_chunk[i], hipEventDisableTiming), "hipEventCreate"); hip_check(hipEventCreateWithFlags(&ev_cols[i], hipEventDisableTiming), "hipEventCreate"); } hip_check(hipEventCreateWithFlags(&ev_fin, hipEventDisableTiming), "hipEventCreate"); hip_check(hipEventCreateWithFlags(&ev_sample, hipEventDisableTiming), "hipEventCreate"); }
+      split_streams();
       FastParams PK;
-      memset(&PK, 0, sizeof(PK));
-      PK.blob = d_blob; PK.rec_off = d_rec_off; PK.rec_len = d_rec_len; PK.grp_first = d_grp_first; PK.blob_len = blob_len;
-      PK.min_reads = o.min_reads; PK.max_reads = o.max_reads; PK.overlap = o.overlapping_consensus;
-      PK.tag0 = o.tag[0]; PK.tag1 = o.tag[1]; PK.cell0 = o.cell_tag[0]; PK.cell1 = o.cell_tag[1];
-      PK.prefix_len = (uint32_t)c->prefix.size();
-      PK.split_rec = P.split_rec; PK.split_fam = P.split_fam;
+      split_parse_params(PK);
       if (direct) { PK.dir_size = P.dir_size; PK.min_input_bq = o.min_input_base_quality; PK.per_base_tags = o.produce_per_base_tags; PK.rg_len = (uint32_t)c->rg.size(); }
-      // families per wavefront of the record kernel: as many as fill its 64 lanes on average
-      const double mean_recs = (double)n_rec / (double)n_grp;
-      uint32_t fpw = mean_recs >= 1.0 ? (uint32_t)(64.0 / mean_recs) : 16u;
-      fpw = fpw < 1u ? 1u : fpw > 16u ? 16u : fpw;
-      if (const char* e = getenv("FGX_SPLIT_FPW")) { const int v = atoi(e); if (v >= 1 && v <= 32) fpw = (uint32_t)v; }   // (measurement knob)
-      static const int chunks_env = [] { const char* e = getenv("FGX_SPLIT_CHUNKS"); return e ? atoi(e) : 0; }();      // (measurement knob)
-      uint32_t n_chunks = chunks_env >= 1 ? (uint32_t)chunks_env : (n_grp >= 400000u ? 8u : n_grp >= 100000u ? 4u : 1u);
-      if (n_chunks > (uint32_t)MAX_CHUNKS - 1) n_chunks = MAX_CHUNKS - 1;   // (the last event marks where the second stream starts)
-      uint32_t chunk_fam = (n_grp + n_chunks - 1) / n_chunks;
-      last_split_chunks = n_chunks;
-      dir_chunks_run = (n_grp + chunk_fam - 1) / chunk_fam;     // chunks that hold families (the rounding of chunk_fam can leave the last ones empty)
-      chunk_fam = ((chunk_fam + 4 * fpw - 1) / (4 * fpw)) * (4 * fpw);      // whole workgroups of both kernels per chunk
+      uint32_t fpw, n_chunks, chunk_fam;
+      {
+        uint32_t chunk_fam_raw;
+        split_geometry(fpw, n_chunks, chunk_fam_raw, chunk_fam);
+        last_split_chunks = n_chunks;
+        dir_chunks_run = (n_grp + chunk_fam_raw - 1) / chunk_fam_raw;     // chunks that hold families (the rounding of chunk_fam can leave the last ones empty)
+      }
       hip_check(hipEventRecord(ev_chunk[MAX_CHUNKS - 1], s), "event");      // (the second stream starts where this one is: buffers, memsets)
       hip_check(hipStreamWaitEvent(s2, ev_chunk[MAX_CHUNKS - 1], 0), "wait");
       size_t dir_scan_bytes = 0;
@@ -3964,18 +4191,18 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
         const uint32_t ga = ci * chunk_fam, gb = std::min<uint64_t>((uint64_t)ga + chunk_fam, n_grp);
         if (ga >= gb) return;
         const uint64_t waves = ((uint64_t)(gb - ga) + fpw - 1) / fpw;
-        hipLaunchKernelGGL(k_split_parse, dim3((uint32_t)((waves + 1) / 2)), dim3(128), 0, s2, PK, ga, gb, fpw, (uint64_t*)nullptr, 3u, (uint4*)nullptr);
+        do { last_launches++; hipLaunchKernelGGL(k_split_parse, dim3((uint32_t)((waves + 1) / 2)), dim3(128), 0, s2, PK, ga, gb, fpw, (uint64_t*)nullptr, 3u, (uint4*)nullptr); } while (0);
         hip_check(hipGetLastError(), "k_split_parse launch");
         if (direct) {   // the chunk's record offsets: exclusive scan of the predicted family sizes, carried on from the chunk before
           const DirSizeIn in(d_dir_size.as<uint32_t>() + ga, DirCast());
           hip_check(hipcub::DeviceScan::ExclusiveSum(d_scan_tmp2.p, dir_scan_bytes, in, d_dir_off.as<uint64_t>() + ga, (int)(gb - ga), s2), "scan of the record sizes");
-          hipLaunchKernelGGL(k_dir_carry, dim3((gb - ga + 255) / 256), dim3(256), 0, s2, d_dir_off.as<uint64_t>() + ga, d_dir_size.as<uint32_t>() + ga, gb - ga,
-                             d_dir_base.as<uint64_t>() + ci);
+          do { last_launches++; hipLaunchKernelGGL(k_dir_carry, dim3((gb - ga + 255) / 256), dim3(256), 0, s2, d_dir_off.as<uint64_t>() + ga, d_dir_size.as<uint32_t>() + ga, gb - ga,
+                             d_dir_base.as<uint64_t>() + ci); } while (0);
           hip_check(hipGetLastError(), "k_dir_carry launch");
         }
         hip_check(hipEventRecord(ev_chunk[ci], s2), "event");
       };
-      launch_parse(0);
+      if (!early_parse) launch_parse(0);
       // the tile strides of the first families decide which build of k_split_cols goes first
       SplitFam fam_sample[64];
       const uint32_t n_sample = n_grp < 64u ? n_grp : 64u;
@@ -3985,15 +4212,15 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       // beside it gets what is left — with every chunk's record kernel queued up front, the first column kernel took 6.9 ms instead of
       // 1.7 and the two streams added up like one (gpurun_out timeline, profiles/r05_timeline_*.txt).  Paced: chunk k + 2 is parsed
       // when the column kernel of chunk k has finished, i.e. under the column kernel of chunk k + 1.
-      static const int pace_env = [] { const char* e = getenv("FGX_S2_PACE"); return e ? atoi(e) : 1; }();      // (measurement knob: 0 = all record kernels up front)
+      static const int pace_env = [] { const char* e = fgx_knob("FGX_S2_PACE"); return e ? atoi(e) : 1; }();      // (measurement knob: 0 = all record kernels up front)
       const bool paced = pace_env != 0 && n_chunks > 2;
       for (uint32_t ci = 1; ci < (paced ? 2u : n_chunks); ci++) launch_parse(ci);
-      hip_check(hipEventSynchronize(ev_sample), "sync");
+      do { last_host_syncs++; hip_check(hipEventSynchronize(ev_sample), "sync"); } while (0);
       // LDS slice of the first launch: the MEAN family's tile (rows of 160 + 80 bytes) + room for its k_call_full items, at least the
       // 4352 bytes of a 16-record family — a deeper library starts at the slice its families need instead of failing the first launch
       // as a whole (depth 12: every family took two launches, 32 ms per 1 M families)
-      static const uint32_t s2_bytes_env = [] { const char* e = getenv("FGX_S2_BYTES"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 2048 && v <= 32768 ? (v & ~15) : 0); }();
-      static const uint32_t s2_wpb_env = [] { const char* e = getenv("FGX_S2_WPB"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= 4 ? v : 0); }();
+      static const uint32_t s2_bytes_env = [] { const char* e = fgx_knob("FGX_S2_BYTES"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 2048 && v <= 32768 ? (v & ~15) : 0); }();
+      static const uint32_t s2_wpb_env = [] { const char* e = fgx_knob("FGX_S2_WPB"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= 4 ? v : 0); }();
       // (round 5: the packed pass sends every column it does not answer itself to k_call_full — also the one-base columns of too few
       // observations, which run_cols's gates answer — and keeps an 8-byte descriptor per such column at the top of the slice: 56 bytes per
       // column, ~14 columns per depth-8 family of `simulate` data; 5632 bytes x 4 wavefronts still leave a CU six workgroups)
@@ -4006,9 +4233,10 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
         auto ok = [&](uint32_t m) { return m < 2u || (m >= P.s2_nsafe && m <= 16u); };
         n_pk += (ok(F.m_a) && ok(F.m_b) && ((F.len_a + 7u) >> 3) + ((F.len_b + 7u) >> 3) <= 64u) ? 1u : 0u;
       }
-      static const int s2_partner_env = [] { const char* e = getenv("FGX_S2_PARTNER"); return e ? atoi(e) : -1; }();   // (measurement knob: 1 = always both kernels, 0 = never)
+      static const int s2_partner_env = [] { const char* e = fgx_knob("FGX_S2_PARTNER"); return e ? atoi(e) : -1; }();   // (measurement knob: 1 = always both kernels, 0 = never)
       if (s2_packed_on && n_sample && 100ull * n_pk < (unsigned long long)n_sample) s2_packed_on = false;               // under 1 % of its shape: the classic kernel alone
       const bool s2_partner = s2_packed_on && (s2_partner_env >= 0 ? s2_partner_env != 0 : 100ull * n_pk < 99ull * n_sample);
+      last_split_build = s2_packed_on ? (s2_partner ? 2u : 1u) : 0u;
       uint32_t s2_bytes0 = s2_packed_on ? 5632 : 4352;
       {
         const uint32_t mean_need = (uint32_t)(mean_recs + 0.999) * 240u + 16u + (s2_packed_on ? 1680u : 400u);
@@ -4017,7 +4245,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       if (s2_bytes_env) s2_bytes0 = s2_bytes_env;
       const uint32_t s2_wpb = s2_wpb_env ? s2_wpb_env : (s2_bytes0 <= 6528u ? 4u : s2_bytes0 <= 13056u ? 2u : 1u);
       // rows of 160 + 80 bytes (reads up to 160 bases) have their own build: member rows at immediate offsets in the column loop
-      static const int s2_fixed_env = [] { const char* e = getenv("FGX_S2_FIXED"); return e ? atoi(e) : -1; }();   // (measurement knob: 0 / 1)
+      static const int s2_fixed_env = [] { const char* e = fgx_knob("FGX_S2_FIXED"); return e ? atoi(e) : -1; }();   // (measurement knob: 0 / 1)
       uint32_t n160 = 0;
       for (uint32_t i = 0; i < n_sample; i++) n160 += (fam_sample[i].qs == 160 && fam_sample[i].ss == 80) ? 1u : 0u;
       const bool s2_fixed = s2_fixed_env >= 0 ? s2_fixed_env != 0 : 2 * n160 > n_sample;
@@ -4056,19 +4284,19 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
           PS.g0 = g_first;
           const dim3 grid((count + wpb - 1) / wpb), block(64 * wpb);
           if (direct) {
-            if (st2[ci].fixed) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<160, 80, 1, 0>), grid, block, lds, s, PS, count);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<0, 0, 1, 0>), grid, block, lds, s, PS, count);
+            if (st2[ci].fixed) do { last_launches++; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<160, 80, 1, 0>), grid, block, lds, s, PS, count); } while (0);
+            else do { last_launches++; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<0, 0, 1, 0>), grid, block, lds, s, PS, count); } while (0);
           } else if (ci == 0 && s2_packed_on) {
             // (round 5) the first stage as two launches over the same families: the packed pass for the families of its shape, run_cols for the rest
             if (st2[ci].fixed) {
-              hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<160, 80, 0, 1>), grid, block, lds, s, PS, count);
-              if (s2_partner) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<160, 80, 0, 2>), grid, block, lds, s, PS, count);
+              do { last_launches++; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<160, 80, 0, 1>), grid, block, lds, s, PS, count); } while (0);
+              if (s2_partner) do { last_launches++; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<160, 80, 0, 2>), grid, block, lds, s, PS, count); } while (0);
             } else {
-              hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<0, 0, 0, 1>), grid, block, lds, s, PS, count);
-              if (s2_partner) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<0, 0, 0, 2>), grid, block, lds, s, PS, count);
+              do { last_launches++; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<0, 0, 0, 1>), grid, block, lds, s, PS, count); } while (0);
+              if (s2_partner) do { last_launches++; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<0, 0, 0, 2>), grid, block, lds, s, PS, count); } while (0);
             }
-          } else if (st2[ci].fixed) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<160, 80, 0, 0>), grid, block, lds, s, PS, count);
-          else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<0, 0, 0, 0>), grid, block, lds, s, PS, count);
+          } else if (st2[ci].fixed) do { last_launches++; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<160, 80, 0, 0>), grid, block, lds, s, PS, count); } while (0);
+          else do { last_launches++; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<0, 0, 0, 0>), grid, block, lds, s, PS, count); } while (0);
         };
         if (ci == 0) {   // the first stage takes the families in file order, chunk by chunk behind the record kernel
           for (uint32_t k = 0; k < n_chunks; k++) {
@@ -4082,29 +4310,36 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
             hip_check(hipStreamWaitEvent(s2, ev_cols[k], 0), "wait");
             FastParams PF = P;
             PF.group_list = nullptr; PF.g0 = ga;
-            hipLaunchKernelGGL(k_split_finish, dim3((gb - ga + 255) / 256), dim3(256), 0, s2, PF, gb - ga);
+            do { last_launches++; hipLaunchKernelGGL(k_split_finish, dim3((gb - ga + 255) / 256), dim3(256), 0, s2, PF, gb - ga); } while (0);
             if (paced && k + 2 < n_chunks) launch_parse(k + 2);
           }
         } else {
           launch_cols(0u, n_s2);
           FastParams PF = P;                       // the families this (larger-slice) launch finished: the list it was given
           PF.group_list = s2_list; PF.g0 = 0;
-          hipLaunchKernelGGL(k_split_finish, dim3((n_s2 + 255) / 256), dim3(256), 0, s, PF, n_s2);
+          do { last_launches++; hipLaunchKernelGGL(k_split_finish, dim3((n_s2 + 255) / 256), dim3(256), 0, s, PF, n_s2); } while (0);
         }
         hip_check(hipGetLastError(), "k_split_cols launch");
         uint32_t n_next = 0;
         hip_check(hipMemcpyAsync(&n_next, d_cnt, 4, hipMemcpyDeviceToHost, s), "D2H");
-        hip_check(hipStreamSynchronize(s), "sync");
+        // (round 6: the route / big counters come along — after the LAST stage they are final, and two host synchronisations of their own go away)
+        hip_check(hipMemcpyAsync(&h_route_seen, d_cnt_route, 4, hipMemcpyDeviceToHost, s), "D2H");
+        hip_check(hipMemcpyAsync(&h_big_seen, d_cnt_big, 4, hipMemcpyDeviceToHost, s), "D2H");
+        split_counts_seen = true;
+        FGX_SYNC(s);
+        if (ci == 0) last_first_stage_retries = PS.retry ? n_next : 0u;
         s2_list = lists[s2_out]; n_s2 = PS.retry ? n_next : 0; s2_out ^= 1;
       }
       hip_check(hipEventRecord(ev_fin, s2), "event");          // the per-chunk k_split_finish launches
       hip_check(hipStreamWaitEvent(s, ev_fin, 0), "wait");
-      uint32_t n_route = 0;
-      hip_check(hipMemcpyAsync(&n_route, d_cnt_route, 4, hipMemcpyDeviceToHost, s), "D2H");
-      hip_check(hipStreamSynchronize(s), "sync");
+      uint32_t n_route = h_route_seen;
+      if (!split_counts_seen) {
+        hip_check(hipMemcpyAsync(&n_route, d_cnt_route, 4, hipMemcpyDeviceToHost, s), "D2H");
+        FGX_SYNC(s);
+      }
       n_v2 = n_route; v2_list = d_route.as<uint32_t>();
       last_routed = n_route;
-      static const bool s2_verbose = [] { const char* e = getenv("FGX_S2_VERBOSE"); return e && e[0] == '1'; }();
+      static const bool s2_verbose = [] { const char* e = fgx_knob("FGX_S2_VERBOSE"); return e && e[0] == '1'; }();
       if (s2_verbose) fprintf(stderr, "[fgx] split pipeline: %u families, %u routed to k_simplex_wave2\n", n_grp, n_route);
     }
     if (simplex_v2) {
@@ -4121,17 +4356,17 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
         build_w2_image(img, c->h_tables.t);
         d_w2img.reserve(sizeof(W2Lds));
         hip_check(hipMemcpyAsync(d_w2img.p, &img, sizeof(W2Lds), hipMemcpyHostToDevice, s), "H2D w2 image");
-        hip_check(hipStreamSynchronize(s), "sync");             // (`img` is on this stack frame)
+        FGX_SYNC(s);             // (`img` is on this stack frame)
       }
       P.w2_image = d_w2img.p;
       P.fam_desc = d_famdesc.as<uint4>();
       struct Stage { int fam_per_wave; uint32_t bytes; uint32_t wpb; };
       std::vector<Stage> chain;
-      static const uint32_t seg_wpb = [] { const char* e = getenv("FGX_SEG_WPB"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= WAVES_PER_BLOCK ? v : WAVES_PER_BLOCK); }();   // (measurement knob)
+      static const uint32_t seg_wpb = [] { const char* e = fgx_knob("FGX_SEG_WPB"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= WAVES_PER_BLOCK ? v : WAVES_PER_BLOCK); }();   // (measurement knob)
       if (use_seg && mean_span + (16 * 8 + 64) <= seg_bytes / 4) chain.push_back({4, seg_bytes, seg_wpb});
       // (two families per wavefront measured slower than one at depth 8 — 14.9 vs 10.7 ms per 1 M families: the column phase costs
       // the same per family and a CU holds 12 instead of 20 wavefronts; kept behind FGX_SEG2=1 for experiments)
-      static const bool use_seg2 = [] { const char* e = getenv("FGX_SEG2"); return e && e[0] == '1'; }();
+      static const bool use_seg2 = [] { const char* e = fgx_knob("FGX_SEG2"); return e && e[0] == '1'; }();
       if (use_seg && use_seg2 && mean_span + (32 * 8 + 64) <= seg_bytes / 2) chain.push_back({2, seg_bytes, (uint32_t)WAVES_PER_BLOCK});
       // (Two workgroup-cooperative variants were built, verified byte-identical and measured slower — the record phases of four
       // families on ONE wavefront while the other three wait at a barrier, 11.9 ms, and the same as a producer / consumer pipeline
@@ -4140,12 +4375,14 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       // independent wavefronts, not by lane utilisation.  profiles/r02c_pmc_1M_blk.json, r02d_pmc_1M_pipe.json; HISTORY.md §4.)
       // wavefronts per workgroup of k_simplex_wave2's first launch: the LDS of a workgroup is freed when its SLOWEST wavefront is
       // done, so small workgroups keep more wavefronts running (FGX_W2_WPB: measurement knob)
-      static const uint32_t w2_wpb = [] { const char* e = getenv("FGX_W2_WPB"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= WAVES_PER_BLOCK ? v : FGX_W2_WPB_DEFAULT); }();
+      static const uint32_t w2_wpb = [] { const char* e = fgx_knob("FGX_W2_WPB"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= WAVES_PER_BLOCK ? v : FGX_W2_WPB_DEFAULT); }();
       for (int st = 0; st < 3; st++) if (st == 0 || stages[st] > stages[st - 1]) chain.push_back({1, stages[st], st == 0 ? w2_wpb : st == 1 ? 2u : 1u});
       d_retry_old.reserve((size_t)n_grp * 4);
       uint32_t* d_cnt_old = (uint32_t*)(misc + 32);
       int v2_out = 0;
+      bool v2_ran = false;
       for (size_t ci = 0; ci < chain.size() && n_v2; ci++) {
+        v2_ran = true;
         const Stage& S = chain[ci];
         const bool last = ci + 1 == chain.size();
         hip_check(hipMemsetAsync(d_cnt, 0, 4, s), "memset");
@@ -4156,18 +4393,20 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
         const uint32_t fpb = S.wpb * (uint32_t)S.fam_per_wave;      // families per workgroup
         const dim3 grid((n_v2 + fpb - 1) / fpb), block(64 * S.wpb);
         const size_t lds = (size_t)S.wpb * S.bytes;
-        if (S.fam_per_wave == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_simplex_seg<4>), grid, block, lds, s, PS, n_v2);
-        else if (S.fam_per_wave == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_simplex_seg<2>), grid, block, lds, s, PS, n_v2);
-        else hipLaunchKernelGGL(k_simplex_wave2, grid, block, lds, s, PS, n_v2);
+        if (S.fam_per_wave == 4) do { last_launches++; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_simplex_seg<4>), grid, block, lds, s, PS, n_v2); } while (0);
+        else if (S.fam_per_wave == 2) do { last_launches++; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_simplex_seg<2>), grid, block, lds, s, PS, n_v2); } while (0);
+        else do { last_launches++; hipLaunchKernelGGL(k_simplex_wave2, grid, block, lds, s, PS, n_v2); } while (0);
         hip_check(hipGetLastError(), "k_simplex launch");
         uint32_t n_next = 0;
         hip_check(hipMemcpyAsync(&n_next, d_cnt, 4, hipMemcpyDeviceToHost, s), "D2H");
-        hip_check(hipStreamSynchronize(s), "sync");
+        FGX_SYNC(s);
         v2_list = lists[v2_out]; n_v2 = PS.retry ? n_next : 0; v2_out ^= 1;
       }
       uint32_t n_old = 0;
-      hip_check(hipMemcpyAsync(&n_old, d_cnt_old, 4, hipMemcpyDeviceToHost, s), "D2H");
-      hip_check(hipStreamSynchronize(s), "sync");
+      if (v2_ran) {   // (no kernel of the chain has run — the split pipeline kept every family —: nothing to read, no synchronisation)
+        hip_check(hipMemcpyAsync(&n_old, d_cnt_old, 4, hipMemcpyDeviceToHost, s), "D2H");
+        FGX_SYNC(s);
+      }
       n_cur = n_old; cur_list = d_retry_old.as<uint32_t>();
       out_list = 0;
     }
@@ -4180,27 +4419,30 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       PS.retry = (last && (duplex || codec)) ? nullptr : lists[out_list]; PS.n_retry = d_cnt;
       // fewer wavefronts per workgroup as the slices grow: the LDS a workgroup asks for is what limits the wavefronts a CU holds
       // (4 x 22 KB = one workgroup = 4 waves per CU; 1 x 22 KB = six workgroups = 6 waves)
-      static const uint32_t fw_wpb = [] { const char* e = getenv("FGX_FW_WPB"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= WAVES_PER_BLOCK ? v : WAVES_PER_BLOCK); }();   // (measurement knob)
+      static const uint32_t fw_wpb = [] { const char* e = fgx_knob("FGX_FW_WPB"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= WAVES_PER_BLOCK ? v : WAVES_PER_BLOCK); }();   // (measurement knob)
       const uint32_t wpb = st == 0 ? fw_wpb : st == 1 ? 2u : 1u;
       const dim3 grid((n_cur + wpb - 1) / wpb), block(64 * wpb);
       const size_t lds = (size_t)wpb * stages[st];
-      if (codec) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_family_wave<2>), grid, block, lds, s, PS, n_cur);
-      else if (duplex) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_family_wave<1>), grid, block, lds, s, PS, n_cur);
-      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_family_wave<0>), grid, block, lds, s, PS, n_cur);
+      if (codec) do { last_launches++; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_family_wave<2>), grid, block, lds, s, PS, n_cur); } while (0);
+      else if (duplex) do { last_launches++; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_family_wave<1>), grid, block, lds, s, PS, n_cur); } while (0);
+      else do { last_launches++; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_family_wave<0>), grid, block, lds, s, PS, n_cur); } while (0);
       hip_check(hipGetLastError(), "k_family_wave launch");
       uint32_t n_next = 0;
       hip_check(hipMemcpyAsync(&n_next, d_cnt, 4, hipMemcpyDeviceToHost, s), "D2H");
-      hip_check(hipStreamSynchronize(s), "sync");
+      FGX_SYNC(s);
       cur_list = lists[out_list]; n_cur = PS.retry ? n_next : 0; out_list ^= 1;
     }
     uint32_t n_big = 0;
     if (!duplex && !codec) {
-      hip_check(hipMemcpyAsync(&n_big, d_cnt_big, 4, hipMemcpyDeviceToHost, s), "D2H");
-      hip_check(hipStreamSynchronize(s), "sync");
+      if (split_counts_seen && last_routed == 0) n_big = h_big_seen;   // (no kernel after the split stages has run: what their last synchronisation read is final)
+      else {
+        hip_check(hipMemcpyAsync(&n_big, d_cnt_big, 4, hipMemcpyDeviceToHost, s), "D2H");
+        FGX_SYNC(s);
+      }
     }
     if (meth_dev) {
       d_big.reserve((size_t)n_grp * 4);
-      hipLaunchKernelGGL(k_iota, dim3((n_grp + 255) / 256), dim3(256), 0, s, d_big.as<uint32_t>(), n_grp);
+      do { last_launches++; hipLaunchKernelGGL(k_iota, dim3((n_grp + 255) / 256), dim3(256), 0, s, d_big.as<uint32_t>(), n_grp); } while (0);
       n_big = n_grp;
     }
     last_big_families = n_big;
@@ -4210,11 +4452,11 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
     const uint32_t* big_list = d_big.as<uint32_t>();
     if (n_big && (use_deep || meth_dev) && !o.trim) {
       if (!d_s2img.p) {   // (the column kernel's LDS tables: the split pipeline's image)
-        S2Lds* img = new S2Lds;
+        S2Image* img = new S2Image;
         build_s2_image(*img, c->h_tables.t);
-        d_s2img.reserve(sizeof(S2Lds));
-        hip_check(hipMemcpyAsync(d_s2img.p, img, sizeof(S2Lds), hipMemcpyHostToDevice, s), "H2D s2 image");
-        hip_check(hipStreamSynchronize(s), "sync");
+        d_s2img.reserve(sizeof(S2Image));
+        hip_check(hipMemcpyAsync(d_s2img.p, img, sizeof(S2Image), hipMemcpyHostToDevice, s), "H2D s2 image");
+        FGX_SYNC(s);
         delete img;
       }
       P.s2_image = d_s2img.p;
@@ -4222,7 +4464,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       // one pass of the streaming kernels over a family list; returns how many families it handed on (to `out_list`)
       auto deep_pass = [&](const uint32_t* list, uint32_t n_list, bool small, uint32_t* out_list) -> uint32_t {
         d_deep_sizes.reserve((size_t)n_list * 8 + 64); d_deep_row0.reserve((size_t)n_list * 8 + 64);
-        hipLaunchKernelGGL(k_deep_sizes, dim3((n_list + 255) / 256), dim3(256), 0, s, list, n_list, d_grp_first, d_deep_sizes.as<uint64_t>());
+        do { last_launches++; hipLaunchKernelGGL(k_deep_sizes, dim3((n_list + 255) / 256), dim3(256), 0, s, list, n_list, d_grp_first, d_deep_sizes.as<uint64_t>()); } while (0);
         size_t tb = 0;
         (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_deep_sizes.as<uint64_t>(), d_deep_row0.as<uint64_t>(), (int)n_list, s);
         d_scan_tmp.reserve(tb);
@@ -4230,7 +4472,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
         uint64_t lastr[2] = {0, 0};
         hip_check(hipMemcpyAsync(&lastr[0], d_deep_row0.as<uint64_t>() + (n_list - 1), 8, hipMemcpyDeviceToHost, s), "D2H");
         hip_check(hipMemcpyAsync(&lastr[1], d_deep_sizes.as<uint64_t>() + (n_list - 1), 8, hipMemcpyDeviceToHost, s), "D2H");
-        hip_check(hipStreamSynchronize(s), "sync");
+        FGX_SYNC(s);
         const uint64_t n_rows = lastr[0] + lastr[1];
         if (n_rows > (uint64_t)n_rec) throw std::runtime_error("device pipeline: " + std::to_string(n_rows) + " rows for the streaming kernels, more than the batch has records");
         d_deep_rows.reserve((size_t)n_rows * sizeof(DeepRow) + 64); d_deep_fams.reserve((size_t)n_list * sizeof(DeepFam) + 64);
@@ -4240,15 +4482,15 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
         DP.rows = d_deep_rows.as<DeepRow>(); DP.fams = d_deep_fams.as<DeepFam>(); DP.out_list = out_list; DP.n_out = d_cnt_deep;
         FastParams PD = P;
         PD.group_list = nullptr;
-        if (small) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_deep_parse<64, 64>), dim3(n_list), dim3(64), 0, s, PD, DP);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_deep_parse<256, DEEP_MAX>), dim3(n_list), dim3(256), 0, s, PD, DP);
+        if (small) do { last_launches++; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_deep_parse<64, 64>), dim3(n_list), dim3(64), 0, s, PD, DP); } while (0);
+        else do { last_launches++; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_deep_parse<256, DEEP_MAX>), dim3(n_list), dim3(256), 0, s, PD, DP); } while (0);
         hip_check(hipGetLastError(), "k_deep_parse launch");
-        if (meth_dev) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_deep_cols<1>), dim3((n_list + 3) / 4), dim3(256), 0, s, PD, DP);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_deep_cols<0>), dim3((n_list + 3) / 4), dim3(256), 0, s, PD, DP);
+        if (meth_dev) do { last_launches++; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_deep_cols<1>), dim3((n_list + 3) / 4), dim3(256), 0, s, PD, DP); } while (0);
+        else do { last_launches++; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_deep_cols<0>), dim3((n_list + 3) / 4), dim3(256), 0, s, PD, DP); } while (0);
         hip_check(hipGetLastError(), "k_deep_cols launch");
         uint32_t n_left = 0;
         hip_check(hipMemcpyAsync(&n_left, d_cnt_deep, 4, hipMemcpyDeviceToHost, s), "D2H");
-        hip_check(hipStreamSynchronize(s), "sync");
+        FGX_SYNC(s);
         return n_left;
       };
       d_deep_out.reserve((size_t)n_big * 4 + 64);
@@ -4274,9 +4516,9 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       if (!cnt) continue;
       FastParams P2 = P;
       P2.group_list = pass == 0 ? cur_list : big_list; P2.retry = nullptr; P2.n_retry = nullptr;
-      if (const char* e = getenv("FGX_LDS_TILE_LARGE")) { uint32_t v = (uint32_t)atoi(e); if (v >= 16384 && v <= 163840) lds_tile_bytes_large = v & ~15u; P2.lds_tile_bytes = lds_tile_bytes_large; }   // tuning knob
+      if (const char* e = fgx_knob("FGX_LDS_TILE_LARGE")) { uint32_t v = (uint32_t)atoi(e); if (v >= 16384 && v <= 163840) lds_tile_bytes_large = v & ~15u; P2.lds_tile_bytes = lds_tile_bytes_large; }   // tuning knob
       hip_check(hipFuncSetAttribute((const void*)k_family, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile_bytes_large), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_family: the device refused the dynamic LDS size");
-      hipLaunchKernelGGL(k_family, dim3(cnt), dim3(NT), lds_tile_bytes_large, s, P2);
+      do { last_launches++; hipLaunchKernelGGL(k_family, dim3(cnt), dim3(NT), lds_tile_bytes_large, s, P2); } while (0);
       hip_check(hipGetLastError(), "k_family (large) launch");
     }
   }
@@ -4284,7 +4526,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
   {   // dense call_full pass over the compacted lists
     std::vector<uint32_t> counts(N_LISTS);
     hip_check(hipMemcpyAsync(counts.data(), d_full_count.p, (size_t)N_LISTS * 4, hipMemcpyDeviceToHost, s), "D2H");
-    hip_check(hipStreamSynchronize(s), "sync");
+    FGX_SYNC(s);
     uint32_t mx = 0, mn = 0xFFFFFFFFu;
     for (uint32_t v : counts) { uint32_t vv = v < full_cap ? v : full_cap; mx = vv > mx ? vv : mx; mn = v < mn ? v : mn; n_full += vv; }
     if (mn >= full_cap && pool_div > 1) {
@@ -4294,7 +4536,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       const uint64_t want = (col_cap / (pool_div / 2) + (uint64_t)N_LISTS * pool_slack) * sizeof(FullItem);
       if (want < (uint64_t)free_b + (uint64_t)d_full_items.cap) {
         pool_div /= 2;
-        static const bool verbose = [] { const char* e = getenv("FGX_S2_VERBOSE"); return e && e[0] == '1'; }();
+        static const bool verbose = [] { const char* e = fgx_knob("FGX_S2_VERBOSE"); return e && e[0] == '1'; }();
         if (verbose) fprintf(stderr, "[fgx] call_full pool exhausted: the batch again with 1/%u of the column bound\n", pool_div);
         return RUN_AGAIN_LARGER_POOL;
       }
@@ -4310,12 +4552,12 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       if (duplex) { F.rx_base = (char*)P.dends + offsetof(DuplexDesc, rx); F.rx_stride = sizeof(DuplexDesc); }
       else if (codec) { F.rx_base = (char*)P.cends + offsetof(CodecDesc, rx); F.rx_stride = sizeof(CodecDesc); }
       else { F.rx_base = (char*)P.ends + offsetof(EndDesc, rx); F.rx_stride = sizeof(EndDesc); }
-      hipLaunchKernelGGL(k_call_full, dim3((mx + 255) / 256, N_LISTS), dim3(256), 0, s, F);
+      do { last_launches++; hipLaunchKernelGGL(k_call_full, dim3((mx + 255) / 256, N_LISTS), dim3(256), 0, s, F); } while (0);
       hip_check(hipGetLastError(), "k_call_full launch");
     }
   }
   if (meth_dev) {   // the methylation tags' share of the record sizes: the consensus bases are final now
-    hipLaunchKernelGGL(k_meth_sizes, dim3((n_slots + 3) / 4), dim3(256), 0, s, P, n_slots, d_mslot.as<MethSlot>());
+    do { last_launches++; hipLaunchKernelGGL(k_meth_sizes, dim3((n_slots + 3) / 4), dim3(256), 0, s, P, n_slots, d_mslot.as<MethSlot>()); } while (0);
     hip_check(hipGetLastError(), "k_meth_sizes launch");
   }
   // ---- direct records: cE of the records whose columns had errors; did every prediction hold; is there anything to merge? ----------
@@ -4323,15 +4565,15 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
   uint32_t dir_routed = 0;
   uint64_t dir_total = 0;
   if (direct) {
-    hipLaunchKernelGGL(k_fix_ce, dim3((n_slots + 255) / 256), dim3(256), 0, s, d_slot_desc.as<SlotDesc>(), d_slot_err.as<uint32_t>(), n_slots, d_out.as<uint8_t>(), P.rg_len);
+    do { last_launches++; hipLaunchKernelGGL(k_fix_ce, dim3((n_slots + 255) / 256), dim3(256), 0, s, d_slot_desc.as<SlotDesc>(), d_slot_err.as<uint32_t>(), n_slots, d_out.as<uint8_t>(), P.rg_len); } while (0);
     hip_check(hipGetLastError(), "k_fix_ce launch");
     unsigned long long h_flags = 0, h_def = 0, h_route = 0;
     hip_check(hipMemcpyAsync(&h_flags, misc + 36, 8, hipMemcpyDeviceToHost, s), "D2H");
     hip_check(hipMemcpyAsync(&h_def, misc + 29, 8, hipMemcpyDeviceToHost, s), "D2H");
     hip_check(hipMemcpyAsync(&h_route, misc + 33, 8, hipMemcpyDeviceToHost, s), "D2H");
     hip_check(hipMemcpyAsync(&dir_total, d_dir_base.as<uint64_t>() + dir_chunks_run, 8, hipMemcpyDeviceToHost, s), "D2H");
-    hip_check(hipStreamSynchronize(s), "sync");
-    static const bool dir_verbose = [] { const char* e = getenv("FGX_S2_VERBOSE"); return e && e[0] == '1'; }();
+    FGX_SYNC(s);
+    static const bool dir_verbose = [] { const char* e = fgx_knob("FGX_S2_VERBOSE"); return e && e[0] == '1'; }();
     if ((uint32_t)h_flags != 0) {          // a family's records are not what k_split_parse predicted: nothing of the batch can be trusted to be in place
       fprintf(stderr, "[fgx] direct records: %u families differ in size from the prediction; this caller goes back to the column scratch (please report)\n", (uint32_t)h_flags);
       direct_off = true;
@@ -4361,7 +4603,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
     uint64_t last[2];
     hip_check(hipMemcpyAsync(&last[0], d_offsets.as<uint64_t>() + (n_slots - 1), 8, hipMemcpyDeviceToHost, s), "D2H");
     hip_check(hipMemcpyAsync(&last[1], d_sizes.as<uint64_t>() + (n_slots - 1), 8, hipMemcpyDeviceToHost, s), "D2H");
-    hip_check(hipStreamSynchronize(s), "sync");
+    FGX_SYNC(s);
     out_len = last[0] + last[1];
     if (out_len > (1ull << 40)) throw std::runtime_error("device pipeline: the scan of the record sizes gives " + std::to_string(out_len) + " bytes of output (a record size is corrupt)");
     if (direct) { d_out2.reserve(out_len + 16); out_ptr = d_out2.as<uint8_t>(); }   // the merged stream: d_out holds the directly written records
@@ -4387,8 +4629,8 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
     CE.has_outer = o.codec_has_outer_bases_qual; CE.outer_qual = o.codec_outer_bases_qual; CE.outer_len = o.codec_outer_bases_length;
     CE.has_ss = o.codec_has_single_strand_qual; CE.ss_qual = o.codec_single_strand_qual;
     CE.stats = d_statslots.as<unsigned long long>();
-    hipLaunchKernelGGL(k_emit_codec_fast, dim3((n_slots + 3) / 4), dim3(256), 0, s, CE);
-    hipLaunchKernelGGL(k_emit_codec, dim3((n_slots + 3) / 4), dim3(256), 0, s, CE);
+    do { last_launches++; hipLaunchKernelGGL(k_emit_codec_fast, dim3((n_slots + 3) / 4), dim3(256), 0, s, CE); } while (0);
+    do { last_launches++; hipLaunchKernelGGL(k_emit_codec, dim3((n_slots + 3) / 4), dim3(256), 0, s, CE); } while (0);
   } else if (duplex) {
     DuplexEmitParams DE;
     memset(&DE, 0, sizeof(DE));
@@ -4397,31 +4639,31 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
     DE.col_code = P.col_code; DE.col_qual = P.col_qual; DE.col_err = P.col_err; DE.col_obs = P.col_obs;
     DE.prefix = E.prefix; DE.prefix_len = E.prefix_len; DE.rg = E.rg; DE.rg_len = E.rg_len;
     DE.per_base_tags = P.per_base_tags; DE.cell0 = P.cell0; DE.cell1 = P.cell1;
-    hipLaunchKernelGGL(k_emit_duplex_fast, dim3((n_slots + 3) / 4), dim3(256), 0, s, DE);
-    hipLaunchKernelGGL(k_emit_duplex, dim3((n_slots + 3) / 4), dim3(256), 0, s, DE);
+    do { last_launches++; hipLaunchKernelGGL(k_emit_duplex_fast, dim3((n_slots + 3) / 4), dim3(256), 0, s, DE); } while (0);
+    do { last_launches++; hipLaunchKernelGGL(k_emit_duplex, dim3((n_slots + 3) / 4), dim3(256), 0, s, DE); } while (0);
   } else if (direct) {
     if (!dir_pure) {
       // the merge: the families that left the split pipeline are written by k_emit from their descriptors, the directly written ones move
       // to their place in the final stream
       if (dir_routed) {
         E.fam_list = d_route.as<uint32_t>(); E.n_fam = dir_routed;
-        hipLaunchKernelGGL(k_emit, dim3((dir_routed + 3) / 4), dim3(256), 0, s, E);
+        do { last_launches++; hipLaunchKernelGGL(k_emit, dim3((dir_routed + 3) / 4), dim3(256), 0, s, E); } while (0);
       }
-      hipLaunchKernelGGL(k_dir_copy, dim3((n_grp + 3) / 4), dim3(256), 0, s, d_split_out.as<SplitOut>(), d_dir_off.as<uint64_t>(), d_offsets.as<uint64_t>(),
-                         d_sizes.as<uint64_t>(), d_out.as<uint8_t>(), out_ptr, n_grp);
+      do { last_launches++; hipLaunchKernelGGL(k_dir_copy, dim3((n_grp + 3) / 4), dim3(256), 0, s, d_split_out.as<SplitOut>(), d_dir_off.as<uint64_t>(), d_offsets.as<uint64_t>(),
+                         d_sizes.as<uint64_t>(), d_out.as<uint8_t>(), out_ptr, n_grp); } while (0);
     }
-  } else hipLaunchKernelGGL(k_emit, dim3((n_grp + 3) / 4), dim3(256), 0, s, E);   // one wavefront per family (slots 3g .. 3g + 2)
+  } else do { last_launches++; hipLaunchKernelGGL(k_emit, dim3((n_grp + 3) / 4), dim3(256), 0, s, E); } while (0);   // one wavefront per family (slots 3g .. 3g + 2)
   hip_check(hipGetLastError(), "k_emit launch");
   if (meth_dev) {
-    hipLaunchKernelGGL(k_meth_tail, dim3((n_slots + 3) / 4), dim3(256), 0, s, P, n_slots, d_mslot.as<MethSlot>(), d_offsets.as<uint64_t>(), out_ptr);
+    do { last_launches++; hipLaunchKernelGGL(k_meth_tail, dim3((n_slots + 3) / 4), dim3(256), 0, s, P, n_slots, d_mslot.as<MethSlot>(), d_offsets.as<uint64_t>(), out_ptr); } while (0);
     hip_check(hipGetLastError(), "k_meth_tail launch");
   }
   hip_check(hipEventRecord(ev[3], s), "event");
   hip_check(hipEventRecord(c->ev1, s), "event");
-  hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(64), 0, s, d_statslots.as<unsigned long long>(), misc);
-  unsigned long long h_misc[32];
+  do { last_launches++; hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(64), 0, s, d_statslots.as<unsigned long long>(), misc); } while (0);
+  unsigned long long h_misc[44];
   hip_check(hipMemcpyAsync(h_misc, misc, sizeof(h_misc), hipMemcpyDeviceToHost, s), "D2H");
-  hip_check(hipStreamSynchronize(s), "sync");
+  FGX_SYNC(s);
   float ms = 0;
   hip_check(hipEventElapsedTime(&ms, c->ev0, c->ev1), "elapsed");
 
@@ -4439,6 +4681,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
   hip_check(hipEventElapsedTime(&msf, ev[0], ev[1]), "elapsed");
   hip_check(hipEventElapsedTime(&mse, ev[2], ev[3]), "elapsed");
   res->ms_k_family = msf; res->ms_k_emit = mse;
+  last_packed_families = h_misc[40]; last_classic_families = h_misc[41];
   res->cols_used = h_misc[28];
   res->full_items = n_full;
   return 0;

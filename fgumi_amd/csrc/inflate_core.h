@@ -226,7 +226,7 @@ FGX_HD inline void infl_store_pending(uint8_t* dst, uint32_t n, uint64_t v0, uin
 constexpr uint32_t INFL_ENTRY_CAP = 65536 / 3 + 65536 / 255 + 2 * 258 + 64;      // 22 681
 // the entries a block of `isize` bytes can need, rounded up to whole 64-byte lines of 32-bit entries: what the device gives a block's list
 // (round 6: lists are laid out back to back by ISIZE, engine.h bgzf_inflate_plan; round 5 gave every block the 64 KiB worst case)
-FGX_HD inline uint32_t infl_entry_cap(uint32_t isize) { return (isize / 3u + isize / 255u + 2u + 15u) & ~15u; }
+FGX_HD constexpr uint32_t infl_entry_cap(uint32_t isize) { return (isize / 3u + isize / 255u + 2u + 15u) & ~15u; }
 FGX_HD inline uint32_t infl_entry(uint32_t lit, uint32_t dist, uint32_t len) { return (lit << 24) | ((dist - 1u) << 9) | (len - 2u); }
 FGX_HD inline uint32_t infl_entry_lit(uint32_t e) { return e >> 24; }
 FGX_HD inline uint32_t infl_entry_len(uint32_t e) { const uint32_t c = e & 511u; return c ? c + 2u : 0u; }

@@ -137,5 +137,28 @@ inline void fill_t1(uint8_t* t1 /* [96] */, const ConsensusTables& t) {
   }
 }
 
+// Two observations of ONE base, qualities q1 then q2 in file order (round 6): the same evaluation — two steps of ConsensusBaseBuilder::add
+// (the Kahan sums in the reference's order), then the call.  t2[q1 * 94 + q2] = the consensus quality, 0xFF where the call does not come
+// back with the observed base.  Such columns are the second most frequent kind the packed pass flags (1.1 per depth-8 family of `simulate`
+// data: the read-through zone, where a random subset of the rows survives the overlap correction); answered from the table they need no
+// k_call_full item.
+constexpr uint32_t T2_DIM = 94, T2_BYTES = T2_DIM * T2_DIM;
+inline void fill_t2(uint8_t* t2 /* [T2_BYTES] */, const ConsensusTables& t) {
+  for (uint32_t q1 = 0; q1 < T2_DIM; q1++)
+    for (uint32_t q2 = 0; q2 < T2_DIM; q2++) {
+      uint8_t& out = t2[q1 * T2_DIM + q2];
+      out = 0xFF;
+      ColumnAcc acc;
+      acc.reset();
+      acc.add(0, t.correct[q1], t.error_per_alt[q1]);
+      acc.add(0, t.correct[q2], t.error_per_alt[q2]);
+      if (!m_isfinite(acc.s[0]) || !m_isfinite(acc.s[1])) continue;
+      int bi = -1;
+      uint8_t ql = 0;
+      column_call(t, acc.s, acc.obs, &bi, &ql);
+      if (bi == 0) out = ql;
+    }
+}
+
 }  // namespace pk
 }  // namespace fgx

@@ -194,29 +194,44 @@ class ConsensusFilter:
 
     def set_reference(self, reference, ref_names: Sequence[str]):
         """`--ref <fasta>`: `reference` maps a contig name to its bases, `ref_names[i]` = the name of contig i of the BAM header (a record's
-        reference id).  A header contig that `reference` lacks raises `KeyError` HERE: the reference fails with "Reference not found: <contig>"
-        at the first record that needs the contig (alignment_tags.rs:482) — an empty stand-in would instead surface as a generic
-        out-of-range error there, and the reference-dependent methylation filters would read every base of that contig as unknown.
-        `set_reference(None, [])` drops the reference again."""
+        reference id).  A header contig that `reference` lacks is NOT an error here: the reference fails lazily, with
+        "Reference not found: <contig>", at the first mapped record that needs the contig (fgumi-sam alignment_tags.rs:272-300, 482) — a BAM
+        whose header lists decoy / alt contigs with no reads on them filters fine there, and does here.  The missing contigs are
+        remembered, get an empty stand-in on the device, and `filter_stream` / `filter_device` raise `KeyError("Reference not found: <contig>")`
+        before anything is filtered when a mapped record of the batch lies on one.  `set_reference(None, [])` drops the reference again."""
         names = list(ref_names or [])
+        self._missing = {}
         if reference is None or not names:
             self._check(lib.fgx_set_reference(self._h, 0, None, None))
             self._o.regenerate_alignment_tags = 0
             return
-        missing = [n for n in names if n not in reference]
-        if missing:
-            raise KeyError(f"Reference not found: {missing[0]} (header contig absent from the FASTA; {len(missing)} of {len(names)} missing)")
-        seqs = [bytes(reference[n]) for n in names]
+        self._missing = {i: n for i, n in enumerate(names) if n not in reference}
+        seqs = [b"" if i in self._missing else bytes(reference[n]) for i, n in enumerate(names)]
         bufs = [C.create_string_buffer(s, max(1, len(s))) for s in seqs]
         ptrs = (C.c_void_p * len(seqs))(*[C.cast(b, C.c_void_p).value for b in bufs])
         lens = (C.c_uint64 * len(seqs))(*[len(s) for s in seqs])
         self._check(lib.fgx_set_reference(self._h, len(seqs), ptrs, lens))
         self._o.regenerate_alignment_tags = 1
 
+    def _refuse_missing_contigs(self, ref_id, flag):
+        """`ref_id` / `flag` of the batch's records (numpy arrays): the reference's lazy "Reference not found" for a mapped record on a contig the FASTA lacks."""
+        missing = getattr(self, "_missing", None)
+        if not missing or not self._o.regenerate_alignment_tags:
+            return
+        mapped = (flag & 0x4) == 0
+        hit = mapped & np.isin(ref_id, np.fromiter(missing.keys(), dtype=np.int64))
+        if hit.any():
+            raise KeyError(f"Reference not found: {missing[int(ref_id[np.argmax(hit)])]}")
+
     def filter_stream(self, blob: np.ndarray, rec_off: np.ndarray, rec_len: np.ndarray) -> FilterResult:
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
         rec_off = np.ascontiguousarray(rec_off, dtype=np.uint64)
         rec_len = np.ascontiguousarray(rec_len, dtype=np.uint32)
+        if getattr(self, "_missing", None) and len(rec_off):
+            o = rec_off.astype(np.int64)
+            rid = (blob[o].astype(np.int64) | (blob[o + 1].astype(np.int64) << 8) | (blob[o + 2].astype(np.int64) << 16) | (blob[o + 3].astype(np.int64) << 24))
+            rid = np.where(rid >= 1 << 31, rid - (1 << 32), rid)
+            self._refuse_missing_contigs(rid, blob[o + 14].astype(np.int64) | (blob[o + 15].astype(np.int64) << 8))
         out = FilterOutput()
         self._check(lib.fgx_filter_records(self._h, C.byref(self._o), blob.ctypes.data, blob.size, rec_off.ctypes.data, rec_len.ctypes.data, len(rec_off),
                                            C.byref(out)))
@@ -232,6 +247,12 @@ class ConsensusFilter:
         """torch tensors resident in HBM; `blob` is masked in place, outputs stay in HBM."""
         import torch
         torch.cuda.synchronize(blob.device)
+        if getattr(self, "_missing", None) and n_rec:
+            o = rec_off[:n_rec].view(torch.int64)
+            b = blob.view(torch.uint8)
+            rid = (b[o].long() | (b[o + 1].long() << 8) | (b[o + 2].long() << 16) | (b[o + 3].long() << 24)).cpu().numpy()
+            rid = np.where(rid >= 1 << 31, rid - (1 << 32), rid)
+            self._refuse_missing_contigs(rid, (b[o + 14].long() | (b[o + 15].long() << 8)).cpu().numpy())
         out = FilterOutput()
         self._check(lib.fgx_filter_records_device(self._h, C.byref(self._o), blob.data_ptr(), blob_len, rec_off.data_ptr(), rec_len.data_ptr(), n_rec, C.byref(out)))
         return DeviceFilterResult(out.data or 0, int(out.data_len), out.rejects or 0, int(out.rejects_len), int(out.records_count), int(out.passed_count),

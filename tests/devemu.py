@@ -48,6 +48,8 @@ def lib():
         L.demu_packed_end.argtypes = [VP, VP, U32, U32, U32, U32, U32, C.c_int, U32, U32, U32, U32, U32, VP, VP, VP, VP]
         L.demu_t1.argtypes = [C.c_uint8, C.c_uint8, U32, VP]
         L.demu_t1.restype = None
+        L.demu_t2.argtypes = [C.c_uint8, C.c_uint8, U32, VP]
+        L.demu_t2.restype = None
         _lib = L
     return _lib
 
@@ -138,3 +140,10 @@ def t1_table(pre, post, tie=0):
     t = np.zeros(96, dtype=np.uint8)
     lib().demu_t1(pre, post, tie, t.ctypes.data)
     return t
+
+
+def t2_table(pre, post, tie=0):
+    """S2Image::t2: the consensus quality of a column that holds TWO observations of one base, [q1 * 94 + q2] in file order (0xFF: no table answer)."""
+    t = np.zeros(94 * 94, dtype=np.uint8)
+    lib().demu_t2(pre, post, tie, t.ctypes.data)
+    return t.reshape(94, 94)

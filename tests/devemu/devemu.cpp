@@ -217,4 +217,12 @@ void demu_t1(uint8_t pre, uint8_t post, uint32_t tie, uint8_t* t1) {
   fgx::pk::fill_t1(t1, t);
 }
 
+// S2Image::t2 (packed_core.h fill_t2): two observations of one base, by their qualities in file order
+void demu_t2(uint8_t pre, uint8_t post, uint32_t tie, uint8_t* t2) {
+  fgx::ConsensusTables t;
+  memset(&t, 0, sizeof(t));
+  fgx::build_tables(t, pre, post, tie);
+  fgx::pk::fill_t2(t2, t);
+}
+
 }  // extern "C"

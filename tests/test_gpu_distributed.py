@@ -72,3 +72,34 @@ def test_two_ranks_on_one_gpu_concatenate_to_the_oracle_output_of_the_whole_stre
     assert sizes[:, 1].sum() == want["count"] and sizes[:, 2].sum() == g.n_rec and sizes[:, 0].sum() == len(want["data"])
     n = len(want["stats"])
     assert np.array_equal(stats[:n], want["stats"].astype(np.int64))
+
+
+# ---- bench.py beyond one rank: the whole line first, the gather to rank 0 last and under a watchdog -----------------------------
+def _bench_two_ranks(extra_env, timeout_s):
+    import json
+    import subprocess
+    env = dict(os.environ, FGX_BENCH_TEST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", **extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--families", "20000", "--gather-timeout", str(timeout_s)]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_prints_one_line_with_the_gather_beside():
+    d = _bench_two_ranks({}, 120)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["reassemble_error"] is None
+    assert d["config"]["value_with_reassembly_on_root"] and d["config"]["reassembled_bytes_on_rank0"] == d["config"]["output_bytes"]
+    assert d["strong_scaling"]["value"] > 0 and d["strong_scaling"]["value_with_reassembly_on_root"]
+
+
+@pytest.mark.timeout(900)
+def test_bench_survives_a_rank_that_fails_in_the_gather():
+    """Rank 1 throws inside the gather loop: rank 0 is blocked in its receive and no exception reaches it — the watchdog prints the line as
+    it stood before the gather and every rank leaves with exit code 0."""
+    d = _bench_two_ranks({"FGX_BENCH_TEST_GATHER_FAIL": "1"}, 15)
+    assert d["value"] > 0 and d["config"]["reassemble_error"] and d["config"]["value_with_reassembly_on_root"] is None
+    assert d["strong_scaling"]["value"] > 0

@@ -336,6 +336,13 @@ def test_filter_with_a_reference_regenerates_alignment_tags(kw):
     f.set_reference({"chr0": contigs[0][:50], "chr1": contigs[1]}, ["chr0", "chr1"])
     with pytest.raises(RuntimeError, match="leaves its reference"):
         f.filter_stream(blob, off, ln)
+    # a header contig the FASTA lacks is fatal only when a mapped record lies on it (the reference fails lazily: "Reference not found: <contig>",
+    # fgumi-sam alignment_tags.rs:482): an extra header contig with no reads changes nothing, a contig with reads raises before anything is filtered
+    f.set_reference({f"chr{i}": s for i, s in enumerate(contigs)}, ["chr0", "chr1", "chrUn_decoy"])
+    assert f.filter_stream(blob, off, ln).data == want["data"]
+    f.set_reference({"chr0": contigs[0]}, ["chr0", "chr1"])
+    with pytest.raises(KeyError, match="Reference not found: chr1"):
+        f.filter_stream(blob, off, ln)
     f.close()
 
 

@@ -151,3 +151,23 @@ def test_one_observation_table_is_the_builders_call(pre, post):
             answered += 1
     assert answered >= 80
     assert (t1[94:] == 0xFF).all()
+
+
+@pytest.mark.parametrize("pre,post", SETTINGS + [(93, 93)])
+def test_two_observation_table_is_the_builders_call(pre, post):
+    """Round 6: S2Image::t2 — two observations of one base, qualities in file order — against the oracle's ConsensusBaseBuilder, every pair of qualities."""
+    t2 = devemu.t2_table(pre, post)
+    b = orc.Builder(pre, post)
+    answered = 0
+    for q1 in range(94):
+        for q2 in range(94):
+            b.reset()
+            b.add("C", q1)
+            b.add("C", q2)
+            base, ql = b.call()
+            if t2[q1, q2] == 0xFF:
+                assert base != "C" or q1 == 0 or q2 == 0, (q1, q2, base, ql)
+            else:
+                assert (base, ql) == ("C", int(t2[q1, q2])), (q1, q2, base, ql, t2[q1, q2])
+                answered += 1
+    assert answered >= 80 * 80
