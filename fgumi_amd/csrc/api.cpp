@@ -4,6 +4,8 @@
 #include <stdexcept>
 #include <cstring>
 #include <mutex>
+#include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include "engine.h"
@@ -42,19 +44,55 @@ namespace fgx {
 void hip_check(hipError_t e, const char* what) {
   if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
 }
+// ---- guard bands (test infrastructure inside the product's allocator): with FGX_GUARD_BAND=<bytes> in the environment every
+//      device buffer is allocated at EXACTLY the size asked for (no growth slack) between two bands of sentinel bytes, and
+//      fgx_debug_check_guard_bands() verifies the bands of every live buffer — a kernel that stores outside its buffer (scratch columns, item pools,
+//      descriptors, output) leaves a mark there instead of in a neighbour's memory.  Off (the default): one static read of the environment per process.
+namespace {
+constexpr int GUARD_SENTINEL = 0xA5;
+struct GuardRegistry {
+  std::mutex m;
+  std::map<void*, std::pair<size_t, size_t>> live;   // user pointer -> (bytes, band bytes)
+};
+GuardRegistry& guard_registry() { static GuardRegistry g; return g; }
+size_t guard_band_bytes() {
+  static const size_t g = [] { const char* e = getenv("FGX_GUARD_BAND"); const long v = e ? atol(e) : 0; return (size_t)((v > 0 && v <= (1 << 20)) ? ((v + 255) & ~255L) : 0); }();
+  return g;
+}
+}  // namespace
 void DevBuf::reserve(size_t n) {
   if (n <= cap) return;
-  size_t want = n + n / 4 + 256;
-  if (p) hip_check(hipFree(p), "hipFree");
-  p = nullptr;
-  cap = 0;
+  const size_t G = guard_band_bytes();
+  const size_t want = G ? n : n + n / 4 + 256;
+  free_();
+  void* base = nullptr;
   {
-    const hipError_t e = hipMalloc(&p, want);
-    if (e != hipSuccess) { p = nullptr; throw std::runtime_error(std::string("hipMalloc of ") + std::to_string(want) + " bytes: " + hipGetErrorString(e)); }
+    const hipError_t e = hipMalloc(&base, want + 2 * G);
+    if (e != hipSuccess) { p = nullptr; throw std::runtime_error(std::string("hipMalloc of ") + std::to_string(want + 2 * G) + " bytes: " + hipGetErrorString(e)); }
   }
+  if (G) {
+    hip_check(hipMemset(base, GUARD_SENTINEL, G), "hipMemset (guard band)");
+    hip_check(hipMemset((uint8_t*)base + G + want, GUARD_SENTINEL, G), "hipMemset (guard band)");
+    hip_check(hipDeviceSynchronize(), "sync (guard band)");
+    GuardRegistry& R = guard_registry();
+    std::lock_guard<std::mutex> lk(R.m);
+    R.live[(uint8_t*)base + G] = std::make_pair(want, G);
+  }
+  p = (uint8_t*)base + G;
   cap = want;
 }
-void DevBuf::free_() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
+void DevBuf::free_() {
+  if (!p) return;
+  size_t G = 0;
+  if (guard_band_bytes()) {
+    GuardRegistry& R = guard_registry();
+    std::lock_guard<std::mutex> lk(R.m);
+    auto it = R.live.find(p);
+    if (it != R.live.end()) { G = it->second.second; R.live.erase(it); }
+  }
+  (void)hipFree((uint8_t*)p - G);
+  p = nullptr; cap = 0;
+}
 void PinnedBuf::reserve(size_t n) {
   if (n <= cap) return;
   size_t want = n + n / 4 + 256;
@@ -1214,6 +1252,49 @@ int fgx_filter_records(fgx_caller* c, const fgx_filter_options* f, const uint8_t
 
 // diagnostics of the last fgx_process_batch call that deferred groups: out2 = {groups the first device pass deferred, of those the
 // molecules the canonical second pass decided (FGX_DUPLEX_CANON=1)}
+// Guard bands (FGX_GUARD_BAND, see DevBuf::reserve): checks the sentinel bytes around every live device buffer of the process.  Returns the number of
+// buffers with a damaged band (0: clean, also when the mode is off; -1: the device could not be read) and describes the first one in `msg`.
+int fgx_debug_check_guard_bands(char* msg, int msg_len) {
+  if (msg && msg_len > 0) msg[0] = 0;
+  const size_t G = fgx::guard_band_bytes();
+  if (!G) return 0;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  fgx::GuardRegistry& R = fgx::guard_registry();
+  std::lock_guard<std::mutex> lk(R.m);
+  std::vector<uint8_t> h(2 * G);
+  int bad = 0;
+  for (const auto& kv : R.live) {
+    const uint8_t* user = (const uint8_t*)kv.first;
+    const size_t bytes = kv.second.first;
+    if (hipMemcpy(h.data(), user - G, G, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(h.data() + G, user + bytes, G, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    long first = -1;
+    for (size_t i = 0; i < 2 * G; i++) if (h[i] != (uint8_t)fgx::GUARD_SENTINEL) { first = (long)i; break; }
+    if (first >= 0) {
+      if (!bad && msg && msg_len > 0)
+        snprintf(msg, (size_t)msg_len, "device buffer of %zu bytes: %s band damaged, first at byte %ld %s the buffer (value 0x%02x); %zu buffers live", bytes,
+                 first < (long)G ? "FRONT" : "BACK", first < (long)G ? (long)G - first : first - (long)G, first < (long)G ? "before" : "past the end of", (unsigned)h[(size_t)first], R.live.size());
+      bad++;
+    }
+  }
+  return bad;
+}
+// number of live guarded buffers (0 when the mode is off): the test asserts that the mode was really on
+int fgx_debug_guarded_buffers(void) {
+  if (!fgx::guard_band_bytes()) return 0;
+  fgx::GuardRegistry& R = fgx::guard_registry();
+  std::lock_guard<std::mutex> lk(R.m);
+  return (int)R.live.size();
+}
+// the mechanism's own check: a buffer of 1000 bytes, one byte stored right behind it — returns what fgx_debug_check_guard_bands then reports (1 when the mode is on)
+int fgx_debug_guard_self_test(void) {
+  if (!fgx::guard_band_bytes()) return 0;
+  fgx::DevBuf b;
+  b.reserve(1000);
+  (void)hipMemset((uint8_t*)b.p + 1000, 0, 1);
+  const int r = fgx_debug_check_guard_bands(nullptr, 0);
+  b.free_();
+  return r;
+}
 void fgx_debug_last_deferral(const fgx_caller* c, uint64_t* out2) { if (c && out2) { out2[0] = c->last_deferred_groups; out2[1] = c->last_canon_molecules; } }
 // Multi-GPU, for a host that is not Python: contiguous shards of a weighted family stream with roughly equal total weight
 // (weight = record bytes of the family; long-tail family sizes make equal-count shards unbalanced).  Shard k = families

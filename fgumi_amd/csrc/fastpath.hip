@@ -3960,7 +3960,11 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
   // waits for its first families anyway (their tile strides pick the column kernel's build).  Before, the second stream started behind
   // k_col_bound + scan + a host synchronisation: 0.37 ms into the step.  Launched when the batch can take the split pipeline at all; should the count of
   // small families then say otherwise (below), its descriptors are simply not used.
-  bool early_parse = false;
+  bool early_parse = false, early_prefix_only = false;
+  // The fused kernel (k_split_fused, simplex_split.inc; FGX_S2_FUSED=0 opts out) can take a batch of the split pipeline that the packed build alone serves;
+  // whether THIS batch is one is known when its first families have been parsed (below).
+  static const bool fused_env = [] { const char* e = getenv("FGX_S2_FUSED"); return !(e && e[0] == '0'); }();
+  const bool fused_possible = fused_env && [] { const char* e = getenv("FGX_S2_PACKED"); return !(e && e[0] == '0'); }() && !([] { const char* e = getenv("FGX_DIRECT"); return e && e[0] == '1'; }());
   {
     const bool direct_env0 = [] { const char* e = getenv("FGX_DIRECT"); return e && e[0] == '1'; }();
     static const bool early_env = [] { const char* e = fgx_knob("FGX_S2_EARLY"); return !(e && e[0] == '0'); }();      // (measurement knob)
@@ -3974,7 +3978,9 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       split_parse_params(PK);
       hip_check(hipEventRecord(ev_chunk[MAX_CHUNKS - 1], s), "event");      // (behind what the stream holds: the batch's buffers, the memsets)
       hip_check(hipStreamWaitEvent(s2, ev_chunk[MAX_CHUNKS - 1], 0), "wait");
-      const uint32_t gb = (uint32_t)std::min<uint64_t>(chunk_fam, n_grp);
+      // (the fused kernel parses its families itself: when it may take the batch, only the families the build is chosen from are parsed ahead)
+      early_prefix_only = fused_possible;
+      const uint32_t gb = (uint32_t)std::min<uint64_t>(early_prefix_only ? std::min<uint64_t>(chunk_fam, (uint64_t)8 * fpw * 64) : chunk_fam, n_grp);
       const uint64_t waves = ((uint64_t)gb + fpw - 1) / fpw;
       do { last_launches++; hipLaunchKernelGGL(k_split_parse, dim3((uint32_t)((waves + 1) / 2)), dim3(128), 0, s2, PK, 0u, gb, fpw, (uint64_t*)nullptr, 3u, (uint4*)nullptr); } while (0);
       hip_check(hipGetLastError(), "k_split_parse launch (first chunk, early)");
@@ -4146,6 +4152,8 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
         hip_check(hipFuncSetAttribute((const void*)k_split_cols<160, 80, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_split_cols<160, 80, 0, 2>: the device refused the dynamic LDS size");
         hip_check(hipFuncSetAttribute((const void*)k_split_cols<0, 0, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_split_cols<0, 0, 1, 0>: the device refused the dynamic LDS size");
         hip_check(hipFuncSetAttribute((const void*)k_split_cols<160, 80, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_split_cols<160, 80, 1, 0>: the device refused the dynamic LDS size");
+        hip_check(hipFuncSetAttribute((const void*)k_split_fused<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_split_fused<0, 0>: the device refused the dynamic LDS size");
+        hip_check(hipFuncSetAttribute((const void*)k_split_fused<160, 80>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_split_fused<160, 80>: the device refused the dynamic LDS size");
         s2_attr_set = true;
       }
       if (!d_s2img.p) {   // the tables of a caller never change: one image per FastPath
@@ -4202,7 +4210,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
         }
         hip_check(hipEventRecord(ev_chunk[ci], s2), "event");
       };
-      if (!early_parse) launch_parse(0);
+      if (!early_parse) launch_parse(0);   // (an early parse of the first families only: the sample below reads those; the chunk follows when the batch is not the fused kernel's)
       // the tile strides of the first families decide which build of k_split_cols goes first
       SplitFam fam_sample[64];
       const uint32_t n_sample = n_grp < 64u ? n_grp : 64u;
@@ -4214,7 +4222,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       // when the column kernel of chunk k has finished, i.e. under the column kernel of chunk k + 1.
       static const int pace_env = [] { const char* e = fgx_knob("FGX_S2_PACE"); return e ? atoi(e) : 1; }();      // (measurement knob: 0 = all record kernels up front)
       const bool paced = pace_env != 0 && n_chunks > 2;
-      for (uint32_t ci = 1; ci < (paced ? 2u : n_chunks); ci++) launch_parse(ci);
+      if (!fused_possible) for (uint32_t ci = 1; ci < (paced ? 2u : n_chunks); ci++) launch_parse(ci);
       do { last_host_syncs++; hip_check(hipEventSynchronize(ev_sample), "sync"); } while (0);
       // LDS slice of the first launch: the MEAN family's tile (rows of 160 + 80 bytes) + room for its k_call_full items, at least the
       // 4352 bytes of a 16-record family — a deeper library starts at the slice its families need instead of failing the first launch
@@ -4236,14 +4244,20 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       static const int s2_partner_env = [] { const char* e = fgx_knob("FGX_S2_PARTNER"); return e ? atoi(e) : -1; }();   // (measurement knob: 1 = always both kernels, 0 = never)
       if (s2_packed_on && n_sample && 100ull * n_pk < (unsigned long long)n_sample) s2_packed_on = false;               // under 1 % of its shape: the classic kernel alone
       const bool s2_partner = s2_packed_on && (s2_partner_env >= 0 ? s2_partner_env != 0 : 100ull * n_pk < 99ull * n_sample);
-      last_split_build = s2_packed_on ? (s2_partner ? 2u : 1u) : 0u;
+      const bool fused = fused_possible && s2_packed_on && !s2_partner && !direct;
+      last_split_build = (s2_packed_on ? (s2_partner ? 2u : 1u) : 0u) | (fused ? 0x100u : 0u);
+      if (fused_possible && !fused) {   // the two-kernel chain after all: the record kernels that were held back
+        if (early_parse && early_prefix_only) launch_parse(0);
+        for (uint32_t ci = 1; ci < (paced ? 2u : n_chunks); ci++) launch_parse(ci);
+      }
       uint32_t s2_bytes0 = s2_packed_on ? 5632 : 4352;
       {
         const uint32_t mean_need = (uint32_t)(mean_recs + 0.999) * 240u + 16u + (s2_packed_on ? 1680u : 400u);
         if (mean_need > s2_bytes0) s2_bytes0 = std::min<uint32_t>((mean_need + 15u) & ~15u, 17408u);
       }
+      if (fused && s2_bytes0 < 7424u) s2_bytes0 = 7424u;   // the record phase's windows (SP_WAVE_LDS) live in the same slice: five workgroups of four wavefronts per CU
       if (s2_bytes_env) s2_bytes0 = s2_bytes_env;
-      const uint32_t s2_wpb = s2_wpb_env ? s2_wpb_env : (s2_bytes0 <= 6528u ? 4u : s2_bytes0 <= 13056u ? 2u : 1u);
+      const uint32_t s2_wpb = s2_wpb_env ? s2_wpb_env : ((s2_bytes0 <= 6528u || (fused && s2_bytes0 <= 8192u)) ? 4u : s2_bytes0 <= 13056u ? 2u : 1u);
       // rows of 160 + 80 bytes (reads up to 160 bases) have their own build: member rows at immediate offsets in the column loop
       static const int s2_fixed_env = [] { const char* e = fgx_knob("FGX_S2_FIXED"); return e ? atoi(e) : -1; }();   // (measurement knob: 0 / 1)
       uint32_t n160 = 0;
@@ -4302,8 +4316,19 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
           for (uint32_t k = 0; k < n_chunks; k++) {
             const uint32_t ga = k * chunk_fam, gb = (uint32_t)std::min<uint64_t>((uint64_t)ga + chunk_fam, n_grp);
             if (ga >= gb) break;
-            hip_check(hipStreamWaitEvent(s, ev_chunk[k], 0), "wait");
-            launch_cols(ga, gb - ga);
+            if (fused) {
+              // one launch parses the chunk's records AND decides its columns: a wavefront takes `fpw` families
+              PS.g0 = ga;
+              const uint32_t count = gb - ga;
+              const uint64_t waves = ((uint64_t)count + fpw - 1) / fpw;
+              const dim3 grid((uint32_t)((waves + wpb - 1) / wpb)), block(64 * wpb);
+              if (k == 0) hip_check(hipStreamWaitEvent(s, ev_chunk[0], 0), "wait");   // (the parse of the first families, which the build was chosen from, writes the same descriptors)
+              if (st2[ci].fixed) do { last_launches++; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_fused<160, 80>), grid, block, lds, s, PS, count, fpw); } while (0);
+              else do { last_launches++; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_fused<0, 0>), grid, block, lds, s, PS, count, fpw); } while (0);
+            } else {
+              hip_check(hipStreamWaitEvent(s, ev_chunk[k], 0), "wait");
+              launch_cols(ga, gb - ga);
+            }
             // the chunk's EndDescs / record sizes / counters (a thread per family: waits on memory, few instructions) on the second
             // stream, under the next chunk's column kernel
             hip_check(hipEventRecord(ev_cols[k], s), "event");
@@ -4311,7 +4336,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
             FastParams PF = P;
             PF.group_list = nullptr; PF.g0 = ga;
             do { last_launches++; hipLaunchKernelGGL(k_split_finish, dim3((gb - ga + 255) / 256), dim3(256), 0, s2, PF, gb - ga); } while (0);
-            if (paced && k + 2 < n_chunks) launch_parse(k + 2);
+            if (!fused && paced && k + 2 < n_chunks) launch_parse(k + 2);
           }
         } else {
           launch_cols(0u, n_s2);

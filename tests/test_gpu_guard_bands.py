@@ -1,0 +1,29 @@
+"""the golden and parity files once more with every device buffer of the product between sentinel-filled guard bands that are
+verified after every test (FGX_GUARD_BAND: the library allocates each DevBuf at exactly the size asked for, 4 KiB of 0xA5 in front and behind;
+tests/guard_plugin.py checks them).  A kernel that stores outside its buffer — scratch columns, the k_call_full item pools, descriptors, the
+output — fails the test that made it do so, instead of corrupting a neighbour's memory or faulting on some later box."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+@pytest.mark.timeout(1800)
+def test_no_kernel_stores_outside_its_buffers():
+    env = dict(os.environ, FGX_GUARD_BAND="4096", PYTHONPATH=HERE + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, "-m", "pytest", os.path.join(HERE, "test_golden.py"), os.path.join(HERE, "test_gpu_parity.py"), "-m", "gpu", "-q", "-x", "-p", "guard_plugin",
+           "-p", "no:cacheprovider", "-s"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1700)
+    tail = p.stdout[-6000:] + "\n--- stderr\n" + p.stderr[-3000:]
+    assert p.returncode == 0, tail
+    m = re.search(r"guard bands: self test (\d+), (\d+) tests checked, up to (\d+) guarded buffers alive", p.stdout)
+    assert m, tail
+    # the mechanism sees a byte stored right behind a buffer, it looked after every test, and the library's buffers really were guarded
+    assert int(m.group(1)) == 1 and int(m.group(2)) >= 50 and int(m.group(3)) >= 10, m.group(0)
