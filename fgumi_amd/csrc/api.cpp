@@ -53,7 +53,24 @@ constexpr int GUARD_SENTINEL = 0xA5;
 struct GuardRegistry {
   std::mutex m;
   std::map<void*, std::pair<size_t, size_t>> live;   // user pointer -> (bytes, band bytes)
+  int damaged_freed = 0;                             // buffers whose bands were found damaged when they were freed (most buffers die with their caller, before a test ends)
+  long checked_freed = 0;
+  std::string first_damage;
 };
+// the bands of one buffer: "" when intact, else a description (the caller holds the registry's mutex or owns the buffer)
+std::string guard_check_one(const uint8_t* user, size_t bytes, size_t G) {
+  std::vector<uint8_t> h(2 * G);
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h.data(), user - G, G, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(h.data() + G, user + bytes, G, hipMemcpyDeviceToHost) != hipSuccess)
+    return "the bands of a device buffer of " + std::to_string(bytes) + " bytes could not be read";
+  for (size_t i = 0; i < 2 * G; i++)
+    if (h[i] != (uint8_t)GUARD_SENTINEL) {
+      char msg[300];
+      snprintf(msg, sizeof(msg), "device buffer of %zu bytes: %s band damaged, first at byte %ld %s the buffer (value 0x%02x)", bytes, i < G ? "FRONT" : "BACK",
+               i < G ? (long)(G - i) : (long)(i - G), i < G ? "before" : "past the end of", (unsigned)h[i]);
+      return msg;
+    }
+  return "";
+}
 GuardRegistry& guard_registry() { static GuardRegistry g; return g; }
 size_t guard_band_bytes() {
   static const size_t g = [] { const char* e = getenv("FGX_GUARD_BAND"); const long v = e ? atol(e) : 0; return (size_t)((v > 0 && v <= (1 << 20)) ? ((v + 255) & ~255L) : 0); }();
@@ -88,7 +105,13 @@ void DevBuf::free_() {
     GuardRegistry& R = guard_registry();
     std::lock_guard<std::mutex> lk(R.m);
     auto it = R.live.find(p);
-    if (it != R.live.end()) { G = it->second.second; R.live.erase(it); }
+    if (it != R.live.end()) {
+      G = it->second.second;
+      const std::string d = guard_check_one((const uint8_t*)p, it->second.first, G);      // the last look at this buffer's bands
+      R.checked_freed++;
+      if (!d.empty()) { if (!R.damaged_freed) R.first_damage = d + " (found when the buffer was freed)"; R.damaged_freed++; }
+      R.live.erase(it);
+    }
   }
   (void)hipFree((uint8_t*)p - G);
   p = nullptr; cap = 0;
@@ -1258,32 +1281,23 @@ int fgx_debug_check_guard_bands(char* msg, int msg_len) {
   if (msg && msg_len > 0) msg[0] = 0;
   const size_t G = fgx::guard_band_bytes();
   if (!G) return 0;
-  if (hipDeviceSynchronize() != hipSuccess) return -1;
   fgx::GuardRegistry& R = fgx::guard_registry();
   std::lock_guard<std::mutex> lk(R.m);
-  std::vector<uint8_t> h(2 * G);
-  int bad = 0;
+  int bad = R.damaged_freed;                      // (buffers freed since the process began: checked when they were freed)
+  std::string first = R.first_damage;
   for (const auto& kv : R.live) {
-    const uint8_t* user = (const uint8_t*)kv.first;
-    const size_t bytes = kv.second.first;
-    if (hipMemcpy(h.data(), user - G, G, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(h.data() + G, user + bytes, G, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    long first = -1;
-    for (size_t i = 0; i < 2 * G; i++) if (h[i] != (uint8_t)fgx::GUARD_SENTINEL) { first = (long)i; break; }
-    if (first >= 0) {
-      if (!bad && msg && msg_len > 0)
-        snprintf(msg, (size_t)msg_len, "device buffer of %zu bytes: %s band damaged, first at byte %ld %s the buffer (value 0x%02x); %zu buffers live", bytes,
-                 first < (long)G ? "FRONT" : "BACK", first < (long)G ? (long)G - first : first - (long)G, first < (long)G ? "before" : "past the end of", (unsigned)h[(size_t)first], R.live.size());
-      bad++;
-    }
+    const std::string d = fgx::guard_check_one((const uint8_t*)kv.first, kv.second.first, G);
+    if (!d.empty()) { if (!bad) first = d + "; " + std::to_string(R.live.size()) + " buffers live"; bad++; }
   }
+  if (bad && msg && msg_len > 0) snprintf(msg, (size_t)msg_len, "%s", first.c_str());
   return bad;
 }
-// number of live guarded buffers (0 when the mode is off): the test asserts that the mode was really on
+// buffers whose bands have been verified so far (when they were freed) + the live ones (0 when the mode is off): the test asserts that the mode was really on
 int fgx_debug_guarded_buffers(void) {
   if (!fgx::guard_band_bytes()) return 0;
   fgx::GuardRegistry& R = fgx::guard_registry();
   std::lock_guard<std::mutex> lk(R.m);
-  return (int)R.live.size();
+  return (int)(R.live.size() + (size_t)R.checked_freed);
 }
 // the mechanism's own check: a buffer of 1000 bytes, one byte stored right behind it — returns what fgx_debug_check_guard_bands then reports (1 when the mode is on)
 int fgx_debug_guard_self_test(void) {
@@ -1291,8 +1305,15 @@ int fgx_debug_guard_self_test(void) {
   fgx::DevBuf b;
   b.reserve(1000);
   (void)hipMemset((uint8_t*)b.p + 1000, 0, 1);
-  const int r = fgx_debug_check_guard_bands(nullptr, 0);
-  b.free_();
+  int r;
+  {
+    fgx::GuardRegistry& R = fgx::guard_registry();
+    std::lock_guard<std::mutex> lk(R.m);
+    r = fgx::guard_check_one((const uint8_t*)b.p, 1000, fgx::guard_band_bytes()).empty() ? 0 : 1;
+    R.live.erase(b.p);                           // (its damage is deliberate: not for the books)
+  }
+  (void)hipFree((uint8_t*)b.p - fgx::guard_band_bytes());
+  b.p = nullptr; b.cap = 0;
   return r;
 }
 void fgx_debug_last_deferral(const fgx_caller* c, uint64_t* out2) { if (c && out2) { out2[0] = c->last_deferred_groups; out2[1] = c->last_canon_molecules; } }

@@ -221,7 +221,7 @@ struct FastPath {
   uint32_t last_meth_device = 0;           // families of the last batch that the device pipeline decided in the methylation-aware mode
   uint32_t last_routed = 0;                // families the split pipeline handed to the k_simplex_wave2 chain in the last batch
   uint64_t last_packed_families = 0, last_classic_families = 0;   // families of the last batch finished by k_split_cols's packed build / by its classic builds (k_split_finish counts them)
-  uint32_t last_split_build = 0;           // first-stage build of the last batch: 0 classic alone (or no split pipeline), 1 packed alone, 2 packed + partner launch; | 0x100: the fused kernel (k_split_fused)
+  uint32_t last_split_build = 0;           // first-stage build of the last batch: 0 classic alone (or no split pipeline), 1 packed alone, 2 packed + partner launch
   uint32_t last_first_stage_retries = 0;   // families the first stage handed to the next launch
   uint32_t last_launches = 0, last_host_syncs = 0;   // kernel launches (library scans not counted) / host synchronisations of the last run_once
   DevBuf d_dir_size, d_dir_off, d_dir_base, d_slot_desc, d_slot_err, d_out2, d_scan_tmp2;   // direct records (simplex_split.inc, fastpath.h)

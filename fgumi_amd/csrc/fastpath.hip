@@ -34,7 +34,9 @@
 // codec_host.cpp): reads with more than 6 CIGAR ops or SEQ / CIGAR length mismatch, unmapped reads, malformed records (so that
 // the general path raises the reference's fatal error), more than FAST_MAX_READS reads or more LDS than the launch provides,
 // duplex / CODEC molecules with indels or a biting per-strand read cap.  See DESIGN.md 4.
+#if !defined(FGX_WAVEMU)      // (tests/wavemu compiles this file for the HOST under a 64-lane lock-step shim, with stand-ins for the runtime and the scans)
 #include <hipcub/hipcub.hpp>
+#endif
 #include "bamrec.h"
 #include "engine.h"
 #include <cstdlib>
@@ -42,6 +44,23 @@
 #include "fastpath.h"
 #include "gate_core.h"
 #include "packed_core.h"
+
+// The device-only spellings behind macros, so that tests/wavemu (a wave-level host emulator of the wavefront kernels) can compile this
+// file for the host: dynamic LDS, and the inline assembly — scheduling pins for the device compiler ("+v" / "s" constraints mean nothing on a CPU) and
+// four scalar-unit idioms with plain C++ twins.
+#if defined(FGX_WAVEMU)
+#define FGX_DYN_LDS(name) uint8_t* const name = wavemu::dyn_lds()
+#define FGX_PIN(...) ((void)0)
+#define FGX_UNDEF4(a, b, c, d) do { a = 0; b = 0; c = 0; d = 0; } while (0)
+#define FGX_MEM_PIN() ((void)0)
+#define FGX_CONST_AS
+#else
+#define FGX_DYN_LDS(name) extern __shared__ __align__(16) uint8_t name[]
+#define FGX_PIN(...) asm volatile("" : __VA_ARGS__)
+#define FGX_UNDEF4(a, b, c, d) asm volatile("" : "=v"(a), "=v"(b), "=v"(c), "=v"(d))     /* "whatever the registers hold" costs no instruction */
+#define FGX_MEM_PIN() asm volatile("" ::: "memory")
+#define FGX_CONST_AS __attribute__((address_space(4)))
+#endif
 
 namespace fgx {
 
@@ -234,11 +253,16 @@ __device__ inline void alignment_filter(Shared& S, uint32_t e, uint32_t n) {
 #include "chain_observe.inc"
 // mask of the lanes l with p0 + l < limit (both scalar), on the scalar unit (k_simplex_wave2's lanes_below, which is defined after this kernel)
 __device__ __forceinline__ unsigned long long fw_lanes_below(uint32_t limit, uint32_t p0) {
+#if defined(FGX_WAVEMU)
+  const uint32_t span = (limit > p0 ? limit : p0) - p0;
+  return span >= 64u ? ~0ull : ((1ull << span) - 1ull);
+#else
   unsigned long long m;
   uint32_t span;
   asm("s_max_u32 %1, %2, %3\n\ts_sub_u32 %1, %1, %3\n\ts_bfm_b64 %0, %1, 0\n\ts_cmp_ge_u32 %1, 64\n\ts_cselect_b64 %0, -1, %0"
       : "=&s"(m), "=&s"(span) : "s"(limit), "s"(p0) : "scc");
   return m;
+#endif
 }
 
 // ---- wavefront helpers, unaligned LDS words, the aux walk (shared by every family kernel) ----------------------------
@@ -385,7 +409,7 @@ __device__ unsigned long long g_phase[64 * 16];
 #define PHB(i)
 #endif
 __global__ __launch_bounds__(NT) void k_family(FastParams P) {
-  extern __shared__ __align__(16) uint8_t dyn[];
+  FGX_DYN_LDS(dyn);
   __shared__ Shared S;
   __shared__ __align__(16) double sPairB[94][2];   // {correct[q], error_per_alt[q]}: one LDS read per observation instead of two global ones
   __shared__ __align__(16) uint8_t sTagCls[256];   // aux value type classes (aux_walk)
@@ -1086,7 +1110,7 @@ template <int MODE>
                                    member loop spilled */
 #endif
 __global__ __launch_bounds__(256, MODE == 1 ? FGX_WAVE_OCC_DUPLEX : FGX_WAVE_OCC) void k_family_wave(FastParams P, uint32_t n_grp_total) {
-  extern __shared__ __align__(16) uint8_t dyn[];
+  FGX_DYN_LDS(dyn);
   __shared__ __align__(16) FwLds sL;
   ConsensusTables& sT = sL.t;
   double (&sPair)[94][2] = sL.pair;
@@ -1354,7 +1378,8 @@ __global__ __launch_bounds__(256, MODE == 1 ? FGX_WAVE_OCC_DUPLEX : FGX_WAVE_OCC
     uint32_t eq_lo = 0, eq_hi = 0;
     for (unsigned long long um = r1mask | r2mask; um; um &= um - 1) {
       const uint32_t u = (uint32_t)__builtin_ctzll(um);
-      const bool eq = rlane(hash, u) == hash && rlane(name_len, u) == name_len && u != lane;
+      const uint32_t hash_u = rlane(hash, u), nlen_u = rlane(name_len, u);      // (both cross-lane reads by every lane: no short circuit between them)
+      const bool eq = hash_u == hash && nlen_u == name_len && u != lane;
       if (u < 32) eq_lo |= (eq ? 1u : 0u) << u; else eq_hi |= (eq ? 1u : 0u) << (u - 32);
     }
     unsigned long long todo = is_r1 ? ((unsigned long long)eq_lo | ((unsigned long long)eq_hi << 32)) : 0ull;
@@ -1878,7 +1903,7 @@ __global__ __launch_bounds__(256, MODE == 1 ? FGX_WAVE_OCC_DUPLEX : FGX_WAVE_OCC
         const uint32_t ix = incol ? (set_rev ? Lrev - 1 - p : p) : 0u;
         const uint32_t iq = ix, is = ix >> 1, ish = (~ix & 1) << 2;
         double s1 = 0.0, c1 = 0.0, sR = 0.0, cR = 0.0, s2, c2, s3, c3;
-        asm volatile("" : "=v"(s2), "=v"(c2), "=v"(s3), "=v"(c3));   // (chains 2 / 3: written when opened)
+        FGX_UNDEF4(s2, c2, s3, c3);   // (chains 2 / 3: written when opened)
         uint32_t allow = incol ? 0x116u : 0u, b1 = 0, b2 = 0, b3 = 0, n1 = 0, n2 = 0, n3 = 0, nR = 0;
         for (unsigned long long m = members; m;) {
           const uint32_t r = (uint32_t)__builtin_ctzll(m);
@@ -1921,13 +1946,18 @@ __global__ __launch_bounds__(256, MODE == 1 ? FGX_WAVE_OCC_DUPLEX : FGX_WAVE_OCC
       }
       continue;
     }
+    // (a single-read set: the read's fields once, by every lane, ahead of the column loop — its trip count differs from lane to lane)
+    uint32_t one_seq = 0, one_qual = 0, one_lseq = 0, one_flags = 0, one_trim = 0;
+    if (mc == 1) {
+      const uint32_t r = (uint32_t)__builtin_ctzll(members);
+      one_seq = rlane(seq_lo, r); one_qual = rlane(qual_lo, r); one_lseq = rlane(l_seq, r); one_flags = rlane(flags, r); one_trim = rlane(trim_to, r);
+    }
     for (uint32_t p = lane; p < elen[k]; p += 64) {
       const uint64_t o = col_base + eoff[k] + p;
       uint32_t depth, obs[4];
       if (mc == 1) {   // single-read consensus: LUT keyed by the unclamped quality (vanilla_caller.rs:1677-1708)
-        const uint32_t r = (uint32_t)__builtin_ctzll(members);
         uint32_t code, q;
-        view(rlane(seq_lo, r), rlane(qual_lo, r), rlane(l_seq, r), (rlane(flags, r) & bam::F_REVERSE) != 0, rlane(trim_to, r), p, &code, &q);
+        view(one_seq, one_qual, one_lseq, (one_flags & bam::F_REVERSE) != 0, one_trim, p, &code, &q);
         const uint8_t adj = q < 94 ? T->single_input_quals[q] : 0;
         const bool low = adj < FGX_MIN_PHRED;
         P.col_code[o] = low ? (uint8_t)15 : (uint8_t)code; P.col_qual[o] = low ? (uint8_t)FGX_MIN_PHRED : adj; P.col_err[o] = 0;
@@ -2142,7 +2172,8 @@ __global__ __launch_bounds__(256, MODE == 1 ? FGX_WAVE_OCC_DUPLEX : FGX_WAVE_OCC
     uint32_t eq_lo = 0, eq_hi = 0;
     for (unsigned long long um = __ballot(act); um; um &= um - 1) {
       const uint32_t u = (uint32_t)__builtin_ctzll(um);
-      const bool eq = rlane(hash, u) == hash && rlane(name_len, u) == name_len && u != lane;
+      const uint32_t hash_u = rlane(hash, u), nlen_u = rlane(name_len, u);      // (both cross-lane reads by every lane: no short circuit between them)
+      const bool eq = hash_u == hash && nlen_u == name_len && u != lane;
       if (u < 32) eq_lo |= (eq ? 1u : 0u) << u; else eq_hi |= (eq ? 1u : 0u) << (u - 32);
     }
     unsigned long long todo = act ? ((unsigned long long)eq_lo | ((unsigned long long)eq_hi << 32)) : 0ull;
@@ -2255,22 +2286,33 @@ __global__ __launch_bounds__(256, MODE == 1 ? FGX_WAVE_OCC_DUPLEX : FGX_WAVE_OCC
   for (int k = 0; k < 2; k++) {
     const unsigned long long members = k == 0 ? r1set : r2set;
     const uint32_t mc = (uint32_t)__popcll(members), elen = k == 0 ? len1 : len2, eoff = k == 0 ? 0 : len1;
-    for (uint32_t p = lane; p < elen; p += 64) {
+    // (the column loop runs the SAME number of passes in every lane — a lane past the end of the set takes part in the cross-lane reads of a pass and
+    // stores nothing —, and a single-read set reads its read's fields once ahead of it: cross-lane operations stay in wave-uniform control flow, which
+    // tests/wavemu checks)
+    uint32_t one_seq = 0, one_qual = 0, one_lseq = 0, one_flags = 0;
+    if (mc == 1) {
+      const uint32_t r = (uint32_t)__builtin_ctzll(members);
+      one_seq = rlane(seq_lo, r); one_qual = rlane(qual_lo, r); one_lseq = rlane(l_seq, r); one_flags = rlane(flags, r);
+    }
+    for (uint32_t p0 = 0; p0 < elen; p0 += 64) {
+      const uint32_t p = p0 + lane;
+      const bool incol = p < elen;
       const uint64_t o = col_base + eoff + p;
       if (mc == 1) {   // single-read consensus: LUT keyed by the unclamped quality (vanilla_caller.rs:1677-1708)
-        const uint32_t r = (uint32_t)__builtin_ctzll(members);
-        uint32_t code, q;
-        view(rlane(seq_lo, r), rlane(qual_lo, r), rlane(l_seq, r), (rlane(flags, r) & bam::F_REVERSE) != 0, 0, p, &code, &q);
-        const uint8_t adjq = q < 94 ? T->single_input_quals[q] : 0;
-        P.col_code[o] = (uint8_t)code; P.col_qual[o] = adjq; P.col_depth[o] = code != 15 ? 1 : 0; P.col_err[o] = 0;
-        if (code != 15 && code != 1 && code != 2 && code != 4 && code != 8) odd_base = true;   // IUPAC code in a lone read: general path
+        if (incol) {
+          uint32_t code, q;
+          view(one_seq, one_qual, one_lseq, (one_flags & bam::F_REVERSE) != 0, 0, p, &code, &q);
+          const uint8_t adjq = q < 94 ? T->single_input_quals[q] : 0;
+          P.col_code[o] = (uint8_t)code; P.col_qual[o] = adjq; P.col_depth[o] = code != 15 ? 1 : 0; P.col_err[o] = 0;
+          if (code != 15 && code != 1 && code != 2 && code != 4 && code != 8) odd_base = true;   // IUPAC code in a lone read: general path
+        }
       } else {
         ChainAcc acc;                           // two Kahan chains while the column shows one base (consensus_math.h)
         acc.reset();
         for (unsigned long long m = members; m; m &= m - 1) {
           const uint32_t r = (uint32_t)__builtin_ctzll(m);
           const uint32_t x0 = rlane(d0, r), x1 = rlane(d1, r), x2 = rlane(d2, r);
-          bool valid = p < (x1 >> 16);
+          bool valid = incol && p < (x1 >> 16);
           const bool rv = (x2 >> 16) != 0;
           const uint32_t idx = valid ? (rv ? (x1 & 0xFFFF) - 1 - p : p) : 0;
           const uint32_t bb = W[(x0 & 0xFFFF) + (idx >> 1)];
@@ -2285,13 +2327,13 @@ __global__ __launch_bounds__(256, MODE == 1 ? FGX_WAVE_OCC_DUPLEX : FGX_WAVE_OCC
         double ll[4];
         uint32_t obs[4];
         acc.finish(ll, obs);
-        int bi;
-        uint8_t q;
-        const bool resolved = column_call_fast_lds(sT, KC, ll, obs, &bi, &q);
+        int bi = -1;
+        uint8_t q = 0;
+        const bool resolved = !incol || column_call_fast_lds(sT, KC, ll, obs, &bi, &q);
         const uint32_t depth = obs[0] + obs[1] + obs[2] + obs[3];
-        P.col_depth[o] = (uint16_t)depth;
+        if (incol) P.col_depth[o] = (uint16_t)depth;
         push_full(!resolved, o, ll, obs);
-        if (resolved) {
+        if (resolved && incol) {
           const uint32_t err = depth - (bi == 0 ? obs[0] : bi == 1 ? obs[1] : bi == 2 ? obs[2] : bi == 3 ? obs[3] : 0u);
           P.col_code[o] = depth < 1 ? (uint8_t)15 : bi >= 0 ? (uint8_t)(1u << bi) : (uint8_t)15;
           P.col_qual[o] = depth < 1 ? (uint8_t)0 : q;
@@ -2923,7 +2965,8 @@ __device__ __forceinline__ bool emit_pair(const EmitParams& P, const EndDesc* D 
   const bool hb = lane >= 32u;
   const uint32_t Lc = hb ? Lc2 : Lc1;
   const uint32_t dcol = hb ? (uint32_t)(col2 - col1) : 0u, dq = hb ? (uint32_t)(oo2 - oo1) : 0u;
-  const uint32_t d_type = hb ? uni(D2.type) : uni(D1.type), rec_size = hb ? uni(D2.rec_size) : uni(D1.rec_size);
+  const uint32_t ty1 = uni(D1.type), ty2 = uni(D2.type), rs1 = uni(D1.rec_size), rs2 = uni(D2.rec_size);   // (uniform reads by every lane, then the half's pick)
+  const uint32_t d_type = hb ? ty2 : ty1, rec_size = hb ? rs2 : rs1;
   const bool hcb = hb ? hcb2 : hcb1, hrx = hb ? hrx2 : hrx1;
   const uint32_t cb_len = hb ? cbl2 : cbl1, rx_len = hb ? rxl2 : rxl1;
   // ---- loads: everything the two records read, before the first store ---------------------------------------------------------------------
@@ -2970,8 +3013,11 @@ __device__ __forceinline__ bool emit_pair(const EmitParams& P, const EndDesc* D 
     if (!pay) { maxd = 0u; mind = 0xFFFFFFFFu; sumd = 0u; sume = 0u; }
   }
   FGX_HALF_REDUCE(maxd, 0u, wr_max); FGX_HALF_REDUCE(mind, 0xFFFFFFFFu, wr_min); FGX_HALF_REDUCE(sumd, 0u, wr_add); FGX_HALF_REDUCE(sume, 0u, wr_add);
-  maxd = hb ? rlane(maxd, 63) : rlane(maxd, 31); mind = hb ? rlane(mind, 63) : rlane(mind, 31);
-  sumd = hb ? rlane(sumd, 63) : rlane(sumd, 31); sume = hb ? rlane(sume, 63) : rlane(sume, 31);
+  {   // (lane 31 / lane 63 hold the halves' results; every lane reads both)
+    const uint32_t mx0 = rlane(maxd, 31), mx1 = rlane(maxd, 63), mn0 = rlane(mind, 31), mn1 = rlane(mind, 63);
+    const uint32_t sd0 = rlane(sumd, 31), sd1 = rlane(sumd, 63), se0 = rlane(sume, 31), se1 = rlane(sume, 63);
+    maxd = hb ? mx1 : mx0; mind = hb ? mn1 : mn0; sumd = hb ? sd1 : sd0; sume = hb ? se1 : se0;
+  }
   const float ce_rate = sumd > 0u ? (float)sume / (float)sumd : 0.0f;
   const uint32_t n_cd = 3u + int_tag_width(maxd), n_cm = 3u + int_tag_width(mind);
   // ---- where the fields of the half's record lie (offsets from record R1's first byte) ----------------------------------------------------
@@ -3071,7 +3117,11 @@ __global__ __launch_bounds__(256, FGX_EMIT_OCC) void k_emit(EmitParams P) {
   if (s0 >= P.slot_end) return;
   // (every kernel argument the records need is asked for here, in one batch: fetched where first used they were five separate
   // scalar-load round trips along the way)
+#if defined(FGX_WAVEMU)
+#define K_EMIT_PIN(x) ((void)(x))
+#else
 #define K_EMIT_PIN(x) asm volatile("" :: "s"(x))
+#endif
   K_EMIT_PIN(P.blob); K_EMIT_PIN(P.out); K_EMIT_PIN(P.out_base); K_EMIT_PIN(P.col_code); K_EMIT_PIN(P.col_qual); K_EMIT_PIN(P.col_depth);
   K_EMIT_PIN(P.col_err); K_EMIT_PIN(P.prefix); K_EMIT_PIN(P.prefix_len); K_EMIT_PIN(P.rg); K_EMIT_PIN(P.rg_len);
 #undef K_EMIT_PIN
@@ -3960,11 +4010,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
   // waits for its first families anyway (their tile strides pick the column kernel's build).  Before, the second stream started behind
   // k_col_bound + scan + a host synchronisation: 0.37 ms into the step.  Launched when the batch can take the split pipeline at all; should the count of
   // small families then say otherwise (below), its descriptors are simply not used.
-  bool early_parse = false, early_prefix_only = false;
-  // The fused kernel (k_split_fused, simplex_split.inc; FGX_S2_FUSED=0 opts out) can take a batch of the split pipeline that the packed build alone serves;
-  // whether THIS batch is one is known when its first families have been parsed (below).
-  static const bool fused_env = [] { const char* e = getenv("FGX_S2_FUSED"); return !(e && e[0] == '0'); }();
-  const bool fused_possible = fused_env && [] { const char* e = getenv("FGX_S2_PACKED"); return !(e && e[0] == '0'); }() && !([] { const char* e = getenv("FGX_DIRECT"); return e && e[0] == '1'; }());
+  bool early_parse = false;
   {
     const bool direct_env0 = [] { const char* e = getenv("FGX_DIRECT"); return e && e[0] == '1'; }();
     static const bool early_env = [] { const char* e = fgx_knob("FGX_S2_EARLY"); return !(e && e[0] == '0'); }();      // (measurement knob)
@@ -3978,9 +4024,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       split_parse_params(PK);
       hip_check(hipEventRecord(ev_chunk[MAX_CHUNKS - 1], s), "event");      // (behind what the stream holds: the batch's buffers, the memsets)
       hip_check(hipStreamWaitEvent(s2, ev_chunk[MAX_CHUNKS - 1], 0), "wait");
-      // (the fused kernel parses its families itself: when it may take the batch, only the families the build is chosen from are parsed ahead)
-      early_prefix_only = fused_possible;
-      const uint32_t gb = (uint32_t)std::min<uint64_t>(early_prefix_only ? std::min<uint64_t>(chunk_fam, (uint64_t)8 * fpw * 64) : chunk_fam, n_grp);
+      const uint32_t gb = (uint32_t)std::min<uint64_t>(chunk_fam, n_grp);
       const uint64_t waves = ((uint64_t)gb + fpw - 1) / fpw;
       do { last_launches++; hipLaunchKernelGGL(k_split_parse, dim3((uint32_t)((waves + 1) / 2)), dim3(128), 0, s2, PK, 0u, gb, fpw, (uint64_t*)nullptr, 3u, (uint4*)nullptr); } while (0);
       hip_check(hipGetLastError(), "k_split_parse launch (first chunk, early)");
@@ -4152,8 +4196,6 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
         hip_check(hipFuncSetAttribute((const void*)k_split_cols<160, 80, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_split_cols<160, 80, 0, 2>: the device refused the dynamic LDS size");
         hip_check(hipFuncSetAttribute((const void*)k_split_cols<0, 0, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_split_cols<0, 0, 1, 0>: the device refused the dynamic LDS size");
         hip_check(hipFuncSetAttribute((const void*)k_split_cols<160, 80, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_split_cols<160, 80, 1, 0>: the device refused the dynamic LDS size");
-        hip_check(hipFuncSetAttribute((const void*)k_split_fused<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_split_fused<0, 0>: the device refused the dynamic LDS size");
-        hip_check(hipFuncSetAttribute((const void*)k_split_fused<160, 80>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) for k_split_fused<160, 80>: the device refused the dynamic LDS size");
         s2_attr_set = true;
       }
       if (!d_s2img.p) {   // the tables of a caller never change: one image per FastPath
@@ -4210,7 +4252,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
         }
         hip_check(hipEventRecord(ev_chunk[ci], s2), "event");
       };
-      if (!early_parse) launch_parse(0);   // (an early parse of the first families only: the sample below reads those; the chunk follows when the batch is not the fused kernel's)
+      if (!early_parse) launch_parse(0);
       // the tile strides of the first families decide which build of k_split_cols goes first
       SplitFam fam_sample[64];
       const uint32_t n_sample = n_grp < 64u ? n_grp : 64u;
@@ -4222,7 +4264,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       // when the column kernel of chunk k has finished, i.e. under the column kernel of chunk k + 1.
       static const int pace_env = [] { const char* e = fgx_knob("FGX_S2_PACE"); return e ? atoi(e) : 1; }();      // (measurement knob: 0 = all record kernels up front)
       const bool paced = pace_env != 0 && n_chunks > 2;
-      if (!fused_possible) for (uint32_t ci = 1; ci < (paced ? 2u : n_chunks); ci++) launch_parse(ci);
+      for (uint32_t ci = 1; ci < (paced ? 2u : n_chunks); ci++) launch_parse(ci);
       do { last_host_syncs++; hip_check(hipEventSynchronize(ev_sample), "sync"); } while (0);
       // LDS slice of the first launch: the MEAN family's tile (rows of 160 + 80 bytes) + room for its k_call_full items, at least the
       // 4352 bytes of a 16-record family — a deeper library starts at the slice its families need instead of failing the first launch
@@ -4238,26 +4280,20 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       uint32_t n_pk = 0;
       if (s2_packed_on) for (uint32_t i = 0; i < n_sample; i++) {
         const SplitFam& F = fam_sample[i];
-        auto ok = [&](uint32_t m) { return m < 2u || (m >= P.s2_nsafe && m <= 16u); };
+        auto ok = [&](uint32_t m) { return m < 2u || (m >= P.s2_nsafe && m <= S2_PACKED_MAX_ROWS); };
         n_pk += (ok(F.m_a) && ok(F.m_b) && ((F.len_a + 7u) >> 3) + ((F.len_b + 7u) >> 3) <= 64u) ? 1u : 0u;
       }
       static const int s2_partner_env = [] { const char* e = fgx_knob("FGX_S2_PARTNER"); return e ? atoi(e) : -1; }();   // (measurement knob: 1 = always both kernels, 0 = never)
       if (s2_packed_on && n_sample && 100ull * n_pk < (unsigned long long)n_sample) s2_packed_on = false;               // under 1 % of its shape: the classic kernel alone
       const bool s2_partner = s2_packed_on && (s2_partner_env >= 0 ? s2_partner_env != 0 : 100ull * n_pk < 99ull * n_sample);
-      const bool fused = fused_possible && s2_packed_on && !s2_partner && !direct;
-      last_split_build = (s2_packed_on ? (s2_partner ? 2u : 1u) : 0u) | (fused ? 0x100u : 0u);
-      if (fused_possible && !fused) {   // the two-kernel chain after all: the record kernels that were held back
-        if (early_parse && early_prefix_only) launch_parse(0);
-        for (uint32_t ci = 1; ci < (paced ? 2u : n_chunks); ci++) launch_parse(ci);
-      }
+      last_split_build = s2_packed_on ? (s2_partner ? 2u : 1u) : 0u;
       uint32_t s2_bytes0 = s2_packed_on ? 5632 : 4352;
       {
         const uint32_t mean_need = (uint32_t)(mean_recs + 0.999) * 240u + 16u + (s2_packed_on ? 1680u : 400u);
         if (mean_need > s2_bytes0) s2_bytes0 = std::min<uint32_t>((mean_need + 15u) & ~15u, 17408u);
       }
-      if (fused && s2_bytes0 < 7424u) s2_bytes0 = 7424u;   // the record phase's windows (SP_WAVE_LDS) live in the same slice: five workgroups of four wavefronts per CU
       if (s2_bytes_env) s2_bytes0 = s2_bytes_env;
-      const uint32_t s2_wpb = s2_wpb_env ? s2_wpb_env : ((s2_bytes0 <= 6528u || (fused && s2_bytes0 <= 8192u)) ? 4u : s2_bytes0 <= 13056u ? 2u : 1u);
+      const uint32_t s2_wpb = s2_wpb_env ? s2_wpb_env : (s2_bytes0 <= 6528u ? 4u : s2_bytes0 <= 13056u ? 2u : 1u);
       // rows of 160 + 80 bytes (reads up to 160 bases) have their own build: member rows at immediate offsets in the column loop
       static const int s2_fixed_env = [] { const char* e = fgx_knob("FGX_S2_FIXED"); return e ? atoi(e) : -1; }();   // (measurement knob: 0 / 1)
       uint32_t n160 = 0;
@@ -4289,7 +4325,8 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
         hip_check(hipMemsetAsync(d_cnt, 0, 4, s), "memset");
         FastParams PS = P;
         PS.group_list = s2_list; PS.lds_wave_bytes = st2[ci].bytes;
-        PS.s2_partner = s2_partner ? 1u : 0u;
+        static const bool later_packed = [] { const char* e = fgx_knob("FGX_S2_LATER_PACKED"); return !(e && e[0] == '0'); }();   // (measurement knob: 0 = the classic build in the later stages, as in round 5)
+        PS.s2_partner = (s2_partner || (ci > 0 && later_packed && s2_packed_on)) ? 1u : 0u;
         PS.retry = last ? nullptr : lists[s2_out]; PS.n_retry = d_cnt;
         if (st2[ci].bytes > 65536u) continue;                 // (more than the attribute limit set above: the family goes down the chain)
         const uint32_t wpb = std::min<uint32_t>(st2[ci].wpb, 65536u / st2[ci].bytes);   // wpb x slice within the 64 KiB requested for k_split_cols
@@ -4300,14 +4337,16 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
           if (direct) {
             if (st2[ci].fixed) do { last_launches++; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<160, 80, 1, 0>), grid, block, lds, s, PS, count); } while (0);
             else do { last_launches++; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<0, 0, 1, 0>), grid, block, lds, s, PS, count); } while (0);
-          } else if (ci == 0 && s2_packed_on) {
-            // (round 5) the first stage as two launches over the same families: the packed pass for the families of its shape, run_cols for the rest
+          } else if (s2_packed_on && (ci == 0 || later_packed)) {
+            // (round 5) the first stage as two launches over the same families: the packed pass for the families of its shape, run_cols for the rest;
+            // (round 6) the later stages — the families that need larger LDS slices: ends of 9 .. 31 rows — likewise, always as the pair (their lists are mixed)
+            const bool pair = s2_partner || ci > 0;
             if (st2[ci].fixed) {
               do { last_launches++; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<160, 80, 0, 1>), grid, block, lds, s, PS, count); } while (0);
-              if (s2_partner) do { last_launches++; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<160, 80, 0, 2>), grid, block, lds, s, PS, count); } while (0);
+              if (pair) do { last_launches++; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<160, 80, 0, 2>), grid, block, lds, s, PS, count); } while (0);
             } else {
               do { last_launches++; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<0, 0, 0, 1>), grid, block, lds, s, PS, count); } while (0);
-              if (s2_partner) do { last_launches++; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<0, 0, 0, 2>), grid, block, lds, s, PS, count); } while (0);
+              if (pair) do { last_launches++; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<0, 0, 0, 2>), grid, block, lds, s, PS, count); } while (0);
             }
           } else if (st2[ci].fixed) do { last_launches++; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<160, 80, 0, 0>), grid, block, lds, s, PS, count); } while (0);
           else do { last_launches++; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_cols<0, 0, 0, 0>), grid, block, lds, s, PS, count); } while (0);
@@ -4316,19 +4355,8 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
           for (uint32_t k = 0; k < n_chunks; k++) {
             const uint32_t ga = k * chunk_fam, gb = (uint32_t)std::min<uint64_t>((uint64_t)ga + chunk_fam, n_grp);
             if (ga >= gb) break;
-            if (fused) {
-              // one launch parses the chunk's records AND decides its columns: a wavefront takes `fpw` families
-              PS.g0 = ga;
-              const uint32_t count = gb - ga;
-              const uint64_t waves = ((uint64_t)count + fpw - 1) / fpw;
-              const dim3 grid((uint32_t)((waves + wpb - 1) / wpb)), block(64 * wpb);
-              if (k == 0) hip_check(hipStreamWaitEvent(s, ev_chunk[0], 0), "wait");   // (the parse of the first families, which the build was chosen from, writes the same descriptors)
-              if (st2[ci].fixed) do { last_launches++; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_fused<160, 80>), grid, block, lds, s, PS, count, fpw); } while (0);
-              else do { last_launches++; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_split_fused<0, 0>), grid, block, lds, s, PS, count, fpw); } while (0);
-            } else {
-              hip_check(hipStreamWaitEvent(s, ev_chunk[k], 0), "wait");
-              launch_cols(ga, gb - ga);
-            }
+            hip_check(hipStreamWaitEvent(s, ev_chunk[k], 0), "wait");
+            launch_cols(ga, gb - ga);
             // the chunk's EndDescs / record sizes / counters (a thread per family: waits on memory, few instructions) on the second
             // stream, under the next chunk's column kernel
             hip_check(hipEventRecord(ev_cols[k], s), "event");
@@ -4336,7 +4364,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
             FastParams PF = P;
             PF.group_list = nullptr; PF.g0 = ga;
             do { last_launches++; hipLaunchKernelGGL(k_split_finish, dim3((gb - ga + 255) / 256), dim3(256), 0, s2, PF, gb - ga); } while (0);
-            if (!fused && paced && k + 2 < n_chunks) launch_parse(k + 2);
+            if (paced && k + 2 < n_chunks) launch_parse(k + 2);
           }
         } else {
           launch_cols(0u, n_s2);
@@ -4487,7 +4515,8 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       P.s2_image = d_s2img.p;
       uint32_t* d_cnt_deep = (uint32_t*)(misc + 38);
       // one pass of the streaming kernels over a family list; returns how many families it handed on (to `out_list`)
-      auto deep_pass = [&](const uint32_t* list, uint32_t n_list, bool small, uint32_t* out_list) -> uint32_t {
+      // `size_class`: 0 = the wavefront-sized build of the record kernel (families of up to 64 records), 1 = two wavefronts (up to 128), 2 = four (up to DEEP_MAX)
+      auto deep_pass = [&](const uint32_t* list, uint32_t n_list, int size_class, uint32_t* out_list) -> uint32_t {
         d_deep_sizes.reserve((size_t)n_list * 8 + 64); d_deep_row0.reserve((size_t)n_list * 8 + 64);
         do { last_launches++; hipLaunchKernelGGL(k_deep_sizes, dim3((n_list + 255) / 256), dim3(256), 0, s, list, n_list, d_grp_first, d_deep_sizes.as<uint64_t>()); } while (0);
         size_t tb = 0;
@@ -4507,7 +4536,8 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
         DP.rows = d_deep_rows.as<DeepRow>(); DP.fams = d_deep_fams.as<DeepFam>(); DP.out_list = out_list; DP.n_out = d_cnt_deep;
         FastParams PD = P;
         PD.group_list = nullptr;
-        if (small) do { last_launches++; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_deep_parse<64, 64>), dim3(n_list), dim3(64), 0, s, PD, DP); } while (0);
+        if (size_class == 0) do { last_launches++; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_deep_parse<64, 64>), dim3(n_list), dim3(64), 0, s, PD, DP); } while (0);
+        else if (size_class == 1) do { last_launches++; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_deep_parse<128, 128>), dim3(n_list), dim3(128), 0, s, PD, DP); } while (0);
         else do { last_launches++; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_deep_parse<256, DEEP_MAX>), dim3(n_list), dim3(256), 0, s, PD, DP); } while (0);
         hip_check(hipGetLastError(), "k_deep_parse launch");
         if (meth_dev) do { last_launches++; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_deep_cols<1>), dim3((n_list + 3) / 4), dim3(256), 0, s, PD, DP); } while (0);
@@ -4522,17 +4552,26 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
       if (meth_dev) {
         // every family: the wavefront-sized build of the record kernel first, the workgroup-sized one for the families above 64 records;
         // what neither takes is on the deferred list (the general path knows the mode)
-        const uint32_t n_large = deep_pass(d_big.as<uint32_t>(), n_big, true, d_deep_out.as<uint32_t>());
+        const uint32_t n_large = deep_pass(d_big.as<uint32_t>(), n_big, 0, d_deep_out.as<uint32_t>());
         if (n_large) {
           d_deep_out2.reserve((size_t)n_large * 4 + 64);
-          (void)deep_pass(d_deep_out.as<uint32_t>(), n_large, false, d_deep_out2.as<uint32_t>());
+          (void)deep_pass(d_deep_out.as<uint32_t>(), n_large, 2, d_deep_out2.as<uint32_t>());
         }
         last_deep_families = n_big;
         last_meth_device = n_grp; n_big = 0;
       } else {
-        const uint32_t n_left = deep_pass(d_big.as<uint32_t>(), n_big, false, d_deep_out.as<uint32_t>());
+        // (round 6) two wavefronts per family first: a family of 65 .. 128 records — every deep family of a 2 .. 50-pair long tail — kept a quarter to a
+        // half of the 256 threads of the large build busy in the record kernel; what has more records (or is not the kernels' shape) goes on to the large build
+        const uint32_t n_mid = deep_pass(d_big.as<uint32_t>(), n_big, 1, d_deep_out.as<uint32_t>());
+        uint32_t n_left = 0;
+        big_list = d_deep_out.as<uint32_t>();
+        if (n_mid) {
+          d_deep_out2.reserve((size_t)n_mid * 4 + 64);
+          n_left = deep_pass(d_deep_out.as<uint32_t>(), n_mid, 2, d_deep_out2.as<uint32_t>());
+          big_list = d_deep_out2.as<uint32_t>();
+        }
         last_deep_families = n_big - n_left;
-        big_list = d_deep_out.as<uint32_t>(); n_big = n_left;
+        n_big = n_left;
       }
     }
     // more than 64 records (the list the first kernels filled), or more bytes than the largest slice (what the chain left): one workgroup per family

@@ -151,6 +151,11 @@ hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned int) {
 hipError_t hipEventSynchronize(hipEvent_t e) { emu::Event* ev = (emu::Event*)e; while (ev->done.load() < ev->gen.load()) std::this_thread::sleep_for(std::chrono::microseconds(20)); return hipSuccess; }
 hipError_t hipEventQuery(hipEvent_t e) { emu::Event* ev = (emu::Event*)e; return ev->done.load() < ev->gen.load() ? hipErrorNotReady : hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned int) { return hipEventCreate(e); }
+hipError_t hipDeviceSynchronize(void) { if (emu::async_on()) emu::drain_all(); return hipSuccess; }
+hipError_t hipMemset(void* d, int v, size_t n) { if (n) memset(d, v, n); return hipSuccess; }
+hipError_t hipMemGetInfo(size_t* free_b, size_t* total_b) { *free_b = (size_t)8 << 30; *total_b = (size_t)16 << 30; return hipSuccess; }
+hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 }
 
 namespace fgx {
@@ -159,6 +164,7 @@ int simplex_process_general(fgx_caller*, const uint8_t*, const uint64_t*, const 
 int duplex_process_general(fgx_caller*, const uint8_t*, const uint64_t*, const uint32_t*, uint32_t, const uint32_t*, uint32_t, fgx_output*);
 int codec_process_general(fgx_caller*, const uint8_t*, const uint64_t*, const uint32_t*, uint32_t, const uint32_t*, uint32_t, fgx_output*);
 
+#ifndef APIEMU_REAL_FASTPATH      // (tests/wavemu links the REAL fastpath.hip, compiled for the host under its lock-step shim, in place of the stand-in)
 // ---- the device-resident pipeline's stand-in ----------------------------------------------------------------------------------------
 static std::map<FastPath*, fgx_caller*> g_helpers;
 
@@ -233,6 +239,7 @@ void FastPath::release() {
   if (it != g_helpers.end()) { fgx_destroy(it->second); g_helpers.erase(it); }
   for (DevBuf* b : {&d_out, &d_offsets, &d_deferred}) b->free_();
 }
+#endif   // APIEMU_REAL_FASTPATH
 
 }  // namespace fgx
 

@@ -182,7 +182,7 @@ uint32_t demu_cap_depth(uint8_t pre, uint8_t post, uint32_t tie, uint32_t min_bq
 int demu_packed_end(const uint8_t* seq, const uint8_t* qual, uint32_t qs, uint32_t ss, uint32_t m, uint32_t lenE, uint32_t cntE, int rev, uint32_t min_bq, uint32_t nsafe,
                     uint32_t cap, uint32_t min_cons_bq, uint32_t min_reads, uint8_t* code, uint8_t* qual_out, uint16_t* depth, uint8_t* flagged) {
   const uint32_t groups = (lenE + 7u) >> 3;
-  if (qs < 8u * groups || ss < 4u * groups || min_bq > 128u || m > 17u) return 1;
+  if (qs < 8u * groups || ss < 4u * groups || min_bq > 128u || m > 31u) return 1;   // (31 rows: the byte counters add 8 per observation)
   const uint32_t mb4 = min_bq * 0x01010101u;
   for (uint32_t k = 0; k < groups; k++) {
     uint32_t nfl, nfh;

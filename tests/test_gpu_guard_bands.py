@@ -23,7 +23,7 @@ def test_no_kernel_stores_outside_its_buffers():
     p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1700)
     tail = p.stdout[-6000:] + "\n--- stderr\n" + p.stderr[-3000:]
     assert p.returncode == 0, tail
-    m = re.search(r"guard bands: self test (\d+), (\d+) tests checked, up to (\d+) guarded buffers alive", p.stdout)
+    m = re.search(r"guard bands: self test (\d+), (\d+) tests checked, (\d+) guarded buffers verified", p.stdout)
     assert m, tail
     # the mechanism sees a byte stored right behind a buffer, it looked after every test, and the library's buffers really were guarded
-    assert int(m.group(1)) == 1 and int(m.group(2)) >= 50 and int(m.group(3)) >= 10, m.group(0)
+    assert int(m.group(1)) == 1 and int(m.group(2)) >= 50 and int(m.group(3)) >= 500, m.group(0)

@@ -133,13 +133,12 @@ def check_forced_chunks(n_families, sim):
     c.close()
 
 
-@pytest.mark.parametrize("fused", ["1", "0"])
 @pytest.mark.parametrize("chunks", [4, 8])
 @pytest.mark.parametrize("sim", [dict(family_size=8), dict(family_size=5, family_size_max=12, error_rate_ppm=20000)])
-def test_forced_split_chunks_equal_the_oracle(chunks, sim, fused):
+def test_forced_split_chunks_equal_the_oracle(chunks, sim):
     """3 000 families cut into 4 / 8 chunks of the record / column pipeline (the boundaries the 5 M-family batch has at 625 000-family
     distance): chunk-local prefix offsets, the second stream's hand-over and the per-chunk finish kernels, against the oracle."""
-    run_isolated("test_gpu_oracle_full_size", "check_forced_chunks", 3000, sim, env={"FGX_SPLIT_CHUNKS": str(chunks), "FGX_S2_FUSED": fused})
+    run_isolated("test_gpu_oracle_full_size", "check_forced_chunks", 3000, sim, env={"FGX_SPLIT_CHUNKS": str(chunks)})
 
 
 # ---- round 6 (VERDICT r5 item 4a): which build of k_split_cols finished the families — asserted, not assumed ------------------------------
@@ -150,13 +149,12 @@ def _split_builds(c):
     lib.fgx_debug_last_split_builds.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     out = (C.c_uint64 * 4)()
     lib.fgx_debug_last_split_builds(c._h, out)
-    return dict(packed=int(out[0]), classic=int(out[1]), build=int(out[2]) & 0xFF, fused=bool(int(out[2]) & 0x100), retries=int(out[3]))
+    return dict(packed=int(out[0]), classic=int(out[1]), build=int(out[2]), retries=int(out[3]))
 
 
-def check_split_build(n_families, sim, want_build, want_fused=None):
+def check_split_build(n_families, sim, want_build):
     """One batch against the oracle, then the path it took: `want_build` = "packed" (the packed build alone finished nearly every family),
-    "pair" (packed + partner launch, both finished families), "classic" (no family through the packed pass); `want_fused`: the record and
-    column kernels ran as ONE launch (k_split_fused)."""
+    "pair" (packed + partner launch, both finished families), "classic" (no family through the packed pass)."""
     import torch  # noqa: F401
     from fgumi_amd import simulate_grouped_reads
     g = simulate_grouped_reads(n_families, **sim)
@@ -167,8 +165,6 @@ def check_split_build(n_families, sim, want_build, want_fused=None):
     assert out.count == want["count"] and out.to_host() == want["data"]
     assert np.array_equal(np.array(c.last_stats_array, dtype=np.uint64), want["stats"])
     b = _split_builds(c)
-    if want_fused is not None:
-        assert b["fused"] == want_fused, b
     if want_build == "packed":
         assert b["build"] == 1 and b["packed"] >= 0.9 * n_families and b["packed"] + b["classic"] == n_families, b
         assert b["classic"] == b["retries"], b          # what the packed build did not finish took the next launch (a classic build)
@@ -179,18 +175,16 @@ def check_split_build(n_families, sim, want_build, want_fused=None):
     c.close()
 
 
-@pytest.mark.parametrize("case", ["depth8_packed", "depth8_two_kernels", "depth3_not_packed", "long_tail_pair", "depth8_switched_off"])
+@pytest.mark.parametrize("case", ["depth8_packed", "depth3_not_packed", "long_tail_pair", "depth8_switched_off"])
 def test_the_packed_build_runs_where_it_should(case):
     """A depth-8 batch is finished by the packed build of k_split_cols (SplitOut.status bit 7, counted by k_split_finish), a depth-3 batch
     by no packed pass at all, a long-tail batch by the launch pair; FGX_S2_PACKED=0 takes the classic build — all four byte-identical to the
     oracle (child interpreters: the switch is read once per process)."""
     if case == "depth8_packed":
-        run_isolated("test_gpu_oracle_full_size", "check_split_build", 20000, dict(family_size=8), "packed", True)
-    elif case == "depth8_two_kernels":      # FGX_S2_FUSED=0: the record kernel on the second stream, the packed column kernel behind it (the round-5 chain)
-        run_isolated("test_gpu_oracle_full_size", "check_split_build", 20000, dict(family_size=8), "packed", False, env={"FGX_S2_FUSED": "0"})
+        run_isolated("test_gpu_oracle_full_size", "check_split_build", 20000, dict(family_size=8), "packed")
     elif case == "depth3_not_packed":
         run_isolated("test_gpu_oracle_full_size", "check_split_build", 20000, dict(family_size=3), "classic")
     elif case == "long_tail_pair":
-        run_isolated("test_gpu_oracle_full_size", "check_split_build", 20000, dict(family_size=2, family_size_max=50), "pair", False)
+        run_isolated("test_gpu_oracle_full_size", "check_split_build", 20000, dict(family_size=2, family_size_max=50), "pair")
     else:
         run_isolated("test_gpu_oracle_full_size", "check_split_build", 20000, dict(family_size=8), "classic", env={"FGX_S2_PACKED": "0"})
