@@ -182,6 +182,7 @@ struct DuplexEmitParams {
   const uint8_t* col_code; const uint8_t* col_qual; const uint16_t* col_err; const uint32_t* col_obs;
   const char* prefix; uint32_t prefix_len; const char* rg; uint32_t rg_len;
   uint8_t per_base_tags; char cell0, cell1;
+  uint32_t* n_slow;                // k_count_slow_duplex counts the valid records the fast writer leaves to the per-field kernel here (0: that kernel is not launched at all)
 };
 
 struct CodecEmitParams {
@@ -192,6 +193,7 @@ struct CodecEmitParams {
   uint8_t per_base_tags; char cell0, cell1;
   uint8_t has_outer, outer_qual, has_ss, ss_qual; uint32_t outer_len;
   unsigned long long* stats;       // slot-spread counters: [24] consensus bases, [25] duplex bases, [26] disagreeing duplex bases
+  uint32_t* n_slow;                // k_count_slow_codec counts the valid records the fast writer leaves to the per-field kernel here
 };
 
 struct FastResult {

@@ -3597,6 +3597,22 @@ __device__ __forceinline__ void put_seq_qual(FW& W, uint32_t L, C code_of, Q qua
   W.q += L;
 }
 
+// (round 6) how many valid records the fast writers refuse — a thread per slot, one atomic per wavefront: the per-field writers (k_emit_duplex / k_emit_codec)
+// are launched only when the count is not 0.  (Counting inside the fast writers cost them a wavefront per SIMD: 71 -> 73 / 79 -> 89 VGPRs.)
+__global__ __launch_bounds__(256) void k_count_slow_duplex(const DuplexDesc* __restrict__ ends, uint32_t slot0, uint32_t slot_end, uint32_t prefix_len, uint32_t rg_len, uint32_t* __restrict__ n_slow) {
+  const uint32_t slot = slot0 + blockIdx.x * blockDim.x + threadIdx.x;
+  bool slow = false;
+  if (slot < slot_end) { const DuplexDesc& D = ends[slot]; slow = D.valid && !duplex_fast_ok(D, prefix_len, rg_len); }
+  const unsigned long long m = __ballot(slow);
+  if (m && (threadIdx.x & 63) == 0) atomicAdd(n_slow, (uint32_t)__popcll(m));
+}
+__global__ __launch_bounds__(256) void k_count_slow_codec(const CodecDesc* __restrict__ ends, uint32_t slot0, uint32_t slot_end, uint32_t prefix_len, uint32_t rg_len, uint32_t* __restrict__ n_slow) {
+  const uint32_t slot = slot0 + blockIdx.x * blockDim.x + threadIdx.x;
+  bool slow = false;
+  if (slot < slot_end) { const CodecDesc& D = ends[slot]; slow = D.valid && !codec_fast_ok(D, prefix_len, rg_len); }
+  const unsigned long long m = __ballot(slow);
+  if (m && (threadIdx.x & 63) == 0) atomicAdd(n_slow, (uint32_t)__popcll(m));
+}
 __global__ __launch_bounds__(256) void k_emit_duplex_fast(DuplexEmitParams P) {
   const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(P.slot0 + ((blockIdx.x * blockDim.x + threadIdx.x) >> 6)));
   const uint32_t lane = threadIdx.x & 63;
@@ -3614,13 +3630,20 @@ __global__ __launch_bounds__(256) void k_emit_duplex_fast(DuplexEmitParams P) {
   // ---- every load of the record (indices clamped into the record's own segments, so unconditional) -----------------------
   uint32_t ca[DUP_SLOTS][2], qa[DUP_SLOTS][2], ea[DUP_SLOTS][2], oa[DUP_SLOTS][2], cb[DUP_SLOTS][2], qb[DUP_SLOTS][2], eb[DUP_SLOTS][2], ob[DUP_SLOTS][2];
 #pragma unroll
-  for (uint32_t t = 0; t < DUP_SLOTS; t++)
-#pragma unroll
-    for (uint32_t k = 0; k < 2; k++) {
-      const uint32_t p = 128 * t + 2 * lane + k, pc = p < lastp ? p : lastp;
-      ca[t][k] = P.col_code[a_off + pc]; qa[t][k] = P.col_qual[a_off + pc]; ea[t][k] = P.col_err[a_off + pc]; oa[t][k] = P.col_obs[a_off + pc];
-      cb[t][k] = P.col_code[b_off + pc]; qb[t][k] = P.col_qual[b_off + pc]; eb[t][k] = P.col_err[b_off + pc]; ob[t][k] = P.col_obs[b_off + pc];
-    }
+  for (uint32_t t = 0; t < DUP_SLOTS; t++) {
+    // (round 6) a lane's two neighbouring positions with ONE load per array and strand (2 + 2 + 4 + 8 bytes) instead of one per position: 16 vector memory
+    // instructions per lane where there were 32.  The pair's first position is clamped into the record; its second may lie one column past the end
+    // (the scratch arrays carry slack) — such a position is masked out of the statistics and written by no field writer.
+    const uint32_t pb = 128 * t + 2 * lane, pc = pb < lastp ? pb : lastp;
+    auto ld2 = [&](uint64_t off, uint32_t* c2, uint32_t* q2, uint32_t* e2, uint32_t* o2) {
+      uint16_t cw, qw; uint32_t ew; unsigned long long ow;
+      __builtin_memcpy(&cw, P.col_code + off, 2); __builtin_memcpy(&qw, P.col_qual + off, 2);
+      __builtin_memcpy(&ew, (const uint8_t*)P.col_err + 2 * off, 4); __builtin_memcpy(&ow, (const uint8_t*)P.col_obs + 4 * off, 8);
+      c2[0] = cw & 0xFFu; c2[1] = cw >> 8; q2[0] = qw & 0xFFu; q2[1] = qw >> 8; e2[0] = ew & 0xFFFFu; e2[1] = ew >> 16; o2[0] = (uint32_t)ow; o2[1] = (uint32_t)(ow >> 32);
+    };
+    ld2(a_off + pc, ca[t], qa[t], ea[t], oa[t]);
+    ld2(b_off + pc, cb[t], qb[t], eb[t], ob[t]);
+  }
   const uint32_t k3 = lane >= 3 ? lane - 3 : 0, ni = lane > P.prefix_len ? lane - P.prefix_len - 1 : 0;
   const uint8_t pfx = (uint8_t)P.prefix[lane < P.prefix_len ? lane : 0], nmb = first[mi_off + (ni < mi_len ? ni : mi_len)];
   // ---- the duplex call of each position, packed: w0 = ca | cb<<4 | oc<<8 | qa<<16 | qb<<24 ; w1 = da | db<<8 | ea<<16 | eb<<24 ; w2 = oq | oe<<8
@@ -4682,6 +4705,12 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
   E.prefix = d_strings.as<char>(); E.prefix_len = P.prefix_len; E.rg = d_strings.as<char>() + P.prefix_len; E.rg_len = P.rg_len;
   E.per_base_tags = P.per_base_tags; E.tag0 = P.tag0; E.tag1 = P.tag1; E.cell0 = P.cell0; E.cell1 = P.cell1;
   hip_check(hipEventRecord(ev[2], s), "event");
+  // (round 6) duplex / CODEC: the per-field record writer (k_emit_duplex / k_emit_codec: any length, any tag size) used to run over EVERY slot behind the fast
+  // writer and find nothing to do (0.97 / 0.33 ms per step of wavefronts that load a descriptor and leave); a counting kernel (a thread per slot) now says
+  // how many records the fast writer refuses, and the per-field kernel is launched — after the batch's last synchronisation — only when there are any
+  DuplexEmitParams DE_late;
+  CodecEmitParams CE_late;
+  int late_emit = 0;
   if (codec) {
     CodecEmitParams CE;
     memset(&CE, 0, sizeof(CE));
@@ -4693,8 +4722,10 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
     CE.has_outer = o.codec_has_outer_bases_qual; CE.outer_qual = o.codec_outer_bases_qual; CE.outer_len = o.codec_outer_bases_length;
     CE.has_ss = o.codec_has_single_strand_qual; CE.ss_qual = o.codec_single_strand_qual;
     CE.stats = d_statslots.as<unsigned long long>();
+    CE.n_slow = (uint32_t*)(misc + 44);
+    CE_late = CE; late_emit = 2;
+    do { last_launches++; hipLaunchKernelGGL(k_count_slow_codec, dim3((n_slots + 255) / 256), dim3(256), 0, s, CE.ends, 0u, n_slots, CE.prefix_len, CE.rg_len, CE.n_slow); } while (0);
     do { last_launches++; hipLaunchKernelGGL(k_emit_codec_fast, dim3((n_slots + 3) / 4), dim3(256), 0, s, CE); } while (0);
-    do { last_launches++; hipLaunchKernelGGL(k_emit_codec, dim3((n_slots + 3) / 4), dim3(256), 0, s, CE); } while (0);
   } else if (duplex) {
     DuplexEmitParams DE;
     memset(&DE, 0, sizeof(DE));
@@ -4703,8 +4734,10 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
     DE.col_code = P.col_code; DE.col_qual = P.col_qual; DE.col_err = P.col_err; DE.col_obs = P.col_obs;
     DE.prefix = E.prefix; DE.prefix_len = E.prefix_len; DE.rg = E.rg; DE.rg_len = E.rg_len;
     DE.per_base_tags = P.per_base_tags; DE.cell0 = P.cell0; DE.cell1 = P.cell1;
+    DE.n_slow = (uint32_t*)(misc + 44);
+    DE_late = DE; late_emit = 1;
+    do { last_launches++; hipLaunchKernelGGL(k_count_slow_duplex, dim3((n_slots + 255) / 256), dim3(256), 0, s, DE.ends, 0u, n_slots, DE.prefix_len, DE.rg_len, DE.n_slow); } while (0);
     do { last_launches++; hipLaunchKernelGGL(k_emit_duplex_fast, dim3((n_slots + 3) / 4), dim3(256), 0, s, DE); } while (0);
-    do { last_launches++; hipLaunchKernelGGL(k_emit_duplex, dim3((n_slots + 3) / 4), dim3(256), 0, s, DE); } while (0);
   } else if (direct) {
     if (!dir_pure) {
       // the merge: the families that left the split pipeline are written by k_emit from their descriptors, the directly written ones move
@@ -4725,9 +4758,17 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
   hip_check(hipEventRecord(ev[3], s), "event");
   hip_check(hipEventRecord(c->ev1, s), "event");
   do { last_launches++; hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(64), 0, s, d_statslots.as<unsigned long long>(), misc); } while (0);
-  unsigned long long h_misc[44];
+  unsigned long long h_misc[46];
   hip_check(hipMemcpyAsync(h_misc, misc, sizeof(h_misc), hipMemcpyDeviceToHost, s), "D2H");
   FGX_SYNC(s);
+  if (late_emit && (uint32_t)h_misc[44] != 0) {     // records the fast writer left: the per-field kernel, then the counters again (the CODEC writer counts bases)
+    if (late_emit == 2) do { last_launches++; hipLaunchKernelGGL(k_emit_codec, dim3((n_slots + 3) / 4), dim3(256), 0, s, CE_late); } while (0);
+    else do { last_launches++; hipLaunchKernelGGL(k_emit_duplex, dim3((n_slots + 3) / 4), dim3(256), 0, s, DE_late); } while (0);
+    hip_check(hipGetLastError(), "per-field record writer launch");
+    do { last_launches++; hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(64), 0, s, d_statslots.as<unsigned long long>(), misc); } while (0);
+    hip_check(hipMemcpyAsync(h_misc, misc, sizeof(h_misc), hipMemcpyDeviceToHost, s), "D2H");
+    FGX_SYNC(s);
+  }
   float ms = 0;
   hip_check(hipEventElapsedTime(&ms, c->ev0, c->ev1), "elapsed");
 

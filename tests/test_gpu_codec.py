@@ -163,3 +163,9 @@ def test_codec_device_resident_matches_oracle():
         ws = want["stats"]
         assert got == [int(ws[0]), int(ws[1]), int(ws[2]), int(ws[24]), int(ws[25]), int(ws[26]), int(ws[27])]
         c.close()
+
+
+def test_long_read_name_prefix_takes_the_per_field_writer():
+    """(round 6) k_emit_codec is launched only when the fast writer counted records it refuses (and the base counters are reduced again behind it)."""
+    from fgumi_amd import simulate_grouped_reads
+    _same(simulate_grouped_reads(200, family_size=3, read_length=150, insert_mean=200, insert_sd=30, codec=1), prefix="c" * 70)

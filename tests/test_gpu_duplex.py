@@ -140,3 +140,10 @@ def test_duplex_device_resident_matches_oracle():
         assert out.n_deferred == 0
         assert out.count == want["count"] and data == want["data"]
         c.close()
+
+
+def test_long_read_name_prefix_takes_the_per_field_writer():
+    """(round 6) k_emit_duplex — the per-field record writer — is launched only when the fast writer counted records it refuses: a 70-character
+    read-name prefix makes it refuse every record."""
+    from fgumi_amd import simulate_grouped_reads
+    _same(simulate_grouped_reads(200, family_size=6, duplex=1), prefix="d" * 70)

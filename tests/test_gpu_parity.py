@@ -392,3 +392,10 @@ def test_noisy_batch_grows_the_call_full_pool_instead_of_deferring(monkeypatch):
     assert out.n_deferred == 0
     assert out.to_host() == want["data"]
     c.close()
+
+
+def test_long_read_name_prefix_takes_the_per_field_writer():
+    """A read-name prefix of 70 characters: names no longer fit the lanes of the one-store field writers (k_emit's pair writer and its per-record fast
+    path refuse the record) — emit_generic, field after field."""
+    g = simulate_grouped_reads(300, family_size=5)
+    _assert_same(g, prefix="p" * 70)

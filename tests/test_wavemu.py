@@ -78,6 +78,15 @@ def test_other_simplex_shapes(case):
         run_isolated("test_wavemu", "check_device_entry", 0, 1500, dict(family_size=6), dict(min_reads=2, overlapping_consensus=0), env=env(), timeout=900)
 
 
+@pytest.mark.parametrize("kind", [0, 1, 2], ids=["simplex", "duplex", "codec"])
+def test_per_field_record_writers(kind):
+    """A 70-character read-name prefix: the one-store field writers refuse every record — emit_generic / k_emit_duplex / k_emit_codec (the latter two launched
+    only because the fast writers counted what they refused)."""
+    sim = [dict(family_size=5), dict(family_size=6, duplex=1), dict(family_size=3, read_length=150, insert_mean=200, insert_sd=30, codec=1)][kind]
+    opts = dict(read_name_prefix=b"n" * 70, **(dict(overlapping_consensus=0) if kind == 2 else dict(min_reads=1)))
+    run_isolated("test_wavemu", "check_device_entry", kind, 150, sim, opts, env=env(), timeout=900)
+
+
 @pytest.mark.parametrize("kind,sim", [(1, dict(family_size=12, duplex=1)), (2, dict(family_size=4, read_length=300, insert_mean=350, insert_sd=60, codec=1))], ids=["duplex", "codec"])
 def test_duplex_and_codec_wavefront_kernels(kind, sim):
     """k_family_wave<1> / <2> and their record writers (k_emit_duplex_fast / k_emit_codec_fast) on 400 molecules."""
