@@ -5,7 +5,7 @@
 # usage: bash tools/profile_round.sh <tag>        results land in gpurun_out/<tag>/ ; copy the summaries to profiles/
 TAG=$1; R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 cd $R
-timeout 900 python -m pytest tests -m gpu -q -x -p no:cacheprovider -rfE --timeout 300 > $OUT/pytest.log 2>&1; rc=$?; echo "pytest rc=$rc" >> $OUT/pytest.log
+timeout 1500 python -m pytest tests -m gpu -q -x -p no:cacheprovider -rfE --timeout 600 > $OUT/pytest.log 2>&1; rc=$?; echo "pytest rc=$rc" >> $OUT/pytest.log
 tail -3 $OUT/pytest.log
 # (round 5: a box whose first GPU test died with a device memory fault went on to burn 25 GPU-minutes in timeouts — nothing below is worth running then)
 [ $rc -ne 0 ] && { echo "GPU suite failed (rc=$rc): the measurement round stops here"; exit 1; }
