@@ -421,13 +421,16 @@ def main():
             for _ in range(2):
                 caller.process_batch_device(dg)
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            out = None
-            for _ in range(steps):
+            out, per_step = None, []
+            for _ in range(steps):               # one rank's step ends with its output on the host's side of a synchronize: time each step that way
+                t0 = time.perf_counter()
                 out = caller.process_batch_device(dg)
-            torch.cuda.synchronize()
-            ms = (time.perf_counter() - t0) / steps * 1e3
-            r = dict(families=int(fam), raw_reads=int(dg.n_rec), ms_per_step=ms, value=dg.n_rec / ms * 1e3, deferred_families=int(out.n_deferred), **(last_chain() or {}))
+                torch.cuda.synchronize()
+                per_step.append((time.perf_counter() - t0) * 1e3)
+            # the median: a 4 ms step is short enough for one host hiccup (tools/share_probe.py saw a single 10 ms step in 200) to move a mean of 20
+            ms = float(np.median(per_step))
+            r = dict(families=int(fam), raw_reads=int(dg.n_rec), ms_per_step=ms, ms_per_step_mean=float(np.mean(per_step)), ms_per_step_max=float(np.max(per_step)), steps=steps,
+                     value=dg.n_rec / ms * 1e3, deferred_families=int(out.n_deferred), **(last_chain() or {}))
             del dg, out
             torch.cuda.empty_cache()
             return r
@@ -449,7 +452,8 @@ def main():
         b["shard_bytes_share"] = float(np.asarray(w[lo:hi], dtype=np.float64).sum() / np.asarray(w, dtype=np.float64).sum())
         res["long_tail_share"] = b
         res["note"] = ("one rank's share of an 8-way strong-scaling run, measured on ONE GPU: ranks are independent (no data-path collective), so eight of them "
-                       "finish in the time of the slowest share; what does not shrink with the batch — launches, host synchronisations, the tail of every kernel — shows here")
+                       "finish in the time of the slowest share; what does not shrink with the batch — launches, host synchronisations, the tail of every kernel — shows here. "
+                       "ms_per_step = the MEDIAN of the timed steps, each ended by a device synchronize (mean and max beside it)")
         return res
 
     M = measure(args.scaling, args.steps, args.warmup)
@@ -554,6 +558,12 @@ def main():
                                                          "value_within_2pct_of_the_weak_line": abs((s_raw * s_steps / S["dt"]) / (total_raw * steps / dt) - 1.0) < 0.02},
                 "value_with_reassembly_on_root": (s_raw * s_steps / S["dt_gather"]) if S["dt_gather"] else None,
             }
+        # (the GPU legs back to back, before the host-side ones: the share step is latency bound and the first to feel a busy host)
+        if world == 1 and plain and not args.no_share_block and not args.no_cpu_baseline and args.families >= 8:     # (profiling runs — --no-cpu-baseline — time the headline workload alone)
+            try:
+                line["share_of_8"] = share_of_8()
+            except Exception as ex:
+                line["share_of_8"] = {"error": str(ex)[:300]}
         if world == 1 and plain and args.end_to_end_families > 0 and not args.no_cpu_baseline:     # (the two extra legs go together: profiling runs switch both off)
             try:
                 line["end_to_end"] = end_to_end(caller, min(args.end_to_end_families, fam), args.depth, L, os.environ.get("FGX_BENCH_TMP", "/tmp/fgx_bench_e2e"))
@@ -571,11 +581,6 @@ def main():
                     line["end_to_end"]["vs_cpu_end_to_end_if_its_stages_overlapped"] = line["end_to_end"]["value"] / ce["value_if_stages_overlapped"]
                 except Exception as ex:
                     line["cpu_baseline"]["end_to_end"] = {"error": str(ex)[:300]}
-        if world == 1 and plain and not args.no_share_block and not args.no_cpu_baseline and args.families >= 8:     # (profiling runs — --no-cpu-baseline — time the headline workload alone)
-            try:
-                line["share_of_8"] = share_of_8()
-            except Exception as ex:
-                line["share_of_8"] = {"error": str(ex)[:300]}
     # ---- the gather to rank 0 (single-writer reassembly), LAST and under a watchdog: every other number of the line is final by now.  A rank that
     #      throws in the gather leaves the others blocked inside RCCL, where no exception reaches them — so each rank arms a timer: rank 0's prints the
     #      line as it stands (reassemble_error = the reason) and every rank's ends its process with exit code 0.
