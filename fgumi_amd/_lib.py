@@ -76,7 +76,7 @@ class BamRunStats(C.Structure):
                 ("seconds_write", C.c_double), ("seconds_h2d", C.c_double), ("seconds_boundaries", C.c_double), ("seconds_grouping", C.c_double),
                 ("seconds_consensus", C.c_double), ("seconds_d2h", C.c_double), ("seconds_device_inflate", C.c_double),
                 ("boundary_repair_rounds", C.c_uint32), ("device_inflate", C.c_uint32), ("seconds_device_deflate", C.c_double),
-                ("device_deflate", C.c_uint32), ("_pad", C.c_uint32)]
+                ("device_deflate", C.c_uint32), ("host_entry_batches", C.c_uint32)]
 
 
 EXPORTS = ["fgx_options_default", "fgx_create", "fgx_destroy", "fgx_last_error", "fgx_global_error", "fgx_process_batch",
@@ -85,7 +85,7 @@ EXPORTS = ["fgx_options_default", "fgx_create", "fgx_destroy", "fgx_last_error",
            "fgx_sim_generate_host", "fgx_sim_generate_device", "fgx_group_records", "fgx_group_records_device", "fgx_filter_options_default",
            "fgx_filter_records", "fgx_filter_records_device", "fgx_filter_last_output_device",
            "fgx_record_boundaries_device", "fgx_inflate_block_host", "fgx_inflate_block_two_phase_host", "fgx_deflate_block_host", "fgx_run_bam", "fgx_run_bam_rejects", "fgx_bgzf_inflate_device_bench", "fgx_bgzf_recompress_file", "fgx_pipeline_last_error",
-           "fgx_set_reference", "fgx_methylation_annotate_host", "fgx_methylation_runs_host", "fgx_methylation_mm_ml_host", "fgx_canon_duplex_host", "fgx_canon_codec_host", "fgx_simplex_rejects_host", "fgx_balanced_shards", "fgx_regenerate_alignment_tags_host"]
+           "fgx_set_reference", "fgx_methylation_annotate_host", "fgx_methylation_runs_host", "fgx_methylation_mm_ml_host", "fgx_canon_duplex_host", "fgx_canon_codec_host", "fgx_simplex_rejects_host", "fgx_strand_rejects_host", "fgx_balanced_shards", "fgx_regenerate_alignment_tags_host"]
 
 _lib = None
 
@@ -184,6 +184,8 @@ def load():
     L.fgx_canon_codec_host.restype = I
     L.fgx_simplex_rejects_host.argtypes = [VP, VP, VP, VP, VP, U32, VP, U64, VP, VP]
     L.fgx_simplex_rejects_host.restype = I
+    L.fgx_strand_rejects_host.argtypes = [VP, VP, VP, VP, VP, U32, VP, VP, U64, VP, VP]
+    L.fgx_strand_rejects_host.restype = I
     # host-only helpers (not part of the public header; used by CPU-side tests)
     L.fgx_build_tables_host.argtypes = [U8, U8, I, VP, P(U32), VP]
     L.fgx_build_tables_host.restype = I

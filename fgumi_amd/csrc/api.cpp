@@ -475,6 +475,45 @@ int fgx_simplex_rejects_host(const fgx_options* o, const uint8_t* blob, const ui
   return 0;
 }
 
+static rej::DuplexParams duplex_reject_params(const fgx_options* o) {
+  rej::DuplexParams P;
+  P.min_bq = o->min_input_base_quality; P.overlapping = o->overlapping_consensus; P.trim = o->trim; P.single_strand_ok = o->duplex_min_reads[2] == 0;
+  return P;
+}
+// reject_core.h on the host: the `--rejects` stream of the DUPLEX (kind 1) or CODEC (kind 2) caller for a batch, given which molecules gave
+// their consensus (`kept[g]` != 0: on the device the pipeline's own output slots say so).  Same contract as fgx_simplex_rejects_host.
+int fgx_strand_rejects_host(const fgx_options* o, const uint8_t* blob, const uint64_t* rec_off, const uint32_t* rec_len, const uint32_t* grp_first, uint32_t n_grp,
+                            const uint8_t* kept, uint8_t* out, uint64_t cap, uint64_t* out_len, uint64_t* n_rejects) {
+  if (!o || o->struct_size != sizeof(fgx_options) || !out_len || !n_rejects || (n_grp && (!blob || !rec_off || !rec_len || !grp_first || !kept))) return 2;
+  if (o->caller_kind != FGX_CALLER_DUPLEX && o->caller_kind != FGX_CALLER_CODEC) return 2;
+  const bool codec = o->caller_kind == FGX_CALLER_CODEC;
+  const rej::DuplexParams P = duplex_reject_params(o);
+  std::unique_ptr<rej::Scratch> S(new rej::Scratch());
+  std::unique_ptr<canon::CodecScratch> SC(new canon::CodecScratch());
+  std::vector<uint8_t> work, code;
+  uint64_t pos = 0, cnt = 0;
+  for (uint32_t g = 0; g < n_grp; g++) {
+    const uint32_t r0 = grp_first[g], n = grp_first[g + 1] - r0;
+    uint64_t bytes = 0;
+    for (uint32_t i = 0; i < n; i++) bytes += rec_len[r0 + i];
+    work.resize(bytes + 16); code.assign(n + 1, 0);
+    uint8_t corrected = 0;
+    const int st = codec ? rej::codec_reject_mask(o->codec_max_reads_per_strand >= 0, blob, ~0ull, rec_off + r0, rec_len + r0, n, kept[g] != 0, code.data(), *SC)
+                         : rej::duplex_reject_codes(P, blob, ~0ull, rec_off + r0, rec_len + r0, n, kept[g] != 0, work.data(), code.data(), *S, &corrected);
+    if (st != rej::REJ_OK) return 1;
+    uint32_t c = 0;
+    const uint64_t b = rej::reject_bytes(rec_len + r0, n, code.data(), &c);
+    if (out && b) {
+      if (pos + b > cap) return 2;
+      if (codec) rej::emit_rejects(blob, rec_off + r0, rec_len + r0, n, code.data(), false, work.data(), S->c.ops, out + pos);
+      else rej::emit_rejects_by_class(blob, rec_off + r0, rec_len + r0, n, code.data(), corrected != 0, work.data(), S->c.ops, out + pos);
+    }
+    pos += b; cnt += c;
+  }
+  *out_len = pos; *n_rejects = cnt;
+  return 0;
+}
+
 // Host-input entry: upload once, run the device-resident pipeline, bring the records back, and send
 // only the families the fast path deferred through the general path, splicing both in group order.
 typedef int (*general_fn)(fgx_caller*, const uint8_t*, const uint64_t*, const uint32_t*, uint32_t, const uint32_t*, uint32_t, fgx_output*);
@@ -598,9 +637,13 @@ static int process_hybrid(fgx_caller* c, general_fn general, const uint8_t* reco
   // uploaded records, a lane per group (reject_device.hip / reject_core.h), and the records from the device pipeline as without --rejects.
   const bool dev_rejects = c->opt.track_rejects && c->opt.caller_kind == FGX_CALLER_SIMPLEX && c->opt.methylation_mode == FGX_METHYLATION_DISABLED && n_grp != 0 &&
                            rejects_device_enabled();
+  // Duplex / CODEC callers (round 6): the same side kernels, AFTER the device pipeline — whether a molecule gave its consensus is read from the pipeline's
+  // output slots (reject_core.h duplex_reject_codes / codec_reject_mask).  A batch with a deferred molecule or one out of the kernels' scope: general path.
+  const bool strand_rejects = c->opt.track_rejects && (c->opt.caller_kind == FGX_CALLER_DUPLEX || c->opt.caller_kind == FGX_CALLER_CODEC) &&
+                              c->opt.methylation_mode == FGX_METHYLATION_DISABLED && n_grp != 0 && rejects_device_enabled();
   c->last_canon_molecules = 0;
   c->last_deferred_groups = n_grp;          // (diagnostics, fgx_debug_last_deferral: the whole batch on the general path counts as every group deferred)
-  if ((c->opt.track_rejects && !dev_rejects) || (c->opt.methylation_mode != FGX_METHYLATION_DISABLED && !meth_device_enabled(c)) || n_grp == 0) return run_general(c, general, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
+  if ((c->opt.track_rejects && !dev_rejects && !strand_rejects) || (c->opt.methylation_mode != FGX_METHYLATION_DISABLED && !meth_device_enabled(c)) || n_grp == 0) return run_general(c, general, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
   if (!c->fast) c->fast = new FastState();
   auto t0 = clk::now();
   hybrid_upload(c, records, records_len, rec_off, rec_len, n_rec, grp_first, n_grp);
@@ -616,9 +659,25 @@ static int process_hybrid(fgx_caller* c, general_fn general, const uint8_t* reco
   // (the rejects of EVERY group are in hand, also of the groups the device pipeline defers: the general path need not track them again)
   struct Untrack { fgx_caller* c; uint8_t saved; Untrack(fgx_caller* cc, bool on) : c(cc), saved(cc->opt.track_rejects) { if (on) set(0); }
                    void set(uint8_t v) { c->opt.track_rejects = v; for (fgx_caller* w : c->workers) w->opt.track_rejects = v; }
-                   ~Untrack() { set(saved); } } untrack(c, dev_rejects);
+                   ~Untrack() { set(saved); } } untrack(c, dev_rejects || strand_rejects);
   int rc = hybrid_after_upload(c, general, records, records_len, rec_off, rec_len, n_rec, grp_first, n_grp, out, nullptr, 0);
-  if (rc == 0 && dev_rejects) { out->rejects = c->rejects_host.data(); out->rejects_len = rr.bytes; out->n_rejects = rr.count; out->ms_kernels += rr.ms; }
+  if (rc == 0 && strand_rejects) {
+    const FastResult& fr = c->fast->last;      // (hybrid_after_upload left the device pass's result there; the uploaded records are still in d_in_*)
+    bool served = c->last_deferred_groups == 0;
+    if (served) {
+      strand_rejects_device(c, c->d_in_blob.as<uint8_t>(), records_len, c->d_in_off.as<uint64_t>(), c->d_in_len.as<uint32_t>(), n_rec, c->d_in_grp.as<uint32_t>(), n_grp,
+                            fr.d_out_off, 3, fr.out_len, &rr);
+      c->last_reject_oos = rr.n_out_of_scope;
+      served = rr.n_out_of_scope == 0;
+    }
+    if (!served) {                                   // the whole batch again, on the general path, which tracks its rejects itself
+      untrack.set(untrack.saved);
+      return run_general(c, general, records, rec_off, rec_len, n_rec, grp_first, n_grp, out);
+    }
+    c->rejects_host.resize(rr.bytes);
+    if (rr.bytes) hip_check(hipMemcpy(c->rejects_host.data(), rr.d_out, rr.bytes, hipMemcpyDeviceToHost), "D2H rejects");
+  }
+  if (rc == 0 && (dev_rejects || strand_rejects)) { out->rejects = c->rejects_host.data(); out->rejects_len = rr.bytes; out->n_rejects = rr.count; out->ms_kernels += rr.ms; }
   if (rc == 0) out->ms_h2d = ms_between(t0, t1);
   return rc;
 }
@@ -768,6 +827,7 @@ static int hybrid_after_upload(fgx_caller* c, general_fn general, const uint8_t*
   FastResult fr;
   c->fast->fp.run(c, c->d_in_blob.as<uint8_t>(), records_len, c->d_in_off.as<uint64_t>(), c->d_in_len.as<uint32_t>(), n_rec,
                   c->d_in_grp.as<uint32_t>(), n_grp, &fr);
+  c->fast->last = fr;          // (has_last stays false: process_hybrid's duplex / CODEC rejects read the slot offsets of THIS pass)
   auto t2 = clk::now();
   // records land in a pinned host buffer owned by the caller object (pageable destinations cost ~10x: first-touch faults + staging)
   const bool direct = dst && fr.n_deferred == 0 && fr.out_len <= dst_cap;
@@ -968,7 +1028,8 @@ int fgx_process_batch_device(fgx_caller* c, const void* d_records, uint64_t reco
       c->err = "fgx_process_batch_device: CODEC duplex-disagreement thresholds need the host path (fgx_process_batch)"; return 1;
     }
     const bool dev_rejects = c->opt.track_rejects && c->opt.caller_kind == FGX_CALLER_SIMPLEX && rejects_device_enabled();
-    if (c->opt.track_rejects && !dev_rejects) { c->err = "fgx_process_batch_device: --rejects needs the host path (fgx_process_batch)"; return 1; }
+    const bool strand_rejects = c->opt.track_rejects && (c->opt.caller_kind == FGX_CALLER_DUPLEX || c->opt.caller_kind == FGX_CALLER_CODEC) && rejects_device_enabled();
+    if (c->opt.track_rejects && !dev_rejects && !strand_rejects) { c->err = "fgx_process_batch_device: --rejects needs the host path (fgx_process_batch)"; return 1; }
     // methylation-aware mode: the simplex caller without --trim runs on the streaming kernels (simplex_deep.inc); FGX_METH_DEVICE=0, duplex or
     // --trim: the host entry (general path)
     if (c->opt.methylation_mode != FGX_METHYLATION_DISABLED && !meth_device_enabled(c)) { c->err = "fgx_process_batch_device: the methylation-aware mode of this caller needs the host entry (fgx_process_batch)"; return 1; }
@@ -989,6 +1050,7 @@ int fgx_process_batch_device(fgx_caller* c, const void* d_records, uint64_t reco
     if (d_deferred_groups) *d_deferred_groups = fr.d_deferred;
     c->last_deferred_groups = fr.n_deferred; c->last_canon_molecules = 0;
     c->last_group_off = fr.d_out_off; c->last_group_stride = 3;
+    uint32_t left_deferred = fr.n_deferred;      // (after the canonical second pass, when it runs)
     if (fr.n_deferred > 0 && canon_resident_enabled(c->opt.caller_kind)) {
       ResidentOut ro;
       if (canon_resident_pass(c, (const uint8_t*)d_records, (const uint64_t*)d_rec_off, (const uint32_t*)d_rec_len, (const uint32_t*)d_grp_first, n_grp, fr, &ro)) {
@@ -998,9 +1060,19 @@ int fgx_process_batch_device(fgx_caller* c, const void* d_records, uint64_t reco
         out->ms_kernels += ro.ms_kernels;
         if (n_deferred) *n_deferred = ro.n_deferred;
         if (d_deferred_groups) *d_deferred_groups = ro.d_deferred;
+        left_deferred = ro.n_deferred;
         c->last_canon_molecules = ro.n_canon;
         c->last_group_off = ro.d_group_off; c->last_group_stride = 1;
       }
+    }
+    if (strand_rejects) {   // duplex / CODEC (round 6): from the records and the batch's own output slots (which molecules gave their consensus)
+      if (left_deferred != 0) { c->err = "fgx_process_batch_device: --rejects: the batch has molecules the device pipeline defers; use the host entry (fgx_process_batch)"; return 1; }
+      RejectResult rr;
+      strand_rejects_device(c, (const uint8_t*)d_records, records_len, (const uint64_t*)d_rec_off, (const uint32_t*)d_rec_len, n_rec, (const uint32_t*)d_grp_first, n_grp,
+                            c->last_group_off, c->last_group_stride, out->data_len, &rr);
+      c->last_reject_oos = rr.n_out_of_scope;
+      if (rr.n_out_of_scope) { c->err = "fgx_process_batch_device: --rejects: a molecule is out of the side kernels' scope (more than 128 records or 16 CIGAR ops, a per-strand cap, malformed records); use the host entry (fgx_process_batch)"; return 1; }
+      out->rejects = rr.d_out; out->rejects_len = rr.bytes; out->n_rejects = rr.count; out->ms_kernels += rr.ms;
     }
     if (dev_rejects) {   // out->rejects is a DEVICE pointer here, like out->data; it covers every group, the deferred ones included
       RejectResult rr;

@@ -207,6 +207,8 @@ namespace rej { struct Params; }
 struct RejectResult { const uint8_t* d_out; uint64_t bytes, count; uint32_t n_out_of_scope; double ms; };
 void simplex_rejects_device(fgx_caller* c, const rej::Params& P, const uint8_t* d_blob, uint64_t blob_len, const uint64_t* d_rec_off, const uint32_t* d_rec_len, uint32_t n_rec,
                             const uint32_t* d_grp_first, uint32_t n_grp, RejectResult* r);
+void strand_rejects_device(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const uint64_t* d_rec_off, const uint32_t* d_rec_len, uint32_t n_rec,
+                           const uint32_t* d_grp_first, uint32_t n_grp, const uint64_t* d_group_off, uint32_t stride, uint64_t out_len, RejectResult* r);
 void reject_release(fgx_caller* c);
 int group_records_device(fgx_caller* c, const fgx_group_options* o, const uint8_t* d_blob, uint64_t blob_len, const uint64_t* d_rec_off,
                          const uint32_t* d_rec_len, uint32_t n, uint64_t* d_out_off, uint32_t* d_out_len, uint32_t* d_grp_first, uint32_t* n_kept,

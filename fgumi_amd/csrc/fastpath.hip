@@ -4276,10 +4276,12 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
         hip_check(hipEventRecord(ev_chunk[ci], s2), "event");
       };
       if (!early_parse) launch_parse(0);
-      // the tile strides of the first families decide which build of k_split_cols goes first
+      // the tile strides of a sample of families decide which build of k_split_cols goes first: 64 families spread evenly over the first chunk (one strided
+      // copy; round 5 took the batch's FIRST 64 — the head of a coordinate-sorted file need not look like the rest)
       SplitFam fam_sample[64];
       const uint32_t n_sample = n_grp < 64u ? n_grp : 64u;
-      hip_check(hipMemcpyAsync(fam_sample, d_split_fam.p, (size_t)n_sample * sizeof(SplitFam), hipMemcpyDeviceToHost, s2), "D2H");
+      const uint32_t sample_span = (uint32_t)std::min<uint64_t>(chunk_fam, n_grp), sample_stride = std::max<uint32_t>(1u, sample_span / 64u);
+      hip_check(hipMemcpy2DAsync(fam_sample, sizeof(SplitFam), d_split_fam.p, (size_t)sample_stride * sizeof(SplitFam), sizeof(SplitFam), n_sample, hipMemcpyDeviceToHost, s2), "D2H sample");
       hip_check(hipEventRecord(ev_sample, s2), "event");
       // (round 5) the record kernel is bound by HBM bandwidth (it reads the whole blob: 4.2 TB/s alone on the chip), and a column kernel
       // beside it gets what is left — with every chunk's record kernel queued up front, the first column kernel took 6.9 ms instead of

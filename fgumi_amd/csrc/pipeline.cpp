@@ -319,8 +319,8 @@ int fgx_run_bam_rejects(fgx_caller* c, const char* in_path, const char* out_path
         uint32_t n_def = 0;
         const void* d_def = nullptr;
         int prc = fgx_process_batch_device(c, base, batch_end, d_koff.p, d_klen.p, batch_rec, d_grp.p, batch_grp, &out, &n_def, &d_def);
-        // --rejects: the device entry serves the simplex caller through its side kernels; what it refuses (a group outside their scope: more
-        // than 128 records, malformed records; the duplex / CODEC callers; FGX_REJECTS_DEVICE=0) goes through the host entry in one piece
+        // --rejects: the device entry serves the callers through its side kernels (duplex / CODEC since round 6); what it refuses (a group outside their
+        // scope: more than 128 records, malformed records; a duplex / CODEC batch with deferred molecules; FGX_REJECTS_DEVICE=0) goes through the host entry in one piece
         // (and the methylation-aware mode, whose annotation runs on the general path: every batch of such a caller)
         const bool host_whole = prc == 1 && (c->opt.track_rejects || c->opt.methylation_mode != FGX_METHYLATION_DISABLED);
         if (prc != 0 && !host_whole) throw std::runtime_error(c->err);
@@ -376,6 +376,7 @@ int fgx_run_bam_rejects(fgx_caller* c, const char* in_path, const char* out_path
         } else {
           // families the device pipelines do not decide: the whole batch through the host entry (it splices both paths in group order)
           st->deferred_groups += host_whole ? 0 : n_def;
+          st->host_entry_batches++;
           if (pipe_debug()) fprintf(stderr, host_whole ? "fgx_run_bam: --rejects / the methylation-aware mode of this batch need the host entry: the whole batch (%u of %u groups)\n"
                                                        : "fgx_run_bam: %u of %u groups deferred: the whole batch through the host entry\n", n_def, batch_grp);
           h_blob.resize(batch_end + 16); h_off.resize(batch_rec); h_len.resize(batch_rec); h_grp.resize((size_t)batch_grp + 1);

@@ -118,6 +118,52 @@ CANON_HD uint32_t trim_point(const uint8_t* q, uint32_t n, bool rev, uint8_t tri
   return point;
 }
 
+// create_source_read (vanilla_caller.rs:1080-1190) as far as the filters need it: the read's final length (quality trimming, masking, the
+// mate clip, the trailing no-call strip) and its simplified CIGAR (reversed for reverse reads, truncated to the final length) in R.
+// 1 = a source read, 0 = dropped (zero length), -1 = out of scope (qualities the reference refuses, an MC tag of too many ops).
+CANON_HD int source_info(uint8_t min_bq, bool trim, const bam::Rec& v, canon::ReadInfo& R, canon::Scratch& C) {
+  const uint32_t l = v.l_seq(), nc = v.n_cigar();
+  R.len = l; R.keep = 1; R.clip = 0; R.final_len = 0; R.n_simp = 0;
+  if (l == 0) return 0;                                                          // Ok(None): zero length
+  if ((uint64_t)v.qual_off() + l > v.len) return -1;
+  const uint8_t* q = v.b + v.qual_off();
+  bool all_ff = true;
+  for (uint32_t x = 0; x < l; x++) if (q[x] != 0xFF) { all_ff = false; break; }
+  if (all_ff) return -1;                                                         // "input read is missing base qualities"
+  for (uint32_t x = 0; x < nc; x++) C.ops[x] = v.cigar_op(x);
+  const uint32_t an = v.len > v.aux_off() ? v.len - v.aux_off() : 0;
+  uint32_t mcl = 0;
+  const int64_t mco = bam::find_z_tag(v.b + v.aux_off(), an, 'M', 'C', &mcl);
+  bool overflow = false;
+  const uint64_t clip = bam::mate_clip(v, C.ops, nc, mco >= 0 ? v.b + v.aux_off() + mco : nullptr, mcl, C.mc_ops, canon::MAX_OPS + 1, &overflow);
+  if (overflow) return -1;
+  const bool rev = (v.flags() & bam::F_REVERSE) != 0;
+  const uint32_t trim_to = trim ? trim_point(q, l, rev, min_bq) : l;
+  const uint32_t clip_pos = (uint64_t)l > clip ? l - (uint32_t)clip : 0;
+  uint32_t fl = clip_pos < trim_to ? clip_pos : trim_to;
+  while (fl > 0) {                                   // oriented position fl-1 = stored position (rev ? l - fl : fl - 1); masked inside [0, trim_to)
+    const uint32_t s = rev ? l - fl : fl - 1;
+    if (v.base_code(s) == 15 || q[s] < min_bq) fl--; else break;
+  }
+  R.final_len = fl;
+  if (fl == 0) return 0;                                                         // ZeroLengthAfterTrimming
+  canon::SimpOp tmp[canon::MAX_OPS];
+  uint32_t nt = 0;
+  for (uint32_t x = 0; x < nc; x++) {
+    const uint32_t t = C.ops[x] & 0xF;
+    const uint8_t kk = (t == 4 || t == 5 || t == 7 || t == 8) ? (uint8_t)0 : (uint8_t)t;
+    if (nt && tmp[nt - 1].k == kk) tmp[nt - 1].len += C.ops[x] >> 4;
+    else { tmp[nt].k = kk; tmp[nt].len = C.ops[x] >> 4; nt++; }
+  }
+  uint32_t remaining = fl;
+  for (uint32_t x = 0; x < nt && remaining > 0; x++) {
+    const canon::SimpOp& op = tmp[rev ? nt - 1 - x : x];
+    if (op.k == 0 || op.k == 1) { const uint32_t take = op.len < remaining ? op.len : remaining; R.simp[R.n_simp].k = op.k; R.simp[R.n_simp].len = take; R.n_simp++; remaining -= take; }
+    else { R.simp[R.n_simp] = op; R.n_simp++; }
+  }
+  return 1;
+}
+
 // process_subgroup (vanilla_caller.rs:1454-1646) over S.sub[0..m): sets mask of the reads it rejects; returns true when the subgroup
 // gives a consensus, with the survivors left in S.sub[0..*n_surv).  status: REJ_OUT_OF_SCOPE on anything it cannot decide.
 CANON_HD bool subgroup(const Params& P, const uint8_t* base, const uint64_t* off, const uint32_t* rec_len, uint32_t m, uint8_t* mask, Scratch& S, uint32_t* n_surv,
@@ -129,47 +175,9 @@ CANON_HD bool subgroup(const Params& P, const uint8_t* base, const uint64_t* off
   uint32_t ns = 0;
   for (uint32_t k = 0; k < m; k++) {
     const uint32_t i = S.sub[k];
-    bam::Rec v{base + off[i], rec_len[i]};
-    canon::ReadInfo& R = S.c.r[i];
-    const uint32_t l = v.l_seq(), nc = v.n_cigar();
-    R.len = l; R.keep = 1; R.clip = 0; R.final_len = 0; R.n_simp = 0;
-    if (l == 0) { mask[i] = 1; continue; }                                      // Ok(None): zero length
-    if ((uint64_t)v.qual_off() + l > v.len) { *status = REJ_OUT_OF_SCOPE; return false; }
-    const uint8_t* q = v.b + v.qual_off();
-    bool all_ff = true;
-    for (uint32_t x = 0; x < l; x++) if (q[x] != 0xFF) { all_ff = false; break; }
-    if (all_ff) { *status = REJ_OUT_OF_SCOPE; return false; }                    // "input read is missing base qualities"
-    for (uint32_t x = 0; x < nc; x++) S.c.ops[x] = v.cigar_op(x);
-    const uint32_t an = v.len > v.aux_off() ? v.len - v.aux_off() : 0;
-    uint32_t mcl = 0;
-    const int64_t mco = bam::find_z_tag(v.b + v.aux_off(), an, 'M', 'C', &mcl);
-    bool overflow = false;
-    const uint64_t clip = bam::mate_clip(v, S.c.ops, nc, mco >= 0 ? v.b + v.aux_off() + mco : nullptr, mcl, S.c.mc_ops, canon::MAX_OPS + 1, &overflow);
-    if (overflow) { *status = REJ_OUT_OF_SCOPE; return false; }
-    const bool rev = (v.flags() & bam::F_REVERSE) != 0;
-    const uint32_t trim_to = P.trim ? trim_point(q, l, rev, P.min_bq) : l;
-    const uint32_t clip_pos = (uint64_t)l > clip ? l - (uint32_t)clip : 0;
-    uint32_t fl = clip_pos < trim_to ? clip_pos : trim_to;
-    while (fl > 0) {                                   // oriented position fl-1 = stored position (rev ? l - fl : fl - 1); masked inside [0, trim_to)
-      const uint32_t s = rev ? l - fl : fl - 1;
-      if (v.base_code(s) == 15 || q[s] < P.min_bq) fl--; else break;
-    }
-    R.final_len = fl;
-    if (fl == 0) { mask[i] = 1; continue; }                                      // ZeroLengthAfterTrimming
-    canon::SimpOp tmp[canon::MAX_OPS];
-    uint32_t nt = 0;
-    for (uint32_t x = 0; x < nc; x++) {
-      const uint32_t t = S.c.ops[x] & 0xF;
-      const uint8_t kk = (t == 4 || t == 5 || t == 7 || t == 8) ? (uint8_t)0 : (uint8_t)t;
-      if (nt && tmp[nt - 1].k == kk) tmp[nt - 1].len += S.c.ops[x] >> 4;
-      else { tmp[nt].k = kk; tmp[nt].len = S.c.ops[x] >> 4; nt++; }
-    }
-    uint32_t remaining = fl;
-    for (uint32_t x = 0; x < nt && remaining > 0; x++) {
-      const canon::SimpOp& op = tmp[rev ? nt - 1 - x : x];
-      if (op.k == 0 || op.k == 1) { const uint32_t take = op.len < remaining ? op.len : remaining; R.simp[R.n_simp].k = op.k; R.simp[R.n_simp].len = take; R.n_simp++; remaining -= take; }
-      else { R.simp[R.n_simp] = op; R.n_simp++; }
-    }
+    const int sr = source_info(P.min_bq, P.trim != 0, bam::Rec{base + off[i], rec_len[i]}, S.c.r[i], S.c);
+    if (sr < 0) { *status = REJ_OUT_OF_SCOPE; return false; }
+    if (sr == 0) { mask[i] = 1; continue; }                                      // zero length / ZeroLengthAfterTrimming
     S.sub[ns++] = i;                                   // (compaction in place: ns <= k)
   }
   if (ns < P.min_reads) { for (uint32_t k = 0; k < ns; k++) mask[S.sub[k]] = 1; return false; }
@@ -280,6 +288,224 @@ CANON_HD void emit_rejects(const uint8_t* blob, const uint64_t* rec_off, const u
     for (uint32_t k = 0; k < rec_len[i]; k++) out[o + 4 + k] = s[k];
     o += 4ull + rec_len[i];
   }
+}
+
+
+// =====================================================================================================================================
+// The duplex caller's rejects (duplex_caller.rs:1944-2120, 2545-2610; src/lib/commands/duplex.rs:742-830).  What it writes for a
+// molecule, in this order:
+//   1  the fragment (unpaired) records, in input order — always (consensus_reads :2545-2570);
+//   then, for a molecule that gave NO consensus pair (too few reads, a strand-orientation collision, a missing end, the per-base
+//   read-count gate after the strand combine):
+//   2  every paired /A record, 3  every paired /B record, each in input order;
+//   or, for a molecule that gave its pair, the reads the single-strand calls dropped:
+//   2 / 3  the reads of zero length after trimming (/A records in input order, then /B: the caller sorts them by their ordinal in
+//          AB ++ BA), 4 / 5  the reads the alignment filter dropped (unmapped among mapped ones, minority alignments), same order.
+// Whether the molecule gave its pair is the ONE thing that depends on the per-position arithmetic (the depth gate looks at the
+// single-strand consensus): the device pipeline has just decided it, so `kept` comes from there (the molecule's output slots are not
+// empty), and everything else is a function of the records, as for the simplex caller.  The records are the overlap-corrected copies
+// when the command's conditional pre-step ran (duplex.rs:786-795): *corrected.
+// code[i] = 0 (not a reject) or the class 1..5 above; the stream is class by class, input order inside a class.
+struct DuplexParams {
+  uint8_t min_bq, overlapping, trim;
+  uint8_t single_strand_ok;       // min-reads YX == 0: the pre-step runs for every molecule
+};
+
+CANON_HD int duplex_reject_codes(const DuplexParams& P, const uint8_t* blob, uint64_t blob_len, const uint64_t* rec_off, const uint32_t* rec_len, uint32_t n, bool kept,
+                                 uint8_t* work, uint8_t* code, Scratch& S, uint8_t* corrected) {
+  *corrected = 0;
+  if (!records_in_scope(blob, blob_len, rec_off, rec_len, n)) return REJ_OUT_OF_SCOPE;
+  for (uint32_t i = 0; i < n; i++) code[i] = 0;
+  if (n == 0) return REJ_OK;
+  // cls: bit 0 paired, bit 1 R2, bit 2 strand /B
+  bool ha = false, hb = false;
+  uint32_t n_paired = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    bam::Rec v{blob + rec_off[i], rec_len[i]};
+    const uint16_t f = v.flags();
+    const int st = canon::mi_strand(v);
+    if (st == 0) ha = true; else if (st == 1) hb = true;
+    if (!(f & bam::F_PAIRED)) { S.cls[i] = 0; code[i] = 1; continue; }
+    if (st < 0) return REJ_OUT_OF_SCOPE;                                   // a paired read without MI / without /A, /B: the reference raises an error
+    if (((f & bam::F_FIRST) != 0) == ((f & bam::F_LAST) != 0)) return REJ_OUT_OF_SCOPE;
+    S.cls[i] = (uint8_t)(1 | ((f & bam::F_LAST) ? 2 : 0) | (st ? 4 : 0));
+    n_paired++;
+  }
+  if (n_paired == 0) return REJ_OK;
+  if (!kept) { for (uint32_t i = 0; i < n; i++) if (S.cls[i] & 1) code[i] = (S.cls[i] & 4) ? 3 : 2; }
+  const bool pre = P.overlapping && (P.single_strand_ok || (n >= 2 && ha && hb));
+  *corrected = pre ? 1 : 0;
+  if (!kept) return REJ_OK;
+  const uint8_t* base = blob;
+  const uint64_t* off = rec_off;
+  if (pre) {
+    corrected_copies(blob, rec_off, rec_len, n, work, S.c.ops);
+    uint64_t w = 0;
+    for (uint32_t i = 0; i < n; i++) { S.woff[i] = w; w += rec_len[i]; }
+    base = work; off = S.woff;
+  }
+  for (int set = 0; set < 2; set++) {            // set 0: AB-R1 ++ BA-R2 (the R1 consensus), set 1: AB-R2 ++ BA-R1
+    uint32_t m = 0;
+    for (int pass = 0; pass < 2; pass++)
+      for (uint32_t i = 0; i < n; i++) {
+        const uint8_t c = S.cls[i];
+        if (!(c & 1) || ((c >> 2) & 1) != pass) continue;
+        const int r2 = (c >> 1) & 1;
+        if ((pass == 0) ? (r2 == set) : (r2 != set)) S.sub[m++] = i;
+      }
+    uint32_t ns = 0;
+    for (uint32_t k = 0; k < m; k++) {
+      const uint32_t i = S.sub[k];
+      const int sr = source_info(P.min_bq, P.trim != 0, bam::Rec{base + off[i], rec_len[i]}, S.c.r[i], S.c);
+      if (sr < 0) return REJ_OUT_OF_SCOPE;
+      if (sr == 0) { code[i] = (S.cls[i] & 4) ? 3 : 2; continue; }
+      S.sub[ns++] = i;
+    }
+    bool any_un = false, all_un = true;
+    for (uint32_t k = 0; k < ns; k++) { const bool u = (bam::Rec{base + off[S.sub[k]], rec_len[S.sub[k]]}.flags() & bam::F_UNMAPPED) != 0; any_un |= u; all_un &= u; }
+    if (any_un && !all_un) {
+      uint32_t w = 0;
+      for (uint32_t k = 0; k < ns; k++) {
+        const uint32_t i = S.sub[k];
+        if (bam::Rec{base + off[i], rec_len[i]}.flags() & bam::F_UNMAPPED) code[i] = (S.cls[i] & 4) ? 5 : 4; else S.sub[w++] = i;
+      }
+      ns = w;
+    }
+    if (ns >= 2) {
+      for (uint32_t k = 0; k < ns; k++) S.c.list[k] = S.sub[k];
+      if (canon::alignment_filter(S.c, ns) < 0) return REJ_OUT_OF_SCOPE;
+      for (uint32_t k = 0; k < ns; k++) { const uint32_t i = S.sub[k]; if (!S.c.r[i].keep) code[i] = (S.cls[i] & 4) ? 5 : 4; }
+    }
+  }
+  return REJ_OK;
+}
+
+// The group's rejects at `out` (reject_bytes of room: `code` is a mask to it), class by class.
+CANON_HD void emit_rejects_by_class(const uint8_t* blob, const uint64_t* rec_off, const uint32_t* rec_len, uint32_t n, const uint8_t* code, bool corrected, uint8_t* work,
+                                    uint32_t* ops_scratch, uint8_t* out) {
+  if (corrected) corrected_copies(blob, rec_off, rec_len, n, work, ops_scratch);
+  uint64_t o = 0;
+  for (uint8_t cl = 1; cl <= 5; cl++) {
+    uint64_t w = 0;
+    for (uint32_t i = 0; i < n; w += rec_len[i], i++) {
+      if (code[i] != cl) continue;
+      const uint8_t* s = corrected ? work + w : blob + rec_off[i];
+      canon::wr32(out + o, rec_len[i]);
+      for (uint32_t k = 0; k < rec_len[i]; k++) out[o + 4 + k] = s[k];
+      o += 4ull + rec_len[i];
+    }
+  }
+}
+
+// =====================================================================================================================================
+// The CODEC caller's rejects (codec_caller.rs:1767-1834 over :625-1262): a mask over the group's records, written in input order, original
+// bytes (the CODEC command has no overlap pre-step).  Fragments; the records of a template that is not exactly one primary FR pair; the
+// reads each strand's alignment filter drops; and, when the molecule gives no consensus (too few templates, the overlap geometry, the
+// strand combine), every read that survived until then.  `kept` again comes from the device pipeline.  Secondary / supplementary
+// records are ignored by the caller: never rejects.  Out of scope: a per-strand cap (the reads it drops are counted but NOT rejects,
+// while a later whole-molecule rejection lists only the reads in hand), more than MAX_READS records.
+CANON_HD int codec_reject_mask(bool has_max_reads, const uint8_t* blob, uint64_t blob_len, const uint64_t* rec_off, const uint32_t* rec_len, uint32_t n, bool kept,
+                               uint8_t* mask, canon::CodecScratch& S) {
+  if (!records_in_scope(blob, blob_len, rec_off, rec_len, n)) return REJ_OUT_OF_SCOPE;
+  for (uint32_t i = 0; i < n; i++) mask[i] = 0;
+  if (n == 0) return REJ_OK;
+  if (has_max_reads) return REJ_OUT_OF_SCOPE;
+  // phase 1 (:625-660): paired primaries only; S.r[i].mate: 0xFFFFFFFF = a paired primary not yet in a template, 0xFFFFFFFE = not one
+  uint32_t n_paired = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    const uint16_t f = bam::Rec{blob + rec_off[i], rec_len[i]}.flags();
+    S.r[i].rec = i; S.r[i].mate = 0xFFFFFFFEu;
+    if (!(f & bam::F_PAIRED)) { mask[i] = 1; continue; }
+    if (f & (bam::F_SECONDARY | bam::F_SUPPLEMENTARY)) continue;
+    S.r[i].mate = 0xFFFFFFFFu; n_paired++;
+  }
+  if (n_paired == 0) return REJ_OK;
+  // phase 2: templates in first-appearance order; exactly one primary FR pair each
+  uint32_t nt = 0;
+  uint32_t opsa[canon::MAX_OPS], opsb[canon::MAX_OPS];
+  for (uint32_t i = 0; i < n; i++) {
+    if (S.r[i].mate != 0xFFFFFFFFu) continue;
+    bam::Rec vi{blob + rec_off[i], rec_len[i]};
+    uint32_t members = 1, j_found = 0xFFFFFFFFu;
+    for (uint32_t j = i + 1; j < n; j++) {
+      if (S.r[j].mate != 0xFFFFFFFFu || !canon::names_equal(vi, bam::Rec{blob + rec_off[j], rec_len[j]})) continue;
+      members++;
+      if (j_found == 0xFFFFFFFFu) j_found = j;
+      S.r[j].mate = 0xFFFFFFFDu;                          // taken by this template
+    }
+    S.r[i].mate = 0xFFFFFFFDu;
+    bool fr = false;
+    if (members == 2) {
+      bam::Rec a{blob + rec_off[i], rec_len[i]}, b{blob + rec_off[j_found], rec_len[j_found]};
+      for (uint32_t k = 0; k < a.n_cigar(); k++) opsa[k] = a.cigar_op(k);
+      for (uint32_t k = 0; k < b.n_cigar(); k++) opsb[k] = b.cigar_op(k);
+      fr = canon::primary_fr_pair(a, opsa, b, opsb);
+    }
+    if (!fr) {                                            // NotPrimaryFrPair: every record of the name
+      mask[i] = 1;
+      for (uint32_t j = i + 1; j < n; j++) if (S.r[j].mate == 0xFFFFFFFDu && canon::names_equal(vi, bam::Rec{blob + rec_off[j], rec_len[j]})) { mask[j] = 1; S.r[j].mate = 0xFFFFFFFEu; }
+      S.r[i].mate = 0xFFFFFFFEu;
+      continue;
+    }
+    S.r[i].mate = j_found; S.r[j_found].mate = i;
+    if (nt >= canon::MAX_READS / 2) return REJ_OUT_OF_SCOPE;
+    const bool i_first = (vi.flags() & bam::F_FIRST) != 0;
+    S.r1[nt] = i_first ? i : j_found; S.r2[nt] = i_first ? j_found : i;
+    nt++;
+  }
+  if (nt == 0) return REJ_OK;
+  if (kept) {
+    // phase 3 (:1130-1174): each strand's alignment filter over the simplified CLIPPED CIGARs (reversed for reverse reads), ordered by the clipped length
+    if (nt >= 2) {
+      for (uint32_t t = 0; t < nt; t++) {
+        const uint32_t i1 = S.r1[t], i2 = S.r2[t];
+        bam::Rec a{blob + rec_off[i1], rec_len[i1]}, b{blob + rec_off[i2], rec_len[i2]};
+        for (uint32_t k = 0; k < a.n_cigar(); k++) opsa[k] = a.cigar_op(k);
+        for (uint32_t k = 0; k < b.n_cigar(); k++) opsb[k] = b.cigar_op(k);
+        for (int side = 0; side < 2; side++) {
+          const bam::Rec& v = side ? b : a;
+          const bam::Rec& mt = side ? a : b;
+          const uint32_t* vo = side ? opsb : opsa;
+          const uint32_t* mo = side ? opsa : opsb;
+          canon::CodecInfo& I = S.r[side ? i2 : i1];
+          const bool rev = (v.flags() & bam::F_REVERSE) != 0;
+          const uint64_t clip = bam::past_mate_ops(rev, (int32_t)((uint32_t)v.pos() + 1u), vo, v.n_cigar(), (int32_t)((uint32_t)mt.pos() + 1u), mo, mt.n_cigar());
+          const uint32_t l = v.l_seq();
+          I.keep = (uint64_t)l > clip ? l - (uint32_t)clip : 0;
+          I.reverse = rev;
+          uint64_t ref_consumed = 0;
+          const int no = canon::clip_cigar(vo, v.n_cigar(), clip, rev, I.ops, canon::MAX_OPS + 2, &ref_consumed);
+          if (no < 0) return REJ_OUT_OF_SCOPE;
+          I.n_ops = (uint32_t)no;
+        }
+      }
+      for (int strand = 0; strand < 2; strand++) {
+        for (uint32_t t = 0; t < nt; t++) {
+          const canon::CodecInfo& I = S.r[strand ? S.r2[t] : S.r1[t]];
+          canon::ReadInfo& R = S.filt.r[t];
+          R.final_len = I.keep; R.keep = 1; R.n_simp = 0;
+          canon::SimpOp tmp[canon::MAX_OPS + 2];
+          uint32_t m = 0;
+          for (uint32_t k = 0; k < I.n_ops; k++) {
+            const uint32_t ty = I.ops[k] & 0xF;
+            const uint8_t kk = (ty == 4 || ty == 5 || ty == 7 || ty == 8) ? (uint8_t)0 : (uint8_t)ty;
+            if (m && tmp[m - 1].k == kk) tmp[m - 1].len += I.ops[k] >> 4;
+            else { tmp[m].k = kk; tmp[m].len = I.ops[k] >> 4; m++; }
+          }
+          if (m > canon::MAX_OPS) return REJ_OUT_OF_SCOPE;
+          for (uint32_t k = 0; k < m; k++) R.simp[k] = tmp[I.reverse ? m - 1 - k : k];
+          R.n_simp = (uint8_t)m;
+          S.filt.list[t] = t;
+        }
+        if (canon::alignment_filter(S.filt, nt) < 0) return REJ_OUT_OF_SCOPE;
+        for (uint32_t t = 0; t < nt; t++) if (!S.filt.r[t].keep) mask[strand ? S.r2[t] : S.r1[t]] = 1;
+      }
+    }
+    return REJ_OK;
+  }
+  // no consensus: the filter's rejects and the reads it left — every read of an FR template
+  for (uint32_t t = 0; t < nt; t++) { mask[S.r1[t]] = 1; mask[S.r2[t]] = 1; }
+  return REJ_OK;
 }
 
 }  // namespace rej

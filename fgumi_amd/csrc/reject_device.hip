@@ -1,4 +1,5 @@
-// reject_device.hip — the simplex caller's `--rejects` stream on the device (default since round 4, FGX_REJECTS_DEVICE=0 opts out), beside the unchanged consensus
+// reject_device.hip — the callers' `--rejects` streams on the device.  The simplex caller's (default since round 4, FGX_REJECTS_DEVICE=0 opts out; duplex / CODEC:
+// round 6, strand_rejects_device at the end of the file), beside the unchanged consensus
 // pipeline: every rejection of the vanilla caller is decided before the per-position arithmetic (reject_core.h has the list and the
 // reference lines), so a side kernel evaluates that decision, one lane per MI group, only when rejects are asked for, and the hot kernels
 // carry no per-record flags.  tests/test_reject_core.py proves the lane body against the reference restatement on the host.
@@ -77,6 +78,47 @@ k_reject_emit(rej::Params P, const uint8_t* __restrict__ blob, const uint64_t* _
   }
 }
 
+// ---- the duplex / CODEC callers (round 6): the same side-kernel scheme.  ONE of their decisions needs the per-position arithmetic — did the molecule give
+// its consensus — and the device pipeline has just taken it: molecule g's records span [group_off[g * stride], group_off[(g + 1) * stride]) of the
+// output (the last one ends at out_len), empty = no consensus.  Everything else is reject_core.h's function of the records.
+template <int KIND>      // 1 duplex (codes 1..5, stream class by class), 2 CODEC (mask, input order)
+__global__ void __launch_bounds__(REJ_BLOCK)
+k_reject_codes_strand(rej::DuplexParams P, uint32_t has_max, const uint8_t* __restrict__ blob, uint64_t blob_len, const uint64_t* __restrict__ rec_off, const uint32_t* __restrict__ rec_len,
+                      const uint32_t* __restrict__ grp_first, uint32_t n_grp, const uint64_t* __restrict__ group_off, uint32_t stride, uint64_t out_len,
+                      uint8_t* code, unsigned long long* grp_bytes, uint8_t* grp_flag, unsigned long long* totals, uint8_t* work, uint64_t slab_bytes, uint8_t* slabs) {
+  const uint32_t lane = blockIdx.x * REJ_BLOCK + threadIdx.x, step = gridDim.x * REJ_BLOCK;
+  uint8_t* w = work + (uint64_t)lane * slab_bytes;
+  for (uint32_t g = lane; g < n_grp; g += step) {
+    const uint32_t r0 = grp_first[g], n = grp_first[g + 1] - r0;
+    const uint64_t o0 = group_off[(uint64_t)g * stride], o1 = g + 1 < n_grp ? group_off[(uint64_t)(g + 1) * stride] : out_len;
+    const bool kept = o1 > o0;
+    uint8_t corrected = 0;
+    int st;
+    if (KIND == 1) st = rej::duplex_reject_codes(P, blob, blob_len, rec_off + r0, rec_len + r0, n, kept, w, code + r0, ((rej::Scratch*)slabs)[lane], &corrected);
+    else st = rej::codec_reject_mask(has_max != 0, blob, blob_len, rec_off + r0, rec_len + r0, n, kept, code + r0, ((canon::CodecScratch*)slabs)[lane]);
+    if (st != rej::REJ_OK) { grp_bytes[g] = 0; grp_flag[g] = 2; atomicAdd(&totals[1], 1ull); continue; }
+    uint32_t cnt = 0;
+    grp_bytes[g] = rej::reject_bytes(rec_len + r0, n, code + r0, &cnt);
+    grp_flag[g] = corrected;
+    if (cnt) atomicAdd(&totals[0], (unsigned long long)cnt);
+  }
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(REJ_BLOCK)
+k_reject_emit_strand(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ rec_off, const uint32_t* __restrict__ rec_len, const uint32_t* __restrict__ grp_first, uint32_t n_grp,
+                     const uint8_t* __restrict__ code, const unsigned long long* __restrict__ grp_bytes, const unsigned long long* __restrict__ grp_off,
+                     const uint8_t* __restrict__ grp_flag, uint8_t* out, uint8_t* work, uint64_t slab_bytes, uint8_t* slabs) {
+  const uint32_t lane = blockIdx.x * REJ_BLOCK + threadIdx.x, step = gridDim.x * REJ_BLOCK;
+  uint8_t* w = work + (uint64_t)lane * slab_bytes;
+  for (uint32_t g = lane; g < n_grp; g += step) {
+    if (grp_bytes[g] == 0) continue;
+    const uint32_t r0 = grp_first[g], n = grp_first[g + 1] - r0;
+    if (KIND == 1) rej::emit_rejects_by_class(blob, rec_off + r0, rec_len + r0, n, code + r0, (grp_flag[g] & 1) != 0, w, ((rej::Scratch*)slabs)[lane].c.ops, out + grp_off[g]);
+    else rej::emit_rejects(blob, rec_off + r0, rec_len + r0, n, code + r0, false, w, nullptr, out + grp_off[g]);
+  }
+}
+
 void reject_release(fgx_caller* c) {
   if (!c->rej_state) return;
   RejectBuffers* B = (RejectBuffers*)c->rej_state;
@@ -140,6 +182,74 @@ void simplex_rejects_device(fgx_caller* c, const rej::Params& P, const uint8_t* 
                        B.out.as<uint8_t>(), B.work.as<uint8_t>(), slab_bytes, B.slabs.as<rej::Scratch>());
     hip_check(hipGetLastError(), "k_reject_emit launch");
     hip_check(hipStreamSynchronize(s), "k_reject_emit");
+    r->d_out = B.out.as<uint8_t>();
+  }
+  r->ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// The duplex (kind FGX_CALLER_DUPLEX) / CODEC caller's rejects of the batch the device pipeline has just decided: `group_off` / `stride` / `out_len` are the
+// batch's group offsets in its output (fgx_caller::last_group_off).  Same result contract as simplex_rejects_device.
+void strand_rejects_device(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, const uint64_t* d_rec_off, const uint32_t* d_rec_len, uint32_t n_rec,
+                           const uint32_t* d_grp_first, uint32_t n_grp, const uint64_t* d_group_off, uint32_t stride, uint64_t out_len, RejectResult* r) {
+  r->d_out = nullptr; r->bytes = 0; r->count = 0; r->n_out_of_scope = 0; r->ms = 0;
+  if (n_grp == 0) return;
+  const bool codec = c->opt.caller_kind == FGX_CALLER_CODEC;
+  const auto t0 = std::chrono::steady_clock::now();
+  if (!c->rej_state) c->rej_state = new RejectBuffers();
+  RejectBuffers& B = *(RejectBuffers*)c->rej_state;
+  hipStream_t s = c->stream;
+  rej::DuplexParams P;
+  P.min_bq = c->opt.min_input_base_quality; P.overlapping = c->opt.overlapping_consensus; P.trim = c->opt.trim; P.single_strand_ok = c->opt.duplex_min_reads[2] == 0;
+  const uint32_t has_max = codec && c->opt.codec_max_reads_per_strand >= 0;
+  B.misc.reserve(64);
+  unsigned long long* misc = B.misc.as<unsigned long long>();
+  hip_check(hipMemsetAsync(misc, 0, 64, s), "memset reject totals");
+  hipLaunchKernelGGL(k_group_bytes_max, dim3((n_grp + 255) / 256), dim3(256), 0, s, d_rec_len, d_grp_first, n_grp, misc + 2);
+  unsigned long long max_bytes = 0;
+  hip_check(hipMemcpyAsync(&max_bytes, misc + 2, 8, hipMemcpyDeviceToHost, s), "D2H largest group");
+  hip_check(hipStreamSynchronize(s), "k_group_bytes_max");
+  const uint64_t slab_bytes = codec ? 16 : ((max_bytes + 15) & ~15ull);              // (the CODEC command has no overlap pre-step: no working copies)
+  const size_t scratch = codec ? sizeof(canon::CodecScratch) : sizeof(rej::Scratch);
+  uint32_t blocks = (n_grp + REJ_BLOCK - 1) / REJ_BLOCK;
+  const uint32_t max_lanes = codec ? REJ_MAX_LANES / 2 : REJ_MAX_LANES;                // (33 KB of lists per CODEC lane)
+  if (blocks > max_lanes / REJ_BLOCK) blocks = max_lanes / REJ_BLOCK;
+  if ((uint64_t)blocks * REJ_BLOCK * slab_bytes > REJ_MAX_WORK) {
+    blocks = (uint32_t)(REJ_MAX_WORK / (slab_bytes * REJ_BLOCK));
+    if (blocks == 0) blocks = 1;
+  }
+  const uint32_t lanes = blocks * REJ_BLOCK;
+  B.mask.reserve((size_t)n_rec + 16);
+  B.grp.reserve((size_t)n_grp * 17 + 64);
+  unsigned long long* grp_bytes = B.grp.as<unsigned long long>();
+  unsigned long long* grp_off = grp_bytes + n_grp;
+  uint8_t* grp_flag = (uint8_t*)(grp_off + n_grp);
+  B.work.reserve((size_t)lanes * slab_bytes + 16);
+  B.slabs.reserve((size_t)lanes * scratch);
+  if (codec) hipLaunchKernelGGL((k_reject_codes_strand<2>), dim3(blocks), dim3(REJ_BLOCK), 0, s, P, has_max, d_blob, blob_len, d_rec_off, d_rec_len, d_grp_first, n_grp, d_group_off, stride, out_len,
+                                B.mask.as<uint8_t>(), grp_bytes, grp_flag, misc, B.work.as<uint8_t>(), slab_bytes, B.slabs.as<uint8_t>());
+  else hipLaunchKernelGGL((k_reject_codes_strand<1>), dim3(blocks), dim3(REJ_BLOCK), 0, s, P, has_max, d_blob, blob_len, d_rec_off, d_rec_len, d_grp_first, n_grp, d_group_off, stride, out_len,
+                          B.mask.as<uint8_t>(), grp_bytes, grp_flag, misc, B.work.as<uint8_t>(), slab_bytes, B.slabs.as<uint8_t>());
+  hip_check(hipGetLastError(), "k_reject_codes_strand launch");
+  size_t tb = 0;
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, grp_bytes, grp_off, (int)n_grp, s);
+  B.scan_tmp.reserve(tb + 64);
+  hip_check(hipcub::DeviceScan::ExclusiveSum(B.scan_tmp.p, tb, grp_bytes, grp_off, (int)n_grp, s), "scan reject bytes");
+  unsigned long long h[2] = {0, 0}, last[2] = {0, 0};
+  hip_check(hipMemcpyAsync(h, misc, 16, hipMemcpyDeviceToHost, s), "D2H reject totals");
+  hip_check(hipMemcpyAsync(&last[0], grp_off + (n_grp - 1), 8, hipMemcpyDeviceToHost, s), "D2H last offset");
+  hip_check(hipMemcpyAsync(&last[1], grp_bytes + (n_grp - 1), 8, hipMemcpyDeviceToHost, s), "D2H last size");
+  hip_check(hipStreamSynchronize(s), "k_reject_codes_strand");
+  r->n_out_of_scope = (uint32_t)h[1];
+  r->count = h[0];
+  r->bytes = last[0] + last[1];
+  if (r->n_out_of_scope == 0 && r->bytes) {
+    B.out.reserve(r->bytes + 16);
+    if (codec) hipLaunchKernelGGL((k_reject_emit_strand<2>), dim3(blocks), dim3(REJ_BLOCK), 0, s, d_blob, d_rec_off, d_rec_len, d_grp_first, n_grp, B.mask.as<uint8_t>(), grp_bytes, grp_off, grp_flag,
+                                  B.out.as<uint8_t>(), B.work.as<uint8_t>(), slab_bytes, B.slabs.as<uint8_t>());
+    else hipLaunchKernelGGL((k_reject_emit_strand<1>), dim3(blocks), dim3(REJ_BLOCK), 0, s, d_blob, d_rec_off, d_rec_len, d_grp_first, n_grp, B.mask.as<uint8_t>(), grp_bytes, grp_off, grp_flag,
+                            B.out.as<uint8_t>(), B.work.as<uint8_t>(), slab_bytes, B.slabs.as<uint8_t>());
+    hip_check(hipGetLastError(), "k_reject_emit_strand launch");
+    hip_check(hipStreamSynchronize(s), "k_reject_emit_strand");
     r->d_out = B.out.as<uint8_t>();
   }
   r->ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

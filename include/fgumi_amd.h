@@ -232,6 +232,15 @@ int fgx_canon_codec_host(const fgx_options* o, const uint8_t* blob, const uint64
 int fgx_simplex_rejects_host(const fgx_options* o, const uint8_t* blob, const uint64_t* rec_off, const uint32_t* rec_len, const uint32_t* grp_first, uint32_t n_grp,
                              uint8_t* out, uint64_t cap, uint64_t* out_len, uint64_t* n_rejects);
 
+/* The same for the duplex (o->caller_kind 1) and CODEC (2) callers (reject_core.h duplex_reject_codes / codec_reject_mask).  ONE of their decisions
+ * needs the per-position arithmetic — whether the molecule gave its consensus (the per-base read-count gate after the strand combine,
+ * duplex_caller.rs:2087-2120; the CODEC strand combine, codec_caller.rs:1272-1512) — so it is an input: kept[g] != 0.  On the device the pipeline's
+ * own output slots say so (fgx_process_batch_device with track_rejects).  Duplex: fragments, then every /A and /B record of a molecule without
+ * consensus, or the zero-length and filtered reads of one with (duplex_caller.rs:1944-2120, 2545-2610; overlap-corrected copies when duplex.rs:786-795
+ * ran the pre-step).  CODEC: a mask in input order (codec_caller.rs:1767-1834). */
+int fgx_strand_rejects_host(const fgx_options* o, const uint8_t* blob, const uint64_t* rec_off, const uint32_t* rec_len, const uint32_t* grp_first, uint32_t n_grp,
+                            const uint8_t* kept, uint8_t* out, uint64_t cap, uint64_t* out_len, uint64_t* n_rejects);
+
 /* Multi-GPU from a host that is not Python (one process / one fgx_caller per GPU): contiguous shards of a weighted family
  * stream — weights[i] = record bytes of family i (fgx_sim_family_bytes for simulated input; Σ rec_len per group otherwise) — with roughly
  * equal total weight: shard k = families [cuts[k], cuts[k + 1]), cuts has world + 1 entries.  The same cuts as the Python mirror
@@ -396,7 +405,8 @@ typedef struct fgx_bam_run_stats {
                                                                                                every chunk's own upload / inflate time: chunks on their way in at once overlap */
   uint32_t boundary_repair_rounds, device_inflate;
   double seconds_device_deflate;                                                            /* inside the device stage (FGX_RUN_DEVICE_DEFLATE) */
-  uint32_t device_deflate, _pad;
+  uint32_t device_deflate;
+  uint32_t host_entry_batches;                                                              /* batches that went through the host entry in one piece (deferred families without the subset way; --rejects / methylation the device entry refused) */
 } fgx_bam_run_stats;
 #define FGX_RUN_HOST_INFLATE   1u   /* flags: inflate the BGZF blocks on the host cores (zlib) instead of on the device */
 #define FGX_RUN_DEVICE_DEFLATE 2u   /* flags: compress the consensus records on the device too (level 1 only; fgumi_amd/csrc/deflate_core.h, a lane
@@ -408,8 +418,8 @@ int fgx_run_bam(fgx_caller* c, const char* in_path, const char* out_path, const 
  * BGZF BAM that advertises the INPUT header (its bytes as the input holds them: @RG / @PG / contigs preserved) and holds the rejected input
  * records in batch-input order — the records of MI groups below --min-reads as they stand, and the caller's rejects (overlap-corrected copies
  * where the pre-correction ran).  `c` must have been created with track_rejects; rejects_path = NULL is fgx_run_bam.  The simplex caller's
- * rejects come from the side kernels of the device entry (fgumi_amd/csrc/reject_device.hip); a batch they refuse, and the duplex / CODEC
- * callers, go through the host entry in one piece.  *rejected_records (may be NULL) = records written to the rejects file. */
+ * rejects come from the side kernels of the device entry (fgumi_amd/csrc/reject_device.hip; the duplex / CODEC callers' too since round 6: reject_core.h duplex_reject_codes / codec_reject_mask
+ * with the batch's own output slots); a batch they refuse (st->host_entry_batches counts them) goes through the host entry in one piece.  *rejected_records (may be NULL) = records written to the rejects file. */
 int fgx_run_bam_rejects(fgx_caller* c, const char* in_path, const char* out_path, const char* rejects_path, const uint8_t* out_header,
                         uint64_t out_header_len, const fgx_group_options* g, uint32_t threads, int level, uint64_t chunk_raw_bytes, uint32_t flags,
                         fgx_bam_run_stats* st, uint64_t* rejected_records);

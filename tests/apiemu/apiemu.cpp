@@ -118,6 +118,12 @@ hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipSt
   if (n) memmove(d, s, n);
   return hipSuccess;
 }
+hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, hipMemcpyKind, hipStream_t st) {
+  auto body = [=] { for (size_t r = 0; r < height; r++) memmove((uint8_t*)d + r * dpitch, (const uint8_t*)s + r * spitch, width); };
+  if (emu::async_on() && st) { if (width && height) emu::enqueue(emu::of(st), body); return hipSuccess; }
+  body();
+  return hipSuccess;
+}
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st) {
   if (emu::async_on() && st) { if (n) emu::enqueue(emu::of(st), [d, v, n] { memset(d, v, n); }); return hipSuccess; }
   if (n) memset(d, v, n);

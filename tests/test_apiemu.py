@@ -141,6 +141,23 @@ def test_rejects_side_kernels_device_entry(kw):
     run_isolated("test_apiemu", "check_device_entry_emu", kw, 12, env=env(FGX_REJECTS_DEVICE=1, APIEMU_DEFER="mod3"))
 
 
+@pytest.mark.parametrize("defer", ["none", "mod3"])
+@pytest.mark.parametrize("kind", ["duplex", "codec"])
+def test_duplex_codec_rejects_side_kernels_host_entry(kind, defer):
+    """Round 6: the duplex / CODEC callers' `--rejects` through api.cpp's new branch (device pipeline first, then the side kernels with the batch's own
+    output slots); with deferred molecules (mod3) the whole batch goes to the general path — same bytes either way."""
+    import test_gpu_zz_rejects_device as tgr
+    for kw in tgr.STRAND_KWS[kind][:3]:
+        run_isolated("test_gpu_zz_rejects_device", "check_host_entry_strand", kind, kw, 21, env=env(FGX_REJECTS_DEVICE=1, APIEMU_DEFER=defer))
+    run_isolated("test_gpu_zz_rejects_device", "check_host_entry_strand", kind, tgr.STRAND_KWS[kind][1], 22, kind == "duplex", env=env(FGX_REJECTS_DEVICE=1, APIEMU_DEFER="indel"))
+
+
+@pytest.mark.parametrize("kind", ["duplex", "codec"])
+def test_duplex_codec_rejects_side_kernels_device_entry(kind):
+    import test_gpu_zz_rejects_device as tgr
+    run_isolated("test_gpu_zz_rejects_device", "check_device_entry_strand", kind, tgr.STRAND_KWS[kind][1], 23, False, env=env(FGX_REJECTS_DEVICE=1, APIEMU_DEFER="none"))
+
+
 def test_rejects_without_the_flag_take_the_general_path():
     run_isolated("test_gpu_zz_rejects_device", "check_host_entry", dict(min_reads=2), 11, env=env(FGX_REJECTS_DEVICE=0))          # (whole batch on the general path: same answer)
     run_isolated("test_apiemu", "check_device_entry_refuses_without_the_flag", env=env(FGX_REJECTS_DEVICE=0))
