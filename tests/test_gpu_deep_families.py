@@ -155,3 +155,14 @@ def test_quality_zero_observations_when_the_quality_floor_admits_them(min_bq):
     g = _with_low_qualities(simulate_grouped_reads(1500, family_size=2, family_size_max=12, error_rate_ppm=2000))
     path = _run(g, dict(min_input_base_quality=min_bq), dict(min_input_base_quality=min_bq))
     assert path["chunks"] >= 1 and path["deferred"] == 0, path
+
+
+# ---- round 6: more shapes of families above 64 records (k_deep_parse's two-wavefront build, k_deep_cols) -----------------------------------------------
+@pytest.mark.parametrize("sim,kw", [(dict(n_families=1500, family_size=35, family_size_max=120), {}),
+                                    (dict(n_families=800, family_size=40, family_size_max=100, error_rate_ppm=20000, read_length=151, insert_mean=170, insert_sd=40), dict(min_reads=3)),
+                                    (dict(n_families=600, family_size=70, family_size_max=127), dict(min_input_base_quality=30))])
+def test_families_above_64_records_equal_the_oracle(sim, kw):
+    g = simulate_grouped_reads(**sim)
+    n = _records_per_family(g)
+    path = _run(g, kw, kw)
+    assert path["deep"] == int((n > 64).sum()) > 0 and path["deferred"] == 0, path

@@ -92,3 +92,13 @@ def test_duplex_and_codec_wavefront_kernels(kind, sim):
     """k_family_wave<1> / <2> and their record writers (k_emit_duplex_fast / k_emit_codec_fast) on 400 molecules."""
     opts = dict(min_reads=1) if kind == 1 else dict(overlapping_consensus=0)
     run_isolated("test_wavemu", "check_device_entry", kind, 400, sim, opts, env=env(), timeout=1500)
+
+
+def test_deep_families_streaming_kernels():
+    """Families above 64 records: k_deep_parse (its two-wavefront build for 65 - 128 records, the workgroup build above) + k_deep_cols, which streams the rows
+    from global memory: plain; noisy with read-through inserts (the pre-correction at the load) and a deeper --min-reads; a quality floor that masks observations."""
+    e = env()
+    run_isolated("test_wavemu", "check_device_entry", 0, 60, dict(family_size=35, family_size_max=60), dict(min_reads=1), env=e, timeout=1500)
+    run_isolated("test_wavemu", "check_device_entry", 0, 50, dict(family_size=40, family_size_max=100, error_rate_ppm=20000, read_length=151, insert_mean=170, insert_sd=40),
+                 dict(min_reads=3), env=e, timeout=1500)
+    run_isolated("test_wavemu", "check_device_entry", 0, 30, dict(family_size=70, family_size_max=120), dict(min_reads=1, min_input_base_quality=25), env=e, timeout=1500)
