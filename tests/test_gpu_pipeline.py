@@ -302,16 +302,18 @@ def test_run_bam_with_rejects_duplex_and_codec_on_the_device(tmp_path):
     (/A records, then /B), the zero-length reads of kept ones; both files equal the oracle's."""
     import test_gpu_zz_rejects_device as tgr
     from fgumi_amd import CodecConsensusCaller, CodecConsensusOptions
+    # (the opt-outs send every batch through the host entry, and so does tests/apiemu's stand-in pipeline when it defers groups by rule: same files)
+    served = os.environ.get("FGX_REJECTS_DEVICE") != "0" and os.environ.get("FGX_OPT_IN_ALL") != "0" and os.environ.get("APIEMU_DEFER") in (None, "none", "indel")
     gd = tgr.strand_batch("duplex", 31)
     od = tgr.strand_options("duplex", dict(duplex_min_reads=(3, 2, 1)))
     cd = DuplexConsensusCaller("", "A", [3, 2, 1], cell_tag="CB", overlapping_consensus=True, track_rejects=True)
     for chunk in (0, 1 << 16):
         st = _rejects_case(tmp_path, cd, od, gd, 100000, chunk, strip_strand_suffix=True)
-        assert st["deferred_groups"] == 0 and st["host_entry_batches"] == 0, (st["deferred_groups"], st["host_entry_batches"])
+        assert st["deferred_groups"] == 0 and (st["host_entry_batches"] == 0 or not served), (st["deferred_groups"], st["host_entry_batches"])
     cd.close()
     gc = tgr.strand_batch("codec", 32)
     oc = tgr.strand_options("codec", dict(codec_min_reads_per_strand=2))
     cc = CodecConsensusCaller("", "A", CodecConsensusOptions(min_reads_per_strand=2, produce_per_base_tags=True, cell_tag="CB"), track_rejects=True)
     st = _rejects_case(tmp_path, cc, oc, gc, 100000, 0)
-    assert st["deferred_groups"] == 0 and st["host_entry_batches"] == 0, (st["deferred_groups"], st["host_entry_batches"])
+    assert st["deferred_groups"] == 0 and (st["host_entry_batches"] == 0 or not served), (st["deferred_groups"], st["host_entry_batches"])
     cc.close()
