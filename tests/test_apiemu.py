@@ -392,7 +392,7 @@ def test_pipeline_resubmits_only_the_deferred_groups(defer, resident):
                         "-p", "no:cacheprovider"], env=e, cwd=apiemu.ROOT, capture_output=True, text=True, timeout=1800)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     trace = p.stdout + p.stderr
-    assert "11 passed" in trace
+    assert "12 passed" in trace
     assert trace.count("decided alone") > (20 if defer == "mod3" else 0) and "the whole batch through the host entry" not in trace
 
 
