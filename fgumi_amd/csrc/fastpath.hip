@@ -3861,7 +3861,7 @@ __global__ __launch_bounds__(256) void k_emit_codec_fast(CodecEmitParams P) {
 // grp_first nor rec_off to know where they are; it checks afterwards that every record lies inside that span).
 // (+ how many records sit in families of at most 32 records: what decides between the two heads of the simplex launch chain)
 __global__ void k_col_bound(const uint32_t* __restrict__ grp_first, const uint32_t* __restrict__ rec_len, const uint64_t* __restrict__ rec_off, uint32_t n_grp,
-                            uint64_t* __restrict__ bound, uint32_t max_ends, uint4* __restrict__ fam_desc, unsigned long long* __restrict__ small_recs) {
+                            uint64_t* __restrict__ bound, uint32_t max_ends, uint4* __restrict__ fam_desc, unsigned long long* __restrict__ small_recs, uint64_t* __restrict__ sizes_tail) {
   uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   {
     uint32_t mine = 0;
@@ -3876,6 +3876,7 @@ __global__ void k_col_bound(const uint32_t* __restrict__ grp_first, const uint32
     if (threadIdx.x == 0 && s_tot) atomicAdd(small_recs, (unsigned long long)s_tot);
   }
   if (g >= n_grp) return;
+  if (g == n_grp - 1) { bound[n_grp] = 0; *sizes_tail = 0; }  // (both scans of the step run over one element more, a zero: their last element is the total)
   uint32_t a = grp_first[g], b = grp_first[g + 1], mx = 0;
   {   // the family's longest record: four lengths per load where the table allows it (a thread-per-family loop of single loads cost 1 ms per 80 M records)
     uint32_t r = a;
@@ -3967,8 +3968,8 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
   if (n_grp == 0) return 0;
   const uint32_t n_slots = 3 * n_grp;   // simplex: Fragment, R1, R2 of each family; duplex: slot 0 unused, R1, R2
   d_ends.reserve((size_t)n_slots * (duplex ? sizeof(DuplexDesc) : codec ? sizeof(CodecDesc) : sizeof(EndDesc)));
-  d_sizes.reserve((size_t)n_slots * 8);
-  d_offsets.reserve((size_t)n_slots * 8);
+  d_sizes.reserve(((size_t)n_slots + 1) * 8);            // (+ 1: a zero behind the last size, so that the scan's last element IS the total — one small copy fewer per step)
+  d_offsets.reserve(((size_t)n_slots + 1) * 8);
   d_deferred.reserve((size_t)n_grp * 4);
   // misc: [0..28) stats, [28] col_cursor, [29] n_deferred (u32 in low half), [30] valid count
   d_misc.reserve(48 * 8);   // ... [31] n_retry, [32] n_retry_old (k_simplex_wave2 → k_family_wave<0>); [40 .. 44) diagnostics (k_reduce_stats)
@@ -3981,7 +3982,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
   (void)n_rec;
   for (int i = 0; i < 4; i++) if (!ev[i]) hip_check(hipEventCreate(&ev[i]), "hipEventCreate");
   unsigned long long* misc = d_misc.as<unsigned long long>();
-  d_bound.reserve((size_t)n_grp * 8); d_colbase.reserve((size_t)n_grp * 8);
+  d_bound.reserve(((size_t)n_grp + 1) * 8); d_colbase.reserve(((size_t)n_grp + 1) * 8);
   d_statslots.reserve((size_t)STAT_SLOTS * 32 * 8);
   hip_check(hipMemsetAsync(d_statslots.p, 0, (size_t)STAT_SLOTS * 32 * 8, s), "memset");
   d_famdesc.reserve((size_t)n_grp * 16);
@@ -4056,16 +4057,16 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
     }
   }
   do { last_launches++; hipLaunchKernelGGL(k_col_bound, dim3((n_grp + 1023) / 1024), dim3(1024), 0, s, d_grp_first, d_rec_len, d_rec_off, n_grp, d_bound.as<uint64_t>(), duplex ? 4u : codec ? 2u : 3u,
-                     d_famdesc.as<uint4>(), misc + 35); } while (0);
+                     d_famdesc.as<uint4>(), misc + 35, d_sizes.as<uint64_t>() + n_slots); } while (0);
   {
     size_t tb = 0;
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_bound.as<uint64_t>(), d_colbase.as<uint64_t>(), (int)n_grp, s);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_bound.as<uint64_t>(), d_colbase.as<uint64_t>(), (int)n_grp + 1, s);
     d_scan_tmp.reserve(tb);
-    hip_check(hipcub::DeviceScan::ExclusiveSum(d_scan_tmp.p, tb, d_bound.as<uint64_t>(), d_colbase.as<uint64_t>(), (int)n_grp, s), "scan bound");
+    hip_check(hipcub::DeviceScan::ExclusiveSum(d_scan_tmp.p, tb, d_bound.as<uint64_t>(), d_colbase.as<uint64_t>(), (int)n_grp + 1, s), "scan bound");
   }
-  uint64_t lastb[2];
-  hip_check(hipMemcpyAsync(&lastb[0], d_colbase.as<uint64_t>() + (n_grp - 1), 8, hipMemcpyDeviceToHost, s), "D2H");
-  hip_check(hipMemcpyAsync(&lastb[1], d_bound.as<uint64_t>() + (n_grp - 1), 8, hipMemcpyDeviceToHost, s), "D2H");
+  // (round 6: every small device-to-host copy costs the stream ~25 us, timeline of the 625 000-family step — so the total is the scan's own last element)
+  uint64_t col_total = 0;
+  hip_check(hipMemcpyAsync(&col_total, d_colbase.as<uint64_t>() + n_grp, 8, hipMemcpyDeviceToHost, s), "D2H");
   unsigned long long small_recs = 0;
   hip_check(hipMemcpyAsync(&small_recs, misc + 35, 8, hipMemcpyDeviceToHost, s), "D2H");
   FGX_SYNC(s);
@@ -4085,7 +4086,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
   last_direct = 0;
   if (early_parse && !use_split) hip_check(hipStreamWaitEvent(s, ev_chunk[0], 0), "wait");   // (its descriptors are not used; nothing of this batch may still run when the call returns)
   last_routed = 0; last_big_families = 0; last_deep_families = 0; last_packed_families = 0; last_classic_families = 0; last_split_build = 0; last_first_stage_retries = 0;
-  uint64_t col_cap = lastb[0] + lastb[1] + 64;
+  uint64_t col_cap = col_total + 64;
   uint64_t dir_cap = 0;
   if (direct) {
     // room for the records: 6 bytes per column of the (generous) column bound covers sequence + qualities + cd + ce twice over for
@@ -4097,7 +4098,7 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
     hip_check(hipMemsetAsync(d_dir_size.p, 0, (size_t)n_grp * 4, s), "memset");
     hip_check(hipMemsetAsync(d_dir_base.p, 0, (MAX_CHUNKS + 2) * 8, s), "memset");
     hip_check(hipMemsetAsync(d_slot_err.p, 0, (size_t)n_slots * 4, s), "memset");
-    hip_check(hipMemsetAsync(d_sizes.p, 0, (size_t)n_slots * 8, s), "memset");
+    hip_check(hipMemsetAsync(d_sizes.p, 0, ((size_t)n_slots + 1) * 8, s), "memset");
   }
   d_code.reserve(col_cap + 64); d_qual.reserve(col_cap + 64); d_err.reserve(col_cap * 2 + 64);   // (+ slack: k_emit reads whole dwords)
   if (meth_dev) { d_mflag.reserve(col_cap + 64); d_mu.reserve(col_cap * 2 + 64); d_mt.reserve(col_cap * 2 + 64); d_mslot.reserve((size_t)n_slots * sizeof(MethSlot) + 64); }
@@ -4398,13 +4399,15 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
           do { last_launches++; hipLaunchKernelGGL(k_split_finish, dim3((n_s2 + 255) / 256), dim3(256), 0, s, PF, n_s2); } while (0);
         }
         hip_check(hipGetLastError(), "k_split_cols launch");
-        uint32_t n_next = 0;
-        hip_check(hipMemcpyAsync(&n_next, d_cnt, 4, hipMemcpyDeviceToHost, s), "D2H");
-        // (round 6: the route / big counters come along — after the LAST stage they are final, and two host synchronisations of their own go away)
-        hip_check(hipMemcpyAsync(&h_route_seen, d_cnt_route, 4, hipMemcpyDeviceToHost, s), "D2H");
-        hip_check(hipMemcpyAsync(&h_big_seen, d_cnt_big, 4, hipMemcpyDeviceToHost, s), "D2H");
+        // (round 6: the route / big counters come along — after the LAST stage they are final, and two host synchronisations of their own go away;
+        // the three are words 31, 33 and 37 of `misc`: ONE copy of its words 31 .. 37)
+        unsigned long long h_cnt7[7] = {0, 0, 0, 0, 0, 0, 0};
+        static_assert(sizeof(h_cnt7) == 56, "misc words 31 .. 37");
+        hip_check(hipMemcpyAsync(h_cnt7, misc + 31, sizeof(h_cnt7), hipMemcpyDeviceToHost, s), "D2H");
         split_counts_seen = true;
         FGX_SYNC(s);
+        const uint32_t n_next = (uint32_t)h_cnt7[0];
+        h_route_seen = (uint32_t)h_cnt7[2]; h_big_seen = (uint32_t)h_cnt7[6];
         if (ci == 0) last_first_stage_retries = PS.retry ? n_next : 0u;
         s2_list = lists[s2_out]; n_s2 = PS.retry ? n_next : 0; s2_out ^= 1;
       }
@@ -4684,16 +4687,16 @@ int FastPath::run_once(fgx_caller* c, const uint8_t* d_blob, uint64_t blob_len, 
   uint8_t* out_ptr = d_out.as<uint8_t>();
   if (!dir_pure) {
     size_t tmp_bytes = 0;
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_sizes.as<uint64_t>(), d_offsets.as<uint64_t>(), (int)n_slots, s);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_sizes.as<uint64_t>(), d_offsets.as<uint64_t>(), (int)n_slots + 1, s);
     d_scan_tmp.reserve(tmp_bytes);
-    hip_check(hipcub::DeviceScan::ExclusiveSum(d_scan_tmp.p, tmp_bytes, d_sizes.as<uint64_t>(), d_offsets.as<uint64_t>(), (int)n_slots, s), "scan");
+    hip_check(hipcub::DeviceScan::ExclusiveSum(d_scan_tmp.p, tmp_bytes, d_sizes.as<uint64_t>(), d_offsets.as<uint64_t>(), (int)n_slots + 1, s), "scan");
 
     // total output size = last offset + last size
-    uint64_t last[2];
-    hip_check(hipMemcpyAsync(&last[0], d_offsets.as<uint64_t>() + (n_slots - 1), 8, hipMemcpyDeviceToHost, s), "D2H");
-    hip_check(hipMemcpyAsync(&last[1], d_sizes.as<uint64_t>() + (n_slots - 1), 8, hipMemcpyDeviceToHost, s), "D2H");
+    // total output size = the scan's element behind the last slot (d_sizes[n_slots] is 0)
+    uint64_t out_total = 0;
+    hip_check(hipMemcpyAsync(&out_total, d_offsets.as<uint64_t>() + n_slots, 8, hipMemcpyDeviceToHost, s), "D2H");
     FGX_SYNC(s);
-    out_len = last[0] + last[1];
+    out_len = out_total;
     if (out_len > (1ull << 40)) throw std::runtime_error("device pipeline: the scan of the record sizes gives " + std::to_string(out_len) + " bytes of output (a record size is corrupt)");
     if (direct) { d_out2.reserve(out_len + 16); out_ptr = d_out2.as<uint8_t>(); }   // the merged stream: d_out holds the directly written records
     else { d_out.reserve(out_len + 16); out_ptr = d_out.as<uint8_t>(); }
