@@ -27,3 +27,35 @@ def test_no_kernel_stores_outside_its_buffers():
     assert m, tail
     # the mechanism sees a byte stored right behind a buffer, it looked after every test, and the library's buffers really were guarded
     assert int(m.group(1)) == 1 and int(m.group(2)) >= 50 and int(m.group(3)) >= 500, m.group(0)
+
+
+def check_rejects_and_deep_families_under_guard_bands():
+    """(child interpreter, FGX_GUARD_BAND set) The round-6 side kernels of the duplex / CODEC `--rejects` (host and device entries), a simplex `--rejects` batch and deep
+    families (the streaming kernels), each followed by a look at every guarded buffer."""
+    import ctypes as C
+    import test_gpu_zz_rejects_device as tgr
+    import test_gpu_deep_families as tdf
+    from fgumi_amd import lib, simulate_grouped_reads
+    lib.fgx_debug_check_guard_bands.restype = C.c_int
+    lib.fgx_debug_check_guard_bands.argtypes = [C.c_char_p, C.c_int]
+    lib.fgx_debug_guarded_buffers.restype = C.c_int
+
+    def look(what):
+        msg = C.create_string_buffer(600)
+        bad = lib.fgx_debug_check_guard_bands(msg, 600)
+        assert bad == 0, f"{what}: {bad} device buffer(s) written outside their bounds: {msg.value.decode()}"
+    for kind in ("duplex", "codec"):
+        tgr.check_host_entry_strand(kind, tgr.STRAND_KWS[kind][1], 21)
+        look(kind + " host entry")
+        tgr.check_device_entry_strand(kind, tgr.STRAND_KWS[kind][1], 23)
+        look(kind + " device entry")
+    tgr.check_host_entry(tgr.KWS[1], 11)
+    look("simplex rejects")
+    tdf._run(simulate_grouped_reads(400, family_size=35, family_size_max=120))
+    look("deep families")
+    assert lib.fgx_debug_guarded_buffers() >= 100, lib.fgx_debug_guarded_buffers()
+
+
+def test_reject_side_kernels_and_streaming_kernels_under_guard_bands():
+    from isolated import run_isolated
+    run_isolated("test_gpu_guard_bands", "check_rejects_and_deep_families_under_guard_bands", env={"FGX_GUARD_BAND": "4096"}, timeout=900)
